@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the IMPORTED reference.
+
+Run in the build container only (needs /root/reference, read-only).  The GPU box never
+sees /root/reference; it only sees the .npz files this script wrote.  A fixture is data:
+seeded inputs plus the outputs the reference's own Python produced for them.
+
+Import recipe: `import VoGE` fails because VoGE/__init__.py pulls in the
+CUDA extension `VoGE._C` and pytorch3d.  Registering a bare namespace package `VoGE`
+whose __path__ is the reference directory, an EMPTY placeholder `VoGE._C`, and empty
+placeholder `pytorch3d.*` modules makes `VoGE.Aggregation`, `VoGE.Renderer` (helpers),
+`VoGE.Converter.Cuboid/Converters/IO` importable.  Nothing in the placeholders is ever
+called by the functions exercised here.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference():
+    pkg = types.ModuleType("VoGE")
+    pkg.__path__ = [os.path.join(REF, "VoGE")]
+    sys.modules["VoGE"] = pkg
+    sys.modules["VoGE._C"] = types.ModuleType("VoGE._C")
+    pkg._C = sys.modules["VoGE._C"]
+    for name in ("pytorch3d", "pytorch3d.renderer", "pytorch3d.renderer.implicit",
+                 "pytorch3d.renderer.implicit.raysampling", "pytorch3d.structures",
+                 "pytorch3d.renderer.cameras"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.modules["pytorch3d.renderer.implicit.raysampling"].NDCMultinomialRaysampler = None
+    sys.modules["pytorch3d.structures"].Meshes = None
+    sys.modules["pytorch3d.renderer"].look_at_rotation = None
+    import VoGE.Aggregation as Agg
+    import VoGE.Renderer as Ren
+    import VoGE.Converter.Cuboid as Cub
+    import VoGE.Converter.Converters as Conv
+    import VoGE.Converter.IO as IO
+    return Agg, Ren, Cub, Conv, IO
+
+
+def synth_sel(rng, npix, K, fill_lo=0, dtype=np.float64, nmax=500):
+    """Seeded stand-ins for the fine kernel's outputs, incl. sentinel tails
+    (idx -1, len 1e10, act 1e10, dsd 0; ray_trace_voge.cu:244-247)."""
+    idx = np.full((npix, K), -1, np.int32)
+    ln = np.full((npix, K), 1e10, dtype)
+    act = np.full((npix, K), 1e10, dtype)
+    dsd = np.zeros((npix, K), dtype)
+    for p in range(npix):
+        n = int(rng.integers(fill_lo, K + 1))
+        ln[p, :n] = np.sort(rng.uniform(2.0, 6.0, n))
+        # a few near-coincident depths so the erf term is exercised around 0
+        if n > 3:
+            ln[p, 1] = ln[p, 0] + 1e-3
+            ln[p, :n] = np.sort(ln[p, :n])
+        act[p, :n] = rng.uniform(0.0, 4.6, n)
+        dsd[p, :n] = rng.uniform(5.0, 4000.0, n)
+        idx[p, :n] = rng.integers(0, nmax, n)
+    return idx, ln, act, dsd
+
+
+def gen_composite(Agg, Ren):
+    rng = np.random.default_rng(20240521)
+    for name, (npix, K, occ) in dict(k5=(48, 5, 1.0), k25=(40, 25, 1.3), k40=(32, 40, 1.0)).items():
+        idx, ln, act, dsd = synth_sel(rng, npix, K)
+        g_w = rng.normal(size=(npix, K))
+        shape = (1, 4, npix // 4, K)
+        t = lambda a, rg=False: torch.tensor(a.reshape(shape), dtype=torch.float64, requires_grad=rg)
+        t_idx = torch.tensor(idx.reshape(shape))
+        t_act, t_len, t_dsd = t(act, True), t(ln, True), t(dsd, True)
+        w, idx_o, vn, hl = Agg.aggregation(t_idx, t_act, t_len, t_dsd, occupation_weight=occ)
+        assert hl is t_len and idx_o is t_idx
+        (w * torch.tensor(g_w.reshape(shape))).sum().backward()
+        # fp32 run of the same program (what the reference actually executes)
+        w32, _, _, _ = Agg.aggregation(t_idx, t(act).float(), t(ln).float(), t(dsd).float(), occupation_weight=occ)
+        np.savez_compressed(os.path.join(OUT, f"composite_{name}.npz"), idx=idx.reshape(shape), act=act.reshape(shape),
+                            len=ln.reshape(shape), dsd=dsd.reshape(shape), occ=occ, g_weight=g_w.reshape(shape),
+                            weight=w.detach().numpy(), weight_f32=w32.numpy(), valid_num=vn.numpy(),
+                            g_act=t_act.grad.numpy(), g_len=t_len.grad.numpy(), g_dsd=t_dsd.grad.numpy())
+        print("composite", name, "w max", float(w.detach().max()), "valid", vn.min().item(), vn.max().item())
+
+
+def gen_merge_blend(Agg, Ren):
+    rng = np.random.default_rng(7)
+    npix, K, N, C = 60, 12, 300, 3
+    idx, ln, act, dsd = synth_sel(rng, npix, K, nmax=N)
+    shape = (1, 6, 10, K)
+    t_idx = torch.tensor(idx.reshape(shape))
+    t64 = lambda a: torch.tensor(a.reshape(shape), dtype=torch.float64)
+    w, _, vn, hl = Agg.aggregation(t_idx, t64(act), t64(ln), t64(dsd), occupation_weight=1.0)
+    # boost some weights so the silhouette clamp (min(sum w, 1)) and the output clamp trigger
+    w = (w * torch.tensor(rng.uniform(0.5, 3.0, size=shape))).detach().requires_grad_(True)
+    colors = torch.tensor(rng.uniform(0, 1, (N, C)), dtype=torch.float64, requires_grad=True)
+    feat = torch.tensor(rng.normal(size=(N, 7)), dtype=torch.float64, requires_grad=True)
+    g_img = torch.tensor(rng.normal(size=(1, 6, 10, C)))
+    g_feat = torch.tensor(rng.normal(size=(1, 6, 10, 7)))
+    out = {}
+    frag = Ren.Fragments(vert_weight=w, vert_index=t_idx.clone(), valid_num=vn, vert_hit_length=hl)
+    idx_before = frag.vert_index.clone()
+    rgb = Ren.interpolate_attr(frag, colors)
+    out["idx_after_merge"] = frag.vert_index.numpy().copy()  # merge_final mutates -1 -> 0 (Aggregation.py:131)
+    img_white = Ren.to_white_background(frag, colors)
+    img_col = Ren.to_colored_background(frag, colors, background_color=(0.2, 0.5, 0.9), thr=0.3)
+    sil = Ren.get_silhouette(frag)
+    fm = Ren.interpolate_attr(frag, feat)
+    ((img_white * g_img).sum() + (fm * g_feat).sum()).backward()
+    out.update(idx=idx_before.numpy(), weight=w.detach().numpy(), valid_num=vn.numpy(), colors=colors.detach().numpy(),
+               feat=feat.detach().numpy(), rgb=rgb.detach().numpy(), img_white=img_white.detach().numpy(),
+               img_colored_thr=img_col.detach().numpy(), bg=np.array([0.2, 0.5, 0.9]), thr=0.3,
+               silhouette=sil.detach().numpy(), feat_map=fm.detach().numpy(), g_img=g_img.numpy(), g_feat=g_feat.numpy(),
+               g_weight=w.grad.numpy(), g_colors=colors.grad.numpy(), g_feat_attr=feat.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, "merge_blend.npz"), **out)
+    print("merge/blend: img max", float(img_white.max()), "sil max", float(sil.max()))
+
+
+def gen_misc(Agg, Ren, Cub, Conv, IO):
+    out = {}
+    s1 = torch.tensor([1.5, 2.5])
+    s2 = torch.tensor([[1., 2., 3.], [4., 5., 6.]])
+    s3 = torch.arange(18.).view(2, 3, 3)
+    out["expend_1"] = Agg.expend_sigma(s1).numpy()
+    out["expend_2"] = Agg.expend_sigma(s2).numpy()
+    out["expend_3"] = Agg.expend_sigma(s3).numpy()
+    st = Ren.GaussianRenderSettings(image_size=128, batch_size=-1, principal_point=(1, 2))
+    out["settings_default"] = np.array([st["image_size"][0], st["image_size"][1], st["max_assign"],
+                                        st["thr_activation"], st["absorptivity"], float(st["inverse_sigma"])])
+    assert st["principal"] is None and st["max_point_per_bin"] is None
+    verts, isig = Cub.cuboid_gauss((-1, 1), (-1, 1), (-1, 1), 1000, percentage=0.6)
+    out["cuboid_verts"] = verts.astype(np.float32)
+    out["cuboid_isigma"] = isig.astype(np.float32)
+    v2, i2, c2 = Cub.cuboid_gauss((-1, 2), (0, 1), (-0.5, 0.5), 300, percentage=0.5,
+                                  colors=np.arange(18.).reshape(6, 3))
+    out["cuboid2_verts"], out["cuboid2_isigma"], out["cuboid2_colors"] = v2, i2, c2
+    np.savez_compressed(os.path.join(OUT, "misc_api.npz"), **out)
+    print("cuboid:", verts.shape, isig[0])
+
+    # config 2 input: the bunny through the reference's own loader + converter
+    bv, bf = IO.load_off(os.path.join(REF, "demo/data/bunny.off"))
+    cv, cs, _ = Conv.naive_vertices_converter(bv, bf, percentage=0.6)
+    # per-vertex normals (area-weighted), standing in for pytorch3d's verts_normals_packed (RenderBunny.py:30)
+    fn = np.cross(bv[bf[:, 1]] - bv[bf[:, 0]], bv[bf[:, 2]] - bv[bf[:, 0]])
+    vn = np.zeros_like(bv)
+    for k in range(3):
+        np.add.at(vn, bf[:, k], fn)
+    vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-12)
+    np.savez_compressed(os.path.join(OUT, "bunny_gaussians.npz"), verts=cv.astype(np.float32),
+                        isigma=cs.astype(np.float32), faces=bf.astype(np.int32), colors=(vn * 0.4 + 0.4).astype(np.float32))
+    print("bunny:", cv.shape, float(cs.mean()), float(cs.max()))
+
+
+def gen_trace_known_answer():
+    """The reference's embedded backward proof (ray_trace_voge.cu:381-448): same inputs, the
+    same three forms, loss = len + act, gradients by torch autograd."""
+    isg = torch.tensor([[2., 1., 0.], [1., 1.2, 0.], [0., 0., 1.]], requires_grad=True)
+    mu = torch.tensor([1.2, 0.2, 0.], requires_grad=True)
+    ray = torch.tensor([1., 0., 0.], requires_grad=True)
+    msk, ksk, msm = mu @ isg @ ray, ray @ isg @ ray, mu @ isg @ mu
+    ln, act = msk / ksk, msm - msk * msk / ksk
+    (ln + act).backward()
+    np.savez(os.path.join(OUT, "trace_bwd_known_answer.npz"), isigma=isg.detach().numpy(), mu=mu.detach().numpy(),
+             ray=ray.detach().numpy(), len=ln.item(), act=act.item(), dsd=ksk.item(), g_mu=mu.grad.numpy(),
+             g_isigma=isg.grad.numpy(), g_ray=ray.grad.numpy())
+    print("known answer:", mu.grad.tolist(), isg.grad.tolist(), ray.grad.tolist())
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    mods = import_reference()
+    gen_composite(mods[0], mods[1])
+    gen_merge_blend(mods[0], mods[1])
+    gen_misc(*mods)
+    gen_trace_known_answer()
