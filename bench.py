@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Benchmark of the VoGE hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+A "step" is one forward+backward frame of BASELINE.json's metric config (config 3: 50 000
+synthetic Gaussians, 512x512, K=40, max_point_per_bin=-1):
+    frag = renderer(gaussians, R=R, T=T); img = to_white_background(frag, colors); img.sum().backward()
+with gradients to verts [N,3], sigmas [N] and colours [N,3].  Inputs are resident in HBM before
+the timed region.  With --gpus N > 1 (one process per GPU, torchrun) the frame's pixel rows are
+sharded over the ranks: each rank traces / composites its own row band, the image is assembled
+by ONE all-gather (RCCL) and the per-Gaussian gradients by ONE all-reduce -> total work is
+fixed, "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg3_50k_512")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=4, help="pixel rows of the frame the CPU oracle is timed on")
+    return ap.parse_args()
+
+
+def stage_bytes(P, npix, K, C=3):
+    """ALGORITHMIC HBM bytes per launch of each stage, fp32/int32."""
+    return {
+        "trace_fwd": P * 48 + npix * 12 + npix * K * 16,
+        "composite_fwd": npix * K * 12 + npix * K * 4 + npix * 8,
+        "merge_fwd": npix * K * 8 + P * 4 * C + npix * 4 * C,
+        "blend_fwd": npix * K * 4 + 2 * npix * 4 * C,
+        "blend_bwd": npix * K * 4 + 2 * npix * 4 * C + npix * K * 4 + npix * 4 * C,
+        "merge_bwd": npix * 4 * C + npix * K * 8 + npix * K * 4 + P * 4 * C,
+        "composite_bwd": npix * K * (12 + 4) + npix * K * 12,
+        "trace_bwd": npix * K * 16 + npix * 12 + P * 48 + npix * 12 + P * 48,
+    }
+
+
+def time_kernel(fn, iters=20, warm=3):
+    """Average duration (ms) of `fn` with HIP events on torch's current stream -- the stream
+    every voge_* entry point is launched on."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the VoGE hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from voge_amd import _lib, ops, scenes
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
+    from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
+    from voge_amd.distributed import allreduce_grads, gather_rows, row_band
+    _lib.load()
+
+    N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[args.config]
+    verts, sig, cols = scenes.random_gaussians(N, seed=0)
+    gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
+    colors = torch.from_numpy(cols).to(dev).requires_grad_(True)
+    R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
+    cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), device=dev)
+    settings = GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1,
+                                      max_point_per_bin=-1)
+    renderer = GaussianRenderer(cams, settings).to(dev)
+    rows = row_band(H, rank, world) if world > 1 else None
+    params = [gm.verts, gm.sigmas, colors]
+
+    def step():
+        for p in params:
+            p.grad = None
+        frag = renderer(gm, R=R, T=T, **({} if rows is None else {"rows": rows}))
+        band = to_white_background(frag, colors)
+        img = gather_rows(band, H)
+        if world > 1:
+            r0, r1 = rows
+            img[:, r0:r1].sum().backward()   # each rank owns the loss of its band; grads are summed below
+            allreduce_grads(params)
+        else:
+            img.sum().backward()
+        return img
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    fps = args.steps / dt
+
+    result = {
+        "metric": "forward+backward frames/sec at 512^2, 50k Gaussians; ray-trace HBM GB/s vs peak",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.config}: {N} random Gaussians, {H}x{W}, K={K}, max_point_per_bin=-1, "
+                               f"fwd+bwd (grads to verts, sigmas, colors)",
+                   "parallelism": "1 gpu" if world == 1 else f"pixel-row bands x{world}, all_gather(image)+all_reduce(grads)"},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- per-stage kernel timings on the same inputs (HIP events, current stream) --------
+        with torch.no_grad():
+            from voge_amd.cameras import pixel_rays
+            from voge_amd.Aggregation import expend_sigma
+            rays, origin = pixel_rays(cams, (H, W))
+            mus = (gm.verts[None] - origin[:, None]).reshape(-1, 3).contiguous()
+            isg = (2 * expend_sigma(gm.sigmas)).contiguous()
+            thr_act = -np.log(0.01 + 1e-10)
+            sel = ops.ray_trace_fine(mus, isg, rays, None, thr_act, 16, K)
+            w, vn = ops.composite(sel[0], sel[2], sel[1], sel[3], 1.0)
+            idx = sel[0].clone()
+            rgb = ops.merge(colors.detach(), w, idx, vn)
+            bg = torch.ones(3, device=dev)
+            g_img = torch.ones_like(rgb)
+            lib = _lib.load()
+            st = torch.cuda.current_stream().cuda_stream
+            npix = H * W
+            ws = torch.empty(lib.voge_trace_workspace_bytes(1, N), dtype=torch.uint8, device=dev)
+            o_i, o_l, o_a, o_d = (torch.empty_like(x) for x in sel)
+            g3 = [torch.empty_like(w) for _ in range(3)]
+            g_ray, g_mu, g_A = torch.empty_like(rays), torch.empty_like(mus), torch.empty_like(isg)
+            out3, g_attr = torch.empty_like(rgb), torch.empty_like(colors)
+            P = lambda x: x.data_ptr()
+            calls = {
+                "trace_fwd": lambda: lib.voge_trace_topk_fwd(P(mus), P(isg), P(rays), None, 1, N, H, W, K, thr_act, P(ws),
+                                                             ws.numel(), P(o_i), P(o_l), P(o_a), P(o_d), st),
+                "composite_fwd": lambda: lib.voge_composite_fwd(P(sel[0]), P(sel[2]), P(sel[1]), P(sel[3]), 1.0, npix, K,
+                                                                P(g3[0]), P(vn), st),
+                "merge_fwd": lambda: lib.voge_merge_fwd(P(colors), P(idx), P(w), P(vn), npix, K, 3, N, 0, P(out3), st),
+                "blend_fwd": lambda: lib.voge_blend_fwd(P(rgb), P(w), P(bg), -1.0, npix, K, 3, P(out3), None, st),
+                "blend_bwd": lambda: lib.voge_blend_bwd(P(rgb), P(w), P(bg), -1.0, P(g_img), npix, K, 3, P(out3), P(g3[0]), st),
+                "merge_bwd": lambda: lib.voge_merge_bwd(P(colors), P(idx), P(w), P(vn), P(g_img), npix, K, 3, N, P(g_attr),
+                                                        P(g3[0]), st),
+                "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), 1.0, npix, K, P(g3[0]),
+                                                                P(g3[1]), P(g3[2]), st),
+                "trace_bwd": lambda: lib.voge_trace_bwd(P(mus), P(isg), P(rays), P(sel[0]), P(w), P(w), P(w), N, npix, K,
+                                                        P(g_ray), P(g_mu), P(g_A), st),
+            }
+            nbytes = stage_bytes(N, npix, K)
+            stages = {}
+            for name, fn in calls.items():
+                t_ms = time_kernel(fn)
+                stages[name] = {"ms": round(t_ms, 4), "algo_MB": round(nbytes[name] / 1e6, 1),
+                                "GBps": round(nbytes[name] / 1e9 / (t_ms / 1e3), 1)}
+            hits = int((sel[0] >= 0).sum().item())
+        dom = "trace_fwd"  # the sweep BASELINE.json's metric names
+        a = stages[dom]["GBps"]
+        result["roofline"] = {"kernel": "voge_trace_topk_fwd (prep_kernel + trace_fwd_kernel)", "bound": "hbm",
+                              "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
+                              "traffic": None, "algorithmic_bytes": nbytes[dom], "avg_launch_ms": stages[dom]["ms"]}
+        result["stages"] = stages
+        result["frame_kernel_ms_sum"] = round(sum(s["ms"] for s in stages.values()), 4)
+        result["hits_per_pixel"] = round(hits / npix, 2)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(verts, sig, cols, H, W, K, focal, pp, (dd, el, az), args.cpu_rows)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(verts, sig, cols, H, W, K, focal, pp, view, nrows):
+    """The CPU oracle (a C/OpenMP port of the reference algorithm, fp64) timed on this host on a
+    bounded sample: `nrows` pixel rows around the image centre, forward + backward, scaled to a
+    whole frame by H / nrows."""
+    import oracle
+    from oracle import camera_np
+    oracle.build()
+    R, T = camera_np.look_at_view_transform(*view)
+    rays, origin = camera_np.pixel_rays(R, T, focal, pp, (H, W))
+    r0 = H // 2 - nrows // 2
+    rays = np.ascontiguousarray(rays[:, r0:r0 + nrows])
+    mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = (2 * camera_np.expand_sigma(sig)).astype(np.float32)[None]
+    thr_act = oracle.thr_act_of(0.01)
+    t0 = time.perf_counter()
+    idx, ln, act, dsd = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    w, vn = oracle.composite_fwd(idx, act, ln, dsd, 1.0)
+    rgb = oracle.merge_fwd(cols, idx, w, vn)
+    img, sil = oracle.blend_fwd(rgb, w)
+    t_fwd = time.perf_counter() - t0
+    g_img = np.ones_like(img)
+    g_rgb = g_img * (rgb + (1 - sil)[..., None] < 1)
+    g_attr, g_w = oracle.merge_bwd(cols, idx, w, vn, g_rgb)
+    g_w = g_w - (g_rgb.sum(-1) * (w.sum(-1) < 1))[..., None]
+    g_act, g_len, g_dsd = oracle.composite_bwd(act, ln, dsd, g_w, 1.0)
+    oracle.trace_bwd(mus, isg, rays, idx, g_len, g_act, g_dsd)
+    t_all = time.perf_counter() - t0
+    scale = H / nrows
+    return {"value": 1.0 / (t_all * scale), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{nrows} of {H} pixel rows (rows {r0}..{r0 + nrows - 1}) of the same frame, fwd+bwd, "
+                      f"oracle/voge_oracle.c fp64 with OpenMP over pixels; {t_all:.2f} s measured "
+                      f"(fwd {t_fwd:.2f} s), scaled x{scale:.0f}"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/*
+ * voge_hip.h -- C ABI of libvoge_hip.so, the MI355X (gfx950) implementation of the VoGE
+ * ray-trace + aggregation hot path.
+ *
+ * This is the drop-in boundary: it replaces the on-path part of the reference's pybind11
+ * module `VoGE._C` (VoGE/csrc/ext.cpp:7-17) and the tensor programs of
+ * VoGE/Aggregation.py that sit directly behind it.  Plain C: raw DEVICE pointers, sizes,
+ * and a HIP stream handle -- no torch / ATen types.
+ *
+ * Conventions (all functions):
+ *   - every pointer is a device pointer on the current HIP device, caller-allocated and
+ *     caller-owned; the library never allocates, frees or keeps state between calls;
+ *   - float = IEEE fp32, idx = int32, valid_num = int64 (Aggregation.py:104 returns int64);
+ *   - tensors are contiguous, row-major, layouts as in the reference:
+ *       mus [P,3], isigmas [P,3,3], rays [B,H,W,3], per-slot arrays [B,H,W,K]
+ *       (ray index = b*H*W + y*W + x, ray_trace_voge.cu:176);
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream), no host synchronisation, re-entrant across streams;
+ *   - return value: 0 on success, a positive hipError_t value if the HIP runtime reported an
+ *     error (the reference raises via AT_CUDA_CHECK, ray_trace_voge.cu:278,:377), or a
+ *     negative VOGE_ERR_* code for argument errors.  Never throws.
+ */
+#ifndef VOGE_HIP_H
+#define VOGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOGE_ABI_VERSION 1
+
+#define VOGE_ERR_BAD_ARG (-1)        /* null pointer / non-positive size */
+#define VOGE_ERR_WORKSPACE (-2)      /* workspace smaller than voge_trace_workspace_bytes() */
+#define VOGE_ERR_K_TOO_LARGE (-3)    /* K above VOGE_MAX_K (top-K lists live in LDS) */
+
+#define VOGE_MAX_K 256
+
+typedef void *voge_stream_t; /* hipStream_t */
+
+/* ABI version of the loaded library (== VOGE_ABI_VERSION it was built with). */
+int voge_abi_version(void);
+
+/* Human-readable text for a return code of any function below. */
+const char *voge_error_string(int code);
+
+/*
+ * Bytes of scratch the forward trace needs for P = B*N Gaussians (per-Gaussian derived
+ * records: cull sphere + quadratic-form coefficients).  Caller allocates, any alignment >= 16.
+ */
+size_t voge_trace_workspace_bytes(int B, int N);
+
+/*
+ * Fine ray trace forward, "all Gaussians are candidates" form.
+ * Replaces: VoGE._C.ray_trace_voge_fine (ray_trace_voge.h:7-15, ray_trace_voge.cu:219-280)
+ * called with the bin list RayTracing.py:22-26 builds for max_points_per_bin == -1
+ * (every pixel of batch b sees Gaussians b*N .. b*N+N-1).  That P-long list is never
+ * materialised here.
+ *
+ * For each pixel ray d and Gaussian (mu, A): dsd = d^T A d, len = mu^T A d / dsd,
+ * act = mu^T A mu - (mu^T A d)^2 / dsd; keep if act < thr_act (and len < 1e10, the
+ * sentinel); output the K kept candidates with the smallest (len, index), ascending;
+ * unused slots hold idx=-1, len=1e10, act=1e10, dsd=0 (ray_trace_voge.cu:184-214,:244-247).
+ * idx holds the global index b*N+i.  Outputs need no pre-fill.
+ *
+ * cam_fwd: NULL, or [B,3] unit view axis in the rays' frame: Gaussians with mu.fwd < 0
+ * are skipped, which is the candidate rule of the reference's coarse stage
+ * (rasterize_coarse.cu:35, "skip z<0") used when max_points_per_bin != -1.
+ */
+int voge_trace_topk_fwd(const float *mus, const float *isigmas, const float *rays,
+                        const float *cam_fwd, int B, int N, int H, int W, int K,
+                        float thr_act, void *workspace, size_t workspace_bytes,
+                        int32_t *idx, float *len, float *act, float *dsd,
+                        voge_stream_t stream);
+
+/*
+ * Fine ray trace forward with caller-supplied candidate lists.
+ * Replaces: VoGE._C.ray_trace_voge_fine for an explicit bin_points tensor
+ * [B,BH,BW,M] int32, -1 = empty (ray_trace_voge.cu:135-217): pixel (y,x) of batch b
+ * scans bin (y/bin_size, x/bin_size).  P = total Gaussians (list entries index [0,P)).
+ * Same outputs as above.  Exact ties in len are ordered by index (the reference orders
+ * them by list position, which is not deterministic for coarse-rasterised lists).
+ */
+int voge_trace_topk_list_fwd(const float *mus, const float *isigmas, const float *rays,
+                             const int32_t *bin_points, int B, int P, int H, int W, int K,
+                             int BH, int BW, int M, int bin_size, float thr_act,
+                             int32_t *idx, float *len, float *act, float *dsd,
+                             voge_stream_t stream);
+
+/*
+ * Fine ray trace backward.
+ * Replaces: VoGE._C.ray_trace_voge_fine_backward (ray_trace_voge.h:17-25,
+ * ray_trace_voge.cu:283-379).  npix = B*H*W.  For every slot with idx >= 0 applies the
+ * chain rule of ray_trace_voge.cu:324-326 and scatters into
+ *   g_ray [npix,3], g_mus [P,3], g_isg [P,3,3]  (raw outer products, not symmetrised).
+ * The three outputs are zero-filled by this call (the reference allocates zeros, :354-356).
+ */
+int voge_trace_bwd(const float *mus, const float *isigmas, const float *rays,
+                   const int32_t *idx, const float *g_len, const float *g_act,
+                   const float *g_dsd, int P, long npix, int K, float *g_ray,
+                   float *g_mus, float *g_isg, voge_stream_t stream);
+
+/*
+ * Composite forward.  Replaces: VoGE/Aggregation.py:82-107 `aggregation`
+ * (get_cross_activation :30-51 + assign2weight :54-79), without any [npix,K,K] temporary.
+ *   w_m = exp(-occ * sum_k exp(-act_k) * (erf((len_m-len_k)*sqrt(dsd_k+1e-10)) + 1)/2)
+ *         * exp(-act_m) / exp(-0.5);   valid_num = #(idx >= 0)
+ */
+int voge_composite_fwd(const int32_t *idx, const float *act, const float *len,
+                       const float *dsd, float occ, long npix, int K, float *weight,
+                       int64_t *valid_num, voge_stream_t stream);
+
+/*
+ * Composite backward (the reference relies on autograd through Aggregation.py:49,70,74,77).
+ * g_weight [npix,K] -> g_act, g_len, g_dsd [npix,K] (fully written).
+ */
+int voge_composite_bwd(const float *act, const float *len, const float *dsd,
+                       const float *g_weight, float occ, long npix, int K, float *g_act,
+                       float *g_len, float *g_dsd, voge_stream_t stream);
+
+/*
+ * Attribute merge forward.  Replaces: VoGE/Aggregation.py:111-141 `merge_final`
+ * (reached through Renderer.py:153 interpolate_attr).
+ *   out[pix,c] = sum_{k < valid_num[pix]} attr[max(idx_k,0)... , c] * weight[pix,k]
+ * attr [Nattr,C].  If fix_negative_idx != 0, idx is updated in place the way the reference
+ * does (`vert_assign += (vert_assign < 0)`, Aggregation.py:131: -1 becomes 0).
+ */
+int voge_merge_fwd(const float *attr, int32_t *idx, const float *weight,
+                   const int64_t *valid_num, long npix, int K, int C, long Nattr,
+                   int fix_negative_idx, float *out, voge_stream_t stream);
+
+/*
+ * Attribute merge backward (autograd of merge_final): g_out [npix,C] ->
+ * g_attr [Nattr,C] (zero-filled here, then scatter-added) and g_weight [npix,K].
+ * Either output pointer may be NULL to skip it.
+ */
+int voge_merge_bwd(const float *attr, const int32_t *idx, const float *weight,
+                   const int64_t *valid_num, const float *g_out, long npix, int K, int C,
+                   long Nattr, float *g_attr, float *g_weight, voge_stream_t stream);
+
+/*
+ * Background blend forward.  Replaces: VoGE/Renderer.py:157-171
+ * (get_silhouette + to_colored_background):
+ *   sil = min(sum_k w_k, 1); mask = thr > 0 ? (sil > thr) : sil;
+ *   out = min(rgb + (1 - mask) * bg, 1)
+ * rgb,out [npix,C], bg [C], sil_out [npix] (may be NULL).
+ */
+int voge_blend_fwd(const float *rgb, const float *weight, const float *bg, float thr,
+                   long npix, int K, int C, float *out, float *sil_out,
+                   voge_stream_t stream);
+
+/*
+ * Background blend backward: g_out [npix,C] -> g_rgb [npix,C] and the additive term
+ * g_weight_add [npix,K] (d out / d weight through the silhouette; zero where thr > 0 or
+ * where the silhouette is clamped).  Recomputes the clamps from rgb / weight / bg.
+ */
+int voge_blend_bwd(const float *rgb, const float *weight, const float *bg, float thr,
+                   const float *g_out, long npix, int K, int C, float *g_rgb,
+                   float *g_weight_add, voge_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOGE_HIP_H */

@@ -1,0 +1,170 @@
+"""CPU tests: the oracle against the golden fixtures produced by the imported reference
+(tests/golden/make_golden.py) and against the reference's embedded known-answer vector."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import camera_np
+from util import GOLDEN
+
+
+@pytest.mark.parametrize("name", ["k5", "k25", "k40"])
+def test_composite_matches_reference(name):
+    g = np.load(os.path.join(GOLDEN, f"composite_{name}.npz"))
+    w, vn = oracle.composite_fwd(g["idx"], g["act"], g["len"], g["dsd"], float(g["occ"]))
+    assert np.abs(w - g["weight"]).max() < 1e-14
+    assert (vn == g["valid_num"]).all()
+    # empty slots give exactly zero weight
+    assert (w[g["idx"] < 0] == 0).all()
+    ga, gl, gd = oracle.composite_bwd(g["act"], g["len"], g["dsd"], g["g_weight"], float(g["occ"]))
+    for got, key in ((ga, "g_act"), (gl, "g_len"), (gd, "g_dsd")):
+        ref = g[key]
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), key
+    # the reference's own fp32 run stays within the stated tolerance of the fp64 truth
+    assert np.abs(g["weight_f32"] - g["weight"]).max() < 1e-4
+
+
+def test_merge_blend_matches_reference():
+    m = np.load(os.path.join(GOLDEN, "merge_blend.npz"))
+    rgb = oracle.merge_fwd(m["colors"], m["idx"], m["weight"], m["valid_num"])
+    assert np.abs(rgb - m["rgb"]).max() < 1e-14
+    fm = oracle.merge_fwd(m["feat"], m["idx"], m["weight"], m["valid_num"])
+    assert np.abs(fm - m["feat_map"]).max() < 1e-13
+    img, sil = oracle.blend_fwd(rgb, m["weight"])
+    assert np.abs(img - m["img_white"]).max() < 1e-14
+    assert np.abs(sil - m["silhouette"]).max() < 1e-14
+    img2, _ = oracle.blend_fwd(rgb, m["weight"], m["bg"], float(m["thr"]))
+    assert np.abs(img2 - m["img_colored_thr"]).max() < 1e-6   # reference keeps bg in fp32
+    # in-place index fix of merge_final: -1 -> 0
+    assert (m["idx_after_merge"] == np.where(m["idx"] < 0, m["idx"] + 1, m["idx"])).all()
+    g_attr, g_w = oracle.merge_bwd(m["feat"], m["idx"], m["weight"], m["valid_num"], m["g_feat"])
+    assert np.abs(g_attr - m["g_feat_attr"]).max() < 1e-12
+
+
+def test_trace_backward_known_answer():
+    """ray_trace_voge.cu:381-448: grad_mu=[1,.78,0], grad_isigma=[[-.04,.24,0],[-.18,.04,0],0], grad_ray=[-1.3,-.944,0]."""
+    k = np.load(os.path.join(GOLDEN, "trace_bwd_known_answer.npz"))
+    ray = k["ray"].reshape(1, 1, 1, 3)
+    idx, ln, act, dsd = oracle.trace_fwd(k["mu"][None], k["isigma"][None], ray, 1, 1e9)
+    assert idx.item() == 0
+    assert abs(ln.item() - float(k["len"])) < 1e-6 and abs(act.item() - float(k["act"])) < 1e-6
+    one, zero = np.ones((1, 1, 1, 1)), np.zeros((1, 1, 1, 1))
+    g_ray, g_mu, g_isg = oracle.trace_bwd(k["mu"][None], k["isigma"][None], ray, idx, one, one, zero)
+    assert np.abs(g_mu[0] - [1.0, 0.78, 0.0]).max() < 1e-6
+    assert np.abs(g_isg[0] - [[-0.04, 0.24, 0], [-0.18, 0.04, 0], [0, 0, 0]]).max() < 1e-6
+    assert np.abs(g_ray.reshape(3) - [-1.3, -0.944, 0.0]).max() < 1e-6
+    assert np.abs(g_mu[0] - k["g_mu"]).max() < 1e-6 and np.abs(g_isg[0] - k["g_isigma"]).max() < 1e-6
+
+
+def _dense_trace(mus, isg, rays, K, thr_act):
+    """Independent numpy formulation: dense quadratic forms + stable argsort."""
+    B, H, W, _ = rays.shape
+    d = rays.reshape(B, -1, 3).astype(np.float64)
+    mu = mus.reshape(B, -1, 3).astype(np.float64)
+    A = isg.reshape(B, -1, 3, 3).astype(np.float64)
+    N = mu.shape[1]
+    out = []
+    for b in range(B):
+        Ad = np.einsum("nij,pj->pni", A[b], d[b])
+        ksk = np.einsum("pi,pni->pn", d[b], Ad)
+        msk = np.einsum("ni,pni->pn", mu[b], Ad)
+        msm = np.einsum("ni,nij,nj->n", mu[b], A[b], mu[b])[None]
+        ln = msk / ksk
+        act = msm - msk * msk / ksk
+        key = np.where(act < thr_act, ln, np.inf)
+        order = np.argsort(key, axis=1, kind="stable")[:, :K]
+        ok = np.take_along_axis(key, order, 1) < 1e10
+        out.append((np.where(ok, order + b * N, -1), np.where(ok, np.take_along_axis(ln, order, 1), 1e10),
+                    np.where(ok, np.take_along_axis(act, order, 1), 1e10),
+                    np.where(ok, np.take_along_axis(ksk, order, 1), 0.0)))
+    return [np.stack([o[i] for o in out]).reshape(B, H, W, K) for i in range(4)]
+
+
+def test_trace_forward_vs_dense_formulation():
+    rng = np.random.default_rng(3)
+    B, N, H, W, K = 2, 150, 9, 13, 6
+    mus = rng.normal(size=(B, N, 3)).astype(np.float32) + np.float32([0, 0, 4])
+    L = np.tril(rng.uniform(-1, 1, (B, N, 3, 3))) * 3
+    isg = (L @ L.transpose(0, 1, 3, 2) + 0.5 * np.eye(3)).astype(np.float32)
+    rays = rng.normal(size=(B, H, W, 3)) * 0.3 + [0, 0, 1]
+    rays = (rays / np.linalg.norm(rays, axis=-1, keepdims=True)).astype(np.float32)
+    thr = oracle.thr_act_of(0.01)
+    got = oracle.trace_fwd(mus, isg, rays, K, thr)
+    ref = _dense_trace(mus, isg, rays, K, thr)
+    assert (got[0] == ref[0]).all()
+    for g, r in zip(got[1:], ref[1:]):
+        assert np.abs(g - r).max() < 1e-9
+    # explicit bin lists: all-candidate list in every bin == NULL list (RayTracing.py:22-26)
+    bs = 8
+    BH, BW = (H - 1) // bs + 1, (W - 1) // bs + 1
+    bins = (np.arange(N)[None, None, None, :] + np.arange(B)[:, None, None, None] * N) * np.ones((1, BH, BW, 1), int)
+    got2 = oracle.trace_fwd(mus, isg, rays, K, thr, bin_points=bins.astype(np.int32), bin_size=bs)
+    for a, b in zip(got, got2):
+        assert (a == b).all()
+    # K larger than the number of hits: tail is sentinels
+    got3 = oracle.trace_fwd(mus, isg, rays, 200, thr)
+    assert (got3[0][..., -1] == -1).all() and (got3[1][..., -1] == 1e10).all()
+
+
+def test_trace_backward_vs_finite_differences():
+    rng = np.random.default_rng(5)
+    N, H, W, K = 7, 2, 3, 3
+    mus = (rng.normal(size=(N, 3)) * 0.2 + [0, 0, 3]).astype(np.float32)
+    L = np.tril(rng.uniform(0.5, 1.5, (N, 3, 3)))
+    isg = (L @ L.transpose(0, 2, 1) + rng.normal(size=(N, 3, 3)) * 0.05).astype(np.float32)  # not symmetric
+    rays = rng.normal(size=(1, H, W, 3)) * 0.05 + [0, 0, 1]
+    rays = (rays / np.linalg.norm(rays, axis=-1, keepdims=True)).astype(np.float32)
+    idx, ln, act, dsd = oracle.trace_fwd(mus, isg, rays, K, 1e9)
+    gl, ga, gd = (rng.normal(size=idx.shape) for _ in range(3))
+    g_ray, g_mu, g_isg = oracle.trace_bwd(mus, isg, rays, idx, gl, ga, gd)
+
+    def loss(m, a, r):
+        tot = 0.0
+        for (y, x, k), p in np.ndenumerate(idx[0]):
+            d = r[0, y, x].astype(np.float64)
+            A, mu = a[p].astype(np.float64), m[p].astype(np.float64)
+            ksk, msk, msm = d @ A @ d, mu @ A @ d, mu @ A @ mu
+            tot += gl[0, y, x, k] * msk / ksk + ga[0, y, x, k] * (msm - msk * msk / ksk) + gd[0, y, x, k] * ksk
+        return tot
+    eps = 1e-3  # inputs are fp32: perturb on a grid exactly representable around the values
+    for arr, grad, pos in ((mus, g_mu, (2, 1)), (isg, g_isg, (3, 0, 2)), (isg, g_isg, (3, 2, 0)), (rays, g_ray, (0, 1, 2, 0))):
+        hi, lo = arr.astype(np.float64), arr.astype(np.float64)
+        hi[pos] += eps
+        lo[pos] -= eps
+        args_hi = [mus, isg, rays]
+        args_lo = [mus, isg, rays]
+        i = 0 if arr is mus else (1 if arr is isg else 2)
+        args_hi[i], args_lo[i] = hi, lo
+        fd = (loss(*args_hi) - loss(*args_lo)) / (2 * eps)
+        assert abs(fd - grad[pos]) <= 1e-5 * max(1.0, abs(fd)), (pos, fd, grad[pos])
+
+
+def test_camera_conventions():
+    R, T = camera_np.look_at_view_transform(6, 10, 70)
+    rays, C = camera_np.pixel_rays(R, T, 300.0, (128.0, 128.0), (256, 256))
+    assert np.abs(np.linalg.norm(rays, axis=-1) - 1).max() < 1e-6
+    assert np.abs(C[0] - 6 * np.array([np.cos(np.deg2rad(10)) * np.sin(np.deg2rad(70)), np.sin(np.deg2rad(10)),
+                                       np.cos(np.deg2rad(10)) * np.cos(np.deg2rad(70))])).max() < 1e-6
+    # a world point projects (x_view = px - fx X/Z ...) onto the pixel whose ray passes through it
+    P = np.array([0.3, -0.2, 0.1])
+    v = P @ R[0].astype(np.float64) + T[0]
+    col, row = 128 - 300 * v[0] / v[2], 128 - 300 * v[1] / v[2]
+    i, j = int(np.floor(row)), int(np.floor(col))
+    d = (P - C[0]) / np.linalg.norm(P - C[0])
+    assert np.arccos(np.clip(rays[0, i, j] @ d, -1, 1)) < 1.5 / 300
+
+
+def test_expend_sigma_and_whole_frame():
+    g = np.load(os.path.join(GOLDEN, "misc_api.npz"))
+    assert (camera_np.expand_sigma(np.float32([1.5, 2.5])) == g["expend_1"]).all()
+    assert (camera_np.expand_sigma(np.float32([[1, 2, 3], [4, 5, 6]])) == g["expend_2"]).all()
+    R, T = camera_np.look_at_view_transform(6, 10, 70)
+    verts, isig = g["cuboid_verts"], g["cuboid_isigma"]
+    out = oracle.render(verts, isig, (verts + 1) / 3, R, T, 60.0, (32.0, 32.0), (64, 64), K=20)
+    assert out["image"].shape == (1, 64, 64, 3) and np.isfinite(out["image"]).all()
+    assert out["weight"].min() >= 0 and out["image"].max() <= 1.0
+    assert out["valid_num"].max() > 3 and (out["image"][0, 0, 0] == 1).all()  # corner is background
+    valid = out["idx"] >= 0
+    assert (np.diff(np.where(valid, out["len"], np.inf), axis=-1)[valid[..., 1:]] >= 0).all()

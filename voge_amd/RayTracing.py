@@ -1,0 +1,65 @@
+"""Host-side mirror of VoGE/RayTracing.py for the MI355X build (same names, same argument
+meaning, same error behaviour for the on-path entry points).
+
+ray_tracing          <- VoGE/RayTracing.py:12-30
+ray_tracing_fine     <- VoGE/RayTracing.py:76-95
+_RayTraceVoGE        <- VoGE/RayTracing.py:154-206  (implemented in voge_amd.ops)
+
+Difference by design (DESIGN.md §Candidate sets): the reference either materialises an
+all-Gaussians list per bin (max_points_per_bin == -1) or runs a lossy coarse rasteriser
+(bin overflow drops candidates, rasterize_coarse.cu:154-170).  Here every setting runs the
+same exact sweep -- culling happens inside the kernel and is conservative -- and
+max_points_per_bin != -1 only adds the coarse stage's "skip Gaussians behind the camera"
+rule (rasterize_coarse.cu:35).
+"""
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .ops import _RayTraceVoGE
+
+inf = 1e8
+
+
+def default_bin_size(image_size):
+    """RayTracing.py:14-16."""
+    return max(int(2 ** np.ceil(np.log2(max(image_size)) - 5)), 10)
+
+
+def ray_tracing(transforms, points, isigmas, rays, image_size, thr: float, n_assign: int,
+                bin_size: Optional[int] = None, max_points_per_bin: Optional[int] = None, **kwargs):
+    """points [B,N,3] camera-centred, isigmas [B,N,3,3], rays [B,H,W,3] -> sel_idx, sel_len,
+    sel_act, sel_dsd, each [B,H,W,n_assign]."""
+    if bin_size is None:
+        bin_size = default_bin_size(image_size)
+    if max_points_per_bin == -1:
+        candidates = None
+    else:
+        # coarse-stage candidate rule kept: view-space z >= 0 (rasterize_coarse.cu:35).  The view
+        # axis in the rays' (world-aligned) frame is the third column of R (X_view = X_world @ R + T).
+        candidates = _view_axis(transforms, points)
+    return ray_tracing_fine(points.reshape(-1, 3), isigmas.reshape(-1, 3, 3), rays, candidates, thr, bin_size,
+                            n_assign)
+
+
+def _view_axis(cameras, points):
+    R = getattr(cameras, "R", None)
+    if R is None:
+        return None
+    R = torch.as_tensor(R, dtype=torch.float32, device=points.device).reshape(-1, 3, 3)
+    B = points.shape[0]
+    if R.shape[0] != B:
+        R = R.expand(B, -1, -1)
+    return R[:, :, 2].detach().contiguous()
+
+
+def ray_tracing_fine(mus, isigmas, rays, bin_points, thr, bin_size, n_assign, inf=1e10):
+    assert isigmas.dim() == 3
+    assert mus.dim() == 2
+    assert rays.dim() == 4
+    assert bin_points is None or bin_points.dim() in (2, 4)
+    assert mus.shape[0] == isigmas.shape[0] and mus.shape[1] == 3 and isigmas.shape[1] == 3 and isigmas.shape[2] == 3
+    thr_act = -math.log(thr + 1 / inf)
+    return _RayTraceVoGE.apply(mus, isigmas, rays, bin_points, thr_act, bin_size, n_assign)

@@ -1,0 +1,147 @@
+"""Host-side mirror of VoGE/Renderer.py: GaussianRenderer (:87-150), GaussianRenderSettings
+(:53-84), Fragments (:13-50), interpolate_attr (:153), get_silhouette (:157-159),
+to_colored_background (:162-171), to_white_background (:174-176) -- same names, same argument
+meaning.  Every stage behind these calls is a HIP kernel (voge_amd.ops); a renderer on CPU
+tensors raises instead of falling back.
+"""
+from typing import Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .Aggregation import aggregation, expend_sigma, merge_final
+from .RayTracing import ray_tracing
+from .cameras import pixel_rays
+
+
+class Fragments(object):
+    """vert_weight [.., K] f32, vert_index [.., K] i32, valid_num [..] i64, vert_hit_length [.., K] f32."""
+
+    _fields = ("vert_weight", "vert_index", "valid_num", "vert_hit_length")
+
+    def __init__(self, vert_weight, vert_index, valid_num, vert_hit_length):
+        self.vert_weight = vert_weight
+        self.vert_index = vert_index
+        self.valid_num = valid_num
+        self.vert_hit_length = vert_hit_length
+
+    def _map(self, fn):
+        return Fragments(**{k: fn(getattr(self, k)) for k in self._fields})
+
+    def __getitem__(self, item):
+        assert len(self.valid_num.shape) == 3, 'Index access is only available when batched.'
+        return self._map(lambda t: t[item])
+
+    def __len__(self):
+        return self.valid_num.shape[0]
+
+    @property
+    def shape(self):
+        return tuple(getattr(self, k).shape for k in self._fields)
+
+    def squeeze(self):
+        assert self.valid_num.shape[0] == 1
+        return self[0]
+
+    def unsqueeze(self):
+        assert len(self.valid_num.shape) == 2
+        return self._map(lambda t: t.unsqueeze(0))
+
+    def to_dict(self):
+        return {k: getattr(self, k) for k in self._fields}
+
+    def copy(self):
+        return self._map(lambda t: t.contiguous())
+
+
+class GaussianRenderSettings:
+    __slots__ = ['image_size', 'max_assign', 'thr_activation', 'absorptivity', 'inverse_sigma', 'principal',
+                 'max_point_per_bin']
+
+    def __init__(self, image_size: Union[int, Tuple[int, int]] = 256, max_assign: int = 20,
+                 thr_activation: float = 0.01, absorptivity: float = 1, inverse_sigma: bool = False,
+                 principal: Union[None, Tuple[int, int], Tuple[float, float]] = None,
+                 max_point_per_bin: Union[None, int] = None, **kwargs):
+        # unknown keywords (batch_size=, principal_point=, ...) are accepted and ignored, as in
+        # Renderer.py:70
+        self.image_size = (image_size, image_size) if isinstance(image_size, int) else image_size
+        self.max_assign = max_assign
+        self.thr_activation = thr_activation
+        self.absorptivity = absorptivity
+        self.inverse_sigma = inverse_sigma
+        self.principal = principal
+        self.max_point_per_bin = max_point_per_bin
+
+    def __getitem__(self, item):
+        return getattr(self, item)
+
+
+class GaussianRenderer(nn.Module):
+    to_set_args = ['R', 'T', 'focal', 'principal']
+
+    def __init__(self, cameras, render_settings: Union[dict, GaussianRenderSettings]):
+        super().__init__()
+        self.cameras = cameras
+        self.render_settings = render_settings
+        self.device = cameras.device
+
+    def to(self, device):
+        # cameras are not nn.Modules: move them by hand (Renderer.py:96-100)
+        self.cameras = self.cameras.to(device)
+        self.device = device
+        return self
+
+    def forward(self, gmeshes, **kwargs):
+        """gmeshes() -> (verts [N,3] | [B,N,3], sigmas [N] | [N,3] | [N,3,3], radians);
+        R=, T= (and the inert focal=, principal=) keywords are stored on the camera object
+        (Renderer.py:104-109).  `rows=(r0, r1)` (extension) renders only that pixel-row band."""
+        cams = self.cameras
+        assert not cams.in_ndc(), 'Got NDC camera. Cameras.in_ndc must be set to false.'
+        for name in self.to_set_args:
+            if name in kwargs:
+                v = kwargs[name]
+                setattr(cams, name, v.to(self.device) if isinstance(v, torch.Tensor) else v)
+        st = self.render_settings
+        image_size = st['image_size']
+
+        verts, sigmas, _radians = gmeshes()
+        sigmas = expend_sigma(sigmas)
+        if verts.dim() == 2:
+            verts = verts[None]
+
+        rays, origin = pixel_rays(cams, image_size, rows=kwargs.get('rows'))     # [B,h,W,3], [B,3]
+        centred = verts - origin[:, None]                                         # Renderer.py:130
+        if sigmas.dim() == 3:
+            sigmas = sigmas.unsqueeze(0).expand(centred.shape[0], -1, -1, -1)
+        isigma = 2 * torch.inverse(sigmas) if st['inverse_sigma'] else 2 * sigmas
+
+        sel_idx, sel_len, sel_act, sel_dsd = ray_tracing(
+            cams, centred, isigma, rays, image_size, thr=st['thr_activation'], n_assign=st['max_assign'],
+            max_points_per_bin=st['max_point_per_bin'])
+        # the trace output is fresh memory owned by this call, so the reference's defensive
+        # sel_idx.clone() (Renderer.py:145, because merge_final mutates indices) is not needed
+        weight, index, valid_num, hit_len = aggregation(sel_idx=sel_idx, sel_act=sel_act, sel_len=sel_len,
+                                                        sel_dsd=sel_dsd, occupation_weight=st['absorptivity'])
+        return Fragments(vert_weight=weight, vert_index=index, valid_num=valid_num, vert_hit_length=hit_len)
+
+
+def interpolate_attr(fragments: Fragments, vert_attr: torch.Tensor):
+    return merge_final(vert_attr=vert_attr, weight=fragments.vert_weight, valid_num=fragments.valid_num,
+                       vert_assign=fragments.vert_index)
+
+
+def get_silhouette(fragments: Fragments):
+    return ops.silhouette(fragments.vert_weight)
+
+
+def to_colored_background(fragments: Fragments, colors: torch.Tensor,
+                          background_color: Union[torch.Tensor, tuple, list] = (1, 1, 1), thr: float = -1):
+    if not torch.is_tensor(background_color):
+        background_color = torch.tensor(list(background_color), dtype=torch.float32, device=colors.device)
+    rgb = interpolate_attr(fragments, colors)
+    return ops.blend(rgb, fragments.vert_weight, background_color.to(colors.device), thr)
+
+
+def to_white_background(fragments: Fragments, colors: torch.Tensor, thr: float = -1):
+    return to_colored_background(fragments=fragments, colors=colors, background_color=(1, 1, 1), thr=thr)

@@ -1,0 +1,76 @@
+"""ctypes binding of libvoge_hip.so (the C ABI declared in include/voge_hip.h).
+
+There is exactly one implementation of the hot path: the HIP library.  If it cannot be
+loaded, or a tensor is not on a HIP device, the ops raise -- there is no CPU fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvoge_hip.so")
+ABI_VERSION = 1
+
+_c_void_p = ctypes.c_void_p
+_c_int = ctypes.c_int
+_c_long = ctypes.c_long
+_c_float = ctypes.c_float
+_c_size_t = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/voge_hip.h one to one
+SIGNATURES = {
+    "voge_abi_version": (_c_int, []),
+    "voge_error_string": (ctypes.c_char_p, [_c_int]),
+    "voge_trace_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "voge_trace_topk_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_float, _c_void_p, _c_size_t]
+                            + [_c_void_p] * 5),
+    "voge_trace_topk_list_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 9 + [_c_float] + [_c_void_p] * 5),
+    "voge_trace_bwd": (_c_int, [_c_void_p] * 7 + [_c_int, _c_long, _c_int] + [_c_void_p] * 4),
+    "voge_composite_fwd": (_c_int, [_c_void_p] * 4 + [_c_float, _c_long, _c_int] + [_c_void_p] * 3),
+    "voge_composite_bwd": (_c_int, [_c_void_p] * 4 + [_c_float, _c_long, _c_int] + [_c_void_p] * 4),
+    "voge_merge_fwd": (_c_int, [_c_void_p] * 4 + [_c_long, _c_int, _c_int, _c_long, _c_int] + [_c_void_p] * 2),
+    "voge_merge_bwd": (_c_int, [_c_void_p] * 5 + [_c_long, _c_int, _c_int, _c_long] + [_c_void_p] * 3),
+    "voge_blend_fwd": (_c_int, [_c_void_p] * 3 + [_c_float, _c_long, _c_int, _c_int] + [_c_void_p] * 3),
+    "voge_blend_bwd": (_c_int, [_c_void_p] * 3 + [_c_float, _c_void_p, _c_long, _c_int, _c_int] + [_c_void_p] * 3),
+}
+
+_lib = None
+
+
+class VogeHipError(RuntimeError):
+    """Raised when libvoge_hip.so is missing or one of its entry points returns non-zero
+    (the reference raises RuntimeError through AT_CUDA_CHECK, ray_trace_voge.cu:278)."""
+
+
+def load():
+    """dlopen libvoge_hip.so and type its entry points.  Raises VogeHipError if the library is
+    absent -- build it with `python -c 'import __graft_entry__ as g; g.build()'` or
+    `make -C voge_amd/csrc`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VogeHipError(
+            f"{LIB_PATH} not found: the VoGE hot path has no CPU fallback. "
+            "Build the HIP library with `make -C voge_amd/csrc` (hipcc, gfx950).")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise VogeHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise VogeHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.voge_abi_version()
+    if got != ABI_VERSION:
+        raise VogeHipError(f"libvoge_hip.so ABI {got} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().voge_error_string(code).decode()
+        raise VogeHipError(f"{what} failed with code {code}: {msg}")

@@ -1,0 +1,131 @@
+"""Camera shim + ray generation for the VoGE hot path.
+
+The reference takes PyTorch3D camera objects and calls
+`NDCMultinomialRaysampler(..., unit_directions=True)(cameras)` (VoGE/Renderer.py:124-128).
+PyTorch3D is an un-vendored dependency that is absent from this image, so this module
+provides (a) `pixel_rays`, which produces the same bundle from ANY object exposing
+`R [B,3,3]`, `T [B,3]`, `focal_length`, `principal_point` (real PyTorch3D screen-space
+`PerspectiveCameras` included, by duck typing), and (b) a minimal `PerspectiveCameras` /
+`look_at_view_transform` pair with PyTorch3D's conventions so the demo scripts' camera code
+has something to import where PyTorch3D is not installed.
+
+Conventions (PyTorch3D, screen space, in_ndc=False): row vectors, X_view = X_world @ R + T;
+view axes +X left, +Y up, +Z forward; pixel (row i, col j) centre <-> view direction
+[(px - j - 0.5)/fx, (py - i - 0.5)/fy, 1]; rays leave the camera centre C = -T @ R^-1.
+Everything is differentiable torch (gradients reach R, T, focal_length, principal_point).
+"""
+import math
+
+import torch
+
+
+def _as_b2(v, B, device, dtype=torch.float32):
+    v = torch.as_tensor(v, dtype=dtype, device=device)
+    if v.dim() == 0:
+        v = v.reshape(1, 1)
+    elif v.dim() == 1:
+        v = v.reshape(1, -1) if v.shape[0] == 2 else v.reshape(-1, 1)
+    if v.shape[-1] == 1:
+        v = v.expand(-1, 2)
+    if v.shape[0] != B:
+        v = v.expand(B, 2)
+    return v
+
+
+class PerspectiveCameras:
+    """Screen-space pinhole cameras: the subset of pytorch3d.renderer.PerspectiveCameras the
+    renderer and the demos touch (attributes R, T, focal_length, principal_point, image_size,
+    device; in_ndc(); to(); get_camera_center())."""
+
+    def __init__(self, focal_length=1.0, principal_point=((0.0, 0.0),), R=None, T=None, device="cpu",
+                 in_ndc=False, image_size=None):
+        self.device = torch.device(device)
+        self.R = torch.eye(3)[None] if R is None else torch.as_tensor(R, dtype=torch.float32).reshape(-1, 3, 3)
+        self.T = torch.zeros(1, 3) if T is None else torch.as_tensor(T, dtype=torch.float32).reshape(-1, 3)
+        B = max(self.R.shape[0], self.T.shape[0])
+        self.focal_length = _as_b2(focal_length, 1, "cpu") if not torch.is_tensor(focal_length) else focal_length
+        self.principal_point = _as_b2(principal_point, 1, "cpu") if not torch.is_tensor(principal_point) else principal_point
+        self.image_size = None if image_size is None else torch.as_tensor(image_size).reshape(-1, 2)
+        self._in_ndc = bool(in_ndc)
+        self._B = B
+        self.to(self.device)
+
+    def in_ndc(self):
+        return self._in_ndc
+
+    def __len__(self):
+        return max(self.R.shape[0], self.T.shape[0])
+
+    def to(self, device):
+        self.device = torch.device(device)
+        for name in ("R", "T", "focal_length", "principal_point", "image_size"):
+            v = getattr(self, name)
+            if torch.is_tensor(v):
+                setattr(self, name, v.to(self.device))
+        return self
+
+    def get_camera_center(self):
+        R = self.R
+        return -torch.einsum("bj,bjk->bk", self.T.expand(R.shape[0], 3), torch.linalg.inv(R))
+
+
+def pixel_rays(cameras, image_size, rows=None):
+    """Unit world-space ray directions [B,h,W,3] for pixel rows `rows=(r0,r1)` (default: all H
+    rows) and the camera centres [B,3]: what Renderer.py:124-128 reads from the ray bundle."""
+    H, W = int(image_size[0]), int(image_size[1])
+    R = cameras.R
+    device = R.device
+    R = R.to(torch.float32).reshape(-1, 3, 3)
+    T = torch.as_tensor(cameras.T, dtype=torch.float32, device=device).reshape(-1, 3)
+    B = max(R.shape[0], T.shape[0])
+    R = R.expand(B, 3, 3)
+    T = T.expand(B, 3)
+    f = _as_b2(cameras.focal_length, B, device)
+    pp = _as_b2(cameras.principal_point, B, device)
+    r0, r1 = (0, H) if rows is None else (int(rows[0]), int(rows[1]))
+    ii = torch.arange(r0, r1, device=device, dtype=torch.float32) + 0.5
+    jj = torch.arange(W, device=device, dtype=torch.float32) + 0.5
+    x = (pp[:, 0, None] - jj[None, :]) / f[:, 0, None]            # [B,W]
+    y = (pp[:, 1, None] - ii[None, :]) / f[:, 1, None]            # [B,h]
+    dv = torch.stack([x[:, None, :].expand(B, r1 - r0, W), y[:, :, None].expand(B, r1 - r0, W),
+                      torch.ones((B, r1 - r0, W), device=device)], dim=-1)
+    Rinv = torch.linalg.inv(R)
+    dw = torch.einsum("bhwj,bjk->bhwk", dv, Rinv)
+    dw = dw / dw.norm(dim=-1, keepdim=True)
+    centre = -torch.einsum("bj,bjk->bk", T, Rinv)
+    return dw, centre
+
+
+def camera_position_from_spherical_angles(distance, elevation, azimuth, degrees=True, device="cpu"):
+    d, e, a = torch.broadcast_tensors(*(torch.as_tensor(v, dtype=torch.float32, device=device).reshape(-1)
+                                        for v in (distance, elevation, azimuth)))
+    if degrees:
+        e, a = e * (math.pi / 180.0), a * (math.pi / 180.0)
+    return torch.stack([d * torch.cos(e) * torch.sin(a), d * torch.sin(e), d * torch.cos(e) * torch.cos(a)], dim=-1)
+
+
+def look_at_rotation(camera_position, at=((0, 0, 0),), up=((0, 1, 0),), device="cpu"):
+    C = torch.as_tensor(camera_position, dtype=torch.float32, device=device).reshape(-1, 3)
+    at = torch.as_tensor(at, dtype=torch.float32, device=device).reshape(-1, 3).expand(C.shape[0], 3)
+    up = torch.as_tensor(up, dtype=torch.float32, device=device).reshape(-1, 3).expand(C.shape[0], 3)
+    nrm = lambda v: torch.nn.functional.normalize(v, eps=1e-5, dim=-1)
+    z = nrm(at - C)
+    x = nrm(torch.cross(up, z, dim=1))
+    y = nrm(torch.cross(z, x, dim=1))
+    degenerate = torch.isclose(x, torch.zeros_like(x), atol=5e-3).all(dim=1, keepdim=True)
+    x = torch.where(degenerate, nrm(torch.cross(y, z, dim=1)), x)
+    return torch.stack([x, y, z], dim=-1)  # x, y, z as columns
+
+
+def look_at_view_transform(dist=1.0, elev=0.0, azim=0.0, degrees=True, eye=None, at=((0, 0, 0),),
+                           up=((0, 1, 0),), device="cpu"):
+    """(R [B,3,3], T [B,3]) with PyTorch3D's spherical convention:
+    C = dist*[cos(e)sin(a), sin(e), cos(e)cos(a)] + at,  T = -R^T C."""
+    if eye is not None:
+        C = torch.as_tensor(eye, dtype=torch.float32, device=device).reshape(-1, 3)
+    else:
+        C = camera_position_from_spherical_angles(dist, elev, azim, degrees=degrees, device=device)
+        C = C + torch.as_tensor(at, dtype=torch.float32, device=device).reshape(-1, 3)
+    R = look_at_rotation(C, at=at, up=up, device=device)
+    T = -torch.bmm(R.transpose(1, 2), C[:, :, None])[:, :, 0]
+    return R, T

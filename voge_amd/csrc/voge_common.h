@@ -1,0 +1,163 @@
+// Shared device helpers for libvoge_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "voge_hip.h"
+
+#define VOGE_WAVE 64
+
+// Sentinels of the fine trace outputs (ray_trace_voge.cu:244-247).
+#define VOGE_SENT_LEN 1e10f
+#define VOGE_SENT_ACT 1e10f
+
+namespace voge {
+
+// ---- per-Gaussian derived records (written by prep_kernel, read by the sweep) ----------
+// cull  : centre (camera-centred, the fp32 `mus` row) + conservative reach R: a ray whose
+//         line passes farther than R from the centre cannot satisfy act < thr_act.
+//         R = +inf -> never cull; R < 0 -> never a candidate (behind-camera skip).
+// eval  : coefficients of the three quadratic forms, arranged so that one (ray, Gaussian)
+//         pair costs ~30 flops and is free of the reference formula's cancellation:
+//           dsd = s00 dx^2 + s11 dy^2 + s22 dz^2 + s01 dx dy + s02 dx dz + s12 dy dz
+//                 (sXY = A_XY + A_YX, i.e. exactly d^T A d for any 3x3 A)
+//           len = (b . d) / dsd,  b = A^T mu            (== mu^T A d / d^T A d)
+//           v   = mu - len * d                            (fma: one rounding per component)
+//           act = v^T A v + len * (k . d),  k = (A - A^T) mu
+//                 (== mu^T A mu - (mu^T A d)^2 / dsd identically; k = 0 for symmetric A)
+struct EvalRec {
+  float s00, s11, s22, s01, s02, s12;
+  float bx, by, bz;
+  float kx, ky, kz;
+};
+static_assert(sizeof(EvalRec) == 48, "EvalRec must be 3 x float4");
+
+struct PairOut {
+  float len, act, dsd;
+};
+
+// One (ray, Gaussian) evaluation.  q* are the ray's quadratic features (dx*dx, ... dy*dz).
+// Written with explicit fmaf so that every call site (sweep, epilogue, list kernel) produces
+// bit-identical results; the library is built with -ffp-contract=off.
+__device__ __forceinline__ PairOut pair_eval(const float mx, const float my, const float mz,
+                                             const EvalRec &e, const float dx, const float dy,
+                                             const float dz, const float qxx, const float qyy,
+                                             const float qzz, const float qxy, const float qxz,
+                                             const float qyz) {
+  PairOut o;
+  float ksk = e.s00 * qxx;
+  ksk = fmaf(e.s11, qyy, ksk);
+  ksk = fmaf(e.s22, qzz, ksk);
+  ksk = fmaf(e.s01, qxy, ksk);
+  ksk = fmaf(e.s02, qxz, ksk);
+  ksk = fmaf(e.s12, qyz, ksk);
+  float msk = e.bx * dx;
+  msk = fmaf(e.by, dy, msk);
+  msk = fmaf(e.bz, dz, msk);
+  const float t = msk / ksk + 0.0f;  // +0 canonicalises -0
+  const float vx = fmaf(-t, dx, mx);
+  const float vy = fmaf(-t, dy, my);
+  const float vz = fmaf(-t, dz, mz);
+  float a = e.s00 * (vx * vx);
+  a = fmaf(e.s11, vy * vy, a);
+  a = fmaf(e.s22, vz * vz, a);
+  a = fmaf(e.s01, vx * vy, a);
+  a = fmaf(e.s02, vx * vz, a);
+  a = fmaf(e.s12, vy * vz, a);
+  float kd = e.kx * dx;
+  kd = fmaf(e.ky, dy, kd);
+  kd = fmaf(e.kz, dz, kd);
+  a = fmaf(t, kd, a);
+  o.len = t;
+  o.act = a;
+  o.dsd = ksk;
+  return o;
+}
+
+// Derive the eval record from raw (mu, A).  Same code in prep_kernel and the list kernel.
+__device__ __forceinline__ EvalRec make_eval(const float mx, const float my, const float mz,
+                                             const float *A) {
+  EvalRec e;
+  e.s00 = A[0];
+  e.s11 = A[4];
+  e.s22 = A[8];
+  e.s01 = A[1] + A[3];
+  e.s02 = A[2] + A[6];
+  e.s12 = A[5] + A[7];
+  e.bx = fmaf(A[6], mz, fmaf(A[3], my, A[0] * mx));
+  e.by = fmaf(A[7], mz, fmaf(A[4], my, A[1] * mx));
+  e.bz = fmaf(A[8], mz, fmaf(A[5], my, A[2] * mx));
+  e.kx = fmaf(A[2] - A[6], mz, (A[1] - A[3]) * my);
+  e.ky = fmaf(A[5] - A[7], mz, (A[3] - A[1]) * mx);
+  e.kz = fmaf(A[7] - A[5], my, (A[6] - A[2]) * mx);
+  return e;
+}
+
+// Monotone map float -> uint32 (all non-NaN values; -0 must be canonicalised by the caller).
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return u ^ (uint32_t)(((int32_t)u >> 31) | 0x80000000);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  const uint32_t u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
+  return __uint_as_float(u);
+}
+
+// Per-lane sorted top-K list of 64-bit keys (ord(len) << 32 | idx) in LDS, slot s of the
+// calling thread at keys[s * stride].  Precondition: key < worst (worst = ~0 while cnt < K).
+// Implements "K lexicographically smallest (len, idx)", which is what the reference's
+// in-place insertion (ray_trace_voge.cu:197-212: strict '<', candidates in ascending index)
+// computes.
+__device__ __forceinline__ void topk_insert(uint64_t *keys, const int stride, const int K,
+                                            int &cnt, uint64_t &worst, const uint64_t key) {
+  int pos = (cnt < K) ? cnt : K - 1;
+  while (pos > 0) {
+    const uint64_t prev = keys[(pos - 1) * stride];
+    if (prev <= key) break;
+    keys[pos * stride] = prev;
+    --pos;
+  }
+  keys[pos * stride] = key;
+  if (cnt < K) ++cnt;
+  if (cnt == K) worst = keys[(K - 1) * stride];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// A bounding cone of a set of unit directions: axis a, cos/sin of the half angle with the
+// rounding pushed to the conservative side.  ok == false -> cone too wide / degenerate,
+// nothing may be culled against it.
+struct Cone {
+  float ax, ay, az, cs, sn;
+  bool ok;
+};
+
+// Conservative "this Gaussian cannot be hit by any line through the origin whose direction
+// lies in the cone".  c = (centre, reach).  Distance from the centre to the double cone is
+// >= q*cos - |p|*sin (p, q = axial / radial parts of the centre).
+__device__ __forceinline__ bool cone_keep(const float4 c, const Cone &k) {
+  if (c.w < 0.0f) return false;
+  const float p = fmaf(c.z, k.az, fmaf(c.y, k.ay, c.x * k.ax));
+  const float rx = fmaf(-p, k.ax, c.x), ry = fmaf(-p, k.ay, c.y), rz = fmaf(-p, k.az, c.z);
+  const float q = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx * rx)));
+  const float gap = fmaf(q, k.cs, -fabsf(p) * k.sn);
+  return !k.ok || !(gap > c.w);
+}
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+}  // namespace voge

@@ -1,0 +1,284 @@
+"""torch.autograd wrappers around the C ABI (include/voge_hip.h).
+
+torch is used here for device memory, streams and autograd bookkeeping only; every
+computation on the path is a HIP kernel in libvoge_hip.so.  Ownership follows SURVEY.md §8b:
+the caller (these Functions) allocates every output; the library never allocates.
+"""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype, name):
+    """Validate a tensor argument the way the C side cannot: device, dtype, contiguity."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise _lib.VogeHipError(
+            f"{name} is on {t.device}: the VoGE hot path runs on a HIP device only (no CPU fallback)")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class _RayTraceVoGE(torch.autograd.Function):
+    """Mirror of VoGE/RayTracing.py:154-206 (`_RayTraceVoGE`).
+
+    forward(mus [P,3], isigmas [P,3,3], rays [B,H,W,3], bin_points, thr_act, bin_size, n_assign)
+    -> sel_idx int32, sel_len, sel_act, sel_dsd, each [B,H,W,K].
+    bin_points: None -> every Gaussian of the batch element is a candidate (the
+    max_points_per_bin == -1 list of RayTracing.py:22-26, never materialised); a tensor
+    [B,BH,BW,M] -> explicit candidate lists as in the reference; a tensor [B,3] of dtype
+    float -> "all candidates in front of the camera" (view axis per batch element).
+    """
+
+    @staticmethod
+    def forward(ctx, mus, isigmas, rays, bin_points, thr_act, bin_size, n_assign):
+        lib = _lib.load()
+        mus_c = _dev(mus, torch.float32, "mus")
+        isg_c = _dev(isigmas, torch.float32, "isigmas")
+        rays_c = _dev(rays, torch.float32, "rays")
+        assert mus_c.dim() == 2 and mus_c.shape[1] == 3
+        assert isg_c.dim() == 3 and isg_c.shape[1:] == (3, 3) and isg_c.shape[0] == mus_c.shape[0]
+        assert rays_c.dim() == 4 and rays_c.shape[3] == 3
+        B, H, W, _ = rays_c.shape
+        P = mus_c.shape[0]
+        K = int(n_assign)
+        dev = rays_c.device
+        sel_idx = torch.empty((B, H, W, K), dtype=torch.int32, device=dev)
+        sel_len = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
+        sel_act = torch.empty_like(sel_len)
+        sel_dsd = torch.empty_like(sel_len)
+        with torch.cuda.device(dev):
+            if bin_points is not None and bin_points.dtype in (torch.int32, torch.int64):
+                bins = _dev(bin_points, torch.int32, "bin_points")
+                assert bins.dim() == 4 and bins.shape[0] == B
+                rc = lib.voge_trace_topk_list_fwd(
+                    _p(mus_c), _p(isg_c), _p(rays_c), _p(bins), B, P, H, W, K, bins.shape[1], bins.shape[2],
+                    bins.shape[3], int(bin_size), float(thr_act), _p(sel_idx), _p(sel_len), _p(sel_act),
+                    _p(sel_dsd), _stream())
+                _lib.check(rc, "voge_trace_topk_list_fwd")
+            else:
+                assert B > 0 and P % B == 0, "mus must hold B*N rows"
+                N = P // B
+                fwd = None if bin_points is None else _dev(bin_points, torch.float32, "cam_fwd")
+                nbytes = lib.voge_trace_workspace_bytes(B, N)
+                ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+                rc = lib.voge_trace_topk_fwd(
+                    _p(mus_c), _p(isg_c), _p(rays_c), _p(fwd), B, N, H, W, K, float(thr_act), _p(ws), nbytes,
+                    _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _stream())
+                _lib.check(rc, "voge_trace_topk_fwd")
+        ctx.save_for_backward(mus_c, isg_c, rays_c, sel_idx)
+        ctx.mark_non_differentiable(sel_idx)
+        return sel_idx, sel_len, sel_act, sel_dsd
+
+    @staticmethod
+    def backward(ctx, grad_sel_idx, grad_sel_len, grad_sel_act, grad_sel_dsd):
+        lib = _lib.load()
+        mus, isg, rays, sel_idx = ctx.saved_tensors
+        B, H, W, K = sel_idx.shape
+        P = mus.shape[0]
+        zeros = None
+
+        def g(t):
+            nonlocal zeros
+            if t is None:
+                if zeros is None:
+                    zeros = torch.zeros(sel_idx.shape, dtype=torch.float32, device=sel_idx.device)
+                return zeros
+            return _dev(t, torch.float32, "grad")
+        gl, ga, gd = g(grad_sel_len), g(grad_sel_act), g(grad_sel_dsd)
+        g_ray = torch.empty_like(rays)
+        g_mus = torch.empty_like(mus)
+        g_isg = torch.empty_like(isg)
+        with torch.cuda.device(rays.device):
+            rc = lib.voge_trace_bwd(_p(mus), _p(isg), _p(rays), _p(sel_idx), _p(gl), _p(ga), _p(gd), P,
+                                    B * H * W, K, _p(g_ray), _p(g_mus), _p(g_isg), _stream())
+        _lib.check(rc, "voge_trace_bwd")
+        return g_mus, g_isg, g_ray, None, None, None, None
+
+
+class _Composite(torch.autograd.Function):
+    """Fused replacement of get_cross_activation + assign2weight (VoGE/Aggregation.py:30-79)
+    and of their autograd backward.  (sel_idx, sel_act, sel_len, sel_dsd, occ) -> weight, valid_num."""
+
+    @staticmethod
+    def forward(ctx, sel_idx, sel_act, sel_len, sel_dsd, occ):
+        lib = _lib.load()
+        idx = _dev(sel_idx, torch.int32, "sel_idx")
+        act = _dev(sel_act, torch.float32, "sel_act")
+        ln = _dev(sel_len, torch.float32, "sel_len")
+        dsd = _dev(sel_dsd, torch.float32, "sel_dsd")
+        K = idx.shape[-1]
+        npix = idx.numel() // max(K, 1)
+        weight = torch.empty_like(act)
+        valid = torch.empty(idx.shape[:-1], dtype=torch.int64, device=idx.device)
+        with torch.cuda.device(idx.device):
+            rc = lib.voge_composite_fwd(_p(idx), _p(act), _p(ln), _p(dsd), float(occ), npix, K, _p(weight),
+                                        _p(valid), _stream())
+        _lib.check(rc, "voge_composite_fwd")
+        ctx.save_for_backward(act, ln, dsd)
+        ctx.occ = float(occ)
+        ctx.mark_non_differentiable(valid)
+        return weight, valid
+
+    @staticmethod
+    def backward(ctx, g_weight, _g_valid):
+        lib = _lib.load()
+        act, ln, dsd = ctx.saved_tensors
+        K = act.shape[-1]
+        npix = act.numel() // max(K, 1)
+        gw = _dev(g_weight, torch.float32, "grad_weight")
+        g_act = torch.empty_like(act)
+        g_len = torch.empty_like(act)
+        g_dsd = torch.empty_like(act)
+        with torch.cuda.device(act.device):
+            rc = lib.voge_composite_bwd(_p(act), _p(ln), _p(dsd), _p(gw), ctx.occ, npix, K, _p(g_act), _p(g_len),
+                                        _p(g_dsd), _stream())
+        _lib.check(rc, "voge_composite_bwd")
+        return None, g_act, g_len, g_dsd, None
+
+
+class _Merge(torch.autograd.Function):
+    """merge_final (VoGE/Aggregation.py:111-141): (attr [N,C], weight, idx, valid_num) -> [..., C].
+    Mutates idx in place (-1 -> 0) exactly like the reference (:131)."""
+
+    @staticmethod
+    def forward(ctx, attr, weight, idx, valid_num):
+        lib = _lib.load()
+        attr_c = _dev(attr, torch.float32, "vert_attr")
+        w = _dev(weight, torch.float32, "weight")
+        if not (idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()):
+            raise _lib.VogeHipError("vert_index must be a contiguous int32 tensor on the HIP device")
+        vn = _dev(valid_num, torch.int64, "valid_num")
+        K = idx.shape[-1]
+        npix = idx.numel() // max(K, 1)
+        Nattr, C = attr_c.shape
+        out = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
+        with torch.cuda.device(idx.device):
+            rc = lib.voge_merge_fwd(_p(attr_c), _p(idx), _p(w), _p(vn), npix, K, C, Nattr, 1, _p(out), _stream())
+        _lib.check(rc, "voge_merge_fwd")
+        ctx.save_for_backward(attr_c, w, idx, vn)
+        ctx.mark_dirty(idx)
+        ctx.needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return out, idx
+
+    @staticmethod
+    def backward(ctx, g_out, _g_idx):
+        lib = _lib.load()
+        attr, w, idx, vn = ctx.saved_tensors
+        K = idx.shape[-1]
+        npix = idx.numel() // max(K, 1)
+        Nattr, C = attr.shape
+        go = _dev(g_out, torch.float32, "grad_out")
+        g_attr = torch.empty_like(attr) if ctx.needs[0] else None
+        g_w = torch.empty_like(w) if ctx.needs[1] else None
+        with torch.cuda.device(idx.device):
+            rc = lib.voge_merge_bwd(_p(attr), _p(idx), _p(w), _p(vn), _p(go), npix, K, C, Nattr, _p(g_attr), _p(g_w),
+                                    _stream())
+        _lib.check(rc, "voge_merge_bwd")
+        return g_attr, g_w, None, None
+
+
+class _Blend(torch.autograd.Function):
+    """get_silhouette + to_colored_background (VoGE/Renderer.py:157-171)."""
+
+    @staticmethod
+    def forward(ctx, rgb, weight, bg, thr):
+        lib = _lib.load()
+        rgb_c = _dev(rgb, torch.float32, "rgb")
+        w = _dev(weight, torch.float32, "weight")
+        bg_c = _dev(bg, torch.float32, "background_color")
+        K = w.shape[-1]
+        C = rgb_c.shape[-1]
+        npix = w.numel() // max(K, 1)
+        assert bg_c.numel() == C and rgb_c.numel() == npix * C
+        out = torch.empty_like(rgb_c)
+        with torch.cuda.device(w.device):
+            rc = lib.voge_blend_fwd(_p(rgb_c), _p(w), _p(bg_c), float(thr), npix, K, C, _p(out), None, _stream())
+        _lib.check(rc, "voge_blend_fwd")
+        ctx.save_for_backward(rgb_c, w, bg_c)
+        ctx.thr = float(thr)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        rgb, w, bg = ctx.saved_tensors
+        K = w.shape[-1]
+        C = rgb.shape[-1]
+        npix = w.numel() // max(K, 1)
+        go = _dev(g_out, torch.float32, "grad_out")
+        g_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[0] else None
+        g_w = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(w.device):
+            rc = lib.voge_blend_bwd(_p(rgb), _p(w), _p(bg), ctx.thr, _p(go), npix, K, C, _p(g_rgb), _p(g_w), _stream())
+        _lib.check(rc, "voge_blend_bwd")
+        return g_rgb, g_w, None, None
+
+
+class _Silhouette(torch.autograd.Function):
+    """get_silhouette (VoGE/Renderer.py:157-159): min(sum_k w_k, 1), via the blend kernels with a
+    zero background and a one-channel zero image (out is discarded, sil_out is the result)."""
+
+    @staticmethod
+    def forward(ctx, weight):
+        lib = _lib.load()
+        w = _dev(weight, torch.float32, "weight")
+        K = w.shape[-1]
+        npix = w.numel() // max(K, 1)
+        sil = torch.empty(w.shape[:-1], dtype=torch.float32, device=w.device)
+        zero = torch.zeros(w.shape[:-1] + (1,), dtype=torch.float32, device=w.device)
+        bg = torch.zeros((1,), dtype=torch.float32, device=w.device)
+        scratch = torch.empty_like(zero)
+        with torch.cuda.device(w.device):
+            rc = lib.voge_blend_fwd(_p(zero), _p(w), _p(bg), -1.0, npix, K, 1, _p(scratch), _p(sil), _stream())
+        _lib.check(rc, "voge_blend_fwd")
+        ctx.save_for_backward(w)
+        return sil
+
+    @staticmethod
+    def backward(ctx, g_sil):
+        lib = _lib.load()
+        (w,) = ctx.saved_tensors
+        K = w.shape[-1]
+        npix = w.numel() // max(K, 1)
+        # d sil / d w_k = [sum w < 1]: reuse blend_bwd with rgb = 0, bg = -1, one channel:
+        # out = min(0 + (1 - sil) * (-1), 1) -> g_mask = +g_out, g_w = g_out * pass(sum w)
+        zero = torch.zeros(w.shape[:-1] + (1,), dtype=torch.float32, device=w.device)
+        bg = torch.full((1,), -1.0, dtype=torch.float32, device=w.device)
+        go = _dev(g_sil, torch.float32, "grad_sil").reshape(zero.shape).contiguous()
+        g_w = torch.empty_like(w)
+        with torch.cuda.device(w.device):
+            rc = lib.voge_blend_bwd(_p(zero), _p(w), _p(bg), -1.0, _p(go), npix, K, 1, None, _p(g_w), _stream())
+        _lib.check(rc, "voge_blend_bwd")
+        return g_w
+
+
+def ray_trace_fine(mus, isigmas, rays, bin_points, thr_act, bin_size, n_assign):
+    return _RayTraceVoGE.apply(mus, isigmas, rays, bin_points, thr_act, bin_size, n_assign)
+
+
+def composite(sel_idx, sel_act, sel_len, sel_dsd, occ=1.0):
+    return _Composite.apply(sel_idx, sel_act, sel_len, sel_dsd, occ)
+
+
+def merge(attr, weight, idx, valid_num):
+    out, _ = _Merge.apply(attr, weight, idx, valid_num)
+    return out
+
+
+def blend(rgb, weight, bg, thr=-1.0):
+    return _Blend.apply(rgb, weight, bg, thr)
+
+
+def silhouette(weight):
+    return _Silhouette.apply(weight)
