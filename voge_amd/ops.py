@@ -166,15 +166,19 @@ class _Merge(torch.autograd.Function):
         with torch.cuda.device(idx.device):
             rc = lib.voge_merge_fwd(_p(attr_c), _p(idx), _p(w), _p(vn), npix, K, C, Nattr, 1, _p(out), _stream())
         _lib.check(rc, "voge_merge_fwd")
-        ctx.save_for_backward(attr_c, w, idx, vn)
-        ctx.mark_dirty(idx)
+        # idx is an int tensor outside autograd; it is kept as a plain attribute because the in-place
+        # fix (-1 -> 0) may be re-applied by later merges of the same fragments.  The backward masks by
+        # valid_num and reads a negative index as 0, so it is insensitive to whether the fix has run.
+        ctx.save_for_backward(attr_c, w, vn)
+        ctx.idx = idx
         ctx.needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return out, idx
+        return out
 
     @staticmethod
-    def backward(ctx, g_out, _g_idx):
+    def backward(ctx, g_out):
         lib = _lib.load()
-        attr, w, idx, vn = ctx.saved_tensors
+        attr, w, vn = ctx.saved_tensors
+        idx = ctx.idx
         K = idx.shape[-1]
         npix = idx.numel() // max(K, 1)
         Nattr, C = attr.shape
@@ -272,8 +276,7 @@ def composite(sel_idx, sel_act, sel_len, sel_dsd, occ=1.0):
 
 
 def merge(attr, weight, idx, valid_num):
-    out, _ = _Merge.apply(attr, weight, idx, valid_num)
-    return out
+    return _Merge.apply(attr, weight, idx, valid_num)
 
 
 def blend(rgb, weight, bg, thr=-1.0):
