@@ -92,14 +92,16 @@ int voge_trace_topk_list_fwd(const float *mus, const float *isigmas, const float
 /*
  * Fine ray trace backward.
  * Replaces: VoGE._C.ray_trace_voge_fine_backward (ray_trace_voge.h:17-25,
- * ray_trace_voge.cu:283-379).  npix = B*H*W.  For every slot with idx >= 0 applies the
+ * ray_trace_voge.cu:283-379).  The pixel grid is given as nrows = B*H rows of W pixels (the
+ * kernel works on 16x16 pixel tiles of that grid).  For every slot with idx >= 0 applies the
  * chain rule of ray_trace_voge.cu:324-326 and scatters into
- *   g_ray [npix,3], g_mus [P,3], g_isg [P,3,3]  (raw outer products, not symmetrised).
- * The three outputs are zero-filled by this call (the reference allocates zeros, :354-356).
+ *   g_ray [nrows*W,3], g_mus [P,3], g_isg [P,3,3]  (raw outer products, not symmetrised).
+ * g_mus / g_isg are zero-filled by this call (the reference allocates zeros, :354-356);
+ * g_ray is fully written, or may be NULL when the ray gradient is not needed.
  */
 int voge_trace_bwd(const float *mus, const float *isigmas, const float *rays,
                    const int32_t *idx, const float *g_len, const float *g_act,
-                   const float *g_dsd, int P, long npix, int K, float *g_ray,
+                   const float *g_dsd, int P, long nrows, int W, int K, float *g_ray,
                    float *g_mus, float *g_isg, voge_stream_t stream);
 
 /*
@@ -132,13 +134,15 @@ int voge_merge_fwd(const float *attr, int32_t *idx, const float *weight,
                    int fix_negative_idx, float *out, voge_stream_t stream);
 
 /*
- * Attribute merge backward (autograd of merge_final): g_out [npix,C] ->
- * g_attr [Nattr,C] (zero-filled here, then scatter-added) and g_weight [npix,K].
+ * Attribute merge backward (autograd of merge_final): g_out [nrows*W,C] ->
+ * g_attr [Nattr,C] (zero-filled here, then scatter-added) and g_weight [nrows*W,K].
+ * The pixel grid is nrows rows of W pixels (any factorisation of the pixel count is valid;
+ * the true image width gives the best locality).
  * Either output pointer may be NULL to skip it.
  */
 int voge_merge_bwd(const float *attr, const int32_t *idx, const float *weight,
-                   const int64_t *valid_num, const float *g_out, long npix, int K, int C,
-                   long Nattr, float *g_attr, float *g_weight, voge_stream_t stream);
+                   const int64_t *valid_num, const float *g_out, long nrows, int W, int K,
+                   int C, long Nattr, float *g_attr, float *g_weight, voge_stream_t stream);
 
 /*
  * Background blend forward.  Replaces: VoGE/Renderer.py:157-171

@@ -70,6 +70,82 @@ merge_bwd_kernel(const float *__restrict__ attr, const int32_t *__restrict__ idx
   }
 }
 
+// C <= 4 (colours): a workgroup owns a 16x16 pixel tile and accumulates the per-Gaussian
+// attribute gradient in an LDS hash table, flushed with one global atomic per (Gaussian,
+// channel) per tile (same scheme as trace_bwd_kernel).
+constexpr int kMT = 16, kMHS = 1024, kMProbe = 24;
+struct MergeBwdLds {
+  int keys[kMHS];
+  float vals[kMHS * 4];
+};
+
+__global__ void __launch_bounds__(256)
+merge_bwd_tile_kernel(const float *__restrict__ attr, const int32_t *__restrict__ idx,
+                      const float *__restrict__ weight, const int64_t *__restrict__ valid_num,
+                      const float *__restrict__ g_out, const long nrows, const int W, const int K,
+                      const int C, const long Nattr, float *__restrict__ g_attr,
+                      float *__restrict__ g_weight) {
+  __shared__ MergeBwdLds L;
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + kMT - 1) / kMT;
+  const int x0 = (blockIdx.x % tiles_x) * kMT;
+  const long y0 = (long)(blockIdx.x / tiles_x) * kMT;
+  const int tw = min(kMT, W - x0);
+  const int th = (int)min((long)kMT, nrows - y0);
+  for (int i = tid; i < kMHS; i += 256) L.keys[i] = -1;
+  for (int i = tid; i < kMHS * 4; i += 256) L.vals[i] = 0.0f;
+  __syncthreads();
+  const int row_items = tw * K;
+  for (int r = 0; r < th; ++r) {
+    const long row_base = ((y0 + r) * W + x0) * (long)K;
+    for (int it = tid; it < row_items; it += 256) {
+      const long t = row_base + it;
+      const int lx = it / K, k = it - lx * K;
+      const long pix = (y0 + r) * W + x0 + lx;
+      float gw = 0.0f;
+      if (k < valid_num[pix]) {
+        int p = idx[t];
+        p += (p < 0);
+        if (p >= 0 && p < Nattr) {
+          const float w = weight[t];
+          float ga[4] = {0.f, 0.f, 0.f, 0.f};
+          bool any = false;
+          for (int c = 0; c < C; ++c) {
+            const float gc = g_out[pix * C + c];
+            gw = fmaf(gc, attr[(size_t)p * C + c], gw);
+            ga[c] = w * gc;
+            any = any || (ga[c] != 0.0f);
+          }
+          if (g_attr != nullptr && any) {
+            unsigned h = ((unsigned)p * 2654435761u) >> 22;
+            int slot = -1;
+#pragma unroll 1
+            for (int pr = 0; pr < kMProbe; ++pr) {
+              const int old = atomicCAS(&L.keys[h], -1, p);
+              if (old == -1 || old == p) { slot = (int)h; break; }
+              h = (h + 1) & (kMHS - 1);
+            }
+            if (slot >= 0) {
+              for (int c = 0; c < C; ++c) atomicAdd(&L.vals[slot * 4 + c], ga[c]);
+            } else {
+              for (int c = 0; c < C; ++c) unsafeAtomicAdd(g_attr + (size_t)p * C + c, ga[c]);
+            }
+          }
+        }
+      }
+      if (g_weight != nullptr) g_weight[t] = gw;
+    }
+  }
+  __syncthreads();
+  if (g_attr != nullptr) {
+    for (int s = tid; s < kMHS; s += 256) {
+      const int p = L.keys[s];
+      if (p < 0) continue;
+      for (int c = 0; c < C; ++c) unsafeAtomicAdd(g_attr + (size_t)p * C + c, L.vals[s * 4 + c]);
+    }
+  }
+}
+
 // min(x, 1) passes the gradient where x < 1 and half of it at the tie, like torch.min.
 __device__ __forceinline__ float clamp1_pass(float x) { return x < 1.0f ? 1.0f : (x == 1.0f ? 0.5f : 0.0f); }
 
@@ -139,18 +215,25 @@ extern "C" int voge_merge_fwd(const float *attr, int32_t *idx, const float *weig
 }
 
 extern "C" int voge_merge_bwd(const float *attr, const int32_t *idx, const float *weight,
-                              const int64_t *valid_num, const float *g_out, long npix, int K, int C,
-                              long Nattr, float *g_attr, float *g_weight, voge_stream_t stream) {
-  if (npix < 0 || K <= 0 || C <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
+                              const int64_t *valid_num, const float *g_out, long nrows, int W, int K,
+                              int C, long Nattr, float *g_attr, float *g_weight, voge_stream_t stream) {
+  if (nrows < 0 || W < 0 || K <= 0 || C <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (g_attr != nullptr && Nattr > 0) {
     hipError_t e = hipMemsetAsync(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
     if (e != hipSuccess) return (int)e;
   }
+  const long npix = nrows * W;
   if (npix == 0) return 0;
   if (!idx || !weight || !valid_num || !g_out || (Nattr > 0 && !attr)) return VOGE_ERR_BAD_ARG;
-  hipLaunchKernelGGL(merge_bwd_kernel, dim3(grid_for(npix * K)), dim3(256), 0, st, attr, idx, weight, valid_num,
-                     g_out, npix, K, C, Nattr, g_attr, g_weight);
+  if (C <= 4) {
+    const long tiles = (long)((W + kMT - 1) / kMT) * ((nrows + kMT - 1) / kMT);
+    hipLaunchKernelGGL(merge_bwd_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, st, attr, idx, weight, valid_num,
+                       g_out, nrows, W, K, C, Nattr, g_attr, g_weight);
+  } else {
+    hipLaunchKernelGGL(merge_bwd_kernel, dim3(grid_for(npix * K)), dim3(256), 0, st, attr, idx, weight, valid_num,
+                       g_out, npix, K, C, Nattr, g_attr, g_weight);
+  }
   return launch_status();
 }
 

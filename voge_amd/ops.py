@@ -96,12 +96,12 @@ class _RayTraceVoGE(torch.autograd.Function):
                 return zeros
             return _dev(t, torch.float32, "grad")
         gl, ga, gd = g(grad_sel_len), g(grad_sel_act), g(grad_sel_dsd)
-        g_ray = torch.empty_like(rays)
+        g_ray = torch.empty_like(rays) if ctx.needs_input_grad[2] else None
         g_mus = torch.empty_like(mus)
         g_isg = torch.empty_like(isg)
         with torch.cuda.device(rays.device):
             rc = lib.voge_trace_bwd(_p(mus), _p(isg), _p(rays), _p(sel_idx), _p(gl), _p(ga), _p(gd), P,
-                                    B * H * W, K, _p(g_ray), _p(g_mus), _p(g_isg), _stream())
+                                    B * H, W, K, _p(g_ray), _p(g_mus), _p(g_isg), _stream())
         _lib.check(rc, "voge_trace_bwd")
         return g_mus, g_isg, g_ray, None, None, None, None
 
@@ -186,8 +186,9 @@ class _Merge(torch.autograd.Function):
         g_attr = torch.empty_like(attr) if ctx.needs[0] else None
         g_w = torch.empty_like(w) if ctx.needs[1] else None
         with torch.cuda.device(idx.device):
-            rc = lib.voge_merge_bwd(_p(attr), _p(idx), _p(w), _p(vn), _p(go), npix, K, C, Nattr, _p(g_attr), _p(g_w),
-                                    _stream())
+            Wd = idx.shape[-2] if idx.dim() >= 3 else npix
+            rc = lib.voge_merge_bwd(_p(attr), _p(idx), _p(w), _p(vn), _p(go), npix // max(Wd, 1), Wd, K, C, Nattr,
+                                    _p(g_attr), _p(g_w), _stream())
         _lib.check(rc, "voge_merge_bwd")
         return g_attr, g_w, None, None
 
