@@ -166,7 +166,7 @@ def main():
             lib = _lib.load()
             st = torch.cuda.current_stream().cuda_stream
             npix = H * W
-            ws = torch.empty(lib.voge_trace_workspace_bytes(1, N), dtype=torch.uint8, device=dev)
+            ws = torch.empty(lib.voge_trace_workspace_bytes(1, N, H, W), dtype=torch.uint8, device=dev)
             o_i, o_l, o_a, o_d = (torch.empty_like(x) for x in sel)
             g3 = [torch.empty_like(w) for _ in range(3)]
             g_ray, g_mu, g_A = torch.empty_like(rays), torch.empty_like(mus), torch.empty_like(isg)

@@ -47,10 +47,12 @@ int voge_abi_version(void);
 const char *voge_error_string(int code);
 
 /*
- * Bytes of scratch the forward trace needs for P = B*N Gaussians (per-Gaussian derived
- * records: cull sphere + quadratic-form coefficients).  Caller allocates, any alignment >= 16.
+ * Bytes of scratch the forward trace needs for B batch elements of N Gaussians and an HxW
+ * image: per-Gaussian derived records (cull sphere + quadratic-form coefficients, 64 B each)
+ * and the per-super-tile (64x64 px) depth-sorted candidate lists.  Caller allocates, 256-byte
+ * aligned (any torch allocation is).
  */
-size_t voge_trace_workspace_bytes(int B, int N);
+size_t voge_trace_workspace_bytes(int B, int N, int H, int W);
 
 /*
  * Fine ray trace forward, "all Gaussians are candidates" form.

@@ -77,39 +77,217 @@ __device__ __forceinline__ EvalRec unpack_eval(const float4 a, const float4 b, c
 }
 
 // ------------------------------------------------------------------------------------------
-// sweep.  One workgroup = WAVES waves = a TW x TH pixel tile (each wave an 8x8 sub-tile, one
-// ray per lane).  The Gaussian stream of batch b is read once per workgroup in chunks of T:
-//   fill   : thread i tests Gaussian base+i against the workgroup's bounding cone; survivors
-//            are compacted (in index order) into LDS with their eval record;
-//   consume: each wave re-tests the survivors against its own 8x8 cone, 64 at a time (one per
-//            lane, ballot), then for every remaining candidate all 64 lanes evaluate their
-//            ray against it (record broadcast from LDS) and insert into their LDS top-K list.
-// Both culls are conservative (cone_keep), so the result equals the brute-force sweep.
+// Bounding cone of a set of rays, workgroup-wide (used by the bin and the sweep kernels).
 // ------------------------------------------------------------------------------------------
-template <int CAP>  // survivors buffered in LDS between fill and consume
+struct RayDir {
+  float ux, uy, uz;
+  bool ok;      // finite, non-zero direction
+  bool unit;    // |d| == 1 within 1e-4 (the depth bound of the early exit assumes unit rays)
+};
+__device__ __forceinline__ RayDir ray_dir(const float dx, const float dy, const float dz) {
+  RayDir r;
+  const float dn2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  const float inv = 1.0f / sqrtf(dn2);
+  r.ok = (dn2 > 0.0f) && (inv < 3e38f) && (inv == inv);
+  r.unit = fabsf(dn2 - 1.0f) < 1e-4f;
+  r.ux = dx * inv; r.uy = dy * inv; r.uz = dz * inv;
+  return r;
+}
+// Partial (per-wave) extrema of one ray w.r.t. a given axis sum; finish with cone_finish().
+__device__ __forceinline__ void cone_partial(const RayDir &u, const float ax, const float ay, const float az,
+                                             float &smax, float &cmin) {
+  const float cl = fmaf(u.uz, az, fmaf(u.uy, ay, u.ux * ax));
+  const float rx = fmaf(-cl, ax, u.ux), ry = fmaf(-cl, ay, u.uy), rz = fmaf(-cl, az, u.uz);
+  const float sl = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx * rx)));
+  smax = fmaxf(smax, u.ok ? sl : 2.0f);
+  cmin = fminf(cmin, u.ok ? cl : -1.0f);
+}
+__device__ __forceinline__ Cone cone_finish(const float ax, const float ay, const float az, const float n,
+                                            const float smax, const float cmin, const bool all_ok) {
+  Cone c;
+  c.ax = ax; c.ay = ay; c.az = az;
+  c.sn = smax * (1.0f + 1e-5f) + 1e-7f;
+  c.cs = cmin - 1e-6f;
+  c.ok = all_ok && (n > 1e-3f) && (cmin > 0.05f) && (c.sn == c.sn);
+  return c;
+}
+
+// Lower bound of len = (mu^T A d)/(d^T A d) over every UNIT ray d of the cone that can hit the
+// Gaussian (i.e. whose line passes within `reach` of mu): len = mu.d - v.d with |v| <= reach.
+// In front of the camera mu.d >= sqrt(|mu|^2 - reach^2); otherwise only |len| <= |mu| + reach.
+__device__ __forceinline__ float len_lower_bound(const float4 c, const Cone &k) {
+  const float nm = sqrtf(fmaf(c.z, c.z, fmaf(c.y, c.y, c.x * c.x)));
+  const float R = c.w;
+  float lb = -(nm + R);
+  if (k.ok && k.cs >= 0.5f && nm > 4.0f * R) {
+    const float p = fmaf(c.z, k.az, fmaf(c.y, k.ay, c.x * k.ax));
+    if (p > 0.0f) lb = sqrtf(fmaxf(fmaf(nm, nm, -R * R), 0.0f)) - R;
+  }
+  lb -= fmaf(1e-5f, nm + R, 1e-30f);
+  return (lb == lb) ? lb : -INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------
+// bin: one 1024-thread workgroup per 64x64-pixel super-tile.  Tests every Gaussian of the
+// batch element against the super-tile's bounding cone (conservative), then sorts the
+// survivors by their len lower bound (bitonic, LDS) and writes the (id, bound) list.
+// More than kBinCap survivors -> count = -1 and the sweep falls back to the full stream.
+// ------------------------------------------------------------------------------------------
+constexpr int kST = 64;
+constexpr int kBinCap = 8192;
+constexpr int kBinThreads = 1024;
+
+struct BinLds {
+  uint64_t keys[kBinCap];
+  float red[16 * 4];
+  int count;
+};
+
+__device__ __forceinline__ void block_reduce16(float *red, const int wave, const int lane, float &a, float &b,
+                                               float &c, float &d, const int mode /*0 sum,1 max/min*/) {
+  // a,b,c: sum (mode 0) or a: max, b: min (mode 1); d: AND-flag as float
+  if (mode == 0) { a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); }
+  else { a = wave_max(a); b = wave_min(b); }
+  d = wave_min(d);
+  __syncthreads();
+  if (lane == 0) { red[wave * 4 + 0] = a; red[wave * 4 + 1] = b; red[wave * 4 + 2] = c; red[wave * 4 + 3] = d; }
+  __syncthreads();
+  float ra = red[0], rb = red[1], rc = red[2], rd = red[3];
+  for (int w = 1; w < kBinThreads / 64; ++w) {
+    if (mode == 0) { ra += red[w * 4 + 0]; rb += red[w * 4 + 1]; rc += red[w * 4 + 2]; }
+    else { ra = fmaxf(ra, red[w * 4 + 0]); rb = fminf(rb, red[w * 4 + 1]); }
+    rd = fminf(rd, red[w * 4 + 3]);
+  }
+  a = ra; b = rb; c = rc; d = rd;
+}
+
+__global__ void __launch_bounds__(kBinThreads)
+bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, const int N, const int H,
+           const int W, const int nstx, int *__restrict__ bin_count, int32_t *__restrict__ bin_id,
+           float *__restrict__ bin_lb) {
+  __shared__ BinLds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int stx = blockIdx.x % nstx, sty = blockIdx.x / nstx, b = blockIdx.y;
+  const int x0 = stx * kST, y0 = sty * kST;
+  const int rw = min(kST, W - x0), rh = min(kST, H - y0);
+  const int npx = rw * rh;
+  // ---- cone of the super-tile's rays ----
+  float sx = 0.f, sy = 0.f, sz = 0.f, okf = 1.f;
+  for (int i = tid; i < npx; i += kBinThreads) {
+    const int y = i / rw, x = i - y * rw;
+    const float *r = rays + (((size_t)b * H + y0 + y) * W + x0 + x) * 3;
+    const RayDir u = ray_dir(r[0], r[1], r[2]);
+    if (u.ok) { sx += u.ux; sy += u.uy; sz += u.uz; } else okf = 0.f;
+  }
+  block_reduce16(L.red, wave, lane, sx, sy, sz, okf, 0);
+  const float n = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
+  const float ax = sx / n, ay = sy / n, az = sz / n;
+  float smax = 0.f, cmin = 1.f, dummy = 0.f, okf2 = 1.f;
+  for (int i = tid; i < npx; i += kBinThreads) {
+    const int y = i / rw, x = i - y * rw;
+    const float *r = rays + (((size_t)b * H + y0 + y) * W + x0 + x) * 3;
+    cone_partial(ray_dir(r[0], r[1], r[2]), ax, ay, az, smax, cmin);
+  }
+  block_reduce16(L.red, wave, lane, smax, cmin, dummy, okf2, 1);
+  const Cone cone = cone_finish(ax, ay, az, n, smax, cmin, okf != 0.f);
+
+  // ---- scan all Gaussians of this batch element, keep (bound, id) of the survivors ----
+  if (tid == 0) L.count = 0;
+  __syncthreads();
+  const float4 *cullb = cull + (size_t)b * N;
+  for (int base = 0; base < N; base += kBinThreads) {
+    const int g = base + tid;
+    bool keep = false;
+    float4 c = make_float4(0.f, 0.f, 0.f, -1.f);
+    if (g < N) { c = cullb[g]; keep = cone_keep(c, cone); }
+    const unsigned long long m = __ballot(keep);
+    if (m) {
+      int start = 0;
+      if (lane == 0) start = atomicAdd(&L.count, __popcll(m));
+      start = __shfl(start, 0, 64);
+      const int slot = start + __popcll(m & ((1ull << lane) - 1ull));
+      if (keep && slot < kBinCap) L.keys[slot] = ((uint64_t)f2ord(len_lower_bound(c, cone)) << 32) | (uint32_t)g;
+    }
+  }
+  __syncthreads();
+  const int total = L.count;
+  const int bin = b * gridDim.x + blockIdx.x;
+  if (total > kBinCap) {
+    if (tid == 0) bin_count[bin] = -1;
+    return;
+  }
+  int np2 = 2;
+  while (np2 < total) np2 <<= 1;
+  for (int i = total + tid; i < np2; i += kBinThreads) L.keys[i] = ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += kBinThreads) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint64_t a = L.keys[i], bb = L.keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > bb) == up) { L.keys[i] = bb; L.keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  int32_t *oid = bin_id + (size_t)bin * kBinCap;
+  float *olb = bin_lb + (size_t)bin * kBinCap;
+  for (int i = tid; i < total; i += kBinThreads) {
+    const uint64_t k = L.keys[i];
+    oid[i] = (int32_t)(uint32_t)k;
+    olb[i] = ord2f((uint32_t)(k >> 32));
+  }
+  if (tid == 0) bin_count[bin] = total;
+}
+
+// ------------------------------------------------------------------------------------------
+// sweep.  One workgroup = WAVES waves = a TW x TH pixel tile (each wave an 8x8 sub-tile, one
+// ray per lane).  Its candidate stream is the sorted list of its super-tile (or, if that bin
+// overflowed, every Gaussian of the batch element), read in chunks of T:
+//   fill   : thread i gathers the cull record of stream entry base+i and tests it against the
+//            workgroup's bounding cone; survivors are compacted IN ORDER into LDS together with
+//            their eval record and len bound;
+//   consume: each wave re-tests the survivors against its own 8x8 cone, 64 at a time (one per
+//            lane, ballot), then for every remaining candidate all 64 lanes evaluate their ray
+//            against it (record broadcast from LDS) and insert into their LDS top-K list.
+//   exit   : once every lane of a wave holds K hits and the next candidate's len bound exceeds
+//            the wave's largest kept len, nothing later in the (sorted) stream can enter.
+// Both culls and the exit test are conservative, so the result equals the brute-force sweep.
+// The epilogue re-maps lanes to (pixel, slot) so that all four outputs are written as
+// contiguous runs of TW*K floats.
+// ------------------------------------------------------------------------------------------
+template <int T>
 struct TraceLds {
-  // layout inside dynamic LDS, after the [K][T] key array
-  float4 cull[CAP];
-  float4 ev[CAP * 3];
-  int32_t id[CAP];
+  // layout inside dynamic LDS, after the [K][T+1] key array
+  float4 cull[2 * T];
+  float4 ev[2 * T * 3];
+  int32_t id[2 * T];
+  float lb[2 * T];
   float red[4 * 8];
   int wcnt[2][4];
+  int cnt[T];
+  int done;
 };
 
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
 trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr,
-                 const float *__restrict__ rays, const int N, const int H, const int W,
-                 const int K, const float thr_act, int32_t *__restrict__ out_idx,
-                 float *__restrict__ out_len, float *__restrict__ out_act,
-                 float *__restrict__ out_dsd) {
+                 const float *__restrict__ rays, const int *__restrict__ bin_count,
+                 const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb, const int nstx,
+                 const int nst, const int N, const int H, const int W, const int K,
+                 const float thr_act, int32_t *__restrict__ out_idx, float *__restrict__ out_len,
+                 float *__restrict__ out_act, float *__restrict__ out_dsd) {
   constexpr int T = 64 * WAVES;
+  constexpr int TP = T + 1;   // key row stride: the transposed epilogue read stays conflict-light
   constexpr int TW = (WAVES >= 2) ? 16 : 8;
   constexpr int TH = (WAVES == 4) ? 16 : 8;
   constexpr int kCap = 2 * T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t *keys = reinterpret_cast<uint64_t *>(smem_raw);
-  TraceLds<kCap> &L = *reinterpret_cast<TraceLds<kCap> *>(smem_raw + sizeof(uint64_t) * (size_t)K * T);
+  TraceLds<T> &L = *reinterpret_cast<TraceLds<T> *>(smem_raw + ((sizeof(uint64_t) * (size_t)K * TP + 15) & ~(size_t)15));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (W + TW - 1) / TW;
@@ -121,32 +299,22 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   const size_t ray_id = ((size_t)b * H + cpy) * W + cpx;
   const float dx = rays[3 * ray_id + 0], dy = rays[3 * ray_id + 1], dz = rays[3 * ray_id + 2];
   const float qxx = dx * dx, qyy = dy * dy, qzz = dz * dz, qxy = dx * dy, qxz = dx * dz, qyz = dy * dz;
+  if (tid == 0) L.done = 0;
 
   // ---- bounding cones (wave, then workgroup) ---------------------------------------------
-  const float dn2 = qxx + qyy + qzz;
-  const float inv = 1.0f / sqrtf(dn2);
-  const bool dir_ok = (dn2 > 0.0f) && (inv < 3e38f) && (inv == inv);
-  const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
-  const bool wave_dirs_ok = __all(dir_ok);
-  auto make_cone = [&](float sx, float sy, float sz, bool all_ok, auto red_max, auto red_min) {
-    Cone c;
-    const float n = sqrtf(sx * sx + sy * sy + sz * sz);
-    c.ax = sx / n; c.ay = sy / n; c.az = sz / n;
-    const float cl = fmaf(uz, c.az, fmaf(uy, c.ay, ux * c.ax));
-    const float rx = fmaf(-cl, c.ax, ux), ry = fmaf(-cl, c.ay, uy), rz = fmaf(-cl, c.az, uz);
-    const float sl = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx * rx)));
-    const float smax = red_max(dir_ok ? sl : 2.0f);
-    const float cmin = red_min(dir_ok ? cl : -1.0f);
-    c.sn = smax * (1.0f + 1e-5f) + 1e-7f;
-    c.cs = cmin - 1e-6f;
-    c.ok = all_ok && (n > 1e-3f) && (cmin > 0.05f) && (c.sn == c.sn);
-    return c;
-  };
-  const float wsx = wave_sum(dir_ok ? ux : 0.f), wsy = wave_sum(dir_ok ? uy : 0.f),
-              wsz = wave_sum(dir_ok ? uz : 0.f);
-  const Cone wcone = make_cone(wsx, wsy, wsz, wave_dirs_ok, [](float v) { return wave_max(v); },
-                               [](float v) { return wave_min(v); });
-  Cone gcone = wcone;
+  const RayDir u = ray_dir(dx, dy, dz);
+  const bool wave_dirs_ok = __all(u.ok);
+  const bool unit_rays = __all(!u.ok || u.unit);
+  const float wsx = wave_sum(u.ok ? u.ux : 0.f), wsy = wave_sum(u.ok ? u.uy : 0.f), wsz = wave_sum(u.ok ? u.uz : 0.f);
+  Cone wcone, gcone;
+  {
+    const float n = sqrtf(fmaf(wsz, wsz, fmaf(wsy, wsy, wsx * wsx)));
+    const float ax = wsx / n, ay = wsy / n, az = wsz / n;
+    float smax = 0.f, cmin = 1.f;
+    cone_partial(u, ax, ay, az, smax, cmin);
+    wcone = cone_finish(ax, ay, az, n, wave_max(smax), wave_min(cmin), wave_dirs_ok);
+    gcone = wcone;
+  }
   if (WAVES > 1) {
     if (lane == 0) {
       L.red[wave * 8 + 0] = wsx; L.red[wave * 8 + 1] = wsy; L.red[wave * 8 + 2] = wsz;
@@ -158,37 +326,56 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       gx += L.red[w * 8 + 0]; gy += L.red[w * 8 + 1]; gz += L.red[w * 8 + 2];
       gok = gok && (L.red[w * 8 + 3] != 0.f);
     }
-    // per-wave extrema w.r.t. the workgroup axis, then across waves through LDS
-    const Cone part = make_cone(gx, gy, gz, gok, [](float v) { return wave_max(v); },
-                                [](float v) { return wave_min(v); });
-    if (lane == 0) { L.red[wave * 8 + 4] = part.sn; L.red[wave * 8 + 5] = part.cs; L.red[wave * 8 + 6] = part.ok ? 1.f : 0.f; }
+    const float n = sqrtf(fmaf(gz, gz, fmaf(gy, gy, gx * gx)));
+    const float ax = gx / n, ay = gy / n, az = gz / n;
+    float smax = 0.f, cmin = 1.f;
+    cone_partial(u, ax, ay, az, smax, cmin);
+    smax = wave_max(smax); cmin = wave_min(cmin);
+    if (lane == 0) { L.red[wave * 8 + 4] = smax; L.red[wave * 8 + 5] = cmin; }
     __syncthreads();
-    gcone = part;
-    for (int w = 0; w < WAVES; ++w) {
-      gcone.sn = fmaxf(gcone.sn, L.red[w * 8 + 4]);
-      gcone.cs = fminf(gcone.cs, L.red[w * 8 + 5]);
-      gcone.ok = gcone.ok && (L.red[w * 8 + 6] != 0.f);
-    }
+    for (int w = 0; w < WAVES; ++w) { smax = fmaxf(smax, L.red[w * 8 + 4]); cmin = fminf(cmin, L.red[w * 8 + 5]); }
+    gcone = cone_finish(ax, ay, az, n, smax, cmin, gok);
+  } else {
+    __syncthreads();
   }
 
-  // ---- sweep -------------------------------------------------------------------------------
-  uint64_t *mykeys = keys + tid;
-  int cnt = 0;
-  uint64_t worst = ~0ull;
+  // ---- candidate stream of this tile -----------------------------------------------------
+  const int bin = b * nst + ((ty * TH) / kST) * nstx + (tx * TW) / kST;
+  const int bc = (bin_count != nullptr) ? bin_count[bin] : -1;
+  const bool binned = bc >= 0;
+  const int src_n = binned ? bc : N;
+  const int32_t *src_id = binned ? bin_id + (size_t)bin * kBinCap : nullptr;
+  const float *src_lb = binned ? bin_lb + (size_t)bin * kBinCap : nullptr;
   const float4 *cullb = cull + (size_t)b * N;
   const float4 *evrb = evr + (size_t)b * N * 3;
   const float4 cull_none = make_float4(0.f, 0.f, 0.f, -1.f);
+  auto load_id = [&](int g) { return (g < src_n) ? (binned ? src_id[g] : g) : -1; };
+  auto load_lb = [&](int g) { return (binned && g < src_n) ? src_lb[g] : -INFINITY; };
+  auto load_rec = [&](int id) { return (id >= 0) ? cullb[id] : cull_none; };
+
+  uint64_t *mykeys = keys + tid;
+  int cnt = 0;
+  uint64_t worst = ~0ull;
+  bool wdone = false, reported = false, can_exit = false;
+  float wmax = INFINITY;
 
   int base = 0, par = 0;
-  float4 cnext = (tid < N) ? cullb[tid] : cull_none;
-  while (base < N) {
+  // two-deep software pipeline: ids two chunks ahead, cull records one chunk ahead
+  int id0 = load_id(tid);
+  float lb0 = load_lb(tid);
+  float4 c0r = load_rec(id0);
+  int id1 = load_id(T + tid);
+  float lb1 = load_lb(T + tid);
+  while (base < src_n) {
     int nbuf = 0;
-    // fill: append survivors until another full chunk might not fit
-    while (base < N && nbuf + T <= kCap) {
-      const int g = base + tid;
-      const float4 c = cnext;
-      const int gn = g + T;
-      cnext = (gn < N) ? cullb[gn] : cull_none;
+    while (base < src_n && nbuf + T <= kCap) {
+      const int id = id0;
+      const float lbv = lb0;
+      const float4 c = c0r;
+      id0 = id1; lb0 = lb1;
+      c0r = load_rec(id0);
+      id1 = load_id(base + 2 * T + tid);
+      lb1 = load_lb(base + 2 * T + tid);
       const bool keep = cone_keep(c, gcone);
       const unsigned long long m = __ballot(keep);
       if (lane == 0) L.wcnt[par][wave] = __popcll(m);
@@ -203,10 +390,11 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       if (keep) {
         const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
         L.cull[slot] = c;
-        L.id[slot] = g;
-        L.ev[slot * 3 + 0] = evrb[(size_t)g * 3 + 0];
-        L.ev[slot * 3 + 1] = evrb[(size_t)g * 3 + 1];
-        L.ev[slot * 3 + 2] = evrb[(size_t)g * 3 + 2];
+        L.id[slot] = id;
+        L.lb[slot] = lbv;
+        L.ev[slot * 3 + 0] = evrb[(size_t)id * 3 + 0];
+        L.ev[slot * 3 + 1] = evrb[(size_t)id * 3 + 1];
+        L.ev[slot * 3 + 2] = evrb[(size_t)id * 3 + 2];
       }
       nbuf += tot;
       base += T;
@@ -214,47 +402,75 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     }
     __syncthreads();
     // consume
-    for (int c0 = 0; c0 < nbuf; c0 += 64) {
-      const int i = c0 + lane;
-      bool keep = false;
-      if (i < nbuf) keep = (WAVES == 1) ? true : cone_keep(L.cull[i], wcone);
-      unsigned long long m = __ballot(keep);
-      while (m) {
-        const int j = __builtin_ctzll(m);
-        m &= m - 1ull;
-        const int s = c0 + j;
-        const float4 cc = L.cull[s];
-        const EvalRec e = unpack_eval(L.ev[s * 3 + 0], L.ev[s * 3 + 1], L.ev[s * 3 + 2]);
-        const PairOut o = pair_eval(cc.x, cc.y, cc.z, e, dx, dy, dz, qxx, qyy, qzz, qxy, qxz, qyz);
-        if (valid && o.act < thr_act && o.len < VOGE_SENT_LEN) {
-          const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)(L.id[s] + b * N);
-          if (key < worst) topk_insert(mykeys, T, K, cnt, worst, key);
+    if (!wdone) {
+      for (int c0 = 0; c0 < nbuf && !wdone; c0 += 64) {
+        const int i = c0 + lane;
+        bool keep = false;
+        if (i < nbuf) keep = (WAVES == 1) ? true : cone_keep(L.cull[i], wcone);
+        unsigned long long m = __ballot(keep);
+        while (m) {
+          const int j = __builtin_ctzll(m);
+          m &= m - 1ull;
+          const int s = c0 + j;
+          if (can_exit && L.lb[s] > wmax) { wdone = true; break; }
+          const float4 cc = L.cull[s];
+          const EvalRec e = unpack_eval(L.ev[s * 3 + 0], L.ev[s * 3 + 1], L.ev[s * 3 + 2]);
+          const PairOut o = pair_eval(cc.x, cc.y, cc.z, e, dx, dy, dz, qxx, qyy, qzz, qxy, qxz, qyz);
+          bool ins = false;
+          if (valid && o.act < thr_act && o.len < VOGE_SENT_LEN) {
+            const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)(L.id[s] + b * N);
+            if (key < worst) { topk_insert(mykeys, TP, K, cnt, worst, key); ins = true; }
+          }
+          if (__any(ins)) {
+            const bool full = __all(!valid || cnt == K);
+            if (full && unit_rays && binned) {
+              wmax = wave_max(valid ? ord2f((uint32_t)(worst >> 32)) : -INFINITY);
+              can_exit = true;
+            }
+          }
         }
       }
     }
+    if (wdone && !reported) {
+      reported = true;
+      if (lane == 0) atomicAdd(&L.done, 1);
+    }
     __syncthreads();
+    if (L.done == WAVES) break;
   }
 
-  // ---- epilogue: decode the winners, recompute act / dsd with the same arithmetic ----------
-  if (!valid) return;
-  const size_t pix = ((size_t)b * H + py) * W + px;
-  for (int s = 0; s < K; ++s) {
-    int32_t oi = -1;
-    float ol = VOGE_SENT_LEN, oa = VOGE_SENT_ACT, od = 0.0f;
-    if (s < cnt) {
-      const uint64_t key = mykeys[(size_t)s * T];
-      oi = (int32_t)(uint32_t)key;
-      const float4 cc = cull[oi];
-      const EvalRec e = unpack_eval(evr[(size_t)oi * 3 + 0], evr[(size_t)oi * 3 + 1], evr[(size_t)oi * 3 + 2]);
-      const PairOut o = pair_eval(cc.x, cc.y, cc.z, e, dx, dy, dz, qxx, qyy, qzz, qxy, qxz, qyz);
-      ol = ord2f((uint32_t)(key >> 32));
-      oa = o.act;
-      od = o.dsd;
+  // ---- epilogue: lanes re-mapped to (pixel, slot); act / dsd recomputed with pair_eval ------
+  L.cnt[tid] = cnt;
+  __syncthreads();
+  const int tw = min(TW, W - tx * TW);
+  const int row_items = tw * K;
+  for (int r = 0; r < TH; ++r) {
+    const int gy = ty * TH + r;
+    if (gy >= H) break;
+    const size_t pix0 = ((size_t)b * H + gy) * W + (size_t)tx * TW;
+    for (int j = tid; j < row_items; j += T) {
+      const int x = j / K, s = j - x * K;
+      const int owner = ((x >> 3) + (TW / 8) * (r >> 3)) * 64 + (x & 7) + 8 * (r & 7);
+      int32_t oi = -1;
+      float ol = VOGE_SENT_LEN, oa = VOGE_SENT_ACT, od = 0.0f;
+      if (s < L.cnt[owner]) {
+        const uint64_t key = keys[(size_t)s * TP + owner];
+        oi = (int32_t)(uint32_t)key;
+        const float *ry = rays + (pix0 + x) * 3;
+        const float ex = ry[0], ey = ry[1], ez = ry[2];
+        const float4 cc = cull[oi];
+        const EvalRec e = unpack_eval(evr[(size_t)oi * 3 + 0], evr[(size_t)oi * 3 + 1], evr[(size_t)oi * 3 + 2]);
+        const PairOut o = pair_eval(cc.x, cc.y, cc.z, e, ex, ey, ez, ex * ex, ey * ey, ez * ez, ex * ey, ex * ez, ey * ez);
+        ol = ord2f((uint32_t)(key >> 32));
+        oa = o.act;
+        od = o.dsd;
+      }
+      const size_t o = pix0 * K + j;
+      out_idx[o] = oi;
+      out_len[o] = ol;
+      out_act[o] = oa;
+      out_dsd[o] = od;
     }
-    out_idx[pix * K + s] = oi;
-    out_len[pix * K + s] = ol;
-    out_act[pix * K + s] = oa;
-    out_dsd[pix * K + s] = od;
   }
 }
 
@@ -321,20 +537,47 @@ trace_list_fwd_kernel(const float *__restrict__ mus, const float *__restrict__ i
   }
 }
 
+struct TraceWs {
+  float4 *cull, *evr;
+  int *bin_count;
+  int32_t *bin_id;
+  float *bin_lb;
+  int nstx, nsty;
+};
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *ws) {
+  const size_t P = (size_t)B * N;
+  const int nstx = (W + kST - 1) / kST, nsty = (H + kST - 1) / kST;
+  const size_t nbin = (size_t)B * nstx * nsty;
+  size_t off = 0;
+  char *p = reinterpret_cast<char *>(base);
+  auto take = [&](size_t bytes) { char *q = p ? p + off : nullptr; off += align256(bytes); return q; };
+  char *c = take(P * 16), *e = take(P * 48), *bc = take(nbin * 4), *bi = take(nbin * kBinCap * 4),
+       *bl = take(nbin * kBinCap * 4);
+  if (ws) {
+    ws->cull = reinterpret_cast<float4 *>(c); ws->evr = reinterpret_cast<float4 *>(e);
+    ws->bin_count = reinterpret_cast<int *>(bc); ws->bin_id = reinterpret_cast<int32_t *>(bi);
+    ws->bin_lb = reinterpret_cast<float *>(bl); ws->nstx = nstx; ws->nsty = nsty;
+  }
+  return off;
+}
+
 template <int WAVES>
-static int launch_trace(const float4 *cull, const float4 *evr, const float *rays, int B, int N,
-                        int H, int W, int K, float thr_act, int32_t *idx, float *len, float *act,
-                        float *dsd, hipStream_t st) {
+static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int H, int W, int K,
+                        float thr_act, int32_t *idx, float *len, float *act, float *dsd, hipStream_t st) {
   constexpr int T = 64 * WAVES;
   constexpr int TW = (WAVES >= 2) ? 16 : 8;
   constexpr int TH = (WAVES == 4) ? 16 : 8;
-  const size_t lds = sizeof(uint64_t) * (size_t)K * T + sizeof(TraceLds<2 * T>);
+  const size_t lds = ((sizeof(uint64_t) * (size_t)K * (T + 1) + 15) & ~(size_t)15) + sizeof(TraceLds<T>);
   auto kern = trace_fwd_kernel<WAVES>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid(((W + TW - 1) / TW) * ((H + TH - 1) / TH), B);
-  hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, cull, evr, rays, N, H, W, K, thr_act, idx, len, act, dsd);
+  hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, rays, ws.bin_count, ws.bin_id, ws.bin_lb,
+                     ws.nstx, ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd);
   return launch_status();
 }
 
@@ -342,9 +585,9 @@ static int launch_trace(const float4 *cull, const float4 *evr, const float *rays
 
 using namespace voge;
 
-extern "C" size_t voge_trace_workspace_bytes(int B, int N) {
-  if (B <= 0 || N <= 0) return 0;
-  return (size_t)B * N * 64;
+extern "C" size_t voge_trace_workspace_bytes(int B, int N, int H, int W) {
+  if (B <= 0 || N < 0 || H <= 0 || W <= 0) return 0;
+  return trace_ws_layout(B, N, H, W, nullptr, nullptr);
 }
 
 extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const float *rays,
@@ -355,29 +598,35 @@ extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const
   if (B < 0 || N < 0 || H < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K) return VOGE_ERR_K_TOO_LARGE;
   if ((size_t)B * H * W == 0) return 0;  // numel == 0 early return (ray_trace_voge.cu:248-251)
-  if (!rays || !idx || !len || !act || !dsd) return VOGE_ERR_BAD_ARG;
-  if (N > 0 && (!mus || !isigmas || !workspace)) return VOGE_ERR_BAD_ARG;
-  if (workspace_bytes < voge_trace_workspace_bytes(B, N)) return VOGE_ERR_WORKSPACE;
+  if (!rays || !idx || !len || !act || !dsd || !workspace) return VOGE_ERR_BAD_ARG;
+  if (N > 0 && (!mus || !isigmas)) return VOGE_ERR_BAD_ARG;
+  if (workspace_bytes < voge_trace_workspace_bytes(B, N, H, W)) return VOGE_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int P = B * N;
-  float4 *cull = reinterpret_cast<float4 *>(workspace);
-  float4 *evr = cull + P;
+  TraceWs ws;
+  trace_ws_layout(B, N, H, W, workspace, &ws);
   if (P > 0) {
     hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P,
-                       thr_act, cull, evr);
+                       thr_act, ws.cull, ws.evr);
+    int rc = launch_status();
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(bin_kernel, dim3(ws.nstx * ws.nsty, B), dim3(kBinThreads), 0, st, ws.cull, rays, N, H, W,
+                     ws.nstx, ws.bin_count, ws.bin_id, ws.bin_lb);
+  {
     int rc = launch_status();
     if (rc) return rc;
   }
   // largest tile whose LDS footprint still lets two workgroups share a CU; else whatever fits
   auto fits = [&](int waves, size_t budget) {
-    const size_t fixed = waves == 4 ? sizeof(TraceLds<512>) : waves == 2 ? sizeof(TraceLds<256>) : sizeof(TraceLds<128>);
-    return sizeof(uint64_t) * (size_t)K * 64 * waves + fixed <= budget;
+    const size_t fixed = waves == 4 ? sizeof(TraceLds<256>) : waves == 2 ? sizeof(TraceLds<128>) : sizeof(TraceLds<64>);
+    return sizeof(uint64_t) * (size_t)K * (64 * waves + 1) + 16 + fixed <= budget;
   };
   const size_t two_per_cu = 80 * 1024, one_per_cu = 160 * 1024;
-  if (fits(4, two_per_cu)) return launch_trace<4>(cull, evr, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
-  if (fits(2, two_per_cu)) return launch_trace<2>(cull, evr, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
-  if (fits(1, two_per_cu)) return launch_trace<1>(cull, evr, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
-  if (fits(1, one_per_cu)) return launch_trace<1>(cull, evr, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
+  if (fits(4, two_per_cu)) return launch_trace<4>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
+  if (fits(2, two_per_cu)) return launch_trace<2>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
+  if (fits(1, two_per_cu)) return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
+  if (fits(1, one_per_cu)) return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
   return VOGE_ERR_K_TOO_LARGE;
 }
 

@@ -70,7 +70,7 @@ class _RayTraceVoGE(torch.autograd.Function):
                 assert B > 0 and P % B == 0, "mus must hold B*N rows"
                 N = P // B
                 fwd = None if bin_points is None else _dev(bin_points, torch.float32, "cam_fwd")
-                nbytes = lib.voge_trace_workspace_bytes(B, N)
+                nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
                 ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
                 rc = lib.voge_trace_topk_fwd(
                     _p(mus_c), _p(isg_c), _p(rays_c), _p(fwd), B, N, H, W, K, float(thr_act), _p(ws), nbytes,
