@@ -167,6 +167,7 @@ def main():
             st = torch.cuda.current_stream().cuda_stream
             npix = H * W
             ws = torch.empty(lib.voge_trace_workspace_bytes(1, N, H, W), dtype=torch.uint8, device=dev)
+            ws_b = torch.empty(lib.voge_trace_bwd_workspace_bytes(N), dtype=torch.uint8, device=dev)
             o_i, o_l, o_a, o_d = (torch.empty_like(x) for x in sel)
             g3 = [torch.empty_like(w) for _ in range(3)]
             g_ray, g_mu, g_A = torch.empty_like(rays), torch.empty_like(mus), torch.empty_like(isg)
@@ -185,7 +186,7 @@ def main():
                 "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), 1.0, npix, K, P(g3[0]),
                                                                 P(g3[1]), P(g3[2]), st),
                 "trace_bwd": lambda: lib.voge_trace_bwd(P(mus), P(isg), P(rays), P(sel[0]), P(w), P(w), P(w), N, H, W, K,
-                                                        P(g_ray), P(g_mu), P(g_A), st),
+                                                        P(ws_b), ws_b.numel(), None, P(g_mu), P(g_A), st),
             }
             nbytes = stage_bytes(N, npix, K)
             stages = {}

@@ -98,13 +98,18 @@ int voge_trace_topk_list_fwd(const float *mus, const float *isigmas, const float
  * kernel works on 16x16 pixel tiles of that grid).  For every slot with idx >= 0 applies the
  * chain rule of ray_trace_voge.cu:324-326 and scatters into
  *   g_ray [nrows*W,3], g_mus [P,3], g_isg [P,3,3]  (raw outer products, not symmetrised).
- * g_mus / g_isg are zero-filled by this call (the reference allocates zeros, :354-356);
+ * g_mus / g_isg are fully written by this call (the reference allocates zeros, :354-356);
  * g_ray is fully written, or may be NULL when the ray gradient is not needed.
+ * workspace: >= voge_trace_bwd_workspace_bytes(P) bytes, 256-byte aligned.
  */
 int voge_trace_bwd(const float *mus, const float *isigmas, const float *rays,
                    const int32_t *idx, const float *g_len, const float *g_act,
-                   const float *g_dsd, int P, long nrows, int W, int K, float *g_ray,
-                   float *g_mus, float *g_isg, voge_stream_t stream);
+                   const float *g_dsd, int P, long nrows, int W, int K, void *workspace,
+                   size_t workspace_bytes, float *g_ray, float *g_mus, float *g_isg,
+                   voge_stream_t stream);
+
+/* Scratch bytes voge_trace_bwd needs for P Gaussians (packed records + padded accumulator). */
+size_t voge_trace_bwd_workspace_bytes(int P);
 
 /*
  * Composite forward.  Replaces: VoGE/Aggregation.py:82-107 `aggregation`

@@ -138,10 +138,11 @@ merge_bwd_tile_kernel(const float *__restrict__ attr, const int32_t *__restrict_
   }
   __syncthreads();
   if (g_attr != nullptr) {
-    for (int s = tid; s < kMHS; s += 256) {
+    // 4 adjacent lanes per table entry -> adjacent floats of g_attr[p]: lane-coalesced atomics
+    const int c = tid & 3;
+    for (int s = tid >> 2; s < kMHS; s += 64) {
       const int p = L.keys[s];
-      if (p < 0) continue;
-      for (int c = 0; c < C; ++c) unsafeAtomicAdd(g_attr + (size_t)p * C + c, L.vals[s * 4 + c]);
+      if (p >= 0 && c < C) unsafeAtomicAdd(g_attr + (size_t)p * C + c, L.vals[s * 4 + c]);
     }
   }
 }

@@ -195,18 +195,26 @@ bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, cons
   if (tid == 0) L.count = 0;
   __syncthreads();
   const float4 *cullb = cull + (size_t)b * N;
-  for (int base = 0; base < N; base += kBinThreads) {
-    const int g = base + tid;
-    bool keep = false;
-    float4 c = make_float4(0.f, 0.f, 0.f, -1.f);
-    if (g < N) { c = cullb[g]; keep = cone_keep(c, cone); }
-    const unsigned long long m = __ballot(keep);
-    if (m) {
-      int start = 0;
-      if (lane == 0) start = atomicAdd(&L.count, __popcll(m));
-      start = __shfl(start, 0, 64);
-      const int slot = start + __popcll(m & ((1ull << lane) - 1ull));
-      if (keep && slot < kBinCap) L.keys[slot] = ((uint64_t)f2ord(len_lower_bound(c, cone)) << 32) | (uint32_t)g;
+  for (int base = 0; base < N; base += 4 * kBinThreads) {
+    // four independent 16-byte loads in flight per lane: the scan is latency-, not compute-bound
+    float4 c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int g = base + q * kBinThreads + tid;
+      c[q] = (g < N) ? cullb[g] : make_float4(0.f, 0.f, 0.f, -1.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int g = base + q * kBinThreads + tid;
+      const bool keep = cone_keep(c[q], cone);
+      const unsigned long long m = __ballot(keep);
+      if (m) {
+        int start = 0;
+        if (lane == 0) start = atomicAdd(&L.count, __popcll(m));
+        start = __shfl(start, 0, 64);
+        const int slot = start + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && slot < kBinCap) L.keys[slot] = ((uint64_t)f2ord(len_lower_bound(c[q], cone)) << 32) | (uint32_t)g;
+      }
     }
   }
   __syncthreads();

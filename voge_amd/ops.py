@@ -100,8 +100,10 @@ class _RayTraceVoGE(torch.autograd.Function):
         g_mus = torch.empty_like(mus)
         g_isg = torch.empty_like(isg)
         with torch.cuda.device(rays.device):
+            nbytes = lib.voge_trace_bwd_workspace_bytes(P)
+            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=rays.device)
             rc = lib.voge_trace_bwd(_p(mus), _p(isg), _p(rays), _p(sel_idx), _p(gl), _p(ga), _p(gd), P,
-                                    B * H, W, K, _p(g_ray), _p(g_mus), _p(g_isg), _stream())
+                                    B * H, W, K, _p(ws), nbytes, _p(g_ray), _p(g_mus), _p(g_isg), _stream())
         _lib.check(rc, "voge_trace_bwd")
         return g_mus, g_isg, g_ray, None, None, None, None
 
