@@ -20,6 +20,7 @@ namespace voge {
 constexpr int kCompThreads = 256;
 constexpr float kInvNorm = 1.6487212707001282f;  // 1 / exp(-0.5), Aggregation.py:79
 constexpr float kRsqrtPi = 0.5641895835477563f;
+constexpr float kSat = 4.0f;  // erf(4) = 1 - 1.5e-8
 
 // Phi(x) = (erf(x)+1)/2 and y = exp(-x^2) in one go.  erf by Abramowitz-Stegun 7.1.26
 // (|err| <= 1.5e-7 absolute), branch-free; the same exponential feeds phi in the backward.
@@ -78,11 +79,19 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   if (em != 0.0f) {
     for (int j = 0; j < hi; ++j) {
       const float4 r = row[j];
-      if (r.z != 0.0f) {
-        float y;
-        const float ca = (lm - r.x) * r.y;
-        sum = fmaf(r.z, phi_cdf(ca, y), sum);
-        if (BWD) rterm = fmaf(r.z * r.y, y * kRsqrtPi, rterm);
+      // |ca| >= 4: erf saturates (|Phi - step| < 8e-9, phi < 7e-8) -> the slot either occludes
+      // fully or not at all.  Lists are depth sorted, so the lanes of a wave (consecutive m) fall
+      // outside slot j's window together and the wave skips the transcendental path uniformly.
+      const float ca = (lm - r.x) * r.y;
+      const bool in_win = (r.z != 0.0f) && (fabsf(ca) < kSat);
+      if (__any(in_win)) {
+        if (r.z != 0.0f) {
+          float y;
+          sum = fmaf(r.z, phi_cdf(ca, y), sum);
+          if (BWD) rterm = fmaf(r.z * r.y, y * kRsqrtPi, rterm);
+        }
+      } else {
+        sum += (ca > 0.0f) ? r.z : 0.0f;
       }
     }
   }
@@ -102,14 +111,20 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
     float cPhi = 0.0f, cphi = 0.0f, cphil = 0.0f;
     for (int m = 0; m < hi; ++m) {
       const float4 r = row[m];
-      if (r.w != 0.0f) {
-        float y;
-        const float dl = r.x - lm;
-        const float Phi = phi_cdf(dl * sm, y);
-        const float ph = r.w * (y * kRsqrtPi);
-        cPhi = fmaf(r.w, Phi, cPhi);
-        cphi += ph;
-        cphil = fmaf(ph, dl, cphil);
+      const float dl = r.x - lm;
+      const float ca = dl * sm;
+      const bool in_win = (r.w != 0.0f) && (fabsf(ca) < kSat);
+      if (__any(in_win)) {
+        if (r.w != 0.0f) {
+          float y;
+          const float Phi = phi_cdf(ca, y);
+          const float ph = r.w * (y * kRsqrtPi);
+          cPhi = fmaf(r.w, Phi, cPhi);
+          cphi += ph;
+          cphil = fmaf(ph, dl, cphil);
+        }
+      } else {
+        cPhi += (ca > 0.0f) ? r.w : 0.0f;
       }
     }
     ga = fmaf(occ * em, cPhi, -um);

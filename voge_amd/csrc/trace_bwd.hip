@@ -12,137 +12,150 @@
 //      g_ray = g_dsd (A + A^T) d + c1 (A^T v - t A d) + g_act t ( -2 A^T v + t (A - A^T) d )
 //    which expand to exactly g_ksk/g_msk/g_msm of ray_trace_voge.cu:324-326 pushed through
 //    Innerdot3dBackward (checked against the embedded known answer, :381-448).
-// 2. A workgroup owns a 16x16 pixel tile (256*K slots, streamed as coalesced runs of the flat
-//    [npix*K] arrays).  The 12 per-Gaussian sums are accumulated in an LDS hash table keyed by
-//    Gaussian index (LDS float atomics; a pixel never lists a Gaussian twice, so the lanes of a
-//    wave rarely collide) and flushed with ONE global atomic per (Gaussian, component) per tile:
-//    ~10x fewer HBM/L2 atomics than one per slot.  Table overflow falls back to direct atomics.
-//    g_ray is pixel-owned: LDS accumulation, plain stores.
+// 2. A wave owns an 8x8 pixel tile and walks it pixel by pixel with ONE LANE PER SLOT (coalesced
+//    160-byte runs of the flat [npix*K] arrays).  The 12 per-Gaussian sums are accumulated in a
+//    wave-private LDS table keyed by Gaussian index with plain read-modify-write (a pixel never
+//    lists a Gaussian twice, so the lanes of one instruction never collide), then flushed with
+//    lane-coalesced global atomics: 12 adjacent lanes add to 12 adjacent floats of one 64-byte
+//    line of a padded [P][16] accumulator.  g_ray is pixel-owned: segmented wave sum, plain stores.
 #include "voge_common.h"
 
 namespace voge {
 
-constexpr int kBT = 16;        // tile edge (pixels)
-constexpr int kHS = 1024;      // hash slots per workgroup
-constexpr int kNV = 12;        // values per Gaussian: g_mu (3) + g_A (9)
-constexpr int kProbe = 24;
+constexpr int kBwdWaves = 2;    // waves per workgroup (each wave is independent)
+constexpr int kBwdNE = 256;     // table entries per wave (an 8x8 tile touches ~100-200 Gaussians)
 
-struct BwdLds {
-  int keys[kHS];
-  float vals[kHS * kNV];
-  float ray[kBT * kBT * 3];
+struct BwdWaveLds {
+  WaveTable<kBwdNE, 3> tab;     // key = Gaussian index, values = g_mu (3) + g_A (9)
+  float ray[64 * 3];
 };
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * kBwdWaves)
 trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
                  const int32_t *__restrict__ idx, const float *__restrict__ g_len,
                  const float *__restrict__ g_act, const float *__restrict__ g_dsd, const int P,
                  const long nrows, const int W, const int K, float *__restrict__ g_ray,
                  float *__restrict__ acc /* [P][16]: g_mu (3), g_A (9), pad (4) */) {
-  __shared__ BwdLds L;
-  const int tid = threadIdx.x;
-  const int tiles_x = (W + kBT - 1) / kBT;
-  const int tx = blockIdx.x % tiles_x;
-  const long ty = blockIdx.x / tiles_x;
-  const int x0 = tx * kBT;
-  const long y0 = ty * kBT;
-  const int tw = min(kBT, W - x0);                 // tile width in pixels
-  const int th = (int)min((long)kBT, nrows - y0);  // tile height
-  for (int i = tid; i < kHS; i += 256) L.keys[i] = -1;
-  for (int i = tid; i < kHS * kNV; i += 256) L.vals[i] = 0.0f;
-  for (int i = tid; i < kBT * kBT * 3; i += 256) L.ray[i] = 0.0f;
-  __syncthreads();
+  __shared__ BwdWaveLds Ls[kBwdWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  BwdWaveLds &L = Ls[wave];
+  const int tiles_x = (W + 7) / 8;
+  const long ntiles = (long)tiles_x * ((nrows + 7) / 8);
+  const long tile = (long)blockIdx.x * kBwdWaves + wave;
+  if (tile >= ntiles) return;  // waves never synchronise with each other
+  const int x0 = (int)(tile % tiles_x) * 8;
+  const long y0 = (tile / tiles_x) * 8;
+  wt_clear(L.tab, lane);
+  for (int i = lane; i < 64 * 3; i += 64) L.ray[i] = 0.0f;
 
-  const int row_items = tw * K;  // contiguous floats per tile row
-  for (int r = 0; r < th; ++r) {
-    const long row_base = ((y0 + r) * W + x0) * (long)K;
-    for (int it = tid; it < row_items; it += 256) {
-      const long pid = row_base + it;
-      const int p = idx[pid];
-      if (p < 0 || p >= P) continue;
-      const float gl = g_len[pid], ga = g_act[pid], gd = g_dsd[pid];
-      if (gl == 0.0f && ga == 0.0f && gd == 0.0f) continue;
-      const int lx = it / K;
-      const long pix = (y0 + r) * W + x0 + lx;
-      const float dx = rays[3 * pix + 0], dy = rays[3 * pix + 1], dz = rays[3 * pix + 2];
-      const float4 r0 = rec[3 * (size_t)p], r1 = rec[3 * (size_t)p + 1], r2 = rec[3 * (size_t)p + 2];
-      const float mx = r0.x, my = r0.y, mz = r0.z;
-      const float A[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-      const float adx = fmaf(A[2], dz, fmaf(A[1], dy, A[0] * dx));
-      const float ady = fmaf(A[5], dz, fmaf(A[4], dy, A[3] * dx));
-      const float adz = fmaf(A[8], dz, fmaf(A[7], dy, A[6] * dx));
-      const float tdx = fmaf(A[6], dz, fmaf(A[3], dy, A[0] * dx));
-      const float tdy = fmaf(A[7], dz, fmaf(A[4], dy, A[1] * dx));
-      const float tdz = fmaf(A[8], dz, fmaf(A[5], dy, A[2] * dx));
-      const float ksk = fmaf(dz, adz, fmaf(dy, ady, dx * adx));
-      const float msk = fmaf(mz, adz, fmaf(my, ady, mx * adx));
-      const float t = msk / ksk;
-      const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
-      const float avx = fmaf(A[2], vz, fmaf(A[1], vy, A[0] * vx));
-      const float avy = fmaf(A[5], vz, fmaf(A[4], vy, A[3] * vx));
-      const float avz = fmaf(A[8], vz, fmaf(A[7], vy, A[6] * vx));
-      const float tvx = fmaf(A[6], vz, fmaf(A[3], vy, A[0] * vx));
-      const float tvy = fmaf(A[7], vz, fmaf(A[4], vy, A[1] * vx));
-      const float tvz = fmaf(A[8], vz, fmaf(A[5], vy, A[2] * vx));
-      const float c1 = gl / ksk;
-      const float gat = ga * t;
-
-      float val[kNV];
-      val[0] = fmaf(c1, adx, ga * (avx + tvx + t * (tdx - adx)));
-      val[1] = fmaf(c1, ady, ga * (avy + tvy + t * (tdy - ady)));
-      val[2] = fmaf(c1, adz, ga * (avz + tvz + t * (tdz - adz)));
-      const float d[3] = {dx, dy, dz}, v[3] = {vx, vy, vz};
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          val[3 + 3 * i + j] = fmaf(ga, fmaf(v[i], v[j], t * (d[i] * v[j] - v[i] * d[j])),
-                                    fmaf(gd, d[i] * d[j], c1 * (v[i] * d[j])));
-
-      // LDS hash: find / claim the slot of Gaussian p
-      unsigned h = ((unsigned)p * 2654435761u) >> 22;  // 10 bits
-      int slot = -1;
-#pragma unroll 1
-      for (int pr = 0; pr < kProbe; ++pr) {
-        const int old = atomicCAS(&L.keys[h], -1, p);
-        if (old == -1 || old == p) { slot = (int)h; break; }
-        h = (h + 1) & (kHS - 1);
+  const int lpp = min(K, 64);   // lanes per pixel
+  const int ppi = 64 / lpp;     // pixels per wave instruction
+  const int sub = lane / lpp, kl = lane - sub * lpp;
+  for (int i0 = 0; i0 < 64; i0 += ppi) {
+    const int i = i0 + sub;
+    const int px = x0 + (i & 7);
+    const long py = y0 + (i >> 3);
+    const bool pix_ok = (sub < ppi) && (i < 64) && (px < W) && (py < nrows);
+    const long pix = py * W + px;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (pix_ok) { dx = rays[3 * pix + 0]; dy = rays[3 * pix + 1]; dz = rays[3 * pix + 2]; }
+    for (int kc = 0; kc < K; kc += 64) {
+      const int k = kc + kl;
+      int p = -1;
+      float gl = 0.f, ga = 0.f, gd = 0.f;
+      if (pix_ok && k < K) {
+        const long pid = pix * K + k;
+        p = idx[pid];
+        if (p >= 0 && p < P) { gl = g_len[pid]; ga = g_act[pid]; gd = g_dsd[pid]; } else p = -1;
       }
-      if (slot >= 0) {
-        float *dst = L.vals + slot * kNV;
+      const bool live = (p >= 0) && !(gl == 0.0f && ga == 0.0f && gd == 0.0f);
+      float4 val[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+      float rx = 0.f, ryv = 0.f, rz = 0.f;
+      if (live) {
+        const float4 r0 = rec[3 * (size_t)p], r1 = rec[3 * (size_t)p + 1], r2 = rec[3 * (size_t)p + 2];
+        const float mx = r0.x, my = r0.y, mz = r0.z;
+        const float A[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+        const float adx = fmaf(A[2], dz, fmaf(A[1], dy, A[0] * dx));
+        const float ady = fmaf(A[5], dz, fmaf(A[4], dy, A[3] * dx));
+        const float adz = fmaf(A[8], dz, fmaf(A[7], dy, A[6] * dx));
+        const float tdx = fmaf(A[6], dz, fmaf(A[3], dy, A[0] * dx));
+        const float tdy = fmaf(A[7], dz, fmaf(A[4], dy, A[1] * dx));
+        const float tdz = fmaf(A[8], dz, fmaf(A[5], dy, A[2] * dx));
+        const float ksk = fmaf(dz, adz, fmaf(dy, ady, dx * adx));
+        const float msk = fmaf(mz, adz, fmaf(my, ady, mx * adx));
+        const float t = msk / ksk;
+        const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
+        const float avx = fmaf(A[2], vz, fmaf(A[1], vy, A[0] * vx));
+        const float avy = fmaf(A[5], vz, fmaf(A[4], vy, A[3] * vx));
+        const float avz = fmaf(A[8], vz, fmaf(A[7], vy, A[6] * vx));
+        const float tvx = fmaf(A[6], vz, fmaf(A[3], vy, A[0] * vx));
+        const float tvy = fmaf(A[7], vz, fmaf(A[4], vy, A[1] * vx));
+        const float tvz = fmaf(A[8], vz, fmaf(A[5], vy, A[2] * vx));
+        const float c1 = gl / ksk;
+        const float gat = ga * t;
+        float o[12];
+        o[0] = fmaf(c1, adx, ga * (avx + tvx + t * (tdx - adx)));
+        o[1] = fmaf(c1, ady, ga * (avy + tvy + t * (tdy - ady)));
+        o[2] = fmaf(c1, adz, ga * (avz + tvz + t * (tdz - adz)));
+        const float d[3] = {dx, dy, dz}, v[3] = {vx, vy, vz};
 #pragma unroll
-        for (int i = 0; i < kNV; ++i) atomicAdd(dst + i, val[i]);
-      } else {
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int i = 0; i < kNV; ++i) unsafeAtomicAdd(acc + 16 * (size_t)p + i, val[i]);
+          for (int c = 0; c < 3; ++c)
+            o[3 + 3 * a + c] = fmaf(ga, fmaf(v[a], v[c], t * (d[a] * v[c] - v[a] * d[c])),
+                                    fmaf(gd, d[a] * d[c], c1 * (v[a] * d[c])));
+        val[0] = make_float4(o[0], o[1], o[2], o[3]);
+        val[1] = make_float4(o[4], o[5], o[6], o[7]);
+        val[2] = make_float4(o[8], o[9], o[10], o[11]);
+        rx = fmaf(gd, adx + tdx, fmaf(c1, fmaf(-t, adx, tvx), gat * fmaf(t, adx - tdx, -2.0f * tvx)));
+        ryv = fmaf(gd, ady + tdy, fmaf(c1, fmaf(-t, ady, tvy), gat * fmaf(t, ady - tdy, -2.0f * tvy)));
+        rz = fmaf(gd, adz + tdz, fmaf(c1, fmaf(-t, adz, tvz), gat * fmaf(t, adz - tdz, -2.0f * tvz)));
       }
-
+      // a pixel lists a Gaussian at most once, so the lanes of ONE pixel carry distinct keys;
+      // several pixels per instruction (small K) are accumulated one pixel group at a time
+      for (int g = 0; g < ppi; ++g) {
+        const bool mine = live && (sub == g);
+        const int slot = wt_find(L.tab, p, mine);
+        if (mine) {
+          if (slot >= 0) {
+            wt_add(L.tab, slot, val);
+          } else {  // table full: rare, straight to HBM
+            const float o[12] = {val[0].x, val[0].y, val[0].z, val[0].w, val[1].x, val[1].y,
+                                 val[1].z, val[1].w, val[2].x, val[2].y, val[2].z, val[2].w};
+#pragma unroll
+            for (int c = 0; c < 12; ++c) unsafeAtomicAdd(acc + 16 * (size_t)p + c, o[c]);
+          }
+        }
+      }
       if (g_ray != nullptr) {
-        const float rx = fmaf(gd, adx + tdx, fmaf(c1, fmaf(-t, adx, tvx), gat * fmaf(t, adx - tdx, -2.0f * tvx)));
-        const float ryv = fmaf(gd, ady + tdy, fmaf(c1, fmaf(-t, ady, tvy), gat * fmaf(t, ady - tdy, -2.0f * tvy)));
-        const float rz = fmaf(gd, adz + tdz, fmaf(c1, fmaf(-t, adz, tvz), gat * fmaf(t, adz - tdz, -2.0f * tvz)));
-        float *ra = L.ray + (r * kBT + lx) * 3;
-        atomicAdd(ra + 0, rx);
-        atomicAdd(ra + 1, ryv);
-        atomicAdd(ra + 2, rz);
+        rx = seg_sum(rx, lane, lpp);
+        ryv = seg_sum(ryv, lane, lpp);
+        rz = seg_sum(rz, lane, lpp);
+        if (pix_ok && kl == 0) {
+          L.ray[i * 3 + 0] += rx;
+          L.ray[i * 3 + 1] += ryv;
+          L.ray[i * 3 + 2] += rz;
+        }
       }
     }
   }
-  __syncthreads();
   // flush: 16 adjacent lanes per table entry add 12 adjacent floats of ONE 64-byte line of
   // acc[p][16] -- lane-coalesced atomics run ~15x faster than 64 scattered ones
   // (tools/atomic_bench.hip: 330 vs 21 Gatomic/s).
   {
-    const int c = tid & 15;
-    for (int s = tid >> 4; s < kHS; s += 16) {
-      const int p = L.keys[s];
-      if (p >= 0 && c < kNV) unsafeAtomicAdd(acc + 16 * (size_t)p + c, L.vals[s * kNV + c]);
+    const int c = lane & 15;
+    const float *vals = reinterpret_cast<const float *>(L.tab.vals);
+    for (int s = lane >> 4; s < kBwdNE; s += 4) {
+      const int p = L.tab.keys[s];
+      if (p >= 0 && c < 12) unsafeAtomicAdd(acc + 16 * (size_t)p + c, vals[s * 12 + c]);
     }
   }
   if (g_ray != nullptr) {
-    for (int i = tid; i < th * tw * 3; i += 256) {
-      const int r = i / (tw * 3), c = i - r * (tw * 3);
-      g_ray[((y0 + r) * W + x0) * 3 + c] = L.ray[r * kBT * 3 + c];
+    for (int j = lane; j < 64 * 3; j += 64) {
+      const int i = j / 3, c = j - i * 3;
+      const int px = x0 + (i & 7);
+      const long py = y0 + (i >> 3);
+      if (px < W && py < nrows) g_ray[(py * W + px) * 3 + c] = L.ray[j];
     }
   }
 }
@@ -164,7 +177,7 @@ bwd_unpack_kernel(const float *__restrict__ acc, const int P, float *__restrict_
                   float *__restrict__ g_isg) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = t >> 4, c = t & 15;
-  if (g >= P || c >= kNV) return;
+  if (g >= P || c >= 12) return;
   const float v = acc[t];
   if (c < 3) g_mus[3 * (size_t)g + c] = v; else g_isg[9 * (size_t)g + (c - 3)] = v;
 }
@@ -197,9 +210,9 @@ extern "C" int voge_trace_bwd(const float *mus, const float *isigmas, const floa
   if (nrows * W > 0) {
     if (!rays || !idx || !g_len || !g_act || !g_dsd) return VOGE_ERR_BAD_ARG;
     hipLaunchKernelGGL(bwd_pack_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, P, rec);
-    const long tiles = (long)((W + kBT - 1) / kBT) * ((nrows + kBT - 1) / kBT);
-    hipLaunchKernelGGL(trace_bwd_kernel, dim3((unsigned)tiles), dim3(256), 0, st, rec, rays, idx, g_len, g_act,
-                       g_dsd, P, nrows, W, K, g_ray, acc);
+    const long tiles = (long)((W + 7) / 8) * ((nrows + 7) / 8);
+    hipLaunchKernelGGL(trace_bwd_kernel, dim3((unsigned)((tiles + kBwdWaves - 1) / kBwdWaves)), dim3(64 * kBwdWaves),
+                       0, st, rec, rays, idx, g_len, g_act, g_dsd, P, nrows, W, K, g_ray, acc);
   }
   hipLaunchKernelGGL(bwd_unpack_kernel, dim3((unsigned)(((size_t)P * 16 + 255) / 256)), dim3(256), 0, st, acc, P,
                      g_mus, g_isg);

@@ -137,9 +137,12 @@ constexpr int kST = 64;
 constexpr int kBinCap = 8192;
 constexpr int kBinThreads = 1024;
 
+constexpr int kBuckets = 1024;  // == kBinThreads (one scan lane per bucket)
 struct BinLds {
   uint64_t keys[kBinCap];
   float red[16 * 4];
+  int hist[kBuckets];
+  int wsum[16];
   int count;
 };
 
@@ -224,29 +227,54 @@ bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, cons
     if (tid == 0) bin_count[bin] = -1;
     return;
   }
-  int np2 = 2;
-  while (np2 < total) np2 <<= 1;
-  for (int i = total + tid; i < np2; i += kBinThreads) L.keys[i] = ~0ull;
-  __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < np2; i += kBinThreads) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const uint64_t a = L.keys[i], bb = L.keys[ixj];
-          const bool up = (i & k) == 0;
-          if ((a > bb) == up) { L.keys[i] = bb; L.keys[ixj] = a; }
-        }
-      }
-      __syncthreads();
-    }
+  // ---- order the survivors front to back: counting sort on the quantised bound -------------
+  // Exact order is not needed (the sweep's top-K insertion is order independent); what the early
+  // exit needs is a MONOTONE per-entry lower bound, so every entry reports the lower edge of its
+  // bucket.  Bucket 0 collects -inf bounds (unbounded reach) and keeps the edge -inf.
+  float lo = INFINITY, hi = -INFINITY, d0 = 0.f, d1 = 1.f;
+  for (int i = tid; i < total; i += kBinThreads) {
+    const float v = ord2f((uint32_t)(L.keys[i] >> 32));
+    if (v > -INFINITY) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
   }
+  block_reduce16(L.red, wave, lane, hi, lo, d0, d1, 1);   // a: max, b: min
+  const float span = fmaxf(hi - lo, 1e-20f);
+  const float scale = (float)(kBuckets - 2) / span;
+  for (int i = tid; i < kBuckets; i += kBinThreads) L.hist[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < total; i += kBinThreads) {
+    const float v = ord2f((uint32_t)(L.keys[i] >> 32));
+    int q = 0;
+    if (v > -INFINITY) q = 1 + min(kBuckets - 2, max(0, (int)((v - lo) * scale)));
+    atomicAdd(&L.hist[q], 1);
+  }
+  __syncthreads();
+  // exclusive scan of kBuckets (== kBinThreads) counters: wave scan + wave offsets
+  {
+    const int v = L.hist[tid];
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) L.wsum[wave] = x;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += L.wsum[w];
+    L.hist[tid] = off + x - v;
+  }
+  __syncthreads();
   int32_t *oid = bin_id + (size_t)bin * kBinCap;
   float *olb = bin_lb + (size_t)bin * kBinCap;
   for (int i = tid; i < total; i += kBinThreads) {
     const uint64_t k = L.keys[i];
-    oid[i] = (int32_t)(uint32_t)k;
-    olb[i] = ord2f((uint32_t)(k >> 32));
+    const float v = ord2f((uint32_t)(k >> 32));
+    int q = 0;
+    if (v > -INFINITY) q = 1 + min(kBuckets - 2, max(0, (int)((v - lo) * scale)));
+    const int pos = atomicAdd(&L.hist[q], 1);
+    oid[pos] = (int32_t)(uint32_t)k;
+    // lower edge of bucket q, nudged down so that rounding in (v - lo) * scale cannot overstate it
+    olb[pos] = (q == 0) ? -INFINITY : (lo + (float)(q - 1) / scale) - 1e-6f * (fabsf(lo) + span);
   }
   if (tid == 0) bin_count[bin] = total;
 }

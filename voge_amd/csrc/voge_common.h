@@ -158,6 +158,79 @@ __device__ __forceinline__ bool cone_keep(const float4 c, const Cone &k) {
   return !k.ok || !(gap > c.w);
 }
 
+// ------------------------------------------------------------------------------------------
+// Wave-private accumulation table in LDS: NV4 float4 values per integer key.
+// Only the owning wave touches a table, and within one wt_find()/wt_add() call all active lanes
+// carry DISTINCT keys, so slots are claimed with a plain write + read-back and values are
+// accumulated with plain read-modify-write.  (LDS float atomics cost ~3 LDS cycles per lane and
+// value on gfx950 -- SQ_LDS_IDX_ACTIVE in profiles/ -- the plain b128 path is ~20x cheaper.)
+// ------------------------------------------------------------------------------------------
+template <int NE, int NV4>
+struct WaveTable {
+  int keys[NE];
+  float4 vals[NE * NV4];
+};
+
+template <int NE, int NV4>
+__device__ __forceinline__ void wt_clear(WaveTable<NE, NV4> &t, const int lane) {
+  for (int i = lane; i < NE; i += VOGE_WAVE) t.keys[i] = -1;
+  for (int i = lane; i < NE * NV4; i += VOGE_WAVE) t.vals[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Slot of `key` for every lane with want == true (claiming an empty slot if needed), or -1 when
+// no slot was found within kWtProbe steps.  Must be called by the whole wave.
+constexpr int kWtProbe = 16;
+template <int NE, int NV4>
+__device__ __forceinline__ int wt_find(WaveTable<NE, NV4> &t, const int key, const bool want) {
+  volatile int *keys = t.keys;
+  unsigned h = ((unsigned)key * 2654435761u) >> (32 - __builtin_ctz(NE));
+  int slot = -1;
+  bool pending = want;
+#pragma unroll 1
+  for (int pr = 0; pr < kWtProbe && __any(pending); ++pr) {
+    if (pending) {
+      const int k0 = keys[h];
+      if (k0 == key) {
+        slot = (int)h;
+        pending = false;
+      } else if (k0 == -1) {
+        keys[h] = key;  // several lanes may try; the read-back below tells who won
+      }
+    }
+    if (pending) {
+      if (keys[h] == key) {
+        slot = (int)h;
+        pending = false;
+      } else {
+        h = (h + 1) & (NE - 1);
+      }
+    }
+  }
+  return slot;
+}
+
+template <int NE, int NV4>
+__device__ __forceinline__ void wt_add(WaveTable<NE, NV4> &t, const int slot, const float4 (&v)[NV4]) {
+  float4 *dst = t.vals + slot * NV4;
+#pragma unroll
+  for (int q = 0; q < NV4; ++q) {
+    float4 x = dst[q];
+    x.x += v[q].x; x.y += v[q].y; x.z += v[q].z; x.w += v[q].w;
+    dst[q] = x;
+  }
+}
+
+// Segmented sum over runs of `seg` consecutive lanes (seg <= 64, any value); the total of each
+// run lands in its first lane.
+__device__ __forceinline__ float seg_sum(float x, const int lane, const int seg) {
+  const int r = lane % seg;
+  for (int o = 1; o < seg; o <<= 1) {
+    const float y = __shfl_down(x, o, VOGE_WAVE);
+    if (r + o < seg) x += y;
+  }
+  return x;
+}
+
 inline int launch_status() { return (int)hipGetLastError(); }
 
 }  // namespace voge
