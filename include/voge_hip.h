@@ -171,6 +171,26 @@ int voge_blend_bwd(const float *rgb, const float *weight, const float *bg, float
                    const float *g_out, long npix, int K, int C, float *g_rgb,
                    float *g_weight_add, voge_stream_t stream);
 
+/*
+ * Pixel-ray generation.  Replaces: the PyTorch3D call in VoGE/Renderer.py:124-130
+ * (NDCMultinomialRaysampler(unit_directions=True) on screen-space PerspectiveCameras):
+ *   d_view(i,j) = [(px-j-0.5)/fx, (py-i-0.5)/fy, 1],  rays = normalise(d_view @ R^-1),
+ *   origin = -T @ R^-1          (row vectors, X_view = X_world @ R + T).
+ * R [B,3,3], T [B,3], focal [B,2], pp [B,2] (principal point, pixels).  Renders image rows
+ * row0 .. row0+h-1 (a pixel-row band): rays [B,h,W,3], origin [B,3].
+ */
+int voge_rays_fwd(const float *R, const float *T, const float *focal, const float *pp, int B,
+                  int row0, int h, int W, float *rays, float *origin, voge_stream_t stream);
+
+/*
+ * Backward of voge_rays_fwd: g_rays [B,h,W,3] (may be NULL) and g_origin [B,3] (may be NULL) ->
+ * g_R [B,3,3], g_T [B,3], g_focal [B,2], g_pp [B,2] (each may be NULL).  scratch: B*16 floats.
+ */
+int voge_rays_bwd(const float *R, const float *T, const float *focal, const float *pp,
+                  const float *g_rays, const float *g_origin, int B, int row0, int h, int W,
+                  float *scratch, float *g_R, float *g_T, float *g_focal, float *g_pp,
+                  voge_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -353,3 +353,82 @@ def test_full_size_properties_config3(hip_lib):
     img.sum().backward()
     assert torch.isfinite(gm.verts.grad).all() and torch.isfinite(gm.sigmas.grad).all()
     assert gm.verts.grad.abs().max() > 0
+
+
+# ------------------------------------------------------------------------------- ray generation
+def _rays_torch64(R, T, f, pp, H, W):
+    """fp64 torch statement of the a-0 convention (autograd reference for the ray kernel)."""
+    ii = torch.arange(H, dtype=torch.float64) + 0.5
+    jj = torch.arange(W, dtype=torch.float64) + 0.5
+    B = R.shape[0]
+    x = (pp[:, 0, None] - jj[None]) / f[:, 0, None]
+    y = (pp[:, 1, None] - ii[None]) / f[:, 1, None]
+    dv = torch.stack([x[:, None, :].expand(B, H, W), y[:, :, None].expand(B, H, W), torch.ones(B, H, W, dtype=torch.float64)], -1)
+    Rinv = torch.linalg.inv(R)
+    dw = torch.einsum("bhwj,bjk->bhwk", dv, Rinv)
+    return dw / dw.norm(dim=-1, keepdim=True), -torch.einsum("bj,bjk->bk", T, Rinv)
+
+
+def test_pixel_rays_fwd_bwd(hip_lib):
+    from voge_amd import ops
+    rng = np.random.default_rng(0)
+    R, T = camera_np.look_at_view_transform([3.0, 4.0], [10.0, -20.0], [30.0, 100.0])
+    R = (R + rng.normal(size=R.shape) * 0.01).astype(np.float32)          # not exactly orthonormal
+    f = np.float32([[300.0, 310.0], [150.0, 140.0]])
+    pp = np.float32([[26.0, 18.0], [30.0, 20.5]])
+    H, W = 37, 53
+    ref_rays, ref_origin = camera_np.pixel_rays(R, T, f, pp, (H, W))
+    tR, tT, tf, tp = t(R, rg=True), t(T, rg=True), t(f, rg=True), t(pp, rg=True)
+    rays, origin = ops.pixel_rays(tR, tT, tf, tp, 0, H, W)
+    assert np.abs(n(rays) - ref_rays).max() < 2e-6 and np.abs(n(origin) - ref_origin).max() < 1e-5
+    band, _ = ops.pixel_rays(tR, tT, tf, tp, 10, 7, W)
+    assert torch.equal(band, rays[:, 10:17])
+    G, Go = rng.normal(size=ref_rays.shape), rng.normal(size=(2, 3))
+    ((rays * t(G)).sum() + (origin * t(Go)).sum()).backward()
+    c = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    cR, cT, cf, cp = c(R), c(T), c(f), c(pp)
+    r64, o64 = _rays_torch64(cR, cT, cf, cp, H, W)
+    ((r64 * torch.tensor(G)).sum() + (o64 * torch.tensor(Go)).sum()).backward()
+    for name, got, want in (("R", tR.grad, cR.grad), ("T", tT.grad, cT.grad), ("focal", tf.grad, cf.grad), ("pp", tp.grad, cp.grad)):
+        w = want.numpy()
+        assert np.abs(n(got) - w).max() <= 2e-4 * max(1.0, np.abs(w).max()), name
+
+
+def test_camera_pose_gradient_end_to_end(hip_lib):
+    """Gradients reach R and T through the rays, the camera-centred means and the trace backward
+    (what the pose-estimation use of the renderer needs).  Reference: the oracle's backward chain
+    down to (g_ray, g_mu), then fp64 autograd through the a-0 camera convention."""
+    sc = cuboid_scene()
+    size = (48, 48)
+    sc = dict(sc, focal=56.0, principal=(24.0, 24.0), K=12)
+    from voge_amd.Meshes import GaussianMeshesNaive
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
+    from voge_amd.cameras import PerspectiveCameras
+    R0, T0 = camera_np.look_at_view_transform(sc["dist"], sc["elev"], sc["azim"])
+    cams = PerspectiveCameras(focal_length=sc["focal"], principal_point=(sc["principal"],), image_size=(size,), device=DEV)
+    renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=size, max_assign=sc["K"], max_point_per_bin=-1))
+    gm = GaussianMeshesNaive(t(sc["verts"]), t(sc["sigmas"]))
+    colors = t(sc["colors"])
+    g_img = np.random.default_rng(1).normal(size=(1,) + size + (3,))
+    Rv, Tv = t(R0, rg=True), t(T0, rg=True)
+    img = to_white_background(renderer(gm, R=Rv, T=Tv), colors)
+    (img * t(g_img)).sum().backward()
+
+    ref = oracle.render(sc["verts"], sc["sigmas"], sc["colors"], R0, T0, sc["focal"], sc["principal"], size, K=sc["K"])
+    assert np.abs(n(img) - ref["image"]).max() < 1e-3
+    x = ref["rgb"] + (1 - ref["silhouette"])[..., None]
+    g_rgb = g_img * (x < 1)
+    g_sil = -(g_rgb.sum(-1)) * (ref["weight"].sum(-1) < 1)
+    _, g_w = oracle.merge_bwd(sc["colors"], ref["idx"], ref["weight"], ref["valid_num"], g_rgb)
+    g_act, g_len, g_dsd = oracle.composite_bwd(ref["act"], ref["len"], ref["dsd"], g_w + g_sil[..., None], 1.0)
+    g_ray, g_mu, _ = oracle.trace_bwd(ref["mus"], ref["isg"], ref["rays"], ref["idx"], g_len, g_act, g_dsd)
+    c = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    cR, cT = c(R0), c(T0)
+    f64 = torch.tensor([[sc["focal"]] * 2], dtype=torch.float64)
+    p64 = torch.tensor([list(sc["principal"])], dtype=torch.float64)
+    r64, o64 = _rays_torch64(cR, cT, f64, p64, *size)
+    ((r64 * torch.tensor(g_ray)).sum() + (o64 * torch.tensor(-g_mu.sum(0, keepdims=True))).sum()).backward()
+    for name, got, want in (("R", Rv.grad, cR.grad), ("T", Tv.grad, cT.grad)):
+        w = want.numpy()
+        err = np.abs(n(got) - w).max()
+        assert err <= 20 * TOL * max(1.0, np.abs(w).max()), f"{name}: {err:.3e} / {np.abs(w).max():.3e}"

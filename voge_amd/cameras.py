@@ -12,7 +12,8 @@ has something to import where PyTorch3D is not installed.
 Conventions (PyTorch3D, screen space, in_ndc=False): row vectors, X_view = X_world @ R + T;
 view axes +X left, +Y up, +Z forward; pixel (row i, col j) centre <-> view direction
 [(px - j - 0.5)/fx, (py - i - 0.5)/fy, 1]; rays leave the camera centre C = -T @ R^-1.
-Everything is differentiable torch (gradients reach R, T, focal_length, principal_point).
+Ray generation is a HIP kernel with an analytic backward (gradients reach R, T, focal_length,
+principal_point).
 """
 import math
 
@@ -71,7 +72,9 @@ class PerspectiveCameras:
 
 def pixel_rays(cameras, image_size, rows=None):
     """Unit world-space ray directions [B,h,W,3] for pixel rows `rows=(r0,r1)` (default: all H
-    rows) and the camera centres [B,3]: what Renderer.py:124-128 reads from the ray bundle."""
+    rows) and the camera centres [B,3]: what Renderer.py:124-128 reads from the ray bundle.
+    One HIP kernel (voge_rays_fwd); differentiable w.r.t. R, T, focal_length, principal_point."""
+    from . import ops
     H, W = int(image_size[0]), int(image_size[1])
     R = cameras.R
     device = R.device
@@ -83,17 +86,7 @@ def pixel_rays(cameras, image_size, rows=None):
     f = _as_b2(cameras.focal_length, B, device)
     pp = _as_b2(cameras.principal_point, B, device)
     r0, r1 = (0, H) if rows is None else (int(rows[0]), int(rows[1]))
-    ii = torch.arange(r0, r1, device=device, dtype=torch.float32) + 0.5
-    jj = torch.arange(W, device=device, dtype=torch.float32) + 0.5
-    x = (pp[:, 0, None] - jj[None, :]) / f[:, 0, None]            # [B,W]
-    y = (pp[:, 1, None] - ii[None, :]) / f[:, 1, None]            # [B,h]
-    dv = torch.stack([x[:, None, :].expand(B, r1 - r0, W), y[:, :, None].expand(B, r1 - r0, W),
-                      torch.ones((B, r1 - r0, W), device=device)], dim=-1)
-    Rinv = torch.linalg.inv(R)
-    dw = torch.einsum("bhwj,bjk->bhwk", dv, Rinv)
-    dw = dw / dw.norm(dim=-1, keepdim=True)
-    centre = -torch.einsum("bj,bjk->bk", T, Rinv)
-    return dw, centre
+    return ops.pixel_rays(R, T, f, pp, r0, r1 - r0, W)
 
 
 def camera_position_from_spherical_angles(distance, elevation, azimuth, degrees=True, device="cpu"):

@@ -1,0 +1,181 @@
+// Pixel-ray generation for gfx950.
+//
+// Reference behaviour being reproduced: VoGE/Renderer.py:124-130 --
+// NDCMultinomialRaysampler(image_width, image_height, unit_directions=True, ...)(cameras)
+// for a screen-space (in_ndc=False) PyTorch3D PerspectiveCameras: unit world-space directions of
+// the pixel centres and the camera centre as common origin.  Conventions (row vectors):
+//   X_view = X_world @ R + T,  view axes +X left / +Y up / +Z forward,
+//   d_view(i, j) = [(px - j - 0.5)/fx, (py - i - 0.5)/fy, 1],
+//   d_world = normalise(d_view @ R^-1),  C = -T @ R^-1.
+// The reference runs ~25 small torch kernels for this (inverse via LU, two GEMMs, norms ...);
+// here it is one kernel forward and two backward (gradients reach R, T, focal, principal point,
+// which the pose-estimation demos optimise).
+#include "voge_common.h"
+
+namespace voge {
+
+struct Mat3 {
+  float m[9];
+};
+
+// inverse by adjugate; fp32 (R is a rotation in practice: cond ~ 1)
+__device__ __forceinline__ Mat3 inv3(const float *R) {
+  Mat3 o;
+  const float a = R[0], b = R[1], c = R[2], d = R[3], e = R[4], f = R[5], g = R[6], h = R[7], i = R[8];
+  const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const float det = a * A + b * B + c * C;
+  const float id = 1.0f / det;
+  o.m[0] = A * id;               o.m[1] = -(b * i - c * h) * id;  o.m[2] = (b * f - c * e) * id;
+  o.m[3] = B * id;               o.m[4] = (a * i - c * g) * id;   o.m[5] = -(a * f - c * d) * id;
+  o.m[6] = C * id;               o.m[7] = -(a * h - b * g) * id;  o.m[8] = (a * e - b * d) * id;
+  return o;
+}
+
+__global__ void __launch_bounds__(256)
+rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const float *__restrict__ focal,
+                const float *__restrict__ pp, const int row0, const int h, const int W,
+                float *__restrict__ rays, float *__restrict__ origin) {
+  const int b = blockIdx.y;
+  const Mat3 Ri = inv3(R + 9 * b);
+  const float fx = focal[2 * b], fy = focal[2 * b + 1], px = pp[2 * b], py = pp[2 * b + 1];
+  if (blockIdx.x == 0 && threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    const float *t = T + 3 * b;
+    origin[3 * b + c] = -(t[0] * Ri.m[c] + t[1] * Ri.m[3 + c] + t[2] * Ri.m[6 + c]);
+  }
+  const int n = h * W;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const int i = p / W, j = p - i * W;
+    const float vx = (px - ((float)j + 0.5f)) / fx;
+    const float vy = (py - ((float)(row0 + i) + 0.5f)) / fy;
+    const float wx = vx * Ri.m[0] + vy * Ri.m[3] + Ri.m[6];
+    const float wy = vx * Ri.m[1] + vy * Ri.m[4] + Ri.m[7];
+    const float wz = vx * Ri.m[2] + vy * Ri.m[5] + Ri.m[8];
+    const float inv = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);
+    float *o = rays + ((size_t)b * n + p) * 3;
+    o[0] = wx * inv; o[1] = wy * inv; o[2] = wz * inv;
+  }
+}
+
+// Backward, stage 1: per-batch sums over pixels.  part[b][0..8] = d_view^T g_dw (gradient of
+// R^-1 from the directions), [9] = sum g_vx * d vx/d fx, [10] = same for fy, [11],[12] = g_px, g_py.
+__global__ void __launch_bounds__(256)
+rays_bwd_reduce_kernel(const float *__restrict__ R, const float *__restrict__ focal,
+                       const float *__restrict__ pp, const float *__restrict__ g_rays, const int row0,
+                       const int h, const int W, float *__restrict__ part /* [B][16], zeroed */) {
+  __shared__ float red[4][13];
+  const int b = blockIdx.y;
+  const Mat3 Ri = inv3(R + 9 * b);
+  const float fx = focal[2 * b], fy = focal[2 * b + 1], px = pp[2 * b], py = pp[2 * b + 1];
+  float acc[13];
+#pragma unroll
+  for (int q = 0; q < 13; ++q) acc[q] = 0.0f;
+  const int n = h * W;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const int i = p / W, j = p - i * W;
+    const float ax = px - ((float)j + 0.5f), ay = py - ((float)(row0 + i) + 0.5f);
+    const float vx = ax / fx, vy = ay / fy;
+    const float wx = vx * Ri.m[0] + vy * Ri.m[3] + Ri.m[6];
+    const float wy = vx * Ri.m[1] + vy * Ri.m[4] + Ri.m[7];
+    const float wz = vx * Ri.m[2] + vy * Ri.m[5] + Ri.m[8];
+    const float inv = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);
+    const float ux = wx * inv, uy = wy * inv, uz = wz * inv;
+    const float *g = g_rays + ((size_t)b * n + p) * 3;
+    const float gu = g[0] * ux + g[1] * uy + g[2] * uz;
+    const float gx = (g[0] - ux * gu) * inv, gy = (g[1] - uy * gu) * inv, gz = (g[2] - uz * gu) * inv;  // g_dw
+    acc[0] += vx * gx; acc[1] += vx * gy; acc[2] += vx * gz;
+    acc[3] += vy * gx; acc[4] += vy * gy; acc[5] += vy * gz;
+    acc[6] += gx;      acc[7] += gy;      acc[8] += gz;
+    const float gvx = gx * Ri.m[0] + gy * Ri.m[1] + gz * Ri.m[2];   // g_dview = g_dw @ Rinv^T
+    const float gvy = gx * Ri.m[3] + gy * Ri.m[4] + gz * Ri.m[5];
+    acc[9] += -gvx * vx / fx;
+    acc[10] += -gvy * vy / fy;
+    acc[11] += gvx / fx;
+    acc[12] += gvy / fy;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 13; ++q) {
+    const float s = wave_sum(acc[q]);
+    if (lane == 0) red[wave][q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 13) {
+    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    unsafeAtomicAdd(part + 16 * b + threadIdx.x, s);
+  }
+}
+
+// Backward, stage 2: one thread per batch element turns the sums (+ the origin gradient) into
+// g_R, g_T, g_focal, g_pp.   d(R^-1) = -R^-1 dR R^-1  ->  g_R = -R^-T g_Rinv R^-T.
+__global__ void rays_bwd_finish_kernel(const float *__restrict__ R, const float *__restrict__ T,
+                                       const float *__restrict__ part, const float *__restrict__ g_origin,
+                                       const int B, float *__restrict__ g_R, float *__restrict__ g_T,
+                                       float *__restrict__ g_focal, float *__restrict__ g_pp) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const Mat3 Ri = inv3(R + 9 * b);
+  float G[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) G[q] = part[16 * b + q];
+  const float *t = T + 3 * b;
+  float go[3] = {0.f, 0.f, 0.f};
+  if (g_origin != nullptr) { go[0] = g_origin[3 * b]; go[1] = g_origin[3 * b + 1]; go[2] = g_origin[3 * b + 2]; }
+  // origin = -T @ Rinv :  g_Rinv += -T^T g_o ,  g_T = -g_o @ Rinv^T
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) G[3 * r + c] -= t[r] * go[c];
+  if (g_T != nullptr)
+    for (int r = 0; r < 3; ++r) g_T[3 * b + r] = -(go[0] * Ri.m[3 * r] + go[1] * Ri.m[3 * r + 1] + go[2] * Ri.m[3 * r + 2]);
+  if (g_R != nullptr) {
+    float M[9];  // Rinv^T @ G
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) M[3 * r + c] = Ri.m[r] * G[c] + Ri.m[3 + r] * G[3 + c] + Ri.m[6 + r] * G[6 + c];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)  // (M @ Rinv^T)[r][c] = sum_k M[r][k] * Rinv[c][k]
+        g_R[9 * b + 3 * r + c] = -(M[3 * r] * Ri.m[3 * c] + M[3 * r + 1] * Ri.m[3 * c + 1] + M[3 * r + 2] * Ri.m[3 * c + 2]);
+  }
+  if (g_focal != nullptr) { g_focal[2 * b] = part[16 * b + 9]; g_focal[2 * b + 1] = part[16 * b + 10]; }
+  if (g_pp != nullptr) { g_pp[2 * b] = part[16 * b + 11]; g_pp[2 * b + 1] = part[16 * b + 12]; }
+}
+
+}  // namespace voge
+
+using namespace voge;
+
+extern "C" int voge_rays_fwd(const float *R, const float *T, const float *focal, const float *pp, int B,
+                             int row0, int h, int W, float *rays, float *origin, voge_stream_t stream) {
+  if (B < 0 || h < 0 || W < 0) return VOGE_ERR_BAD_ARG;
+  if (B == 0) return 0;
+  if (!R || !T || !focal || !pp || !origin || ((size_t)h * W > 0 && !rays)) return VOGE_ERR_BAD_ARG;
+  const int n = h * W;
+  int blocks = (n + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rays_fwd_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, R, T, focal, pp, row0, h, W,
+                     rays, origin);
+  return launch_status();
+}
+
+extern "C" int voge_rays_bwd(const float *R, const float *T, const float *focal, const float *pp,
+                             const float *g_rays, const float *g_origin, int B, int row0, int h, int W,
+                             float *scratch /* [B][16] floats */, float *g_R, float *g_T, float *g_focal,
+                             float *g_pp, voge_stream_t stream) {
+  if (B < 0 || h < 0 || W < 0) return VOGE_ERR_BAD_ARG;
+  if (B == 0) return 0;
+  if (!R || !T || !focal || !pp || !scratch) return VOGE_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float) * 16 * (size_t)B, st);
+  if (e != hipSuccess) return (int)e;
+  const int n = h * W;
+  if (n > 0 && g_rays != nullptr) {
+    int blocks = (n + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(rays_bwd_reduce_kernel, dim3(blocks, B), dim3(256), 0, st, R, focal, pp, g_rays, row0, h, W,
+                       scratch);
+  }
+  hipLaunchKernelGGL(rays_bwd_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, st, R, T, scratch, g_origin, B, g_R,
+                     g_T, g_focal, g_pp);
+  return launch_status();
+}

@@ -270,6 +270,52 @@ class _Silhouette(torch.autograd.Function):
         return g_w
 
 
+class _PixelRays(torch.autograd.Function):
+    """Ray bundle of VoGE/Renderer.py:124-130: (R [B,3,3], T [B,3], focal [B,2], pp [B,2]) ->
+    unit world-space directions [B,h,W,3] of image rows row0..row0+h-1 and the camera centres [B,3]."""
+
+    @staticmethod
+    def forward(ctx, R, T, focal, pp, row0, h, W):
+        lib = _lib.load()
+        R_c, T_c = _dev(R, torch.float32, "R"), _dev(T, torch.float32, "T")
+        f_c, p_c = _dev(focal, torch.float32, "focal_length"), _dev(pp, torch.float32, "principal_point")
+        B = R_c.shape[0]
+        assert R_c.shape == (B, 3, 3) and T_c.shape == (B, 3) and f_c.shape == (B, 2) and p_c.shape == (B, 2)
+        rays = torch.empty((B, h, W, 3), dtype=torch.float32, device=R_c.device)
+        origin = torch.empty((B, 3), dtype=torch.float32, device=R_c.device)
+        with torch.cuda.device(R_c.device):
+            rc = lib.voge_rays_fwd(_p(R_c), _p(T_c), _p(f_c), _p(p_c), B, int(row0), int(h), int(W), _p(rays),
+                                   _p(origin), _stream())
+        _lib.check(rc, "voge_rays_fwd")
+        ctx.save_for_backward(R_c, T_c, f_c, p_c)
+        ctx.geom = (int(row0), int(h), int(W))
+        return rays, origin
+
+    @staticmethod
+    def backward(ctx, g_rays, g_origin):
+        lib = _lib.load()
+        R, T, f, pp = ctx.saved_tensors
+        row0, h, W = ctx.geom
+        B = R.shape[0]
+        gr = None if g_rays is None else _dev(g_rays, torch.float32, "grad_rays")
+        go = None if g_origin is None else _dev(g_origin, torch.float32, "grad_origin")
+        need = ctx.needs_input_grad
+        g_R = torch.empty_like(R) if need[0] else None
+        g_T = torch.empty_like(T) if need[1] else None
+        g_f = torch.empty_like(f) if need[2] else None
+        g_p = torch.empty_like(pp) if need[3] else None
+        scratch = torch.empty((B, 16), dtype=torch.float32, device=R.device)
+        with torch.cuda.device(R.device):
+            rc = lib.voge_rays_bwd(_p(R), _p(T), _p(f), _p(pp), _p(gr), _p(go), B, row0, h, W, _p(scratch), _p(g_R),
+                                   _p(g_T), _p(g_f), _p(g_p), _stream())
+        _lib.check(rc, "voge_rays_bwd")
+        return g_R, g_T, g_f, g_p, None, None, None
+
+
+def pixel_rays(R, T, focal, pp, row0, h, W):
+    return _PixelRays.apply(R, T, focal, pp, row0, h, W)
+
+
 def ray_trace_fine(mus, isigmas, rays, bin_points, thr_act, bin_size, n_assign):
     return _RayTraceVoGE.apply(mus, isigmas, rays, bin_points, thr_act, bin_size, n_assign)
 
