@@ -44,10 +44,9 @@ def stage_bytes(P, npix, K, C=3):
     return {
         "trace_fwd": P * 48 + npix * 12 + npix * K * 16,
         "composite_fwd": npix * K * 12 + npix * K * 4 + npix * 8,
-        "merge_fwd": npix * K * 8 + P * 4 * C + npix * 4 * C,
-        "blend_fwd": npix * K * 4 + 2 * npix * 4 * C,
-        "blend_bwd": npix * K * 4 + 2 * npix * 4 * C + npix * K * 4 + npix * 4 * C,
-        "merge_bwd": npix * 4 * C + npix * K * 8 + npix * K * 4 + P * 4 * C,
+        # fused merge+silhouette+blend: read idx,w + colours, write rgb,img / read idx,w,rgb,g_img, write g_w,g_col
+        "shade_fwd": npix * K * 8 + P * 4 * C + 2 * npix * 4 * C,
+        "shade_bwd": npix * K * 8 + 2 * npix * 4 * C + P * 4 * C + npix * K * 4 + P * 4 * C,
         "composite_bwd": npix * K * (12 + 4) + npix * K * 12,
         "trace_bwd": npix * K * 16 + npix * 12 + P * 48 + npix * 12 + P * 48,
     }
@@ -178,11 +177,10 @@ def main():
                                                              ws.numel(), P(o_i), P(o_l), P(o_a), P(o_d), st),
                 "composite_fwd": lambda: lib.voge_composite_fwd(P(sel[0]), P(sel[2]), P(sel[1]), P(sel[3]), 1.0, npix, K,
                                                                 P(g3[0]), P(vn), st),
-                "merge_fwd": lambda: lib.voge_merge_fwd(P(colors), P(idx), P(w), P(vn), npix, K, 3, N, 0, P(out3), st),
-                "blend_fwd": lambda: lib.voge_blend_fwd(P(rgb), P(w), P(bg), -1.0, npix, K, 3, P(out3), None, st),
-                "blend_bwd": lambda: lib.voge_blend_bwd(P(rgb), P(w), P(bg), -1.0, P(g_img), npix, K, 3, P(out3), P(g3[0]), st),
-                "merge_bwd": lambda: lib.voge_merge_bwd(P(colors), P(idx), P(w), P(vn), P(g_img), H, W, K, 3, N, P(g_attr),
-                                                        P(g3[0]), st),
+                "shade_fwd": lambda: lib.voge_shade_fwd(P(colors), P(idx), P(w), P(vn), P(bg), -1.0, npix, K, 3, N, 1, P(rgb),
+                                                        P(out3), None, st),
+                "shade_bwd": lambda: lib.voge_shade_bwd(P(colors), P(idx), P(w), P(vn), P(rgb), P(bg), -1.0, P(g_img), H, W, K,
+                                                        3, N, P(g_attr), P(g3[0]), st),
                 "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), 1.0, npix, K, P(g3[0]),
                                                                 P(g3[1]), P(g3[2]), st),
                 "trace_bwd": lambda: lib.voge_trace_bwd(P(mus), P(isg), P(rays), P(sel[0]), P(w), P(w), P(w), N, H, W, K,

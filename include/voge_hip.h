@@ -172,6 +172,30 @@ int voge_blend_bwd(const float *rgb, const float *weight, const float *bg, float
                    float *g_weight_add, voge_stream_t stream);
 
 /*
+ * Fused merge + silhouette + blend ("shade").  Replaces, in one pass: interpolate_attr ->
+ * merge_final (Aggregation.py:111-141), get_silhouette (Renderer.py:157-159) and
+ * to_colored_background (Renderer.py:162-171):
+ *   rgb = sum_{k < valid_num} attr[idx_k] w_k ;  sil = min(sum_k w_k, 1) ;
+ *   img = min(rgb + (1 - (thr > 0 ? sil > thr : sil)) * bg, 1)
+ * Outputs (each may be NULL): out_rgb [npix,C] (needed again by voge_shade_bwd), out_img
+ * [npix,C] (requires bg [C]), out_sil [npix].  fix_negative_idx as in voge_merge_fwd.
+ */
+int voge_shade_fwd(const float *attr, int32_t *idx, const float *weight, const int64_t *valid_num,
+                   const float *bg, float thr, long npix, int K, int C, long Nattr,
+                   int fix_negative_idx, float *out_rgb, float *out_img, float *out_sil,
+                   voge_stream_t stream);
+
+/*
+ * Backward of voge_shade_fwd for C <= 4.  g_up [nrows*W,C] is the gradient of img (bg != NULL;
+ * rgb = the forward's out_rgb) or of rgb itself (bg == NULL, rgb ignored).  Writes g_weight
+ * [nrows*W,K] (may be NULL) and g_attr [Nattr,C] (zero-filled here then accumulated; may be NULL).
+ */
+int voge_shade_bwd(const float *attr, const int32_t *idx, const float *weight,
+                   const int64_t *valid_num, const float *rgb, const float *bg, float thr,
+                   const float *g_up, long nrows, int W, int K, int C, long Nattr, float *g_attr,
+                   float *g_weight, voge_stream_t stream);
+
+/*
  * Pixel-ray generation.  Replaces: the PyTorch3D call in VoGE/Renderer.py:124-130
  * (NDCMultinomialRaysampler(unit_directions=True) on screen-space PerspectiveCameras):
  *   d_view(i,j) = [(px-j-0.5)/fx, (py-i-0.5)/fy, 1],  rays = normalise(d_view @ R^-1),

@@ -140,8 +140,12 @@ def to_colored_background(fragments: Fragments, colors: torch.Tensor,
                           background_color: Union[torch.Tensor, tuple, list] = (1, 1, 1), thr: float = -1):
     if not torch.is_tensor(background_color):
         background_color = torch.tensor(list(background_color), dtype=torch.float32, device=colors.device)
+    background_color = background_color.to(colors.device)
+    if colors.dim() == 2 and colors.shape[1] <= 4:
+        # merge + silhouette + blend fused in one kernel (and one backward kernel)
+        return ops.shade(colors, fragments.vert_weight, fragments.vert_index, fragments.valid_num, background_color, thr)
     rgb = interpolate_attr(fragments, colors)
-    return ops.blend(rgb, fragments.vert_weight, background_color.to(colors.device), thr)
+    return ops.blend(rgb, fragments.vert_weight, background_color, thr)
 
 
 def to_white_background(fragments: Fragments, colors: torch.Tensor, thr: float = -1):

@@ -31,6 +31,8 @@ SIGNATURES = {
     "voge_merge_fwd": (_c_int, [_c_void_p] * 4 + [_c_long, _c_int, _c_int, _c_long, _c_int] + [_c_void_p] * 2),
     "voge_merge_bwd": (_c_int, [_c_void_p] * 5 + [_c_long, _c_int, _c_int, _c_int, _c_long] + [_c_void_p] * 3),
     "voge_blend_fwd": (_c_int, [_c_void_p] * 3 + [_c_float, _c_long, _c_int, _c_int] + [_c_void_p] * 3),
+    "voge_shade_fwd": (_c_int, [_c_void_p] * 5 + [_c_float, _c_long, _c_int, _c_int, _c_long, _c_int] + [_c_void_p] * 4),
+    "voge_shade_bwd": (_c_int, [_c_void_p] * 6 + [_c_float, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_long] + [_c_void_p] * 3),
     "voge_rays_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p] * 3),
     "voge_rays_bwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_void_p] * 6),
     "voge_blend_bwd": (_c_int, [_c_void_p] * 3 + [_c_float, _c_void_p, _c_long, _c_int, _c_int] + [_c_void_p] * 3),

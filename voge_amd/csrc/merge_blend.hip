@@ -1,198 +1,349 @@
-// Attribute merge and background blend for gfx950.
+// Attribute merge, background blend, and their fusion ("shade") for gfx950.
 //
 // Reference behaviour being reproduced: merge_final (VoGE/Aggregation.py:111-141, reached via
 // interpolate_attr, VoGE/Renderer.py:153) and get_silhouette / to_colored_background
-// (VoGE/Renderer.py:157-171).  The reference gathers a [B,H,W,K,C] temporary; here each
-// thread owns one pixel and a group of up to 4 channels and accumulates in registers.
+// (VoGE/Renderer.py:157-171).  The reference gathers a [B,H,W,K,C] temporary and runs ~10
+// elementwise kernels; here ONE LANE OWNS ONE (pixel, slot): the per-slot arrays are read as
+// coalesced runs, the per-pixel sums are segmented wave reductions, and merge + silhouette +
+// blend happen in one pass (shade_fwd) / one backward pass (shade_bwd).
 #include "voge_common.h"
 
 namespace voge {
 
-__global__ void __launch_bounds__(256)
-merge_fwd_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx,
-                 const float *__restrict__ weight, const int64_t *__restrict__ valid_num,
-                 const long npix, const int K, const int C, const long Nattr, const int fix_idx,
-                 float *__restrict__ out) {
-  const int groups = (C + 3) / 4;
-  const long total = npix * groups;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const long pix = t / groups;
-    const int c0 = (int)(t - pix * groups) * 4;
-    const int nc = min(4, C - c0);
-    const int nv = (int)min((int64_t)K, max((int64_t)0, valid_num[pix]));
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < nv; ++k) {
-      int p = idx[pix * K + k];
-      p += (p < 0);
-      if (p < 0 || p >= Nattr) continue;
-      const float w = weight[pix * K + k];
-      const float *a = attr + (size_t)p * C + c0;
-      for (int c = 0; c < nc; ++c) acc[c] = fmaf(a[c], w, acc[c]);
-    }
-    for (int c = 0; c < nc; ++c) out[pix * C + c0 + c] = acc[c];
-  }
-}
-
-// The reference mutates the index tensor in place over ALL slots (Aggregation.py:131).
-__global__ void __launch_bounds__(256)
-fix_idx_kernel(int32_t *__restrict__ idx, const long n) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int p = idx[i];
-    if (p < 0) idx[i] = p + 1;
-  }
-}
-
-__global__ void __launch_bounds__(256)
-merge_bwd_kernel(const float *__restrict__ attr, const int32_t *__restrict__ idx,
-                 const float *__restrict__ weight, const int64_t *__restrict__ valid_num,
-                 const float *__restrict__ g_out, const long npix, const int K, const int C,
-                 const long Nattr, float *__restrict__ g_attr, float *__restrict__ g_weight) {
-  const long total = npix * K;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const long pix = t / K;
-    const int k = (int)(t - pix * K);
-    float gw = 0.0f;
-    if (k < valid_num[pix]) {
-      int p = idx[t];
-      p += (p < 0);
-      if (p >= 0 && p < Nattr) {
-        const float w = weight[t];
-        const float *a = attr + (size_t)p * C;
-        const float *g = g_out + pix * C;
-        for (int c = 0; c < C; ++c) {
-          const float gc = g[c];
-          gw = fmaf(gc, a[c], gw);
-          if (g_attr != nullptr && w != 0.0f && gc != 0.0f) unsafeAtomicAdd(g_attr + (size_t)p * C + c, w * gc);
-        }
-      }
-    }
-    if (g_weight != nullptr) g_weight[t] = gw;
-  }
-}
-
-// C <= 4 (colours): a workgroup owns a 16x16 pixel tile and accumulates the per-Gaussian
-// attribute gradient in an LDS hash table, flushed with one global atomic per (Gaussian,
-// channel) per tile (same scheme as trace_bwd_kernel).
-constexpr int kMT = 16, kMHS = 1024, kMProbe = 24;
-struct MergeBwdLds {
-  int keys[kMHS];
-  float vals[kMHS * 4];
-};
-
-__global__ void __launch_bounds__(256)
-merge_bwd_tile_kernel(const float *__restrict__ attr, const int32_t *__restrict__ idx,
-                      const float *__restrict__ weight, const int64_t *__restrict__ valid_num,
-                      const float *__restrict__ g_out, const long nrows, const int W, const int K,
-                      const int C, const long Nattr, float *__restrict__ g_attr,
-                      float *__restrict__ g_weight) {
-  __shared__ MergeBwdLds L;
-  const int tid = threadIdx.x;
-  const int tiles_x = (W + kMT - 1) / kMT;
-  const int x0 = (blockIdx.x % tiles_x) * kMT;
-  const long y0 = (long)(blockIdx.x / tiles_x) * kMT;
-  const int tw = min(kMT, W - x0);
-  const int th = (int)min((long)kMT, nrows - y0);
-  for (int i = tid; i < kMHS; i += 256) L.keys[i] = -1;
-  for (int i = tid; i < kMHS * 4; i += 256) L.vals[i] = 0.0f;
-  __syncthreads();
-  const int row_items = tw * K;
-  for (int r = 0; r < th; ++r) {
-    const long row_base = ((y0 + r) * W + x0) * (long)K;
-    for (int it = tid; it < row_items; it += 256) {
-      const long t = row_base + it;
-      const int lx = it / K, k = it - lx * K;
-      const long pix = (y0 + r) * W + x0 + lx;
-      float gw = 0.0f;
-      if (k < valid_num[pix]) {
-        int p = idx[t];
-        p += (p < 0);
-        if (p >= 0 && p < Nattr) {
-          const float w = weight[t];
-          float ga[4] = {0.f, 0.f, 0.f, 0.f};
-          bool any = false;
-          for (int c = 0; c < C; ++c) {
-            const float gc = g_out[pix * C + c];
-            gw = fmaf(gc, attr[(size_t)p * C + c], gw);
-            ga[c] = w * gc;
-            any = any || (ga[c] != 0.0f);
-          }
-          if (g_attr != nullptr && any) {
-            unsigned h = ((unsigned)p * 2654435761u) >> 22;
-            int slot = -1;
-#pragma unroll 1
-            for (int pr = 0; pr < kMProbe; ++pr) {
-              const int old = atomicCAS(&L.keys[h], -1, p);
-              if (old == -1 || old == p) { slot = (int)h; break; }
-              h = (h + 1) & (kMHS - 1);
-            }
-            if (slot >= 0) {
-              for (int c = 0; c < C; ++c) atomicAdd(&L.vals[slot * 4 + c], ga[c]);
-            } else {
-              for (int c = 0; c < C; ++c) unsafeAtomicAdd(g_attr + (size_t)p * C + c, ga[c]);
-            }
-          }
-        }
-      }
-      if (g_weight != nullptr) g_weight[t] = gw;
-    }
-  }
-  __syncthreads();
-  if (g_attr != nullptr) {
-    // 4 adjacent lanes per table entry -> adjacent floats of g_attr[p]: lane-coalesced atomics
-    const int c = tid & 3;
-    for (int s = tid >> 2; s < kMHS; s += 64) {
-      const int p = L.keys[s];
-      if (p >= 0 && c < C) unsafeAtomicAdd(g_attr + (size_t)p * C + c, L.vals[s * 4 + c]);
-    }
-  }
-}
-
 // min(x, 1) passes the gradient where x < 1 and half of it at the tie, like torch.min.
 __device__ __forceinline__ float clamp1_pass(float x) { return x < 1.0f ? 1.0f : (x == 1.0f ? 0.5f : 0.0f); }
 
+constexpr int kRun = 8;      // pixels per wave run: their kRun*K slots are one contiguous stream
+constexpr int kShadeU = 4;   // 64-slot batches whose loads are issued together
+
+// Lane layout of the simple per-pixel kernels below: lpp = min(K, 64) lanes per pixel, ppi = 64 / lpp
+// pixels per wave instruction, `sub` = which of those pixels, `kl` = slot within the chunk.
+constexpr int kShadePixPerWave = 16;
+struct SlotLanes {
+  int lpp, ppi, sub, kl;
+};
+__device__ __forceinline__ SlotLanes slot_lanes(const int K, const int lane) {
+  SlotLanes s;
+  s.lpp = min(K, 64);
+  s.ppi = 64 / s.lpp;
+  s.sub = lane / s.lpp;
+  s.kl = lane - s.sub * s.lpp;
+  return s;
+}
+// broadcast the value held by the first lane of each lpp-lane segment to the whole segment
+__device__ __forceinline__ float seg_bcast(const float x, const int lane, const int kl) {
+  return __shfl(x, lane - kl, 64);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: rgb = sum_{k < valid} attr[idx_k] w_k ; sil = min(sum_k w_k, 1) ;
+//          img = min(rgb + (1 - mask(sil)) bg, 1).   Any of out_rgb / out_img / out_sil may be NULL;
+//          attr == NULL skips the merge (silhouette / blend of a given rgb_in).
+// A wave streams the kRun*K slots of kRun consecutive pixels, one lane per slot; per-pixel sums
+// are segmented wave reductions accumulated in a few LDS words.
+// ------------------------------------------------------------------------------------------
+struct ShadeFwdLds {
+  float acc[kRun][5];   // up to 4 channels + sum of weights
+};
+
 __global__ void __launch_bounds__(256)
-blend_fwd_kernel(const float *__restrict__ rgb, const float *__restrict__ weight,
-                 const float *__restrict__ bg, const float thr, const long npix, const int K,
-                 const int C, float *__restrict__ out, float *__restrict__ sil_out) {
-  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
-    float s = 0.0f;
-    for (int k = 0; k < K; ++k) s += weight[pix * K + k];
-    float sil = fminf(s, 1.0f);
-    if (sil_out != nullptr) sil_out[pix] = sil;
-    if (thr > 0.0f) sil = sil > thr ? 1.0f : 0.0f;
-    for (int c = 0; c < C; ++c) out[pix * C + c] = fminf(fmaf(1.0f - sil, bg[c], rgb[pix * C + c]), 1.0f);
+shade_fwd_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx, const float *__restrict__ weight,
+                 const int64_t *__restrict__ valid_num, const float *__restrict__ rgb_in,
+                 const float *__restrict__ bg, const float thr, const long npix, const int K, const int C,
+                 const long Nattr, const int fix_idx, float *__restrict__ out_rgb, float *__restrict__ out_img,
+                 float *__restrict__ out_sil) {
+  __shared__ ShadeFwdLds Ls[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  ShadeFwdLds &L = Ls[wave];
+  const long run = (long)blockIdx.x * 4 + wave;
+  const long pix0 = run * kRun;
+  if (pix0 >= npix) return;  // waves are independent
+  const int npx = (int)min((long)kRun, npix - pix0);
+  const int n_items = npx * K;
+  const int nit = (n_items + 63) >> 6;
+  const long base = pix0 * K;
+  for (int c0 = 0; c0 < max(C, 1); c0 += 4) {
+    const int nc = max(0, min(4, C - c0));
+    if (lane < kRun * 5) (&L.acc[0][0])[lane] = 0.0f;
+    for (int it0 = 0; it0 < nit; it0 += kShadeU) {
+      float w[kShadeU];
+      int p[kShadeU], lx[kShadeU];
+      bool take[kShadeU];
+#pragma unroll
+      for (int u = 0; u < kShadeU; ++u) {
+        const int j = (it0 + u) * 64 + lane;
+        const bool ok = (it0 + u < nit) && (j < n_items);
+        lx[u] = ok ? j / K : 64 + lane;
+        w[u] = ok ? weight[base + j] : 0.0f;
+        p[u] = -1;
+        take[u] = false;
+        if (ok && attr != nullptr) {
+          const int raw = idx[base + j];
+          p[u] = raw + (raw < 0);
+          if (fix_idx && c0 == 0 && raw < 0) idx[base + j] = raw + 1;   // Aggregation.py:131
+          const int k = j - lx[u] * K;
+          const int64_t nv = valid_num[pix0 + lx[u]];
+          take[u] = (k < nv) && (p[u] >= 0) && (p[u] < Nattr) && (w[u] != 0.0f);
+        }
+      }
+      float a[kShadeU][4];
+#pragma unroll
+      for (int u = 0; u < kShadeU; ++u) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[u][c] = (take[u] && c < nc) ? attr[(size_t)p[u] * C + c0 + c] * w[u] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kShadeU; ++u) {
+        if (it0 + u >= nit) break;  // uniform
+        const int prev = __shfl_up(lx[u], 1, 64);
+        const bool head = (lane == 0 || prev != lx[u]) && lx[u] < kRun;
+        for (int c = 0; c < nc; ++c) {
+          const float v = seg_sum_key(a[u][c], lx[u], lane);
+          if (head) L.acc[lx[u]][c] += v;
+        }
+        if (c0 == 0) {
+          const float v = seg_sum_key(w[u], lx[u], lane);
+          if (head) L.acc[lx[u]][4] += v;
+        }
+      }
+    }
+    // finalise the run: lane = (pixel, channel)
+    if (lane < npx * 4) {
+      const int x = lane >> 2, c = lane & 3;
+      const long pix = pix0 + x;
+      if (c0 == 0 && c == 0 && out_sil != nullptr) out_sil[pix] = fminf(L.acc[x][4], 1.0f);
+      if (c < nc) {
+        float sil = fminf(L.acc[x][4], 1.0f);
+        if (thr > 0.0f) sil = sil > thr ? 1.0f : 0.0f;
+        const float v = (attr != nullptr) ? L.acc[x][c] : rgb_in[pix * C + c0 + c];
+        if (out_rgb != nullptr) out_rgb[pix * C + c0 + c] = v;
+        if (out_img != nullptr) out_img[pix * C + c0 + c] = fminf(fmaf(1.0f - sil, bg[c0 + c], v), 1.0f);
+      }
+    }
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward for C <= 4.  A wave owns an 8x8 pixel tile (locality for the attribute-gradient
+// table) and streams it row by row, one lane per slot.
+//   blend part (bg != NULL): g_rgb = g_up * [x < 1], x = rgb + (1 - mask) bg ;
+//                            g_sum_w = -(sum_c g_rgb bg) * [sum w < 1]   (0 when thr > 0)
+//   merge part             : g_w[k] = [k < valid] <g_rgb, attr[idx_k]> + g_sum_w ;
+//                            g_attr[idx_k] += [k < valid] w_k g_rgb   (wave-private LDS table,
+//                            flushed with lane-coalesced atomics)
+// bg == NULL: g_up is the gradient of the merged attributes themselves (interpolate_attr).
+// ------------------------------------------------------------------------------------------
+constexpr int kShadeWaves = 4;
+constexpr int kShadeNE = 256;
+
+struct ShadeBwdLds {
+  WaveTable<kShadeNE, 1> tab;
+  float wsum[kRun];
+  float gr[kRun][4];
+  float gsw[kRun];
+};
+
+__global__ void __launch_bounds__(64 * kShadeWaves)
+shade_bwd_tile_kernel(const float *__restrict__ attr, const int32_t *__restrict__ idx,
+                      const float *__restrict__ weight, const int64_t *__restrict__ valid_num,
+                      const float *__restrict__ rgb, const float *__restrict__ bg, const float thr,
+                      const float *__restrict__ g_up, const long nrows, const int W, const int K, const int C,
+                      const long Nattr, float *__restrict__ g_attr, float *__restrict__ g_weight) {
+  __shared__ ShadeBwdLds Ls[kShadeWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  ShadeBwdLds &L = Ls[wave];
+  const int tiles_x = (W + 7) / 8;
+  const long ntiles = (long)tiles_x * ((nrows + 7) / 8);
+  const long tile = (long)blockIdx.x * kShadeWaves + wave;
+  if (tile >= ntiles) return;  // waves are independent
+  const int x0 = (int)(tile % tiles_x) * 8;
+  const long y0 = (tile / tiles_x) * 8;
+  wt_clear(L.tab, lane);
+  const int tw = min(8, W - x0);
+  const int n_items = tw * K;
+  const int nit = (n_items + 63) >> 6;
+  for (int r = 0; r < 8; ++r) {
+    const long py = y0 + r;
+    if (py >= nrows) break;
+    const long pix0 = py * W + x0;
+    const long base = pix0 * K;
+    // ---- per-pixel upstream gradient (and, for the blend, the silhouette) -> LDS ----
+    if (bg != nullptr) {
+      if (lane < kRun) L.wsum[lane] = 0.0f;
+      for (int it = 0; it < nit; ++it) {
+        const int j = it * 64 + lane;
+        const bool ok = j < n_items;
+        const int lx = ok ? j / K : 64 + lane;
+        const float v = seg_sum_key(ok ? weight[base + j] : 0.0f, lx, lane);
+        const int prev = __shfl_up(lx, 1, 64);
+        if ((lane == 0 || prev != lx) && lx < kRun) L.wsum[lx] += v;
+      }
+    }
+    if (lane < tw) {
+      const long pix = pix0 + lane;
+      float g_sum_w = 0.0f;
+      float g[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bg != nullptr) {
+        const float ws = L.wsum[lane];
+        float sil = fminf(ws, 1.0f);
+        const float pass_s = (thr > 0.0f) ? 0.0f : clamp1_pass(ws);
+        if (thr > 0.0f) sil = sil > thr ? 1.0f : 0.0f;
+        float g_mask = 0.0f;
+        for (int c = 0; c < C; ++c) {
+          const float x = fmaf(1.0f - sil, bg[c], rgb[pix * C + c]);
+          g[c] = g_up[pix * C + c] * clamp1_pass(x);
+          g_mask = fmaf(-g[c], bg[c], g_mask);
+        }
+        g_sum_w = g_mask * pass_s;
+      } else {
+        for (int c = 0; c < C; ++c) g[c] = g_up[pix * C + c];
+      }
+      for (int c = 0; c < 4; ++c) L.gr[lane][c] = g[c];
+      L.gsw[lane] = g_sum_w;
+    }
+    // ---- slots of the row: g_weight and the attribute-gradient table ----
+    for (int it0 = 0; it0 < nit; it0 += kShadeU) {
+      float w[kShadeU];
+      int p[kShadeU], lx[kShadeU];
+      bool ok[kShadeU];
+#pragma unroll
+      for (int u = 0; u < kShadeU; ++u) {
+        const int j = (it0 + u) * 64 + lane;
+        ok[u] = (it0 + u < nit) && (j < n_items);
+        lx[u] = ok[u] ? j / K : 0;
+        w[u] = 0.0f;
+        p[u] = -1;
+        if (ok[u]) {
+          const int k = j - lx[u] * K;
+          if (k < valid_num[pix0 + lx[u]]) {
+            const int raw = idx[base + j];
+            const int q = raw + (raw < 0);
+            if (q >= 0 && q < Nattr) { p[u] = q; w[u] = weight[base + j]; }
+          }
+        }
+      }
+      float a[kShadeU][4];
+#pragma unroll
+      for (int u = 0; u < kShadeU; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[u][c] = (p[u] >= 0 && c < C) ? attr[(size_t)p[u] * C + c] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < kShadeU; ++u) {
+        if (it0 + u >= nit) break;  // uniform
+        const float g0 = L.gr[lx[u]][0], g1 = L.gr[lx[u]][1], g2 = L.gr[lx[u]][2], g3 = L.gr[lx[u]][3];
+        if (ok[u] && g_weight != nullptr) {
+          const float gw = fmaf(g3, a[u][3], fmaf(g2, a[u][2], fmaf(g1, a[u][1], fmaf(g0, a[u][0], L.gsw[lx[u]]))));
+          g_weight[base + (it0 + u) * 64 + lane] = gw;
+        }
+        if (g_attr != nullptr) {
+          const float4 v[1] = {make_float4(w[u] * g0, w[u] * g1, w[u] * g2, w[u] * g3)};
+          const bool live = (p[u] >= 0) && (v[0].x != 0.0f || v[0].y != 0.0f || v[0].z != 0.0f || v[0].w != 0.0f);
+          const int slot = wt_find(L.tab, p[u], live);
+          wt_add(L.tab, slot, v, live && slot >= 0, lane);
+          if (live && slot < 0) {
+            const float o[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
+            for (int c = 0; c < C; ++c) unsafeAtomicAdd(g_attr + (size_t)p[u] * C + c, o[c]);
+          }
+        }
+      }
+    }
+  }
+  if (g_attr != nullptr) {
+    // 4 adjacent lanes per table entry -> adjacent floats of g_attr[p]: lane-coalesced atomics
+    const int c = lane & 3;
+    const float *vals = reinterpret_cast<const float *>(L.tab.vals);
+    for (int s = lane >> 2; s < kShadeNE; s += 16) {
+      const int p = L.tab.keys[s];
+      if (p >= 0 && c < C) unsafeAtomicAdd(g_attr + (size_t)p * C + c, vals[s * 4 + c]);
+    }
+  }
+}
+
+// merge backward for C > 4 (feature maps): one (pixel, slot) item per wave iteration, lanes over
+// channels: g_up / attr rows are read coalesced and the scatter is a run of C adjacent atomics.
 __global__ void __launch_bounds__(256)
-blend_bwd_kernel(const float *__restrict__ rgb, const float *__restrict__ weight,
-                 const float *__restrict__ bg, const float thr, const float *__restrict__ g_out,
-                 const long npix, const int K, const int C, float *__restrict__ g_rgb,
-                 float *__restrict__ g_weight_add) {
-  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
-    float s = 0.0f;
-    for (int k = 0; k < K; ++k) s += weight[pix * K + k];
-    float sil = fminf(s, 1.0f);
-    const float pass_s = (thr > 0.0f) ? 0.0f : clamp1_pass(s);
+merge_bwd_chan_kernel(const float *__restrict__ attr, const int32_t *__restrict__ idx,
+                      const float *__restrict__ weight, const int64_t *__restrict__ valid_num,
+                      const float *__restrict__ g_up, const long npix, const int K, const int C,
+                      const long Nattr, float *__restrict__ g_attr, float *__restrict__ g_weight) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  for (long pix = wave_id; pix < npix; pix += nwaves) {
+    const int nv = (int)min((int64_t)K, max((int64_t)0, valid_num[pix]));
+    for (int k = 0; k < K; ++k) {
+      const long f = pix * K + k;
+      float gw = 0.0f;
+      if (k < nv) {
+        const int raw = idx[f];
+        const int p = raw + (raw < 0);
+        if (p >= 0 && p < Nattr) {
+          const float w = weight[f];
+          for (int c = lane; c < C; c += 64) {
+            const float g = g_up[pix * C + c];
+            gw = fmaf(g, attr[(size_t)p * C + c], gw);
+            if (g_attr != nullptr && w != 0.0f && g != 0.0f) unsafeAtomicAdd(g_attr + (size_t)p * C + c, w * g);
+          }
+          gw = wave_sum(gw);
+        }
+      }
+      if (g_weight != nullptr && lane == 0) g_weight[f] = gw;
+    }
+  }
+}
+
+// blend backward alone (C > 4, or a caller that merged separately): g_rgb [npix,C] and the
+// additive silhouette term g_weight_add [npix,K].
+__global__ void __launch_bounds__(256)
+blend_bwd_kernel(const float *__restrict__ rgb, const float *__restrict__ weight, const float *__restrict__ bg,
+                 const float thr, const float *__restrict__ g_out, const long npix, const int K, const int C,
+                 float *__restrict__ g_rgb, float *__restrict__ g_weight_add) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const SlotLanes sl = slot_lanes(K, lane);
+  const long pix_begin = wave_id * kShadePixPerWave;
+  for (int i0 = 0; i0 < kShadePixPerWave; i0 += sl.ppi) {
+    const long pix = pix_begin + i0 + sl.sub;
+    const bool pix_ok = (sl.sub < sl.ppi) && (i0 + sl.sub < kShadePixPerWave) && (pix < npix);
+    float wsum = 0.0f;
+    for (int kc = 0; kc < K; kc += 64) {
+      const int k = kc + sl.kl;
+      if (pix_ok && k < K) wsum += weight[pix * K + k];
+    }
+    wsum = seg_bcast(seg_sum(wsum, lane, sl.lpp), lane, sl.kl);
+    float sil = fminf(wsum, 1.0f);
+    const float pass_s = (thr > 0.0f) ? 0.0f : clamp1_pass(wsum);
     if (thr > 0.0f) sil = sil > thr ? 1.0f : 0.0f;
     float g_mask = 0.0f;
-    for (int c = 0; c < C; ++c) {
-      const float x = fmaf(1.0f - sil, bg[c], rgb[pix * C + c]);
-      const float g = g_out[pix * C + c] * clamp1_pass(x);
-      if (g_rgb != nullptr) g_rgb[pix * C + c] = g;
-      g_mask = fmaf(-g, bg[c], g_mask);
+    if (pix_ok) {
+      for (int c = sl.kl; c < C; c += sl.lpp) {
+        const float x = fmaf(1.0f - sil, bg[c], rgb[pix * C + c]);
+        const float g = g_out[pix * C + c] * clamp1_pass(x);
+        if (g_rgb != nullptr) g_rgb[pix * C + c] = g;
+        g_mask = fmaf(-g, bg[c], g_mask);
+      }
     }
+    g_mask = seg_bcast(seg_sum(g_mask, lane, sl.lpp), lane, sl.kl);
     if (g_weight_add != nullptr) {
       const float gs = g_mask * pass_s;
-      for (int k = 0; k < K; ++k) g_weight_add[pix * K + k] = gs;
+      for (int kc = 0; kc < K; kc += 64) {
+        const int k = kc + sl.kl;
+        if (pix_ok && k < K) g_weight_add[pix * K + k] = gs;
+      }
     }
   }
 }
 
-static inline unsigned grid_for(long items) {
-  long b = (items + 255) / 256;
+static inline unsigned shade_grid(long npix) {   // blend_bwd_kernel: kShadePixPerWave pixels per wave
+  const long waves = (npix + kShadePixPerWave - 1) / kShadePixPerWave;
+  long b = (waves + 3) / 4;
   if (b < 1) b = 1;
-  if (b > 256L * 32) b = 256L * 32;
+  return (unsigned)b;
+}
+static inline unsigned run_grid(long npix) {     // shade_fwd_kernel: kRun pixels per wave
+  const long waves = (npix + kRun - 1) / kRun;
+  long b = (waves + 3) / 4;
+  if (b < 1) b = 1;
   return (unsigned)b;
 }
 
@@ -200,25 +351,53 @@ static inline unsigned grid_for(long items) {
 
 using namespace voge;
 
+extern "C" int voge_shade_fwd(const float *attr, int32_t *idx, const float *weight, const int64_t *valid_num,
+                              const float *bg, float thr, long npix, int K, int C, long Nattr,
+                              int fix_negative_idx, float *out_rgb, float *out_img, float *out_sil,
+                              voge_stream_t stream) {
+  if (npix < 0 || K <= 0 || C < 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
+  if (npix == 0) return 0;
+  if (!weight) return VOGE_ERR_BAD_ARG;
+  if (C > 0 && (!attr || !idx || !valid_num)) return VOGE_ERR_BAD_ARG;
+  if (out_img && !bg) return VOGE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(shade_fwd_kernel, dim3(run_grid(npix)), dim3(256), 0, (hipStream_t)stream, attr, idx, weight,
+                     valid_num, nullptr, bg, thr, npix, K, C, Nattr, fix_negative_idx, out_rgb, out_img, out_sil);
+  return launch_status();
+}
+
+extern "C" int voge_shade_bwd(const float *attr, const int32_t *idx, const float *weight,
+                              const int64_t *valid_num, const float *rgb, const float *bg, float thr,
+                              const float *g_up, long nrows, int W, int K, int C, long Nattr, float *g_attr,
+                              float *g_weight, voge_stream_t stream) {
+  if (nrows < 0 || W < 0 || K <= 0 || C <= 0 || C > 4 || Nattr < 0) return VOGE_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (g_attr != nullptr && Nattr > 0) {
+    hipError_t e = hipMemsetAsync(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (nrows * W == 0) return 0;
+  if (!idx || !weight || !valid_num || !g_up || (Nattr > 0 && !attr) || (bg && !rgb)) return VOGE_ERR_BAD_ARG;
+  const long tiles = (long)((W + 7) / 8) * ((nrows + 7) / 8);
+  hipLaunchKernelGGL(shade_bwd_tile_kernel, dim3((unsigned)((tiles + kShadeWaves - 1) / kShadeWaves)),
+                     dim3(64 * kShadeWaves), 0, st, attr, idx, weight, valid_num, rgb, bg, thr, g_up, nrows, W, K, C,
+                     Nattr, g_attr, g_weight);
+  return launch_status();
+}
+
 extern "C" int voge_merge_fwd(const float *attr, int32_t *idx, const float *weight,
                               const int64_t *valid_num, long npix, int K, int C, long Nattr,
                               int fix_negative_idx, float *out, voge_stream_t stream) {
-  if (npix < 0 || K <= 0 || C <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
-  if (npix == 0) return 0;
-  if (!idx || !weight || !valid_num || !out || (Nattr > 0 && !attr)) return VOGE_ERR_BAD_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(merge_fwd_kernel, dim3(grid_for(npix * ((C + 3) / 4))), dim3(256), 0, st, attr, idx, weight,
-                     valid_num, npix, K, C, Nattr, fix_negative_idx, out);
-  int rc = launch_status();
-  if (rc || !fix_negative_idx) return rc;
-  hipLaunchKernelGGL(fix_idx_kernel, dim3(grid_for(npix * K)), dim3(256), 0, st, idx, npix * K);
-  return launch_status();
+  if (C <= 0 || !out) return VOGE_ERR_BAD_ARG;
+  return voge_shade_fwd(attr, idx, weight, valid_num, nullptr, -1.0f, npix, K, C, Nattr, fix_negative_idx, out, nullptr,
+                        nullptr, stream);
 }
 
 extern "C" int voge_merge_bwd(const float *attr, const int32_t *idx, const float *weight,
                               const int64_t *valid_num, const float *g_out, long nrows, int W, int K,
                               int C, long Nattr, float *g_attr, float *g_weight, voge_stream_t stream) {
   if (nrows < 0 || W < 0 || K <= 0 || C <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
+  if (C <= 4) return voge_shade_bwd(attr, idx, weight, valid_num, nullptr, nullptr, -1.0f, g_out, nrows, W, K, C, Nattr,
+                                    g_attr, g_weight, stream);
   hipStream_t st = (hipStream_t)stream;
   if (g_attr != nullptr && Nattr > 0) {
     hipError_t e = hipMemsetAsync(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
@@ -227,25 +406,21 @@ extern "C" int voge_merge_bwd(const float *attr, const int32_t *idx, const float
   const long npix = nrows * W;
   if (npix == 0) return 0;
   if (!idx || !weight || !valid_num || !g_out || (Nattr > 0 && !attr)) return VOGE_ERR_BAD_ARG;
-  if (C <= 4) {
-    const long tiles = (long)((W + kMT - 1) / kMT) * ((nrows + kMT - 1) / kMT);
-    hipLaunchKernelGGL(merge_bwd_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, st, attr, idx, weight, valid_num,
-                       g_out, nrows, W, K, C, Nattr, g_attr, g_weight);
-  } else {
-    hipLaunchKernelGGL(merge_bwd_kernel, dim3(grid_for(npix * K)), dim3(256), 0, st, attr, idx, weight, valid_num,
-                       g_out, npix, K, C, Nattr, g_attr, g_weight);
-  }
+  long blocks = (npix + 3) / 4;
+  if (blocks > 256L * 16) blocks = 256L * 16;
+  hipLaunchKernelGGL(merge_bwd_chan_kernel, dim3((unsigned)blocks), dim3(256), 0, st, attr, idx, weight, valid_num,
+                     g_out, npix, K, C, Nattr, g_attr, g_weight);
   return launch_status();
 }
 
 extern "C" int voge_blend_fwd(const float *rgb, const float *weight, const float *bg, float thr,
                               long npix, int K, int C, float *out, float *sil_out,
                               voge_stream_t stream) {
-  if (npix < 0 || K <= 0 || C <= 0) return VOGE_ERR_BAD_ARG;
+  if (npix < 0 || K <= 0 || C < 0) return VOGE_ERR_BAD_ARG;
   if (npix == 0) return 0;
-  if (!rgb || !weight || !bg || !out) return VOGE_ERR_BAD_ARG;
-  hipLaunchKernelGGL(blend_fwd_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, rgb, weight, bg,
-                     thr, npix, K, C, out, sil_out);
+  if (!weight || (C > 0 && (!rgb || !bg || !out))) return VOGE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(shade_fwd_kernel, dim3(run_grid(npix)), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr,
+                     weight, nullptr, rgb, bg, thr, npix, K, C, 0L, 0, nullptr, out, sil_out);
   return launch_status();
 }
 
@@ -255,7 +430,7 @@ extern "C" int voge_blend_bwd(const float *rgb, const float *weight, const float
   if (npix < 0 || K <= 0 || C <= 0) return VOGE_ERR_BAD_ARG;
   if (npix == 0) return 0;
   if (!rgb || !weight || !bg || !g_out) return VOGE_ERR_BAD_ARG;
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, rgb, weight, bg,
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(shade_grid(npix)), dim3(256), 0, (hipStream_t)stream, rgb, weight, bg,
                      thr, g_out, npix, K, C, g_rgb, g_weight_add);
   return launch_status();
 }

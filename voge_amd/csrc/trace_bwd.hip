@@ -12,10 +12,11 @@
 //      g_ray = g_dsd (A + A^T) d + c1 (A^T v - t A d) + g_act t ( -2 A^T v + t (A - A^T) d )
 //    which expand to exactly g_ksk/g_msk/g_msm of ray_trace_voge.cu:324-326 pushed through
 //    Innerdot3dBackward (checked against the embedded known answer, :381-448).
-// 2. A wave owns an 8x8 pixel tile and walks it pixel by pixel with ONE LANE PER SLOT (coalesced
-//    160-byte runs of the flat [npix*K] arrays).  The 12 per-Gaussian sums are accumulated in a
-//    wave-private LDS table keyed by Gaussian index with plain read-modify-write (a pixel never
-//    lists a Gaussian twice, so the lanes of one instruction never collide), then flushed with
+// 2. A wave owns an 8x8 pixel tile and streams it row by row, ONE LANE PER SLOT: the 8*K slots of
+//    a tile row are one contiguous run of the flat [npix*K] arrays, read 64 at a time with the
+//    loads of four batches in flight.  The 12 per-Gaussian sums are accumulated in a wave-private
+//    LDS table keyed by Gaussian index with plain read-modify-write (lanes of one instruction
+//    that share a Gaussian elect one writer per round), then flushed with
 //    lane-coalesced global atomics: 12 adjacent lanes add to 12 adjacent floats of one 64-byte
 //    line of a padded [P][16] accumulator.  g_ray is pixel-owned: segmented wave sum, plain stores.
 #include "voge_common.h"
@@ -24,10 +25,11 @@ namespace voge {
 
 constexpr int kBwdWaves = 2;    // waves per workgroup (each wave is independent)
 constexpr int kBwdNE = 256;     // table entries per wave (an 8x8 tile touches ~100-200 Gaussians)
+constexpr int kBwdU = 4;        // 64-slot batches whose loads are issued together
 
 struct BwdWaveLds {
   WaveTable<kBwdNE, 3> tab;     // key = Gaussian index, values = g_mu (3) + g_A (9)
-  float ray[64 * 3];
+  float ray[8 * 3];             // g_ray of the current 8-pixel row
 };
 
 __global__ void __launch_bounds__(64 * kBwdWaves)
@@ -46,97 +48,111 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
   const int x0 = (int)(tile % tiles_x) * 8;
   const long y0 = (tile / tiles_x) * 8;
   wt_clear(L.tab, lane);
-  for (int i = lane; i < 64 * 3; i += 64) L.ray[i] = 0.0f;
+  if (lane < 24) L.ray[lane] = 0.0f;
+  const int tw = min(8, W - x0);
+  const int n_items = tw * K;              // slots of one 8-pixel row: one contiguous run
+  const int nit = (n_items + 63) >> 6;
 
-  const int lpp = min(K, 64);   // lanes per pixel
-  const int ppi = 64 / lpp;     // pixels per wave instruction
-  const int sub = lane / lpp, kl = lane - sub * lpp;
-  for (int i0 = 0; i0 < 64; i0 += ppi) {
-    const int i = i0 + sub;
-    const int px = x0 + (i & 7);
-    const long py = y0 + (i >> 3);
-    const bool pix_ok = (sub < ppi) && (i < 64) && (px < W) && (py < nrows);
-    const long pix = py * W + px;
-    float dx = 0.f, dy = 0.f, dz = 0.f;
-    if (pix_ok) { dx = rays[3 * pix + 0]; dy = rays[3 * pix + 1]; dz = rays[3 * pix + 2]; }
-    for (int kc = 0; kc < K; kc += 64) {
-      const int k = kc + kl;
-      int p = -1;
-      float gl = 0.f, ga = 0.f, gd = 0.f;
-      if (pix_ok && k < K) {
-        const long pid = pix * K + k;
-        p = idx[pid];
-        if (p >= 0 && p < P) { gl = g_len[pid]; ga = g_act[pid]; gd = g_dsd[pid]; } else p = -1;
+  for (int r = 0; r < 8; ++r) {
+    const long py = y0 + r;
+    if (py >= nrows) break;
+    const long pix0 = py * W + x0;
+    const long base = pix0 * K;
+    for (int it0 = 0; it0 < nit; it0 += kBwdU) {
+      int p[kBwdU], lx[kBwdU];
+      float gl[kBwdU], ga[kBwdU], gd[kBwdU];
+      bool live[kBwdU];
+#pragma unroll
+      for (int u = 0; u < kBwdU; ++u) {
+        const int j = (it0 + u) * 64 + lane;
+        const bool ok = (it0 + u < nit) && (j < n_items);
+        p[u] = ok ? idx[base + j] : -1;
+        gl[u] = ok ? g_len[base + j] : 0.0f;
+        ga[u] = ok ? g_act[base + j] : 0.0f;
+        gd[u] = ok ? g_dsd[base + j] : 0.0f;
+        lx[u] = ok ? j / K : 64 + lane;      // inactive lanes: private segment keys
       }
-      const bool live = (p >= 0) && !(gl == 0.0f && ga == 0.0f && gd == 0.0f);
-      float4 val[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-      float rx = 0.f, ryv = 0.f, rz = 0.f;
-      if (live) {
-        const float4 r0 = rec[3 * (size_t)p], r1 = rec[3 * (size_t)p + 1], r2 = rec[3 * (size_t)p + 2];
-        const float mx = r0.x, my = r0.y, mz = r0.z;
-        const float A[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-        const float adx = fmaf(A[2], dz, fmaf(A[1], dy, A[0] * dx));
-        const float ady = fmaf(A[5], dz, fmaf(A[4], dy, A[3] * dx));
-        const float adz = fmaf(A[8], dz, fmaf(A[7], dy, A[6] * dx));
-        const float tdx = fmaf(A[6], dz, fmaf(A[3], dy, A[0] * dx));
-        const float tdy = fmaf(A[7], dz, fmaf(A[4], dy, A[1] * dx));
-        const float tdz = fmaf(A[8], dz, fmaf(A[5], dy, A[2] * dx));
-        const float ksk = fmaf(dz, adz, fmaf(dy, ady, dx * adx));
-        const float msk = fmaf(mz, adz, fmaf(my, ady, mx * adx));
-        const float t = msk / ksk;
-        const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
-        const float avx = fmaf(A[2], vz, fmaf(A[1], vy, A[0] * vx));
-        const float avy = fmaf(A[5], vz, fmaf(A[4], vy, A[3] * vx));
-        const float avz = fmaf(A[8], vz, fmaf(A[7], vy, A[6] * vx));
-        const float tvx = fmaf(A[6], vz, fmaf(A[3], vy, A[0] * vx));
-        const float tvy = fmaf(A[7], vz, fmaf(A[4], vy, A[1] * vx));
-        const float tvz = fmaf(A[8], vz, fmaf(A[5], vy, A[2] * vx));
-        const float c1 = gl / ksk;
-        const float gat = ga * t;
-        float o[12];
-        o[0] = fmaf(c1, adx, ga * (avx + tvx + t * (tdx - adx)));
-        o[1] = fmaf(c1, ady, ga * (avy + tvy + t * (tdy - ady)));
-        o[2] = fmaf(c1, adz, ga * (avz + tvz + t * (tdz - adz)));
-        const float d[3] = {dx, dy, dz}, v[3] = {vx, vy, vz};
+      float4 r0[kBwdU], r1[kBwdU], r2[kBwdU];
+      float dxs[kBwdU], dys[kBwdU], dzs[kBwdU];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c)
-            o[3 + 3 * a + c] = fmaf(ga, fmaf(v[a], v[c], t * (d[a] * v[c] - v[a] * d[c])),
-                                    fmaf(gd, d[a] * d[c], c1 * (v[a] * d[c])));
-        val[0] = make_float4(o[0], o[1], o[2], o[3]);
-        val[1] = make_float4(o[4], o[5], o[6], o[7]);
-        val[2] = make_float4(o[8], o[9], o[10], o[11]);
-        rx = fmaf(gd, adx + tdx, fmaf(c1, fmaf(-t, adx, tvx), gat * fmaf(t, adx - tdx, -2.0f * tvx)));
-        ryv = fmaf(gd, ady + tdy, fmaf(c1, fmaf(-t, ady, tvy), gat * fmaf(t, ady - tdy, -2.0f * tvy)));
-        rz = fmaf(gd, adz + tdz, fmaf(c1, fmaf(-t, adz, tvz), gat * fmaf(t, adz - tdz, -2.0f * tvz)));
+      for (int u = 0; u < kBwdU; ++u) {
+        live[u] = (p[u] >= 0) && (p[u] < P) && !(gl[u] == 0.0f && ga[u] == 0.0f && gd[u] == 0.0f);
+        if (live[u]) {
+          r0[u] = rec[3 * (size_t)p[u]]; r1[u] = rec[3 * (size_t)p[u] + 1]; r2[u] = rec[3 * (size_t)p[u] + 2];
+          const float *ry = rays + (pix0 + lx[u]) * 3;
+          dxs[u] = ry[0]; dys[u] = ry[1]; dzs[u] = ry[2];
+        }
       }
-      // a pixel lists a Gaussian at most once, so the lanes of ONE pixel carry distinct keys;
-      // several pixels per instruction (small K) are accumulated one pixel group at a time
-      for (int g = 0; g < ppi; ++g) {
-        const bool mine = live && (sub == g);
-        const int slot = wt_find(L.tab, p, mine);
-        if (mine) {
-          if (slot >= 0) {
-            wt_add(L.tab, slot, val);
-          } else {  // table full: rare, straight to HBM
-            const float o[12] = {val[0].x, val[0].y, val[0].z, val[0].w, val[1].x, val[1].y,
-                                 val[1].z, val[1].w, val[2].x, val[2].y, val[2].z, val[2].w};
 #pragma unroll
-            for (int c = 0; c < 12; ++c) unsafeAtomicAdd(acc + 16 * (size_t)p + c, o[c]);
+      for (int u = 0; u < kBwdU; ++u) {
+        if (it0 + u >= nit) break;   // uniform
+        float4 val[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        float rx = 0.f, ryv = 0.f, rz = 0.f;
+        if (live[u]) {
+          const float dx = dxs[u], dy = dys[u], dz = dzs[u];
+          const float mx = r0[u].x, my = r0[u].y, mz = r0[u].z;
+          const float A[9] = {r0[u].w, r1[u].x, r1[u].y, r1[u].z, r1[u].w, r2[u].x, r2[u].y, r2[u].z, r2[u].w};
+          const float adx = fmaf(A[2], dz, fmaf(A[1], dy, A[0] * dx));
+          const float ady = fmaf(A[5], dz, fmaf(A[4], dy, A[3] * dx));
+          const float adz = fmaf(A[8], dz, fmaf(A[7], dy, A[6] * dx));
+          const float tdx = fmaf(A[6], dz, fmaf(A[3], dy, A[0] * dx));
+          const float tdy = fmaf(A[7], dz, fmaf(A[4], dy, A[1] * dx));
+          const float tdz = fmaf(A[8], dz, fmaf(A[5], dy, A[2] * dx));
+          const float ksk = fmaf(dz, adz, fmaf(dy, ady, dx * adx));
+          const float msk = fmaf(mz, adz, fmaf(my, ady, mx * adx));
+          const float t = msk / ksk;
+          const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
+          const float avx = fmaf(A[2], vz, fmaf(A[1], vy, A[0] * vx));
+          const float avy = fmaf(A[5], vz, fmaf(A[4], vy, A[3] * vx));
+          const float avz = fmaf(A[8], vz, fmaf(A[7], vy, A[6] * vx));
+          const float tvx = fmaf(A[6], vz, fmaf(A[3], vy, A[0] * vx));
+          const float tvy = fmaf(A[7], vz, fmaf(A[4], vy, A[1] * vx));
+          const float tvz = fmaf(A[8], vz, fmaf(A[5], vy, A[2] * vx));
+          const float c1 = gl[u] / ksk;
+          const float g_a = ga[u], g_d = gd[u];
+          const float gat = g_a * t;
+          float o[12];
+          o[0] = fmaf(c1, adx, g_a * (avx + tvx + t * (tdx - adx)));
+          o[1] = fmaf(c1, ady, g_a * (avy + tvy + t * (tdy - ady)));
+          o[2] = fmaf(c1, adz, g_a * (avz + tvz + t * (tdz - adz)));
+          const float d[3] = {dx, dy, dz}, v[3] = {vx, vy, vz};
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              o[3 + 3 * a + c] = fmaf(g_a, fmaf(v[a], v[c], t * (d[a] * v[c] - v[a] * d[c])),
+                                      fmaf(g_d, d[a] * d[c], c1 * (v[a] * d[c])));
+          val[0] = make_float4(o[0], o[1], o[2], o[3]);
+          val[1] = make_float4(o[4], o[5], o[6], o[7]);
+          val[2] = make_float4(o[8], o[9], o[10], o[11]);
+          rx = fmaf(g_d, adx + tdx, fmaf(c1, fmaf(-t, adx, tvx), gat * fmaf(t, adx - tdx, -2.0f * tvx)));
+          ryv = fmaf(g_d, ady + tdy, fmaf(c1, fmaf(-t, ady, tvy), gat * fmaf(t, ady - tdy, -2.0f * tvy)));
+          rz = fmaf(g_d, adz + tdz, fmaf(c1, fmaf(-t, adz, tvz), gat * fmaf(t, adz - tdz, -2.0f * tvz)));
+        }
+        const int slot = wt_find(L.tab, p[u], live[u]);
+        wt_add(L.tab, slot, val, live[u] && slot >= 0, lane);
+        if (live[u] && slot < 0) {  // table full: rare, straight to HBM
+          const float o[12] = {val[0].x, val[0].y, val[0].z, val[0].w, val[1].x, val[1].y,
+                               val[1].z, val[1].w, val[2].x, val[2].y, val[2].z, val[2].w};
+#pragma unroll
+          for (int c = 0; c < 12; ++c) unsafeAtomicAdd(acc + 16 * (size_t)p[u] + c, o[c]);
+        }
+        if (g_ray != nullptr) {  // pixel-owned: segmented sum over the lanes of each pixel
+          rx = seg_sum_key(rx, lx[u], lane);
+          ryv = seg_sum_key(ryv, lx[u], lane);
+          rz = seg_sum_key(rz, lx[u], lane);
+          const int prev = __shfl_up(lx[u], 1, 64);
+          if ((lane == 0 || prev != lx[u]) && lx[u] < 8) {
+            L.ray[lx[u] * 3 + 0] += rx;
+            L.ray[lx[u] * 3 + 1] += ryv;
+            L.ray[lx[u] * 3 + 2] += rz;
           }
         }
       }
-      if (g_ray != nullptr) {
-        rx = seg_sum(rx, lane, lpp);
-        ryv = seg_sum(ryv, lane, lpp);
-        rz = seg_sum(rz, lane, lpp);
-        if (pix_ok && kl == 0) {
-          L.ray[i * 3 + 0] += rx;
-          L.ray[i * 3 + 1] += ryv;
-          L.ray[i * 3 + 2] += rz;
-        }
-      }
+    }
+    if (g_ray != nullptr) {
+      if (lane < tw * 3) g_ray[pix0 * 3 + lane] = L.ray[lane];
+      if (lane < 24) L.ray[lane] = 0.0f;
     }
   }
   // flush: 16 adjacent lanes per table entry add 12 adjacent floats of ONE 64-byte line of
@@ -148,14 +164,6 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
     for (int s = lane >> 4; s < kBwdNE; s += 4) {
       const int p = L.tab.keys[s];
       if (p >= 0 && c < 12) unsafeAtomicAdd(acc + 16 * (size_t)p + c, vals[s * 12 + c]);
-    }
-  }
-  if (g_ray != nullptr) {
-    for (int j = lane; j < 64 * 3; j += 64) {
-      const int i = j / 3, c = j - i * 3;
-      const int px = x0 + (i & 7);
-      const long py = y0 + (i >> 3);
-      if (px < W && py < nrows) g_ray[(py * W + px) * 3 + c] = L.ray[j];
     }
   }
 }

@@ -160,14 +160,16 @@ __device__ __forceinline__ bool cone_keep(const float4 c, const Cone &k) {
 
 // ------------------------------------------------------------------------------------------
 // Wave-private accumulation table in LDS: NV4 float4 values per integer key.
-// Only the owning wave touches a table, and within one wt_find()/wt_add() call all active lanes
-// carry DISTINCT keys, so slots are claimed with a plain write + read-back and values are
-// accumulated with plain read-modify-write.  (LDS float atomics cost ~3 LDS cycles per lane and
-// value on gfx950 -- SQ_LDS_IDX_ACTIVE in profiles/ -- the plain b128 path is ~20x cheaper.)
+// Only the owning wave touches a table, so slots are claimed with a plain write + read-back and
+// values are accumulated with plain read-modify-write; lanes of one instruction that carry the
+// SAME key elect one writer per round (owner[] write + read-back), so duplicates are safe.
+// (LDS float atomics cost ~3 LDS cycles per lane and value on gfx950 -- SQ_LDS_IDX_ACTIVE in
+// profiles/ -- the plain b128 path is ~20x cheaper.)
 // ------------------------------------------------------------------------------------------
 template <int NE, int NV4>
 struct WaveTable {
   int keys[NE];
+  int owner[NE];
   float4 vals[NE * NV4];
 };
 
@@ -209,14 +211,25 @@ __device__ __forceinline__ int wt_find(WaveTable<NE, NV4> &t, const int key, con
   return slot;
 }
 
+// vals[slot] += v for every lane with `on` (slot >= 0).  Must be called by the whole wave.
 template <int NE, int NV4>
-__device__ __forceinline__ void wt_add(WaveTable<NE, NV4> &t, const int slot, const float4 (&v)[NV4]) {
-  float4 *dst = t.vals + slot * NV4;
+__device__ __forceinline__ void wt_add(WaveTable<NE, NV4> &t, const int slot, const float4 (&v)[NV4],
+                                       const bool on, const int lane) {
+  volatile int *owner = t.owner;
+  bool pending = on;
+#pragma unroll 1
+  while (__any(pending)) {
+    if (pending) owner[slot] = lane;
+    if (pending && owner[slot] == lane) {
+      float4 *dst = t.vals + slot * NV4;
 #pragma unroll
-  for (int q = 0; q < NV4; ++q) {
-    float4 x = dst[q];
-    x.x += v[q].x; x.y += v[q].y; x.z += v[q].z; x.w += v[q].w;
-    dst[q] = x;
+      for (int q = 0; q < NV4; ++q) {
+        float4 x = dst[q];
+        x.x += v[q].x; x.y += v[q].y; x.z += v[q].z; x.w += v[q].w;
+        dst[q] = x;
+      }
+      pending = false;
+    }
   }
 }
 
@@ -227,6 +240,18 @@ __device__ __forceinline__ float seg_sum(float x, const int lane, const int seg)
   for (int o = 1; o < seg; o <<= 1) {
     const float y = __shfl_down(x, o, VOGE_WAVE);
     if (r + o < seg) x += y;
+  }
+  return x;
+}
+
+// Segmented sum by key: lanes holding equal `key` form contiguous runs (key is monotone along
+// the lanes); the total of each run lands in its FIRST lane.
+__device__ __forceinline__ float seg_sum_key(float x, const int key, const int lane) {
+#pragma unroll
+  for (int o = 1; o < VOGE_WAVE; o <<= 1) {
+    const float y = __shfl_down(x, o, VOGE_WAVE);
+    const int k2 = __shfl_down(key, o, VOGE_WAVE);
+    if (lane + o < VOGE_WAVE && k2 == key) x += y;
   }
   return x;
 }

@@ -232,6 +232,53 @@ class _Blend(torch.autograd.Function):
         return g_rgb, g_w, None, None
 
 
+class _Shade(torch.autograd.Function):
+    """interpolate_attr + get_silhouette + to_colored_background in one kernel each way
+    (VoGE/Renderer.py:153-171, VoGE/Aggregation.py:111-141); attr has <= 4 channels."""
+
+    @staticmethod
+    def forward(ctx, attr, weight, idx, valid_num, bg, thr):
+        lib = _lib.load()
+        attr_c = _dev(attr, torch.float32, "colors")
+        w = _dev(weight, torch.float32, "weight")
+        if not (idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()):
+            raise _lib.VogeHipError("vert_index must be a contiguous int32 tensor on the HIP device")
+        vn = _dev(valid_num, torch.int64, "valid_num")
+        bg_c = _dev(bg, torch.float32, "background_color")
+        K = idx.shape[-1]
+        npix = idx.numel() // max(K, 1)
+        Nattr, C = attr_c.shape
+        assert C <= 4 and bg_c.numel() == C
+        rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
+        img = torch.empty_like(rgb)
+        with torch.cuda.device(idx.device):
+            rc = lib.voge_shade_fwd(_p(attr_c), _p(idx), _p(w), _p(vn), _p(bg_c), float(thr), npix, K, C, Nattr, 1,
+                                    _p(rgb), _p(img), None, _stream())
+        _lib.check(rc, "voge_shade_fwd")
+        ctx.save_for_backward(attr_c, w, vn, rgb, bg_c)
+        ctx.idx = idx      # see _Merge: kept outside the version counter on purpose
+        ctx.thr = float(thr)
+        return img
+
+    @staticmethod
+    def backward(ctx, g_img):
+        lib = _lib.load()
+        attr, w, vn, rgb, bg = ctx.saved_tensors
+        idx = ctx.idx
+        K = idx.shape[-1]
+        npix = idx.numel() // max(K, 1)
+        Nattr, C = attr.shape
+        go = _dev(g_img, torch.float32, "grad_image")
+        g_attr = torch.empty_like(attr) if ctx.needs_input_grad[0] else None
+        g_w = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        Wd = idx.shape[-2] if idx.dim() >= 3 else npix
+        with torch.cuda.device(idx.device):
+            rc = lib.voge_shade_bwd(_p(attr), _p(idx), _p(w), _p(vn), _p(rgb), _p(bg), ctx.thr, _p(go),
+                                    npix // max(Wd, 1), Wd, K, C, Nattr, _p(g_attr), _p(g_w), _stream())
+        _lib.check(rc, "voge_shade_bwd")
+        return g_attr, g_w, None, None, None, None
+
+
 class _Silhouette(torch.autograd.Function):
     """get_silhouette (VoGE/Renderer.py:157-159): min(sum_k w_k, 1), via the blend kernels with a
     zero background and a one-channel zero image (out is discarded, sil_out is the result)."""
@@ -243,11 +290,8 @@ class _Silhouette(torch.autograd.Function):
         K = w.shape[-1]
         npix = w.numel() // max(K, 1)
         sil = torch.empty(w.shape[:-1], dtype=torch.float32, device=w.device)
-        zero = torch.zeros(w.shape[:-1] + (1,), dtype=torch.float32, device=w.device)
-        bg = torch.zeros((1,), dtype=torch.float32, device=w.device)
-        scratch = torch.empty_like(zero)
         with torch.cuda.device(w.device):
-            rc = lib.voge_blend_fwd(_p(zero), _p(w), _p(bg), -1.0, npix, K, 1, _p(scratch), _p(sil), _stream())
+            rc = lib.voge_blend_fwd(None, _p(w), None, -1.0, npix, K, 0, None, _p(sil), _stream())
         _lib.check(rc, "voge_blend_fwd")
         ctx.save_for_backward(w)
         return sil
@@ -330,6 +374,10 @@ def merge(attr, weight, idx, valid_num):
 
 def blend(rgb, weight, bg, thr=-1.0):
     return _Blend.apply(rgb, weight, bg, thr)
+
+
+def shade(attr, weight, idx, valid_num, bg, thr=-1.0):
+    return _Shade.apply(attr, weight, idx, valid_num, bg, thr)
 
 
 def silhouette(weight):
