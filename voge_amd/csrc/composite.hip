@@ -27,7 +27,7 @@ constexpr float kSat = 4.0f;  // erf(4) = 1 - 1.5e-8
 __device__ __forceinline__ float phi_cdf(const float x, float &y) {
   const float ax = fabsf(x);
   y = __expf(-ax * ax);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);

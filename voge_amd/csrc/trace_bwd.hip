@@ -100,7 +100,8 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
           const float tdz = fmaf(A[8], dz, fmaf(A[5], dy, A[2] * dx));
           const float ksk = fmaf(dz, adz, fmaf(dy, ady, dx * adx));
           const float msk = fmaf(mz, adz, fmaf(my, ady, mx * adx));
-          const float t = msk / ksk;
+          const float ik = __builtin_amdgcn_rcpf(ksk);
+          const float t = msk * ik;
           const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
           const float avx = fmaf(A[2], vz, fmaf(A[1], vy, A[0] * vx));
           const float avy = fmaf(A[5], vz, fmaf(A[4], vy, A[3] * vx));
@@ -108,7 +109,7 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
           const float tvx = fmaf(A[6], vz, fmaf(A[3], vy, A[0] * vx));
           const float tvy = fmaf(A[7], vz, fmaf(A[4], vy, A[1] * vx));
           const float tvz = fmaf(A[8], vz, fmaf(A[5], vy, A[2] * vx));
-          const float c1 = gl[u] / ksk;
+          const float c1 = gl[u] * ik;
           const float g_a = ga[u], g_d = gd[u];
           const float gat = g_a * t;
           float o[12];

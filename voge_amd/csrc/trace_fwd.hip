@@ -444,14 +444,8 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
         bool keep = false;
         if (i < nbuf) keep = (WAVES == 1) ? true : cone_keep(L.cull[i], wcone);
         unsigned long long m = __ballot(keep);
-        while (m) {
-          const int j = __builtin_ctzll(m);
-          m &= m - 1ull;
-          const int s = c0 + j;
-          if (can_exit && L.lb[s] > wmax) { wdone = true; break; }
-          const float4 cc = L.cull[s];
-          const EvalRec e = unpack_eval(L.ev[s * 3 + 0], L.ev[s * 3 + 1], L.ev[s * 3 + 2]);
-          const PairOut o = pair_eval(cc.x, cc.y, cc.z, e, dx, dy, dz, qxx, qyy, qzz, qxy, qxz, qyz);
+        // insert one evaluated candidate and refresh the wave's exit bound
+        auto commit = [&](const PairOut &o, const int s) {
           bool ins = false;
           if (valid && o.act < thr_act && o.len < VOGE_SENT_LEN) {
             const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)(L.id[s] + b * N);
@@ -463,6 +457,27 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
               wmax = wave_max(valid ? ord2f((uint32_t)(worst >> 32)) : -INFINITY);
               can_exit = true;
             }
+          }
+        };
+        auto eval = [&](const int s) {
+          const float4 cc = L.cull[s];
+          const EvalRec e = unpack_eval(L.ev[s * 3 + 0], L.ev[s * 3 + 1], L.ev[s * 3 + 2]);
+          return pair_eval(cc.x, cc.y, cc.z, e, dx, dy, dz, qxx, qyy, qzz, qxy, qxz, qyz);
+        };
+        while (m) {
+          // two candidates per trip: their evaluations are independent instruction streams
+          const int s0 = c0 + __builtin_ctzll(m);
+          m &= m - 1ull;
+          const bool two = m != 0ull;
+          const int s1 = two ? c0 + __builtin_ctzll(m) : s0;
+          m &= m - 1ull;
+          if (can_exit && L.lb[s0] > wmax) { wdone = true; break; }
+          const PairOut o0 = eval(s0);
+          const PairOut o1 = eval(s1);
+          commit(o0, s0);
+          if (two) {
+            if (can_exit && L.lb[s1] > wmax) { wdone = true; break; }
+            commit(o1, s1);
           }
         }
       }

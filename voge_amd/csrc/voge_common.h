@@ -32,6 +32,10 @@ struct EvalRec {
 };
 static_assert(sizeof(EvalRec) == 48, "EvalRec must be 3 x float4");
 
+// a / b with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the ~12-instruction IEEE
+// division sequence; relative error ~1.5e-7, three orders below the 1e-4 parity tolerance.
+__device__ __forceinline__ float fast_div(const float a, const float b) { return a * __builtin_amdgcn_rcpf(b); }
+
 struct PairOut {
   float len, act, dsd;
 };
@@ -54,7 +58,7 @@ __device__ __forceinline__ PairOut pair_eval(const float mx, const float my, con
   float msk = e.bx * dx;
   msk = fmaf(e.by, dy, msk);
   msk = fmaf(e.bz, dz, msk);
-  const float t = msk / ksk + 0.0f;  // +0 canonicalises -0
+  const float t = fast_div(msk, ksk) + 0.0f;  // +0 canonicalises -0
   const float vx = fmaf(-t, dx, mx);
   const float vy = fmaf(-t, dy, my);
   const float vz = fmaf(-t, dz, mz);
