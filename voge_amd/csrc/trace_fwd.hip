@@ -280,6 +280,101 @@ bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, cons
 }
 
 // ------------------------------------------------------------------------------------------
+// bin2: one 256-thread workgroup per sweep tile (TW x TH pixels).  Filters the sorted list of
+// the tile's super-tile with the tile's own bounding cone, keeping the order, so that the sweep
+// streams only the ~10 % of the super-tile list that can touch its pixels.  More than kTileCap
+// survivors (or an overflowed parent) -> count = -1 and the sweep falls back to the parent list.
+// ------------------------------------------------------------------------------------------
+constexpr int kTileCap = 2048;
+
+__global__ void __launch_bounds__(256)
+bin2_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, const int *__restrict__ bin_count,
+            const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb, const int nstx, const int nst,
+            const int N, const int H, const int W, const int TW, const int TH, int *__restrict__ tl_count,
+            int32_t *__restrict__ tl_id, float *__restrict__ tl_lb) {
+  __shared__ float red[4 * 8];
+  __shared__ int wcnt[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (W + TW - 1) / TW;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int tile = b * gridDim.x + blockIdx.x;
+  const int bin = b * nst + ((ty * TH) / kST) * nstx + (tx * TW) / kST;
+  const int bc = bin_count[bin];
+  if (bc < 0) {
+    if (tid == 0) tl_count[tile] = -1;
+    return;
+  }
+  // ---- cone of the tile's rays (thread <-> pixel, clamped at the image border) ----
+  const int lx = tid % TW, ly = tid / TW;
+  const bool has = ly < TH;
+  const int px = min(tx * TW + lx, W - 1), py = min(ty * TH + min(ly, TH - 1), H - 1);
+  const float *r = rays + (((size_t)b * H + py) * W + px) * 3;
+  const RayDir u = ray_dir(r[0], r[1], r[2]);
+  float sx = wave_sum((has && u.ok) ? u.ux : 0.f), sy = wave_sum((has && u.ok) ? u.uy : 0.f),
+        sz = wave_sum((has && u.ok) ? u.uz : 0.f);
+  const bool wok = __all(!has || u.ok);
+  if (lane == 0) { red[wave * 8 + 0] = sx; red[wave * 8 + 1] = sy; red[wave * 8 + 2] = sz; red[wave * 8 + 3] = wok ? 1.f : 0.f; }
+  __syncthreads();
+  sx = red[0] + red[8] + red[16] + red[24];
+  sy = red[1] + red[9] + red[17] + red[25];
+  sz = red[2] + red[10] + red[18] + red[26];
+  const bool all_ok = (red[3] != 0.f) && (red[11] != 0.f) && (red[19] != 0.f) && (red[27] != 0.f);
+  const float n = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
+  const float ax = sx / n, ay = sy / n, az = sz / n;
+  float smax = 0.f, cmin = 1.f;
+  if (has) cone_partial(u, ax, ay, az, smax, cmin);
+  smax = wave_max(smax); cmin = wave_min(cmin);
+  if (lane == 0) { red[wave * 8 + 4] = smax; red[wave * 8 + 5] = cmin; }
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) { smax = fmaxf(smax, red[w * 8 + 4]); cmin = fminf(cmin, red[w * 8 + 5]); }
+  const Cone cone = cone_finish(ax, ay, az, n, smax, cmin, all_ok);
+
+  // ---- ordered filter of the parent list ----
+  const int32_t *src_id = bin_id + (size_t)bin * kBinCap;
+  const float *src_lb = bin_lb + (size_t)bin * kBinCap;
+  const float4 *cullb = cull + (size_t)b * N;
+  int32_t *oid = tl_id + (size_t)tile * kTileCap;
+  float *olb = tl_lb + (size_t)tile * kTileCap;
+  int total = 0, par = 0;
+  for (int base = 0; base < bc; base += 1024) {
+    // four chunks per trip: 4 independent (id -> record) chains in flight per lane
+    int id[4];
+    float lbv[4];
+    float4 c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int g = base + q * 256 + tid;
+      id[q] = (g < bc) ? src_id[g] : -1;
+      lbv[q] = (g < bc) ? src_lb[g] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = (id[q] >= 0) ? cullb[id[q]] : make_float4(0.f, 0.f, 0.f, -1.f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (base + q * 256 >= bc) break;  // uniform
+      const bool keep = cone_keep(c[q], cone);
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) wcnt[par][wave] = __popcll(m);
+      __syncthreads();
+      int off = total, tot = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int cw = wcnt[par][w];
+        if (w < wave) off += cw;
+        tot += cw;
+      }
+      if (keep) {
+        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < kTileCap) { oid[pos] = id[q]; olb[pos] = lbv[q]; }
+      }
+      total += tot;
+      par ^= 1;
+    }
+  }
+  if (tid == 0) tl_count[tile] = (total > kTileCap) ? -1 : total;
+}
+
+// ------------------------------------------------------------------------------------------
 // sweep.  One workgroup = WAVES waves = a TW x TH pixel tile (each wave an 8x8 sub-tile, one
 // ray per lane).  Its candidate stream is the sorted list of its super-tile (or, if that bin
 // overflowed, every Gaussian of the batch element), read in chunks of T:
@@ -312,10 +407,11 @@ template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
 trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr,
                  const float *__restrict__ rays, const int *__restrict__ bin_count,
-                 const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb, const int nstx,
-                 const int nst, const int N, const int H, const int W, const int K,
-                 const float thr_act, int32_t *__restrict__ out_idx, float *__restrict__ out_len,
-                 float *__restrict__ out_act, float *__restrict__ out_dsd) {
+                 const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb,
+                 const int *__restrict__ tl_count, const int32_t *__restrict__ tl_id,
+                 const float *__restrict__ tl_lb, const int nstx, const int nst, const int N, const int H,
+                 const int W, const int K, const float thr_act, int32_t *__restrict__ out_idx,
+                 float *__restrict__ out_len, float *__restrict__ out_act, float *__restrict__ out_dsd) {
   constexpr int T = 64 * WAVES;
   constexpr int TP = T + 1;   // key row stride: the transposed epilogue read stays conflict-light
   constexpr int TW = (WAVES >= 2) ? 16 : 8;
@@ -376,12 +472,15 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   }
 
   // ---- candidate stream of this tile -----------------------------------------------------
+  // tile list (bin2) -> super-tile list (bin) -> every Gaussian of the batch element
+  const int tile = b * gridDim.x + blockIdx.x;
   const int bin = b * nst + ((ty * TH) / kST) * nstx + (tx * TW) / kST;
-  const int bc = (bin_count != nullptr) ? bin_count[bin] : -1;
+  const int tc = (tl_count != nullptr) ? tl_count[tile] : -1;
+  const int bc = (tc >= 0) ? tc : ((bin_count != nullptr) ? bin_count[bin] : -1);
   const bool binned = bc >= 0;
   const int src_n = binned ? bc : N;
-  const int32_t *src_id = binned ? bin_id + (size_t)bin * kBinCap : nullptr;
-  const float *src_lb = binned ? bin_lb + (size_t)bin * kBinCap : nullptr;
+  const int32_t *src_id = (tc >= 0) ? tl_id + (size_t)tile * kTileCap : (binned ? bin_id + (size_t)bin * kBinCap : nullptr);
+  const float *src_lb = (tc >= 0) ? tl_lb + (size_t)tile * kTileCap : (binned ? bin_lb + (size_t)bin * kBinCap : nullptr);
   const float4 *cullb = cull + (size_t)b * N;
   const float4 *evrb = evr + (size_t)b * N * 3;
   const float4 cull_none = make_float4(0.f, 0.f, 0.f, -1.f);
@@ -593,6 +692,9 @@ struct TraceWs {
   int *bin_count;
   int32_t *bin_id;
   float *bin_lb;
+  int *tl_count;
+  int32_t *tl_id;
+  float *tl_lb;
   int nstx, nsty;
 };
 
@@ -605,9 +707,14 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
   size_t off = 0;
   char *p = reinterpret_cast<char *>(base);
   auto take = [&](size_t bytes) { char *q = p ? p + off : nullptr; off += align256(bytes); return q; };
+  // sweep tiles are at least 8x8 pixels: size the tile lists for that worst case
+  const size_t ntile = (size_t)B * ((W + 7) / 8) * ((H + 7) / 8);
   char *c = take(P * 16), *e = take(P * 48), *bc = take(nbin * 4), *bi = take(nbin * kBinCap * 4),
-       *bl = take(nbin * kBinCap * 4);
+       *bl = take(nbin * kBinCap * 4), *tc = take(ntile * 4), *ti = take(ntile * kTileCap * 4),
+       *tl = take(ntile * kTileCap * 4);
   if (ws) {
+    ws->tl_count = reinterpret_cast<int *>(tc); ws->tl_id = reinterpret_cast<int32_t *>(ti);
+    ws->tl_lb = reinterpret_cast<float *>(tl);
     ws->cull = reinterpret_cast<float4 *>(c); ws->evr = reinterpret_cast<float4 *>(e);
     ws->bin_count = reinterpret_cast<int *>(bc); ws->bin_id = reinterpret_cast<int32_t *>(bi);
     ws->bin_lb = reinterpret_cast<float *>(bl); ws->nstx = nstx; ws->nsty = nsty;
@@ -627,8 +734,14 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid(((W + TW - 1) / TW) * ((H + TH - 1) / TH), B);
+  hipLaunchKernelGGL(bin2_kernel, grid, dim3(256), 0, st, ws.cull, rays, ws.bin_count, ws.bin_id, ws.bin_lb, ws.nstx,
+                     ws.nstx * ws.nsty, N, H, W, TW, TH, ws.tl_count, ws.tl_id, ws.tl_lb);
+  {
+    int rc = launch_status();
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, rays, ws.bin_count, ws.bin_id, ws.bin_lb,
-                     ws.nstx, ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd);
+                     ws.tl_count, ws.tl_id, ws.tl_lb, ws.nstx, ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd);
   return launch_status();
 }
 
