@@ -1,0 +1,62 @@
+"""world_size-2 test of the pixel-row sharding on CPU (gloo): the host logic that the 8-GPU run
+uses with RCCL.  The per-rank "renderer" here is the oracle (test infrastructure), because the
+product kernels need a GPU; what is under test is row_band / gather_rows / allreduce_grads."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from oracle import camera_np
+from util import cuboid_scene
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, H, W, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from voge_amd.distributed import allreduce_grads, gather_rows, row_band
+    sc = cuboid_scene()
+    R, T = camera_np.look_at_view_transform(sc["dist"], sc["elev"], sc["azim"])
+    r0, r1 = row_band(H, rank, world)
+    rays, origin = camera_np.pixel_rays(R, T, 60.0, (W / 2, H / 2), (H, W))
+    mus = (sc["verts"][None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = (2 * camera_np.expand_sigma(sc["sigmas"])).astype(np.float32)[None]
+    idx, ln, act, dsd = oracle.trace_fwd(mus, isg, rays[:, r0:r1], 8, oracle.thr_act_of(0.01))
+    w, vn = oracle.composite_fwd(idx, act, ln, dsd, 1.0)
+    colors = torch.tensor(sc["colors"], dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w)
+    valid = torch.tensor(np.arange(8)[None, None, None] < vn[..., None])
+    gathered = colors[torch.tensor(np.maximum(idx, 0)).long()]                 # [1,h,W,K,3]
+    band = (gathered * (wt * valid)[..., None]).sum(-2)                         # merge of the band
+    img = gather_rows(band, H)
+    assert img.shape == (1, H, W, 3)
+    img[:, r0:r1].sum().backward()          # each rank owns the loss of its band
+    allreduce_grads([colors])
+    if rank == 0:
+        torch.save({"img": img.detach(), "g": colors.grad}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_frame_equals_single_rank(tmp_path):
+    H, W, world = 21, 16, 2          # odd height: uneven bands
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(world, _free_port(), H, W, out), nprocs=world, join=True)
+    got = torch.load(out)
+    sc = cuboid_scene()
+    R, T = camera_np.look_at_view_transform(sc["dist"], sc["elev"], sc["azim"])
+    ref = oracle.render(sc["verts"], sc["sigmas"], sc["colors"], R, T, 60.0, (W / 2, H / 2), (H, W), K=8)
+    assert np.abs(got["img"].numpy() - ref["rgb"]).max() < 1e-12
+    g_attr, _ = oracle.merge_bwd(sc["colors"], ref["idx"], ref["weight"], ref["valid_num"], np.ones_like(ref["rgb"]))
+    assert np.abs(got["g"].numpy() - g_attr).max() < 1e-10
