@@ -45,7 +45,7 @@ prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg,
   const double lmin = lambda_min_sym3(A[0], A[4], A[8], 0.5 * ((double)A[1] + A[3]),
                                       0.5 * ((double)A[2] + A[6]), 0.5 * ((double)A[5] + A[7]));
   const double lmax_bound = fabs((double)A[0]) + fabs((double)A[4]) + fabs((double)A[8]) +
-                            fabs((double)e.s01) + fabs((double)e.s02) + fabs((double)e.s12);
+                            fabs((double)A[1] + A[3]) + fabs((double)A[2] + A[6]) + fabs((double)A[5] + A[7]);
   const double lsafe = lmin * (1.0 - 1e-6) - 1e-12 * lmax_bound;
   float reach = INFINITY;
   if (lsafe > 0.0 && lsafe < 1e300) {
@@ -112,25 +112,31 @@ __device__ __forceinline__ Cone cone_finish(const float ax, const float ay, cons
   return c;
 }
 
-// Lower bound of len = (mu^T A d)/(d^T A d) over every UNIT ray d of the cone that can hit the
-// Gaussian (i.e. whose line passes within `reach` of mu): len = mu.d - v.d with |v| <= reach.
-// In front of the camera mu.d >= sqrt(|mu|^2 - reach^2); otherwise only |len| <= |mu| + reach.
-__device__ __forceinline__ float len_lower_bound(const float4 c, const Cone &k) {
+// Depth key of a candidate for the front-to-back order of a bin: kappa = +|mu| for a Gaussian in
+// front of the camera, -|mu| otherwise (behind it, or too close / cone too wide to tell), and
+// -inf for an unbounded reach.  For every UNIT ray d of the cone that can hit the Gaussian
+// (its line passes within `reach` R of mu): len = mu.d - v.d with |v| <= R, hence
+//   front (|mu| > 4R, mu.axis > 0): len >= sqrt(|mu|^2 - R^2) - R >= kappa - 1.13 R
+//   otherwise                     : len >= -|mu| - R               = kappa - R
+// so  kappa - 1.13 * Rmax  (Rmax = largest finite reach in the bin) is a lower bound of len that
+// is MONOTONE in kappa -- what the sweep's early exit needs.
+__device__ __forceinline__ float depth_key(const float4 c, const Cone &k) {
   const float nm = sqrtf(fmaf(c.z, c.z, fmaf(c.y, c.y, c.x * c.x)));
   const float R = c.w;
-  float lb = -(nm + R);
+  if (!(R < 3e38f) || !(nm < 3e38f)) return -INFINITY;
+  float kappa = -nm;
   if (k.ok && k.cs >= 0.5f && nm > 4.0f * R) {
     const float p = fmaf(c.z, k.az, fmaf(c.y, k.ay, c.x * k.ax));
-    if (p > 0.0f) lb = sqrtf(fmaxf(fmaf(nm, nm, -R * R), 0.0f)) - R;
+    if (p > 0.0f) kappa = nm;
   }
-  lb -= fmaf(1e-5f, nm + R, 1e-30f);
-  return (lb == lb) ? lb : -INFINITY;
+  return kappa;
 }
 
 // ------------------------------------------------------------------------------------------
 // bin: one 1024-thread workgroup per 64x64-pixel super-tile.  Tests every Gaussian of the
-// batch element against the super-tile's bounding cone (conservative), then sorts the
-// survivors by their len lower bound (bitonic, LDS) and writes the (id, bound) list.
+// batch element against the super-tile's bounding cone (conservative), then orders the
+// survivors front to back by depth key (counting sort + per-bucket insertion sort, LDS) and
+// writes the (id, monotone len lower bound) list.
 // More than kBinCap survivors -> count = -1 and the sweep falls back to the full stream.
 // ------------------------------------------------------------------------------------------
 constexpr int kST = 64;
@@ -139,9 +145,11 @@ constexpr int kBinThreads = 1024;
 
 constexpr int kBuckets = 1024;  // == kBinThreads (one scan lane per bucket)
 struct BinLds {
-  uint64_t keys[kBinCap];
+  uint64_t keys[kBinCap];     // (ord(depth key) << 32 | id), unordered
+  uint64_t sorted[kBinCap];   // the same, front to back
   float red[16 * 4];
   int hist[kBuckets];
+  int start[kBuckets + 1];
   int wsum[16];
   int count;
 };
@@ -198,6 +206,7 @@ bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, cons
   if (tid == 0) L.count = 0;
   __syncthreads();
   const float4 *cullb = cull + (size_t)b * N;
+  float rmax = 0.0f;   // largest finite reach among this thread's survivors
   for (int base = 0; base < N; base += 4 * kBinThreads) {
     // four independent 16-byte loads in flight per lane: the scan is latency-, not compute-bound
     float4 c[4];
@@ -210,13 +219,14 @@ bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, cons
     for (int q = 0; q < 4; ++q) {
       const int g = base + q * kBinThreads + tid;
       const bool keep = cone_keep(c[q], cone);
+      if (keep && c[q].w < 3e38f) rmax = fmaxf(rmax, c[q].w);
       const unsigned long long m = __ballot(keep);
       if (m) {
         int start = 0;
         if (lane == 0) start = atomicAdd(&L.count, __popcll(m));
         start = __shfl(start, 0, 64);
         const int slot = start + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep && slot < kBinCap) L.keys[slot] = ((uint64_t)f2ord(len_lower_bound(c[q], cone)) << 32) | (uint32_t)g;
+        if (keep && slot < kBinCap) L.keys[slot] = ((uint64_t)f2ord(depth_key(c[q], cone)) << 32) | (uint32_t)g;
       }
     }
   }
@@ -227,16 +237,18 @@ bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, cons
     if (tid == 0) bin_count[bin] = -1;
     return;
   }
-  // ---- order the survivors front to back: counting sort on the quantised bound -------------
-  // Exact order is not needed (the sweep's top-K insertion is order independent); what the early
-  // exit needs is a MONOTONE per-entry lower bound, so every entry reports the lower edge of its
-  // bucket.  Bucket 0 collects -inf bounds (unbounded reach) and keeps the edge -inf.
+  // ---- order the survivors front to back: counting sort on the depth key, then an insertion
+  // sort inside every bucket (a handful of entries each).  Exact order is not needed for
+  // correctness (the sweep's top-K insertion is order independent) but it turns nearly every
+  // insertion into an append.  Bucket 0 collects the -inf keys (unbounded reach).
   float lo = INFINITY, hi = -INFINITY, d0 = 0.f, d1 = 1.f;
   for (int i = tid; i < total; i += kBinThreads) {
     const float v = ord2f((uint32_t)(L.keys[i] >> 32));
     if (v > -INFINITY) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
   }
   block_reduce16(L.red, wave, lane, hi, lo, d0, d1, 1);   // a: max, b: min
+  float rm = rmax, rdummy = 0.f;
+  block_reduce16(L.red, wave, lane, rm, rdummy, d0, d1, 1);
   const float span = fmaxf(hi - lo, 1e-20f);
   const float scale = (float)(kBuckets - 2) / span;
   for (int i = tid; i < kBuckets; i += kBinThreads) L.hist[i] = 0;
@@ -262,19 +274,36 @@ bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, cons
     int off = 0;
     for (int w = 0; w < wave; ++w) off += L.wsum[w];
     L.hist[tid] = off + x - v;
+    L.start[tid] = off + x - v;
+    if (tid == kBuckets - 1) L.start[kBuckets] = off + x;
   }
   __syncthreads();
-  int32_t *oid = bin_id + (size_t)bin * kBinCap;
-  float *olb = bin_lb + (size_t)bin * kBinCap;
   for (int i = tid; i < total; i += kBinThreads) {
     const uint64_t k = L.keys[i];
     const float v = ord2f((uint32_t)(k >> 32));
     int q = 0;
     if (v > -INFINITY) q = 1 + min(kBuckets - 2, max(0, (int)((v - lo) * scale)));
-    const int pos = atomicAdd(&L.hist[q], 1);
-    oid[pos] = (int32_t)(uint32_t)k;
-    // lower edge of bucket q, nudged down so that rounding in (v - lo) * scale cannot overstate it
-    olb[pos] = (q == 0) ? -INFINITY : (lo + (float)(q - 1) / scale) - 1e-6f * (fabsf(lo) + span);
+    L.sorted[atomicAdd(&L.hist[q], 1)] = k;
+  }
+  __syncthreads();
+  {  // thread q orders bucket q (keys are unique: the id is in the low word)
+    const int s0 = L.start[tid], s1 = L.start[tid + 1];
+    for (int i = s0 + 1; i < s1; ++i) {
+      const uint64_t k = L.sorted[i];
+      int j = i;
+      while (j > s0 && L.sorted[j - 1] > k) { L.sorted[j] = L.sorted[j - 1]; --j; }
+      L.sorted[j] = k;
+    }
+  }
+  __syncthreads();
+  int32_t *oid = bin_id + (size_t)bin * kBinCap;
+  float *olb = bin_lb + (size_t)bin * kBinCap;
+  const float slack = 1.13f * rm * (1.0f + 1e-5f);
+  for (int i = tid; i < total; i += kBinThreads) {
+    const uint64_t k = L.sorted[i];
+    const float v = ord2f((uint32_t)(k >> 32));
+    oid[i] = (int32_t)(uint32_t)k;
+    olb[i] = (v > -INFINITY) ? v - slack - 1e-5f * fabsf(v) - 1e-30f : -INFINITY;
   }
   if (tid == 0) bin_count[bin] = total;
 }
@@ -393,10 +422,10 @@ bin2_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, con
 template <int T>
 struct TraceLds {
   // layout inside dynamic LDS, after the [K][T+1] key array
-  float4 cull[2 * T];
-  float4 ev[2 * T * 3];
-  int32_t id[2 * T];
-  float lb[2 * T];
+  float4 cull[T];
+  float4 ev[T * 3];
+  int32_t id[T];
+  float lb[T];
   float red[4 * 8];
   int wcnt[2][4];
   int cnt[T];
@@ -416,7 +445,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   constexpr int TP = T + 1;   // key row stride: the transposed epilogue read stays conflict-light
   constexpr int TW = (WAVES >= 2) ? 16 : 8;
   constexpr int TH = (WAVES == 4) ? 16 : 8;
-  constexpr int kCap = 2 * T;
+  constexpr int kCap = T;     // one chunk of the candidate stream is staged at a time
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t *keys = reinterpret_cast<uint64_t *>(smem_raw);
   TraceLds<T> &L = *reinterpret_cast<TraceLds<T> *>(smem_raw + ((sizeof(uint64_t) * (size_t)K * TP + 15) & ~(size_t)15));
@@ -490,7 +519,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 
   uint64_t *mykeys = keys + tid;
   int cnt = 0;
-  uint64_t worst = ~0ull;
+  uint64_t worst = ~0ull, tail = 0ull;
   bool wdone = false, reported = false, can_exit = false;
   float wmax = INFINITY;
 
@@ -543,41 +572,69 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
         bool keep = false;
         if (i < nbuf) keep = (WAVES == 1) ? true : cone_keep(L.cull[i], wcone);
         unsigned long long m = __ballot(keep);
-        // insert one evaluated candidate and refresh the wave's exit bound
+        // Exit bound, refreshed once per 64-candidate batch: a stale (larger) bound only delays
+        // the exit, it never makes it wrong, because a lane's worst key only ever decreases.
+        if (binned && unit_rays && __all(!valid || cnt == K)) {
+          wmax = wave_max(valid ? ord2f((uint32_t)(worst >> 32)) : -INFINITY);
+          can_exit = true;
+        }
         auto commit = [&](const PairOut &o, const int s) {
-          bool ins = false;
           if (valid && o.act < thr_act && o.len < VOGE_SENT_LEN) {
             const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)(L.id[s] + b * N);
-            if (key < worst) { topk_insert(mykeys, TP, K, cnt, worst, key); ins = true; }
+            if (key < worst) topk_insert(mykeys, TP, K, cnt, worst, tail, key);
           }
-          if (__any(ins)) {
-            const bool full = __all(!valid || cnt == K);
-            if (full && unit_rays && binned) {
-              wmax = wave_max(valid ? ord2f((uint32_t)(worst >> 32)) : -INFINITY);
-              can_exit = true;
-            }
-          }
-        };
-        auto eval = [&](const int s) {
-          const float4 cc = L.cull[s];
-          const EvalRec e = unpack_eval(L.ev[s * 3 + 0], L.ev[s * 3 + 1], L.ev[s * 3 + 2]);
-          return pair_eval(cc.x, cc.y, cc.z, e, dx, dy, dz, qxx, qyy, qzz, qxy, qxz, qyz);
         };
         while (m) {
-          // two candidates per trip: their evaluations are independent instruction streams
-          const int s0 = c0 + __builtin_ctzll(m);
-          m &= m - 1ull;
-          const bool two = m != 0ull;
-          const int s1 = two ? c0 + __builtin_ctzll(m) : s0;
-          m &= m - 1ull;
-          if (can_exit && L.lb[s0] > wmax) { wdone = true; break; }
-          const PairOut o0 = eval(s0);
-          const PairOut o1 = eval(s1);
-          commit(o0, s0);
-          if (two) {
-            if (can_exit && L.lb[s1] > wmax) { wdone = true; break; }
-            commit(o1, s1);
+          // four candidates per trip: their evaluations are independent instruction streams
+          int sq[4];
+          int nt = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            sq[q] = c0 + (m ? __builtin_ctzll(m) : 0);
+            if (m) { ++nt; m &= m - 1ull; }
           }
+          if (can_exit && L.lb[sq[0]] > wmax) { wdone = true; break; }
+          // The four evaluations form ONE straight-line block (the isotropic / general choice is
+          // made per batch, on scalar registers), so the scheduler interleaves their chains.
+          PairOut o[4];
+          float4 cc[4], e0[4];
+          bool iso = true, any_iso = false;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            cc[q] = L.cull[sq[q]];
+            e0[q] = L.ev[sq[q] * 3];
+            const bool f = __builtin_amdgcn_readfirstlane(__float_as_uint(e0[q].w)) == kIsoFlag;
+            iso = iso && f;
+            any_iso = any_iso || f;
+          }
+          if (iso) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              o[q] = pair_eval_iso(cc[q].x, cc[q].y, cc[q].z, e0[q].x, dx, dy, dz, qxx, qyy, qzz);
+          } else {
+            float4 e1[4], e2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { e1[q] = L.ev[sq[q] * 3 + 1]; e2[q] = L.ev[sq[q] * 3 + 2]; }
+            if (!any_iso) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                o[q] = pair_eval_gen(cc[q].x, cc[q].y, cc[q].z, unpack_eval(e0[q], e1[q], e2[q]), dx, dy, dz, qxx, qyy,
+                                     qzz, qxy, qxz, qyz);
+            } else {  // mixed batch: per-candidate dispatch (same arithmetic, just not interleaved)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                o[q] = pair_eval(cc[q].x, cc[q].y, cc[q].z, unpack_eval(e0[q], e1[q], e2[q]), dx, dy, dz, qxx, qyy, qzz,
+                                 qxy, qxz, qyz);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (q < nt) {
+              if (q > 0 && can_exit && L.lb[sq[q]] > wmax) { wdone = true; break; }
+              commit(o[q], sq[q]);
+            }
+          }
+          if (wdone) break;
         }
       }
     }
@@ -594,32 +651,54 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   __syncthreads();
   const int tw = min(TW, W - tx * TW);
   const int row_items = tw * K;
+  auto slot_value = [&](const int r, const int x, const int s, const size_t pix, int32_t &oi, float &ol, float &oa,
+                        float &od) {
+    const int owner = ((x >> 3) + (TW / 8) * (r >> 3)) * 64 + (x & 7) + 8 * (r & 7);
+    oi = -1; ol = VOGE_SENT_LEN; oa = VOGE_SENT_ACT; od = 0.0f;
+    if (s < L.cnt[owner]) {
+      const uint64_t key = keys[(size_t)s * TP + owner];
+      oi = (int32_t)(uint32_t)key;
+      const float *ry = rays + pix * 3;
+      const float ex = ry[0], ey = ry[1], ez = ry[2];
+      const float4 cc = cull[oi];
+      const EvalRec e = unpack_eval(evr[(size_t)oi * 3 + 0], evr[(size_t)oi * 3 + 1], evr[(size_t)oi * 3 + 2]);
+      const PairOut o = pair_eval(cc.x, cc.y, cc.z, e, ex, ey, ez, ex * ex, ey * ey, ez * ez, ex * ey, ex * ez, ey * ez);
+      ol = ord2f((uint32_t)(key >> 32));
+      oa = o.act;
+      od = o.dsd;
+    }
+  };
+  const bool vec4 = ((K & 3) == 0);   // rows of K floats stay 16-byte aligned: 16-byte stores
   for (int r = 0; r < TH; ++r) {
     const int gy = ty * TH + r;
     if (gy >= H) break;
     const size_t pix0 = ((size_t)b * H + gy) * W + (size_t)tx * TW;
-    for (int j = tid; j < row_items; j += T) {
-      const int x = j / K, s = j - x * K;
-      const int owner = ((x >> 3) + (TW / 8) * (r >> 3)) * 64 + (x & 7) + 8 * (r & 7);
-      int32_t oi = -1;
-      float ol = VOGE_SENT_LEN, oa = VOGE_SENT_ACT, od = 0.0f;
-      if (s < L.cnt[owner]) {
-        const uint64_t key = keys[(size_t)s * TP + owner];
-        oi = (int32_t)(uint32_t)key;
-        const float *ry = rays + (pix0 + x) * 3;
-        const float ex = ry[0], ey = ry[1], ez = ry[2];
-        const float4 cc = cull[oi];
-        const EvalRec e = unpack_eval(evr[(size_t)oi * 3 + 0], evr[(size_t)oi * 3 + 1], evr[(size_t)oi * 3 + 2]);
-        const PairOut o = pair_eval(cc.x, cc.y, cc.z, e, ex, ey, ez, ex * ex, ey * ey, ez * ez, ex * ey, ex * ez, ey * ez);
-        ol = ord2f((uint32_t)(key >> 32));
-        oa = o.act;
-        od = o.dsd;
+    if (vec4) {
+      for (int j4 = tid; j4 < row_items / 4; j4 += T) {
+        const int j = j4 * 4;
+        const int x = j / K, s = j - x * K;
+        int32_t oi[4];
+        float ol[4], oa[4], od[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) slot_value(r, x, s + q, pix0 + x, oi[q], ol[q], oa[q], od[q]);
+        const size_t o = pix0 * K + j;
+        *reinterpret_cast<int4 *>(out_idx + o) = make_int4(oi[0], oi[1], oi[2], oi[3]);
+        *reinterpret_cast<float4 *>(out_len + o) = make_float4(ol[0], ol[1], ol[2], ol[3]);
+        *reinterpret_cast<float4 *>(out_act + o) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+        *reinterpret_cast<float4 *>(out_dsd + o) = make_float4(od[0], od[1], od[2], od[3]);
       }
-      const size_t o = pix0 * K + j;
-      out_idx[o] = oi;
-      out_len[o] = ol;
-      out_act[o] = oa;
-      out_dsd[o] = od;
+    } else {
+      for (int j = tid; j < row_items; j += T) {
+        const int x = j / K, s = j - x * K;
+        int32_t oi;
+        float ol, oa, od;
+        slot_value(r, x, s, pix0 + x, oi, ol, oa, od);
+        const size_t o = pix0 * K + j;
+        out_idx[o] = oi;
+        out_len[o] = ol;
+        out_act[o] = oa;
+        out_dsd[o] = od;
+      }
     }
   }
 }
@@ -649,7 +728,7 @@ trace_list_fwd_kernel(const float *__restrict__ mus, const float *__restrict__ i
   const int32_t *lst = bins + (((size_t)b * BH + by) * BW + bx) * M;
   uint64_t *mykeys = keys + lane;
   int cnt = 0;
-  uint64_t worst = ~0ull;
+  uint64_t worst = ~0ull, tail = 0ull;
   for (int m = 0; m < M; ++m) {
     const int p = lst[m];
     if (p < 0 || p >= P) continue;
@@ -661,7 +740,7 @@ trace_list_fwd_kernel(const float *__restrict__ mus, const float *__restrict__ i
     const PairOut o = pair_eval(mx, my, mz, e, dx, dy, dz, qxx, qyy, qzz, qxy, qxz, qyz);
     if (o.act < thr_act && o.len < VOGE_SENT_LEN) {
       const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)p;
-      if (key < worst) topk_insert(mykeys, 64, K, cnt, worst, key);
+      if (key < worst) topk_insert(mykeys, 64, K, cnt, worst, tail, key);
     }
   }
   for (int s = 0; s < K; ++s) {

@@ -36,6 +36,9 @@ static_assert(sizeof(EvalRec) == 48, "EvalRec must be 3 x float4");
 // division sequence; relative error ~1.5e-7, three orders below the 1e-4 parity tolerance.
 __device__ __forceinline__ float fast_div(const float a, const float b) { return a * __builtin_amdgcn_rcpf(b); }
 
+// s01 of an isotropic record carries this NaN bit pattern (never produced by arithmetic)
+constexpr uint32_t kIsoFlag = 0x7fc0a150u;
+
 struct PairOut {
   float len, act, dsd;
 };
@@ -43,11 +46,28 @@ struct PairOut {
 // One (ray, Gaussian) evaluation.  q* are the ray's quadratic features (dx*dx, ... dy*dz).
 // Written with explicit fmaf so that every call site (sweep, epilogue, list kernel) produces
 // bit-identical results; the library is built with -ffp-contract=off.
-__device__ __forceinline__ PairOut pair_eval(const float mx, const float my, const float mz,
-                                             const EvalRec &e, const float dx, const float dy,
-                                             const float dz, const float qxx, const float qyy,
-                                             const float qzz, const float qxy, const float qxz,
-                                             const float qyz) {
+// Isotropic A = a*I (the converters' output): dsd = a|d|^2, len = mu.d/|d|^2, act = a|v|^2.
+__device__ __forceinline__ PairOut pair_eval_iso(const float mx, const float my, const float mz, const float a,
+                                                 const float dx, const float dy, const float dz,
+                                                 const float qxx, const float qyy, const float qzz) {
+  PairOut o;
+  const float dn2 = qxx + qyy + qzz;
+  const float md = fmaf(mz, dz, fmaf(my, dy, mx * dx));
+  const float t = fast_div(md, dn2) + 0.0f;  // +0 canonicalises -0
+  const float vx = fmaf(-t, dx, mx);
+  const float vy = fmaf(-t, dy, my);
+  const float vz = fmaf(-t, dz, mz);
+  o.len = t;
+  o.act = a * fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+  o.dsd = a * dn2;
+  return o;
+}
+
+__device__ __forceinline__ PairOut pair_eval_gen(const float mx, const float my, const float mz,
+                                                 const EvalRec &e, const float dx, const float dy,
+                                                 const float dz, const float qxx, const float qyy,
+                                                 const float qzz, const float qxy, const float qxz,
+                                                 const float qyz) {
   PairOut o;
   float ksk = e.s00 * qxx;
   ksk = fmaf(e.s11, qyy, ksk);
@@ -78,6 +98,17 @@ __device__ __forceinline__ PairOut pair_eval(const float mx, const float my, con
   return o;
 }
 
+__device__ __forceinline__ bool is_iso(const EvalRec &e) { return __float_as_uint(e.s01) == kIsoFlag; }
+
+__device__ __forceinline__ PairOut pair_eval(const float mx, const float my, const float mz,
+                                             const EvalRec &e, const float dx, const float dy,
+                                             const float dz, const float qxx, const float qyy,
+                                             const float qzz, const float qxy, const float qxz,
+                                             const float qyz) {
+  if (is_iso(e)) return pair_eval_iso(mx, my, mz, e.s00, dx, dy, dz, qxx, qyy, qzz);
+  return pair_eval_gen(mx, my, mz, e, dx, dy, dz, qxx, qyy, qzz, qxy, qxz, qyz);
+}
+
 // Derive the eval record from raw (mu, A).  Same code in prep_kernel and the list kernel.
 __device__ __forceinline__ EvalRec make_eval(const float mx, const float my, const float mz,
                                              const float *A) {
@@ -94,6 +125,9 @@ __device__ __forceinline__ EvalRec make_eval(const float mx, const float my, con
   e.kx = fmaf(A[2] - A[6], mz, (A[1] - A[3]) * my);
   e.ky = fmaf(A[5] - A[7], mz, (A[3] - A[1]) * mx);
   e.kz = fmaf(A[7] - A[5], my, (A[6] - A[2]) * mx);
+  if (A[1] == 0.0f && A[2] == 0.0f && A[3] == 0.0f && A[5] == 0.0f && A[6] == 0.0f && A[7] == 0.0f &&
+      A[0] == A[4] && A[0] == A[8])
+    e.s01 = __uint_as_float(kIsoFlag);
   return e;
 }
 
@@ -111,19 +145,41 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
 // calling thread at keys[s * stride].  Precondition: key < worst (worst = ~0 while cnt < K).
 // Implements "K lexicographically smallest (len, idx)", which is what the reference's
 // in-place insertion (ray_trace_voge.cu:197-212: strict '<', candidates in ascending index)
-// computes.
+// computes.  `tail` mirrors the largest stored key in a register (0 while empty): with a
+// front-to-back candidate stream most insertions are appends and touch LDS with one write only.
 __device__ __forceinline__ void topk_insert(uint64_t *keys, const int stride, const int K,
-                                            int &cnt, uint64_t &worst, const uint64_t key) {
-  int pos = (cnt < K) ? cnt : K - 1;
+                                            int &cnt, uint64_t &worst, uint64_t &tail, const uint64_t key) {
+  if (cnt < K) {
+    if (key >= tail) {  // append
+      keys[cnt * stride] = key;
+      tail = key;
+      if (++cnt == K) worst = key;
+      return;
+    }
+    int pos = cnt;      // somewhere in the middle: everything above moves up, the tail stays the tail
+    while (pos > 0) {
+      const uint64_t prev = keys[(pos - 1) * stride];
+      if (prev <= key) break;
+      keys[pos * stride] = prev;
+      --pos;
+    }
+    keys[pos * stride] = key;
+    if (++cnt == K) worst = tail;
+    return;
+  }
+  // full: the current tail (== worst) drops out
+  int pos = K - 1;
+  uint64_t new_tail = key;
   while (pos > 0) {
     const uint64_t prev = keys[(pos - 1) * stride];
     if (prev <= key) break;
+    if (pos == K - 1) new_tail = prev;
     keys[pos * stride] = prev;
     --pos;
   }
   keys[pos * stride] = key;
-  if (cnt < K) ++cnt;
-  if (cnt == K) worst = keys[(K - 1) * stride];
+  tail = new_tail;
+  worst = new_tail;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
