@@ -38,10 +38,20 @@ __device__ __forceinline__ float phi_cdf(const float x, float &y) {
 
 struct CompLds {
   float4 rec[kCompThreads];  // (len, s, E, u) of slot tid
+  float pre[kCompThreads];   // exclusive prefix sum of E within the pixel
+  float suf[kCompThreads];   // inclusive suffix sum of u within the pixel (backward)
+  float scan[2][kCompThreads];
   int cnt[kCompThreads];     // per local pixel: #(idx >= 0)
   int hi[kCompThreads];      // per local pixel: 1 + last slot with E != 0
+  int rmax[kCompThreads];    // per local pixel: bits of max_k 4/s_k (window radius in len)
+  int unsorted[kCompThreads];
 };
 
+// The pixel's list is depth sorted (the trace emits it that way).  Slot j influences row m only
+// through Phi((len_m - len_j) s_j), which saturates to 0 / 1 beyond |len_m - len_j| >= 4 / s_j
+// (|Phi - step| < 8e-9), so every row scans a WINDOW around itself and takes the far front
+// slots (Phi = 1) from a prefix sum of E; far back slots contribute nothing.  An unsorted list
+// (possible through the public API) simply gets an infinite window, i.e. the full K x K scan.
 template <bool BWD>
 __global__ void __launch_bounds__(kCompThreads)
 composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
@@ -56,7 +66,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   const long pix = (long)blockIdx.x * ppw + p;
   const bool active = (p < ppw) && (pix < npix);
   const long f = pix * K + k;
-  if (tid < ppw) { L.cnt[tid] = 0; L.hi[tid] = 0; }
+  if (tid < ppw) { L.cnt[tid] = 0; L.hi[tid] = 0; L.rmax[tid] = 0; L.unsorted[tid] = 0; }
   float lm = 0.f, sm = 1.f, em = 0.f, gw = 0.f;
   int id = -1;
   if (active) {
@@ -65,33 +75,58 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
     sm = sqrtf(dsd[f] + 1e-10f);
     if (BWD) gw = g_weight[f]; else id = idx[f];
   }
+  L.rec[tid] = make_float4(lm, sm, em, 0.0f);
   __syncthreads();
   if (active) {
     if (!BWD && id >= 0) atomicAdd(&L.cnt[p], 1);
-    if (em != 0.0f) atomicMax(&L.hi[p], k + 1);
+    if (em != 0.0f) {
+      atomicMax(&L.hi[p], k + 1);
+      atomicMax(&L.rmax[p], __float_as_int(kSat / sm));   // positive floats order like ints
+    }
+    if (k > 0 && !(L.rec[tid - 1].x <= lm)) L.unsorted[p] = 1;
   }
-  L.rec[tid] = make_float4(lm, sm, em, 0.0f);
   __syncthreads();
   const int hi = active ? L.hi[p] : 0;
   const float4 *row = L.rec + (active ? p * K : 0);
+  const float *pre = L.pre + (active ? p * K : 0);
+  const bool sorted = active && (L.unsorted[p] == 0);
+  const float rwin = sorted ? __int_as_float(L.rmax[p]) : INFINITY;
+  {   // exclusive prefix sum of E within each pixel: log2(K) ping-pong steps over the workgroup
+    float x = em;
+    int par = 0;
+    for (int o = 1; o < K; o <<= 1) {
+      L.scan[par][tid] = x;
+      __syncthreads();
+      if (k >= o && p < ppw) x += L.scan[par][tid - o];
+      par ^= 1;
+    }
+    L.pre[tid] = x - em;
+  }
+  __syncthreads();
 
+  // ---- row m: S_m = sum_{far front} E_j + sum_{window} E_j Phi_mj ; r_m = sum_{window} E_j s_j phi_mj
   float sum = 0.0f, rterm = 0.0f;
   if (em != 0.0f) {
-    for (int j = 0; j < hi; ++j) {
+    int j = min(k, hi - 1);
+    for (; j >= 0; --j) {             // self and towards the camera
       const float4 r = row[j];
-      // |ca| >= 4: erf saturates (|Phi - step| < 8e-9, phi < 7e-8) -> the slot either occludes
-      // fully or not at all.  Lists are depth sorted, so the lanes of a wave (consecutive m) fall
-      // outside slot j's window together and the wave skips the transcendental path uniformly.
-      const float ca = (lm - r.x) * r.y;
-      const bool in_win = (r.z != 0.0f) && (fabsf(ca) < kSat);
-      if (__any(in_win)) {
-        if (r.z != 0.0f) {
-          float y;
-          sum = fmaf(r.z, phi_cdf(ca, y), sum);
-          if (BWD) rterm = fmaf(r.z * r.y, y * kRsqrtPi, rterm);
-        }
-      } else {
-        sum += (ca > 0.0f) ? r.z : 0.0f;
+      const float d = lm - r.x;
+      if (d >= rwin) break;
+      if (r.z != 0.0f) {
+        float y;
+        sum = fmaf(r.z, phi_cdf(d * r.y, y), sum);
+        if (BWD) rterm = fmaf(r.z * r.y, y * kRsqrtPi, rterm);
+      }
+    }
+    if (j >= 0) sum += pre[j + 1];    // slots 0..j are fully in front: Phi = 1
+    for (j = k + 1; j < hi; ++j) {    // away from the camera
+      const float4 r = row[j];
+      const float d = lm - r.x;
+      if (-d >= rwin) break;
+      if (r.z != 0.0f) {
+        float y;
+        sum = fmaf(r.z, phi_cdf(d * r.y, y), sum);
+        if (BWD) rterm = fmaf(r.z * r.y, y * kRsqrtPi, rterm);
       }
     }
   }
@@ -106,25 +141,51 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   const float um = gw * w;
   L.rec[tid].w = um;
   __syncthreads();
+  {   // inclusive suffix sum of u within each pixel
+    float x = um;
+    int par = 0;
+    for (int o = 1; o < K; o <<= 1) {
+      L.scan[par][tid] = x;
+      __syncthreads();
+      if (k + o < K && p < ppw) x += L.scan[par][tid + o];
+      par ^= 1;
+    }
+    L.suf[tid] = x;
+  }
+  __syncthreads();
+  const float *suf = L.suf + (active ? p * K : 0);
+  // ---- column j (= this lane): rows far behind see Phi_mj = 1 (suffix sum of u), rows far in
+  // front see 0; phi terms live in the window |len_m - len_j| < 4 / s_j only.
   float ga = 0.0f, gl = 0.0f, gd = 0.0f;
   if (em != 0.0f) {
+    const float rj = sorted ? kSat / sm : INFINITY;
     float cPhi = 0.0f, cphi = 0.0f, cphil = 0.0f;
-    for (int m = 0; m < hi; ++m) {
+    int m = min(k, hi - 1);
+    for (; m < hi; ++m) {             // self and rows behind
       const float4 r = row[m];
       const float dl = r.x - lm;
-      const float ca = dl * sm;
-      const bool in_win = (r.w != 0.0f) && (fabsf(ca) < kSat);
-      if (__any(in_win)) {
-        if (r.w != 0.0f) {
-          float y;
-          const float Phi = phi_cdf(ca, y);
-          const float ph = r.w * (y * kRsqrtPi);
-          cPhi = fmaf(r.w, Phi, cPhi);
-          cphi += ph;
-          cphil = fmaf(ph, dl, cphil);
-        }
-      } else {
-        cPhi += (ca > 0.0f) ? r.w : 0.0f;
+      if (dl >= rj) break;
+      if (r.w != 0.0f) {
+        float y;
+        const float Phi = phi_cdf(dl * sm, y);
+        const float ph = r.w * (y * kRsqrtPi);
+        cPhi = fmaf(r.w, Phi, cPhi);
+        cphi += ph;
+        cphil = fmaf(ph, dl, cphil);
+      }
+    }
+    if (m < hi) cPhi += suf[m];       // rows m..hi-1 are fully behind: Phi = 1
+    for (m = k - 1; m >= 0; --m) {    // rows in front
+      const float4 r = row[m];
+      const float dl = r.x - lm;
+      if (-dl >= rj) break;
+      if (r.w != 0.0f) {
+        float y;
+        const float Phi = phi_cdf(dl * sm, y);
+        const float ph = r.w * (y * kRsqrtPi);
+        cPhi = fmaf(r.w, Phi, cPhi);
+        cphi += ph;
+        cphil = fmaf(ph, dl, cphil);
       }
     }
     ga = fmaf(occ * em, cPhi, -um);
