@@ -159,6 +159,7 @@ def main():
             sel = ops.ray_trace_fine(mus, isg, rays, None, thr_act, 16, K)
             w, vn = ops.composite(sel[0], sel[2], sel[1], sel[3], 1.0)
             idx = sel[0].clone()
+            vn32 = vn.to(torch.int32).contiguous()
             rgb = ops.merge(colors.detach(), w, idx, vn)
             bg = torch.ones(3, device=dev)
             g_img = torch.ones_like(rgb)
@@ -168,13 +169,14 @@ def main():
             ws = torch.empty(lib.voge_trace_workspace_bytes(1, N, H, W), dtype=torch.uint8, device=dev)
             ws_b = torch.empty(lib.voge_trace_bwd_workspace_bytes(N), dtype=torch.uint8, device=dev)
             o_i, o_l, o_a, o_d = (torch.empty_like(x) for x in sel)
+            o_c = torch.empty((1, H, W), dtype=torch.int32, device=dev)
             g3 = [torch.empty_like(w) for _ in range(3)]
             g_ray, g_mu, g_A = torch.empty_like(rays), torch.empty_like(mus), torch.empty_like(isg)
             out3, g_attr = torch.empty_like(rgb), torch.empty_like(colors)
             P = lambda x: x.data_ptr()
             calls = {
                 "trace_fwd": lambda: lib.voge_trace_topk_fwd(P(mus), P(isg), P(rays), None, 1, N, H, W, K, thr_act, P(ws),
-                                                             ws.numel(), P(o_i), P(o_l), P(o_a), P(o_d), st),
+                                                             ws.numel(), P(o_i), P(o_l), P(o_a), P(o_d), P(o_c), st),
                 "composite_fwd": lambda: lib.voge_composite_fwd(P(sel[0]), P(sel[2]), P(sel[1]), P(sel[3]), 1.0, npix, K,
                                                                 P(g3[0]), P(vn), st),
                 "shade_fwd": lambda: lib.voge_shade_fwd(P(colors), P(idx), P(w), P(vn), P(bg), -1.0, npix, K, 3, N, 1, P(rgb),
@@ -183,7 +185,7 @@ def main():
                                                         3, N, P(g_attr), P(g3[0]), st),
                 "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), 1.0, npix, K, P(g3[0]),
                                                                 P(g3[1]), P(g3[2]), st),
-                "trace_bwd": lambda: lib.voge_trace_bwd(P(mus), P(isg), P(rays), P(sel[0]), P(w), P(w), P(w), N, H, W, K,
+                "trace_bwd": lambda: lib.voge_trace_bwd(P(mus), P(isg), P(rays), P(sel[0]), P(vn32), P(w), P(w), P(w), N, H, W, K,
                                                         P(ws_b), ws_b.numel(), None, P(g_mu), P(g_A), st),
             }
             nbytes = stage_bytes(N, npix, K)

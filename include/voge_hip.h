@@ -65,7 +65,8 @@ size_t voge_trace_workspace_bytes(int B, int N, int H, int W);
  * act = mu^T A mu - (mu^T A d)^2 / dsd; keep if act < thr_act (and len < 1e10, the
  * sentinel); output the K kept candidates with the smallest (len, index), ascending;
  * unused slots hold idx=-1, len=1e10, act=1e10, dsd=0 (ray_trace_voge.cu:184-214,:244-247).
- * idx holds the global index b*N+i.  Outputs need no pre-fill.
+ * idx holds the global index b*N+i.  Outputs need no pre-fill.  cnt: NULL, or [B,H,W] int32
+ * receiving the number of hits kept per pixel (the filled prefix of the K slots).
  *
  * cam_fwd: NULL, or [B,3] unit view axis in the rays' frame: Gaussians with mu.fwd < 0
  * are skipped, which is the candidate rule of the reference's coarse stage
@@ -74,7 +75,7 @@ size_t voge_trace_workspace_bytes(int B, int N, int H, int W);
 int voge_trace_topk_fwd(const float *mus, const float *isigmas, const float *rays,
                         const float *cam_fwd, int B, int N, int H, int W, int K,
                         float thr_act, void *workspace, size_t workspace_bytes,
-                        int32_t *idx, float *len, float *act, float *dsd,
+                        int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
                         voge_stream_t stream);
 
 /*
@@ -100,10 +101,12 @@ int voge_trace_topk_list_fwd(const float *mus, const float *isigmas, const float
  *   g_ray [nrows*W,3], g_mus [P,3], g_isg [P,3,3]  (raw outer products, not symmetrised).
  * g_mus / g_isg are fully written by this call (the reference allocates zeros, :354-356);
  * g_ray is fully written, or may be NULL when the ray gradient is not needed.
+ * cnt: NULL, or [nrows*W] int32 = number of leading slots of each pixel that may hold a hit
+ * (the forward's out_cnt): slots k >= cnt[pixel] are not even loaded.
  * workspace: >= voge_trace_bwd_workspace_bytes(P) bytes, 256-byte aligned.
  */
 int voge_trace_bwd(const float *mus, const float *isigmas, const float *rays,
-                   const int32_t *idx, const float *g_len, const float *g_act,
+                   const int32_t *idx, const int32_t *cnt, const float *g_len, const float *g_act,
                    const float *g_dsd, int P, long nrows, int W, int K, void *workspace,
                    size_t workspace_bytes, float *g_ray, float *g_mus, float *g_isg,
                    voge_stream_t stream);

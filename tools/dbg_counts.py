@@ -16,7 +16,7 @@ nb = lib.voge_trace_workspace_bytes(1, N, H, W)
 ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
 out = [torch.empty((1, H, W, K), dtype=d, device=dev) for d in (torch.int32, torch.float32, torch.float32, torch.float32)]
 P = lambda x: x.data_ptr()
-rc = lib.voge_trace_topk_fwd(P(mus), P(isg), P(rays), None, 1, N, H, W, K, 4.6051702, P(ws), nb, *[P(o) for o in out], None)
+rc = lib.voge_trace_topk_fwd(P(mus), P(isg), P(rays), None, 1, N, H, W, K, 4.6051702, P(ws), nb, *[P(o) for o in out], None, None)
 torch.cuda.synchronize()
 # locate bin_lb: layout cull(P*16), evr(P*48), bin_count, bin_id, bin_lb  (256-aligned)
 al = lambda v: (v + 255) & ~255

@@ -119,9 +119,9 @@ class GaussianRenderer(nn.Module):
         sel_idx, sel_len, sel_act, sel_dsd = ray_tracing(
             cams, centred, isigma, rays, image_size, thr=st['thr_activation'], n_assign=st['max_assign'],
             max_points_per_bin=st['max_point_per_bin'])
-        # merge_final later rewrites -1 -> 0 inside the fragments' index tensor, while the trace
-        # backward needs the untouched -1 sentinels: hand out a copy, as Renderer.py:145 does
-        sel_idx = sel_idx.clone()
+        # merge_final later rewrites -1 -> 0 inside the fragments' index tensor.  The reference clones
+        # it here (Renderer.py:145) because its backward finds empty slots by idx == -1; this trace
+        # backward uses the per-pixel hit count instead, so no copy is needed.
         weight, index, valid_num, hit_len = aggregation(sel_idx=sel_idx, sel_act=sel_act, sel_len=sel_len,
                                                         sel_dsd=sel_dsd, occupation_weight=st['absorptivity'])
         return Fragments(vert_weight=weight, vert_index=index, valid_num=valid_num, vert_hit_length=hit_len)

@@ -29,15 +29,31 @@ constexpr int kBwdU = 4;        // 64-slot batches whose loads are issued togeth
 
 struct BwdWaveLds {
   WaveTable<kBwdNE, 3> tab;     // key = Gaussian index, values = g_mu (3) + g_A (9)
-  float ray[8 * 3];             // g_ray of the current 8-pixel row
+  float ray[64 * 3];            // g_ray of the tile's pixels
+  int cntv[64];                 // number of leading valid slots per pixel
+};
+
+// Slot batch = 64 consecutive slots of one 8-pixel tile row; a GROUP is kBwdU batches whose loads
+// are issued together:
+//   A(g): idx / g_len / g_act / g_dsd of the slots      (coalesced streams)
+//   B(g): packed (mu, A) record of each slot's Gaussian  (gather, needs A(g)) and the pixel's ray
+//   C(g): gradient terms + table accumulation            (LDS)
+struct BwdGroupA {
+  int p[kBwdU], pl[kBwdU];
+  float gl[kBwdU], ga[kBwdU], gd[kBwdU];
+};
+struct BwdGroupB {
+  float4 r0[kBwdU], r1[kBwdU], r2[kBwdU];
+  float dx[kBwdU], dy[kBwdU], dz[kBwdU];
+  bool live[kBwdU];
 };
 
 __global__ void __launch_bounds__(64 * kBwdWaves)
 trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
-                 const int32_t *__restrict__ idx, const float *__restrict__ g_len,
-                 const float *__restrict__ g_act, const float *__restrict__ g_dsd, const int P,
-                 const long nrows, const int W, const int K, float *__restrict__ g_ray,
-                 float *__restrict__ acc /* [P][16]: g_mu (3), g_A (9), pad (4) */) {
+                 const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt,
+                 const float *__restrict__ g_len, const float *__restrict__ g_act,
+                 const float *__restrict__ g_dsd, const int P, const long nrows, const int W, const int K,
+                 float *__restrict__ g_ray, float *__restrict__ acc /* [P][16]: g_mu (3), g_A (9), pad (4) */) {
   __shared__ BwdWaveLds Ls[kBwdWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   BwdWaveLds &L = Ls[wave];
@@ -47,113 +63,144 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
   if (tile >= ntiles) return;  // waves never synchronise with each other
   const int x0 = (int)(tile % tiles_x) * 8;
   const long y0 = (tile / tiles_x) * 8;
-  wt_clear(L.tab, lane);
-  if (lane < 24) L.ray[lane] = 0.0f;
   const int tw = min(8, W - x0);
+  const int th = (int)min(8L, nrows - y0);
+  {   // per-pixel slot counts (all K when the caller has none)
+    const int lx = lane & 7, ly = lane >> 3;
+    int c = 0;
+    if (lx < tw && ly < th) c = (cnt != nullptr) ? min(K, max(0, cnt[(y0 + ly) * W + x0 + lx])) : K;
+    L.cntv[lane] = c;
+    if (__all(c == 0)) {   // nothing was hit in this tile
+      if (g_ray != nullptr && lx < tw && ly < th) {
+        float *o = g_ray + ((y0 + ly) * W + x0 + lx) * 3;
+        o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+      }
+      return;
+    }
+  }
+  wt_clear(L.tab, lane);
+  for (int i = lane; i < 64 * 3; i += 64) L.ray[i] = 0.0f;
   const int n_items = tw * K;              // slots of one 8-pixel row: one contiguous run
   const int nit = (n_items + 63) >> 6;
+  const int nb = th * nit;                 // batches of the tile
+  const int ng = (nb + kBwdU - 1) / kBwdU;
+  const float invK = 1.0f / (float)K;
 
-  for (int r = 0; r < 8; ++r) {
-    const long py = y0 + r;
-    if (py >= nrows) break;
-    const long pix0 = py * W + x0;
-    const long base = pix0 * K;
-    for (int it0 = 0; it0 < nit; it0 += kBwdU) {
-      int p[kBwdU], lx[kBwdU];
-      float gl[kBwdU], ga[kBwdU], gd[kBwdU];
-      bool live[kBwdU];
+  auto loadA = [&](const int g, BwdGroupA &a) {
 #pragma unroll
-      for (int u = 0; u < kBwdU; ++u) {
-        const int j = (it0 + u) * 64 + lane;
-        const bool ok = (it0 + u < nit) && (j < n_items);
-        p[u] = ok ? idx[base + j] : -1;
-        gl[u] = ok ? g_len[base + j] : 0.0f;
-        ga[u] = ok ? g_act[base + j] : 0.0f;
-        gd[u] = ok ? g_dsd[base + j] : 0.0f;
-        lx[u] = ok ? j / K : 64 + lane;      // inactive lanes: private segment keys
+    for (int u = 0; u < kBwdU; ++u) {
+      const int bb = g * kBwdU + u;
+      const int r = bb / nit, it = bb - r * nit;
+      const int j = it * 64 + lane;
+      const int lx = __float2int_rz(((float)j + 0.5f) * invK);
+      const int k = j - lx * K;
+      const int pl = r * 8 + lx;
+      const bool ok = (bb < nb) && (j < n_items) && (k < L.cntv[min(pl, 63)]);
+      const long pid = ((y0 + r) * W + x0) * (long)K + j;
+      a.p[u] = ok ? idx[pid] : -1;
+      a.gl[u] = ok ? g_len[pid] : 0.0f;
+      a.ga[u] = ok ? g_act[pid] : 0.0f;
+      a.gd[u] = ok ? g_dsd[pid] : 0.0f;
+      a.pl[u] = ok ? pl : 64 + lane;       // inactive lanes: private segment keys
+    }
+  };
+  auto loadB = [&](const BwdGroupA &a, BwdGroupB &b) {
+#pragma unroll
+    for (int u = 0; u < kBwdU; ++u) {
+      b.live[u] = (a.p[u] >= 0) && (a.p[u] < P) && !(a.gl[u] == 0.0f && a.ga[u] == 0.0f && a.gd[u] == 0.0f);
+      if (b.live[u]) {
+        b.r0[u] = rec[3 * (size_t)a.p[u]]; b.r1[u] = rec[3 * (size_t)a.p[u] + 1]; b.r2[u] = rec[3 * (size_t)a.p[u] + 2];
+        const float *ry = rays + ((y0 + (a.pl[u] >> 3)) * W + x0 + (a.pl[u] & 7)) * 3;
+        b.dx[u] = ry[0]; b.dy[u] = ry[1]; b.dz[u] = ry[2];
       }
-      float4 r0[kBwdU], r1[kBwdU], r2[kBwdU];
-      float dxs[kBwdU], dys[kBwdU], dzs[kBwdU];
+    }
+  };
+  auto compute = [&](const BwdGroupA &a, const BwdGroupB &b) {
 #pragma unroll
-      for (int u = 0; u < kBwdU; ++u) {
-        live[u] = (p[u] >= 0) && (p[u] < P) && !(gl[u] == 0.0f && ga[u] == 0.0f && gd[u] == 0.0f);
-        if (live[u]) {
-          r0[u] = rec[3 * (size_t)p[u]]; r1[u] = rec[3 * (size_t)p[u] + 1]; r2[u] = rec[3 * (size_t)p[u] + 2];
-          const float *ry = rays + (pix0 + lx[u]) * 3;
-          dxs[u] = ry[0]; dys[u] = ry[1]; dzs[u] = ry[2];
-        }
+    for (int u = 0; u < kBwdU; ++u) {
+      float4 val[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+      float rx = 0.f, ryv = 0.f, rz = 0.f;
+      if (b.live[u]) {
+        const float dx = b.dx[u], dy = b.dy[u], dz = b.dz[u];
+        const float mx = b.r0[u].x, my = b.r0[u].y, mz = b.r0[u].z;
+        const float A[9] = {b.r0[u].w, b.r1[u].x, b.r1[u].y, b.r1[u].z, b.r1[u].w, b.r2[u].x, b.r2[u].y, b.r2[u].z, b.r2[u].w};
+        const float adx = fmaf(A[2], dz, fmaf(A[1], dy, A[0] * dx));
+        const float ady = fmaf(A[5], dz, fmaf(A[4], dy, A[3] * dx));
+        const float adz = fmaf(A[8], dz, fmaf(A[7], dy, A[6] * dx));
+        const float tdx = fmaf(A[6], dz, fmaf(A[3], dy, A[0] * dx));
+        const float tdy = fmaf(A[7], dz, fmaf(A[4], dy, A[1] * dx));
+        const float tdz = fmaf(A[8], dz, fmaf(A[5], dy, A[2] * dx));
+        const float ksk = fmaf(dz, adz, fmaf(dy, ady, dx * adx));
+        const float msk = fmaf(mz, adz, fmaf(my, ady, mx * adx));
+        const float ik = __builtin_amdgcn_rcpf(ksk);
+        const float t = msk * ik;
+        const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
+        const float avx = fmaf(A[2], vz, fmaf(A[1], vy, A[0] * vx));
+        const float avy = fmaf(A[5], vz, fmaf(A[4], vy, A[3] * vx));
+        const float avz = fmaf(A[8], vz, fmaf(A[7], vy, A[6] * vx));
+        const float tvx = fmaf(A[6], vz, fmaf(A[3], vy, A[0] * vx));
+        const float tvy = fmaf(A[7], vz, fmaf(A[4], vy, A[1] * vx));
+        const float tvz = fmaf(A[8], vz, fmaf(A[5], vy, A[2] * vx));
+        const float c1 = a.gl[u] * ik;
+        const float g_a = a.ga[u], g_d = a.gd[u];
+        const float gat = g_a * t;
+        float o[12];
+        o[0] = fmaf(c1, adx, g_a * (avx + tvx + t * (tdx - adx)));
+        o[1] = fmaf(c1, ady, g_a * (avy + tvy + t * (tdy - ady)));
+        o[2] = fmaf(c1, adz, g_a * (avz + tvz + t * (tdz - adz)));
+        const float d[3] = {dx, dy, dz}, v[3] = {vx, vy, vz};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            o[3 + 3 * i + c] = fmaf(g_a, fmaf(v[i], v[c], t * (d[i] * v[c] - v[i] * d[c])),
+                                    fmaf(g_d, d[i] * d[c], c1 * (v[i] * d[c])));
+        val[0] = make_float4(o[0], o[1], o[2], o[3]);
+        val[1] = make_float4(o[4], o[5], o[6], o[7]);
+        val[2] = make_float4(o[8], o[9], o[10], o[11]);
+        rx = fmaf(g_d, adx + tdx, fmaf(c1, fmaf(-t, adx, tvx), gat * fmaf(t, adx - tdx, -2.0f * tvx)));
+        ryv = fmaf(g_d, ady + tdy, fmaf(c1, fmaf(-t, ady, tvy), gat * fmaf(t, ady - tdy, -2.0f * tvy)));
+        rz = fmaf(g_d, adz + tdz, fmaf(c1, fmaf(-t, adz, tvz), gat * fmaf(t, adz - tdz, -2.0f * tvz)));
       }
+      if (!__any(b.live[u])) continue;   // uniform
+      const int slot = wt_find(L.tab, a.p[u], b.live[u]);
+      wt_add(L.tab, slot, val, b.live[u] && slot >= 0, lane);
+      if (b.live[u] && slot < 0) {  // table full: rare, straight to HBM
+        const float o[12] = {val[0].x, val[0].y, val[0].z, val[0].w, val[1].x, val[1].y,
+                             val[1].z, val[1].w, val[2].x, val[2].y, val[2].z, val[2].w};
 #pragma unroll
-      for (int u = 0; u < kBwdU; ++u) {
-        if (it0 + u >= nit) break;   // uniform
-        float4 val[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-        float rx = 0.f, ryv = 0.f, rz = 0.f;
-        if (live[u]) {
-          const float dx = dxs[u], dy = dys[u], dz = dzs[u];
-          const float mx = r0[u].x, my = r0[u].y, mz = r0[u].z;
-          const float A[9] = {r0[u].w, r1[u].x, r1[u].y, r1[u].z, r1[u].w, r2[u].x, r2[u].y, r2[u].z, r2[u].w};
-          const float adx = fmaf(A[2], dz, fmaf(A[1], dy, A[0] * dx));
-          const float ady = fmaf(A[5], dz, fmaf(A[4], dy, A[3] * dx));
-          const float adz = fmaf(A[8], dz, fmaf(A[7], dy, A[6] * dx));
-          const float tdx = fmaf(A[6], dz, fmaf(A[3], dy, A[0] * dx));
-          const float tdy = fmaf(A[7], dz, fmaf(A[4], dy, A[1] * dx));
-          const float tdz = fmaf(A[8], dz, fmaf(A[5], dy, A[2] * dx));
-          const float ksk = fmaf(dz, adz, fmaf(dy, ady, dx * adx));
-          const float msk = fmaf(mz, adz, fmaf(my, ady, mx * adx));
-          const float ik = __builtin_amdgcn_rcpf(ksk);
-          const float t = msk * ik;
-          const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
-          const float avx = fmaf(A[2], vz, fmaf(A[1], vy, A[0] * vx));
-          const float avy = fmaf(A[5], vz, fmaf(A[4], vy, A[3] * vx));
-          const float avz = fmaf(A[8], vz, fmaf(A[7], vy, A[6] * vx));
-          const float tvx = fmaf(A[6], vz, fmaf(A[3], vy, A[0] * vx));
-          const float tvy = fmaf(A[7], vz, fmaf(A[4], vy, A[1] * vx));
-          const float tvz = fmaf(A[8], vz, fmaf(A[5], vy, A[2] * vx));
-          const float c1 = gl[u] * ik;
-          const float g_a = ga[u], g_d = gd[u];
-          const float gat = g_a * t;
-          float o[12];
-          o[0] = fmaf(c1, adx, g_a * (avx + tvx + t * (tdx - adx)));
-          o[1] = fmaf(c1, ady, g_a * (avy + tvy + t * (tdy - ady)));
-          o[2] = fmaf(c1, adz, g_a * (avz + tvz + t * (tdz - adz)));
-          const float d[3] = {dx, dy, dz}, v[3] = {vx, vy, vz};
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-              o[3 + 3 * a + c] = fmaf(g_a, fmaf(v[a], v[c], t * (d[a] * v[c] - v[a] * d[c])),
-                                      fmaf(g_d, d[a] * d[c], c1 * (v[a] * d[c])));
-          val[0] = make_float4(o[0], o[1], o[2], o[3]);
-          val[1] = make_float4(o[4], o[5], o[6], o[7]);
-          val[2] = make_float4(o[8], o[9], o[10], o[11]);
-          rx = fmaf(g_d, adx + tdx, fmaf(c1, fmaf(-t, adx, tvx), gat * fmaf(t, adx - tdx, -2.0f * tvx)));
-          ryv = fmaf(g_d, ady + tdy, fmaf(c1, fmaf(-t, ady, tvy), gat * fmaf(t, ady - tdy, -2.0f * tvy)));
-          rz = fmaf(g_d, adz + tdz, fmaf(c1, fmaf(-t, adz, tvz), gat * fmaf(t, adz - tdz, -2.0f * tvz)));
-        }
-        const int slot = wt_find(L.tab, p[u], live[u]);
-        wt_add(L.tab, slot, val, live[u] && slot >= 0, lane);
-        if (live[u] && slot < 0) {  // table full: rare, straight to HBM
-          const float o[12] = {val[0].x, val[0].y, val[0].z, val[0].w, val[1].x, val[1].y,
-                               val[1].z, val[1].w, val[2].x, val[2].y, val[2].z, val[2].w};
-#pragma unroll
-          for (int c = 0; c < 12; ++c) unsafeAtomicAdd(acc + 16 * (size_t)p[u] + c, o[c]);
-        }
-        if (g_ray != nullptr) {  // pixel-owned: segmented sum over the lanes of each pixel
-          rx = seg_sum_key(rx, lx[u], lane);
-          ryv = seg_sum_key(ryv, lx[u], lane);
-          rz = seg_sum_key(rz, lx[u], lane);
-          const int prev = __shfl_up(lx[u], 1, 64);
-          if ((lane == 0 || prev != lx[u]) && lx[u] < 8) {
-            L.ray[lx[u] * 3 + 0] += rx;
-            L.ray[lx[u] * 3 + 1] += ryv;
-            L.ray[lx[u] * 3 + 2] += rz;
-          }
+        for (int c = 0; c < 12; ++c) unsafeAtomicAdd(acc + 16 * (size_t)a.p[u] + c, o[c]);
+      }
+      if (g_ray != nullptr) {  // pixel-owned: segmented sum over the lanes of each pixel
+        rx = seg_sum_key(rx, a.pl[u], lane);
+        ryv = seg_sum_key(ryv, a.pl[u], lane);
+        rz = seg_sum_key(rz, a.pl[u], lane);
+        const int prev = __shfl_up(a.pl[u], 1, 64);
+        if ((lane == 0 || prev != a.pl[u]) && a.pl[u] < 64) {
+          L.ray[a.pl[u] * 3 + 0] += rx;
+          L.ray[a.pl[u] * 3 + 1] += ryv;
+          L.ray[a.pl[u] * 3 + 2] += rz;
         }
       }
     }
-    if (g_ray != nullptr) {
-      if (lane < tw * 3) g_ray[pix0 * 3 + lane] = L.ray[lane];
-      if (lane < 24) L.ray[lane] = 0.0f;
+  };
+
+  // No register double-buffering across groups: at 80 VGPRs ten waves share a CU (the LDS tables
+  // are the limit) and hide each other's latency; a two-deep software pipeline needed 176-256
+  // VGPRs and measured slower (254 / 362 us vs 223 us on MI355X).
+  for (int g = 0; g < ng; ++g) {
+    BwdGroupA a;
+    BwdGroupB b;
+    loadA(g, a);
+    loadB(a, b);
+    compute(a, b);
+  }
+
+  if (g_ray != nullptr) {
+    for (int j = lane; j < 64 * 3; j += 64) {
+      const int i = j / 3, c = j - i * 3;
+      const int px = i & 7, py = i >> 3;
+      if (px < tw && py < th) g_ray[((y0 + py) * W + x0 + px) * 3 + c] = L.ray[j];
     }
   }
   // flush: 16 adjacent lanes per table entry add 12 adjacent floats of ONE 64-byte line of
@@ -200,7 +247,7 @@ extern "C" size_t voge_trace_bwd_workspace_bytes(int P) {
 }
 
 extern "C" int voge_trace_bwd(const float *mus, const float *isigmas, const float *rays,
-                              const int32_t *idx, const float *g_len, const float *g_act,
+                              const int32_t *idx, const int32_t *cnt, const float *g_len, const float *g_act,
                               const float *g_dsd, int P, long nrows, int W, int K, void *workspace,
                               size_t workspace_bytes, float *g_ray, float *g_mus, float *g_isg,
                               voge_stream_t stream) {
@@ -221,7 +268,7 @@ extern "C" int voge_trace_bwd(const float *mus, const float *isigmas, const floa
     hipLaunchKernelGGL(bwd_pack_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, P, rec);
     const long tiles = (long)((W + 7) / 8) * ((nrows + 7) / 8);
     hipLaunchKernelGGL(trace_bwd_kernel, dim3((unsigned)((tiles + kBwdWaves - 1) / kBwdWaves)), dim3(64 * kBwdWaves),
-                       0, st, rec, rays, idx, g_len, g_act, g_dsd, P, nrows, W, K, g_ray, acc);
+                       0, st, rec, rays, idx, cnt, g_len, g_act, g_dsd, P, nrows, W, K, g_ray, acc);
   }
   hipLaunchKernelGGL(bwd_unpack_kernel, dim3((unsigned)(((size_t)P * 16 + 255) / 256)), dim3(256), 0, st, acc, P,
                      g_mus, g_isg);

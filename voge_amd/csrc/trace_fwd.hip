@@ -440,7 +440,8 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
                  const int *__restrict__ tl_count, const int32_t *__restrict__ tl_id,
                  const float *__restrict__ tl_lb, const int nstx, const int nst, const int N, const int H,
                  const int W, const int K, const float thr_act, int32_t *__restrict__ out_idx,
-                 float *__restrict__ out_len, float *__restrict__ out_act, float *__restrict__ out_dsd) {
+                 float *__restrict__ out_len, float *__restrict__ out_act, float *__restrict__ out_dsd,
+                 int32_t *__restrict__ out_cnt) {
   constexpr int T = 64 * WAVES;
   constexpr int TP = T + 1;   // key row stride: the transposed epilogue read stays conflict-light
   constexpr int TW = (WAVES >= 2) ? 16 : 8;
@@ -648,6 +649,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 
   // ---- epilogue: lanes re-mapped to (pixel, slot); act / dsd recomputed with pair_eval ------
   L.cnt[tid] = cnt;
+  if (out_cnt != nullptr && valid) out_cnt[((size_t)b * H + py) * W + px] = cnt;
   __syncthreads();
   const int tw = min(TW, W - tx * TW);
   const int row_items = tw * K;
@@ -803,7 +805,8 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
 
 template <int WAVES>
 static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int H, int W, int K,
-                        float thr_act, int32_t *idx, float *len, float *act, float *dsd, hipStream_t st) {
+                        float thr_act, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
+                        hipStream_t st) {
   constexpr int T = 64 * WAVES;
   constexpr int TW = (WAVES >= 2) ? 16 : 8;
   constexpr int TH = (WAVES == 4) ? 16 : 8;
@@ -820,7 +823,7 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
     if (rc) return rc;
   }
   hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, rays, ws.bin_count, ws.bin_id, ws.bin_lb,
-                     ws.tl_count, ws.tl_id, ws.tl_lb, ws.nstx, ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd);
+                     ws.tl_count, ws.tl_id, ws.tl_lb, ws.nstx, ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd, cnt);
   return launch_status();
 }
 
@@ -836,7 +839,7 @@ extern "C" size_t voge_trace_workspace_bytes(int B, int N, int H, int W) {
 extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const float *rays,
                                    const float *cam_fwd, int B, int N, int H, int W, int K,
                                    float thr_act, void *workspace, size_t workspace_bytes,
-                                   int32_t *idx, float *len, float *act, float *dsd,
+                                   int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
                                    voge_stream_t stream) {
   if (B < 0 || N < 0 || H < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K) return VOGE_ERR_K_TOO_LARGE;
@@ -866,10 +869,10 @@ extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const
     return sizeof(uint64_t) * (size_t)K * (64 * waves + 1) + 16 + fixed <= budget;
   };
   const size_t two_per_cu = 80 * 1024, one_per_cu = 160 * 1024;
-  if (fits(4, two_per_cu)) return launch_trace<4>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
-  if (fits(2, two_per_cu)) return launch_trace<2>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
-  if (fits(1, two_per_cu)) return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
-  if (fits(1, one_per_cu)) return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, st);
+  if (fits(4, two_per_cu)) return launch_trace<4>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
+  if (fits(2, two_per_cu)) return launch_trace<2>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
+  if (fits(1, two_per_cu)) return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
+  if (fits(1, one_per_cu)) return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
   return VOGE_ERR_K_TOO_LARGE;
 }
 

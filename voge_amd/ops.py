@@ -57,6 +57,7 @@ class _RayTraceVoGE(torch.autograd.Function):
         sel_len = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
         sel_act = torch.empty_like(sel_len)
         sel_dsd = torch.empty_like(sel_len)
+        cnt = None
         with torch.cuda.device(dev):
             if bin_points is not None and bin_points.dtype in (torch.int32, torch.int64):
                 bins = _dev(bin_points, torch.int32, "bin_points")
@@ -72,18 +73,32 @@ class _RayTraceVoGE(torch.autograd.Function):
                 fwd = None if bin_points is None else _dev(bin_points, torch.float32, "cam_fwd")
                 nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
                 ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+                cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
                 rc = lib.voge_trace_topk_fwd(
                     _p(mus_c), _p(isg_c), _p(rays_c), _p(fwd), B, N, H, W, K, float(thr_act), _p(ws), nbytes,
-                    _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _stream())
+                    _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _p(cnt), _stream())
                 _lib.check(rc, "voge_trace_topk_fwd")
-        ctx.save_for_backward(mus_c, isg_c, rays_c, sel_idx)
+        if cnt is None:
+            # explicit bin lists: the backward recognises empty slots by idx == -1, so the index tensor
+            # must stay untouched until then (autograd's version check enforces it)
+            ctx.save_for_backward(mus_c, isg_c, rays_c, sel_idx)
+        else:
+            # the per-pixel hit count tells the backward which slots are filled, so the index tensor
+            # may later be rewritten in place by merge_final (-1 -> 0) without a defensive copy
+            ctx.save_for_backward(mus_c, isg_c, rays_c)
+            ctx.sel_idx = sel_idx
+        ctx.cnt = cnt
         ctx.mark_non_differentiable(sel_idx)
         return sel_idx, sel_len, sel_act, sel_dsd
 
     @staticmethod
     def backward(ctx, grad_sel_idx, grad_sel_len, grad_sel_act, grad_sel_dsd):
         lib = _lib.load()
-        mus, isg, rays, sel_idx = ctx.saved_tensors
+        if ctx.cnt is None:
+            mus, isg, rays, sel_idx = ctx.saved_tensors
+        else:
+            mus, isg, rays = ctx.saved_tensors
+            sel_idx = ctx.sel_idx
         B, H, W, K = sel_idx.shape
         P = mus.shape[0]
         zeros = None
@@ -102,7 +117,7 @@ class _RayTraceVoGE(torch.autograd.Function):
         with torch.cuda.device(rays.device):
             nbytes = lib.voge_trace_bwd_workspace_bytes(P)
             ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=rays.device)
-            rc = lib.voge_trace_bwd(_p(mus), _p(isg), _p(rays), _p(sel_idx), _p(gl), _p(ga), _p(gd), P,
+            rc = lib.voge_trace_bwd(_p(mus), _p(isg), _p(rays), _p(sel_idx), _p(ctx.cnt), _p(gl), _p(ga), _p(gd), P,
                                     B * H, W, K, _p(ws), nbytes, _p(g_ray), _p(g_mus), _p(g_isg), _stream())
         _lib.check(rc, "voge_trace_bwd")
         return g_mus, g_isg, g_ray, None, None, None, None
