@@ -449,7 +449,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   constexpr int kCap = T;     // one chunk of the candidate stream is staged at a time
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t *keys = reinterpret_cast<uint64_t *>(smem_raw);
-  TraceLds<T> &L = *reinterpret_cast<TraceLds<T> *>(smem_raw + ((sizeof(uint64_t) * (size_t)K * TP + 15) & ~(size_t)15));
+  TraceLds<T> &L = *reinterpret_cast<TraceLds<T> *>(smem_raw + ((sizeof(uint64_t) * (size_t)(K + 1) * TP + 15) & ~(size_t)15));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (W + TW - 1) / TW;
@@ -521,8 +521,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   uint64_t *mykeys = keys + tid;
   int cnt = 0;
   uint64_t worst = ~0ull, tail = 0ull;
-  bool wdone = false, reported = false, can_exit = false;
-  float wmax = INFINITY;
+  bool wdone = false, reported = false;
 
   int base = 0, par = 0;
   // two-deep software pipeline: ids two chunks ahead, cull records one chunk ahead
@@ -573,17 +572,22 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
         bool keep = false;
         if (i < nbuf) keep = (WAVES == 1) ? true : cone_keep(L.cull[i], wcone);
         unsigned long long m = __ballot(keep);
-        // Exit bound, refreshed once per 64-candidate batch: a stale (larger) bound only delays
-        // the exit, it never makes it wrong, because a lane's worst key only ever decreases.
+        // Exit test, once per 64-candidate batch.  The bound is refreshed here only: a stale
+        // (larger) bound merely delays the exit, because a lane's worst key only ever decreases.
+        // The list bounds are monotone, so "first candidate past the bound" cuts the batch.
+        bool last_batch = false;
         if (binned && unit_rays && __all(!valid || cnt == K)) {
-          wmax = wave_max(valid ? ord2f((uint32_t)(worst >> 32)) : -INFINITY);
-          can_exit = true;
-        }
-        auto commit = [&](const PairOut &o, const int s) {
-          if (valid && o.act < thr_act && o.len < VOGE_SENT_LEN) {
-            const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)(L.id[s] + b * N);
-            if (key < worst) topk_insert(mykeys, TP, K, cnt, worst, tail, key);
+          const float wmax = wave_max(valid ? ord2f((uint32_t)(worst >> 32)) : -INFINITY);
+          const unsigned long long ex = __ballot(i < nbuf && L.lb[i] > wmax);
+          if (ex) {
+            m &= (1ull << __builtin_ctzll(ex)) - 1ull;
+            last_batch = true;
           }
+        }
+        auto commit = [&](const PairOut &o, const int s, const bool on) {
+          const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)(L.id[s] + b * N);
+          const bool take = on && valid && (o.act < thr_act) && (o.len < VOGE_SENT_LEN) && (key < worst);
+          topk_commit(mykeys, TP, K, cnt, worst, tail, key, take);
         };
         while (m) {
           // four candidates per trip: their evaluations are independent instruction streams
@@ -594,7 +598,6 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             sq[q] = c0 + (m ? __builtin_ctzll(m) : 0);
             if (m) { ++nt; m &= m - 1ull; }
           }
-          if (can_exit && L.lb[sq[0]] > wmax) { wdone = true; break; }
           // The four evaluations form ONE straight-line block (the isotropic / general choice is
           // made per batch, on scalar registers), so the scheduler interleaves their chains.
           PairOut o[4];
@@ -629,14 +632,9 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             }
           }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (q < nt) {
-              if (q > 0 && can_exit && L.lb[sq[q]] > wmax) { wdone = true; break; }
-              commit(o[q], sq[q]);
-            }
-          }
-          if (wdone) break;
+          for (int q = 0; q < 4; ++q) commit(o[q], sq[q], q < nt);
         }
+        if (last_batch) wdone = true;
       }
     }
     if (wdone && !reported) {
@@ -810,7 +808,7 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
   constexpr int T = 64 * WAVES;
   constexpr int TW = (WAVES >= 2) ? 16 : 8;
   constexpr int TH = (WAVES == 4) ? 16 : 8;
-  const size_t lds = ((sizeof(uint64_t) * (size_t)K * (T + 1) + 15) & ~(size_t)15) + sizeof(TraceLds<T>);
+  const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + sizeof(TraceLds<T>);
   auto kern = trace_fwd_kernel<WAVES>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -866,7 +864,7 @@ extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const
   // largest tile whose LDS footprint still lets two workgroups share a CU; else whatever fits
   auto fits = [&](int waves, size_t budget) {
     const size_t fixed = waves == 4 ? sizeof(TraceLds<256>) : waves == 2 ? sizeof(TraceLds<128>) : sizeof(TraceLds<64>);
-    return sizeof(uint64_t) * (size_t)K * (64 * waves + 1) + 16 + fixed <= budget;
+    return sizeof(uint64_t) * (size_t)(K + 1) * (64 * waves + 1) + 16 + fixed <= budget;
   };
   const size_t two_per_cu = 80 * 1024, one_per_cu = 160 * 1024;
   if (fits(4, two_per_cu)) return launch_trace<4>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);

@@ -182,6 +182,50 @@ __device__ __forceinline__ void topk_insert(uint64_t *keys, const int stride, co
   worst = new_tail;
 }
 
+// Same contract, written for the sweep's common case: `take` lanes whose key is >= their tail and
+// whose list is not full APPEND; they do so without a branch (the other lanes store into the
+// spare row K of their column, which is never read).  Only lanes that must shift stored keys
+// (out-of-order arrival, or a full list) enter the loop-carrying slow path, and the wave skips
+// that path entirely when no lane needs it.  keys has K + 1 rows.
+__device__ __forceinline__ void topk_commit(uint64_t *keys, const int stride, const int K, int &cnt,
+                                            uint64_t &worst, uint64_t &tail, const uint64_t key,
+                                            const bool take /* key < worst */) {
+  const bool app = take && (cnt < K) && (key >= tail);
+  keys[(app ? cnt : K) * stride] = key;
+  cnt += app ? 1 : 0;
+  tail = app ? key : tail;
+  worst = (app && cnt == K) ? key : worst;
+  const bool slow = take && !app;
+  if (__any(slow)) {
+    if (slow) {
+      if (cnt < K) {   // somewhere in the middle: everything above moves up, the tail stays the tail
+        int pos = cnt;
+        while (pos > 0) {
+          const uint64_t prev = keys[(pos - 1) * stride];
+          if (prev <= key) break;
+          keys[pos * stride] = prev;
+          --pos;
+        }
+        keys[pos * stride] = key;
+        if (++cnt == K) worst = tail;
+      } else {         // full: the current tail (== worst) drops out
+        int pos = K - 1;
+        uint64_t new_tail = key;
+        while (pos > 0) {
+          const uint64_t prev = keys[(pos - 1) * stride];
+          if (prev <= key) break;
+          if (pos == K - 1) new_tail = prev;
+          keys[pos * stride] = prev;
+          --pos;
+        }
+        keys[pos * stride] = key;
+        tail = new_tail;
+        worst = new_tail;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
