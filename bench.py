@@ -197,9 +197,16 @@ def main():
             hits = int((sel[0] >= 0).sum().item())
         dom = "trace_fwd"  # the sweep BASELINE.json's metric names
         a = stages[dom]["GBps"]
-        result["roofline"] = {"kernel": "voge_trace_topk_fwd (prep_kernel + trace_fwd_kernel)", "bound": "hbm",
-                              "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
-                              "traffic": None, "algorithmic_bytes": nbytes[dom], "avg_launch_ms": stages[dom]["ms"]}
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if args.config == "cfg3_50k_512" and os.path.exists(tfile):
+            # HBM bytes per launch from rocprofv3 PMC passes of this same command (not collectable live)
+            traffic = json.load(open(tfile)).get("voge_trace_topk_fwd_bytes")
+            traffic_src = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
+        result["roofline"] = {"kernel": "voge_trace_topk_fwd = prep_kernel + bin_kernel + bin2_kernel + trace_fwd_kernel",
+                              "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                              "algorithmic_bytes": nbytes[dom], "avg_launch_ms": stages[dom]["ms"]}
         result["stages"] = stages
         result["frame_kernel_ms_sum"] = round(sum(s["ms"] for s in stages.values()), 4)
         result["hits_per_pixel"] = round(hits / npix, 2)
