@@ -133,13 +133,13 @@ __device__ __forceinline__ float depth_key(const float4 c, const Cone &k) {
 }
 
 // ------------------------------------------------------------------------------------------
-// bin: one 1024-thread workgroup per 64x64-pixel super-tile.  Tests every Gaussian of the
+// bin: one 1024-thread workgroup per kST x kST-pixel super-tile.  Tests every Gaussian of the
 // batch element against the super-tile's bounding cone (conservative), then orders the
 // survivors front to back by depth key (counting sort + per-bucket insertion sort, LDS) and
 // writes the (id, monotone len lower bound) list.
 // More than kBinCap survivors -> count = -1 and the sweep falls back to the full stream.
 // ------------------------------------------------------------------------------------------
-constexpr int kST = 64;
+constexpr int kST = 32;
 constexpr int kBinCap = 8192;
 constexpr int kBinThreads = 1024;
 
@@ -207,16 +207,17 @@ bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, cons
   __syncthreads();
   const float4 *cullb = cull + (size_t)b * N;
   float rmax = 0.0f;   // largest finite reach among this thread's survivors
-  for (int base = 0; base < N; base += 4 * kBinThreads) {
-    // four independent 16-byte loads in flight per lane: the scan is latency-, not compute-bound
-    float4 c[4];
+  constexpr int kScanU = 8;
+  for (int base = 0; base < N; base += kScanU * kBinThreads) {
+    // eight independent 16-byte loads in flight per lane: the scan is latency-, not compute-bound
+    float4 c[kScanU];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kScanU; ++q) {
       const int g = base + q * kBinThreads + tid;
       c[q] = (g < N) ? cullb[g] : make_float4(0.f, 0.f, 0.f, -1.f);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kScanU; ++q) {
       const int g = base + q * kBinThreads + tid;
       const bool keep = cone_keep(c[q], cone);
       if (keep && c[q].w < 3e38f) rmax = fmaxf(rmax, c[q].w);

@@ -89,6 +89,7 @@ class _RayTraceVoGE(torch.autograd.Function):
             ctx.sel_idx = sel_idx
         ctx.cnt = cnt
         ctx.mark_non_differentiable(sel_idx)
+        ctx.set_materialize_grads(False)
         return sel_idx, sel_len, sel_act, sel_dsd
 
     @staticmethod
@@ -145,11 +146,14 @@ class _Composite(torch.autograd.Function):
         ctx.save_for_backward(act, ln, dsd)
         ctx.occ = float(occ)
         ctx.mark_non_differentiable(valid)
+        ctx.set_materialize_grads(False)
         return weight, valid
 
     @staticmethod
     def backward(ctx, g_weight, _g_valid):
         lib = _lib.load()
+        if g_weight is None:
+            return None, None, None, None, None
         act, ln, dsd = ctx.saved_tensors
         K = act.shape[-1]
         npix = act.numel() // max(K, 1)
