@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3_50k_512")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU oracle work for cpu_baseline")
     return ap.parse_args()
 
@@ -122,12 +123,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The frame is launch-bound on the host (~35 kernels of 5-220 us): capture one forward+backward
+    # into a HIP graph and replay it per step.  Every replay runs exactly the kernels of an eager
+    # step on the same (static) tensors; eager launches remain available with --no-graph.
+    run = step
+    graphed = False
+    if not args.no_graph and world == 1:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            graph.replay()
+            torch.cuda.synchronize()
+            run, graphed = graph.replay, True
+        except Exception as e:  # pragma: no cover - depends on the runtime
+            print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            run = step
+
     for _ in range(args.warmup):
-        step()
+        run()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -144,6 +170,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {N} random Gaussians, {H}x{W}, K={K}, max_point_per_bin=-1, "
                                f"fwd+bwd (grads to verts, sigmas, colors)",
+                   "launch": "hip graph replay" if graphed else "eager",
                    "parallelism": "1 gpu" if world == 1 else f"pixel-row bands x{world}, all_gather(image)+all_reduce(grads)"},
     }
 
