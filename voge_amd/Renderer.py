@@ -136,10 +136,23 @@ def get_silhouette(fragments: Fragments):
     return ops.silhouette(fragments.vert_weight)
 
 
+_BG_CACHE = {}
+
+
+def _background_tensor(color, device):
+    """Device tensor of a constant background colour, uploaded once per (colour, device): a
+    host-to-device copy per frame would also make the frame impossible to capture in a HIP graph."""
+    key = (tuple(float(c) for c in color), str(device))
+    t = _BG_CACHE.get(key)
+    if t is None:
+        t = _BG_CACHE[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+    return t
+
+
 def to_colored_background(fragments: Fragments, colors: torch.Tensor,
                           background_color: Union[torch.Tensor, tuple, list] = (1, 1, 1), thr: float = -1):
     if not torch.is_tensor(background_color):
-        background_color = torch.tensor(list(background_color), dtype=torch.float32, device=colors.device)
+        background_color = _background_tensor(background_color, colors.device)
     background_color = background_color.to(colors.device)
     if colors.dim() == 2 and colors.shape[1] <= 4:
         # merge + silhouette + blend fused in one kernel (and one backward kernel)
