@@ -218,6 +218,51 @@ int voge_rays_bwd(const float *R, const float *T, const float *focal, const floa
                   float *scratch, float *g_R, float *g_T, float *g_focal, float *g_pp,
                   voge_stream_t stream);
 
+/* ---- rows "next" (SURVEY.md §8f): dense ray API and the sampler's helpers ------------------ */
+
+/*
+ * Dense trace: every (ray n, Gaussian m) pair.  Replaces: VoGE._C.ray_trace_voge_ray
+ * (voge_ray_tracing_ray.cu:114-143, :242-283).  mus [M,3], isigmas [M,3,3], rays [N,3] ->
+ * len, act, dsd [N,M] (same arithmetic as the fine trace).
+ */
+int voge_ray_dense_fwd(const float *mus, const float *isigmas, const float *rays, int M, long N,
+                       float *len, float *act, float *dsd, voge_stream_t stream);
+
+/*
+ * Its backward.  Replaces: VoGE._C.ray_trace_voge_ray_backward (voge_ray_tracing_ray.cu:147-188).
+ * g_len, g_act, g_dsd [N,M] -> g_ray [N,3], g_mus [M,3], g_isg [M,3,3] (all written).
+ */
+int voge_ray_dense_bwd(const float *mus, const float *isigmas, const float *rays, const float *g_len,
+                       const float *g_act, const float *g_dsd, int M, long N, float *g_ray,
+                       float *g_mus, float *g_isg, voge_stream_t stream);
+
+/*
+ * Top-K over dense rows.  Replaces: VoGE._C.find_nearest_k (voge_ray_tracing_ray.cu:191-239,
+ * :328-375): per ray the K entries with act < thr_act and the smallest (len, m), ascending;
+ * unused slots: idx -1, len 1e10, act 0, dsd 0.
+ */
+int voge_find_nearest_k(const float *len_in, const float *act_in, const float *dsd_in, float thr_act,
+                        int M, int K, long N, int32_t *idx, float *len, float *act, float *dsd,
+                        voge_stream_t stream);
+
+/*
+ * Gradient of that selection (the reference scatters in Python, RayTracing.py:230-241):
+ * gi_*[n, idx[n,k]] = g_*[n,k] for idx >= 0, zero elsewhere.  gi_* [N,M] are fully written.
+ */
+int voge_find_nearest_k_bwd(const int32_t *idx, const float *g_len, const float *g_act, const float *g_dsd,
+                            int M, int K, long N, float *gi_len, float *gi_act, float *gi_dsd,
+                            voge_stream_t stream);
+
+/*
+ * Per-Gaussian maximum weight.  Replaces: VoGE._C.scatter_max (sample_voge.cu:69-92,:135-170):
+ * out[idx] = max over the n slots with that index of weight (weights are >= 0); out [Nv] zero-filled.
+ * (sample_voge / sample_voge_backward, sample_voge.cu:35-66,:173-252, are the transpose of
+ * merge_final: use voge_merge_bwd with g_out = [image | 1] for the forward and voge_merge_fwd /
+ * voge_merge_bwd for the backward -- voge_amd/Sampler.py.)
+ */
+int voge_scatter_max(const float *weight, const int32_t *idx, long n, long Nv, float *out,
+                     voge_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,117 @@
+"""GPU parity tests for the "next" rows of SURVEY.md §8f: dense ray API, find_nearest_k /
+find_farest_k, Sampler (sample_features, scatter_max_weight)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import camera_np, extras_np
+from util import TOL, cuboid_scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(a, dtype=torch.float32, rg=False):
+    return torch.tensor(np.asarray(a), dtype=dtype, device=DEV, requires_grad=rg)
+
+
+def n(x):
+    return x.detach().cpu().numpy()
+
+
+def _dense_inputs(M=37, N=53, seed=0):
+    rng = np.random.default_rng(seed)
+    mus = (rng.normal(size=(M, 3)) * 0.3 + [0, 0, 3]).astype(np.float32)
+    L = np.tril(rng.uniform(0.5, 1.5, (M, 3, 3))) * 4
+    isg = (L @ L.transpose(0, 2, 1) + rng.normal(size=(M, 3, 3)) * 0.1).astype(np.float32)
+    rays = rng.normal(size=(N, 3)) * 0.1 + [0, 0, 1]
+    rays = (rays / np.linalg.norm(rays, axis=1, keepdims=True)).astype(np.float32)
+    return mus, isg, rays
+
+
+def test_dense_ray_trace_fwd_bwd(hip_lib):
+    from voge_amd.RayTracing import ray_trace_voge_ray
+    mus, isg, rays = _dense_inputs()
+    tm, tA, tr = t(mus, rg=True), t(isg, rg=True), t(rays, rg=True)
+    ln, act, dsd = ray_trace_voge_ray(tm, tA, tr)
+    rl, ra, rd = extras_np.ray_dense_fwd(mus, isg, rays)
+    for got, ref in ((ln, rl), (act, ra), (dsd, rd)):
+        assert np.abs(n(got) - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+    rng = np.random.default_rng(1)
+    gl, ga, gd = (rng.normal(size=rl.shape) for _ in range(3))
+    (ln * t(gl) + act * t(ga) + dsd * t(gd)).sum().backward()
+    g_ray, g_mu, g_A = extras_np.ray_dense_bwd(mus, isg, rays, gl, ga, gd)
+    for name, got, ref in (("ray", tr.grad, g_ray), ("mu", tm.grad, g_mu), ("A", tA.grad, g_A)):
+        assert np.abs(n(got) - ref).max() <= TOL * max(1.0, np.abs(ref).max()), name
+    # scalar / per-Gaussian sigma forms (RayTracing.py:98-101)
+    l2, a2, _ = ray_trace_voge_ray(t(mus), 7.0, t(rays))
+    l3, a3, _ = ray_trace_voge_ray(t(mus), torch.full((mus.shape[0],), 7.0, device=DEV), t(rays))
+    assert torch.equal(l2, l3) and torch.equal(a2, a3)
+
+
+@pytest.mark.parametrize("K", [1, 5, 40])
+def test_find_nearest_and_farest_k(hip_lib, K):
+    from voge_amd.RayTracing import find_farest_k, find_nearest_k, inf
+    import math
+    mus, isg, rays = _dense_inputs(M=60, N=70, seed=3)
+    ln, act, dsd = extras_np.ray_dense_fwd(mus, isg, rays)
+    act = act - act.min() + 0.1
+    thr = 0.05
+    thr_act = -math.log(thr + 1 / inf)
+    tl, ta, td = t(ln, rg=True), t(act, rg=True), t(dsd, rg=True)
+    idx, ol, oa, od = find_nearest_k(tl, ta, td, K, thr)
+    f32 = lambda a: np.asarray(a, np.float32)
+    ri, rl, ra, rd = extras_np.find_nearest_k(f32(ln), f32(act), f32(dsd), K, thr_act)
+    assert (n(idx) == ri).all()
+    for got, ref in ((ol, rl), (oa, ra), (od, rd)):
+        assert np.abs(n(got) - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+    g = np.random.default_rng(0).normal(size=(3,) + ri.shape)
+    (ol * t(g[0]) + oa * t(g[1]) + od * t(g[2])).sum().backward()
+    for got, gi in ((tl.grad, g[0]), (ta.grad, g[1]), (td.grad, g[2])):
+        ref = np.zeros_like(ln)
+        for r in range(ri.shape[0]):
+            for k in range(K):
+                if ri[r, k] >= 0:
+                    ref[r, ri[r, k]] = gi[r, k]
+        assert np.abs(n(got) - ref).max() < 1e-6
+    fi, fl, fa, fd = find_farest_k(t(ln), t(act), t(dsd), K, thr)
+    qi, ql, qa, qd = extras_np.find_nearest_k(-f32(ln), f32(act), f32(dsd), K, thr_act)
+    assert (n(fi) == qi).all() and np.abs(n(fl) + ql).max() <= 1e-6 * 1e10
+
+
+def test_sampler_matches_oracle_and_dense_formulation(hip_lib):
+    from voge_amd.Meshes import GaussianMeshesNaive
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings
+    from voge_amd.Sampler import sample_features, scatter_max_weight
+    from voge_amd.cameras import PerspectiveCameras
+    sc = cuboid_scene()
+    size = (40, 56)
+    R, T = camera_np.look_at_view_transform(sc["dist"], sc["elev"], sc["azim"])
+    cams = PerspectiveCameras(focal_length=50.0, principal_point=((28.0, 20.0),), image_size=(size,), device=DEV)
+    renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=size, max_assign=10, max_point_per_bin=-1))
+    frag = renderer(GaussianMeshesNaive(t(sc["verts"]), t(sc["sigmas"])), R=t(R), T=t(T))
+    N = sc["verts"].shape[0]
+    rng = np.random.default_rng(5)
+    for C in (3, 6):
+        image = t(rng.uniform(0, 1, (1,) + size + (C,)), rg=True)
+        w = frag.vert_weight.detach().clone().requires_grad_(True)
+        frag2 = type(frag)(vert_weight=w, vert_index=frag.vert_index, valid_num=frag.valid_num, vert_hit_length=frag.vert_hit_length)
+        feat, wsum = sample_features(frag2, image, n_vert=N)
+        rf, rw = extras_np.sample_voge(n(image), n(w), n(frag.vert_index), N)
+        assert np.abs(n(feat) - rf).max() <= TOL * max(1.0, np.abs(rf).max())
+        assert np.abs(n(wsum) - rw).max() <= TOL * max(1.0, np.abs(rw).max())
+        # the dense formulation quoted in the reference docstring (Sampler.py:7-11)
+        dense = np.zeros((size[0] * size[1], N))
+        ix, ww = n(frag.vert_index).reshape(-1, 10), n(w).reshape(-1, 10)
+        for k in range(10):
+            ok = ix[:, k] >= 0
+            dense[np.nonzero(ok)[0], ix[ok, k]] += ww[ok, k]
+        assert np.abs(dense.T @ n(image).reshape(-1, C) - rf).max() < 1e-9
+        gF, gW = rng.normal(size=rf.shape), rng.normal(size=rw.shape)
+        ((feat * t(gF)).sum() + (wsum * t(gW)).sum()).backward()
+        g_img, g_w = extras_np.sample_voge_bwd(n(image), n(w), n(frag.vert_index), gF, gW)
+        assert np.abs(n(image.grad) - g_img).max() <= TOL * max(1.0, np.abs(g_img).max())
+        assert np.abs(n(w.grad) - g_w).max() <= TOL * max(1.0, np.abs(g_w).max())
+    mx = scatter_max_weight(frag, n_vert=N)
+    assert np.abs(n(mx) - extras_np.scatter_max(n(frag.vert_weight), n(frag.vert_index), N)).max() < 1e-6

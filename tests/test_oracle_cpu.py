@@ -168,3 +168,39 @@ def test_expend_sigma_and_whole_frame():
     assert out["valid_num"].max() > 3 and (out["image"][0, 0, 0] == 1).all()  # corner is background
     valid = out["idx"] >= 0
     assert (np.diff(np.where(valid, out["len"], np.inf), axis=-1)[valid[..., 1:]] >= 0).all()
+
+
+def test_next_row_restatements_are_self_consistent():
+    """oracle/extras_np.py: dense backward vs central differences, nearest-K vs a stable sort,
+    sampler backward vs the bilinear identity <g, sample(image)> = <image, g_img>."""
+    from oracle import extras_np
+    rng = np.random.default_rng(9)
+    M, N = 5, 7
+    mus = rng.normal(size=(M, 3)) * 0.3 + [0, 0, 3]
+    L = np.tril(rng.uniform(0.5, 1.5, (M, 3, 3)))
+    A = L @ L.transpose(0, 2, 1) + rng.normal(size=(M, 3, 3)) * 0.05
+    d = rng.normal(size=(N, 3)) * 0.1 + [0, 0, 1]
+    gl, ga, gd = (rng.normal(size=(N, M)) for _ in range(3))
+    loss = lambda m, a, r: sum((x * g).sum() for x, g in zip(extras_np.ray_dense_fwd(m, a, r), (gl, ga, gd)))
+    g_ray, g_mu, g_A = extras_np.ray_dense_bwd(mus, A, d, gl, ga, gd)
+    eps = 1e-6
+    for arr, grad, pos in ((mus, g_mu, (2, 1)), (A, g_A, (3, 0, 2)), (A, g_A, (3, 2, 0)), (d, g_ray, (4, 1))):
+        hi, lo = arr.copy(), arr.copy()
+        hi[pos] += eps
+        lo[pos] -= eps
+        args = [mus, A, d]
+        i = 0 if arr is mus else (1 if arr is A else 2)
+        fd = (loss(*[hi if j == i else x for j, x in enumerate(args)]) - loss(*[lo if j == i else x for j, x in enumerate(args)])) / (2 * eps)
+        assert abs(fd - grad[pos]) <= 1e-6 * max(1.0, abs(fd))
+    ln, act, dsd = extras_np.ray_dense_fwd(mus, A, d)
+    idx, ol, oa, od = extras_np.find_nearest_k(ln, act, dsd, 3, np.median(act))
+    for r in range(N):
+        order = [m for m in np.argsort(ln[r], kind="stable") if act[r, m] < np.median(act)][:3]
+        assert idx[r, :len(order)].tolist() == order and (idx[r, len(order):] == -1).all()
+    image, w = rng.uniform(size=(1, 3, 4, 2)), rng.uniform(size=(1, 3, 4, 5))
+    ix = rng.integers(-1, 6, (1, 3, 4, 5)).astype(np.int32)
+    feat, wsum = extras_np.sample_voge(image, w, ix, 6)
+    gF, gW = rng.normal(size=feat.shape), rng.normal(size=wsum.shape)
+    g_img, g_w = extras_np.sample_voge_bwd(image, w, ix, gF, gW)
+    assert abs((feat * gF).sum() - (image * g_img).sum()) < 1e-10          # linear in image
+    assert abs((feat * gF).sum() + (wsum * gW).sum() - (w * g_w).sum()) < 1e-10  # and in w

@@ -18,7 +18,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .ops import _RayTraceVoGE
+from .ops import _FindNearestK, _RayTraceVoGE, _RayTraceVoGERay
 
 inf = 1e8
 
@@ -63,3 +63,31 @@ def ray_tracing_fine(mus, isigmas, rays, bin_points, thr, bin_size, n_assign, in
     assert mus.shape[0] == isigmas.shape[0] and mus.shape[1] == 3 and isigmas.shape[1] == 3 and isigmas.shape[2] == 3
     thr_act = -math.log(thr + 1 / inf)
     return _RayTraceVoGE.apply(mus, isigmas, rays, bin_points, thr_act, bin_size, n_assign)
+
+
+def ray_trace_voge_ray(mus, sigmas, rays):
+    """Dense (N rays x M Gaussians) trace, RayTracing.py:97-108: sigmas may be a float, (M,) or (M,3,3)."""
+    if isinstance(sigmas, (float, int)):
+        sigmas = torch.eye(3, device=mus.device)[None].expand(mus.shape[0], -1, -1) * sigmas
+    if sigmas.dim() == 1:
+        sigmas = sigmas.view(-1, 1, 1) * torch.eye(3, device=sigmas.device)[None]
+    assert mus.is_cuda and sigmas.is_cuda and rays.is_cuda
+    assert mus.dim() == 2 and mus.shape[1] == 3
+    assert rays.dim() == 2 and rays.shape[1] == 3
+    assert sigmas.dim() == 3 and sigmas.shape[1] == 3 and sigmas.shape[2] == 3
+    return _RayTraceVoGERay.apply(mus, sigmas, rays)
+
+
+def find_nearest_k(hit_len_in, hit_act_in, hit_dsd_in, K, thr):
+    """RayTracing.py:111-115 (note: this entry point uses the module-level inf = 1e8)."""
+    assert hit_len_in.is_cuda and hit_act_in.is_cuda and hit_dsd_in.is_cuda
+    thr_act = -math.log(thr + 1 / inf)
+    return _FindNearestK.apply(hit_len_in, hit_act_in, hit_dsd_in, thr_act, K)
+
+
+def find_farest_k(hit_len_in, hit_act_in, hit_dsd_in, K, thr):
+    """RayTracing.py:118-123: nearest-K on the negated lengths."""
+    assert hit_len_in.is_cuda and hit_act_in.is_cuda and hit_dsd_in.is_cuda
+    thr_act = -math.log(thr + 1 / inf)
+    point_idx, hit_len, hit_act, hit_dsd = _FindNearestK.apply(-hit_len_in, hit_act_in, hit_dsd_in, thr_act, K)
+    return point_idx, -hit_len, hit_act, hit_dsd

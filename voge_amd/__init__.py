@@ -7,7 +7,7 @@ re-exports these modules under the reference's import names.
 __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401  (ctypes binding; the .so itself is loaded on first use)
-from . import Aggregation, Meshes, RayTracing, Renderer, Utils, cameras  # noqa: F401
+from . import Aggregation, Meshes, RayTracing, Renderer, Sampler, Utils, cameras  # noqa: F401
 from . import Converter  # noqa: F401
 from .Converter import IO, Converters, Cuboid  # noqa: F401
 

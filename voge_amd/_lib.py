@@ -35,6 +35,11 @@ SIGNATURES = {
     "voge_shade_bwd": (_c_int, [_c_void_p] * 6 + [_c_float, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_long] + [_c_void_p] * 3),
     "voge_rays_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p] * 3),
     "voge_rays_bwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_void_p] * 6),
+    "voge_ray_dense_fwd": (_c_int, [_c_void_p] * 3 + [_c_int, _c_long] + [_c_void_p] * 4),
+    "voge_ray_dense_bwd": (_c_int, [_c_void_p] * 6 + [_c_int, _c_long] + [_c_void_p] * 4),
+    "voge_find_nearest_k": (_c_int, [_c_void_p] * 3 + [_c_float, _c_int, _c_int, _c_long] + [_c_void_p] * 5),
+    "voge_find_nearest_k_bwd": (_c_int, [_c_void_p] * 4 + [_c_int, _c_int, _c_long] + [_c_void_p] * 4),
+    "voge_scatter_max": (_c_int, [_c_void_p] * 2 + [_c_long, _c_long] + [_c_void_p] * 2),
     "voge_blend_bwd": (_c_int, [_c_void_p] * 3 + [_c_float, _c_void_p, _c_long, _c_int, _c_int] + [_c_void_p] * 3),
 }
 

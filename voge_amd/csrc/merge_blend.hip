@@ -226,7 +226,7 @@ shade_bwd_tile_kernel(const float *__restrict__ attr, const int32_t *__restrict_
 #pragma unroll
       for (int u = 0; u < kShadeU; ++u)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a[u][c] = (p[u] >= 0 && c < C) ? attr[(size_t)p[u] * C + c] : 0.0f;
+        for (int c = 0; c < 4; ++c) a[u][c] = (attr != nullptr && p[u] >= 0 && c < C) ? attr[(size_t)p[u] * C + c] : 0.0f;
 #pragma unroll
       for (int u = 0; u < kShadeU; ++u) {
         if (it0 + u >= nit) break;  // uniform
@@ -281,7 +281,7 @@ merge_bwd_chan_kernel(const float *__restrict__ attr, const int32_t *__restrict_
           const float w = weight[f];
           for (int c = lane; c < C; c += 64) {
             const float g = g_up[pix * C + c];
-            gw = fmaf(g, attr[(size_t)p * C + c], gw);
+            if (attr != nullptr) gw = fmaf(g, attr[(size_t)p * C + c], gw);
             if (g_attr != nullptr && w != 0.0f && g != 0.0f) unsafeAtomicAdd(g_attr + (size_t)p * C + c, w * g);
           }
           gw = wave_sum(gw);
@@ -376,7 +376,7 @@ extern "C" int voge_shade_bwd(const float *attr, const int32_t *idx, const float
     if (e != hipSuccess) return (int)e;
   }
   if (nrows * W == 0) return 0;
-  if (!idx || !weight || !valid_num || !g_up || (Nattr > 0 && !attr) || (bg && !rgb)) return VOGE_ERR_BAD_ARG;
+  if (!idx || !weight || !valid_num || !g_up || (Nattr > 0 && !attr && g_weight) || (bg && !rgb)) return VOGE_ERR_BAD_ARG;
   const long tiles = (long)((W + 7) / 8) * ((nrows + 7) / 8);
   hipLaunchKernelGGL(shade_bwd_tile_kernel, dim3((unsigned)((tiles + kShadeWaves - 1) / kShadeWaves)),
                      dim3(64 * kShadeWaves), 0, st, attr, idx, weight, valid_num, rgb, bg, thr, g_up, nrows, W, K, C,
@@ -405,7 +405,7 @@ extern "C" int voge_merge_bwd(const float *attr, const int32_t *idx, const float
   }
   const long npix = nrows * W;
   if (npix == 0) return 0;
-  if (!idx || !weight || !valid_num || !g_out || (Nattr > 0 && !attr)) return VOGE_ERR_BAD_ARG;
+  if (!idx || !weight || !valid_num || !g_out || (Nattr > 0 && !attr && g_weight)) return VOGE_ERR_BAD_ARG;
   long blocks = (npix + 3) / 4;
   if (blocks > 256L * 16) blocks = 256L * 16;
   hipLaunchKernelGGL(merge_bwd_chan_kernel, dim3((unsigned)blocks), dim3(256), 0, st, attr, idx, weight, valid_num,

@@ -375,6 +375,134 @@ class _PixelRays(torch.autograd.Function):
         return g_R, g_T, g_f, g_p, None, None, None
 
 
+class _RayTraceVoGERay(torch.autograd.Function):
+    """Dense trace, mirror of VoGE/RayTracing.py:209-220: (mus [M,3], sigmas [M,3,3], rays [N,3]) ->
+    hit_len, hit_act, hit_dsd [N,M]."""
+
+    @staticmethod
+    def forward(ctx, mus, sigmas, rays):
+        lib = _lib.load()
+        mus_c, sig_c, rays_c = _dev(mus, torch.float32, "mus"), _dev(sigmas, torch.float32, "sigmas"), _dev(rays, torch.float32, "rays")
+        M, N = mus_c.shape[0], rays_c.shape[0]
+        out = [torch.empty((N, M), dtype=torch.float32, device=rays_c.device) for _ in range(3)]
+        with torch.cuda.device(rays_c.device):
+            rc = lib.voge_ray_dense_fwd(_p(mus_c), _p(sig_c), _p(rays_c), M, N, _p(out[0]), _p(out[1]), _p(out[2]), _stream())
+        _lib.check(rc, "voge_ray_dense_fwd")
+        ctx.save_for_backward(mus_c, sig_c, rays_c)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, g_len, g_act, g_dsd):
+        lib = _lib.load()
+        mus, sig, rays = ctx.saved_tensors
+        M, N = mus.shape[0], rays.shape[0]
+        gs = [torch.zeros((N, M), dtype=torch.float32, device=rays.device) if g is None else _dev(g, torch.float32, "grad")
+              for g in (g_len, g_act, g_dsd)]
+        g_ray, g_mus, g_sig = torch.empty_like(rays), torch.empty_like(mus), torch.empty_like(sig)
+        with torch.cuda.device(rays.device):
+            rc = lib.voge_ray_dense_bwd(_p(mus), _p(sig), _p(rays), _p(gs[0]), _p(gs[1]), _p(gs[2]), M, N, _p(g_ray),
+                                        _p(g_mus), _p(g_sig), _stream())
+        _lib.check(rc, "voge_ray_dense_bwd")
+        return g_mus, g_sig, g_ray
+
+
+class _FindNearestK(torch.autograd.Function):
+    """Mirror of VoGE/RayTracing.py:223-241 with the intended gradient (zero for empty slots)."""
+
+    @staticmethod
+    def forward(ctx, hit_len_in, hit_act_in, hit_dsd_in, thr_act, K):
+        lib = _lib.load()
+        l, a, d = (_dev(t, torch.float32, "hit") for t in (hit_len_in, hit_act_in, hit_dsd_in))
+        N, M = l.shape
+        idx = torch.empty((N, K), dtype=torch.int32, device=l.device)
+        outs = [torch.empty((N, K), dtype=torch.float32, device=l.device) for _ in range(3)]
+        with torch.cuda.device(l.device):
+            rc = lib.voge_find_nearest_k(_p(l), _p(a), _p(d), float(thr_act), M, int(K), N, _p(idx), _p(outs[0]),
+                                         _p(outs[1]), _p(outs[2]), _stream())
+        _lib.check(rc, "voge_find_nearest_k")
+        ctx.save_for_backward(idx)
+        ctx.M = M
+        ctx.mark_non_differentiable(idx)
+        return idx, outs[0], outs[1], outs[2]
+
+    @staticmethod
+    def backward(ctx, _g_idx, g_len, g_act, g_dsd):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        N, K = idx.shape
+        gs = [torch.zeros((N, K), dtype=torch.float32, device=idx.device) if g is None else _dev(g, torch.float32, "grad")
+              for g in (g_len, g_act, g_dsd)]
+        gi = [torch.empty((N, ctx.M), dtype=torch.float32, device=idx.device) for _ in range(3)]
+        with torch.cuda.device(idx.device):
+            rc = lib.voge_find_nearest_k_bwd(_p(idx), _p(gs[0]), _p(gs[1]), _p(gs[2]), ctx.M, K, N, _p(gi[0]), _p(gi[1]),
+                                             _p(gi[2]), _stream())
+        _lib.check(rc, "voge_find_nearest_k_bwd")
+        return gi[0], gi[1], gi[2], None, None
+
+
+class _ScatterAttr(torch.autograd.Function):
+    """Transpose of merge_final: out[v, c] = sum over slots (pixel, k < valid) with index v of
+    weight * pix_attr[pixel, c].  This is sample_voge (VoGE/csrc/sample_voge/sample_voge.cu:35-66)
+    when pix_attr = [image | 1]; it runs on the merge-backward kernel and its own backward on the
+    merge forward/backward kernels."""
+
+    @staticmethod
+    def forward(ctx, pix_attr, weight, idx, valid_num, n_vert):
+        lib = _lib.load()
+        pa = _dev(pix_attr, torch.float32, "image")
+        w = _dev(weight, torch.float32, "weight")
+        ix = _dev(idx, torch.int32, "vert_index")
+        vn = _dev(valid_num, torch.int64, "valid_num")
+        K = ix.shape[-1]
+        C = pa.shape[-1]
+        npix = ix.numel() // max(K, 1)
+        Wd = ix.shape[-2] if ix.dim() >= 3 else npix
+        out = torch.empty((int(n_vert), C), dtype=torch.float32, device=ix.device)
+        with torch.cuda.device(ix.device):
+            rc = lib.voge_merge_bwd(None, _p(ix), _p(w), _p(vn), _p(pa), npix // max(Wd, 1), Wd, K, C, int(n_vert), _p(out),
+                                    None, _stream())
+        _lib.check(rc, "voge_merge_bwd")
+        ctx.save_for_backward(pa, w, ix, vn)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        pa, w, ix, vn = ctx.saved_tensors
+        K = ix.shape[-1]
+        C = pa.shape[-1]
+        npix = ix.numel() // max(K, 1)
+        Wd = ix.shape[-2] if ix.dim() >= 3 else npix
+        go = _dev(g_out, torch.float32, "grad_features")
+        nv = go.shape[0]
+        g_pa = torch.empty_like(pa) if ctx.needs_input_grad[0] else None
+        g_w = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(ix.device):
+            if g_pa is not None:   # g_pix_attr = merge(g_out): sum_k w * g_out[idx_k]
+                rc = lib.voge_merge_fwd(_p(go), _p(ix), _p(w), _p(vn), npix, K, C, nv, 0, _p(g_pa), _stream())
+                _lib.check(rc, "voge_merge_fwd")
+            if g_w is not None:    # g_w = <pix_attr, g_out[idx]>
+                rc = lib.voge_merge_bwd(_p(go), _p(ix), _p(w), _p(vn), _p(pa), npix // max(Wd, 1), Wd, K, C, nv, None,
+                                        _p(g_w), _stream())
+                _lib.check(rc, "voge_merge_bwd")
+        return g_pa, g_w, None, None, None
+
+
+def scatter_attr(pix_attr, weight, idx, valid_num, n_vert):
+    return _ScatterAttr.apply(pix_attr, weight, idx, valid_num, n_vert)
+
+
+def scatter_max(weight, idx, n_vert):
+    lib = _lib.load()
+    w = _dev(weight.detach(), torch.float32, "weight")
+    ix = _dev(idx, torch.int32, "vert_index")
+    out = torch.empty((int(n_vert),), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = lib.voge_scatter_max(_p(w), _p(ix), w.numel(), int(n_vert), _p(out), _stream())
+    _lib.check(rc, "voge_scatter_max")
+    return out
+
+
 def pixel_rays(R, T, focal, pp, row0, h, W):
     return _PixelRays.apply(R, T, focal, pp, row0, h, W)
 
