@@ -200,6 +200,7 @@ def main():
             g3 = [torch.empty_like(w) for _ in range(3)]
             g_ray, g_mu, g_A = torch.empty_like(rays), torch.empty_like(mus), torch.empty_like(isg)
             out3, g_attr = torch.empty_like(rgb), torch.empty_like(colors)
+            wsum = torch.empty(rgb.shape[:-1], dtype=torch.float32, device=rgb.device)
             P = lambda x: x.data_ptr()
             calls = {
                 "trace_fwd": lambda: lib.voge_trace_topk_fwd(P(mus), P(isg), P(rays), None, 1, N, H, W, K, thr_act, P(ws),
@@ -207,8 +208,8 @@ def main():
                 "composite_fwd": lambda: lib.voge_composite_fwd(P(sel[0]), P(sel[2]), P(sel[1]), P(sel[3]), 1.0, npix, K,
                                                                 P(g3[0]), P(vn), st),
                 "shade_fwd": lambda: lib.voge_shade_fwd(P(colors), P(idx), P(w), P(vn), P(bg), -1.0, npix, K, 3, N, 1, P(rgb),
-                                                        P(out3), None, st),
-                "shade_bwd": lambda: lib.voge_shade_bwd(P(colors), P(idx), P(w), P(vn), P(rgb), P(bg), -1.0, P(g_img), H, W, K,
+                                                        P(out3), None, P(wsum), st),
+                "shade_bwd": lambda: lib.voge_shade_bwd(P(colors), P(idx), P(w), P(vn), P(rgb), P(wsum), P(bg), -1.0, P(g_img), H, W, K,
                                                         3, N, P(g_attr), P(g3[0]), st),
                 "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), 1.0, npix, K, P(g3[0]),
                                                                 P(g3[1]), P(g3[2]), st),

@@ -181,22 +181,24 @@ int voge_blend_bwd(const float *rgb, const float *weight, const float *bg, float
  *   rgb = sum_{k < valid_num} attr[idx_k] w_k ;  sil = min(sum_k w_k, 1) ;
  *   img = min(rgb + (1 - (thr > 0 ? sil > thr : sil)) * bg, 1)
  * Outputs (each may be NULL): out_rgb [npix,C] (needed again by voge_shade_bwd), out_img
- * [npix,C] (requires bg [C]), out_sil [npix].  fix_negative_idx as in voge_merge_fwd.
+ * [npix,C] (requires bg [C]), out_sil [npix], out_wsum [npix] (sum_k w_k before the clamp; saves
+ * voge_shade_bwd a pass over weight).  fix_negative_idx as in voge_merge_fwd.
  */
 int voge_shade_fwd(const float *attr, int32_t *idx, const float *weight, const int64_t *valid_num,
                    const float *bg, float thr, long npix, int K, int C, long Nattr,
                    int fix_negative_idx, float *out_rgb, float *out_img, float *out_sil,
-                   voge_stream_t stream);
+                   float *out_wsum, voge_stream_t stream);
 
 /*
  * Backward of voge_shade_fwd for C <= 4.  g_up [nrows*W,C] is the gradient of img (bg != NULL;
  * rgb = the forward's out_rgb) or of rgb itself (bg == NULL, rgb ignored).  Writes g_weight
  * [nrows*W,K] (may be NULL) and g_attr [Nattr,C] (zero-filled here then accumulated; may be NULL).
+ * wsum [nrows*W] = the forward's out_wsum (unclamped sum_k w_k); NULL -> recomputed from weight.
  */
 int voge_shade_bwd(const float *attr, const int32_t *idx, const float *weight,
-                   const int64_t *valid_num, const float *rgb, const float *bg, float thr,
-                   const float *g_up, long nrows, int W, int K, int C, long Nattr, float *g_attr,
-                   float *g_weight, voge_stream_t stream);
+                   const int64_t *valid_num, const float *rgb, const float *wsum, const float *bg,
+                   float thr, const float *g_up, long nrows, int W, int K, int C, long Nattr,
+                   float *g_attr, float *g_weight, voge_stream_t stream);
 
 /*
  * Pixel-ray generation.  Replaces: the PyTorch3D call in VoGE/Renderer.py:124-130

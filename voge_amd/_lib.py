@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvoge_hip.so")
+# VOGE_HIP_LIB points at another build of the same ABI (kernel tuning variants)
+LIB_PATH = os.environ.get("VOGE_HIP_LIB") or os.path.join(_HERE, "libvoge_hip.so")
 ABI_VERSION = 1
 
 _c_void_p = ctypes.c_void_p
@@ -31,8 +32,8 @@ SIGNATURES = {
     "voge_merge_fwd": (_c_int, [_c_void_p] * 4 + [_c_long, _c_int, _c_int, _c_long, _c_int] + [_c_void_p] * 2),
     "voge_merge_bwd": (_c_int, [_c_void_p] * 5 + [_c_long, _c_int, _c_int, _c_int, _c_long] + [_c_void_p] * 3),
     "voge_blend_fwd": (_c_int, [_c_void_p] * 3 + [_c_float, _c_long, _c_int, _c_int] + [_c_void_p] * 3),
-    "voge_shade_fwd": (_c_int, [_c_void_p] * 5 + [_c_float, _c_long, _c_int, _c_int, _c_long, _c_int] + [_c_void_p] * 4),
-    "voge_shade_bwd": (_c_int, [_c_void_p] * 6 + [_c_float, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_long] + [_c_void_p] * 3),
+    "voge_shade_fwd": (_c_int, [_c_void_p] * 5 + [_c_float, _c_long, _c_int, _c_int, _c_long, _c_int] + [_c_void_p] * 5),
+    "voge_shade_bwd": (_c_int, [_c_void_p] * 7 + [_c_float, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_long] + [_c_void_p] * 3),
     "voge_rays_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p] * 3),
     "voge_rays_bwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_void_p] * 6),
     "voge_ray_dense_fwd": (_c_int, [_c_void_p] * 3 + [_c_int, _c_long] + [_c_void_p] * 4),

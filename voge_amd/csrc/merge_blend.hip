@@ -51,7 +51,7 @@ shade_fwd_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx, cons
                  const int64_t *__restrict__ valid_num, const float *__restrict__ rgb_in,
                  const float *__restrict__ bg, const float thr, const long npix, const int K, const int C,
                  const long Nattr, const int fix_idx, float *__restrict__ out_rgb, float *__restrict__ out_img,
-                 float *__restrict__ out_sil) {
+                 float *__restrict__ out_sil, float *__restrict__ out_wsum) {
   __shared__ ShadeFwdLds Ls[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   ShadeFwdLds &L = Ls[wave];
@@ -112,6 +112,7 @@ shade_fwd_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx, cons
       const int x = lane >> 2, c = lane & 3;
       const long pix = pix0 + x;
       if (c0 == 0 && c == 0 && out_sil != nullptr) out_sil[pix] = fminf(L.acc[x][4], 1.0f);
+      if (c0 == 0 && c == 0 && out_wsum != nullptr) out_wsum[pix] = L.acc[x][4];
       if (c < nc) {
         float sil = fminf(L.acc[x][4], 1.0f);
         if (thr > 0.0f) sil = sil > thr ? 1.0f : 0.0f;
@@ -133,58 +134,80 @@ shade_fwd_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx, cons
 //                            flushed with lane-coalesced atomics)
 // bg == NULL: g_up is the gradient of the merged attributes themselves (interpolate_attr).
 // ------------------------------------------------------------------------------------------
-constexpr int kShadeWaves = 4;
-constexpr int kShadeNE = 256;
+#ifndef VOGE_SHADE_WAVES
+#define VOGE_SHADE_WAVES 4
+#endif
+constexpr int kShadeWaves = VOGE_SHADE_WAVES;
+#ifndef VOGE_SHADE_TH
+#define VOGE_SHADE_TH 2
+#endif
+#ifndef VOGE_SHADE_NE
+#define VOGE_SHADE_NE 256
+#endif
+constexpr int kShadeNE = VOGE_SHADE_NE;
+constexpr int kShadeTH = VOGE_SHADE_TH;   // a wave owns an 8 x kShadeTH pixel tile
+
+#ifndef VOGE_SHADE_BU
+#define VOGE_SHADE_BU 5
+#endif
+constexpr int kShadeBU = VOGE_SHADE_BU;   // 64-slot batches whose loads are issued together (backward)
+constexpr int kShadePix = 8 * kShadeTH;
 
 struct ShadeBwdLds {
   WaveTable<kShadeNE, 1> tab;
-  float wsum[kRun];
-  float gr[kRun][4];
-  float gsw[kRun];
+  float wsum[kShadePix];
+  float gr[kShadePix][4];
+  float gsw[kShadePix];
+  int vn[kShadePix];
 };
 
 __global__ void __launch_bounds__(64 * kShadeWaves)
 shade_bwd_tile_kernel(const float *__restrict__ attr, const int32_t *__restrict__ idx,
                       const float *__restrict__ weight, const int64_t *__restrict__ valid_num,
-                      const float *__restrict__ rgb, const float *__restrict__ bg, const float thr,
-                      const float *__restrict__ g_up, const long nrows, const int W, const int K, const int C,
-                      const long Nattr, float *__restrict__ g_attr, float *__restrict__ g_weight) {
+                      const float *__restrict__ rgb, const float *__restrict__ wsum_in,
+                      const float *__restrict__ bg, const float thr, const float *__restrict__ g_up,
+                      const long nrows, const int W, const int K, const int C, const long Nattr,
+                      float *__restrict__ g_attr, float *__restrict__ g_weight) {
   __shared__ ShadeBwdLds Ls[kShadeWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   ShadeBwdLds &L = Ls[wave];
   const int tiles_x = (W + 7) / 8;
-  const long ntiles = (long)tiles_x * ((nrows + 7) / 8);
+  const long ntiles = (long)tiles_x * ((nrows + kShadeTH - 1) / kShadeTH);
   const long tile = (long)blockIdx.x * kShadeWaves + wave;
   if (tile >= ntiles) return;  // waves are independent
   const int x0 = (int)(tile % tiles_x) * 8;
-  const long y0 = (tile / tiles_x) * 8;
-  wt_clear(L.tab, lane);
+  const long y0 = (tile / tiles_x) * kShadeTH;
   const int tw = min(8, W - x0);
-  const int n_items = tw * K;
+  const int th = (int)min((long)kShadeTH, nrows - y0);
+  const int n_items = tw * K;              // slots of one 8-pixel row: one contiguous run
   const int nit = (n_items + 63) >> 6;
-  for (int r = 0; r < 8; ++r) {
-    const long py = y0 + r;
-    if (py >= nrows) break;
-    const long pix0 = py * W + x0;
-    const long base = pix0 * K;
-    // ---- per-pixel upstream gradient (and, for the blend, the silhouette) -> LDS ----
-    if (bg != nullptr) {
-      if (lane < kRun) L.wsum[lane] = 0.0f;
-      for (int it = 0; it < nit; ++it) {
-        const int j = it * 64 + lane;
-        const bool ok = j < n_items;
-        const int lx = ok ? j / K : 64 + lane;
-        const float v = seg_sum_key(ok ? weight[base + j] : 0.0f, lx, lane);
-        const int prev = __shfl_up(lx, 1, 64);
-        if ((lane == 0 || prev != lx) && lx < kRun) L.wsum[lx] += v;
-      }
+  const int nb = th * nit;                 // 64-slot batches of the tile
+  const float invK = 1.0f / (float)K;
+  wt_clear(L.tab, lane);
+  // ---- per-pixel silhouette sum (only when the caller did not keep the forward's) ----
+  if (bg != nullptr && wsum_in == nullptr) {
+    for (int i = lane; i < kShadePix; i += 64) L.wsum[i] = 0.0f;
+    for (int bb = 0; bb < nb; ++bb) {
+      const int r = bb / nit, it = bb - r * nit;
+      const int j = it * 64 + lane;
+      const bool ok = j < n_items;
+      const int pl = ok ? r * 8 + __float2int_rz(((float)j + 0.5f) * invK) : 64 + lane;
+      const float v = seg_sum_key(ok ? weight[((y0 + r) * W + x0) * (long)K + j] : 0.0f, pl, lane);
+      const int prev = __shfl_up(pl, 1, 64);
+      if ((lane == 0 || prev != pl) && pl < kShadePix) L.wsum[pl] += v;
     }
-    if (lane < tw) {
-      const long pix = pix0 + lane;
-      float g_sum_w = 0.0f;
-      float g[4] = {0.f, 0.f, 0.f, 0.f};
+  }
+  // ---- per-pixel upstream gradient -> LDS ----
+  for (int i = lane; i < kShadePix; i += 64) {
+    const int lx = i & 7, r = i >> 3;
+    float g_sum_w = 0.0f;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    int vn = 0;
+    if (lx < tw && r < th) {
+      const long pix = (y0 + r) * W + x0 + lx;
+      vn = (int)min((int64_t)K, valid_num[pix]);
       if (bg != nullptr) {
-        const float ws = L.wsum[lane];
+        const float ws = (wsum_in != nullptr) ? wsum_in[pix] : L.wsum[i];
         float sil = fminf(ws, 1.0f);
         const float pass_s = (thr > 0.0f) ? 0.0f : clamp1_pass(ws);
         if (thr > 0.0f) sil = sil > thr ? 1.0f : 0.0f;
@@ -198,52 +221,54 @@ shade_bwd_tile_kernel(const float *__restrict__ attr, const int32_t *__restrict_
       } else {
         for (int c = 0; c < C; ++c) g[c] = g_up[pix * C + c];
       }
-      for (int c = 0; c < 4; ++c) L.gr[lane][c] = g[c];
-      L.gsw[lane] = g_sum_w;
     }
-    // ---- slots of the row: g_weight and the attribute-gradient table ----
-    for (int it0 = 0; it0 < nit; it0 += kShadeU) {
-      float w[kShadeU];
-      int p[kShadeU], lx[kShadeU];
-      bool ok[kShadeU];
+    for (int c = 0; c < 4; ++c) L.gr[i][c] = g[c];
+    L.gsw[i] = g_sum_w;
+    L.vn[i] = vn;
+  }
+  // ---- slots of the tile: g_weight and the attribute-gradient table ----
+  for (int g0 = 0; g0 < nb; g0 += kShadeBU) {
+    float w[kShadeBU];
+    int p[kShadeBU], pl[kShadeBU];
+    long flat[kShadeBU];
+    bool ok[kShadeBU];
 #pragma unroll
-      for (int u = 0; u < kShadeU; ++u) {
-        const int j = (it0 + u) * 64 + lane;
-        ok[u] = (it0 + u < nit) && (j < n_items);
-        lx[u] = ok[u] ? j / K : 0;
-        w[u] = 0.0f;
-        p[u] = -1;
-        if (ok[u]) {
-          const int k = j - lx[u] * K;
-          if (k < valid_num[pix0 + lx[u]]) {
-            const int raw = idx[base + j];
-            const int q = raw + (raw < 0);
-            if (q >= 0 && q < Nattr) { p[u] = q; w[u] = weight[base + j]; }
-          }
-        }
+    for (int u = 0; u < kShadeBU; ++u) {
+      const int bb = g0 + u;
+      const int r = bb / nit, it = bb - r * nit;
+      const int j = it * 64 + lane;
+      ok[u] = (bb < nb) && (j < n_items);
+      const int lx = __float2int_rz(((float)j + 0.5f) * invK);
+      pl[u] = ok[u] ? r * 8 + lx : 0;
+      flat[u] = ((y0 + r) * W + x0) * (long)K + j;
+      w[u] = 0.0f;
+      p[u] = -1;
+      if (ok[u] && (j - lx * K) < L.vn[pl[u]]) {
+        const int raw = idx[flat[u]];
+        const int q = raw + (raw < 0);
+        if (q >= 0 && q < Nattr) { p[u] = q; w[u] = weight[flat[u]]; }
       }
-      float a[kShadeU][4];
+    }
+    float a[kShadeBU][4];
 #pragma unroll
-      for (int u = 0; u < kShadeU; ++u)
+    for (int u = 0; u < kShadeBU; ++u)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a[u][c] = (attr != nullptr && p[u] >= 0 && c < C) ? attr[(size_t)p[u] * C + c] : 0.0f;
+      for (int c = 0; c < 4; ++c) a[u][c] = (attr != nullptr && p[u] >= 0 && c < C) ? attr[(size_t)p[u] * C + c] : 0.0f;
 #pragma unroll
-      for (int u = 0; u < kShadeU; ++u) {
-        if (it0 + u >= nit) break;  // uniform
-        const float g0 = L.gr[lx[u]][0], g1 = L.gr[lx[u]][1], g2 = L.gr[lx[u]][2], g3 = L.gr[lx[u]][3];
-        if (ok[u] && g_weight != nullptr) {
-          const float gw = fmaf(g3, a[u][3], fmaf(g2, a[u][2], fmaf(g1, a[u][1], fmaf(g0, a[u][0], L.gsw[lx[u]]))));
-          g_weight[base + (it0 + u) * 64 + lane] = gw;
-        }
-        if (g_attr != nullptr) {
-          const float4 v[1] = {make_float4(w[u] * g0, w[u] * g1, w[u] * g2, w[u] * g3)};
-          const bool live = (p[u] >= 0) && (v[0].x != 0.0f || v[0].y != 0.0f || v[0].z != 0.0f || v[0].w != 0.0f);
-          const int slot = wt_find(L.tab, p[u], live);
-          wt_add(L.tab, slot, v, live && slot >= 0, lane);
-          if (live && slot < 0) {
-            const float o[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
-            for (int c = 0; c < C; ++c) unsafeAtomicAdd(g_attr + (size_t)p[u] * C + c, o[c]);
-          }
+    for (int u = 0; u < kShadeBU; ++u) {
+      if (g0 + u >= nb) break;  // uniform
+      const float g0c = L.gr[pl[u]][0], g1 = L.gr[pl[u]][1], g2 = L.gr[pl[u]][2], g3 = L.gr[pl[u]][3];
+      if (ok[u] && g_weight != nullptr)
+        g_weight[flat[u]] = fmaf(g3, a[u][3], fmaf(g2, a[u][2], fmaf(g1, a[u][1], fmaf(g0c, a[u][0], L.gsw[pl[u]]))));
+      if (g_attr != nullptr) {
+        const float4 v[1] = {make_float4(w[u] * g0c, w[u] * g1, w[u] * g2, w[u] * g3)};
+        const bool live = (p[u] >= 0) && (v[0].x != 0.0f || v[0].y != 0.0f || v[0].z != 0.0f || v[0].w != 0.0f);
+        if (!__any(live)) continue;  // uniform
+        const int slot = wt_find(L.tab, p[u], live);
+        wt_add(L.tab, slot, v, live && slot >= 0, lane);
+        if (live && slot < 0) {
+          const float o[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
+          for (int c = 0; c < C; ++c) unsafeAtomicAdd(g_attr + (size_t)p[u] * C + c, o[c]);
         }
       }
     }
@@ -252,9 +277,12 @@ shade_bwd_tile_kernel(const float *__restrict__ attr, const int32_t *__restrict_
     // 4 adjacent lanes per table entry -> adjacent floats of g_attr[p]: lane-coalesced atomics
     const int c = lane & 3;
     const float *vals = reinterpret_cast<const float *>(L.tab.vals);
-    for (int s = lane >> 2; s < kShadeNE; s += 16) {
+    const int n = wt_compact(L.tab, lane);
+    const volatile int *list = L.tab.owner;
+    for (int i = lane >> 2; i < n; i += 16) {
+      const int s = list[i];
       const int p = L.tab.keys[s];
-      if (p >= 0 && c < C) unsafeAtomicAdd(g_attr + (size_t)p * C + c, vals[s * 4 + c]);
+      if (c < C) unsafeAtomicAdd(g_attr + (size_t)p * C + c, vals[s * 4 + c]);
     }
   }
 }
@@ -354,21 +382,21 @@ using namespace voge;
 extern "C" int voge_shade_fwd(const float *attr, int32_t *idx, const float *weight, const int64_t *valid_num,
                               const float *bg, float thr, long npix, int K, int C, long Nattr,
                               int fix_negative_idx, float *out_rgb, float *out_img, float *out_sil,
-                              voge_stream_t stream) {
+                              float *out_wsum, voge_stream_t stream) {
   if (npix < 0 || K <= 0 || C < 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
   if (npix == 0) return 0;
   if (!weight) return VOGE_ERR_BAD_ARG;
   if (C > 0 && (!attr || !idx || !valid_num)) return VOGE_ERR_BAD_ARG;
   if (out_img && !bg) return VOGE_ERR_BAD_ARG;
   hipLaunchKernelGGL(shade_fwd_kernel, dim3(run_grid(npix)), dim3(256), 0, (hipStream_t)stream, attr, idx, weight,
-                     valid_num, nullptr, bg, thr, npix, K, C, Nattr, fix_negative_idx, out_rgb, out_img, out_sil);
+                     valid_num, nullptr, bg, thr, npix, K, C, Nattr, fix_negative_idx, out_rgb, out_img, out_sil, out_wsum);
   return launch_status();
 }
 
 extern "C" int voge_shade_bwd(const float *attr, const int32_t *idx, const float *weight,
-                              const int64_t *valid_num, const float *rgb, const float *bg, float thr,
-                              const float *g_up, long nrows, int W, int K, int C, long Nattr, float *g_attr,
-                              float *g_weight, voge_stream_t stream) {
+                              const int64_t *valid_num, const float *rgb, const float *wsum, const float *bg,
+                              float thr, const float *g_up, long nrows, int W, int K, int C, long Nattr,
+                              float *g_attr, float *g_weight, voge_stream_t stream) {
   if (nrows < 0 || W < 0 || K <= 0 || C <= 0 || C > 4 || Nattr < 0) return VOGE_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (g_attr != nullptr && Nattr > 0) {
@@ -377,9 +405,9 @@ extern "C" int voge_shade_bwd(const float *attr, const int32_t *idx, const float
   }
   if (nrows * W == 0) return 0;
   if (!idx || !weight || !valid_num || !g_up || (Nattr > 0 && !attr && g_weight) || (bg && !rgb)) return VOGE_ERR_BAD_ARG;
-  const long tiles = (long)((W + 7) / 8) * ((nrows + 7) / 8);
+  const long tiles = (long)((W + 7) / 8) * ((nrows + kShadeTH - 1) / kShadeTH);
   hipLaunchKernelGGL(shade_bwd_tile_kernel, dim3((unsigned)((tiles + kShadeWaves - 1) / kShadeWaves)),
-                     dim3(64 * kShadeWaves), 0, st, attr, idx, weight, valid_num, rgb, bg, thr, g_up, nrows, W, K, C,
+                     dim3(64 * kShadeWaves), 0, st, attr, idx, weight, valid_num, rgb, wsum, bg, thr, g_up, nrows, W, K, C,
                      Nattr, g_attr, g_weight);
   return launch_status();
 }
@@ -389,14 +417,14 @@ extern "C" int voge_merge_fwd(const float *attr, int32_t *idx, const float *weig
                               int fix_negative_idx, float *out, voge_stream_t stream) {
   if (C <= 0 || !out) return VOGE_ERR_BAD_ARG;
   return voge_shade_fwd(attr, idx, weight, valid_num, nullptr, -1.0f, npix, K, C, Nattr, fix_negative_idx, out, nullptr,
-                        nullptr, stream);
+                        nullptr, nullptr, stream);
 }
 
 extern "C" int voge_merge_bwd(const float *attr, const int32_t *idx, const float *weight,
                               const int64_t *valid_num, const float *g_out, long nrows, int W, int K,
                               int C, long Nattr, float *g_attr, float *g_weight, voge_stream_t stream) {
   if (nrows < 0 || W < 0 || K <= 0 || C <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
-  if (C <= 4) return voge_shade_bwd(attr, idx, weight, valid_num, nullptr, nullptr, -1.0f, g_out, nrows, W, K, C, Nattr,
+  if (C <= 4) return voge_shade_bwd(attr, idx, weight, valid_num, nullptr, nullptr, nullptr, -1.0f, g_out, nrows, W, K, C, Nattr,
                                     g_attr, g_weight, stream);
   hipStream_t st = (hipStream_t)stream;
   if (g_attr != nullptr && Nattr > 0) {
@@ -420,7 +448,7 @@ extern "C" int voge_blend_fwd(const float *rgb, const float *weight, const float
   if (npix == 0) return 0;
   if (!weight || (C > 0 && (!rgb || !bg || !out))) return VOGE_ERR_BAD_ARG;
   hipLaunchKernelGGL(shade_fwd_kernel, dim3(run_grid(npix)), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr,
-                     weight, nullptr, rgb, bg, thr, npix, K, C, 0L, 0, nullptr, out, sil_out);
+                     weight, nullptr, rgb, bg, thr, npix, K, C, 0L, 0, nullptr, out, sil_out, nullptr);
   return launch_status();
 }
 

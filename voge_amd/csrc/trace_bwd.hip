@@ -23,13 +23,23 @@
 
 namespace voge {
 
-constexpr int kBwdWaves = 2;    // waves per workgroup (each wave is independent)
-constexpr int kBwdNE = 256;     // table entries per wave (an 8x8 tile touches ~100-200 Gaussians)
+#ifndef VOGE_BWD_WAVES
+#define VOGE_BWD_WAVES 1
+#endif
+constexpr int kBwdWaves = VOGE_BWD_WAVES;    // waves per workgroup (each wave is independent)
+#ifndef VOGE_BWD_TH
+#define VOGE_BWD_TH 2
+#endif
+#ifndef VOGE_BWD_NE
+#define VOGE_BWD_NE 128
+#endif
+constexpr int kBwdTH = VOGE_BWD_TH;       // tile height: a wave owns an 8 x kBwdTH pixel tile
+constexpr int kBwdNE = VOGE_BWD_NE;     // table entries per wave (an 8x4 tile touches ~50-100 Gaussians)
 constexpr int kBwdU = 4;        // 64-slot batches whose loads are issued together
 
 struct BwdWaveLds {
   WaveTable<kBwdNE, 3> tab;     // key = Gaussian index, values = g_mu (3) + g_A (9)
-  float ray[64 * 3];            // g_ray of the tile's pixels
+  float ray[8 * kBwdTH * 3];    // g_ray of the tile's pixels
   int cntv[64];                 // number of leading valid slots per pixel
 };
 
@@ -58,13 +68,13 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   BwdWaveLds &L = Ls[wave];
   const int tiles_x = (W + 7) / 8;
-  const long ntiles = (long)tiles_x * ((nrows + 7) / 8);
+  const long ntiles = (long)tiles_x * ((nrows + kBwdTH - 1) / kBwdTH);
   const long tile = (long)blockIdx.x * kBwdWaves + wave;
   if (tile >= ntiles) return;  // waves never synchronise with each other
   const int x0 = (int)(tile % tiles_x) * 8;
-  const long y0 = (tile / tiles_x) * 8;
+  const long y0 = (tile / tiles_x) * kBwdTH;
   const int tw = min(8, W - x0);
-  const int th = (int)min(8L, nrows - y0);
+  const int th = (int)min((long)kBwdTH, nrows - y0);
   {   // per-pixel slot counts (all K when the caller has none)
     const int lx = lane & 7, ly = lane >> 3;
     int c = 0;
@@ -79,7 +89,7 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
     }
   }
   wt_clear(L.tab, lane);
-  for (int i = lane; i < 64 * 3; i += 64) L.ray[i] = 0.0f;
+  for (int i = lane; i < 8 * kBwdTH * 3; i += 64) L.ray[i] = 0.0f;
   const int n_items = tw * K;              // slots of one 8-pixel row: one contiguous run
   const int nit = (n_items + 63) >> 6;
   const int nb = th * nit;                 // batches of the tile
@@ -176,7 +186,7 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
         ryv = seg_sum_key(ryv, a.pl[u], lane);
         rz = seg_sum_key(rz, a.pl[u], lane);
         const int prev = __shfl_up(a.pl[u], 1, 64);
-        if ((lane == 0 || prev != a.pl[u]) && a.pl[u] < 64) {
+        if ((lane == 0 || prev != a.pl[u]) && a.pl[u] < 8 * kBwdTH) {
           L.ray[a.pl[u] * 3 + 0] += rx;
           L.ray[a.pl[u] * 3 + 1] += ryv;
           L.ray[a.pl[u] * 3 + 2] += rz;
@@ -197,7 +207,7 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
   }
 
   if (g_ray != nullptr) {
-    for (int j = lane; j < 64 * 3; j += 64) {
+    for (int j = lane; j < 8 * kBwdTH * 3; j += 64) {
       const int i = j / 3, c = j - i * 3;
       const int px = i & 7, py = i >> 3;
       if (px < tw && py < th) g_ray[((y0 + py) * W + x0 + px) * 3 + c] = L.ray[j];
@@ -209,9 +219,12 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
   {
     const int c = lane & 15;
     const float *vals = reinterpret_cast<const float *>(L.tab.vals);
-    for (int s = lane >> 4; s < kBwdNE; s += 4) {
+    const int n = wt_compact(L.tab, lane);
+    const volatile int *list = L.tab.owner;
+    for (int i = lane >> 4; i < n; i += 4) {
+      const int s = list[i];
       const int p = L.tab.keys[s];
-      if (p >= 0 && c < 12) unsafeAtomicAdd(acc + 16 * (size_t)p + c, vals[s * 12 + c]);
+      if (c < 12) unsafeAtomicAdd(acc + 16 * (size_t)p + c, vals[s * 12 + c]);
     }
   }
 }
@@ -266,7 +279,7 @@ extern "C" int voge_trace_bwd(const float *mus, const float *isigmas, const floa
   if (nrows * W > 0) {
     if (!rays || !idx || !g_len || !g_act || !g_dsd) return VOGE_ERR_BAD_ARG;
     hipLaunchKernelGGL(bwd_pack_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, P, rec);
-    const long tiles = (long)((W + 7) / 8) * ((nrows + 7) / 8);
+    const long tiles = (long)((W + 7) / 8) * ((nrows + kBwdTH - 1) / kBwdTH);
     hipLaunchKernelGGL(trace_bwd_kernel, dim3((unsigned)((tiles + kBwdWaves - 1) / kBwdWaves)), dim3(64 * kBwdWaves),
                        0, st, rec, rays, idx, cnt, g_len, g_act, g_dsd, P, nrows, W, K, g_ray, acc);
   }

@@ -337,6 +337,23 @@ __device__ __forceinline__ void wt_add(WaveTable<NE, NV4> &t, const int slot, co
   }
 }
 
+// Compact the occupied slots into t.owner[0..n) (the election array is free once accumulation
+// is over) and return n, so the flush issues full-width atomics instead of walking empty slots.
+// Must be called by the whole wave.
+template <int NE, int NV4>
+__device__ __forceinline__ int wt_compact(WaveTable<NE, NV4> &t, const int lane) {
+  volatile int *list = t.owner;
+  int n = 0;
+#pragma unroll
+  for (int base = 0; base < NE; base += VOGE_WAVE) {
+    const bool occ = (base + lane < NE) && (t.keys[base + lane] >= 0);
+    const unsigned long long m = __ballot(occ);
+    if (occ) list[n + __popcll(m & ((1ull << lane) - 1ull))] = base + lane;
+    n += __popcll(m);
+  }
+  return n;
+}
+
 // Segmented sum over runs of `seg` consecutive lanes (seg <= 64, any value); the total of each
 // run lands in its first lane.
 __device__ __forceinline__ float seg_sum(float x, const int lane, const int seg) {

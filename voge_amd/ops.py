@@ -270,11 +270,12 @@ class _Shade(torch.autograd.Function):
         assert C <= 4 and bg_c.numel() == C
         rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
         img = torch.empty_like(rgb)
+        wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
         with torch.cuda.device(idx.device):
             rc = lib.voge_shade_fwd(_p(attr_c), _p(idx), _p(w), _p(vn), _p(bg_c), float(thr), npix, K, C, Nattr, 1,
-                                    _p(rgb), _p(img), None, _stream())
+                                    _p(rgb), _p(img), None, _p(wsum), _stream())
         _lib.check(rc, "voge_shade_fwd")
-        ctx.save_for_backward(attr_c, w, vn, rgb, bg_c)
+        ctx.save_for_backward(attr_c, w, vn, rgb, bg_c, wsum)
         ctx.idx = idx      # see _Merge: kept outside the version counter on purpose
         ctx.thr = float(thr)
         return img
@@ -282,7 +283,7 @@ class _Shade(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_img):
         lib = _lib.load()
-        attr, w, vn, rgb, bg = ctx.saved_tensors
+        attr, w, vn, rgb, bg, wsum = ctx.saved_tensors
         idx = ctx.idx
         K = idx.shape[-1]
         npix = idx.numel() // max(K, 1)
@@ -292,7 +293,7 @@ class _Shade(torch.autograd.Function):
         g_w = torch.empty_like(w) if ctx.needs_input_grad[1] else None
         Wd = idx.shape[-2] if idx.dim() >= 3 else npix
         with torch.cuda.device(idx.device):
-            rc = lib.voge_shade_bwd(_p(attr), _p(idx), _p(w), _p(vn), _p(rgb), _p(bg), ctx.thr, _p(go),
+            rc = lib.voge_shade_bwd(_p(attr), _p(idx), _p(w), _p(vn), _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go),
                                     npix // max(Wd, 1), Wd, K, C, Nattr, _p(g_attr), _p(g_w), _stream())
         _lib.check(rc, "voge_shade_bwd")
         return g_attr, g_w, None, None, None, None
