@@ -1,0 +1,64 @@
+"""Counters of the forward sweep (debug build: tools/tune_variants.sh stats:"-DVOGE_SWEEP_STATS").
+usage on the GPU box: VOGE_HIP_LIB=build/variants/stats.so python tools/sweep_stats.py [config]"""
+import ctypes
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from voge_amd import _lib, scenes  # noqa: E402
+from voge_amd.cameras import PerspectiveCameras, look_at_view_transform  # noqa: E402
+from voge_amd.Renderer import GaussianRenderSettings, GaussianRenderer  # noqa: E402
+from voge_amd.Meshes import GaussianMeshes  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_50k_512"
+N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[name]
+verts, sig, colors = scenes.random_gaussians(N, seed=0)
+dev = torch.device("cuda", 0)
+gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
+R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
+cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), device=dev)
+settings = GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1,
+                                  max_point_per_bin=-1)
+renderer = GaussianRenderer(cams, settings).to(dev)
+lib = _lib.load()
+out = (ctypes.c_ulonglong * 16)()
+ctypes.CDLL(_lib.LIB_PATH).voge_debug_sweep_stats(out)
+with torch.no_grad():
+    for _ in range(3):
+        frag = renderer(gm, R=R, T=T)
+    torch.cuda.synchronize()
+    ctypes.CDLL(_lib.LIB_PATH).voge_debug_sweep_stats(out)
+    frag = renderer(gm, R=R, T=T)
+torch.cuda.synchronize()
+ctypes.CDLL(_lib.LIB_PATH).voge_debug_sweep_stats(out)
+names = ["waves", "staged(per WG)", "evaluated(per wave sum)", "trips", "slow_entries", "slow_shift_steps(wave max sum)",
+         "hits(lane sum)", "list_len(per WG sum)", "list_consumed", "batches"]
+v = list(out)
+for n, x in zip(names, v):
+    print(f"{n:36s} {x:14d}   per wave {x / max(v[0], 1):10.1f}")
+print("rays", H * W, "hits per ray", v[6] / (H * W), "evals per ray (wave evals)", v[2] * 64 / (H * W))
+
+import numpy as np
+nwg = ((W + 15) // 16) * ((H + 7) // 8)
+nwg = min(nwg, 8192)
+buf = (ctypes.c_ulonglong * (8 * nwg))()
+ctypes.CDLL(_lib.LIB_PATH).voge_debug_sweep_times(buf, nwg)
+t = np.array(list(buf), dtype=np.float64).reshape(nwg, 8)
+t0 = t[:, 0].min()
+tick = 0.01  # us per tick (100 MHz)
+start, cones, fill, cons, loop_end, end, ev = [(t[:, i]) for i in range(7)]
+print("kernel span us", (end.max() - t0) * tick)
+act = ev > 0
+for nm, sel in (("active", act), ("empty", ~act)):
+    if sel.sum() == 0:
+        continue
+    print(f"{nm}: n={sel.sum()} start(mean/max)={(start[sel]-t0).mean()*tick:.1f}/{(start[sel]-t0).max()*tick:.1f} "
+          f"prologue={(cones-start)[sel].mean()*tick:.1f} fill={fill[sel].mean()*tick:.1f} consume={cons[sel].mean()*tick:.1f} "
+          f"loop={(loop_end-cones)[sel].mean()*tick:.1f} epilogue={(end-loop_end)[sel].mean()*tick:.1f} "
+          f"total={(end-start)[sel].mean()*tick:.1f} max_total={(end-start)[sel].max()*tick:.1f} evals={ev[sel].mean():.0f}")
+# histogram of start times: dispatch rounds
+h, edges = np.histogram((start - t0) * tick, bins=12)
+print("start-time histogram (us):", list(zip(np.round(edges[:-1], 1), h)))
+h, edges = np.histogram((end - t0) * tick, bins=12)
+print("end-time histogram (us):", list(zip(np.round(edges[:-1], 1), h)))

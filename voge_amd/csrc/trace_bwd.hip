@@ -35,7 +35,10 @@ constexpr int kBwdWaves = VOGE_BWD_WAVES;    // waves per workgroup (each wave i
 #endif
 constexpr int kBwdTH = VOGE_BWD_TH;       // tile height: a wave owns an 8 x kBwdTH pixel tile
 constexpr int kBwdNE = VOGE_BWD_NE;     // table entries per wave (an 8x4 tile touches ~50-100 Gaussians)
-constexpr int kBwdU = 4;        // 64-slot batches whose loads are issued together
+#ifndef VOGE_BWD_U
+#define VOGE_BWD_U 1
+#endif
+constexpr int kBwdU = VOGE_BWD_U;        // 64-slot batches whose loads are issued together
 
 struct BwdWaveLds {
   WaveTable<kBwdNE, 3> tab;     // key = Gaussian index, values = g_mu (3) + g_A (9)

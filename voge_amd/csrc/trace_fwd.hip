@@ -33,7 +33,7 @@ __device__ inline double lambda_min_sym3(double a00, double a11, double a22, dou
 __global__ void __launch_bounds__(256)
 prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg,
             const float *__restrict__ cam_fwd, const int N, const int P, const float thr_act,
-            float4 *__restrict__ cull, float4 *__restrict__ evr) {
+            float4 *__restrict__ cull, float4 *__restrict__ evr, float4 *__restrict__ ms) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= P) return;
   const float mx = mus[3 * g + 0], my = mus[3 * g + 1], mz = mus[3 * g + 2];
@@ -66,6 +66,9 @@ prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg,
   evr[3 * (size_t)g + 0] = make_float4(e.s00, e.s11, e.s22, e.s01);
   evr[3 * (size_t)g + 1] = make_float4(e.s02, e.s12, e.bx, e.by);
   evr[3 * (size_t)g + 2] = make_float4(e.bz, e.kx, e.ky, e.kz);
+  // epilogue record: everything an isotropic Gaussian needs in one 16-byte gather; w = NaN sends
+  // the reader to the full records
+  ms[g] = make_float4(mx, my, mz, is_iso(e) ? e.s00 : __uint_as_float(0x7fc00000u));
 }
 
 __device__ __forceinline__ EvalRec unpack_eval(const float4 a, const float4 b, const float4 c) {
@@ -420,6 +423,15 @@ bin2_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, con
 // The epilogue re-maps lanes to (pixel, slot) so that all four outputs are written as
 // contiguous runs of TW*K floats.
 // ------------------------------------------------------------------------------------------
+#ifdef VOGE_SWEEP_STATS
+__device__ unsigned long long g_sweep_stats[16];
+__device__ unsigned long long g_sweep_times[8192 * 8];   // per WG: start, after cones, fill sum, consume sum, loop end, end, evals, smid
+#endif
+#ifndef VOGE_TRIP
+#define VOGE_TRIP 4
+#endif
+constexpr int kTrip = VOGE_TRIP;   // candidates evaluated per trip of the sweep's inner loop
+
 template <int T>
 struct TraceLds {
   // layout inside dynamic LDS, after the [K][T+1] key array
@@ -436,7 +448,7 @@ struct TraceLds {
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
 trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr,
-                 const float *__restrict__ rays, const int *__restrict__ bin_count,
+                 const float4 *__restrict__ ms, const float *__restrict__ rays, const int *__restrict__ bin_count,
                  const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb,
                  const int *__restrict__ tl_count, const int32_t *__restrict__ tl_id,
                  const float *__restrict__ tl_lb, const int nstx, const int nst, const int N, const int H,
@@ -452,6 +464,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   uint64_t *keys = reinterpret_cast<uint64_t *>(smem_raw);
   TraceLds<T> &L = *reinterpret_cast<TraceLds<T> *>(smem_raw + ((sizeof(uint64_t) * (size_t)(K + 1) * TP + 15) & ~(size_t)15));
 
+#ifdef VOGE_SWEEP_STATS
+  const unsigned long long ts0 = wall_clock64();
+  unsigned long long ts_fill = 0, ts_cons = 0;
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (W + TW - 1) / TW;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
@@ -502,6 +518,9 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     __syncthreads();
   }
 
+#ifdef VOGE_SWEEP_STATS
+  const unsigned long long ts1 = wall_clock64();
+#endif
   // ---- candidate stream of this tile -----------------------------------------------------
   // tile list (bin2) -> super-tile list (bin) -> every Gaussian of the batch element
   const int tile = b * gridDim.x + blockIdx.x;
@@ -523,6 +542,9 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   int cnt = 0;
   uint64_t worst = ~0ull, tail = 0ull;
   bool wdone = false, reported = false;
+#ifdef VOGE_SWEEP_STATS
+  unsigned st_staged = 0, st_eval = 0, st_trips = 0, st_slow = 0, st_shift = 0, st_hits = 0, st_batches = 0;
+#endif
 
   int base = 0, par = 0;
   // two-deep software pipeline: ids two chunks ahead, cull records one chunk ahead
@@ -533,6 +555,9 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   float lb1 = load_lb(T + tid);
   while (base < src_n) {
     int nbuf = 0;
+#ifdef VOGE_SWEEP_STATS
+    const unsigned long long tsa = wall_clock64();
+#endif
     while (base < src_n && nbuf + T <= kCap) {
       const int id = id0;
       const float lbv = lb0;
@@ -565,8 +590,18 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       base += T;
       par ^= 1;
     }
+#ifdef VOGE_SWEEP_STATS
+    st_staged += nbuf;
+#endif
     __syncthreads();
+#ifdef VOGE_SWEEP_STATS
+    const unsigned long long tsb = wall_clock64();
+    ts_fill += tsb - tsa;
+#endif
     // consume
+#ifdef VOGE_ABL_CONSUME
+    wdone = true;
+#endif
     if (!wdone) {
       for (int c0 = 0; c0 < nbuf && !wdone; c0 += 64) {
         const int i = c0 + lane;
@@ -588,24 +623,43 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
         auto commit = [&](const PairOut &o, const int s, const bool on) {
           const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)(L.id[s] + b * N);
           const bool take = on && valid && (o.act < thr_act) && (o.len < VOGE_SENT_LEN) && (key < worst);
+#ifdef VOGE_SWEEP_STATS
+          {
+            const bool app = take && (cnt < K) && (key >= tail);
+            const bool slow = take && !app;
+            st_hits += __popcll(__ballot(take));
+            if (__any(slow)) {
+              ++st_slow;
+              int steps = 0;
+              if (slow) { int pos = min(cnt, K - 1); while (pos > 0 && mykeys[(pos - 1) * TP] > key) { --pos; ++steps; } }
+              st_shift += (unsigned)wave_max((float)steps);
+            }
+          }
+#endif
           topk_commit(mykeys, TP, K, cnt, worst, tail, key, take);
         };
+#ifdef VOGE_SWEEP_STATS
+        st_eval += __popcll(m); ++st_batches;
+#endif
         while (m) {
+#ifdef VOGE_SWEEP_STATS
+          ++st_trips;
+#endif
           // four candidates per trip: their evaluations are independent instruction streams
-          int sq[4];
+          int sq[kTrip];
           int nt = 0;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < kTrip; ++q) {
             sq[q] = c0 + (m ? __builtin_ctzll(m) : 0);
             if (m) { ++nt; m &= m - 1ull; }
           }
           // The four evaluations form ONE straight-line block (the isotropic / general choice is
           // made per batch, on scalar registers), so the scheduler interleaves their chains.
-          PairOut o[4];
-          float4 cc[4], e0[4];
+          PairOut o[kTrip];
+          float4 cc[kTrip], e0[kTrip];
           bool iso = true, any_iso = false;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < kTrip; ++q) {
             cc[q] = L.cull[sq[q]];
             e0[q] = L.ev[sq[q] * 3];
             const bool f = __builtin_amdgcn_readfirstlane(__float_as_uint(e0[q].w)) == kIsoFlag;
@@ -614,30 +668,33 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
           }
           if (iso) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < kTrip; ++q)
               o[q] = pair_eval_iso(cc[q].x, cc[q].y, cc[q].z, e0[q].x, dx, dy, dz, qxx, qyy, qzz);
           } else {
-            float4 e1[4], e2[4];
+            float4 e1[kTrip], e2[kTrip];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { e1[q] = L.ev[sq[q] * 3 + 1]; e2[q] = L.ev[sq[q] * 3 + 2]; }
+            for (int q = 0; q < kTrip; ++q) { e1[q] = L.ev[sq[q] * 3 + 1]; e2[q] = L.ev[sq[q] * 3 + 2]; }
             if (!any_iso) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
+              for (int q = 0; q < kTrip; ++q)
                 o[q] = pair_eval_gen(cc[q].x, cc[q].y, cc[q].z, unpack_eval(e0[q], e1[q], e2[q]), dx, dy, dz, qxx, qyy,
                                      qzz, qxy, qxz, qyz);
             } else {  // mixed batch: per-candidate dispatch (same arithmetic, just not interleaved)
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
+              for (int q = 0; q < kTrip; ++q)
                 o[q] = pair_eval(cc[q].x, cc[q].y, cc[q].z, unpack_eval(e0[q], e1[q], e2[q]), dx, dy, dz, qxx, qyy, qzz,
                                  qxy, qxz, qyz);
             }
           }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) commit(o[q], sq[q], q < nt);
+          for (int q = 0; q < kTrip; ++q) commit(o[q], sq[q], q < nt);
         }
         if (last_batch) wdone = true;
       }
     }
+#ifdef VOGE_SWEEP_STATS
+    ts_cons += wall_clock64() - tsb;
+#endif
     if (wdone && !reported) {
       reported = true;
       if (lane == 0) atomicAdd(&L.done, 1);
@@ -646,6 +703,21 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     if (L.done == WAVES) break;
   }
 
+#ifdef VOGE_SWEEP_STATS
+  const unsigned long long ts2 = wall_clock64();
+  if (lane == 0) {
+    atomicAdd(&g_sweep_stats[0], 1ull);
+    atomicAdd(&g_sweep_stats[1], (unsigned long long)(wave == 0 ? st_staged : 0));
+    atomicAdd(&g_sweep_stats[2], (unsigned long long)st_eval);
+    atomicAdd(&g_sweep_stats[3], (unsigned long long)st_trips);
+    atomicAdd(&g_sweep_stats[4], (unsigned long long)st_slow);
+    atomicAdd(&g_sweep_stats[5], (unsigned long long)st_shift);
+    atomicAdd(&g_sweep_stats[6], (unsigned long long)st_hits);
+    atomicAdd(&g_sweep_stats[7], (unsigned long long)(wave == 0 ? src_n : 0));
+    atomicAdd(&g_sweep_stats[8], (unsigned long long)(wave == 0 ? min(base, src_n) : 0));
+    atomicAdd(&g_sweep_stats[9], (unsigned long long)st_batches);
+  }
+#endif
   // ---- epilogue: lanes re-mapped to (pixel, slot); act / dsd recomputed with pair_eval ------
   L.cnt[tid] = cnt;
   if (out_cnt != nullptr && valid) out_cnt[((size_t)b * H + py) * W + px] = cnt;
@@ -670,25 +742,83 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     }
   };
   const bool vec4 = ((K & 3) == 0);   // rows of K floats stay 16-byte aligned: 16-byte stores
-  for (int r = 0; r < TH; ++r) {
+  if (vec4) {
+    // All rows of the tile as one item space; an item = 4 consecutive slots of one pixel.  kEpiU
+    // items per thread go through the stages together -- LDS keys, then one 16-byte gather per
+    // slot (isotropic Gaussians need nothing more), then arithmetic and the 16-byte stores -- so
+    // a thread has up to 4 * kEpiU gathers in flight instead of one dependent chain per slot.
+    constexpr int kEpiU = 4;
+    const int th = min(TH, H - ty * TH);
+    const int ipr = row_items >> 2;
+    const int nitem = th * ipr;
+    const float inv_ipr = 1.0f / (float)ipr, invK = 1.0f / (float)K;
+    for (int it0 = tid; it0 < nitem; it0 += T * kEpiU) {
+      uint64_t key[kEpiU][4];
+      float4 rec[kEpiU][4];
+      float ex[kEpiU], ey[kEpiU], ez[kEpiU];
+      size_t ob[kEpiU];
+      int nv[kEpiU];
+#pragma unroll
+      for (int u = 0; u < kEpiU; ++u) {
+        const int it = it0 + u * T;
+        nv[u] = -1;
+        ob[u] = 0;
+        ex[u] = ey[u] = ez[u] = 0.0f;
+        if (it < nitem) {
+          const int r = __float2int_rz(((float)it + 0.5f) * inv_ipr);
+          const int j = (it - r * ipr) * 4;
+          const int x = __float2int_rz(((float)j + 0.5f) * invK);
+          const int sl = j - x * K;
+          const int owner = ((x >> 3) + (TW / 8) * (r >> 3)) * 64 + (x & 7) + 8 * (r & 7);
+          const size_t pix = ((size_t)b * H + ty * TH + r) * W + (size_t)tx * TW + x;
+          ob[u] = pix * K + sl;
+          nv[u] = max(0, min(4, L.cnt[owner] - sl));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) key[u][q] = (q < nv[u]) ? keys[(size_t)(sl + q) * TP + owner] : 0ull;
+          if (nv[u] > 0) { ex[u] = rays[pix * 3]; ey[u] = rays[pix * 3 + 1]; ez[u] = rays[pix * 3 + 2]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kEpiU; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          rec[u][q] = (q < nv[u]) ? ms[(uint32_t)key[u][q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < kEpiU; ++u) {
+        if (nv[u] < 0) continue;
+        int32_t oi[4];
+        float ol[4], oa[4], od[4];
+        const float qxx = ex[u] * ex[u], qyy = ey[u] * ey[u], qzz = ez[u] * ez[u];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          oi[q] = -1; ol[q] = VOGE_SENT_LEN; oa[q] = VOGE_SENT_ACT; od[q] = 0.0f;
+          if (q < nv[u]) {
+            oi[q] = (int32_t)(uint32_t)key[u][q];
+            ol[q] = ord2f((uint32_t)(key[u][q] >> 32));
+            PairOut o;
+            if (rec[u][q].w == rec[u][q].w) {
+              o = pair_eval_iso(rec[u][q].x, rec[u][q].y, rec[u][q].z, rec[u][q].w, ex[u], ey[u], ez[u], qxx, qyy, qzz);
+            } else {
+              const EvalRec e = unpack_eval(evr[(size_t)oi[q] * 3 + 0], evr[(size_t)oi[q] * 3 + 1], evr[(size_t)oi[q] * 3 + 2]);
+              o = pair_eval(rec[u][q].x, rec[u][q].y, rec[u][q].z, e, ex[u], ey[u], ez[u], qxx, qyy, qzz, ex[u] * ey[u],
+                            ex[u] * ez[u], ey[u] * ez[u]);
+            }
+            oa[q] = o.act;
+            od[q] = o.dsd;
+          }
+        }
+        *reinterpret_cast<int4 *>(out_idx + ob[u]) = make_int4(oi[0], oi[1], oi[2], oi[3]);
+        *reinterpret_cast<float4 *>(out_len + ob[u]) = make_float4(ol[0], ol[1], ol[2], ol[3]);
+        *reinterpret_cast<float4 *>(out_act + ob[u]) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+        *reinterpret_cast<float4 *>(out_dsd + ob[u]) = make_float4(od[0], od[1], od[2], od[3]);
+      }
+    }
+  }
+  for (int r = 0; r < TH && !vec4; ++r) {
     const int gy = ty * TH + r;
     if (gy >= H) break;
     const size_t pix0 = ((size_t)b * H + gy) * W + (size_t)tx * TW;
-    if (vec4) {
-      for (int j4 = tid; j4 < row_items / 4; j4 += T) {
-        const int j = j4 * 4;
-        const int x = j / K, s = j - x * K;
-        int32_t oi[4];
-        float ol[4], oa[4], od[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) slot_value(r, x, s + q, pix0 + x, oi[q], ol[q], oa[q], od[q]);
-        const size_t o = pix0 * K + j;
-        *reinterpret_cast<int4 *>(out_idx + o) = make_int4(oi[0], oi[1], oi[2], oi[3]);
-        *reinterpret_cast<float4 *>(out_len + o) = make_float4(ol[0], ol[1], ol[2], ol[3]);
-        *reinterpret_cast<float4 *>(out_act + o) = make_float4(oa[0], oa[1], oa[2], oa[3]);
-        *reinterpret_cast<float4 *>(out_dsd + o) = make_float4(od[0], od[1], od[2], od[3]);
-      }
-    } else {
+    {
       for (int j = tid; j < row_items; j += T) {
         const int x = j / K, s = j - x * K;
         int32_t oi;
@@ -702,6 +832,13 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       }
     }
   }
+#ifdef VOGE_SWEEP_STATS
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) {
+    unsigned long long *o = g_sweep_times + 8 * (size_t)blockIdx.x;
+    o[0] = ts0; o[1] = ts1; o[2] = ts_fill; o[3] = ts_cons; o[4] = ts2; o[5] = wall_clock64(); o[6] = st_eval;
+    o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -768,7 +905,7 @@ trace_list_fwd_kernel(const float *__restrict__ mus, const float *__restrict__ i
 }
 
 struct TraceWs {
-  float4 *cull, *evr;
+  float4 *cull, *evr, *ms;
   int *bin_count;
   int32_t *bin_id;
   float *bin_lb;
@@ -789,13 +926,14 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
   auto take = [&](size_t bytes) { char *q = p ? p + off : nullptr; off += align256(bytes); return q; };
   // sweep tiles are at least 8x8 pixels: size the tile lists for that worst case
   const size_t ntile = (size_t)B * ((W + 7) / 8) * ((H + 7) / 8);
-  char *c = take(P * 16), *e = take(P * 48), *bc = take(nbin * 4), *bi = take(nbin * kBinCap * 4),
+  char *c = take(P * 16), *e = take(P * 48), *m4 = take(P * 16), *bc = take(nbin * 4), *bi = take(nbin * kBinCap * 4),
        *bl = take(nbin * kBinCap * 4), *tc = take(ntile * 4), *ti = take(ntile * kTileCap * 4),
        *tl = take(ntile * kTileCap * 4);
   if (ws) {
     ws->tl_count = reinterpret_cast<int *>(tc); ws->tl_id = reinterpret_cast<int32_t *>(ti);
     ws->tl_lb = reinterpret_cast<float *>(tl);
     ws->cull = reinterpret_cast<float4 *>(c); ws->evr = reinterpret_cast<float4 *>(e);
+    ws->ms = reinterpret_cast<float4 *>(m4);
     ws->bin_count = reinterpret_cast<int *>(bc); ws->bin_id = reinterpret_cast<int32_t *>(bi);
     ws->bin_lb = reinterpret_cast<float *>(bl); ws->nstx = nstx; ws->nsty = nsty;
   }
@@ -821,7 +959,7 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
     int rc = launch_status();
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, rays, ws.bin_count, ws.bin_id, ws.bin_lb,
+  hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, ws.ms, rays, ws.bin_count, ws.bin_id, ws.bin_lb,
                      ws.tl_count, ws.tl_id, ws.tl_lb, ws.nstx, ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd, cnt);
   return launch_status();
 }
@@ -829,6 +967,19 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
 }  // namespace voge
 
 using namespace voge;
+
+#ifdef VOGE_SWEEP_STATS
+// debug builds only (tools/sweep_stats.py): read and clear the sweep counters
+extern "C" int voge_debug_sweep_stats(unsigned long long *out16) {
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(voge::g_sweep_stats), sizeof(unsigned long long) * 16);
+  if (e != hipSuccess) return (int)e;
+  unsigned long long z[16] = {0};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(voge::g_sweep_stats), z, sizeof(z));
+}
+extern "C" int voge_debug_sweep_times(unsigned long long *out, int n_wg) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(voge::g_sweep_times), sizeof(unsigned long long) * 8 * (size_t)n_wg);
+}
+#endif
 
 extern "C" size_t voge_trace_workspace_bytes(int B, int N, int H, int W) {
   if (B <= 0 || N < 0 || H <= 0 || W <= 0) return 0;
@@ -852,7 +1003,7 @@ extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const
   trace_ws_layout(B, N, H, W, workspace, &ws);
   if (P > 0) {
     hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P,
-                       thr_act, ws.cull, ws.evr);
+                       thr_act, ws.cull, ws.evr, ws.ms);
     int rc = launch_status();
     if (rc) return rc;
   }
