@@ -29,8 +29,12 @@ with torch.no_grad():
         frag = renderer(gm, R=R, T=T)
     torch.cuda.synchronize()
     ctypes.CDLL(_lib.LIB_PATH).voge_debug_sweep_stats(out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     frag = renderer(gm, R=R, T=T)
+    e1.record()
 torch.cuda.synchronize()
+print('renderer forward (events) us', e0.elapsed_time(e1) * 1000)
 ctypes.CDLL(_lib.LIB_PATH).voge_debug_sweep_stats(out)
 names = ["waves", "staged(per WG)", "evaluated(per wave sum)", "trips", "slow_entries", "slow_shift_steps(wave max sum)",
          "hits(lane sum)", "list_len(per WG sum)", "list_consumed", "batches"]

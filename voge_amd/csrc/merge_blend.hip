@@ -125,6 +125,97 @@ shade_fwd_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx, cons
 }
 
 // ------------------------------------------------------------------------------------------
+// forward, K % 4 == 0 and K <= 64 (the renderer's case).  A lane owns FOUR consecutive slots of
+// one pixel (16-byte loads of idx and weight), a pixel owns an aligned row of 16 lanes, so the
+// per-pixel sums are DPP row reductions: no LDS, no shuffles, a quarter of the instructions of
+// the lane-per-slot kernel above.  A wave covers 4 * kSh4P pixels.
+// ------------------------------------------------------------------------------------------
+#ifndef VOGE_SH4_P
+#define VOGE_SH4_P 1
+#endif
+constexpr int kSh4P = VOGE_SH4_P;
+
+__global__ void __launch_bounds__(256)
+shade_fwd4_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx, const float *__restrict__ weight,
+                  const int64_t *__restrict__ valid_num, const float *__restrict__ bg, const float thr,
+                  const long npix, const int K, const int C, const long Nattr, const int fix_idx,
+                  float *__restrict__ out_rgb, float *__restrict__ out_img, float *__restrict__ out_sil,
+                  float *__restrict__ out_wsum) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane >> 4, q = lane & 15;
+  const bool lane_on = q < (K >> 2);
+  const long pixbase = ((long)blockIdx.x * 4 + wave) * (4 * kSh4P);
+  if (pixbase >= npix) return;
+  for (int c0 = 0; c0 < C; c0 += 4) {
+    const int nc = min(4, C - c0);
+    float4 w[kSh4P];
+    int4 id[kSh4P];
+    int vn[kSh4P];
+    bool ok[kSh4P];
+#pragma unroll
+    for (int u = 0; u < kSh4P; ++u) {
+      const long pix = pixbase + u * 4 + row;
+      ok[u] = lane_on && pix < npix;
+      w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      id[u] = make_int4(-1, -1, -1, -1);
+      vn[u] = 0;
+      if (ok[u]) {
+        const long o = pix * K + 4 * q;
+        w[u] = *reinterpret_cast<const float4 *>(weight + o);
+        id[u] = *reinterpret_cast<const int4 *>(idx + o);
+        vn[u] = (int)min((int64_t)K, valid_num[pix]);
+      }
+    }
+    float acc[kSh4P][4];
+    float a[kSh4P][4][4];
+    bool take[kSh4P][4];
+    int pp[kSh4P][4];
+#pragma unroll
+    for (int u = 0; u < kSh4P; ++u) {
+      const int raw[4] = {id[u].x, id[u].y, id[u].z, id[u].w};
+      const float wv[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        pp[u][s] = raw[s] + (raw[s] < 0);
+        take[u][s] = ok[u] && (4 * q + s < vn[u]) && (pp[u][s] >= 0) && (pp[u][s] < Nattr) && (wv[s] != 0.0f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[u][s][c] = (take[u][s] && c < nc) ? attr[(size_t)pp[u][s] * C + c0 + c] : 0.0f;
+      }
+      if (fix_idx && c0 == 0 && ok[u] && (raw[0] < 0 || raw[1] < 0 || raw[2] < 0 || raw[3] < 0))   // Aggregation.py:131
+        *reinterpret_cast<int4 *>(idx + (pixbase + u * 4 + row) * K + 4 * q) =
+            make_int4(pp[u][0], pp[u][1], pp[u][2], pp[u][3]);
+    }
+#pragma unroll
+    for (int u = 0; u < kSh4P; ++u) {
+      const float wv[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float x = a[u][0][c] * wv[0];
+        x = fmaf(a[u][1][c], wv[1], x);
+        x = fmaf(a[u][2][c], wv[2], x);
+        x = fmaf(a[u][3][c], wv[3], x);
+        acc[u][c] = row16_sum(x);
+      }
+      const float ws = row16_sum((wv[0] + wv[1]) + (wv[2] + wv[3]));
+      const long pix = pixbase + u * 4 + row;
+      if (pix < npix && q < 4) {   // lane q of the row finalises channel q
+        const float v = q == 0 ? acc[u][0] : q == 1 ? acc[u][1] : q == 2 ? acc[u][2] : acc[u][3];
+        if (c0 == 0 && q == 0) {
+          if (out_sil != nullptr) out_sil[pix] = fminf(ws, 1.0f);
+          if (out_wsum != nullptr) out_wsum[pix] = ws;
+        }
+        if (q < nc) {
+          float sil = fminf(ws, 1.0f);
+          if (thr > 0.0f) sil = sil > thr ? 1.0f : 0.0f;
+          if (out_rgb != nullptr) out_rgb[pix * C + c0 + q] = v;
+          if (out_img != nullptr) out_img[pix * C + c0 + q] = fminf(fmaf(1.0f - sil, bg[c0 + q], v), 1.0f);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward for C <= 4.  A wave owns an 8x8 pixel tile (locality for the attribute-gradient
 // table) and streams it row by row, one lane per slot.
 //   blend part (bg != NULL): g_rgb = g_up * [x < 1], x = rgb + (1 - mask) bg ;
@@ -388,6 +479,14 @@ extern "C" int voge_shade_fwd(const float *attr, int32_t *idx, const float *weig
   if (!weight) return VOGE_ERR_BAD_ARG;
   if (C > 0 && (!attr || !idx || !valid_num)) return VOGE_ERR_BAD_ARG;
   if (out_img && !bg) return VOGE_ERR_BAD_ARG;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(weight)) & 15) == 0;
+  if (C > 0 && (K & 3) == 0 && K <= 64 && aligned) {
+    const long per_wg = 4L * 4 * kSh4P;
+    hipLaunchKernelGGL(shade_fwd4_kernel, dim3((unsigned)((npix + per_wg - 1) / per_wg)), dim3(256), 0,
+                       (hipStream_t)stream, attr, idx, weight, valid_num, bg, thr, npix, K, C, Nattr, fix_negative_idx,
+                       out_rgb, out_img, out_sil, out_wsum);
+    return launch_status();
+  }
   hipLaunchKernelGGL(shade_fwd_kernel, dim3(run_grid(npix)), dim3(256), 0, (hipStream_t)stream, attr, idx, weight,
                      valid_num, nullptr, bg, thr, npix, K, C, Nattr, fix_negative_idx, out_rgb, out_img, out_sil, out_wsum);
   return launch_status();

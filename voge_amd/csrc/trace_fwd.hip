@@ -1019,6 +1019,9 @@ extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const
     return sizeof(uint64_t) * (size_t)(K + 1) * (64 * waves + 1) + 16 + fixed <= budget;
   };
   const size_t two_per_cu = 80 * 1024, one_per_cu = 160 * 1024;
+#ifdef VOGE_FORCE_WAVES
+  return launch_trace<VOGE_FORCE_WAVES>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
+#endif
   if (fits(4, two_per_cu)) return launch_trace<4>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
   if (fits(2, two_per_cu)) return launch_trace<2>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
   if (fits(1, two_per_cu)) return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);

@@ -354,6 +354,16 @@ __device__ __forceinline__ int wt_compact(WaveTable<NE, NV4> &t, const int lane)
   return n;
 }
 
+// Sum over each aligned group of 16 lanes (a DPP "row"), result in every lane of the row.
+// Four VALU instructions with DPP operands -- no LDS traffic, unlike ds_bpermute shuffles.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
 // Segmented sum over runs of `seg` consecutive lanes (seg <= 64, any value); the total of each
 // run lands in its first lane.
 __device__ __forceinline__ float seg_sum(float x, const int lane, const int seg) {
