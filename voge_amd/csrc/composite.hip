@@ -4,8 +4,8 @@
 // assign2weight, aggregation).  The reference materialises ~6 [npix,K,K] fp32 temporaries and
 // lets autograd replay them.  Here ONE LANE OWNS ONE (pixel, slot) PAIR: a 256-thread
 // workgroup covers floor(256/K) whole pixels, every HBM access is a perfectly coalesced
-// stream over the flat [npix*K] arrays, the pixel's K (len, s, E) triples sit in 4 KB of LDS
-// and are broadcast-read in the K-long inner loop.  Nothing of size K x K ever exists.
+// stream over the flat [npix*K] arrays, the pixel's K (len, s, E) triples sit in LDS.
+// Nothing of size K x K ever exists.
 //
 //   fwd : row m        S_m = sum_k E_k Phi((len_m - len_k) s_k),  w_m = exp(-occ S_m) E_m e^{1/2}
 //   bwd : row m        u_m = g_m w_m,  r_m = sum_k E_k s_k phi_mk
@@ -13,45 +13,84 @@
 //                      dL/dlen_j = -occ (u_j r_j - E_j s_j sum_m u_m phi_mj)
 //                      dL/ddsd_j = -occ E_j / (2 s_j) sum_m u_m phi_mj (len_m - len_j)
 //   with E = exp(-act), s = sqrt(dsd + 1e-10), Phi = (erf + 1)/2, phi = exp(-x^2)/sqrt(pi).
+//
+// The kernel is VALU-issue bound (rocprofv3: SQ_INSTS_VALU x 4 cycles = kernel time), so the
+// inner loops are written for instruction count:
+//   * The pixel's list is depth sorted (the trace emits it that way), so the sign of
+//     x = (len_m - len_k) s_k is known from the side of the diagonal: both loops evaluate only
+//     h(|x|) = erfc(|x|)/2, and  Phi = 1 - h in front, h behind.  The "1" parts are prefix /
+//     suffix sums, the h parts die out beyond |len_m - len_k| >= 4 / s (h < 8e-9), so every row
+//     walks a WINDOW away from the diagonal and stops.
+//   * h(x) = 2^Q(x'), x' = x sqrt(log2 e), Q a degree-8 polynomial (|err| <= 5.2e-8 absolute on
+//     [0, 5], h(0) = 1/2 exactly): one transcendental per evaluation, no reciprocal, no select.
+//   * Two list entries per trip: (len, s, E) live in separate LDS arrays, ds_read2_b32 returns
+//     neighbours as a register pair and the arithmetic is packed fp32 (v_pk_fma_f32 ...).
+//   * Pads of sentinel entries (E = 0, len = -/+ 3e38) on both sides of every pixel's row: no
+//     index clamps or bounds tests in the loops.
+// An unsorted list (possible through the public API) takes a plain full K x K scan instead.
 #include "voge_common.h"
 
 namespace voge {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 constexpr int kCompThreads = 256;
 constexpr float kInvNorm = 1.6487212707001282f;  // 1 / exp(-0.5), Aggregation.py:79
 constexpr float kRsqrtPi = 0.5641895835477563f;
-constexpr float kSat = 4.0f;  // erf(4) = 1 - 1.5e-8
+constexpr float kSat = 4.0f;                     // erfc(4)/2 = 7.7e-9
+constexpr float kCs = 1.2011224087864498f;       // sqrt(log2 e): x' = x * kCs, exp(-x^2) = 2^(-x'^2)
+constexpr float kXcap = 5.0f * kCs;              // the fit's range; h(5) = 7.7e-13
+constexpr float kBig = 3.0e38f;
 
-// Phi(x) = (erf(x)+1)/2 and y = exp(-x^2) in one go.  erf by Abramowitz-Stegun 7.1.26
-// (|err| <= 1.5e-7 absolute), branch-free; the same exponential feeds phi in the backward.
-__device__ __forceinline__ float phi_cdf(const float x, float &y) {
-  const float ax = fabsf(x);
-  y = __expf(-ax * ax);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float h = 0.5f * (p * t) * y;  // (1 - erf(|x|)) / 2
-  return x >= 0.0f ? 1.0f - h : h;
+// log2(erfc(x)/2) as a polynomial in x' = x sqrt(log2 e) on [0, 5 sqrt(log2 e)], weighted minimax
+// on the absolute error of 2^Q (tools/fit_erfc.py).
+constexpr float kQ0 = -1.000000000e+00f, kQ1 = -1.355323434e+00f, kQ2 = -6.365932822e-01f,
+                kQ3 = -8.570024371e-02f, kQ4 = 1.359716244e-02f, kQ5 = -3.297536168e-04f,
+                kQ6 = -4.863584472e-04f, kQ7 = 1.211055496e-04f, kQ8 = -1.022832203e-05f;
+
+__device__ __forceinline__ v2f pk_fma(const v2f a, const v2f b, const v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(const float x) { return (v2f){x, x}; }
+
+// h(x') = erfc(x'/kCs)/2 for x' >= 0 (capped at kXcap), two at a time
+__device__ __forceinline__ v2f h_pair(v2f xp) {
+  xp.x = fminf(xp.x, kXcap);
+  xp.y = fminf(xp.y, kXcap);
+  v2f q = pk_fma(splat(kQ8), xp, splat(kQ7));
+  q = pk_fma(q, xp, splat(kQ6));
+  q = pk_fma(q, xp, splat(kQ5));
+  q = pk_fma(q, xp, splat(kQ4));
+  q = pk_fma(q, xp, splat(kQ3));
+  q = pk_fma(q, xp, splat(kQ2));
+  q = pk_fma(q, xp, splat(kQ1));
+  q = pk_fma(q, xp, splat(kQ0));
+  return (v2f){__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
 }
+// 2^(-x'^2) = exp(-x^2), two at a time
+__device__ __forceinline__ v2f gauss_pair(const v2f xp) {
+  const v2f q = -(xp * xp);
+  return (v2f){__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+}
+__device__ __forceinline__ float h_one(const float xp) { return h_pair(splat(xp)).x; }
+
+// Row stride of the padded per-pixel arrays: K entries + (K + 2) sentinels on either side, so a
+// lane that keeps reading while its wave finishes never leaves its pixel's pads.
+__host__ __device__ constexpr int comp_row_stride(const int K) { return 3 * K + 4; }
 
 struct CompLds {
-  float4 rec[kCompThreads];  // (len, s, E, u) of slot tid
-  float pre[kCompThreads];   // exclusive prefix sum of E within the pixel
+  float pre[kCompThreads];   // inclusive prefix sum of E within the pixel
   float suf[kCompThreads];   // inclusive suffix sum of u within the pixel (backward)
   float scan[2][kCompThreads];
-  int cnt[kCompThreads];     // per local pixel: #(idx >= 0)
-  int hi[kCompThreads];      // per local pixel: 1 + last slot with E != 0
-  int rmax[kCompThreads];    // per local pixel: bits of max_k 4/s_k (window radius in len)
+  float scanm[2][kCompThreads];
+  int scanc[2][kCompThreads];   // forward only (aliases nothing the backward uses)
   int unsorted[kCompThreads];
 };
+// dynamic LDS: CompLds, then the padded per-pixel arrays len / sp / E (/ u in the backward),
+// `rows` floats each
+__host__ __device__ inline int comp_rows(const int K) { return ((kCompThreads / K) * comp_row_stride(K) + 3) & ~3; }
+__host__ __device__ inline size_t comp_lds_bytes(const int K, const bool bwd) {
+  return sizeof(CompLds) + sizeof(float) * (size_t)comp_rows(K) * (bwd ? 4 : 3);
+}
 
-// The pixel's list is depth sorted (the trace emits it that way).  Slot j influences row m only
-// through Phi((len_m - len_j) s_j), which saturates to 0 / 1 beyond |len_m - len_j| >= 4 / s_j
-// (|Phi - step| < 8e-9), so every row scans a WINDOW around itself and takes the far front
-// slots (Phi = 1) from a prefix sum of E; far back slots contribute nothing.  An unsorted list
-// (possible through the public API) simply gets an infinite window, i.e. the full K x K scan.
 template <bool BWD>
 __global__ void __launch_bounds__(kCompThreads)
 composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
@@ -60,13 +99,23 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
                  const int ppw, float *__restrict__ out0 /* weight | g_act */,
                  float *__restrict__ out1 /* g_len */, float *__restrict__ out2 /* g_dsd */,
                  int64_t *__restrict__ valid_num) {
-  __shared__ CompLds L;
+  extern __shared__ __attribute__((aligned(16))) unsigned char comp_smem[];
+  CompLds &L = *reinterpret_cast<CompLds *>(comp_smem);
+  const int rows = comp_rows(K);
+  float *const Llen = reinterpret_cast<float *>(comp_smem + sizeof(CompLds));
+  float *const Lsp = Llen + rows;
+  float *const LE = Lsp + rows;
+  float *const Lu = LE + rows;   // backward only
   const int tid = threadIdx.x;
   const int p = tid / K, k = tid - p * K;
   const long pix = (long)blockIdx.x * ppw + p;
-  const bool active = (p < ppw) && (pix < npix);
+  const bool in_wg = p < ppw;
+  const bool active = in_wg && (pix < npix);
   const long f = pix * K + k;
-  if (tid < ppw) { L.cnt[tid] = 0; L.hi[tid] = 0; L.rmax[tid] = 0; L.unsorted[tid] = 0; }
+  const int RS = comp_row_stride(K);
+  const int PAD = K + 2;
+  const int bi = (in_wg ? p : 0) * RS + PAD + (in_wg ? k : 0);   // this slot's entry in the padded arrays
+  if (tid < ppw) L.unsorted[tid] = 0;
   float lm = 0.f, sm = 1.f, em = 0.f, gw = 0.f;
   int id = -1;
   if (active) {
@@ -75,58 +124,95 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
     sm = sqrtf(dsd[f] + 1e-10f);
     if (BWD) gw = g_weight[f]; else id = idx[f];
   }
-  L.rec[tid] = make_float4(lm, sm, em, 0.0f);
-  __syncthreads();
-  if (active) {
-    if (!BWD && id >= 0) atomicAdd(&L.cnt[p], 1);
-    if (em != 0.0f) {
-      atomicMax(&L.hi[p], k + 1);
-      atomicMax(&L.rmax[p], __float_as_int(kSat / sm));   // positive floats order like ints
-    }
-    if (k > 0 && !(L.rec[tid - 1].x <= lm)) L.unsorted[p] = 1;
+  if (in_wg) {
+    Llen[bi] = lm; Lsp[bi] = sm * kCs; LE[bi] = em;
+    if (BWD) Lu[bi] = 0.0f;
+  }
+  // sentinels: 2 * PAD entries per pixel row
+  for (int i = tid; i < ppw * 2 * PAD; i += kCompThreads) {
+    const int pp = i / (2 * PAD), r = i - pp * (2 * PAD);
+    const int e = pp * RS + (r < PAD ? r : K + r);
+    Llen[e] = (r < PAD) ? -kBig : kBig;
+    Lsp[e] = 1.0f;
+    LE[e] = 0.0f;
+    if (BWD) Lu[e] = 0.0f;
   }
   __syncthreads();
-  const int hi = active ? L.hi[p] : 0;
-  const float4 *row = L.rec + (active ? p * K : 0);
-  const float *pre = L.pre + (active ? p * K : 0);
-  const bool sorted = active && (L.unsorted[p] == 0);
-  const float rwin = sorted ? __int_as_float(L.rmax[p]) : INFINITY;
-  {   // exclusive prefix sum of E within each pixel: log2(K) ping-pong steps over the workgroup
+  if (active && k > 0 && !(Llen[bi - 1] <= lm)) L.unsorted[p] = 1;
+  // One ping-pong scan over the workgroup (log2 K steps) yields, per pixel: the inclusive prefix
+  // sum of E, the largest 4/s (window radius in len) and the number of assigned slots.
+  float pre_incl;
+  int cnt_all;
+  float rwin_all;
+  {
     float x = em;
+    float mx = (em != 0.0f) ? kSat / sm : 0.0f;
+    int c = (!BWD && id >= 0) ? 1 : 0;
     int par = 0;
     for (int o = 1; o < K; o <<= 1) {
       L.scan[par][tid] = x;
+      L.scanm[par][tid] = mx;
+      if (!BWD) L.scanc[par][tid] = c;
       __syncthreads();
-      if (k >= o && p < ppw) x += L.scan[par][tid - o];
+      if (k >= o && in_wg) {
+        x += L.scan[par][tid - o];
+        mx = fmaxf(mx, L.scanm[par][tid - o]);
+        if (!BWD) c += L.scanc[par][tid - o];
+      }
       par ^= 1;
     }
-    L.pre[tid] = x - em;
+    pre_incl = x;
+    L.pre[tid] = x;
+    L.scanm[par][tid] = mx;      // slot K-1 of each pixel holds the pixel-wide values
+    if (!BWD) L.scanc[par][tid] = c;
+    __syncthreads();
+    const int last = in_wg ? p * K + K - 1 : tid;
+    rwin_all = L.scanm[par][last];
+    cnt_all = BWD ? 0 : L.scanc[par][last];
   }
-  __syncthreads();
+  const bool sorted = active && (L.unsorted[p] == 0);
+  const float rwin = sorted ? rwin_all : 0.0f;   // 0: the windowed loops do nothing
 
-  // ---- row m: S_m = sum_{far front} E_j + sum_{window} E_j Phi_mj ; r_m = sum_{window} E_j s_j phi_mj
+  // ---- row m (sorted list): S_m = prefix_E[m] - sum_front E_j h_mj + sum_back E_j h_mj ;
+  //      r_m = sum_window E_j s_j phi_mj.  Pairs walk away from the diagonal until the nearer
+  //      entry of the pair leaves the window.
   float sum = 0.0f, rterm = 0.0f;
-  if (em != 0.0f) {
-    int j = min(k, hi - 1);
-    for (; j >= 0; --j) {             // self and towards the camera
-      const float4 r = row[j];
-      const float d = lm - r.x;
-      if (d >= rwin) break;
-      if (r.z != 0.0f) {
-        float y;
-        sum = fmaf(r.z, phi_cdf(d * r.y, y), sum);
-        if (BWD) rterm = fmaf(r.z * r.y, y * kRsqrtPi, rterm);
-      }
+  if (em != 0.0f && sorted) {
+    v2f accF = splat(0.0f), accB = splat(0.0f), accR = splat(0.0f);
+    const v2f lm2 = splat(lm);
+    for (int e = bi - 1;; e -= 2) {      // entries (e, e+1) = slots (j-1, j), j = k, k-2, ...
+      const v2f l2 = {Llen[e], Llen[e + 1]};
+      const v2f s2 = {Lsp[e], Lsp[e + 1]};
+      const v2f E2 = {LE[e], LE[e + 1]};
+      const v2f d = lm2 - l2;
+      if (!(d.y < rwin)) break;
+      const v2f xp = d * s2;
+      accF = pk_fma(E2, h_pair(xp), accF);
+      if (BWD) accR = pk_fma(E2 * s2, gauss_pair(xp), accR);
     }
-    if (j >= 0) sum += pre[j + 1];    // slots 0..j are fully in front: Phi = 1
-    for (j = k + 1; j < hi; ++j) {    // away from the camera
-      const float4 r = row[j];
-      const float d = lm - r.x;
-      if (-d >= rwin) break;
-      if (r.z != 0.0f) {
-        float y;
-        sum = fmaf(r.z, phi_cdf(d * r.y, y), sum);
-        if (BWD) rterm = fmaf(r.z * r.y, y * kRsqrtPi, rterm);
+    for (int e = bi + 1;; e += 2) {      // slots (j, j+1), j = k+1, k+3, ...
+      const v2f l2 = {Llen[e], Llen[e + 1]};
+      const v2f s2 = {Lsp[e], Lsp[e + 1]};
+      const v2f E2 = {LE[e], LE[e + 1]};
+      const v2f d = l2 - lm2;
+      if (!(d.x < rwin)) break;
+      const v2f xp = d * s2;
+      accB = pk_fma(E2, h_pair(xp), accB);
+      if (BWD) accR = pk_fma(E2 * s2, gauss_pair(xp), accR);
+    }
+    sum = (pre_incl - (accF.x + accF.y)) + (accB.x + accB.y);
+    rterm = (accR.x + accR.y) * (kRsqrtPi / kCs);
+  } else if (em != 0.0f && active) {     // unsorted list: every column, signs from the data
+    for (int j = 0; j < K; ++j) {
+      const int e = bi - k + j;
+      const float Ej = LE[e];
+      if (Ej == 0.0f) continue;
+      const float xp = (lm - Llen[e]) * Lsp[e];
+      const float h = h_one(fabsf(xp));
+      sum = fmaf(Ej, xp >= 0.0f ? 1.0f - h : h, sum);
+      if (BWD) {
+        const float xc = fminf(fabsf(xp), 16.0f);
+        rterm = fmaf(Ej * Lsp[e], __builtin_amdgcn_exp2f(-xc * xc) * (kRsqrtPi / kCs), rterm);
       }
     }
   }
@@ -134,56 +220,72 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   if (!BWD) {
     if (active) {
       out0[f] = w;
-      if (k == 0) valid_num[pix] = L.cnt[p];
+      if (k == 0) valid_num[pix] = cnt_all;
     }
     return;
   }
   const float um = gw * w;
-  L.rec[tid].w = um;
-  __syncthreads();
+  if (in_wg) Lu[bi] = um;
   {   // inclusive suffix sum of u within each pixel
     float x = um;
     int par = 0;
     for (int o = 1; o < K; o <<= 1) {
       L.scan[par][tid] = x;
       __syncthreads();
-      if (k + o < K && p < ppw) x += L.scan[par][tid + o];
+      if (k + o < K && in_wg) x += L.scan[par][tid + o];
       par ^= 1;
     }
     L.suf[tid] = x;
   }
   __syncthreads();
-  const float *suf = L.suf + (active ? p * K : 0);
-  // ---- column j (= this lane): rows far behind see Phi_mj = 1 (suffix sum of u), rows far in
-  // front see 0; phi terms live in the window |len_m - len_j| < 4 / s_j only.
+  // ---- column j (= this lane): Phi_mj = 1 - h for rows behind (suffix sum of u minus the h
+  // part), h for rows in front; phi terms live in the window |len_m - len_j| < 4 / s_j only.
   float ga = 0.0f, gl = 0.0f, gd = 0.0f;
-  if (em != 0.0f) {
-    const float rj = sorted ? kSat / sm : INFINITY;
-    float cPhi = 0.0f, cphi = 0.0f, cphil = 0.0f;
-    int m = min(k, hi - 1);
-    for (; m < hi; ++m) {             // self and rows behind
-      const float4 r = row[m];
-      const float dl = r.x - lm;
-      if (dl >= rj) break;
-      if (r.w != 0.0f) {
-        float y;
-        const float Phi = phi_cdf(dl * sm, y);
-        const float ph = r.w * (y * kRsqrtPi);
-        cPhi = fmaf(r.w, Phi, cPhi);
-        cphi += ph;
-        cphil = fmaf(ph, dl, cphil);
+  if (em != 0.0f && active) {
+    float cPhi, cphi, cphil;
+    const float sp = sm * kCs;
+    if (sorted) {
+      const float rj = kSat / sm;
+      const v2f lm2 = splat(lm), sp2 = splat(sp);
+      v2f aH = splat(0.0f), aP = splat(0.0f), aL = splat(0.0f);   // behind: sum u h, sum u y, sum u y dl
+      v2f bH = splat(0.0f), bP = splat(0.0f), bL = splat(0.0f);   // in front
+      for (int e = bi;; e += 2) {          // rows (m, m+1), m = j, j+2, ...
+        const v2f l2 = {Llen[e], Llen[e + 1]};
+        const v2f d = l2 - lm2;
+        if (!(d.x < rj)) break;
+        const v2f u2 = {Lu[e], Lu[e + 1]};
+        const v2f xp = d * sp2;
+        const v2f uy = u2 * gauss_pair(xp);
+        aH = pk_fma(u2, h_pair(xp), aH);
+        aP = aP + uy;
+        aL = pk_fma(uy, d, aL);
       }
-    }
-    if (m < hi) cPhi += suf[m];       // rows m..hi-1 are fully behind: Phi = 1
-    for (m = k - 1; m >= 0; --m) {    // rows in front
-      const float4 r = row[m];
-      const float dl = r.x - lm;
-      if (-dl >= rj) break;
-      if (r.w != 0.0f) {
-        float y;
-        const float Phi = phi_cdf(dl * sm, y);
-        const float ph = r.w * (y * kRsqrtPi);
-        cPhi = fmaf(r.w, Phi, cPhi);
+      for (int e = bi - 2;; e -= 2) {      // rows (m-1, m), m = j-1, j-3, ...
+        const v2f l2 = {Llen[e], Llen[e + 1]};
+        const v2f d = lm2 - l2;
+        if (!(d.y < rj)) break;
+        const v2f u2 = {Lu[e], Lu[e + 1]};
+        const v2f xp = d * sp2;
+        const v2f uy = u2 * gauss_pair(xp);
+        bH = pk_fma(u2, h_pair(xp), bH);
+        bP = bP + uy;
+        bL = pk_fma(uy, d, bL);
+      }
+      cPhi = (L.suf[tid] - (aH.x + aH.y)) + (bH.x + bH.y);
+      cphi = ((aP.x + aP.y) + (bP.x + bP.y)) * kRsqrtPi;
+      cphil = ((aL.x + aL.y) - (bL.x + bL.y)) * kRsqrtPi;
+    } else {
+      cPhi = 0.0f; cphi = 0.0f; cphil = 0.0f;
+      for (int m = 0; m < K; ++m) {
+        const int e = bi - k + m;
+        const float ur = Lu[e];
+        if (ur == 0.0f) continue;
+        const float dl = Llen[e] - lm;
+        const float xp = dl * sp;
+        const float h = h_one(fabsf(xp));
+        const float xc = fminf(fabsf(xp), 16.0f);
+        const float ph = ur * (__builtin_amdgcn_exp2f(-xc * xc) * kRsqrtPi);
+        cPhi = fmaf(ur, xp >= 0.0f ? 1.0f - h : h, cPhi);
         cphi += ph;
         cphil = fmaf(ph, dl, cphil);
       }
@@ -209,10 +311,12 @@ static int launch_composite(bool bwd, const int32_t *idx, const float *act, cons
   const int ppw = kCompThreads / K;
   const long blocks = (npix + ppw - 1) / ppw;
   if (bwd)
-    hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)blocks), dim3(kCompThreads), 0, (hipStream_t)stream, idx,
+    hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)blocks), dim3(kCompThreads), comp_lds_bytes(K, true),
+                       (hipStream_t)stream, idx,
                        act, len, dsd, g_weight, occ, npix, K, ppw, o0, o1, o2, valid_num);
   else
-    hipLaunchKernelGGL(composite_kernel<false>, dim3((unsigned)blocks), dim3(kCompThreads), 0, (hipStream_t)stream, idx,
+    hipLaunchKernelGGL(composite_kernel<false>, dim3((unsigned)blocks), dim3(kCompThreads), comp_lds_bytes(K, false),
+                       (hipStream_t)stream, idx,
                        act, len, dsd, g_weight, occ, npix, K, ppw, o0, o1, o2, valid_num);
   return launch_status();
 }
