@@ -34,10 +34,23 @@ namespace voge {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifdef VOGE_COMP_PRECISE
+#define FAST_EXP(x) expf(x)
+#define FAST_SQRT(x) sqrtf(x)
+#else
+// hardware exp2 / sqrt: ~1-2 ulp, far inside the 1e-4 parity tolerance; the libm versions cost
+// ~35 VALU instructions per lane in a VALU-bound kernel
+#define FAST_EXP(x) __builtin_amdgcn_exp2f((x) * 1.4426950408889634f)
+#define FAST_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#endif
+
 constexpr int kCompThreads = 256;
 constexpr float kInvNorm = 1.6487212707001282f;  // 1 / exp(-0.5), Aggregation.py:79
 constexpr float kRsqrtPi = 0.5641895835477563f;
-constexpr float kSat = 4.0f;                     // erfc(4)/2 = 7.7e-9
+#ifndef VOGE_KSAT
+#define VOGE_KSAT 3.5f
+#endif
+constexpr float kSat = VOGE_KSAT;                // erfc(3.5)/2 = 3.7e-7, below the fp32 rounding of S ~ O(1..K)
 constexpr float kCs = 1.2011224087864498f;       // sqrt(log2 e): x' = x * kCs, exp(-x^2) = 2^(-x'^2)
 constexpr float kXcap = 5.0f * kCs;              // the fit's range; h(5) = 7.7e-13
 constexpr float kBig = 3.0e38f;
@@ -107,7 +120,8 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   float *const LE = Lsp + rows;
   float *const Lu = LE + rows;   // backward only
   const int tid = threadIdx.x;
-  const int p = tid / K, k = tid - p * K;
+  // tid / K without the integer-division sequence (exact for tid < 2^20)
+  const int p = __float2int_rz(((float)tid + 0.5f) * __builtin_amdgcn_rcpf((float)K)), k = tid - p * K;
   const long pix = (long)blockIdx.x * ppw + p;
   const bool in_wg = p < ppw;
   const bool active = in_wg && (pix < npix);
@@ -119,23 +133,25 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   float lm = 0.f, sm = 1.f, em = 0.f, gw = 0.f;
   int id = -1;
   if (active) {
-    em = expf(-act[f]);
+    em = FAST_EXP(-act[f]);
     lm = len[f];
-    sm = sqrtf(dsd[f] + 1e-10f);
+    sm = FAST_SQRT(dsd[f] + 1e-10f);
     if (BWD) gw = g_weight[f]; else id = idx[f];
   }
   if (in_wg) {
     Llen[bi] = lm; Lsp[bi] = sm * kCs; LE[bi] = em;
     if (BWD) Lu[bi] = 0.0f;
   }
-  // sentinels: 2 * PAD entries per pixel row
-  for (int i = tid; i < ppw * 2 * PAD; i += kCompThreads) {
-    const int pp = i / (2 * PAD), r = i - pp * (2 * PAD);
-    const int e = pp * RS + (r < PAD ? r : K + r);
-    Llen[e] = (r < PAD) ? -kBig : kBig;
-    Lsp[e] = 1.0f;
-    LE[e] = 0.0f;
-    if (BWD) Lu[e] = 0.0f;
+  // sentinels: PAD = K + 2 entries on either side of the row; thread k writes pad entries k
+  // (and K + k for k < 2) of its own pixel -- no index arithmetic beyond an add
+  if (in_wg) {
+    const int r0 = p * RS;
+    for (int q = k; q < PAD; q += K) {
+      const int ef = r0 + q, eb = r0 + PAD + K + q;
+      Llen[ef] = -kBig; Lsp[ef] = 1.0f; LE[ef] = 0.0f;
+      Llen[eb] = kBig; Lsp[eb] = 1.0f; LE[eb] = 0.0f;
+      if (BWD) { Lu[ef] = 0.0f; Lu[eb] = 0.0f; }
+    }
   }
   __syncthreads();
   if (active && k > 0 && !(Llen[bi - 1] <= lm)) L.unsorted[p] = 1;
@@ -146,7 +162,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   float rwin_all;
   {
     float x = em;
-    float mx = (em != 0.0f) ? kSat / sm : 0.0f;
+    float mx = (em != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm) : 0.0f;
     int c = (!BWD && id >= 0) ? 1 : 0;
     int par = 0;
     for (int o = 1; o < K; o <<= 1) {
@@ -185,7 +201,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
       const v2f s2 = {Lsp[e], Lsp[e + 1]};
       const v2f E2 = {LE[e], LE[e + 1]};
       const v2f d = lm2 - l2;
-      if (!(d.y < rwin)) break;
+      if (d.y >= rwin) break;
       const v2f xp = d * s2;
       accF = pk_fma(E2, h_pair(xp), accF);
       if (BWD) accR = pk_fma(E2 * s2, gauss_pair(xp), accR);
@@ -195,7 +211,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
       const v2f s2 = {Lsp[e], Lsp[e + 1]};
       const v2f E2 = {LE[e], LE[e + 1]};
       const v2f d = l2 - lm2;
-      if (!(d.x < rwin)) break;
+      if (d.x >= rwin) break;
       const v2f xp = d * s2;
       accB = pk_fma(E2, h_pair(xp), accB);
       if (BWD) accR = pk_fma(E2 * s2, gauss_pair(xp), accR);
@@ -216,7 +232,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
       }
     }
   }
-  const float w = (em != 0.0f) ? expf(-occ * sum) * em * kInvNorm : 0.0f;
+  const float w = (em != 0.0f) ? FAST_EXP(-occ * sum) * em * kInvNorm : 0.0f;
   if (!BWD) {
     if (active) {
       out0[f] = w;
@@ -245,14 +261,14 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
     float cPhi, cphi, cphil;
     const float sp = sm * kCs;
     if (sorted) {
-      const float rj = kSat / sm;
+      const float rj = kSat * __builtin_amdgcn_rcpf(sm);
       const v2f lm2 = splat(lm), sp2 = splat(sp);
       v2f aH = splat(0.0f), aP = splat(0.0f), aL = splat(0.0f);   // behind: sum u h, sum u y, sum u y dl
       v2f bH = splat(0.0f), bP = splat(0.0f), bL = splat(0.0f);   // in front
       for (int e = bi;; e += 2) {          // rows (m, m+1), m = j, j+2, ...
         const v2f l2 = {Llen[e], Llen[e + 1]};
         const v2f d = l2 - lm2;
-        if (!(d.x < rj)) break;
+        if (d.x >= rj) break;
         const v2f u2 = {Lu[e], Lu[e + 1]};
         const v2f xp = d * sp2;
         const v2f uy = u2 * gauss_pair(xp);
@@ -263,7 +279,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
       for (int e = bi - 2;; e -= 2) {      // rows (m-1, m), m = j-1, j-3, ...
         const v2f l2 = {Llen[e], Llen[e + 1]};
         const v2f d = lm2 - l2;
-        if (!(d.y < rj)) break;
+        if (d.y >= rj) break;
         const v2f u2 = {Lu[e], Lu[e + 1]};
         const v2f xp = d * sp2;
         const v2f uy = u2 * gauss_pair(xp);
