@@ -198,6 +198,7 @@ def main():
             o_i, o_l, o_a, o_d = (torch.empty_like(x) for x in sel)
             o_c = torch.empty((1, H, W), dtype=torch.int32, device=dev)
             g3 = [torch.empty_like(w) for _ in range(3)]
+            g_w = torch.rand_like(w)
             g_ray, g_mu, g_A = torch.empty_like(rays), torch.empty_like(mus), torch.empty_like(isg)
             out3, g_attr = torch.empty_like(rgb), torch.empty_like(colors)
             wsum = torch.empty(rgb.shape[:-1], dtype=torch.float32, device=rgb.device)
@@ -211,7 +212,7 @@ def main():
                                                         P(out3), None, P(wsum), st),
                 "shade_bwd": lambda: lib.voge_shade_bwd(P(colors), P(idx), P(w), P(vn), P(rgb), P(wsum), P(bg), -1.0, P(g_img), H, W, K,
                                                         3, N, P(g_attr), P(g3[0]), st),
-                "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), 1.0, npix, K, P(g3[0]),
+                "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), P(g_w), 1.0, npix, K, P(g3[0]),
                                                                 P(g3[1]), P(g3[2]), st),
                 "trace_bwd": lambda: lib.voge_trace_bwd(P(mus), P(isg), P(rays), P(sel[0]), P(vn32), P(w), P(w), P(w), N, H, W, K,
                                                         P(ws_b), ws_b.numel(), None, P(g_mu), P(g_A), st),

@@ -222,6 +222,38 @@ def test_composite_random_vs_oracle(hip_lib, K):
     ra, rl, rd = oracle.composite_bwd(act.astype(np.float32), ln.astype(np.float32), dsd.astype(np.float32), gw, 0.7)
     for got, ref in ((ta.grad, ra), (tl.grad, rl), (td.grad, rd)):
         assert np.abs(n(got).reshape(npix, K) - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+    # the same backward through the C ABI without the forward's weights (recompute mode)
+    from voge_amd import _lib
+    lib = _lib.load()
+    tg = t(gw.reshape(shape))
+    outs = [torch.empty_like(ta) for _ in range(3)]
+    rc = lib.voge_composite_bwd(ta.data_ptr(), tl.data_ptr(), td.data_ptr(), None, tg.data_ptr(), 0.7, npix, K,
+                                *[o.data_ptr() for o in outs], torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    for got, ref in zip(outs, (ra, rl, rd)):
+        assert np.abs(n(got).reshape(npix, K) - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
+def test_composite_unsorted_list(hip_lib):
+    """Lists that are not depth sorted (possible through the public API) take the full K x K scan."""
+    from voge_amd import ops
+    rng = np.random.default_rng(7)
+    npix, K = 2 * 33, 24
+    ln = rng.uniform(1, 3, (npix, K))
+    ln[::3] = np.sort(ln[::3], axis=1)          # a third of the pixels stay sorted
+    act = rng.uniform(0, 5, (npix, K))
+    dsd = rng.uniform(1, 400, (npix, K))
+    idx = rng.integers(0, 1000, (npix, K)).astype(np.int32)
+    shape = (2, 33, K)
+    ta, tl, td = (t(x.reshape(shape), rg=True) for x in (act, ln, dsd))
+    w, vn = ops.composite(t(idx.reshape(shape), torch.int32), ta, tl, td, 1.3)
+    wr, vr = oracle.composite_fwd(idx, act, ln, dsd, 1.3)
+    assert np.abs(n(w).reshape(npix, K) - wr).max() < TOL
+    gw = rng.normal(size=(npix, K))
+    (w * t(gw.reshape(shape))).sum().backward()
+    ra, rl, rd = oracle.composite_bwd(act.astype(np.float32), ln.astype(np.float32), dsd.astype(np.float32), gw, 1.3)
+    for got, ref in ((ta.grad, ra), (tl.grad, rl), (td.grad, rd)):
+        assert np.abs(n(got).reshape(npix, K) - ref).max() <= TOL * max(1.0, np.abs(ref).max())
 
 
 # ------------------------------------------------------------------------------- merge / blend

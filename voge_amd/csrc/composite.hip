@@ -104,14 +104,18 @@ __host__ __device__ inline size_t comp_lds_bytes(const int K, const bool bwd) {
   return sizeof(CompLds) + sizeof(float) * (size_t)comp_rows(K) * (bwd ? 4 : 3);
 }
 
-template <bool BWD>
+// MODE 0: forward.  1: backward, weights recomputed (S_m again).  2: backward with the forward's
+// weights given: the row pass only needs r_m, i.e. exp(-x^2) but no erfc.
+template <int MODE>
 __global__ void __launch_bounds__(kCompThreads)
 composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
                  const float *__restrict__ len, const float *__restrict__ dsd,
-                 const float *__restrict__ g_weight, const float occ, const long npix, const int K,
+                 const float *__restrict__ w_in, const float *__restrict__ g_weight, const float occ, const long npix, const int K,
                  const int ppw, float *__restrict__ out0 /* weight | g_act */,
                  float *__restrict__ out1 /* g_len */, float *__restrict__ out2 /* g_dsd */,
                  int64_t *__restrict__ valid_num) {
+  constexpr bool BWD = MODE != 0;
+  constexpr bool HAVE_W = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char comp_smem[];
   CompLds &L = *reinterpret_cast<CompLds *>(comp_smem);
   const int rows = comp_rows(K);
@@ -130,16 +134,17 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   const int PAD = K + 2;
   const int bi = (in_wg ? p : 0) * RS + PAD + (in_wg ? k : 0);   // this slot's entry in the padded arrays
   if (tid < ppw) L.unsorted[tid] = 0;
-  float lm = 0.f, sm = 1.f, em = 0.f, gw = 0.f;
+  float lm = 0.f, sm = 1.f, em = 0.f, gw = 0.f, wgiven = 0.f;
   int id = -1;
   if (active) {
     em = FAST_EXP(-act[f]);
     lm = len[f];
     sm = FAST_SQRT(dsd[f] + 1e-10f);
     if (BWD) gw = g_weight[f]; else id = idx[f];
+    if (HAVE_W) wgiven = w_in[f];
   }
   if (in_wg) {
-    Llen[bi] = lm; Lsp[bi] = sm * kCs; LE[bi] = em;
+    Llen[bi] = lm; Lsp[bi] = sm * kCs; LE[bi] = HAVE_W ? em * (sm * kCs) : em;
     if (BWD) Lu[bi] = 0.0f;
   }
   // sentinels: PAD = K + 2 entries on either side of the row; thread k writes pad entries k
@@ -166,12 +171,12 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
     int c = (!BWD && id >= 0) ? 1 : 0;
     int par = 0;
     for (int o = 1; o < K; o <<= 1) {
-      L.scan[par][tid] = x;
+      if (!HAVE_W) L.scan[par][tid] = x;
       L.scanm[par][tid] = mx;
       if (!BWD) L.scanc[par][tid] = c;
       __syncthreads();
       if (k >= o && in_wg) {
-        x += L.scan[par][tid - o];
+        if (!HAVE_W) x += L.scan[par][tid - o];
         mx = fmaxf(mx, L.scanm[par][tid - o]);
         if (!BWD) c += L.scanc[par][tid - o];
       }
@@ -203,8 +208,8 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
       const v2f d = lm2 - l2;
       if (d.y >= rwin) break;
       const v2f xp = d * s2;
-      accF = pk_fma(E2, h_pair(xp), accF);
-      if (BWD) accR = pk_fma(E2 * s2, gauss_pair(xp), accR);
+      if (!HAVE_W) accF = pk_fma(E2, h_pair(xp), accF);
+      if (BWD) accR = pk_fma(HAVE_W ? E2 : E2 * s2, gauss_pair(xp), accR);
     }
     for (int e = bi + 1;; e += 2) {      // slots (j, j+1), j = k+1, k+3, ...
       const v2f l2 = {Llen[e], Llen[e + 1]};
@@ -213,8 +218,8 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
       const v2f d = l2 - lm2;
       if (d.x >= rwin) break;
       const v2f xp = d * s2;
-      accB = pk_fma(E2, h_pair(xp), accB);
-      if (BWD) accR = pk_fma(E2 * s2, gauss_pair(xp), accR);
+      if (!HAVE_W) accB = pk_fma(E2, h_pair(xp), accB);
+      if (BWD) accR = pk_fma(HAVE_W ? E2 : E2 * s2, gauss_pair(xp), accR);
     }
     sum = (pre_incl - (accF.x + accF.y)) + (accB.x + accB.y);
     rterm = (accR.x + accR.y) * (kRsqrtPi / kCs);
@@ -224,15 +229,17 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
       const float Ej = LE[e];
       if (Ej == 0.0f) continue;
       const float xp = (lm - Llen[e]) * Lsp[e];
-      const float h = h_one(fabsf(xp));
-      sum = fmaf(Ej, xp >= 0.0f ? 1.0f - h : h, sum);
+      if (!HAVE_W) {
+        const float h = h_one(fabsf(xp));
+        sum = fmaf(Ej, xp >= 0.0f ? 1.0f - h : h, sum);
+      }
       if (BWD) {
         const float xc = fminf(fabsf(xp), 16.0f);
-        rterm = fmaf(Ej * Lsp[e], __builtin_amdgcn_exp2f(-xc * xc) * (kRsqrtPi / kCs), rterm);
+        rterm = fmaf(HAVE_W ? Ej : Ej * Lsp[e], __builtin_amdgcn_exp2f(-xc * xc) * (kRsqrtPi / kCs), rterm);
       }
     }
   }
-  const float w = (em != 0.0f) ? FAST_EXP(-occ * sum) * em * kInvNorm : 0.0f;
+  const float w = HAVE_W ? wgiven : ((em != 0.0f) ? FAST_EXP(-occ * sum) * em * kInvNorm : 0.0f);
   if (!BWD) {
     if (active) {
       out0[f] = w;
@@ -321,19 +328,22 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
 
 using namespace voge;
 
-static int launch_composite(bool bwd, const int32_t *idx, const float *act, const float *len, const float *dsd,
-                            const float *g_weight, float occ, long npix, int K, float *o0, float *o1, float *o2,
-                            int64_t *valid_num, voge_stream_t stream) {
+static int launch_composite(int mode, const int32_t *idx, const float *act, const float *len, const float *dsd,
+                            const float *w_in, const float *g_weight, float occ, long npix, int K, float *o0, float *o1,
+                            float *o2, int64_t *valid_num, voge_stream_t stream) {
   const int ppw = kCompThreads / K;
-  const long blocks = (npix + ppw - 1) / ppw;
-  if (bwd)
-    hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)blocks), dim3(kCompThreads), comp_lds_bytes(K, true),
-                       (hipStream_t)stream, idx,
-                       act, len, dsd, g_weight, occ, npix, K, ppw, o0, o1, o2, valid_num);
+  const dim3 grid((unsigned)((npix + ppw - 1) / ppw)), block(kCompThreads);
+  const size_t lds = comp_lds_bytes(K, mode != 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 2)
+    hipLaunchKernelGGL(composite_kernel<2>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, occ, npix, K, ppw, o0,
+                       o1, o2, valid_num);
+  else if (mode == 1)
+    hipLaunchKernelGGL(composite_kernel<1>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, occ, npix, K, ppw, o0,
+                       o1, o2, valid_num);
   else
-    hipLaunchKernelGGL(composite_kernel<false>, dim3((unsigned)blocks), dim3(kCompThreads), comp_lds_bytes(K, false),
-                       (hipStream_t)stream, idx,
-                       act, len, dsd, g_weight, occ, npix, K, ppw, o0, o1, o2, valid_num);
+    hipLaunchKernelGGL(composite_kernel<0>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, occ, npix, K, ppw, o0,
+                       o1, o2, valid_num);
   return launch_status();
 }
 
@@ -344,15 +354,16 @@ extern "C" int voge_composite_fwd(const int32_t *idx, const float *act, const fl
   if (K > VOGE_MAX_K || K > kCompThreads) return VOGE_ERR_K_TOO_LARGE;
   if (npix == 0) return 0;
   if (!idx || !act || !len || !dsd || !weight || !valid_num) return VOGE_ERR_BAD_ARG;
-  return launch_composite(false, idx, act, len, dsd, nullptr, occ, npix, K, weight, nullptr, nullptr, valid_num, stream);
+  return launch_composite(0, idx, act, len, dsd, nullptr, nullptr, occ, npix, K, weight, nullptr, nullptr, valid_num, stream);
 }
 
-extern "C" int voge_composite_bwd(const float *act, const float *len, const float *dsd,
+extern "C" int voge_composite_bwd(const float *act, const float *len, const float *dsd, const float *weight,
                                   const float *g_weight, float occ, long npix, int K, float *g_act,
                                   float *g_len, float *g_dsd, voge_stream_t stream) {
   if (npix < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K || K > kCompThreads) return VOGE_ERR_K_TOO_LARGE;
   if (npix == 0) return 0;
   if (!act || !len || !dsd || !g_weight || !g_act || !g_len || !g_dsd) return VOGE_ERR_BAD_ARG;
-  return launch_composite(true, nullptr, act, len, dsd, g_weight, occ, npix, K, g_act, g_len, g_dsd, nullptr, stream);
+  return launch_composite(weight ? 2 : 1, nullptr, act, len, dsd, weight, g_weight, occ, npix, K, g_act, g_len, g_dsd,
+                          nullptr, stream);
 }
