@@ -136,8 +136,8 @@ __device__ __forceinline__ float depth_key(const float4 c, const Cone &k) {
 }
 
 // ------------------------------------------------------------------------------------------
-// bin: one 1024-thread workgroup per kST x kST-pixel super-tile.  Tests every Gaussian of the
-// batch element against the super-tile's bounding cone (conservative), then orders the
+// bin: one 1024-thread workgroup per kST x kST-pixel super-tile.  Tests every Gaussian on its
+// parent region's list (bin0) against the super-tile's bounding cone (conservative), then orders the
 // survivors front to back by depth key (counting sort + per-bucket insertion sort, LDS) and
 // writes the (id, monotone len lower bound) list.
 // More than kBinCap survivors -> count = -1 and the sweep falls back to the full stream.
@@ -175,35 +175,205 @@ __device__ __forceinline__ void block_reduce16(float *red, const int wave, const
   a = ra; b = rb; c = rc; d = rd;
 }
 
+// Bounding cone of the rays of a pixel rectangle, computed by a whole 1024-thread workgroup.
+__device__ __forceinline__ Cone region_cone(const float *__restrict__ rays, const int b, const int H, const int W,
+                                            const int x0, const int y0, const int rw, const int rh, float *red,
+                                            const int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int npx = rw * rh;
+  const float inv_rw = 1.0f / (float)rw;
+  // kCU rays per thread are loaded before any is used: a 128 x 128 region is 16 rays per thread
+  // and two passes, i.e. 32 dependent round trips if taken one at a time
+  constexpr int kCU = 8;
+  auto load_rays = [&](const int i0, float (&rx)[kCU], float (&ry)[kCU], float (&rz)[kCU]) {
+#pragma unroll
+    for (int u = 0; u < kCU; ++u) {
+      const int i = i0 + u * kBinThreads;
+      rx[u] = 0.f; ry[u] = 0.f; rz[u] = 0.f;
+      if (i < npx) {
+        const int y = __float2int_rz(((float)i + 0.5f) * inv_rw), x = i - y * rw;
+        const float *r = rays + (((size_t)b * H + y0 + y) * W + x0 + x) * 3;
+        rx[u] = r[0]; ry[u] = r[1]; rz[u] = r[2];
+      }
+    }
+  };
+  // Pass 1: axis = direction of the plain vector sum (any axis gives a valid cone; rays of a
+  // pinhole camera have near-equal lengths, so this is the mean direction).  Pass 2: extrema of
+  // the axial cosine and of the SQUARED radial sine -- one v_rsq per ray, one sqrt per workgroup.
+  // (The libm sqrt / divide per ray made a 128 x 128 region cost ~20 us of VALU time.)
+  float sx = 0.f, sy = 0.f, sz = 0.f, okf = 1.f;
+  for (int i0 = tid; i0 < npx; i0 += kCU * kBinThreads) {
+    float rx[kCU], ry[kCU], rz[kCU];
+    load_rays(i0, rx, ry, rz);
+#pragma unroll
+    for (int u = 0; u < kCU; ++u) {
+      if (i0 + u * kBinThreads < npx) {
+        const float dn2 = fmaf(rz[u], rz[u], fmaf(ry[u], ry[u], rx[u] * rx[u]));
+        if (dn2 > 1e-30f && dn2 < 1e30f) { sx += rx[u]; sy += ry[u]; sz += rz[u]; } else okf = 0.f;
+      }
+    }
+  }
+  block_reduce16(red, wave, lane, sx, sy, sz, okf, 0);
+  const float n = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
+  const float ax = sx / n, ay = sy / n, az = sz / n;
+  float s2max = 0.f, cmin = 1.f, dummy = 0.f, okf2 = 1.f;
+  for (int i0 = tid; i0 < npx; i0 += kCU * kBinThreads) {
+    float rx[kCU], ry[kCU], rz[kCU];
+    load_rays(i0, rx, ry, rz);
+#pragma unroll
+    for (int u = 0; u < kCU; ++u) {
+      if (i0 + u * kBinThreads < npx) {
+        const float dn2 = fmaf(rz[u], rz[u], fmaf(ry[u], ry[u], rx[u] * rx[u]));
+        const bool ok = dn2 > 1e-30f && dn2 < 1e30f;
+        const float inv = __builtin_amdgcn_rsqf(dn2);
+        const float da = fmaf(rz[u], az, fmaf(ry[u], ay, rx[u] * ax));
+        const float qx = fmaf(-da, ax, rx[u]), qy = fmaf(-da, ay, ry[u]), qz = fmaf(-da, az, rz[u]);
+        const float s2 = fmaf(qz, qz, fmaf(qy, qy, qx * qx)) * (inv * inv);
+        s2max = fmaxf(s2max, ok ? s2 : 4.0f);
+        cmin = fminf(cmin, ok ? da * inv : -1.0f);
+      }
+    }
+  }
+  block_reduce16(red, wave, lane, s2max, cmin, dummy, okf2, 1);
+  // v_rsq is good to ~1 ulp: pad the bounds by 4e-7 relative on top of cone_finish's margins
+  return cone_finish(ax, ay, az, n / (float)max(npx, 1), sqrtf(s2max) * (1.0f + 4e-7f) + 4e-7f, cmin - 4e-7f, okf != 0.f);
+}
+
+// Cones of all kST x kST super-tiles, computed once: bin_kernel reads its own, bin0_kernel
+// composes its region's cone from the <= 16 children instead of touching 16k rays again.
+struct ConeRec {
+  float ax, ay, az, cs, sn, ok, pad0, pad1;
+};
+
 __global__ void __launch_bounds__(kBinThreads)
-bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, const int N, const int H,
+bincone_kernel(const float *__restrict__ rays, const int H, const int W, const int nstx,
+               ConeRec *__restrict__ cones /* [B][nst] */) {
+  __shared__ float red[16 * 4];
+  const int tid = threadIdx.x;
+  const int stx = blockIdx.x % nstx, sty = blockIdx.x / nstx, b = blockIdx.y;
+  const int x0 = stx * kST, y0 = sty * kST;
+  const Cone c = region_cone(rays, b, H, W, x0, y0, min(kST, W - x0), min(kST, H - y0), red, tid);
+  if (tid == 0) cones[(size_t)b * gridDim.x + blockIdx.x] = ConeRec{c.ax, c.ay, c.az, c.cs, c.sn, c.ok ? 1.f : 0.f, 0.f, 0.f};
+}
+
+__device__ __forceinline__ Cone load_cone(const ConeRec &r) {
+  Cone c;
+  c.ax = r.ax; c.ay = r.ay; c.az = r.az; c.cs = r.cs; c.sn = r.sn; c.ok = r.ok != 0.f;
+  return c;
+}
+
+// Conservative union of child cones: a ray of child i makes at most alpha_i + theta_i with the
+// parent axis (alpha_i = angle between the axes), so
+//   cos >= cos(alpha_i) cs_i - sin(alpha_i) sn_i ,   sin <= sin(alpha_i) + cos(alpha_i) sn_i .
+__device__ __forceinline__ Cone compose_cones(const ConeRec *__restrict__ ch, const int nstx, const int cx0, const int cy0,
+                                              const int ncx, const int ncy) {
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  bool ok = true;
+  for (int j = 0; j < ncy; ++j)
+    for (int i = 0; i < ncx; ++i) {
+      const ConeRec r = ch[(cy0 + j) * nstx + cx0 + i];
+      sx += r.ax; sy += r.ay; sz += r.az;
+      ok = ok && (r.ok != 0.f);
+    }
+  const float n = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
+  const float ax = sx / n, ay = sy / n, az = sz / n;
+  float smax = 0.f, cmin = 1.f;
+  for (int j = 0; j < ncy; ++j)
+    for (int i = 0; i < ncx; ++i) {
+      const ConeRec r = ch[(cy0 + j) * nstx + cx0 + i];
+      const float ca = fmaf(r.az, az, fmaf(r.ay, ay, r.ax * ax));
+      const float qx = fmaf(-ca, ax, r.ax), qy = fmaf(-ca, ay, r.ay), qz = fmaf(-ca, az, r.az);
+      const float sa = sqrtf(fmaf(qz, qz, fmaf(qy, qy, qx * qx))) * (1.0f + 1e-6f) + 1e-7f;
+      const float cl = fminf(ca, 1.0f) - 1e-7f;
+      if (!(cl > 0.0f)) ok = false;
+      cmin = fminf(cmin, fmaf(cl, r.cs, -sa * r.sn));
+      smax = fmaxf(smax, fmaf(fminf(ca + 1e-7f, 1.0f), r.sn, sa));
+    }
+  return cone_finish(ax, ay, az, n / (float)(ncx * ncy), smax, cmin, ok);
+}
+
+// ------------------------------------------------------------------------------------------
+// bin0: the coarse level.  A kST0 x kST0-pixel region is covered by kBin0Split workgroups, each
+// testing its slice of the batch element's Gaussians against the region's cone and appending the
+// survivors' ids (unordered) to the region's list.  bin_kernel then scans its parent region's
+// list (~N/10) instead of all N Gaussians: the scan work drops from nst*N to nst0*N + nst*N/10.
+// ------------------------------------------------------------------------------------------
+constexpr int kST0 = 128;
+constexpr int kBin0Split = 8;
+
+__global__ void __launch_bounds__(kBinThreads)
+bin0_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, const int nstx, const int nsty,
+            const int N, const int nst0x, int *__restrict__ c_count /* zeroed */,
+            int32_t *__restrict__ c_id /* [B*nst0][N] */) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int region = blockIdx.x / kBin0Split, part = blockIdx.x - region * kBin0Split, b = blockIdx.y;
+  const int stx = region % nst0x, sty = region / nst0x;
+  constexpr int kCh = kST0 / kST;   // children per side
+  const int cx0 = stx * kCh, cy0 = sty * kCh;
+  const Cone cone = compose_cones(cones + (size_t)b * nstx * nsty, nstx, cx0, cy0, min(kCh, nstx - cx0), min(kCh, nsty - cy0));
+  const int nreg = gridDim.x / kBin0Split;
+  int *cnt = c_count + (size_t)b * nreg + region;
+  int32_t *out = c_id + ((size_t)b * nreg + region) * N;
+  const float4 *cullb = cull + (size_t)b * N;
+  const int per = (N + kBin0Split - 1) / kBin0Split;
+  const int g0 = part * per, g1 = min(N, g0 + per);
+  // Rounds of up to 32 candidates per thread: test them (keep flags in one register, 8 loads in
+  // flight), reserve the round's output range with ONE global atomic per workgroup, then write
+  // the ids wave by wave.  (One atomic per wave-ballot on the region counter serialises in L2.)
+  __shared__ int wtot[kBinThreads / 64];
+  __shared__ int wg_base;
+  const int wave = tid >> 6;
+  constexpr int kRound = 32, kU = 8;
+  for (int r0 = g0; r0 < g1; r0 += kRound * kBinThreads) {
+    unsigned flags = 0;
+    int wcount = 0;   // wave-uniform
+#pragma unroll
+    for (int q0 = 0; q0 < kRound; q0 += kU) {
+      if (r0 + q0 * kBinThreads >= g1) break;   // uniform
+      float4 c[kU];
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        const int g = r0 + (q0 + q) * kBinThreads + tid;
+        c[q] = (g < g1) ? cullb[g] : make_float4(0.f, 0.f, 0.f, -1.f);
+      }
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        const bool keep = cone_keep(c[q], cone);
+        flags |= keep ? (1u << (q0 + q)) : 0u;
+        wcount += __popcll(__ballot(keep));
+      }
+    }
+    __syncthreads();   // previous round's wtot / wg_base fully consumed
+    if (lane == 0) wtot[wave] = wcount;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < kBinThreads / 64; ++w) t += wtot[w];
+      wg_base = (t > 0) ? atomicAdd(cnt, t) : 0;
+    }
+    __syncthreads();
+    int off = wg_base;
+    for (int w = 0; w < wave; ++w) off += wtot[w];
+    for (int q = 0; q < kRound; ++q) {
+      if (r0 + q * kBinThreads >= g1) break;   // uniform
+      const bool keep = (flags >> q) & 1u;
+      const unsigned long long m = __ballot(keep);
+      if (keep) out[off + __popcll(m & ((1ull << lane) - 1ull))] = r0 + q * kBinThreads + tid;
+      off += __popcll(m);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBinThreads)
+bin_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, const int *__restrict__ c_count,
+           const int32_t *__restrict__ c_id, const int nst0x, const int nst0, const int N, const int H,
            const int W, const int nstx, int *__restrict__ bin_count, int32_t *__restrict__ bin_id,
            float *__restrict__ bin_lb) {
   __shared__ BinLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int stx = blockIdx.x % nstx, sty = blockIdx.x / nstx, b = blockIdx.y;
   const int x0 = stx * kST, y0 = sty * kST;
-  const int rw = min(kST, W - x0), rh = min(kST, H - y0);
-  const int npx = rw * rh;
-  // ---- cone of the super-tile's rays ----
-  float sx = 0.f, sy = 0.f, sz = 0.f, okf = 1.f;
-  for (int i = tid; i < npx; i += kBinThreads) {
-    const int y = i / rw, x = i - y * rw;
-    const float *r = rays + (((size_t)b * H + y0 + y) * W + x0 + x) * 3;
-    const RayDir u = ray_dir(r[0], r[1], r[2]);
-    if (u.ok) { sx += u.ux; sy += u.uy; sz += u.uz; } else okf = 0.f;
-  }
-  block_reduce16(L.red, wave, lane, sx, sy, sz, okf, 0);
-  const float n = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
-  const float ax = sx / n, ay = sy / n, az = sz / n;
-  float smax = 0.f, cmin = 1.f, dummy = 0.f, okf2 = 1.f;
-  for (int i = tid; i < npx; i += kBinThreads) {
-    const int y = i / rw, x = i - y * rw;
-    const float *r = rays + (((size_t)b * H + y0 + y) * W + x0 + x) * 3;
-    cone_partial(ray_dir(r[0], r[1], r[2]), ax, ay, az, smax, cmin);
-  }
-  block_reduce16(L.red, wave, lane, smax, cmin, dummy, okf2, 1);
-  const Cone cone = cone_finish(ax, ay, az, n, smax, cmin, okf != 0.f);
+  const Cone cone = load_cone(cones[(size_t)b * gridDim.x + blockIdx.x]);
 
   // ---- scan all Gaussians of this batch element, keep (bound, id) of the survivors ----
   if (tid == 0) L.count = 0;
@@ -211,17 +381,24 @@ bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, cons
   const float4 *cullb = cull + (size_t)b * N;
   float rmax = 0.0f;   // largest finite reach among this thread's survivors
   constexpr int kScanU = 8;
-  for (int base = 0; base < N; base += kScanU * kBinThreads) {
-    // eight independent 16-byte loads in flight per lane: the scan is latency-, not compute-bound
+  // candidates: the parent region's list, or (small problems, no coarse level) every Gaussian
+  const int parent = b * nst0 + (y0 / kST0) * nst0x + x0 / kST0;
+  const int n_src = (c_count != nullptr) ? c_count[parent] : N;
+  const int32_t *src = (c_count != nullptr) ? c_id + (size_t)parent * N : nullptr;
+  for (int base = 0; base < n_src; base += kScanU * kBinThreads) {
+    // eight independent gathers in flight per lane: the scan is latency-, not compute-bound
     float4 c[kScanU];
+    int gid[kScanU];
 #pragma unroll
     for (int q = 0; q < kScanU; ++q) {
-      const int g = base + q * kBinThreads + tid;
-      c[q] = (g < N) ? cullb[g] : make_float4(0.f, 0.f, 0.f, -1.f);
+      const int i = base + q * kBinThreads + tid;
+      gid[q] = (i < n_src) ? (src != nullptr ? src[i] : i) : -1;
     }
 #pragma unroll
+    for (int q = 0; q < kScanU; ++q) c[q] = (gid[q] >= 0) ? cullb[gid[q]] : make_float4(0.f, 0.f, 0.f, -1.f);
+#pragma unroll
     for (int q = 0; q < kScanU; ++q) {
-      const int g = base + q * kBinThreads + tid;
+      const int g = gid[q];
       const bool keep = cone_keep(c[q], cone);
       if (keep && c[q].w < 3e38f) rmax = fmaxf(rmax, c[q].w);
       const unsigned long long m = __ballot(keep);
@@ -290,6 +467,7 @@ bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, cons
     L.sorted[atomicAdd(&L.hist[q], 1)] = k;
   }
   __syncthreads();
+#ifdef VOGE_BIN_FULLSORT
   {  // thread q orders bucket q (keys are unique: the id is in the low word)
     const int s0 = L.start[tid], s1 = L.start[tid + 1];
     for (int i = s0 + 1; i < s1; ++i) {
@@ -300,14 +478,26 @@ bin_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, cons
     }
   }
   __syncthreads();
+#endif
+  // Entries are ordered by BUCKET only (1022 buckets over the bin's depth range, i.e. a few
+  // thousandths of a scene unit each -- far finer than the reach that separates kappa from the
+  // actual len), and every entry carries its bucket's lower edge as the len bound: monotone along
+  // the list, which is all the sweep's early exit needs.  The order inside a bucket is whatever
+  // the LDS atomics produced; the sweep's top-K is order independent.
   int32_t *oid = bin_id + (size_t)bin * kBinCap;
   float *olb = bin_lb + (size_t)bin * kBinCap;
   const float slack = 1.13f * rm * (1.0f + 1e-5f);
+  const float inv_scale = span / (float)(kBuckets - 2);
   for (int i = tid; i < total; i += kBinThreads) {
     const uint64_t k = L.sorted[i];
     const float v = ord2f((uint32_t)(k >> 32));
+    float edge = -INFINITY;
+    if (v > -INFINITY) {
+      const int q = min(kBuckets - 2, max(0, (int)((v - lo) * scale)));
+      edge = fminf(v, lo + (float)q * inv_scale - 4e-6f * span);
+    }
     oid[i] = (int32_t)(uint32_t)k;
-    olb[i] = (v > -INFINITY) ? v - slack - 1e-5f * fabsf(v) - 1e-30f : -INFINITY;
+    olb[i] = (edge > -INFINITY) ? edge - slack - 1e-5f * fabsf(edge) - 1e-30f : -INFINITY;
   }
   if (tid == 0) bin_count[bin] = total;
 }
@@ -912,7 +1102,10 @@ struct TraceWs {
   int *tl_count;
   int32_t *tl_id;
   float *tl_lb;
-  int nstx, nsty;
+  int *c_count;        // coarse regions (bin0)
+  int32_t *c_id;
+  ConeRec *cones;      // per super-tile
+  int nstx, nsty, nst0x, nst0y;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -929,7 +1122,13 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
   char *c = take(P * 16), *e = take(P * 48), *m4 = take(P * 16), *bc = take(nbin * 4), *bi = take(nbin * kBinCap * 4),
        *bl = take(nbin * kBinCap * 4), *tc = take(ntile * 4), *ti = take(ntile * kTileCap * 4),
        *tl = take(ntile * kTileCap * 4);
+  const int nst0x = (W + kST0 - 1) / kST0, nst0y = (H + kST0 - 1) / kST0;
+  const size_t nreg = (size_t)B * nst0x * nst0y;
+  char *cc = take(nreg * 4), *ci = take(nreg * (size_t)N * 4), *cn = take(nbin * sizeof(ConeRec));
   if (ws) {
+    ws->c_count = reinterpret_cast<int *>(cc); ws->c_id = reinterpret_cast<int32_t *>(ci);
+    ws->cones = reinterpret_cast<ConeRec *>(cn);
+    ws->nst0x = nst0x; ws->nst0y = nst0y;
     ws->tl_count = reinterpret_cast<int *>(tc); ws->tl_id = reinterpret_cast<int32_t *>(ti);
     ws->tl_lb = reinterpret_cast<float *>(tl);
     ws->cull = reinterpret_cast<float4 *>(c); ws->evr = reinterpret_cast<float4 *>(e);
@@ -1007,25 +1206,32 @@ extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const
     int rc = launch_status();
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(bin_kernel, dim3(ws.nstx * ws.nsty, B), dim3(kBinThreads), 0, st, ws.cull, rays, N, H, W,
-                     ws.nstx, ws.bin_count, ws.bin_id, ws.bin_lb);
+  // The coarse level pays off once the per-super-tile scans of all N dominate (nst * N tests);
+  // tiny problems skip its two launches.
+  const bool coarse = (size_t)ws.nstx * ws.nsty * (size_t)N >= ((size_t)1 << 21);
+  hipLaunchKernelGGL(bincone_kernel, dim3(ws.nstx * ws.nsty, B), dim3(kBinThreads), 0, st, rays, H, W, ws.nstx, ws.cones);
+  if (coarse) {
+    hipError_t e = hipMemsetAsync(ws.c_count, 0, sizeof(int) * (size_t)B * ws.nst0x * ws.nst0y, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bin0_kernel, dim3(ws.nst0x * ws.nst0y * kBin0Split, B), dim3(kBinThreads), 0, st, ws.cull, ws.cones,
+                       ws.nstx, ws.nsty, N, ws.nst0x, ws.c_count, ws.c_id);
+  }
+  hipLaunchKernelGGL(bin_kernel, dim3(ws.nstx * ws.nsty, B), dim3(kBinThreads), 0, st, ws.cull, ws.cones,
+                     coarse ? ws.c_count : nullptr, ws.c_id, ws.nst0x, ws.nst0x * ws.nst0y, N, H, W, ws.nstx, ws.bin_count,
+                     ws.bin_id, ws.bin_lb);
   {
     int rc = launch_status();
     if (rc) return rc;
   }
-  // largest tile whose LDS footprint still lets two workgroups share a CU; else whatever fits
-  auto fits = [&](int waves, size_t budget) {
-    const size_t fixed = waves == 4 ? sizeof(TraceLds<256>) : waves == 2 ? sizeof(TraceLds<128>) : sizeof(TraceLds<64>);
-    return sizeof(uint64_t) * (size_t)(K + 1) * (64 * waves + 1) + 16 + fixed <= budget;
-  };
-  const size_t two_per_cu = 80 * 1024, one_per_cu = 160 * 1024;
+  // One wave (an 8x8 pixel tile) per workgroup.  Residency is set by the LDS top-K lists either
+  // way (~6 waves per CU at K = 40), and independent single-wave workgroups measured 4-10 % faster
+  // than 16x8 / 16x16 tiles on all three BASELINE configs (no barriers, finer load balance,
+  // tighter per-tile candidate lists).  The multi-wave instantiations remain for experiments.
 #ifdef VOGE_FORCE_WAVES
   return launch_trace<VOGE_FORCE_WAVES>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
 #endif
-  if (fits(4, two_per_cu)) return launch_trace<4>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
-  if (fits(2, two_per_cu)) return launch_trace<2>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
-  if (fits(1, two_per_cu)) return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
-  if (fits(1, one_per_cu)) return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
+  if (sizeof(uint64_t) * (size_t)(K + 1) * 65 + 16 + sizeof(TraceLds<64>) <= 160 * 1024)
+    return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
   return VOGE_ERR_K_TOO_LARGE;
 }
 
