@@ -625,8 +625,9 @@ constexpr int kTrip = VOGE_TRIP;   // candidates evaluated per trip of the sweep
 template <int T>
 struct TraceLds {
   // layout inside dynamic LDS, after the [K][T+1] key array
-  float4 cull[T];
-  float4 ev[T * 3];
+  float4 cull[T > 64 ? T : 1];   // (mu, reach): the per-wave re-test of multi-wave tiles only
+  float4 ms[T];         // (mu, s00 | NaN): all an isotropic evaluation needs
+  float4 ev[T * 3];     // full eval record, staged for anisotropic candidates only
   int32_t id[T];
   float lb[T];
   float red[4 * 8];
@@ -727,6 +728,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   auto load_id = [&](int g) { return (g < src_n) ? (binned ? src_id[g] : g) : -1; };
   auto load_lb = [&](int g) { return (binned && g < src_n) ? src_lb[g] : -INFINITY; };
   auto load_rec = [&](int id) { return (id >= 0) ? cullb[id] : cull_none; };
+  const float4 *msb = ms + (size_t)b * N;
+  auto load_ms = [&](int id) { return (id >= 0) ? msb[id] : cull_none; };
+  // the tile's own list was already filtered with this tile's cone (bin2): no second test
+  const bool prefiltered = (WAVES == 1) && (tc >= 0);
 
   uint64_t *mykeys = keys + tid;
   int cnt = 0;
@@ -737,10 +742,11 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 #endif
 
   int base = 0, par = 0;
-  // two-deep software pipeline: ids two chunks ahead, cull records one chunk ahead
+  // two-deep software pipeline: ids two chunks ahead, cull / ms records one chunk ahead
   int id0 = load_id(tid);
   float lb0 = load_lb(tid);
-  float4 c0r = load_rec(id0);
+  float4 c0r = prefiltered ? cull_none : load_rec(id0);
+  float4 m0r = load_ms(id0);
   int id1 = load_id(T + tid);
   float lb1 = load_lb(T + tid);
   while (base < src_n) {
@@ -752,11 +758,13 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       const int id = id0;
       const float lbv = lb0;
       const float4 c = c0r;
+      const float4 mrec = m0r;
       id0 = id1; lb0 = lb1;
-      c0r = load_rec(id0);
+      c0r = prefiltered ? cull_none : load_rec(id0);
+      m0r = load_ms(id0);
       id1 = load_id(base + 2 * T + tid);
       lb1 = load_lb(base + 2 * T + tid);
-      const bool keep = cone_keep(c, gcone);
+      const bool keep = prefiltered ? (id >= 0) : cone_keep(c, gcone);
       const unsigned long long m = __ballot(keep);
       if (lane == 0) L.wcnt[par][wave] = __popcll(m);
       __syncthreads();
@@ -769,12 +777,15 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       }
       if (keep) {
         const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
-        L.cull[slot] = c;
+        if (WAVES > 1) L.cull[slot] = c;
+        L.ms[slot] = mrec;
         L.id[slot] = id;
         L.lb[slot] = lbv;
-        L.ev[slot * 3 + 0] = evrb[(size_t)id * 3 + 0];
-        L.ev[slot * 3 + 1] = evrb[(size_t)id * 3 + 1];
-        L.ev[slot * 3 + 2] = evrb[(size_t)id * 3 + 2];
+        if (!(mrec.w == mrec.w)) {   // anisotropic: the full record (dependent gather, not prefetched)
+          L.ev[slot * 3 + 0] = evrb[(size_t)id * 3 + 0];
+          L.ev[slot * 3 + 1] = evrb[(size_t)id * 3 + 1];
+          L.ev[slot * 3 + 2] = evrb[(size_t)id * 3 + 2];
+        }
       }
       nbuf += tot;
       base += T;
@@ -848,22 +859,24 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
           PairOut o[kTrip];
           float4 cc[kTrip], e0[kTrip];
           bool iso = true, any_iso = false;
+          bool fiso[kTrip];
 #pragma unroll
           for (int q = 0; q < kTrip; ++q) {
-            cc[q] = L.cull[sq[q]];
-            e0[q] = L.ev[sq[q] * 3];
-            const bool f = __builtin_amdgcn_readfirstlane(__float_as_uint(e0[q].w)) == kIsoFlag;
+            cc[q] = L.ms[sq[q]];
+            const bool f = fiso[q] = (__builtin_amdgcn_readfirstlane(__float_as_uint(cc[q].w)) & 0x7fffffffu) <= 0x7f800000u;
             iso = iso && f;
             any_iso = any_iso || f;
           }
           if (iso) {
 #pragma unroll
             for (int q = 0; q < kTrip; ++q)
-              o[q] = pair_eval_iso(cc[q].x, cc[q].y, cc[q].z, e0[q].x, dx, dy, dz, qxx, qyy, qzz);
+              o[q] = pair_eval_iso(cc[q].x, cc[q].y, cc[q].z, cc[q].w, dx, dy, dz, qxx, qyy, qzz);
           } else {
             float4 e1[kTrip], e2[kTrip];
 #pragma unroll
-            for (int q = 0; q < kTrip; ++q) { e1[q] = L.ev[sq[q] * 3 + 1]; e2[q] = L.ev[sq[q] * 3 + 2]; }
+            for (int q = 0; q < kTrip; ++q) {
+              e0[q] = L.ev[sq[q] * 3]; e1[q] = L.ev[sq[q] * 3 + 1]; e2[q] = L.ev[sq[q] * 3 + 2];
+            }
             if (!any_iso) {
 #pragma unroll
               for (int q = 0; q < kTrip; ++q)
@@ -871,9 +884,13 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
                                      qzz, qxy, qxz, qyz);
             } else {  // mixed batch: per-candidate dispatch (same arithmetic, just not interleaved)
 #pragma unroll
-              for (int q = 0; q < kTrip; ++q)
-                o[q] = pair_eval(cc[q].x, cc[q].y, cc[q].z, unpack_eval(e0[q], e1[q], e2[q]), dx, dy, dz, qxx, qyy, qzz,
-                                 qxy, qxz, qyz);
+              for (int q = 0; q < kTrip; ++q) {
+                if (fiso[q])   // uniform: the flag came through readfirstlane
+                  o[q] = pair_eval_iso(cc[q].x, cc[q].y, cc[q].z, cc[q].w, dx, dy, dz, qxx, qyy, qzz);
+                else
+                  o[q] = pair_eval_gen(cc[q].x, cc[q].y, cc[q].z, unpack_eval(e0[q], e1[q], e2[q]), dx, dy, dz, qxx, qyy,
+                                       qzz, qxy, qxz, qyz);
+              }
             }
           }
 #pragma unroll
