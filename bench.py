@@ -40,16 +40,18 @@ def parse():
     return ap.parse_args()
 
 
-def stage_bytes(P, npix, K, C=3):
-    """ALGORITHMIC HBM bytes per launch of each stage, fp32/int32."""
+def stage_bytes(P, npix, K, C=3, iso=False):
+    """ALGORITHMIC HBM bytes per launch of each stage, fp32/int32.  iso: the Gaussians
+    enter as (mu, a) = 16 bytes instead of (mu, A) = 48."""
+    g = 16 if iso else 48
     return {
-        "trace_fwd": P * 48 + npix * 12 + npix * K * 16,
+        "trace_fwd": P * g + npix * 12 + npix * K * 16,
         "composite_fwd": npix * K * 12 + npix * K * 4 + npix * 8,
         # fused merge+silhouette+blend: read idx,w + colours, write rgb,img / read idx,w,rgb,g_img, write g_w,g_col
         "shade_fwd": npix * K * 8 + P * 4 * C + 2 * npix * 4 * C,
         "shade_bwd": npix * K * 8 + 2 * npix * 4 * C + P * 4 * C + npix * K * 4 + P * 4 * C,
-        "composite_bwd": npix * K * (12 + 4) + npix * K * 12,
-        "trace_bwd": npix * K * 16 + npix * 12 + P * 48 + npix * 12 + P * 48,
+        "composite_bwd": npix * K * (12 + 4 + 4) + npix * K * 12,      # act,len,dsd + weight + g_weight -> 3 grads
+        "trace_bwd": npix * K * 16 + npix * 12 + P * g + npix * 12 + P * g,
     }
 
 
@@ -181,9 +183,13 @@ def main():
             from voge_amd.Aggregation import expend_sigma
             rays, origin = pixel_rays(cams, (H, W))
             mus = (gm.verts[None] - origin[:, None]).reshape(-1, 3).contiguous()
-            isg = (2 * expend_sigma(gm.sigmas)).contiguous()
+            iso = gm.sigmas.dim() == 1     # the renderer keeps (N,) sigmas in scalar form (A = a I)
+            isg = (2 * gm.sigmas).contiguous() if iso else (2 * expend_sigma(gm.sigmas)).contiguous()
             thr_act = -np.log(0.01 + 1e-10)
-            sel = ops.ray_trace_fine(mus, isg, rays, None, thr_act, 16, K)
+            if iso:
+                sel = ops._RayTraceVoGEIso.apply(mus, isg, rays, None, thr_act, K)
+            else:
+                sel = ops.ray_trace_fine(mus, isg, rays, None, thr_act, 16, K)
             w, vn = ops.composite(sel[0], sel[2], sel[1], sel[3], 1.0)
             idx = sel[0].clone()
             vn32 = vn.to(torch.int32).contiguous()
@@ -195,6 +201,8 @@ def main():
             npix = H * W
             ws = torch.empty(lib.voge_trace_workspace_bytes(1, N, H, W), dtype=torch.uint8, device=dev)
             ws_b = torch.empty(lib.voge_trace_bwd_workspace_bytes(N), dtype=torch.uint8, device=dev)
+            trace_fwd_fn = lib.voge_trace_topk_fwd_iso if iso else lib.voge_trace_topk_fwd
+            trace_bwd_fn = lib.voge_trace_bwd_iso if iso else lib.voge_trace_bwd
             o_i, o_l, o_a, o_d = (torch.empty_like(x) for x in sel)
             o_c = torch.empty((1, H, W), dtype=torch.int32, device=dev)
             g3 = [torch.empty_like(w) for _ in range(3)]
@@ -204,7 +212,7 @@ def main():
             wsum = torch.empty(rgb.shape[:-1], dtype=torch.float32, device=rgb.device)
             P = lambda x: x.data_ptr()
             calls = {
-                "trace_fwd": lambda: lib.voge_trace_topk_fwd(P(mus), P(isg), P(rays), None, 1, N, H, W, K, thr_act, P(ws),
+                "trace_fwd": lambda: trace_fwd_fn(P(mus), P(isg), P(rays), None, 1, N, H, W, K, thr_act, P(ws),
                                                              ws.numel(), P(o_i), P(o_l), P(o_a), P(o_d), P(o_c), st),
                 "composite_fwd": lambda: lib.voge_composite_fwd(P(sel[0]), P(sel[2]), P(sel[1]), P(sel[3]), 1.0, npix, K,
                                                                 P(g3[0]), P(vn), st),
@@ -214,10 +222,10 @@ def main():
                                                         3, N, P(g_attr), P(g3[0]), st),
                 "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), P(g_w), 1.0, npix, K, P(g3[0]),
                                                                 P(g3[1]), P(g3[2]), st),
-                "trace_bwd": lambda: lib.voge_trace_bwd(P(mus), P(isg), P(rays), P(sel[0]), P(vn32), P(w), P(w), P(w), N, H, W, K,
+                "trace_bwd": lambda: trace_bwd_fn(P(mus), P(isg), P(rays), P(sel[0]), P(vn32), P(w), P(w), P(w), N, H, W, K,
                                                         P(ws_b), ws_b.numel(), None, P(g_mu), P(g_A), st),
             }
-            nbytes = stage_bytes(N, npix, K)
+            nbytes = stage_bytes(N, npix, K, iso=iso)
             stages = {}
             for name, fn in calls.items():
                 t_ms = time_kernel(fn)

@@ -115,6 +115,25 @@ int voge_trace_bwd(const float *mus, const float *isigmas, const float *rays,
 size_t voge_trace_bwd_workspace_bytes(int P);
 
 /*
+ * Isotropic variants of the two calls above: every Gaussian is A = a I with ONE scalar a [P]
+ * (the reference's (N,) sigma form: expend_sigma, Aggregation.py:155-157, then 2*sigma,
+ * Renderer.py:133).  Same outputs as voge_trace_topk_fwd; the backward returns g_a [P], the
+ * gradient of that scalar (= trace of the general call's g_isg), and g_mus [P,3].  Four sums per
+ * Gaussian instead of twelve, and the caller's scalar -> 3x3 expansion (and its backward)
+ * disappears.  workspace of the backward: >= voge_trace_bwd_iso_workspace_bytes(P).
+ */
+int voge_trace_topk_fwd_iso(const float *mus, const float *a, const float *rays,
+                            const float *cam_fwd, int B, int N, int H, int W, int K,
+                            float thr_act, void *workspace, size_t workspace_bytes,
+                            int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
+                            voge_stream_t stream);
+int voge_trace_bwd_iso(const float *mus, const float *a, const float *rays, const int32_t *idx,
+                       const int32_t *cnt, const float *g_len, const float *g_act, const float *g_dsd,
+                       int P, long nrows, int W, int K, void *workspace, size_t workspace_bytes,
+                       float *g_ray, float *g_mus, float *g_a, voge_stream_t stream);
+size_t voge_trace_bwd_iso_workspace_bytes(int P);
+
+/*
  * Composite forward.  Replaces: VoGE/Aggregation.py:82-107 `aggregation`
  * (get_cross_activation :30-51 + assign2weight :54-79), without any [npix,K,K] temporary.
  *   w_m = exp(-occ * sum_k exp(-act_k) * (erf((len_m-len_k)*sqrt(dsd_k+1e-10)) + 1)/2)

@@ -184,6 +184,33 @@ def test_trace_bwd_vs_oracle(hip_lib, aniso):
         assert err <= TOL * max(1.0, np.abs(ref).max()), f"{name}: {err:.3e} vs scale {np.abs(ref).max():.3e}"
 
 
+def test_trace_iso_scalar_form_vs_oracle(hip_lib):
+    """Isotropic Gaussians kept as one scalar each (the (N,) sigma form): forward equals the
+    general trace on a*I, the backward returns d/da = trace(g_A) and the same g_mus / g_ray."""
+    from voge_amd import ops
+    verts, sig, _ = random_scene(600, seed=33, lo=0.06, hi=0.15)            # sig: (N,) scalars
+    assert sig.ndim == 1
+    H, W, K, B = 40, 56, 14, 2
+    sc = dict(verts=verts, sigmas=sig, focal=45.0, principal=(28.0, 20.0), image_size=(H, W), dist=3.2, elev=-10.0, azim=30.0)
+    mus, isg, rays, _, _ = camera_inputs(sc, B=B)                             # isg = 2 * sig * I, [B,N,3,3]
+    a = np.ascontiguousarray(isg[..., 0, 0])                                  # [B,N]
+    thr_act = oracle.thr_act_of(0.01)
+    tm, ta, tr = t(mus.reshape(-1, 3), rg=True), t(a.reshape(-1), rg=True), t(rays, rg=True)
+    idx, ln, act, dsd = ops._RayTraceVoGEIso.apply(tm, ta, tr, None, thr_act, K)
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    compare_trace([n(x) for x in (idx, ln, act, dsd)], ref, thr_act, min_match=0.995)
+    rng = np.random.default_rng(5)
+    valid = n(idx) >= 0
+    gl, ga, gd = (rng.normal(size=idx.shape) * valid for _ in range(3))
+    gd = gd * 1e-3
+    (ln * t(gl) + act * t(ga) + dsd * t(gd)).sum().backward()
+    g_ray, g_mu, g_A = oracle.trace_bwd(mus, isg, rays, n(idx), gl, ga, gd)
+    g_a = np.einsum("nii->n", g_A.reshape(-1, 3, 3))
+    for name, got, want in (("mus", tm.grad, g_mu), ("a", ta.grad, g_a), ("rays", tr.grad, g_ray)):
+        err = np.abs(n(got).astype(np.float64).reshape(want.shape) - want).max()
+        assert err <= TOL * max(1.0, np.abs(want).max()), f"{name}: {err:.3e} vs scale {np.abs(want).max():.3e}"
+
+
 # ------------------------------------------------------------------------------- composite
 @pytest.mark.parametrize("name", ["k5", "k25", "k40"])
 def test_composite_golden(hip_lib, name):

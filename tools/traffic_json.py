@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""profiles/r1_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
+as MI355X_MICROARCH.md's HBM section prescribes).  usage: traffic_json.py <fetch_dir> <write_dir> <out.json>
+Units: counters are KiB; FETCH_SIZE x2 on gfx950 for wide coalesced reads (same guide); per launch averages."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+TRACE_FWD = ("prep_kernel", "bincone_kernel", "bin0_kernel", "bin_kernel", "bin2_kernel", "trace_fwd_kernel")
+
+
+def collect(d, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "voge::" not in k or r["Counter_Name"] != counter:
+                continue
+            k = k.split("(")[0].replace("void ", "").replace("voge::", "")
+            acc[k].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main(fetch_dir, write_dir, out):
+    fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fe) | set(wr)):
+        f, w = fe.get(k, 0.0), wr.get(k, 0.0)
+        kernels[k] = {"fetch_KiB_raw": round(f), "write_KiB": round(w), "hbm_bytes": int((2 * f + w) * 1024)}
+    total = sum(v["hbm_bytes"] for k, v in kernels.items() if k.split("<")[0] in TRACE_FWD)
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --no-graph (cfg3). "
+                       "Units KiB per launch; hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of "
+                       "MI355X_MICROARCH.md's HBM section).",
+               "kernels": kernels, "voge_trace_topk_fwd_kernels": list(TRACE_FWD),
+               "voge_trace_topk_fwd_bytes": total}, open(out, "w"), indent=1)
+    print("voge_trace_topk_fwd_bytes", total)
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])

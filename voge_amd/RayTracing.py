@@ -18,7 +18,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .ops import _FindNearestK, _RayTraceVoGE, _RayTraceVoGERay
+from .ops import _FindNearestK, _RayTraceVoGE, _RayTraceVoGEIso, _RayTraceVoGERay
 
 inf = 1e8
 
@@ -42,6 +42,19 @@ def ray_tracing(transforms, points, isigmas, rays, image_size, thr: float, n_ass
         candidates = _view_axis(transforms, points)
     return ray_tracing_fine(points.reshape(-1, 3), isigmas.reshape(-1, 3, 3), rays, candidates, thr, bin_size,
                             n_assign)
+
+
+def ray_tracing_iso(transforms, points, a, rays, image_size, thr: float, n_assign: int,
+                    max_points_per_bin: Optional[int] = None, inf=1e10, **kwargs):
+    """ray_tracing for isotropic Gaussians kept in scalar form: points [B,N,3] camera-centred,
+    a [N] (shared by the batch) or [B,N] with A = a I.  Same outputs as ray_tracing(points,
+    a[..., None, None] * eye(3), ...); the gradient reaches `a` directly."""
+    B, N = points.shape[0], points.shape[1]
+    if a.dim() == 1:
+        a = a.unsqueeze(0).expand(B, -1)
+    candidates = None if max_points_per_bin == -1 else _view_axis(transforms, points)
+    thr_act = -math.log(thr + 1 / inf)
+    return _RayTraceVoGEIso.apply(points.reshape(-1, 3), a.reshape(-1), rays, candidates, thr_act, n_assign)
 
 
 def _view_axis(cameras, points):

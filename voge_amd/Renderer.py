@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import ops
 from .Aggregation import aggregation, expend_sigma, merge_final
-from .RayTracing import ray_tracing
+from .RayTracing import ray_tracing, ray_tracing_iso
 from .cameras import pixel_rays
 
 
@@ -106,19 +106,27 @@ class GaussianRenderer(nn.Module):
         image_size = st['image_size']
 
         verts, sigmas, _radians = gmeshes()
-        sigmas = expend_sigma(sigmas)
         if verts.dim() == 2:
             verts = verts[None]
 
         rays, origin = pixel_rays(cams, image_size, rows=kwargs.get('rows'))     # [B,h,W,3], [B,3]
         centred = verts - origin[:, None]                                         # Renderer.py:130
-        if sigmas.dim() == 3:
-            sigmas = sigmas.unsqueeze(0).expand(centred.shape[0], -1, -1, -1)
-        isigma = 2 * torch.inverse(sigmas) if st['inverse_sigma'] else 2 * sigmas
-
-        sel_idx, sel_len, sel_act, sel_dsd = ray_tracing(
-            cams, centred, isigma, rays, image_size, thr=st['thr_activation'], n_assign=st['max_assign'],
-            max_points_per_bin=st['max_point_per_bin'])
+        if sigmas.dim() == 1:
+            # (N,) sigmas are isotropic: expend_sigma would give sigma * I (Aggregation.py:155-157) and
+            # Renderer.py:133 doubles (or inverts and doubles) it.  Keep the scalar: the trace has an
+            # isotropic form whose backward produces d/d(scalar) directly.
+            a = 2.0 / sigmas if st['inverse_sigma'] else 2.0 * sigmas
+            sel_idx, sel_len, sel_act, sel_dsd = ray_tracing_iso(
+                cams, centred, a, rays, image_size, thr=st['thr_activation'], n_assign=st['max_assign'],
+                max_points_per_bin=st['max_point_per_bin'])
+        else:
+            sigmas = expend_sigma(sigmas)
+            if sigmas.dim() == 3:
+                sigmas = sigmas.unsqueeze(0).expand(centred.shape[0], -1, -1, -1)
+            isigma = 2 * torch.inverse(sigmas) if st['inverse_sigma'] else 2 * sigmas
+            sel_idx, sel_len, sel_act, sel_dsd = ray_tracing(
+                cams, centred, isigma, rays, image_size, thr=st['thr_activation'], n_assign=st['max_assign'],
+                max_points_per_bin=st['max_point_per_bin'])
         # merge_final later rewrites -1 -> 0 inside the fragments' index tensor.  The reference clones
         # it here (Renderer.py:145) because its backward finds empty slots by idx == -1; this trace
         # backward uses the per-pixel hit count instead, so no copy is needed.

@@ -235,9 +235,11 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
 // mus [P,3] + isigmas [P,9] -> 3 x float4 per Gaussian, so the sweep gathers with dwordx4 loads
 __global__ void __launch_bounds__(256)
 bwd_pack_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const int P,
-                float4 *__restrict__ rec) {
+                float4 *__restrict__ rec, float4 *__restrict__ acc /* [P][4] float4, zeroed here */) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= P) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[4 * (size_t)g + q] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float *m = mus + 3 * (size_t)g, *A = isg + 9 * (size_t)g;
   rec[3 * (size_t)g + 0] = make_float4(m[0], m[1], m[2], A[0]);
   rec[3 * (size_t)g + 1] = make_float4(A[1], A[2], A[3], A[4]);
@@ -254,7 +256,184 @@ bwd_unpack_kernel(const float *__restrict__ acc, const int P, float *__restrict_
   if (c < 3) g_mus[3 * (size_t)g + c] = v; else g_isg[9 * (size_t)g + (c - 3)] = v;
 }
 
+// ------------------------------------------------------------------------------------------
+// Isotropic Gaussians, A = a I with ONE scalar a per Gaussian (the reference's (N,) sigma form,
+// Aggregation.py:155-157 / Cuboid.py:51-52).  len = mu.d/|d|^2, v = mu - len d, act = a |v|^2,
+// dsd = a |d|^2, so per slot
+//   g_mu  = g_len d/|d|^2 + 2 a g_act v ,      g_a = g_act |v|^2 + g_dsd |d|^2 ,
+//   g_ray = g_len (mu - 2 len d)/|d|^2 - 2 a len g_act v + 2 a g_dsd d .
+// Four sums per Gaussian instead of twelve: one float4 per table entry (a third of the LDS, of
+// the flush atomics and of the arithmetic of the general kernel); the caller gets the gradient
+// of the scalar directly instead of a 3x3 block it would reduce again.
+// ------------------------------------------------------------------------------------------
+#ifndef VOGE_BWDI_NE
+#define VOGE_BWDI_NE 256
+#endif
+#ifndef VOGE_BWDI_WAVES
+#define VOGE_BWDI_WAVES 2
+#endif
+#ifndef VOGE_BWDI_U
+#define VOGE_BWDI_U 2
+#endif
+constexpr int kBwdINE = VOGE_BWDI_NE, kBwdIWaves = VOGE_BWDI_WAVES, kBwdIU = VOGE_BWDI_U;
+
+struct BwdIsoLds {
+  WaveTable<kBwdINE, 1> tab;   // key = Gaussian index, value = (g_mu, g_a)
+  float ray[8 * kBwdTH * 3];
+  int cntv[64];
+};
+
+__global__ void __launch_bounds__(64 * kBwdIWaves)
+trace_bwd_iso_kernel(const float4 *__restrict__ rec /* (mu, a) */, const float *__restrict__ rays,
+                     const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt,
+                     const float *__restrict__ g_len, const float *__restrict__ g_act,
+                     const float *__restrict__ g_dsd, const int P, const long nrows, const int W, const int K,
+                     float *__restrict__ g_ray, float *__restrict__ acc /* [P][4] */) {
+  __shared__ BwdIsoLds Ls[kBwdIWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  BwdIsoLds &L = Ls[wave];
+  const int tiles_x = (W + 7) / 8;
+  const long ntiles = (long)tiles_x * ((nrows + kBwdTH - 1) / kBwdTH);
+  const long tile = (long)blockIdx.x * kBwdIWaves + wave;
+  if (tile >= ntiles) return;  // waves never synchronise with each other
+  const int x0 = (int)(tile % tiles_x) * 8;
+  const long y0 = (tile / tiles_x) * kBwdTH;
+  const int tw = min(8, W - x0);
+  const int th = (int)min((long)kBwdTH, nrows - y0);
+  {
+    const int lx = lane & 7, ly = lane >> 3;
+    int c = 0;
+    if (lx < tw && ly < th) c = (cnt != nullptr) ? min(K, max(0, cnt[(y0 + ly) * W + x0 + lx])) : K;
+    L.cntv[lane] = c;
+    if (__all(c == 0)) {
+      if (g_ray != nullptr && lx < tw && ly < th) {
+        float *o = g_ray + ((y0 + ly) * W + x0 + lx) * 3;
+        o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+      }
+      return;
+    }
+  }
+  wt_clear(L.tab, lane);
+  for (int i = lane; i < 8 * kBwdTH * 3; i += 64) L.ray[i] = 0.0f;
+  const int n_items = tw * K;
+  const int nit = (n_items + 63) >> 6;
+  const int nb = th * nit;
+  const float invK = 1.0f / (float)K;
+  for (int g0 = 0; g0 < nb; g0 += kBwdIU) {
+    int p[kBwdIU], pl[kBwdIU];
+    float gl[kBwdIU], ga[kBwdIU], gd[kBwdIU];
+#pragma unroll
+    for (int u = 0; u < kBwdIU; ++u) {
+      const int bb = g0 + u;
+      const int r = bb / nit, it = bb - r * nit;
+      const int j = it * 64 + lane;
+      const int lx = __float2int_rz(((float)j + 0.5f) * invK);
+      const int k = j - lx * K;
+      const int pq = r * 8 + lx;
+      const bool ok = (bb < nb) && (j < n_items) && (k < L.cntv[min(pq, 63)]);
+      const long pid = ((y0 + r) * W + x0) * (long)K + j;
+      p[u] = ok ? idx[pid] : -1;
+      gl[u] = ok ? g_len[pid] : 0.0f;
+      ga[u] = ok ? g_act[pid] : 0.0f;
+      gd[u] = ok ? g_dsd[pid] : 0.0f;
+      pl[u] = ok ? pq : 64 + lane;
+    }
+    float4 rc[kBwdIU];
+    float dx[kBwdIU], dy[kBwdIU], dz[kBwdIU];
+    bool live[kBwdIU];
+#pragma unroll
+    for (int u = 0; u < kBwdIU; ++u) {
+      live[u] = (p[u] >= 0) && (p[u] < P) && !(gl[u] == 0.0f && ga[u] == 0.0f && gd[u] == 0.0f);
+      rc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dx[u] = dy[u] = dz[u] = 0.0f;
+      if (live[u]) {
+        rc[u] = rec[p[u]];
+        const float *ry = rays + ((y0 + (pl[u] >> 3)) * W + x0 + (pl[u] & 7)) * 3;
+        dx[u] = ry[0]; dy[u] = ry[1]; dz[u] = ry[2];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kBwdIU; ++u) {
+      if (g0 + u >= nb) break;   // uniform
+      float4 val[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+      float rx = 0.f, ryv = 0.f, rz = 0.f;
+      if (live[u]) {
+        const float mx = rc[u].x, my = rc[u].y, mz = rc[u].z, a = rc[u].w;
+        const float dn2 = fmaf(dz[u], dz[u], fmaf(dy[u], dy[u], dx[u] * dx[u]));
+        const float idn = __builtin_amdgcn_rcpf(dn2);
+        const float t = fmaf(mz, dz[u], fmaf(my, dy[u], mx * dx[u])) * idn;
+        const float vx = fmaf(-t, dx[u], mx), vy = fmaf(-t, dy[u], my), vz = fmaf(-t, dz[u], mz);
+        const float c1 = gl[u] * idn, c2 = 2.0f * a * ga[u];
+        val[0] = make_float4(fmaf(c1, dx[u], c2 * vx), fmaf(c1, dy[u], c2 * vy), fmaf(c1, dz[u], c2 * vz),
+                             fmaf(ga[u], fmaf(vz, vz, fmaf(vy, vy, vx * vx)), gd[u] * dn2));
+        if (g_ray != nullptr) {
+          const float c3 = 2.0f * a * gd[u], c4 = -c2 * t;
+          rx = fmaf(c3, dx[u], fmaf(c4, vx, c1 * fmaf(-2.0f * t, dx[u], mx)));
+          ryv = fmaf(c3, dy[u], fmaf(c4, vy, c1 * fmaf(-2.0f * t, dy[u], my)));
+          rz = fmaf(c3, dz[u], fmaf(c4, vz, c1 * fmaf(-2.0f * t, dz[u], mz)));
+        }
+      }
+      if (__any(live[u])) {
+        const int slot = wt_find(L.tab, p[u], live[u]);
+        wt_add(L.tab, slot, val, live[u] && slot >= 0, lane);
+        if (live[u] && slot < 0) {   // table full: rare, straight to HBM
+          const float o[4] = {val[0].x, val[0].y, val[0].z, val[0].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) unsafeAtomicAdd(acc + 4 * (size_t)p[u] + c, o[c]);
+        }
+      }
+      if (g_ray != nullptr) {
+        rx = seg_sum_key(rx, pl[u], lane);
+        ryv = seg_sum_key(ryv, pl[u], lane);
+        rz = seg_sum_key(rz, pl[u], lane);
+        const int prev = __shfl_up(pl[u], 1, 64);
+        if ((lane == 0 || prev != pl[u]) && pl[u] < 8 * kBwdTH) {
+          L.ray[pl[u] * 3 + 0] += rx;
+          L.ray[pl[u] * 3 + 1] += ryv;
+          L.ray[pl[u] * 3 + 2] += rz;
+        }
+      }
+    }
+  }
+  if (g_ray != nullptr) {
+    for (int j = lane; j < 8 * kBwdTH * 3; j += 64) {
+      const int i = j / 3, c = j - i * 3;
+      const int px = i & 7, py = i >> 3;
+      if (px < tw && py < th) g_ray[((y0 + py) * W + x0 + px) * 3 + c] = L.ray[j];
+    }
+  }
+  {   // flush: 4 adjacent lanes per entry -> the 16 bytes of acc[p]: lane-coalesced atomics
+    const int c = lane & 3;
+    const float *vals = reinterpret_cast<const float *>(L.tab.vals);
+    const int n = wt_compact(L.tab, lane);
+    const volatile int *list = L.tab.owner;
+    for (int i = lane >> 2; i < n; i += 16) {
+      const int s = list[i];
+      unsafeAtomicAdd(acc + 4 * (size_t)L.tab.keys[s] + c, vals[s * 4 + c]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bwd_pack_iso_kernel(const float *__restrict__ mus, const float *__restrict__ a, const int P,
+                    float4 *__restrict__ rec, float4 *__restrict__ acc) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P) return;
+  rec[g] = make_float4(mus[3 * (size_t)g], mus[3 * (size_t)g + 1], mus[3 * (size_t)g + 2], a[g]);
+  acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(256)
+bwd_unpack_iso_kernel(const float4 *__restrict__ acc, const int P, float *__restrict__ g_mus, float *__restrict__ g_a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P) return;
+  const float4 v = acc[g];
+  g_mus[3 * (size_t)g] = v.x; g_mus[3 * (size_t)g + 1] = v.y; g_mus[3 * (size_t)g + 2] = v.z;
+  g_a[g] = v.w;
+}
+
 }  // namespace voge
+
 
 using namespace voge;
 
@@ -277,16 +456,43 @@ extern "C" int voge_trace_bwd(const float *mus, const float *isigmas, const floa
   if (workspace_bytes < voge_trace_bwd_workspace_bytes(P)) return VOGE_ERR_WORKSPACE;
   float *acc = reinterpret_cast<float *>(workspace);
   float4 *rec = reinterpret_cast<float4 *>(reinterpret_cast<char *>(workspace) + (size_t)P * 64);
-  hipError_t e = hipMemsetAsync(acc, 0, (size_t)P * 64, st);
-  if (e != hipSuccess) return (int)e;
+  if (nrows * W > 0 && (!rays || !idx || !g_len || !g_act || !g_dsd)) return VOGE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bwd_pack_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, P, rec,
+                     reinterpret_cast<float4 *>(acc));
   if (nrows * W > 0) {
-    if (!rays || !idx || !g_len || !g_act || !g_dsd) return VOGE_ERR_BAD_ARG;
-    hipLaunchKernelGGL(bwd_pack_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, P, rec);
     const long tiles = (long)((W + 7) / 8) * ((nrows + kBwdTH - 1) / kBwdTH);
     hipLaunchKernelGGL(trace_bwd_kernel, dim3((unsigned)((tiles + kBwdWaves - 1) / kBwdWaves)), dim3(64 * kBwdWaves),
                        0, st, rec, rays, idx, cnt, g_len, g_act, g_dsd, P, nrows, W, K, g_ray, acc);
   }
   hipLaunchKernelGGL(bwd_unpack_kernel, dim3((unsigned)(((size_t)P * 16 + 255) / 256)), dim3(256), 0, st, acc, P,
                      g_mus, g_isg);
+  return launch_status();
+}
+
+extern "C" size_t voge_trace_bwd_iso_workspace_bytes(int P) { return P <= 0 ? 0 : (size_t)P * 32; }
+
+extern "C" int voge_trace_bwd_iso(const float *mus, const float *a, const float *rays, const int32_t *idx,
+                                  const int32_t *cnt, const float *g_len, const float *g_act, const float *g_dsd,
+                                  int P, long nrows, int W, int K, void *workspace, size_t workspace_bytes,
+                                  float *g_ray, float *g_mus, float *g_a, voge_stream_t stream) {
+  if (P < 0 || nrows < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 0) {
+    if (g_ray && nrows * W > 0) return (int)hipMemsetAsync(g_ray, 0, sizeof(float) * 3 * (size_t)(nrows * W), st);
+    return 0;
+  }
+  if (!g_mus || !g_a || !mus || !a || !workspace) return VOGE_ERR_BAD_ARG;
+  if (workspace_bytes < voge_trace_bwd_iso_workspace_bytes(P)) return VOGE_ERR_WORKSPACE;
+  if (nrows * W > 0 && (!rays || !idx || !g_len || !g_act || !g_dsd)) return VOGE_ERR_BAD_ARG;
+  float4 *acc = reinterpret_cast<float4 *>(workspace);
+  float4 *rec = acc + P;
+  hipLaunchKernelGGL(bwd_pack_iso_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, a, P, rec, acc);
+  if (nrows * W > 0) {
+    const long tiles = (long)((W + 7) / 8) * ((nrows + kBwdTH - 1) / kBwdTH);
+    hipLaunchKernelGGL(trace_bwd_iso_kernel, dim3((unsigned)((tiles + kBwdIWaves - 1) / kBwdIWaves)),
+                       dim3(64 * kBwdIWaves), 0, st, rec, rays, idx, cnt, g_len, g_act, g_dsd, P, nrows, W, K, g_ray,
+                       reinterpret_cast<float *>(acc));
+  }
+  hipLaunchKernelGGL(bwd_unpack_iso_kernel, dim3((P + 255) / 256), dim3(256), 0, st, acc, P, g_mus, g_a);
   return launch_status();
 }

@@ -32,14 +32,20 @@ __device__ inline double lambda_min_sym3(double a00, double a11, double a22, dou
 
 __global__ void __launch_bounds__(256)
 prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg,
-            const float *__restrict__ cam_fwd, const int N, const int P, const float thr_act,
+            const float *__restrict__ cam_fwd, const int N, const int P, const float thr_act, const int iso_in,
             float4 *__restrict__ cull, float4 *__restrict__ evr, float4 *__restrict__ ms) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= P) return;
   const float mx = mus[3 * g + 0], my = mus[3 * g + 1], mz = mus[3 * g + 2];
   float A[9];
+  if (iso_in) {   // isg holds one scalar per Gaussian: A = a I
+    const float a = isg[g];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) A[i] = isg[9 * (size_t)g + i];
+    for (int i = 0; i < 9; ++i) A[i] = (i % 4 == 0) ? a : 0.0f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = isg[9 * (size_t)g + i];
+  }
   const EvalRec e = make_eval(mx, my, mz, A);
 
   const double lmin = lambda_min_sym3(A[0], A[4], A[8], 0.5 * ((double)A[1] + A[3]),
@@ -1202,11 +1208,11 @@ extern "C" size_t voge_trace_workspace_bytes(int B, int N, int H, int W) {
   return trace_ws_layout(B, N, H, W, nullptr, nullptr);
 }
 
-extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const float *rays,
-                                   const float *cam_fwd, int B, int N, int H, int W, int K,
-                                   float thr_act, void *workspace, size_t workspace_bytes,
-                                   int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
-                                   voge_stream_t stream) {
+static int trace_topk_fwd_impl(const int iso_in, const float *mus, const float *isigmas, const float *rays,
+                               const float *cam_fwd, int B, int N, int H, int W, int K,
+                               float thr_act, void *workspace, size_t workspace_bytes,
+                               int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
+                               voge_stream_t stream) {
   if (B < 0 || N < 0 || H < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K) return VOGE_ERR_K_TOO_LARGE;
   if ((size_t)B * H * W == 0) return 0;  // numel == 0 early return (ray_trace_voge.cu:248-251)
@@ -1219,7 +1225,7 @@ extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const
   trace_ws_layout(B, N, H, W, workspace, &ws);
   if (P > 0) {
     hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P,
-                       thr_act, ws.cull, ws.evr, ws.ms);
+                       thr_act, iso_in, ws.cull, ws.evr, ws.ms);
     int rc = launch_status();
     if (rc) return rc;
   }
@@ -1250,6 +1256,24 @@ extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const
   if (sizeof(uint64_t) * (size_t)(K + 1) * 65 + 16 + sizeof(TraceLds<64>) <= 160 * 1024)
     return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
   return VOGE_ERR_K_TOO_LARGE;
+}
+
+extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const float *rays,
+                                   const float *cam_fwd, int B, int N, int H, int W, int K,
+                                   float thr_act, void *workspace, size_t workspace_bytes,
+                                   int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
+                                   voge_stream_t stream) {
+  return trace_topk_fwd_impl(0, mus, isigmas, rays, cam_fwd, B, N, H, W, K, thr_act, workspace, workspace_bytes, idx, len,
+                             act, dsd, cnt, stream);
+}
+
+extern "C" int voge_trace_topk_fwd_iso(const float *mus, const float *a, const float *rays,
+                                       const float *cam_fwd, int B, int N, int H, int W, int K,
+                                       float thr_act, void *workspace, size_t workspace_bytes,
+                                       int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
+                                       voge_stream_t stream) {
+  return trace_topk_fwd_impl(1, mus, a, rays, cam_fwd, B, N, H, W, K, thr_act, workspace, workspace_bytes, idx, len, act,
+                             dsd, cnt, stream);
 }
 
 extern "C" int voge_trace_topk_list_fwd(const float *mus, const float *isigmas, const float *rays,

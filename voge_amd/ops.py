@@ -124,6 +124,73 @@ class _RayTraceVoGE(torch.autograd.Function):
         return g_mus, g_isg, g_ray, None, None, None, None
 
 
+class _RayTraceVoGEIso(torch.autograd.Function):
+    """The same trace for isotropic Gaussians given as ONE scalar each (A = a I): what
+    expend_sigma((N,)) followed by 2*sigma (Aggregation.py:155-157, Renderer.py:133) describes.
+    forward(mus [P,3], a [P], rays [B,H,W,3], cam_fwd | None, thr_act, n_assign); the backward
+    returns the gradient of the scalar directly (four sums per Gaussian instead of twelve)."""
+
+    @staticmethod
+    def forward(ctx, mus, a, rays, cam_fwd, thr_act, n_assign):
+        lib = _lib.load()
+        mus_c = _dev(mus, torch.float32, "mus")
+        a_c = _dev(a, torch.float32, "a")
+        rays_c = _dev(rays, torch.float32, "rays")
+        assert mus_c.dim() == 2 and mus_c.shape[1] == 3 and a_c.dim() == 1 and a_c.shape[0] == mus_c.shape[0]
+        assert rays_c.dim() == 4 and rays_c.shape[3] == 3
+        B, H, W, _ = rays_c.shape
+        P = mus_c.shape[0]
+        assert B > 0 and P % B == 0, "mus must hold B*N rows"
+        N, K, dev = P // B, int(n_assign), rays_c.device
+        sel_idx = torch.empty((B, H, W, K), dtype=torch.int32, device=dev)
+        sel_len = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
+        sel_act = torch.empty_like(sel_len)
+        sel_dsd = torch.empty_like(sel_len)
+        cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+        fwd = None if cam_fwd is None else _dev(cam_fwd, torch.float32, "cam_fwd")
+        with torch.cuda.device(dev):
+            nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
+            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+            rc = lib.voge_trace_topk_fwd_iso(
+                _p(mus_c), _p(a_c), _p(rays_c), _p(fwd), B, N, H, W, K, float(thr_act), _p(ws), nbytes,
+                _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _p(cnt), _stream())
+        _lib.check(rc, "voge_trace_topk_fwd_iso")
+        ctx.save_for_backward(mus_c, a_c, rays_c)
+        ctx.sel_idx = sel_idx      # may later be rewritten in place by merge_final; cnt marks the filled slots
+        ctx.cnt = cnt
+        ctx.mark_non_differentiable(sel_idx)
+        ctx.set_materialize_grads(False)
+        return sel_idx, sel_len, sel_act, sel_dsd
+
+    @staticmethod
+    def backward(ctx, grad_sel_idx, grad_sel_len, grad_sel_act, grad_sel_dsd):
+        lib = _lib.load()
+        mus, a, rays = ctx.saved_tensors
+        sel_idx = ctx.sel_idx
+        B, H, W, K = sel_idx.shape
+        P = mus.shape[0]
+        zeros = None
+
+        def g(t):
+            nonlocal zeros
+            if t is None:
+                if zeros is None:
+                    zeros = torch.zeros(sel_idx.shape, dtype=torch.float32, device=sel_idx.device)
+                return zeros
+            return _dev(t, torch.float32, "grad")
+        gl, ga, gd = g(grad_sel_len), g(grad_sel_act), g(grad_sel_dsd)
+        g_ray = torch.empty_like(rays) if ctx.needs_input_grad[2] else None
+        g_mus = torch.empty_like(mus)
+        g_a = torch.empty_like(a)
+        with torch.cuda.device(rays.device):
+            nbytes = lib.voge_trace_bwd_iso_workspace_bytes(P)
+            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=rays.device)
+            rc = lib.voge_trace_bwd_iso(_p(mus), _p(a), _p(rays), _p(sel_idx), _p(ctx.cnt), _p(gl), _p(ga), _p(gd), P,
+                                        B * H, W, K, _p(ws), nbytes, _p(g_ray), _p(g_mus), _p(g_a), _stream())
+        _lib.check(rc, "voge_trace_bwd_iso")
+        return g_mus, g_a, g_ray, None, None, None
+
+
 class _Composite(torch.autograd.Function):
     """Fused replacement of get_cross_activation + assign2weight (VoGE/Aggregation.py:30-79)
     and of their autograd backward.  (sel_idx, sel_act, sel_len, sel_dsd, occ) -> weight, valid_num."""
