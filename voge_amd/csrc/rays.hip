@@ -38,22 +38,43 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
   const int b = blockIdx.y;
   const Mat3 Ri = inv3(R + 9 * b);
   const float fx = focal[2 * b], fy = focal[2 * b + 1], px = pp[2 * b], py = pp[2 * b + 1];
-  if (blockIdx.x == 0 && threadIdx.x < 3) {
-    const int c = threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // (static indices only: a lane-dependent index into Ri makes the compiler park the matrix in LDS)
     const float *t = T + 3 * b;
-    origin[3 * b + c] = -(t[0] * Ri.m[c] + t[1] * Ri.m[3 + c] + t[2] * Ri.m[6 + c]);
+    origin[3 * b + 0] = -(t[0] * Ri.m[0] + t[1] * Ri.m[3] + t[2] * Ri.m[6]);
+    origin[3 * b + 1] = -(t[0] * Ri.m[1] + t[1] * Ri.m[4] + t[2] * Ri.m[7]);
+    origin[3 * b + 2] = -(t[0] * Ri.m[2] + t[1] * Ri.m[5] + t[2] * Ri.m[8]);
   }
   const int n = h * W;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-    const int i = p / W, j = p - i * W;
-    const float vx = (px - ((float)j + 0.5f)) / fx;
-    const float vy = (py - ((float)(row0 + i) + 0.5f)) / fy;
-    const float wx = vx * Ri.m[0] + vy * Ri.m[3] + Ri.m[6];
-    const float wy = vx * Ri.m[1] + vy * Ri.m[4] + Ri.m[7];
-    const float wz = vx * Ri.m[2] + vy * Ri.m[5] + Ri.m[8];
-    const float inv = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);
-    float *o = rays + ((size_t)b * n + p) * 3;
-    o[0] = wx * inv; o[1] = wy * inv; o[2] = wz * inv;
+  const float ifx = 1.0f / fx, ify = 1.0f / fy, iW = 1.0f / (float)W;
+  float *ob = rays + (size_t)b * n * 3;
+  // four consecutive pixels per thread: 48 contiguous bytes leave as three 16-byte stores
+  const int n4 = (n + 3) >> 2;
+  const bool aligned = (reinterpret_cast<uintptr_t>(ob) & 15) == 0;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += gridDim.x * blockDim.x) {
+    float o[12];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = min(4 * q + u, n - 1);
+      int i = __float2int_rz(((float)p + 0.5f) * iW);      // p / W, corrected below (exact for any size)
+      int j = p - i * W;
+      if (j < 0) { --i; j += W; } else if (j >= W) { ++i; j -= W; }
+      const float vx = (px - ((float)j + 0.5f)) * ifx;
+      const float vy = (py - ((float)(row0 + i) + 0.5f)) * ify;
+      const float wx = vx * Ri.m[0] + vy * Ri.m[3] + Ri.m[6];
+      const float wy = vx * Ri.m[1] + vy * Ri.m[4] + Ri.m[7];
+      const float wz = vx * Ri.m[2] + vy * Ri.m[5] + Ri.m[8];
+      const float inv = __builtin_amdgcn_rsqf(wx * wx + wy * wy + wz * wz);
+      o[3 * u] = wx * inv; o[3 * u + 1] = wy * inv; o[3 * u + 2] = wz * inv;
+    }
+    if (4 * q + 3 < n && aligned) {
+      float4 *dst = reinterpret_cast<float4 *>(ob + (size_t)q * 12);
+      dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+      dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+      dst[2] = make_float4(o[8], o[9], o[10], o[11]);
+    } else {
+      for (int u = 0; u < 4 && 4 * q + u < n; ++u) { ob[(size_t)(4 * q + u) * 3] = o[3 * u]; ob[(size_t)(4 * q + u) * 3 + 1] = o[3 * u + 1]; ob[(size_t)(4 * q + u) * 3 + 2] = o[3 * u + 2]; }
+    }
   }
 }
 
@@ -150,7 +171,7 @@ extern "C" int voge_rays_fwd(const float *R, const float *T, const float *focal,
   if (B == 0) return 0;
   if (!R || !T || !focal || !pp || !origin || ((size_t)h * W > 0 && !rays)) return VOGE_ERR_BAD_ARG;
   const int n = h * W;
-  int blocks = (n + 255) / 256;
+  int blocks = ((n + 3) / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(rays_fwd_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, R, T, focal, pp, row0, h, W,
