@@ -21,8 +21,8 @@
 //     h(|x|) = erfc(|x|)/2, and  Phi = 1 - h in front, h behind.  The "1" parts are prefix /
 //     suffix sums, the h parts die out beyond |len_m - len_k| >= 4 / s (h < 8e-9), so every row
 //     walks a WINDOW away from the diagonal and stops.
-//   * h(x) = 2^Q(x'), x' = x sqrt(log2 e), Q a degree-8 polynomial (|err| <= 5.2e-8 absolute on
-//     [0, 5], h(0) = 1/2 exactly): one transcendental per evaluation, no reciprocal, no select.
+//   * h(x) = 2^Q(x'), x' = x sqrt(log2 e), Q a degree-6 polynomial (|err| <= 1.5e-7 absolute on
+//     [0, 5]): one transcendental per evaluation, no reciprocal, no select.
 //   * Two list entries per trip: (len, s, E) live in separate LDS arrays, ds_read2_b32 returns
 //     neighbours as a register pair and the arithmetic is packed fp32 (v_pk_fma_f32 ...).
 //   * Pads of sentinel entries (E = 0, len = -/+ 3e38) on both sides of every pixel's row: no
@@ -56,10 +56,21 @@ constexpr float kXcap = 5.0f * kCs;              // the fit's range; h(5) = 7.7e
 constexpr float kBig = 3.0e38f;
 
 // log2(erfc(x)/2) as a polynomial in x' = x sqrt(log2 e) on [0, 5 sqrt(log2 e)], weighted minimax
-// on the absolute error of 2^Q (tools/fit_erfc.py).
+// on the absolute error of 2^Q (tools/fit_erfc.py).  Degree 6: |err| <= 1.5e-7 (the accuracy of
+// Abramowitz-Stegun 7.1.26); VOGE_ERFC_DEG=8 gives 5.2e-8 and h(0) = 1/2 exactly for two more
+// packed FMAs per pair of entries.
+#ifndef VOGE_ERFC_DEG
+#define VOGE_ERFC_DEG 6
+#endif
+#if VOGE_ERFC_DEG == 8
 constexpr float kQ0 = -1.000000000e+00f, kQ1 = -1.355323434e+00f, kQ2 = -6.365932822e-01f,
                 kQ3 = -8.570024371e-02f, kQ4 = 1.359716244e-02f, kQ5 = -3.297536168e-04f,
                 kQ6 = -4.863584472e-04f, kQ7 = 1.211055496e-04f, kQ8 = -1.022832203e-05f;
+#else
+constexpr float kQ0 = -9.999997020e-01f, kQ1 = -1.355341077e+00f, kQ2 = -6.364040971e-01f,
+                kQ3 = -8.642258495e-02f, kQ4 = 1.487037074e-02f, kQ5 = -1.475012978e-03f,
+                kQ6 = 4.851150516e-05f;
+#endif
 
 __device__ __forceinline__ v2f pk_fma(const v2f a, const v2f b, const v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat(const float x) { return (v2f){x, x}; }
@@ -68,9 +79,13 @@ __device__ __forceinline__ v2f splat(const float x) { return (v2f){x, x}; }
 __device__ __forceinline__ v2f h_pair(v2f xp) {
   xp.x = fminf(xp.x, kXcap);
   xp.y = fminf(xp.y, kXcap);
+#if VOGE_ERFC_DEG == 8
   v2f q = pk_fma(splat(kQ8), xp, splat(kQ7));
   q = pk_fma(q, xp, splat(kQ6));
   q = pk_fma(q, xp, splat(kQ5));
+#else
+  v2f q = pk_fma(splat(kQ6), xp, splat(kQ5));
+#endif
   q = pk_fma(q, xp, splat(kQ4));
   q = pk_fma(q, xp, splat(kQ3));
   q = pk_fma(q, xp, splat(kQ2));
@@ -84,10 +99,16 @@ __device__ __forceinline__ v2f gauss_pair(const v2f xp) {
   return (v2f){__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
 }
 __device__ __forceinline__ float h_one(const float xp) { return h_pair(splat(xp)).x; }
+// entries (e, e+1), e even: one 8-byte LDS read
+__device__ __forceinline__ v2f ld2(const float *a, const int e) { return *reinterpret_cast<const v2f *>(a + e); }
+__device__ __forceinline__ v2f abs2(const v2f v) { return (v2f){fabsf(v.x), fabsf(v.y)}; }
 
 // Row stride of the padded per-pixel arrays: K entries + (K + 2) sentinels on either side, so a
 // lane that keeps reading while its wave finishes never leaves its pixel's pads.
-__host__ __device__ constexpr int comp_row_stride(const int K) { return 3 * K + 4; }
+// PAD and the stride are even: an entry's parity is its slot's parity and the pairs (2t, 2t+1) of a
+// row are 8-byte aligned (ds_read_b64: 2 LDS cycles per wave; ds_read2_b32 of an odd pair costs 4).
+__host__ __device__ constexpr int comp_pad(const int K) { return (K + 3) & ~1; }
+__host__ __device__ constexpr int comp_row_stride(const int K) { return ((K + 1) & ~1) + 2 * comp_pad(K); }
 
 struct CompLds {
   float pre[kCompThreads];   // inclusive prefix sum of E within the pixel
@@ -131,7 +152,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   const bool active = in_wg && (pix < npix);
   const long f = pix * K + k;
   const int RS = comp_row_stride(K);
-  const int PAD = K + 2;
+  const int PAD = comp_pad(K);
   const int bi = (in_wg ? p : 0) * RS + PAD + (in_wg ? k : 0);   // this slot's entry in the padded arrays
   if (tid < ppw) L.unsorted[tid] = 0;
   float lm = 0.f, sm = 1.f, em = 0.f, gw = 0.f, wgiven = 0.f;
@@ -147,12 +168,13 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
     Llen[bi] = lm; Lsp[bi] = sm * kCs; LE[bi] = HAVE_W ? em * (sm * kCs) : em;
     if (BWD) Lu[bi] = 0.0f;
   }
-  // sentinels: PAD = K + 2 entries on either side of the row; thread k writes pad entries k
-  // (and K + k for k < 2) of its own pixel -- no index arithmetic beyond an add
+  // sentinels: PAD (>= K + 2) entries on either side of the row; thread k writes pad entries
+  // k, k + K, ... of its own pixel -- no index arithmetic beyond an add.  (K odd: the back pad
+  // has one more entry so that the row's last aligned pair is whole.)
   if (in_wg) {
     const int r0 = p * RS;
-    for (int q = k; q < PAD; q += K) {
-      const int ef = r0 + q, eb = r0 + PAD + K + q;
+    for (int q = k; q < PAD + (K & 1); q += K) {
+      const int ef = r0 + min(q, PAD - 1), eb = r0 + PAD + K + q;
       Llen[ef] = -kBig; Lsp[ef] = 1.0f; LE[ef] = 0.0f;
       Llen[eb] = kBig; Lsp[eb] = 1.0f; LE[eb] = 0.0f;
       if (BWD) { Lu[ef] = 0.0f; Lu[eb] = 0.0f; }
@@ -201,20 +223,28 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   if (em != 0.0f && sorted) {
     v2f accF = splat(0.0f), accB = splat(0.0f), accR = splat(0.0f);
     const v2f lm2 = splat(lm);
-    for (int e = bi - 1;; e -= 2) {      // entries (e, e+1) = slots (j-1, j), j = k, k-2, ...
-      const v2f l2 = {Llen[e], Llen[e + 1]};
-      const v2f s2 = {Lsp[e], Lsp[e + 1]};
-      const v2f E2 = {LE[e], LE[e + 1]};
+    const int d0 = bi & ~1;              // the aligned pair that holds the diagonal
+    const bool odd = (bi & 1) != 0;
+    {   // diagonal pair: entry d0 is in front of (or is) this slot; d0+1 is this slot (odd) or behind
+      const v2f s2 = ld2(Lsp, d0), E2 = ld2(LE, d0);
+      const v2f xp = abs2(lm2 - ld2(Llen, d0)) * s2;
+      if (!HAVE_W) {
+        const v2f eh = E2 * h_pair(xp);
+        accF = (v2f){eh.x, odd ? eh.y : 0.0f};
+        accB = (v2f){0.0f, odd ? 0.0f : eh.y};
+      }
+      if (BWD) accR = (HAVE_W ? E2 : E2 * s2) * gauss_pair(xp);
+    }
+    for (int e = d0 - 2;; e -= 2) {      // pairs in front, nearest first
+      const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
       const v2f d = lm2 - l2;
       if (d.y >= rwin) break;
       const v2f xp = d * s2;
       if (!HAVE_W) accF = pk_fma(E2, h_pair(xp), accF);
       if (BWD) accR = pk_fma(HAVE_W ? E2 : E2 * s2, gauss_pair(xp), accR);
     }
-    for (int e = bi + 1;; e += 2) {      // slots (j, j+1), j = k+1, k+3, ...
-      const v2f l2 = {Llen[e], Llen[e + 1]};
-      const v2f s2 = {Lsp[e], Lsp[e + 1]};
-      const v2f E2 = {LE[e], LE[e + 1]};
+    for (int e = d0 + 2;; e += 2) {      // pairs behind
+      const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
       const v2f d = l2 - lm2;
       if (d.x >= rwin) break;
       const v2f xp = d * s2;
@@ -270,24 +300,33 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
     if (sorted) {
       const float rj = kSat * __builtin_amdgcn_rcpf(sm);
       const v2f lm2 = splat(lm), sp2 = splat(sp);
-      v2f aH = splat(0.0f), aP = splat(0.0f), aL = splat(0.0f);   // behind: sum u h, sum u y, sum u y dl
-      v2f bH = splat(0.0f), bP = splat(0.0f), bL = splat(0.0f);   // in front
-      for (int e = bi;; e += 2) {          // rows (m, m+1), m = j, j+2, ...
-        const v2f l2 = {Llen[e], Llen[e + 1]};
+      v2f aH, aP, aL;   // behind (and self): sum u h, sum u y, sum u y |dl|
+      v2f bH, bP, bL;   // in front
+      const int d0 = bi & ~1;
+      const bool odd = (bi & 1) != 0;
+      {   // diagonal pair: entry d0 is this slot (even) or the row just in front (odd); d0+1 is behind / this slot
+        const v2f u2 = ld2(Lu, d0);
+        const v2f d = abs2(ld2(Llen, d0) - lm2);
+        const v2f xp = d * sp2;
+        const v2f uy = u2 * gauss_pair(xp), uh = u2 * h_pair(xp), ul = uy * d;
+        aH = (v2f){odd ? 0.0f : uh.x, uh.y}; bH = (v2f){odd ? uh.x : 0.0f, 0.0f};
+        aP = (v2f){odd ? 0.0f : uy.x, uy.y}; bP = (v2f){odd ? uy.x : 0.0f, 0.0f};
+        aL = (v2f){odd ? 0.0f : ul.x, ul.y}; bL = (v2f){odd ? ul.x : 0.0f, 0.0f};
+      }
+      for (int e = d0 + 2;; e += 2) {      // rows behind
+        const v2f l2 = ld2(Llen, e), u2 = ld2(Lu, e);
         const v2f d = l2 - lm2;
         if (d.x >= rj) break;
-        const v2f u2 = {Lu[e], Lu[e + 1]};
         const v2f xp = d * sp2;
         const v2f uy = u2 * gauss_pair(xp);
         aH = pk_fma(u2, h_pair(xp), aH);
         aP = aP + uy;
         aL = pk_fma(uy, d, aL);
       }
-      for (int e = bi - 2;; e -= 2) {      // rows (m-1, m), m = j-1, j-3, ...
-        const v2f l2 = {Llen[e], Llen[e + 1]};
+      for (int e = d0 - 2;; e -= 2) {      // rows in front
+        const v2f l2 = ld2(Llen, e), u2 = ld2(Lu, e);
         const v2f d = lm2 - l2;
         if (d.y >= rj) break;
-        const v2f u2 = {Lu[e], Lu[e + 1]};
         const v2f xp = d * sp2;
         const v2f uy = u2 * gauss_pair(xp);
         bH = pk_fma(u2, h_pair(xp), bH);

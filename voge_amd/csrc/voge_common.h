@@ -288,23 +288,15 @@ __device__ __forceinline__ void wt_clear(WaveTable<NE, NV4> &t, const int lane) 
 constexpr int kWtProbe = 16;
 template <int NE, int NV4>
 __device__ __forceinline__ int wt_find(WaveTable<NE, NV4> &t, const int key, const bool want) {
-  volatile int *keys = t.keys;
   unsigned h = ((unsigned)key * 2654435761u) >> (32 - __builtin_ctz(NE));
   int slot = -1;
   bool pending = want;
 #pragma unroll 1
   for (int pr = 0; pr < kWtProbe && __any(pending); ++pr) {
     if (pending) {
-      const int k0 = keys[h];
-      if (k0 == key) {
-        slot = (int)h;
-        pending = false;
-      } else if (k0 == -1) {
-        keys[h] = key;  // several lanes may try; the read-back below tells who won
-      }
-    }
-    if (pending) {
-      if (keys[h] == key) {
+      // one LDS compare-and-swap per probe: claims an empty slot or reports who holds it
+      const int old = atomicCAS(&t.keys[h], -1, key);
+      if (old == -1 || old == key) {
         slot = (int)h;
         pending = false;
       } else {
