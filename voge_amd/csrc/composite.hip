@@ -111,11 +111,9 @@ __host__ __device__ constexpr int comp_pad(const int K) { return (K + 3) & ~1; }
 __host__ __device__ constexpr int comp_row_stride(const int K) { return ((K + 1) & ~1) + 2 * comp_pad(K); }
 
 struct CompLds {
-  float pre[kCompThreads];   // inclusive prefix sum of E within the pixel
-  float suf[kCompThreads];   // inclusive suffix sum of u within the pixel (backward)
-  float scan[2][kCompThreads];
-  float scanm[2][kCompThreads];
-  int scanc[2][kCompThreads];   // forward only (aliases nothing the backward uses)
+  v2f scan[2][kCompThreads];   // (running sum, running max) / (running sum, -) of the scans
+  int rmaxi[kCompThreads];      // per pixel: bits of the largest 3.5/s
+  int cnt[kCompThreads];        // per pixel: number of assigned slots (forward)
   int unsorted[kCompThreads];
 };
 // dynamic LDS: CompLds, then the padded per-pixel arrays len / sp / E (/ u in the backward),
@@ -154,7 +152,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   const int RS = comp_row_stride(K);
   const int PAD = comp_pad(K);
   const int bi = (in_wg ? p : 0) * RS + PAD + (in_wg ? k : 0);   // this slot's entry in the padded arrays
-  if (tid < ppw) L.unsorted[tid] = 0;
+  if (tid < ppw) { L.unsorted[tid] = 0; L.rmaxi[tid] = 0; L.cnt[tid] = 0; }
   float lm = 0.f, sm = 1.f, em = 0.f, gw = 0.f, wgiven = 0.f;
   int id = -1;
   if (active) {
@@ -182,37 +180,51 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   }
   __syncthreads();
   if (active && k > 0 && !(Llen[bi - 1] <= lm)) L.unsorted[p] = 1;
-  // One ping-pong scan over the workgroup (log2 K steps) yields, per pixel: the inclusive prefix
-  // sum of E, the largest 4/s (window radius in len) and the number of assigned slots.
-  float pre_incl;
-  int cnt_all;
-  float rwin_all;
-  {
-    float x = em;
-    float mx = (em != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm) : 0.0f;
-    int c = (!BWD && id >= 0) ? 1 : 0;
+  // Per-pixel reductions.  The workgroup scan below is LDS-issue bound, so as little as possible
+  // rides on it: the assigned-slot count is a ballot + popcount per wave merged by one LDS atomic
+  // per (wave, pixel) run; the window radius (largest 3.5/s) shares the scan's 64-bit elements
+  // when there is a scan (an 8-byte LDS access costs the same issue slots as a 4-byte one), and is
+  // a segmented wave max + one atomic per run when there is none (backward with given weights).
+  // Max and integer add are order independent: no determinism is lost.
+  const int lane = tid & 63;
+  const bool head = in_wg && (lane == 0 || k == 0);
+  if (!BWD) {
+    const unsigned long long m = __ballot(id >= 0);
+    const int lo = max(0, lane - k), hi = min(63, lane + (K - 1 - k));     // this pixel's lanes in the wave
+    const unsigned long long seg = ((hi - lo == 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull) << lo);
+    if (head) atomicAdd(&L.cnt[p], __popcll(m & seg));
+  }
+  float mx = (em != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm) : 0.0f;
+  // Inclusive prefix sum of E within each pixel: ping-pong Hillis-Steele scan over the workgroup.
+  // Its association is a function of the slot index only, so a pixel's result does not depend on
+  // where it sits in the workgroup (row bands reproduce the whole frame bit for bit).
+  float pre_incl = em;
+  if (!HAVE_W) {
+    v2f x = {em, mx};
     int par = 0;
     for (int o = 1; o < K; o <<= 1) {
-      if (!HAVE_W) L.scan[par][tid] = x;
-      L.scanm[par][tid] = mx;
-      if (!BWD) L.scanc[par][tid] = c;
+      L.scan[par][tid] = x;
       __syncthreads();
       if (k >= o && in_wg) {
-        if (!HAVE_W) x += L.scan[par][tid - o];
-        mx = fmaxf(mx, L.scanm[par][tid - o]);
-        if (!BWD) c += L.scanc[par][tid - o];
+        const v2f y = L.scan[par][tid - o];
+        x.x += y.x;
+        x.y = fmaxf(x.y, y.y);
       }
       par ^= 1;
     }
-    pre_incl = x;
-    L.pre[tid] = x;
-    L.scanm[par][tid] = mx;      // slot K-1 of each pixel holds the pixel-wide values
-    if (!BWD) L.scanc[par][tid] = c;
-    __syncthreads();
-    const int last = in_wg ? p * K + K - 1 : tid;
-    rwin_all = L.scanm[par][last];
-    cnt_all = BWD ? 0 : L.scanc[par][last];
+    pre_incl = x.x;
+    if (in_wg && k == K - 1) L.rmaxi[p] = __float_as_int(x.y);
+  } else {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {     // lane + o holds slot k + o of the same pixel iff k + o < K
+      const float y = __shfl_down(mx, o, 64);
+      if (lane + o < 64 && k + o < K) mx = fmaxf(mx, y);
+    }
+    if (head) atomicMax(&L.rmaxi[p], __float_as_int(mx));     // mx >= 0: float order == int order
   }
+  __syncthreads();
+  const float rwin_all = in_wg ? __int_as_float(L.rmaxi[p]) : 0.0f;
+  const int cnt_all = (!BWD && in_wg) ? L.cnt[p] : 0;
   const bool sorted = active && (L.unsorted[p] == 0);
   const float rwin = sorted ? rwin_all : 0.0f;   // 0: the windowed loops do nothing
 
@@ -279,16 +291,18 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   }
   const float um = gw * w;
   if (in_wg) Lu[bi] = um;
-  {   // inclusive suffix sum of u within each pixel
+  float suf_incl;
+  {   // inclusive suffix sum of u within each pixel (same scan, mirrored)
     float x = um;
     int par = 0;
+    float(*sf)[kCompThreads] = reinterpret_cast<float(*)[kCompThreads]>(L.scan);   // 4-byte elements here
     for (int o = 1; o < K; o <<= 1) {
-      L.scan[par][tid] = x;
+      sf[par][tid] = x;
       __syncthreads();
-      if (k + o < K && in_wg) x += L.scan[par][tid + o];
+      if (k + o < K && in_wg) x += sf[par][tid + o];
       par ^= 1;
     }
-    L.suf[tid] = x;
+    suf_incl = x;
   }
   __syncthreads();
   // ---- column j (= this lane): Phi_mj = 1 - h for rows behind (suffix sum of u minus the h
@@ -333,7 +347,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
         bP = bP + uy;
         bL = pk_fma(uy, d, bL);
       }
-      cPhi = (L.suf[tid] - (aH.x + aH.y)) + (bH.x + bH.y);
+      cPhi = (suf_incl - (aH.x + aH.y)) + (bH.x + bH.y);
       cphi = ((aP.x + aP.y) + (bP.x + bP.y)) * kRsqrtPi;
       cphil = ((aL.x + aL.y) - (bL.x + bL.y)) * kRsqrtPi;
     } else {
