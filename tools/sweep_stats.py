@@ -44,7 +44,7 @@ for n, x in zip(names, v):
 print("rays", H * W, "hits per ray", v[6] / (H * W), "evals per ray (wave evals)", v[2] * 64 / (H * W))
 
 import numpy as np
-nwg = ((W + 15) // 16) * ((H + 7) // 8)
+nwg = ((W + 7) // 8) * ((H + 7) // 8)
 nwg = min(nwg, 8192)
 buf = (ctypes.c_ulonglong * (8 * nwg))()
 ctypes.CDLL(_lib.LIB_PATH).voge_debug_sweep_times(buf, nwg)

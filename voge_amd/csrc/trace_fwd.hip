@@ -620,6 +620,9 @@ bin2_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, con
 // contiguous runs of TW*K floats.
 // ------------------------------------------------------------------------------------------
 #ifdef VOGE_SWEEP_STATS
+#define VOGE_SWEEP_TIMES 1
+#endif
+#ifdef VOGE_SWEEP_TIMES
 __device__ unsigned long long g_sweep_stats[16];
 __device__ unsigned long long g_sweep_times[8192 * 8];   // per WG: start, after cones, fill sum, consume sum, loop end, end, evals, smid
 #endif
@@ -661,7 +664,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   uint64_t *keys = reinterpret_cast<uint64_t *>(smem_raw);
   TraceLds<T> &L = *reinterpret_cast<TraceLds<T> *>(smem_raw + ((sizeof(uint64_t) * (size_t)(K + 1) * TP + 15) & ~(size_t)15));
 
-#ifdef VOGE_SWEEP_STATS
+#ifdef VOGE_SWEEP_TIMES
   const unsigned long long ts0 = wall_clock64();
   unsigned long long ts_fill = 0, ts_cons = 0;
 #endif
@@ -715,7 +718,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     __syncthreads();
   }
 
-#ifdef VOGE_SWEEP_STATS
+#ifdef VOGE_SWEEP_TIMES
   const unsigned long long ts1 = wall_clock64();
 #endif
   // ---- candidate stream of this tile -----------------------------------------------------
@@ -757,7 +760,8 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   float lb1 = load_lb(T + tid);
   while (base < src_n) {
     int nbuf = 0;
-#ifdef VOGE_SWEEP_STATS
+    bool chunk_iso = true;   // every staged candidate of this buffer is isotropic (wave-uniform)
+#ifdef VOGE_SWEEP_TIMES
     const unsigned long long tsa = wall_clock64();
 #endif
     while (base < src_n && nbuf + T <= kCap) {
@@ -772,6 +776,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       lb1 = load_lb(base + 2 * T + tid);
       const bool keep = prefiltered ? (id >= 0) : cone_keep(c, gcone);
       const unsigned long long m = __ballot(keep);
+      chunk_iso = chunk_iso && __all(!keep || (mrec.w == mrec.w));
       if (lane == 0) L.wcnt[par][wave] = __popcll(m);
       __syncthreads();
       int off = nbuf, tot = 0;
@@ -801,7 +806,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     st_staged += nbuf;
 #endif
     __syncthreads();
-#ifdef VOGE_SWEEP_STATS
+#ifdef VOGE_SWEEP_TIMES
     const unsigned long long tsb = wall_clock64();
     ts_fill += tsb - tsa;
 #endif
@@ -848,6 +853,26 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 #ifdef VOGE_SWEEP_STATS
         st_eval += __popcll(m); ++st_batches;
 #endif
+        if (WAVES == 1 && chunk_iso) {
+          // Single-wave tile, all-isotropic chunk (the common case): the surviving candidates are
+          // the contiguous range [c0, c0 + n) -- no bit scanning, no per-candidate isotropy test.
+          const int s_end = c0 + __popcll(m);
+          for (int s0 = c0; s0 < s_end; s0 += kTrip) {
+#ifdef VOGE_SWEEP_STATS
+            ++st_trips;
+#endif
+            float4 cc[kTrip];
+            PairOut o[kTrip];
+#pragma unroll
+            for (int q = 0; q < kTrip; ++q) cc[q] = L.ms[min(s0 + q, s_end - 1)];
+#pragma unroll
+            for (int q = 0; q < kTrip; ++q)
+              o[q] = pair_eval_iso(cc[q].x, cc[q].y, cc[q].z, cc[q].w, dx, dy, dz, qxx, qyy, qzz);
+#pragma unroll
+            for (int q = 0; q < kTrip; ++q) commit(o[q], min(s0 + q, s_end - 1), s0 + q < s_end);
+          }
+          m = 0ull;
+        }
         while (m) {
 #ifdef VOGE_SWEEP_STATS
           ++st_trips;
@@ -905,7 +930,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
         if (last_batch) wdone = true;
       }
     }
-#ifdef VOGE_SWEEP_STATS
+#ifdef VOGE_SWEEP_TIMES
     ts_cons += wall_clock64() - tsb;
 #endif
     if (wdone && !reported) {
@@ -916,8 +941,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     if (L.done == WAVES) break;
   }
 
-#ifdef VOGE_SWEEP_STATS
+#ifdef VOGE_SWEEP_TIMES
   const unsigned long long ts2 = wall_clock64();
+#endif
+#ifdef VOGE_SWEEP_STATS
   if (lane == 0) {
     atomicAdd(&g_sweep_stats[0], 1ull);
     atomicAdd(&g_sweep_stats[1], (unsigned long long)(wave == 0 ? st_staged : 0));
@@ -933,6 +960,9 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 #endif
   // ---- epilogue: lanes re-mapped to (pixel, slot); act / dsd recomputed with pair_eval ------
   L.cnt[tid] = cnt;
+#ifdef VOGE_SWEEP_TIMES
+  const int cnt_dbg = (int)__popcll(__ballot(cnt > 0));   // rays of the tile with at least one hit
+#endif
   if (out_cnt != nullptr && valid) out_cnt[((size_t)b * H + py) * W + px] = cnt;
   __syncthreads();
   const int tw = min(TW, W - tx * TW);
@@ -1045,10 +1075,15 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       }
     }
   }
-#ifdef VOGE_SWEEP_STATS
+#ifdef VOGE_SWEEP_TIMES
   if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) {
     unsigned long long *o = g_sweep_times + 8 * (size_t)blockIdx.x;
-    o[0] = ts0; o[1] = ts1; o[2] = ts_fill; o[3] = ts_cons; o[4] = ts2; o[5] = wall_clock64(); o[6] = st_eval;
+    o[0] = ts0; o[1] = ts1; o[2] = ts_fill; o[3] = ts_cons; o[4] = ts2; o[5] = wall_clock64();
+#ifdef VOGE_SWEEP_STATS
+    o[6] = st_eval;
+#else
+    o[6] = (unsigned long long)cnt_dbg;
+#endif
     o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
   }
 #endif
@@ -1190,7 +1225,7 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
 
 using namespace voge;
 
-#ifdef VOGE_SWEEP_STATS
+#ifdef VOGE_SWEEP_TIMES
 // debug builds only (tools/sweep_stats.py): read and clear the sweep counters
 extern "C" int voge_debug_sweep_stats(unsigned long long *out16) {
   hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(voge::g_sweep_stats), sizeof(unsigned long long) * 16);
