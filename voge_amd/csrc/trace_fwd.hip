@@ -604,6 +604,117 @@ bin2_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, con
 }
 
 // ------------------------------------------------------------------------------------------
+// tile_order: launch order of the sweep = tiles by descending candidate count (counting sort into
+// 256 buckets of 8).  The sweep's residency is small (LDS top-K lists), tile costs span 10-80 us,
+// and a heavy tile that starts late is the kernel's tail; longest-first removes that tail.  The
+// sweep's results do not depend on the order.
+// ------------------------------------------------------------------------------------------
+constexpr int kOrderClasses = 16;
+constexpr int kOrderPer = 16;   // counts per thread kept in registers (one memory round trip)
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(const int *__restrict__ tl_count, const int ntile, int *__restrict__ order) {
+  // Partition into 16 classes of the count range, heaviest first, with ballots only (no atomics:
+  // thousands of tiles with near-equal counts would serialise on a handful of LDS addresses).
+  // Position = class base + this wave's base within the class + rank inside the ballot: a pure
+  // function of the counts (deterministic).  Chunks of 16384 tiles; chunks are ordered one
+  // after the other (a frame has more than one only beyond 1024^2 pixels or in batches).
+  __shared__ int red[16];
+  __shared__ float redf[16];
+  __shared__ int wtot[kOrderClasses][16];
+  __shared__ int ctot[kOrderClasses];
+  __shared__ int cexc[kOrderClasses];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c0 = 0; c0 < ntile; c0 += 1024 * kOrderPer) {
+    const int n = min(ntile - c0, 1024 * kOrderPer);
+    int cnt[kOrderPer];
+#pragma unroll
+    for (int u = 0; u < kOrderPer; ++u) {
+      const int i = u * 1024 + tid;
+      cnt[u] = (i < n) ? tl_count[c0 + i] : 0;
+    }
+    int cmax = 0;
+    float csum = 0.0f;
+#pragma unroll
+    for (int u = 0; u < kOrderPer; ++u) {
+      cmax = max(cmax, cnt[u] < 0 ? (1 << 20) : cnt[u]);
+      csum += (float)max(cnt[u], 0);
+    }
+    cmax = (int)wave_max((float)cmax);
+    csum = wave_sum(csum);
+    __syncthreads();   // previous chunk done with the shared arrays
+    if (lane == 0) { red[wave] = cmax; redf[wave] = csum; }
+    __syncthreads();
+    cmax = red[0];
+    csum = redf[0];
+    for (int w = 1; w < 16; ++w) { cmax = max(cmax, red[w]); csum += redf[w]; }
+    // Balanced chunk (mean list at least half the longest): keep the spatial launch order -- there
+    // is no tail to remove and neighbouring tiles share their super-tile's list and Gaussians in L2.
+    if (csum * 2.0f >= (float)cmax * (float)n) {
+#pragma unroll
+      for (int u = 0; u < kOrderPer; ++u)
+        if (u * 1024 + tid < n) order[c0 + u * 1024 + tid] = c0 + u * 1024 + tid;
+      continue;   // uniform
+    }
+    const float scale = (float)kOrderClasses / ((float)cmax + 1.0f);
+    int cls[kOrderPer];
+    // lanes of the wave that hold the same class as this lane, from the four bit-ballots of the
+    // 4-bit class id (instead of one ballot per class)
+    auto same_class = [&](const int c) {
+      unsigned long long same = __ballot(c >= 0);
+#pragma unroll
+      for (int bit = 0; bit < 4; ++bit) {
+        const unsigned long long mb = __ballot((c >> bit) & 1);
+        same &= ((c >> bit) & 1) ? mb : ~mb;
+      }
+      return same;
+    };
+    for (int i = tid; i < kOrderClasses * 16; i += 1024) (&wtot[0][0])[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kOrderPer; ++u) {
+      cls[u] = (u * 1024 + tid >= n) ? -1
+               : (cnt[u] < 0)        ? 0
+                                     : (kOrderClasses - 1) - min(kOrderClasses - 1, (int)((float)cnt[u] * scale));
+      if (u * 1024 < n) {   // uniform
+        const unsigned long long same = same_class(cls[u]);
+        if (cls[u] >= 0 && (same & ((1ull << lane) - 1ull)) == 0) wtot[cls[u]][wave] += __popcll(same);   // class leader
+      }
+    }
+    __syncthreads();
+    // exclusive prefix over (class, wave): one thread per class scans its 16 waves, then thread 0
+    // chains the class totals (two short dependent chains instead of one of 256 LDS round trips)
+    if (tid < kOrderClasses) {
+      int v[16], run = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) v[w] = wtot[tid][w];
+#pragma unroll
+      for (int w = 0; w < 16; ++w) { const int c = v[w]; v[w] = run; run += c; }
+#pragma unroll
+      for (int w = 0; w < 16; ++w) wtot[tid][w] = v[w];
+      ctot[tid] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int q = 0; q < kOrderClasses; ++q) { cexc[q] = run; run += ctot[q]; }
+    }
+    __syncthreads();
+    // wtot[class][wave] now holds this wave's running write offset inside the class
+#pragma unroll
+    for (int u = 0; u < kOrderPer; ++u) {
+      if (u * 1024 >= n) break;   // uniform
+      const unsigned long long same = same_class(cls[u]);
+      if (cls[u] >= 0) {
+        const int rank = __popcll(same & ((1ull << lane) - 1ull));
+        const int off = wtot[cls[u]][wave];
+        order[c0 + cexc[cls[u]] + off + rank] = c0 + u * 1024 + tid;
+        if (rank == 0) wtot[cls[u]][wave] = off + __popcll(same);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // sweep.  One workgroup = WAVES waves = a TW x TH pixel tile (each wave an 8x8 sub-tile, one
 // ray per lane).  Its candidate stream is the sorted list of its super-tile (or, if that bin
 // overflowed, every Gaussian of the batch element), read in chunks of T:
@@ -651,7 +762,8 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
                  const float4 *__restrict__ ms, const float *__restrict__ rays, const int *__restrict__ bin_count,
                  const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb,
                  const int *__restrict__ tl_count, const int32_t *__restrict__ tl_id,
-                 const float *__restrict__ tl_lb, const int nstx, const int nst, const int N, const int H,
+                 const float *__restrict__ tl_lb, const int *__restrict__ tile_order, const int nstx, const int nst,
+                 const int N, const int H,
                  const int W, const int K, const float thr_act, int32_t *__restrict__ out_idx,
                  float *__restrict__ out_len, float *__restrict__ out_act, float *__restrict__ out_dsd,
                  int32_t *__restrict__ out_cnt) {
@@ -670,7 +782,11 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (W + TW - 1) / TW;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  // heavy tiles first: the launch order is a permutation of (batch element, tile) sorted by list length
+  int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  if (tile_order != nullptr) lin = tile_order[lin];
+  const int b = lin / (int)gridDim.x, bx = lin - b * (int)gridDim.x;
+  const int tx = bx % tiles_x, ty = bx / tiles_x;
   const int px = tx * TW + (wave & 1) * 8 * (TW == 16) + (lane & 7);
   const int py = ty * TH + (wave >> 1) * 8 + (lane >> 3);
   const bool valid = (px < W) && (py < H);
@@ -723,7 +839,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 #endif
   // ---- candidate stream of this tile -----------------------------------------------------
   // tile list (bin2) -> super-tile list (bin) -> every Gaussian of the batch element
-  const int tile = b * gridDim.x + blockIdx.x;
+  const int tile = lin;
   const int bin = b * nst + ((ty * TH) / kST) * nstx + (tx * TW) / kST;
   const int tc = (tl_count != nullptr) ? tl_count[tile] : -1;
   const int bc = (tc >= 0) ? tc : ((bin_count != nullptr) ? bin_count[bin] : -1);
@@ -1076,8 +1192,8 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     }
   }
 #ifdef VOGE_SWEEP_TIMES
-  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) {
-    unsigned long long *o = g_sweep_times + 8 * (size_t)blockIdx.x;
+  if (tid == 0 && b == 0 && bx < 8192) {
+    unsigned long long *o = g_sweep_times + 8 * (size_t)bx;
     o[0] = ts0; o[1] = ts1; o[2] = ts_fill; o[3] = ts_cons; o[4] = ts2; o[5] = wall_clock64();
 #ifdef VOGE_SWEEP_STATS
     o[6] = st_eval;
@@ -1163,6 +1279,7 @@ struct TraceWs {
   int *c_count;        // coarse regions (bin0)
   int32_t *c_id;
   ConeRec *cones;      // per super-tile
+  int *tile_order;     // per sweep tile
   int nstx, nsty, nst0x, nst0y;
 };
 
@@ -1182,10 +1299,11 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
        *tl = take(ntile * kTileCap * 4);
   const int nst0x = (W + kST0 - 1) / kST0, nst0y = (H + kST0 - 1) / kST0;
   const size_t nreg = (size_t)B * nst0x * nst0y;
-  char *cc = take(nreg * 4), *ci = take(nreg * (size_t)N * 4), *cn = take(nbin * sizeof(ConeRec));
+  char *cc = take(nreg * 4), *ci = take(nreg * (size_t)N * 4), *cn = take(nbin * sizeof(ConeRec)), *to = take(ntile * 4);
   if (ws) {
     ws->c_count = reinterpret_cast<int *>(cc); ws->c_id = reinterpret_cast<int32_t *>(ci);
     ws->cones = reinterpret_cast<ConeRec *>(cn);
+    ws->tile_order = reinterpret_cast<int *>(to);
     ws->nst0x = nst0x; ws->nst0y = nst0y;
     ws->tl_count = reinterpret_cast<int *>(tc); ws->tl_id = reinterpret_cast<int32_t *>(ti);
     ws->tl_lb = reinterpret_cast<float *>(tl);
@@ -1216,8 +1334,12 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
     int rc = launch_status();
     if (rc) return rc;
   }
+  // ordering only matters when the tiles do not all fit on the chip at once
+  const bool ordered = (size_t)grid.x * grid.y > 2048;
+  if (ordered)
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, ws.tl_count, (int)(grid.x * grid.y), ws.tile_order);
   hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, ws.ms, rays, ws.bin_count, ws.bin_id, ws.bin_lb,
-                     ws.tl_count, ws.tl_id, ws.tl_lb, ws.nstx, ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd, cnt);
+                     ws.tl_count, ws.tl_id, ws.tl_lb, ordered ? ws.tile_order : nullptr, ws.nstx, ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd, cnt);
   return launch_status();
 }
 

@@ -191,7 +191,9 @@ __device__ __forceinline__ void topk_commit(uint64_t *keys, const int stride, co
                                             uint64_t &worst, uint64_t &tail, const uint64_t key,
                                             const bool take /* key < worst */) {
   const bool app = take && (cnt < K) && (key >= tail);
-  keys[(app ? cnt : K) * stride] = key;
+  // 32-bit element offset (24-bit multiply): a 64-bit multiply-add per candidate is quarter rate
+  const unsigned off = __umul24((unsigned)(app ? cnt : K), (unsigned)stride);
+  keys[off] = key;
   cnt += app ? 1 : 0;
   tail = app ? key : tail;
   worst = (app && cnt == K) ? key : worst;
