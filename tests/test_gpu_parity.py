@@ -90,6 +90,35 @@ def test_trace_fwd_anisotropic_ragged(hip_lib, H, W, K, B, thr):
     compare_trace(got, ref, thr_act, min_match=0.99)
 
 
+@pytest.mark.parametrize("iso_api", [False, True])
+def test_trace_fwd_large_frame_coarse_bins_and_tile_order(hip_lib, iso_api):
+    """A frame big enough to take the paths small tests skip: the coarse 128x128 binning level
+    (super-tiles x Gaussians >= 2^21), more than 2048 sweep tiles (longest-first launch order,
+    unbalanced: most of the frame is empty), a batch of two views; mixed isotropic / anisotropic
+    Gaussians through the general entry point, all-isotropic through the scalar one."""
+    from voge_amd import ops
+    N, H, W, K, B = 13000, 392, 408, 10, 2
+    verts, sig, _ = random_scene(N, seed=77, lo=0.02, hi=0.05, extent=0.8)
+    sc = dict(verts=verts, sigmas=sig, focal=430.0, principal=(W / 2.0, H / 2.0), image_size=(H, W),
+              dist=4.5, elev=15.0, azim=-25.0)
+    mus, isg, rays, _, _ = camera_inputs(sc, B=B)
+    if not iso_api:   # every third Gaussian gets a full symmetric 3x3 form (plus a 1e-3 skew part)
+        rng = np.random.default_rng(3)
+        isg = isg.copy()
+        nz = rng.normal(size=isg[:, ::3].shape)
+        nz = 0.1 * (nz + nz.swapaxes(-1, -2)) / 2 + 1e-3 * (nz - nz.swapaxes(-1, -2))
+        isg[:, ::3] += (nz * isg[:, ::3, 0:1, 0:1]).astype(np.float32)
+    thr_act = oracle.thr_act_of(0.01)
+    if iso_api:
+        a = np.ascontiguousarray(isg[..., 0, 0])
+        got = [n(x) for x in ops._RayTraceVoGEIso.apply(t(mus.reshape(-1, 3)), t(a.reshape(-1)), t(rays), None, thr_act, K)]
+    else:
+        got = run_trace(mus, isg, rays, K, thr_act)
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    compare_trace(got, ref, thr_act, min_match=0.999)
+    assert (ref[0][..., -1] >= 0).mean() > 0.05 and (ref[0][..., 0] < 0).mean() > 0.3   # full lists and empty pixels
+
+
 def test_trace_fwd_nonsymmetric_and_behind_camera(hip_lib):
     """All 9 entries of isigmas are independent inputs (ray_trace_voge.cu:11-38), and Gaussians
     behind the camera are kept with negative len in the -1 path (no sign test, :197)."""
