@@ -520,7 +520,9 @@ __global__ void __launch_bounds__(256)
 bin2_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, const int *__restrict__ bin_count,
             const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb, const int nstx, const int nst,
             const int N, const int H, const int W, const int TW, const int TH, int *__restrict__ tl_count,
-            int32_t *__restrict__ tl_id, float *__restrict__ tl_lb) {
+            int32_t *__restrict__ tl_id, float *__restrict__ tl_lb, const int K, int32_t *__restrict__ out_idx,
+            float *__restrict__ out_len, float *__restrict__ out_act, float *__restrict__ out_dsd,
+            int32_t *__restrict__ out_cnt) {
   __shared__ float red[4 * 8];
   __shared__ int wcnt[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -601,6 +603,31 @@ bin2_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, con
     }
   }
   if (tid == 0) tl_count[tile] = (total > kTileCap) ? -1 : total;
+  // A tile nothing can hit gets its outputs right here: this kernel runs at full occupancy and
+  // is latency-bound, so the stores are free, whereas in the sweep (a few waves per CU) the empty
+  // tiles were a pure write phase of ~8 us each.  The sweep returns at once on a zero count.
+  if (total == 0) {
+    const int tw = min(TW, W - tx * TW), th = min(TH, H - ty * TH);
+    const int row_items = tw * K;
+    for (int r = 0; r < th; ++r) {
+      const size_t pix0 = ((size_t)b * H + ty * TH + r) * W + (size_t)tx * TW;
+      if ((K & 3) == 0) {
+        for (int j4 = tid; j4 < row_items / 4; j4 += 256) {
+          const size_t o = pix0 * K + (size_t)j4 * 4;
+          *reinterpret_cast<int4 *>(out_idx + o) = make_int4(-1, -1, -1, -1);
+          *reinterpret_cast<float4 *>(out_len + o) = make_float4(VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN);
+          *reinterpret_cast<float4 *>(out_act + o) = make_float4(VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT);
+          *reinterpret_cast<float4 *>(out_dsd + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {
+        for (int j = tid; j < row_items; j += 256) {
+          const size_t o = pix0 * K + j;
+          out_idx[o] = -1; out_len[o] = VOGE_SENT_LEN; out_act[o] = VOGE_SENT_ACT; out_dsd[o] = 0.0f;
+        }
+      }
+      if (out_cnt != nullptr && tid < tw) out_cnt[pix0 + tid] = 0;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -785,6 +812,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   // heavy tiles first: the launch order is a permutation of (batch element, tile) sorted by list length
   int lin = blockIdx.y * gridDim.x + blockIdx.x;
   if (tile_order != nullptr) lin = tile_order[lin];
+  if (tl_count != nullptr && tl_count[lin] == 0) return;   // bin2 already wrote this tile's all-sentinel outputs
   const int b = lin / (int)gridDim.x, bx = lin - b * (int)gridDim.x;
   const int tx = bx % tiles_x, ty = bx / tiles_x;
   const int px = tx * TW + (wave & 1) * 8 * (TW == 16) + (lane & 7);
@@ -1329,7 +1357,7 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
   if (e != hipSuccess) return (int)e;
   dim3 grid(((W + TW - 1) / TW) * ((H + TH - 1) / TH), B);
   hipLaunchKernelGGL(bin2_kernel, grid, dim3(256), 0, st, ws.cull, rays, ws.bin_count, ws.bin_id, ws.bin_lb, ws.nstx,
-                     ws.nstx * ws.nsty, N, H, W, TW, TH, ws.tl_count, ws.tl_id, ws.tl_lb);
+                     ws.nstx * ws.nsty, N, H, W, TW, TH, ws.tl_count, ws.tl_id, ws.tl_lb, K, idx, len, act, dsd, cnt);
   {
     int rc = launch_status();
     if (rc) return rc;
