@@ -30,12 +30,10 @@ __device__ inline double lambda_min_sym3(double a00, double a11, double a22, dou
   return q + 2.0 * p * cos(phi + 2.0943951023931953);
 }
 
-__global__ void __launch_bounds__(256)
-prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg,
-            const float *__restrict__ cam_fwd, const int N, const int P, const float thr_act, const int iso_in,
-            float4 *__restrict__ cull, float4 *__restrict__ evr, float4 *__restrict__ ms) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P) return;
+__device__ __forceinline__ void prep_one(const int g, const float *__restrict__ mus, const float *__restrict__ isg,
+                                         const float *__restrict__ cam_fwd, const int N, const float thr_act,
+                                         const int iso_in, float4 *__restrict__ cull, float4 *__restrict__ evr,
+                                         float4 *__restrict__ ms) {
   const float mx = mus[3 * g + 0], my = mus[3 * g + 1], mz = mus[3 * g + 2];
   float A[9];
   if (iso_in) {   // isg holds one scalar per Gaussian: A = a I
@@ -251,15 +249,29 @@ struct ConeRec {
   float ax, ay, az, cs, sn, ok, pad0, pad1;
 };
 
+// One launch for the two independent preparation steps: blocks [0, ncone) compute super-tile
+// cones (block 0 also clears the coarse-region counters), the rest derive the per-Gaussian records.
 __global__ void __launch_bounds__(kBinThreads)
-bincone_kernel(const float *__restrict__ rays, const int H, const int W, const int nstx,
-               ConeRec *__restrict__ cones /* [B][nst] */) {
+prep_cone_kernel(const float *__restrict__ rays, const int H, const int W, const int nstx, const int nst, const int B,
+                 ConeRec *__restrict__ cones /* [B][nst] */, int *__restrict__ c_count, const int n_count,
+                 const float *__restrict__ mus, const float *__restrict__ isg, const float *__restrict__ cam_fwd,
+                 const int N, const int P, const float thr_act, const int iso_in, float4 *__restrict__ cull,
+                 float4 *__restrict__ evr, float4 *__restrict__ ms) {
   __shared__ float red[16 * 4];
   const int tid = threadIdx.x;
-  const int stx = blockIdx.x % nstx, sty = blockIdx.x / nstx, b = blockIdx.y;
+  const int ncone = nst * B;
+  if ((int)blockIdx.x >= ncone) {
+    const int g = ((int)blockIdx.x - ncone) * kBinThreads + tid;
+    if (g < P) prep_one(g, mus, isg, cam_fwd, N, thr_act, iso_in, cull, evr, ms);
+    return;
+  }
+  if (blockIdx.x == 0)
+    for (int i = tid; i < n_count; i += kBinThreads) c_count[i] = 0;
+  const int b = blockIdx.x / nst, bin = blockIdx.x - b * nst;
+  const int stx = bin % nstx, sty = bin / nstx;
   const int x0 = stx * kST, y0 = sty * kST;
   const Cone c = region_cone(rays, b, H, W, x0, y0, min(kST, W - x0), min(kST, H - y0), red, tid);
-  if (tid == 0) cones[(size_t)b * gridDim.x + blockIdx.x] = ConeRec{c.ax, c.ay, c.az, c.cs, c.sn, c.ok ? 1.f : 0.f, 0.f, 0.f};
+  if (tid == 0) cones[blockIdx.x] = ConeRec{c.ax, c.ay, c.az, c.cs, c.sn, c.ok ? 1.f : 0.f, 0.f, 0.f};
 }
 
 __device__ __forceinline__ Cone load_cone(const ConeRec &r) {
@@ -1134,7 +1146,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     // items per thread go through the stages together -- LDS keys, then one 16-byte gather per
     // slot (isotropic Gaussians need nothing more), then arithmetic and the 16-byte stores -- so
     // a thread has up to 4 * kEpiU gathers in flight instead of one dependent chain per slot.
-    constexpr int kEpiU = 4;
+#ifndef VOGE_EPI_U
+#define VOGE_EPI_U 4
+#endif
+    constexpr int kEpiU = VOGE_EPI_U;
     const int th = min(TH, H - ty * TH);
     const int ipr = row_items >> 2;
     const int nitem = th * ipr;
@@ -1408,19 +1423,19 @@ static int trace_topk_fwd_impl(const int iso_in, const float *mus, const float *
   const int P = B * N;
   TraceWs ws;
   trace_ws_layout(B, N, H, W, workspace, &ws);
-  if (P > 0) {
-    hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P,
-                       thr_act, iso_in, ws.cull, ws.evr, ws.ms);
+  // The coarse level pays off once the per-super-tile scans of all N dominate (nst * N tests);
+  // tiny problems skip its launch.
+  const bool coarse = (size_t)ws.nstx * ws.nsty * (size_t)N >= ((size_t)1 << 21);
+  {
+    const int nst = ws.nstx * ws.nsty;
+    const int nprep = (P + kBinThreads - 1) / kBinThreads;
+    hipLaunchKernelGGL(prep_cone_kernel, dim3(nst * B + nprep), dim3(kBinThreads), 0, st, rays, H, W, ws.nstx, nst, B,
+                       ws.cones, ws.c_count, B * ws.nst0x * ws.nst0y, mus, isigmas, cam_fwd, N, P, thr_act, iso_in, ws.cull,
+                       ws.evr, ws.ms);
     int rc = launch_status();
     if (rc) return rc;
   }
-  // The coarse level pays off once the per-super-tile scans of all N dominate (nst * N tests);
-  // tiny problems skip its two launches.
-  const bool coarse = (size_t)ws.nstx * ws.nsty * (size_t)N >= ((size_t)1 << 21);
-  hipLaunchKernelGGL(bincone_kernel, dim3(ws.nstx * ws.nsty, B), dim3(kBinThreads), 0, st, rays, H, W, ws.nstx, ws.cones);
   if (coarse) {
-    hipError_t e = hipMemsetAsync(ws.c_count, 0, sizeof(int) * (size_t)B * ws.nst0x * ws.nst0y, st);
-    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bin0_kernel, dim3(ws.nst0x * ws.nst0y * kBin0Split, B), dim3(kBinThreads), 0, st, ws.cull, ws.cones,
                        ws.nstx, ws.nsty, N, ws.nst0x, ws.c_count, ws.c_id);
   }
