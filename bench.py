@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--config", default="cfg3_50k_512")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="single GPU: use the multi-GPU launch scheme (forward graph / eager exchange / backward graph)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU oracle work for cpu_baseline")
     return ap.parse_args()
 
@@ -130,24 +132,70 @@ def main():
     # step on the same (static) tensors; eager launches remain available with --no-graph.
     run = step
     graphed = False
-    if not args.no_graph and world == 1:
+    launch = "eager"
+
+    def warm_side_stream(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+    if not args.no_graph and world == 1 and not args.split_graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+            warm_side_stream(step)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 step()
             graph.replay()
             torch.cuda.synchronize()
-            run, graphed = graph.replay, True
+            run, graphed, launch = graph.replay, True, "hip graph replay"
         except Exception as e:  # pragma: no cover - depends on the runtime
             print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
+            run = step
+    elif not args.no_graph:
+        # Multi-GPU: the local compute is two HIP graphs -- band forward, band backward -- and the
+        # two exchanges (all_gather of image rows, all_reduce of the gradients) run eagerly between
+        # and after them, so no collective is ever captured.  The loss is sum(image): every rank
+        # owns the loss of its band, whose upstream gradient is a constant tensor of ones.
+        try:
+            def fwd_only():
+                frag = renderer(gm, R=R, T=T, **({} if rows is None else {"rows": rows}))
+                return to_white_background(frag, colors)
+
+            def eager_once():
+                b = fwd_only()
+                torch.autograd.grad(b, params, torch.ones_like(b))
+            warm_side_stream(eager_once)
+            g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fwd):
+                band_static = fwd_only()
+            ones_static = torch.ones_like(band_static)
+            with torch.cuda.graph(g_bwd, pool=g_fwd.pool()):
+                grads_static = torch.autograd.grad(band_static, params, ones_static)
+            for p_, g_ in zip(params, grads_static):
+                p_.grad = g_
+
+            def run_split():
+                g_fwd.replay()
+                img = gather_rows(band_static.detach(), H)      # eager all_gather (no-op on one GPU)
+                loss = img.sum()                                    # the full-image loss every rank holds
+                g_bwd.replay()
+                if world > 1:
+                    allreduce_grads(params)                         # eager all_reduce, in place on .grad
+                return loss
+            run_split()
+            torch.cuda.synchronize()
+            run, graphed = run_split, True
+            launch = "hip graphs (band forward, band backward) + eager all_gather / all_reduce"
+        except Exception as e:  # pragma: no cover - depends on the runtime
+            print(f"[bench] split HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            for p_ in params:
+                p_.grad = None
             run = step
 
     for _ in range(args.warmup):
@@ -172,7 +220,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {N} random Gaussians, {H}x{W}, K={K}, max_point_per_bin=-1, "
                                f"fwd+bwd (grads to verts, sigmas, colors)",
-                   "launch": "hip graph replay" if graphed else "eager",
+                   "launch": launch,
                    "parallelism": "1 gpu" if world == 1 else f"pixel-row bands x{world}, all_gather(image)+all_reduce(grads)"},
     }
 
