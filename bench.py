@@ -83,11 +83,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the VoGE hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VOGE_BENCH_BACKEND=gloo lets several ranks share one GPU (a functional check of the multi-GPU
+    # launch scheme on a single-GPU box); the real runs use RCCL, one rank per GPU.
+    backend = os.environ.get("VOGE_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from voge_amd import _lib, ops, scenes
     from voge_amd.Meshes import GaussianMeshes
