@@ -967,9 +967,6 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     ts_fill += tsb - tsa;
 #endif
     // consume
-#ifdef VOGE_ABL_CONSUME
-    wdone = true;
-#endif
     if (!wdone) {
       for (int c0 = 0; c0 < nbuf && !wdone; c0 += 64) {
         const int i = c0 + lane;
