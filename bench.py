@@ -100,7 +100,7 @@ def main():
     from voge_amd.Meshes import GaussianMeshes
     from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
     from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
-    from voge_amd.distributed import allreduce_grads, gather_rows, row_band
+    from voge_amd.distributed import allreduce_grads, gather_rows, gather_rows_async, row_band
     _lib.load()
 
     N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[args.config]
@@ -165,8 +165,8 @@ def main():
             run = step
     elif not args.no_graph:
         # Multi-GPU: the local compute is two HIP graphs -- band forward, band backward -- and the
-        # two exchanges (all_gather of image rows, all_reduce of the gradients) run eagerly between
-        # and after them, so no collective is ever captured.  The loss is sum(image): every rank
+        # two exchanges (all_gather of image rows -- asynchronous, overlapping the backward graph --
+        # and all_reduce of the gradients) run eagerly, so no collective is ever captured.  The loss is sum(image): every rank
         # owns the loss of its band, whose upstream gradient is a constant tensor of ones.
         try:
             def fwd_only():
@@ -188,12 +188,11 @@ def main():
 
             def run_split():
                 g_fwd.replay()
-                img = gather_rows(band_static.detach(), H)      # eager all_gather (no-op on one GPU)
-                loss = img.sum()                                    # the full-image loss every rank holds
-                g_bwd.replay()
+                finish = gather_rows_async(band_static.detach(), H)   # all_gather starts (no-op on one GPU) ...
+                g_bwd.replay()                                          # ... and overlaps the band's backward
                 if world > 1:
-                    allreduce_grads(params)                         # eager all_reduce, in place on .grad
-                return loss
+                    allreduce_grads(params)                             # eager all_reduce, in place on .grad
+                return finish().sum()                                   # the full-image loss every rank holds
             run_split()
             torch.cuda.synchronize()
             run, graphed = run_split, True

@@ -25,7 +25,7 @@ def _free_port():
 def _worker(rank, world, port, H, W, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from voge_amd.distributed import allreduce_grads, gather_rows, row_band
+    from voge_amd.distributed import allreduce_grads, gather_rows, gather_rows_async, row_band
     sc = cuboid_scene()
     R, T = camera_np.look_at_view_transform(sc["dist"], sc["elev"], sc["azim"])
     r0, r1 = row_band(H, rank, world)
@@ -41,6 +41,8 @@ def _worker(rank, world, port, H, W, out):
     band = (gathered * (wt * valid)[..., None]).sum(-2)                         # merge of the band
     img = gather_rows(band, H)
     assert img.shape == (1, H, W, 3)
+    finish = gather_rows_async(band.detach(), H)          # the overlapped form bench.py uses
+    assert torch.equal(finish(), img.detach())
     img[:, r0:r1].sum().backward()          # each rank owns the loss of its band
     allreduce_grads([colors])
     if rank == 0:

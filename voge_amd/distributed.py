@@ -49,6 +49,29 @@ def gather_rows(band, H, group=None):
     return _GatherRows.apply(band, H, group)
 
 
+def gather_rows_async(band, H, group=None):
+    """Start the all_gather of the row bands and return `finish() -> [B,H,W,C]`.  No autograd (the
+    caller's loss is local to its band); the collective runs on the backend's own stream, so
+    whatever is launched before finish() -- the band's backward -- overlaps it."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return lambda: band
+    world = dist.get_world_size(group)
+    B, h, W, C = band.shape
+    hmax = -(-H // world)
+    if h == hmax:
+        pad = band.contiguous()
+    else:
+        pad = band.new_zeros((B, hmax, W, C))
+        pad[:, :h] = band
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    work = dist.all_gather(parts, pad, group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        return torch.cat([parts[r][:, : row_band(H, r, world)[1] - row_band(H, r, world)[0]] for r in range(world)], dim=1)
+    return finish
+
+
 def allreduce_grads(tensors, group=None):
     """Sum the per-Gaussian gradients of all ranks with ONE flat all-reduce (bucketed: the
     concatenated [verts, sigmas, colours] gradient is ~N*15 floats, 3 MB at 50k Gaussians)."""
