@@ -987,7 +987,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
         }
         auto commit = [&](const PairOut &o, const int s, const bool on) {
           const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)(L.id[s] + b * N);
-          const bool take = on && valid && (o.act < thr_act) && (o.len < VOGE_SENT_LEN) && (key < worst);
+          const bool take = on & valid & (o.act < thr_act) & (o.len < VOGE_SENT_LEN) & (key < worst);
 #ifdef VOGE_SWEEP_STATS
           {
             const bool app = take && (cnt < K) && (key >= tail);
@@ -1021,6 +1021,11 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 #pragma unroll
             for (int q = 0; q < kTrip; ++q)
               o[q] = pair_eval_iso(cc[q].x, cc[q].y, cc[q].z, cc[q].w, dx, dy, dz, qxx, qyy, qzz);
+            // The evaluations must finish as one block of four interleaved chains: without this
+            // the compiler sinks each one behind its own commit's predicate and the wave (alone on
+            // its SIMD) runs four dependent chains back to back.
+#pragma unroll
+            for (int q = 0; q < kTrip; ++q) asm volatile("" : "+v"(o[q].len), "+v"(o[q].act));
 #pragma unroll
             for (int q = 0; q < kTrip; ++q) commit(o[q], min(s0 + q, s_end - 1), s0 + q < s_end);
           }
