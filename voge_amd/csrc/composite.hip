@@ -44,7 +44,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define FAST_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #endif
 
-constexpr int kCompThreads = 256;
+#ifndef VOGE_COMP_MAXT
+#define VOGE_COMP_MAXT 256
+#endif
+constexpr int kCompThreads = VOGE_COMP_MAXT;
 constexpr float kInvNorm = 1.6487212707001282f;  // 1 / exp(-0.5), Aggregation.py:79
 constexpr float kRsqrtPi = 0.5641895835477563f;
 #ifndef VOGE_KSAT
@@ -117,7 +120,7 @@ struct CompLds {
 };
 // dynamic LDS: CompLds, then the padded per-pixel arrays len / sp / E (/ u in the backward),
 // `rows` floats each
-__host__ __device__ inline int comp_rows(const int K) { return ((kCompThreads / K) * comp_row_stride(K) + 3) & ~3; }
+__host__ __device__ inline int comp_rows(const int K) { return ((kCompThreads / K) * comp_row_stride(K) + 3) & ~3; }   // sized for the largest workgroup
 __host__ __device__ inline size_t comp_lds_bytes(const int K, const bool bwd) {
   return sizeof(CompLds) + sizeof(float) * (size_t)comp_rows(K) * (bwd ? 4 : 3);
 }
@@ -382,8 +385,13 @@ using namespace voge;
 static int launch_composite(int mode, const int32_t *idx, const float *act, const float *len, const float *dsd,
                             const float *w_in, const float *g_weight, float occ, long npix, int K, float *o0, float *o1,
                             float *o2, int64_t *valid_num, voge_stream_t stream) {
-  const int ppw = kCompThreads / K;
-  const dim3 grid((unsigned)((npix + ppw - 1) / ppw)), block(kCompThreads);
+#ifndef VOGE_COMP_T
+#define VOGE_COMP_T 256
+#endif
+  // workgroup size: the smallest multiple of 64 that is >= VOGE_COMP_T and holds one pixel
+  const int threads = (K <= VOGE_COMP_T) ? VOGE_COMP_T : kCompThreads;
+  const int ppw = threads / K;
+  const dim3 grid((unsigned)((npix + ppw - 1) / ppw)), block(threads);
   const size_t lds = comp_lds_bytes(K, mode != 0);
   hipStream_t st = (hipStream_t)stream;
   if (mode == 2)
