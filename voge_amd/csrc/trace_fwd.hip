@@ -180,6 +180,7 @@ __device__ __forceinline__ void block_reduce16(float *red, const int wave, const
 }
 
 // Bounding cone of the rays of a pixel rectangle, computed by a whole 1024-thread workgroup.
+template <int kCU>
 __device__ __forceinline__ Cone region_cone(const float *__restrict__ rays, const int b, const int H, const int W,
                                             const int x0, const int y0, const int rw, const int rh, float *red,
                                             const int tid) {
@@ -188,7 +189,6 @@ __device__ __forceinline__ Cone region_cone(const float *__restrict__ rays, cons
   const float inv_rw = 1.0f / (float)rw;
   // kCU rays per thread are loaded before any is used: a 128 x 128 region is 16 rays per thread
   // and two passes, i.e. 32 dependent round trips if taken one at a time
-  constexpr int kCU = 8;
   auto load_rays = [&](const int i0, float (&rx)[kCU], float (&ry)[kCU], float (&rz)[kCU]) {
 #pragma unroll
     for (int u = 0; u < kCU; ++u) {
@@ -249,8 +249,8 @@ struct ConeRec {
   float ax, ay, az, cs, sn, ok, pad0, pad1;
 };
 
-// One launch for the two independent preparation steps: blocks [0, ncone) compute super-tile
-// cones (block 0 also clears the coarse-region counters), the rest derive the per-Gaussian records.
+// One launch for the two independent preparation steps: the first blocks derive the per-Gaussian
+// records, the rest compute super-tile cones (the first of them also clears the region counters).
 __global__ void __launch_bounds__(kBinThreads)
 prep_cone_kernel(const float *__restrict__ rays, const int H, const int W, const int nstx, const int nst, const int B,
                  ConeRec *__restrict__ cones /* [B][nst] */, int *__restrict__ c_count, const int n_count,
@@ -259,19 +259,20 @@ prep_cone_kernel(const float *__restrict__ rays, const int H, const int W, const
                  float4 *__restrict__ evr, float4 *__restrict__ ms) {
   __shared__ float red[16 * 4];
   const int tid = threadIdx.x;
-  const int ncone = nst * B;
-  if ((int)blockIdx.x >= ncone) {
-    const int g = ((int)blockIdx.x - ncone) * kBinThreads + tid;
+  const int nprep = (P + kBinThreads - 1) / kBinThreads;
+  if ((int)blockIdx.x < nprep) {     // record blocks first: they are the longer ones (fp64 eigenvalue)
+    const int g = (int)blockIdx.x * kBinThreads + tid;
     if (g < P) prep_one(g, mus, isg, cam_fwd, N, thr_act, iso_in, cull, evr, ms);
     return;
   }
-  if (blockIdx.x == 0)
+  const int cb = (int)blockIdx.x - nprep;
+  if (cb == 0)
     for (int i = tid; i < n_count; i += kBinThreads) c_count[i] = 0;
-  const int b = blockIdx.x / nst, bin = blockIdx.x - b * nst;
+  const int b = cb / nst, bin = cb - b * nst;
   const int stx = bin % nstx, sty = bin / nstx;
   const int x0 = stx * kST, y0 = sty * kST;
-  const Cone c = region_cone(rays, b, H, W, x0, y0, min(kST, W - x0), min(kST, H - y0), red, tid);
-  if (tid == 0) cones[blockIdx.x] = ConeRec{c.ax, c.ay, c.az, c.cs, c.sn, c.ok ? 1.f : 0.f, 0.f, 0.f};
+  const Cone c = region_cone<1>(rays, b, H, W, x0, y0, min(kST, W - x0), min(kST, H - y0), red, tid);   // 1 ray per thread
+  if (tid == 0) cones[cb] = ConeRec{c.ax, c.ay, c.az, c.cs, c.sn, c.ok ? 1.f : 0.f, 0.f, 0.f};
 }
 
 __device__ __forceinline__ Cone load_cone(const ConeRec &r) {
