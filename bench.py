@@ -48,7 +48,7 @@ def stage_bytes(P, npix, K, C=3, iso=False):
     g = 16 if iso else 48
     return {
         "trace_fwd": P * g + npix * 12 + npix * K * 16,
-        "composite_fwd": npix * K * 12 + npix * K * 4 + npix * 8,
+        "composite_fwd": npix * K * 12 + npix * 4 + npix * K * 4 + npix * 8,     # act,len,dsd + hit count -> weight, valid_num
         # fused merge+silhouette+blend: read idx,w + colours, write rgb,img / read idx,w,rgb,g_img, write g_w,g_col
         "shade_fwd": npix * K * 8 + P * 4 * C + 2 * npix * 4 * C,
         "shade_bwd": npix * K * 8 + 2 * npix * 4 * C + P * 4 * C + npix * K * 4 + P * 4 * C,
@@ -268,7 +268,7 @@ def main():
             calls = {
                 "trace_fwd": lambda: trace_fwd_fn(P(mus), P(isg), P(rays), None, 1, N, H, W, K, thr_act, P(ws),
                                                              ws.numel(), P(o_i), P(o_l), P(o_a), P(o_d), P(o_c), st),
-                "composite_fwd": lambda: lib.voge_composite_fwd(P(sel[0]), P(sel[2]), P(sel[1]), P(sel[3]), 1.0, npix, K,
+                "composite_fwd": lambda: lib.voge_composite_fwd(None, P(sel[0].voge_hit_count), P(sel[2]), P(sel[1]), P(sel[3]), 1.0, npix, K,
                                                                 P(g3[0]), P(vn), st),
                 "shade_fwd": lambda: lib.voge_shade_fwd(P(colors), P(idx), P(w), P(vn), P(bg), -1.0, npix, K, 3, N, 1, P(rgb),
                                                         P(out3), None, P(wsum), st),

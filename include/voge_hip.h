@@ -138,8 +138,10 @@ size_t voge_trace_bwd_iso_workspace_bytes(int P);
  * (get_cross_activation :30-51 + assign2weight :54-79), without any [npix,K,K] temporary.
  *   w_m = exp(-occ * sum_k exp(-act_k) * (erf((len_m-len_k)*sqrt(dsd_k+1e-10)) + 1)/2)
  *         * exp(-act_m) / exp(-0.5);   valid_num = #(idx >= 0)
+ * cnt: NULL, or [npix] int32 = #(idx >= 0) per pixel as the trace forward already produced it
+ * (out_cnt); idx may then be NULL and is not read (a quarter of this call's input bytes).
  */
-int voge_composite_fwd(const int32_t *idx, const float *act, const float *len,
+int voge_composite_fwd(const int32_t *idx, const int32_t *cnt, const float *act, const float *len,
                        const float *dsd, float occ, long npix, int K, float *weight,
                        int64_t *valid_num, voge_stream_t stream);
 

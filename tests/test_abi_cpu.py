@@ -63,7 +63,7 @@ def test_version_errors_and_sizes_without_gpu(lib):
     assert lib.voge_trace_workspace_bytes(2, 1000, 64, 64) > lib.voge_trace_workspace_bytes(1, 1000, 64, 64)
     assert lib.voge_trace_bwd_workspace_bytes(1000) == 1000 * 112
     # argument validation happens before any HIP call
-    assert lib.voge_composite_fwd(None, None, None, None, 1.0, 10, 0, None, None, None) == -1
+    assert lib.voge_composite_fwd(None, None, None, None, None, 1.0, 10, 0, None, None, None) == -1
     assert lib.voge_trace_topk_fwd(None, None, None, None, 1, 10, 8, 8, 1000, 4.6, None, 0, None, None, None, None, None, None) == -3
 
 

@@ -131,7 +131,8 @@ template <int MODE>
 __global__ void __launch_bounds__(kCompThreads)
 composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
                  const float *__restrict__ len, const float *__restrict__ dsd,
-                 const float *__restrict__ w_in, const float *__restrict__ g_weight, const float occ, const long npix, const int K,
+                 const float *__restrict__ w_in, const float *__restrict__ g_weight, const int32_t *__restrict__ cnt_in,
+                 const float occ, const long npix, const int K,
                  const int ppw, float *__restrict__ out0 /* weight | g_act */,
                  float *__restrict__ out1 /* g_len */, float *__restrict__ out2 /* g_dsd */,
                  int64_t *__restrict__ valid_num) {
@@ -161,7 +162,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
     em = FAST_EXP(-act[f]);
     lm = len[f];
     sm = FAST_SQRT(dsd[f] + 1e-10f);
-    if (BWD) gw = g_weight[f]; else id = idx[f];
+    if (BWD) gw = g_weight[f]; else if (cnt_in == nullptr) id = idx[f];
     if (HAVE_W) wgiven = w_in[f];
   }
   if (in_wg) {
@@ -189,7 +190,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   // Max and integer add are order independent: no determinism is lost.
   const int lane = tid & 63;
   const bool head = in_wg && (lane == 0 || k == 0);
-  if (!BWD) {
+  if (!BWD && cnt_in == nullptr) {
     const unsigned long long m = __ballot(id >= 0);
     const int lo = max(0, lane - k), hi = min(63, lane + (K - 1 - k));     // this pixel's lanes in the wave
     const unsigned long long seg = ((hi - lo == 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull) << lo);
@@ -225,7 +226,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   }
   __syncthreads();
   const float rwin_all = in_wg ? __int_as_float(L.rmaxi[p]) : 0.0f;
-  const int cnt_all = (!BWD && in_wg) ? L.cnt[p] : 0;
+  const int cnt_all = (!BWD && in_wg) ? (cnt_in != nullptr ? (active ? cnt_in[pix] : 0) : L.cnt[p]) : 0;
   const bool sorted = active && (L.unsorted[p] == 0);
   const float rwin = sorted ? rwin_all : 0.0f;   // 0: the windowed loops do nothing
 
@@ -383,7 +384,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
 using namespace voge;
 
 static int launch_composite(int mode, const int32_t *idx, const float *act, const float *len, const float *dsd,
-                            const float *w_in, const float *g_weight, float occ, long npix, int K, float *o0, float *o1,
+                            const float *w_in, const float *g_weight, const int32_t *cnt_in, float occ, long npix, int K, float *o0, float *o1,
                             float *o2, int64_t *valid_num, voge_stream_t stream) {
 #ifndef VOGE_COMP_T
 #define VOGE_COMP_T 256
@@ -395,25 +396,25 @@ static int launch_composite(int mode, const int32_t *idx, const float *act, cons
   const size_t lds = comp_lds_bytes(K, mode != 0);
   hipStream_t st = (hipStream_t)stream;
   if (mode == 2)
-    hipLaunchKernelGGL(composite_kernel<2>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, occ, npix, K, ppw, o0,
+    hipLaunchKernelGGL(composite_kernel<2>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, npix, K, ppw, o0,
                        o1, o2, valid_num);
   else if (mode == 1)
-    hipLaunchKernelGGL(composite_kernel<1>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, occ, npix, K, ppw, o0,
+    hipLaunchKernelGGL(composite_kernel<1>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, npix, K, ppw, o0,
                        o1, o2, valid_num);
   else
-    hipLaunchKernelGGL(composite_kernel<0>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, occ, npix, K, ppw, o0,
+    hipLaunchKernelGGL(composite_kernel<0>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, npix, K, ppw, o0,
                        o1, o2, valid_num);
   return launch_status();
 }
 
-extern "C" int voge_composite_fwd(const int32_t *idx, const float *act, const float *len,
+extern "C" int voge_composite_fwd(const int32_t *idx, const int32_t *cnt, const float *act, const float *len,
                                   const float *dsd, float occ, long npix, int K, float *weight,
                                   int64_t *valid_num, voge_stream_t stream) {
   if (npix < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K || K > kCompThreads) return VOGE_ERR_K_TOO_LARGE;
   if (npix == 0) return 0;
-  if (!idx || !act || !len || !dsd || !weight || !valid_num) return VOGE_ERR_BAD_ARG;
-  return launch_composite(0, idx, act, len, dsd, nullptr, nullptr, occ, npix, K, weight, nullptr, nullptr, valid_num, stream);
+  if ((!idx && !cnt) || !act || !len || !dsd || !weight || !valid_num) return VOGE_ERR_BAD_ARG;
+  return launch_composite(0, idx, act, len, dsd, nullptr, nullptr, cnt, occ, npix, K, weight, nullptr, nullptr, valid_num, stream);
 }
 
 extern "C" int voge_composite_bwd(const float *act, const float *len, const float *dsd, const float *weight,
@@ -423,6 +424,6 @@ extern "C" int voge_composite_bwd(const float *act, const float *len, const floa
   if (K > VOGE_MAX_K || K > kCompThreads) return VOGE_ERR_K_TOO_LARGE;
   if (npix == 0) return 0;
   if (!act || !len || !dsd || !g_weight || !g_act || !g_len || !g_dsd) return VOGE_ERR_BAD_ARG;
-  return launch_composite(weight ? 2 : 1, nullptr, act, len, dsd, weight, g_weight, occ, npix, K, g_act, g_len, g_dsd,
+  return launch_composite(weight ? 2 : 1, nullptr, act, len, dsd, weight, g_weight, nullptr, occ, npix, K, g_act, g_len, g_dsd,
                           nullptr, stream);
 }

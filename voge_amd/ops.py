@@ -88,6 +88,8 @@ class _RayTraceVoGE(torch.autograd.Function):
             ctx.save_for_backward(mus_c, isg_c, rays_c)
             ctx.sel_idx = sel_idx
         ctx.cnt = cnt
+        if cnt is not None:
+            sel_idx.voge_hit_count = cnt     # lets aggregation() skip its own pass over idx
         ctx.mark_non_differentiable(sel_idx)
         ctx.set_materialize_grads(False)
         return sel_idx, sel_len, sel_act, sel_dsd
@@ -158,6 +160,8 @@ class _RayTraceVoGEIso(torch.autograd.Function):
         ctx.save_for_backward(mus_c, a_c, rays_c)
         ctx.sel_idx = sel_idx      # may later be rewritten in place by merge_final; cnt marks the filled slots
         ctx.cnt = cnt
+        if cnt is not None:
+            sel_idx.voge_hit_count = cnt     # lets aggregation() skip its own pass over idx
         ctx.mark_non_differentiable(sel_idx)
         ctx.set_materialize_grads(False)
         return sel_idx, sel_len, sel_act, sel_dsd
@@ -199,6 +203,11 @@ class _Composite(torch.autograd.Function):
     def forward(ctx, sel_idx, sel_act, sel_len, sel_dsd, occ):
         lib = _lib.load()
         idx = _dev(sel_idx, torch.int32, "sel_idx")
+        # the trace forward leaves its per-pixel hit count on the index tensor it returns
+        # (voge_hit_count): valid_num then needs no pass over idx
+        cnt = getattr(sel_idx, "voge_hit_count", None)
+        if cnt is not None and (cnt.shape != idx.shape[:-1] or cnt.device != idx.device):
+            cnt = None
         act = _dev(sel_act, torch.float32, "sel_act")
         ln = _dev(sel_len, torch.float32, "sel_len")
         dsd = _dev(sel_dsd, torch.float32, "sel_dsd")
@@ -207,7 +216,7 @@ class _Composite(torch.autograd.Function):
         weight = torch.empty_like(act)
         valid = torch.empty(idx.shape[:-1], dtype=torch.int64, device=idx.device)
         with torch.cuda.device(idx.device):
-            rc = lib.voge_composite_fwd(_p(idx), _p(act), _p(ln), _p(dsd), float(occ), npix, K, _p(weight),
+            rc = lib.voge_composite_fwd(_p(idx), _p(cnt), _p(act), _p(ln), _p(dsd), float(occ), npix, K, _p(weight),
                                         _p(valid), _stream())
         _lib.check(rc, "voge_composite_fwd")
         ctx.save_for_backward(act, ln, dsd, weight)
