@@ -178,10 +178,11 @@ def main():
                 torch.autograd.grad(b, params, torch.ones_like(b))
             warm_side_stream(eager_once)
             g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fwd):
+            # thread_local: RCCL's watchdog thread polls events while we capture
+            with torch.cuda.graph(g_fwd, capture_error_mode="thread_local"):
                 band_static = fwd_only()
             ones_static = torch.ones_like(band_static)
-            with torch.cuda.graph(g_bwd, pool=g_fwd.pool()):
+            with torch.cuda.graph(g_bwd, pool=g_fwd.pool(), capture_error_mode="thread_local"):
                 grads_static = torch.autograd.grad(band_static, params, ones_static)
             for p_, g_ in zip(params, grads_static):
                 p_.grad = g_
