@@ -149,9 +149,11 @@ int voge_composite_fwd(const int32_t *idx, const int32_t *cnt, const float *act,
  * Composite backward (the reference relies on autograd through Aggregation.py:49,70,74,77).
  * g_weight [npix,K] -> g_act, g_len, g_dsd [npix,K] (fully written).  weight = the forward's
  * output for the same inputs (saves the backward recomputing it); NULL -> recomputed.
+ * valid_num = the forward's valid_num (NULL allowed): workgroups whose pixels all have none skip
+ * their loads and write zeros (as does the forward when it is given cnt).
  */
 int voge_composite_bwd(const float *act, const float *len, const float *dsd, const float *weight,
-                       const float *g_weight, float occ, long npix, int K, float *g_act,
+                       const int64_t *valid_num, const float *g_weight, float occ, long npix, int K, float *g_act,
                        float *g_len, float *g_dsd, voge_stream_t stream);
 
 /*

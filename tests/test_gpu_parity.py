@@ -283,7 +283,7 @@ def test_composite_random_vs_oracle(hip_lib, K):
     lib = _lib.load()
     tg = t(gw.reshape(shape))
     outs = [torch.empty_like(ta) for _ in range(3)]
-    rc = lib.voge_composite_bwd(ta.data_ptr(), tl.data_ptr(), td.data_ptr(), None, tg.data_ptr(), 0.7, npix, K,
+    rc = lib.voge_composite_bwd(ta.data_ptr(), tl.data_ptr(), td.data_ptr(), None, None, tg.data_ptr(), 0.7, npix, K,
                                 *[o.data_ptr() for o in outs], torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     for got, ref in zip(outs, (ra, rl, rd)):
