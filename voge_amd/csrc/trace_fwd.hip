@@ -918,6 +918,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   while (base < src_n) {
     int nbuf = 0;
     bool chunk_iso = true;   // every staged candidate of this buffer is isotropic (wave-uniform)
+    bool chunk_gen = true;   // ... or every one is anisotropic
 #ifdef VOGE_SWEEP_TIMES
     const unsigned long long tsa = wall_clock64();
 #endif
@@ -934,6 +935,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       const bool keep = prefiltered ? (id >= 0) : cone_keep(c, gcone);
       const unsigned long long m = __ballot(keep);
       chunk_iso = chunk_iso && __all(!keep || (mrec.w == mrec.w));
+      chunk_gen = chunk_gen && __all(!keep || !(mrec.w == mrec.w));
       if (lane == 0) L.wcnt[par][wave] = __popcll(m);
       __syncthreads();
       int off = nbuf, tot = 0;
@@ -1025,6 +1027,27 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             // The evaluations must finish as one block of four interleaved chains: without this
             // the compiler sinks each one behind its own commit's predicate and the wave (alone on
             // its SIMD) runs four dependent chains back to back.
+#pragma unroll
+            for (int q = 0; q < kTrip; ++q) asm volatile("" : "+v"(o[q].len), "+v"(o[q].act));
+#pragma unroll
+            for (int q = 0; q < kTrip; ++q) commit(o[q], min(s0 + q, s_end - 1), s0 + q < s_end);
+          }
+          m = 0ull;
+        } else if (WAVES == 1 && chunk_gen) {
+          // the same contiguous-range loop for an all-anisotropic chunk (full records from LDS)
+          const int s_end = c0 + __popcll(m);
+          for (int s0 = c0; s0 < s_end; s0 += kTrip) {
+#ifdef VOGE_SWEEP_STATS
+            ++st_trips;
+#endif
+            PairOut o[kTrip];
+#pragma unroll
+            for (int q = 0; q < kTrip; ++q) {
+              const int sidx = min(s0 + q, s_end - 1);
+              const float4 cc = L.ms[sidx];
+              o[q] = pair_eval_gen(cc.x, cc.y, cc.z, unpack_eval(L.ev[sidx * 3], L.ev[sidx * 3 + 1], L.ev[sidx * 3 + 2]), dx, dy,
+                                   dz, qxx, qyy, qzz, qxy, qxz, qyz);
+            }
 #pragma unroll
             for (int q = 0; q < kTrip; ++q) asm volatile("" : "+v"(o[q].len), "+v"(o[q].act));
 #pragma unroll
