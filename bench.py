@@ -275,7 +275,7 @@ def main():
                                                         P(out3), None, P(wsum), st),
                 "shade_bwd": lambda: lib.voge_shade_bwd(P(colors), P(idx), P(w), P(vn), P(rgb), P(wsum), P(bg), -1.0, P(g_img), H, W, K,
                                                         3, N, P(g_attr), P(g3[0]), st),
-                "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), P(vn), P(g_w), 1.0, npix, K, P(g3[0]),
+                "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), P(sel[0].voge_hit_count), P(g_w), 1.0, npix, K, P(g3[0]),
                                                                 P(g3[1]), P(g3[2]), st),
                 "trace_bwd": lambda: trace_bwd_fn(P(mus), P(isg), P(rays), P(sel[0]), P(vn32), P(w), P(w), P(w), N, H, W, K,
                                                         P(ws_b), ws_b.numel(), None, P(g_mu), P(g_A), st),

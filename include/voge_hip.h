@@ -138,8 +138,9 @@ size_t voge_trace_bwd_iso_workspace_bytes(int P);
  * (get_cross_activation :30-51 + assign2weight :54-79), without any [npix,K,K] temporary.
  *   w_m = exp(-occ * sum_k exp(-act_k) * (erf((len_m-len_k)*sqrt(dsd_k+1e-10)) + 1)/2)
  *         * exp(-act_m) / exp(-0.5);   valid_num = #(idx >= 0)
- * cnt: NULL, or [npix] int32 = #(idx >= 0) per pixel as the trace forward already produced it
- * (out_cnt); idx may then be NULL and is not read (a quarter of this call's input bytes).
+ * cnt: NULL, or [npix] int32 = the trace forward's out_cnt for the same lists (slots k >= cnt are
+ * its sentinels): valid_num = cnt, idx may be NULL and is not read, slots beyond cnt are not
+ * loaded at all and workgroups whose pixels are all empty only write zeros.
  */
 int voge_composite_fwd(const int32_t *idx, const int32_t *cnt, const float *act, const float *len,
                        const float *dsd, float occ, long npix, int K, float *weight,
@@ -149,11 +150,11 @@ int voge_composite_fwd(const int32_t *idx, const int32_t *cnt, const float *act,
  * Composite backward (the reference relies on autograd through Aggregation.py:49,70,74,77).
  * g_weight [npix,K] -> g_act, g_len, g_dsd [npix,K] (fully written).  weight = the forward's
  * output for the same inputs (saves the backward recomputing it); NULL -> recomputed.
- * valid_num = the forward's valid_num (NULL allowed): workgroups whose pixels all have none skip
- * their loads and write zeros (as does the forward when it is given cnt).
+ * cnt (NULL allowed) = the trace forward's out_cnt, as in voge_composite_fwd: slots k >= cnt are
+ * the trace's sentinels and are not loaded; workgroups whose pixels are all empty write zeros.
  */
 int voge_composite_bwd(const float *act, const float *len, const float *dsd, const float *weight,
-                       const int64_t *valid_num, const float *g_weight, float occ, long npix, int K, float *g_act,
+                       const int32_t *cnt, const float *g_weight, float occ, long npix, int K, float *g_act,
                        float *g_len, float *g_dsd, voge_stream_t stream);
 
 /*

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(kCompThreads)
 composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
                  const float *__restrict__ len, const float *__restrict__ dsd,
                  const float *__restrict__ w_in, const float *__restrict__ g_weight, const int32_t *__restrict__ cnt_in,
-                 const int64_t *__restrict__ vn_in, const float occ, const long npix, const int K,
+                 const float occ, const long npix, const int K,
                  const int ppw, float *__restrict__ out0 /* weight | g_act */,
                  float *__restrict__ out1 /* g_len */, float *__restrict__ out2 /* g_dsd */,
                  int64_t *__restrict__ valid_num) {
@@ -155,13 +155,14 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
   const int RS = comp_row_stride(K);
   const int PAD = comp_pad(K);
   const int bi = (in_wg ? p : 0) * RS + PAD + (in_wg ? k : 0);   // this slot's entry in the padded arrays
-  // Pixels without a single assigned slot (the caller says so: the trace's hit count forward, the
-  // forward's valid_num backward) have E = 0 everywhere: weights and all three gradients are zero.
-  // A workgroup that covers only such pixels writes its zeros and leaves before loading anything
-  // (a sparse frame like cfg3 has ~40 % empty pixels).
-  if ((!BWD && cnt_in != nullptr) || (BWD && vn_in != nullptr)) {
-    const bool some = active && (BWD ? (vn_in[pix] > 0) : (cnt_in[pix] > 0));
-    if (!__syncthreads_or(some)) {
+  // cnt_in (optional) = the trace's per-pixel hit count: slots k >= cnt hold the trace's sentinels
+  // (len = act = 1e10, dsd = 0, idx = -1), i.e. E = 0.  Those slots are not even loaded, and a
+  // workgroup whose pixels are all empty writes its zeros and leaves before touching anything else
+  // (a sparse frame like cfg3 has ~40 % empty pixels and ~25 % empty slots in the others).
+  int lead = K;
+  if (cnt_in != nullptr) {
+    lead = active ? min(K, max(0, cnt_in[pix])) : 0;
+    if (!__syncthreads_or(lead > 0)) {
       if (active) {
         out0[f] = 0.0f;
         if (BWD) { out1[f] = 0.0f; out2[f] = 0.0f; }
@@ -171,9 +172,9 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
     }
   }
   if (tid < ppw) { L.unsorted[tid] = 0; L.rmaxi[tid] = 0; L.cnt[tid] = 0; }
-  float lm = 0.f, sm = 1.f, em = 0.f, gw = 0.f, wgiven = 0.f;
+  float lm = VOGE_SENT_LEN, sm = 1e-5f, em = 0.f, gw = 0.f, wgiven = 0.f;   // what a sentinel slot evaluates to
   int id = -1;
-  if (active) {
+  if (active && k < lead) {
     em = FAST_EXP(-act[f]);
     lm = len[f];
     sm = FAST_SQRT(dsd[f] + 1e-10f);
@@ -399,8 +400,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
 using namespace voge;
 
 static int launch_composite(int mode, const int32_t *idx, const float *act, const float *len, const float *dsd,
-                            const float *w_in, const float *g_weight, const int32_t *cnt_in, const int64_t *vn_in,
-                            float occ, long npix, int K, float *o0, float *o1,
+                            const float *w_in, const float *g_weight, const int32_t *cnt_in, float occ, long npix, int K, float *o0, float *o1,
                             float *o2, int64_t *valid_num, voge_stream_t stream) {
 #ifndef VOGE_COMP_T
 #define VOGE_COMP_T 256
@@ -412,13 +412,13 @@ static int launch_composite(int mode, const int32_t *idx, const float *act, cons
   const size_t lds = comp_lds_bytes(K, mode != 0);
   hipStream_t st = (hipStream_t)stream;
   if (mode == 2)
-    hipLaunchKernelGGL(composite_kernel<2>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, cnt_in, vn_in, occ, npix, K, ppw, o0,
+    hipLaunchKernelGGL(composite_kernel<2>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, npix, K, ppw, o0,
                        o1, o2, valid_num);
   else if (mode == 1)
-    hipLaunchKernelGGL(composite_kernel<1>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, cnt_in, vn_in, occ, npix, K, ppw, o0,
+    hipLaunchKernelGGL(composite_kernel<1>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, npix, K, ppw, o0,
                        o1, o2, valid_num);
   else
-    hipLaunchKernelGGL(composite_kernel<0>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, cnt_in, vn_in, occ, npix, K, ppw, o0,
+    hipLaunchKernelGGL(composite_kernel<0>, grid, block, lds, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, npix, K, ppw, o0,
                        o1, o2, valid_num);
   return launch_status();
 }
@@ -430,16 +430,16 @@ extern "C" int voge_composite_fwd(const int32_t *idx, const int32_t *cnt, const 
   if (K > VOGE_MAX_K || K > kCompThreads) return VOGE_ERR_K_TOO_LARGE;
   if (npix == 0) return 0;
   if ((!idx && !cnt) || !act || !len || !dsd || !weight || !valid_num) return VOGE_ERR_BAD_ARG;
-  return launch_composite(0, idx, act, len, dsd, nullptr, nullptr, cnt, nullptr, occ, npix, K, weight, nullptr, nullptr, valid_num, stream);
+  return launch_composite(0, idx, act, len, dsd, nullptr, nullptr, cnt, occ, npix, K, weight, nullptr, nullptr, valid_num, stream);
 }
 
 extern "C" int voge_composite_bwd(const float *act, const float *len, const float *dsd, const float *weight,
-                                  const int64_t *valid_num, const float *g_weight, float occ, long npix, int K, float *g_act,
+                                  const int32_t *cnt, const float *g_weight, float occ, long npix, int K, float *g_act,
                                   float *g_len, float *g_dsd, voge_stream_t stream) {
   if (npix < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K || K > kCompThreads) return VOGE_ERR_K_TOO_LARGE;
   if (npix == 0) return 0;
   if (!act || !len || !dsd || !g_weight || !g_act || !g_len || !g_dsd) return VOGE_ERR_BAD_ARG;
-  return launch_composite(weight ? 2 : 1, nullptr, act, len, dsd, weight, g_weight, nullptr, valid_num, occ, npix, K, g_act, g_len, g_dsd,
+  return launch_composite(weight ? 2 : 1, nullptr, act, len, dsd, weight, g_weight, cnt, occ, npix, K, g_act, g_len, g_dsd,
                           nullptr, stream);
 }

@@ -219,7 +219,8 @@ class _Composite(torch.autograd.Function):
             rc = lib.voge_composite_fwd(_p(idx), _p(cnt), _p(act), _p(ln), _p(dsd), float(occ), npix, K, _p(weight),
                                         _p(valid), _stream())
         _lib.check(rc, "voge_composite_fwd")
-        ctx.save_for_backward(act, ln, dsd, weight, valid)
+        ctx.save_for_backward(act, ln, dsd, weight)
+        ctx.cnt = cnt      # the trace's hit count (or None): lets the backward skip empty slots / pixels
         ctx.occ = float(occ)
         ctx.mark_non_differentiable(valid)
         ctx.set_materialize_grads(False)
@@ -230,7 +231,7 @@ class _Composite(torch.autograd.Function):
         lib = _lib.load()
         if g_weight is None:
             return None, None, None, None, None
-        act, ln, dsd, weight, valid = ctx.saved_tensors
+        act, ln, dsd, weight = ctx.saved_tensors
         K = act.shape[-1]
         npix = act.numel() // max(K, 1)
         gw = _dev(g_weight, torch.float32, "grad_weight")
@@ -238,7 +239,7 @@ class _Composite(torch.autograd.Function):
         g_len = torch.empty_like(act)
         g_dsd = torch.empty_like(act)
         with torch.cuda.device(act.device):
-            rc = lib.voge_composite_bwd(_p(act), _p(ln), _p(dsd), _p(weight), _p(valid), _p(gw), ctx.occ, npix, K, _p(g_act), _p(g_len),
+            rc = lib.voge_composite_bwd(_p(act), _p(ln), _p(dsd), _p(weight), _p(ctx.cnt), _p(gw), ctx.occ, npix, K, _p(g_act), _p(g_len),
                                         _p(g_dsd), _stream())
         _lib.check(rc, "voge_composite_bwd")
         return None, g_act, g_len, g_dsd, None
