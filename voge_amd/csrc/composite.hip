@@ -397,60 +397,65 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
 
 
 // ------------------------------------------------------------------------------------------
-// Two slots per lane (forward, and backward with the forward's weights; sorted lists).
-// A lane owns the ALIGNED PAIR of slots (2q, 2q+1) of its pixel, so every pair of list entries
-// it reads from LDS serves four (row, column) evaluations instead of two, the lane's own pair is
-// the diagonal block (no LDS read at all), global loads / stores are 8 bytes wide and the
-// per-pixel scans run over half as many lanes.  The kernel above remains the reference form: it
-// handles the backward without given weights and is what VOGE_COMP_ONE_SLOT=1 builds select.
+// NS (2 or 4) consecutive slots per lane (forward, and backward with the forward's weights).
+// A lane owns the aligned group of slots [NS q, NS q + NS) of its pixel, so every pair of list
+// entries it reads from LDS serves 2 NS (row, column) evaluations, the lane's own group is the
+// diagonal block (registers only), global loads / stores are 4 NS bytes wide and the per-pixel
+// scans run over K / NS lanes.  The one-slot kernel above remains the reference form: it handles
+// the backward without given weights and is what VOGE_COMP_ONE_SLOT=1 builds select.
 // ------------------------------------------------------------------------------------------
-__host__ __device__ inline int comp2_lanes(const int K) { return (K + 1) >> 1; }
-__host__ __device__ inline int comp2_rows(const int K) { return ((kCompThreads / comp2_lanes(K)) * comp_row_stride(K) + 3) & ~3; }
-__host__ __device__ inline size_t comp2_lds_bytes(const int K, const bool bwd) {
-  return sizeof(CompLds) + sizeof(float) * (size_t)comp2_rows(K) * (bwd ? 4 : 3);
+__host__ __device__ inline int compn_lanes(const int K, const int NS) { return (K + NS - 1) / NS; }
+__host__ __device__ inline int compn_stride(const int K, const int NS) { return compn_lanes(K, NS) * NS + 2 * comp_pad(K); }
+__host__ __device__ inline int compn_rows(const int K, const int NS) {
+  return ((kCompThreads / compn_lanes(K, NS)) * compn_stride(K, NS) + 3) & ~3;
+}
+__host__ __device__ inline size_t compn_lds_bytes(const int K, const int NS, const bool bwd) {
+  return sizeof(CompLds) + sizeof(float) * (size_t)compn_rows(K, NS) * (bwd ? 4 : 3);
 }
 
-template <int MODE>   // 0: forward, 2: backward with weights
-__global__ void __launch_bounds__(kCompThreads)
-composite2_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
+#ifndef VOGE_COMP_WPE
+#define VOGE_COMP_WPE 1
+#endif
+template <int MODE, int NS>   // MODE 0: forward, 2: backward with weights
+__global__ void __launch_bounds__(kCompThreads) __attribute__((amdgpu_waves_per_eu(VOGE_COMP_WPE)))
+compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
                   const float *__restrict__ len, const float *__restrict__ dsd,
                   const float *__restrict__ w_in, const float *__restrict__ g_weight,
                   const int32_t *__restrict__ cnt_in, const float occ, const long npix, const int K, const int ppw,
                   float *__restrict__ out0 /* weight | g_act */, float *__restrict__ out1 /* g_len */,
                   float *__restrict__ out2 /* g_dsd */, int64_t *__restrict__ valid_num) {
   constexpr bool BWD = MODE != 0;
+  constexpr int NP = NS / 2;       // own aligned pairs
   extern __shared__ __attribute__((aligned(16))) unsigned char comp_smem[];
   CompLds &L = *reinterpret_cast<CompLds *>(comp_smem);
-  const int rows = comp2_rows(K);
+  const int rows = compn_rows(K, NS);
   float *const Llen = reinterpret_cast<float *>(comp_smem + sizeof(CompLds));
   float *const Lsp = Llen + rows;
   float *const LE = Lsp + rows;     // E (forward) or E * s' (backward)
   float *const Lu = LE + rows;      // backward only
   const int tid = threadIdx.x, lane = tid & 63;
-  const int LP = comp2_lanes(K);
+  const int LP = compn_lanes(K, NS);
   const int p = __float2int_rz(((float)tid + 0.5f) * __builtin_amdgcn_rcpf((float)LP)), q = tid - p * LP;
   const long pix = (long)blockIdx.x * ppw + p;
   const bool in_wg = p < ppw;
   const bool active = in_wg && (pix < npix);
-  const int k0 = 2 * q;
-  const bool has1 = k0 + 1 < K;
+  const int k0 = NS * q;
   const long f = pix * K + k0;
-  const int RS = comp_row_stride(K);
+  const int RS = compn_stride(K, NS);
   const int PAD = comp_pad(K);
-  const int d0 = (in_wg ? p : 0) * RS + PAD + (in_wg ? k0 : 0);   // own aligned pair in the padded arrays
-  const bool vec = (K & 1) == 0;                                    // pix*K + 2q even: 8-byte accesses
+  const int d0 = (in_wg ? p : 0) * RS + PAD + (in_wg ? k0 : 0);   // own group in the padded arrays (even index)
+  const bool vec = (K % NS) == 0;                                    // whole groups, 4 NS-byte aligned accesses
+  bool has[NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) has[a] = k0 + a < K;
   int lead = K;
   if (cnt_in != nullptr) {
     lead = active ? min(K, max(0, cnt_in[pix])) : 0;
     if (!__syncthreads_or(lead > 0)) {      // every pixel of the workgroup is empty
       if (active) {
-        if (vec) {
-          *reinterpret_cast<v2f *>(out0 + f) = splat(0.0f);
-          if (BWD) { *reinterpret_cast<v2f *>(out1 + f) = splat(0.0f); *reinterpret_cast<v2f *>(out2 + f) = splat(0.0f); }
-        } else {
-          out0[f] = 0.0f; if (has1) out0[f + 1] = 0.0f;
-          if (BWD) { out1[f] = 0.0f; out2[f] = 0.0f; if (has1) { out1[f + 1] = 0.0f; out2[f + 1] = 0.0f; } }
-        }
+#pragma unroll
+        for (int a = 0; a < NS; ++a)
+          if (has[a]) { out0[f + a] = 0.0f; if (BWD) { out1[f + a] = 0.0f; out2[f + a] = 0.0f; } }
         if (!BWD && q == 0) valid_num[pix] = 0;
       }
       return;
@@ -458,77 +463,110 @@ composite2_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   }
   if (tid < ppw) { L.unsorted[tid] = 0; L.rmaxi[tid] = 0; L.cnt[tid] = 0; }
   // what a sentinel slot evaluates to: E = 0, len = 1e10, s = 1e-5
-  v2f lm = splat(VOGE_SENT_LEN), sm = splat(1e-5f), em = splat(0.0f), gw = splat(0.0f), wg = splat(0.0f);
-  int id0 = -1, id1 = -1;
+  float lm[NS], sm[NS], em[NS], gw[NS], wg[NS];
+  int id[NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) { lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.0f; gw[a] = 0.0f; wg[a] = 0.0f; id[a] = -1; }
   if (active) {
-    const bool ld0 = k0 < lead, ld1 = has1 && (k0 + 1 < lead);
-    if (vec && ld1) {
-      const v2f a2 = *reinterpret_cast<const v2f *>(act + f), l2 = *reinterpret_cast<const v2f *>(len + f),
-                d2 = *reinterpret_cast<const v2f *>(dsd + f);
-      em = (v2f){FAST_EXP(-a2.x), FAST_EXP(-a2.y)};
-      lm = l2;
-      sm = (v2f){FAST_SQRT(d2.x + 1e-10f), FAST_SQRT(d2.y + 1e-10f)};
-      if (BWD) { gw = *reinterpret_cast<const v2f *>(g_weight + f); wg = *reinterpret_cast<const v2f *>(w_in + f); }
-      else if (cnt_in == nullptr) { id0 = idx[f]; id1 = idx[f + 1]; }
-    } else {
-      if (ld0) {
-        em.x = FAST_EXP(-act[f]); lm.x = len[f]; sm.x = FAST_SQRT(dsd[f] + 1e-10f);
-        if (BWD) { gw.x = g_weight[f]; wg.x = w_in[f]; } else if (cnt_in == nullptr) id0 = idx[f];
+    if (vec && k0 + NS <= lead) {        // the whole group is live: one wide access per array
+      float av[NS], lv[NS], dv[NS];
+      if (NS == 4) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(act + f), l4 = *reinterpret_cast<const float4 *>(len + f),
+                     d4 = *reinterpret_cast<const float4 *>(dsd + f);
+        av[0] = a4.x; av[1] = a4.y; av[NS - 2] = a4.z; av[NS - 1] = a4.w;
+        lv[0] = l4.x; lv[1] = l4.y; lv[NS - 2] = l4.z; lv[NS - 1] = l4.w;
+        dv[0] = d4.x; dv[1] = d4.y; dv[NS - 2] = d4.z; dv[NS - 1] = d4.w;
+        if (BWD) {
+          const float4 g4 = *reinterpret_cast<const float4 *>(g_weight + f), w4 = *reinterpret_cast<const float4 *>(w_in + f);
+          gw[0] = g4.x; gw[1] = g4.y; gw[NS - 2] = g4.z; gw[NS - 1] = g4.w;
+          wg[0] = w4.x; wg[1] = w4.y; wg[NS - 2] = w4.z; wg[NS - 1] = w4.w;
+        }
+      } else {
+        const v2f a2 = *reinterpret_cast<const v2f *>(act + f), l2 = *reinterpret_cast<const v2f *>(len + f),
+                  d2 = *reinterpret_cast<const v2f *>(dsd + f);
+        av[0] = a2.x; av[1] = a2.y; lv[0] = l2.x; lv[1] = l2.y; dv[0] = d2.x; dv[1] = d2.y;
+        if (BWD) {
+          const v2f g2 = *reinterpret_cast<const v2f *>(g_weight + f), w2 = *reinterpret_cast<const v2f *>(w_in + f);
+          gw[0] = g2.x; gw[1] = g2.y; wg[0] = w2.x; wg[1] = w2.y;
+        }
       }
-      if (ld1) {
-        em.y = FAST_EXP(-act[f + 1]); lm.y = len[f + 1]; sm.y = FAST_SQRT(dsd[f + 1] + 1e-10f);
-        if (BWD) { gw.y = g_weight[f + 1]; wg.y = w_in[f + 1]; } else if (cnt_in == nullptr) id1 = idx[f + 1];
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        em[a] = FAST_EXP(-av[a]); lm[a] = lv[a]; sm[a] = FAST_SQRT(dv[a] + 1e-10f);
+        if (!BWD && cnt_in == nullptr) id[a] = idx[f + a];
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        if (has[a] && k0 + a < lead) {
+          em[a] = FAST_EXP(-act[f + a]); lm[a] = len[f + a]; sm[a] = FAST_SQRT(dsd[f + a] + 1e-10f);
+          if (BWD) { gw[a] = g_weight[f + a]; wg[a] = w_in[f + a]; } else if (cnt_in == nullptr) id[a] = idx[f + a];
+        }
       }
     }
   }
-  const v2f sp = sm * splat(kCs);
+  float sp[NS], Es[NS];           // s' = s sqrt(log2 e); what LE holds
+#pragma unroll
+  for (int a = 0; a < NS; ++a) { sp[a] = sm[a] * kCs; Es[a] = BWD ? em[a] * sp[a] : em[a]; }
   if (in_wg) {
-    // (K odd: the last lane's second entry is the first back sentinel; E = 0 there either way)
-    *reinterpret_cast<v2f *>(Llen + d0) = has1 ? lm : (v2f){lm.x, kBig};
-    *reinterpret_cast<v2f *>(Lsp + d0) = has1 ? sp : (v2f){sp.x, 1.0f};
-    *reinterpret_cast<v2f *>(LE + d0) = BWD ? em * sp : em;
-    if (BWD) *reinterpret_cast<v2f *>(Lu + d0) = splat(0.0f);
-    if (q < 2) {      // sentinels: the aligned pair in front, and the one (or 1.5) behind
+    // (slots of the last group beyond K are back sentinels: len = +big, E = 0)
+#pragma unroll
+    for (int h2 = 0; h2 < NP; ++h2) {
+      const int a = 2 * h2;
+      *reinterpret_cast<v2f *>(Llen + d0 + a) = (v2f){has[a] ? lm[a] : kBig, has[a + 1] ? lm[a + 1] : kBig};
+      *reinterpret_cast<v2f *>(Lsp + d0 + a) = (v2f){has[a] ? sp[a] : 1.0f, has[a + 1] ? sp[a + 1] : 1.0f};
+      *reinterpret_cast<v2f *>(LE + d0 + a) = (v2f){Es[a], Es[a + 1]};
+      if (BWD) *reinterpret_cast<v2f *>(Lu + d0 + a) = splat(0.0f);
+    }
+    if (q < 2) {      // the sentinel pair in front of the row and the one behind it
       const int r0 = p * RS;
-      for (int t = q; t < 3; t += LP) {
-        if (t < PAD) { Llen[r0 + t] = -kBig; Lsp[r0 + t] = 1.0f; LE[r0 + t] = 0.0f; if (BWD) Lu[r0 + t] = 0.0f; }
-        const int eb = r0 + PAD + ((K + 1) & ~1) + t;
-        if (eb < r0 + RS) { Llen[eb] = kBig; Lsp[eb] = 1.0f; LE[eb] = 0.0f; if (BWD) Lu[eb] = 0.0f; }
+      for (int t = q; t < 2; t += LP) {
+        Llen[r0 + t] = -kBig; Lsp[r0 + t] = 1.0f; LE[r0 + t] = 0.0f; if (BWD) Lu[r0 + t] = 0.0f;
+        const int eb = r0 + RS - 2 + t;
+        Llen[eb] = kBig; Lsp[eb] = 1.0f; LE[eb] = 0.0f; if (BWD) Lu[eb] = 0.0f;
       }
     }
   }
   __syncthreads();
-  // sortedness: own pair, and the seam to the previous pair
-  if (active && (!(lm.x <= lm.y) && has1)) L.unsorted[p] = 1;
-  if (active && q > 0 && !(Llen[d0 - 1] <= lm.x)) L.unsorted[p] = 1;
+  // sortedness: inside the own group, and the seam to the previous group
+  if (active) {
+    bool uns = (q > 0) && !(Llen[d0 - 1] <= lm[0]);
+#pragma unroll
+    for (int a = 1; a < NS; ++a) uns = uns || (has[a] && !(lm[a - 1] <= lm[a]));
+    if (uns) L.unsorted[p] = 1;
+  }
   const bool head = in_wg && (lane == 0 || q == 0);
-  if (!BWD && cnt_in == nullptr) {   // assigned-slot count: two ballots, one LDS atomic per (wave, pixel) run
-    const unsigned long long m0 = __ballot(id0 >= 0), m1 = __ballot(id1 >= 0);
+  if (!BWD && cnt_in == nullptr) {   // assigned-slot count: NS ballots, one LDS atomic per (wave, pixel) run
     const int lo = max(0, lane - q), hi = min(63, lane + (LP - 1 - q));
     const unsigned long long seg = ((hi - lo == 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull) << lo);
-    if (head) atomicAdd(&L.cnt[p], __popcll(m0 & seg) + __popcll(m1 & seg));
+    int c = 0;
+#pragma unroll
+    for (int a = 0; a < NS; ++a) c += __popcll(__ballot(id[a] >= 0) & seg);
+    if (head) atomicAdd(&L.cnt[p], c);
   }
-  float mx = fmaxf((em.x != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm.x) : 0.0f,
-                   (em.y != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm.y) : 0.0f);
-  // Exclusive prefix (over lanes of the pixel) of the per-lane sums E0 + E1, Hillis-Steele with the
-  // window radius riding along; association = function of the lane's index in the pixel only.
-  float ex = 0.0f;   // sum of E over the slots in front of this lane's pair
+  float mx = 0.0f, esum = 0.0f;
+#pragma unroll
+  for (int a = 0; a < NS; ++a) {
+    mx = fmaxf(mx, (em[a] != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm[a]) : 0.0f);
+    esum += em[a];
+  }
+  // Exclusive prefix (over the lanes of the pixel) of the per-lane sums of E, Hillis-Steele with the
+  // window radius riding along; the association is a function of the lane's index in the pixel only.
+  float ex = 0.0f;   // sum of E over the slots in front of this lane's group
   if (!BWD) {
-    v2f x = {em.x + em.y, mx};
+    v2f x = {esum, mx};
     L.scan[0][tid] = x;
     __syncthreads();
-    v2f y = (q > 0 && in_wg) ? L.scan[0][tid - 1] : splat(0.0f);
+    const v2f y = (q > 0 && in_wg) ? L.scan[0][tid - 1] : splat(0.0f);
     x = (v2f){y.x, fmaxf(mx, y.y)};      // exclusive sum so far, inclusive max so far
     int par = 1;
     for (int o = 1; o < LP; o <<= 1) {
       L.scan[par][tid] = x;
       __syncthreads();
-      if (q > o && in_wg) {               // element q-1-o of the shifted sequence exists
+      if (q >= o && in_wg) {
         const v2f z = L.scan[par][tid - o];
-        x.x += z.x;
+        x.x += z.x;                        // (z.x = 0 for the pixel's first lane)
         x.y = fmaxf(x.y, z.y);
-      } else if (q == o && in_wg) {
-        x.y = fmaxf(x.y, L.scan[par][tid - o].y);
       }
       par ^= 1;
     }
@@ -546,54 +584,65 @@ composite2_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   const float rwin_all = in_wg ? __int_as_float(L.rmaxi[p]) : 0.0f;
   const bool sorted = active && (L.unsorted[in_wg ? p : 0] == 0);
   const float rwin = sorted ? rwin_all : 0.0f;
-  const bool any_e = (em.x != 0.0f) || (em.y != 0.0f);
+  bool any_e = false;
+#pragma unroll
+  for (int a = 0; a < NS; ++a) any_e = any_e || (em[a] != 0.0f);
   const float h0 = __builtin_amdgcn_exp2f(kQ0);      // h(0), exactly what h_pair(0) returns
-  const float gap = lm.y - lm.x;                     // >= 0 in a sorted list
 
-  // ---- rows r0 = 2q, r1 = 2q+1 ----------------------------------------------------------------
-  v2f S = splat(0.0f), rterm = splat(0.0f);
+  // ---- rows = the lane's own slots -------------------------------------------------------------
+  float S[NS], rterm[NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) { S[a] = 0.0f; rterm[a] = 0.0f; }
   if (any_e && sorted) {
-    v2f accF0 = splat(0.0f), accF1 = splat(0.0f), accB0 = splat(0.0f), accB1 = splat(0.0f);
-    v2f accR0 = splat(0.0f), accR1 = splat(0.0f);
-    const v2f Es = BWD ? em * sp : em;               // what LE holds
-    {   // diagonal block: column 1 is behind row 0, column 0 in front of row 1
-      const v2f xp = (v2f){gap * sp.y, gap * sp.x};
-      if (!BWD) {
-        const v2f h = h_pair(xp);
-        accF0.x = em.x * h0;            // (r0, c0) self
-        accB0.x = em.y * h.x;           // (r0, c1)
-        accF1.x = em.x * h.y;           // (r1, c0)
-        accF1.y = em.y * h0;            // (r1, c1) self
-      } else {
-        const v2f g = gauss_pair(xp);
-        accR0 = (v2f){Es.x, Es.y * g.x};
-        accR1 = (v2f){Es.x * g.y, Es.y};
+    v2f accF[NS], accB[NS], accR[NS];
+#pragma unroll
+    for (int a = 0; a < NS; ++a) { accF[a] = splat(0.0f); accB[a] = splat(0.0f); accR[a] = splat(0.0f); }
+    // diagonal block (registers): for rows a < b, column b is behind row a and column a in front of row b
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+      if (!BWD) accF[a].x = em[a] * h0; else accR[a].x = Es[a];         // self
+#pragma unroll
+      for (int b2 = a + 1; b2 < NS; ++b2) {
+        const float gap = lm[b2] - lm[a];
+        const v2f xp = (v2f){gap * sp[b2], gap * sp[a]};                 // (row a, col b), (row b, col a)
+        if (!BWD) {
+          const v2f h = h_pair(xp);
+          accB[a].y = fmaf(em[b2], h.x, accB[a].y);
+          accF[b2].y = fmaf(em[a], h.y, accF[b2].y);
+        } else {
+          const v2f g = gauss_pair(xp);
+          accR[a].y = fmaf(Es[b2], g.x, accR[a].y);
+          accR[b2].y = fmaf(Es[a], g.y, accR[b2].y);
+        }
       }
     }
-    const v2f lm0 = splat(lm.x), lm1 = splat(lm.y);
-    const float lmB = (em.y != 0.0f) ? lm.y : lm.x;     // the row that decides how far back to walk
-    for (int e = d0 - 2;; e -= 2) {      // column pairs in front of both rows; row 0 is the nearer one
+    float lmB = lm[0];                 // the last live row decides how far back to walk
+#pragma unroll
+    for (int a = 1; a < NS; ++a) lmB = (em[a] != 0.0f) ? lm[a] : lmB;
+    for (int e = d0 - 2;; e -= 2) {      // column pairs in front of every own row; row 0 is the nearest
       const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
-      const v2f dA = lm0 - l2, dB = lm1 - l2;
-      if (!(dA.y < rwin)) break;
-      const v2f xa = dA * s2, xb = dB * s2;
-      if (!BWD) { accF0 = pk_fma(E2, h_pair(xa), accF0); accF1 = pk_fma(E2, h_pair(xb), accF1); }
-      else { accR0 = pk_fma(E2, gauss_pair(xa), accR0); accR1 = pk_fma(E2, gauss_pair(xb), accR1); }
+      if (!(lm[0] - l2.y < rwin)) break;
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const v2f xa = (splat(lm[a]) - l2) * s2;
+        if (!BWD) accF[a] = pk_fma(E2, h_pair(xa), accF[a]); else accR[a] = pk_fma(E2, gauss_pair(xa), accR[a]);
+      }
     }
-    for (int e = d0 + 2;; e += 2) {      // column pairs behind both rows; row 1 is the nearer one
+    for (int e = d0 + NS;; e += 2) {     // column pairs behind every own row
       const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
-      const v2f dA = l2 - lm0, dB = l2 - lm1;
       if (!(l2.x - lmB < rwin)) break;
-      const v2f xa = dA * s2, xb = dB * s2;
-      if (!BWD) { accB0 = pk_fma(E2, h_pair(xa), accB0); accB1 = pk_fma(E2, h_pair(xb), accB1); }
-      else { accR0 = pk_fma(E2, gauss_pair(xa), accR0); accR1 = pk_fma(E2, gauss_pair(xb), accR1); }
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const v2f xa = (l2 - splat(lm[a])) * s2;
+        if (!BWD) accB[a] = pk_fma(E2, h_pair(xa), accB[a]); else accR[a] = pk_fma(E2, gauss_pair(xa), accR[a]);
+      }
     }
-    if (!BWD) {
-      const float pre0 = ex + em.x, pre1 = pre0 + em.y;     // inclusive prefix sums of E
-      S.x = (pre0 - (accF0.x + accF0.y)) + (accB0.x + accB0.y);
-      S.y = (pre1 - (accF1.x + accF1.y)) + (accB1.x + accB1.y);
-    } else {
-      rterm = (v2f){(accR0.x + accR0.y), (accR1.x + accR1.y)} * splat(kRsqrtPi / kCs);
+    float pre = ex;
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+      pre += em[a];                                                     // inclusive prefix sum of E
+      if (!BWD) S[a] = (pre - (accF[a].x + accF[a].y)) + (accB[a].x + accB[a].y);
+      else rterm[a] = (accR[a].x + accR[a].y) * (kRsqrtPi / kCs);
     }
   } else if (any_e && active) {          // unsorted list: every column, signs from the data
     const int r0 = d0 - k0;
@@ -601,114 +650,162 @@ composite2_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
       const float Ej = LE[r0 + j];
       if (Ej == 0.0f) continue;
       const float lj = Llen[r0 + j], sj = Lsp[r0 + j];
-      const v2f xp = (lm - splat(lj)) * splat(sj);
-      if (!BWD) {
-        const v2f h = h_pair(abs2(xp));
-        S.x = fmaf(Ej, xp.x >= 0.0f ? 1.0f - h.x : h.x, S.x);
-        S.y = fmaf(Ej, xp.y >= 0.0f ? 1.0f - h.y : h.y, S.y);
-      } else {
-        const v2f xc = (v2f){fminf(fabsf(xp.x), 16.0f), fminf(fabsf(xp.y), 16.0f)};
-        rterm = pk_fma(splat(Ej * (kRsqrtPi / kCs)), gauss_pair(xc), rterm);
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const float xp = (lm[a] - lj) * sj;
+        if (!BWD) {
+          const float h = h_one(fabsf(xp));
+          S[a] = fmaf(Ej, xp >= 0.0f ? 1.0f - h : h, S[a]);
+        } else {
+          const float xc = fminf(fabsf(xp), 16.0f);
+          rterm[a] = fmaf(Ej * (kRsqrtPi / kCs), __builtin_amdgcn_exp2f(-xc * xc), rterm[a]);
+        }
       }
     }
   }
   if (!BWD) {
-    v2f w;
-    w.x = (em.x != 0.0f) ? FAST_EXP(-occ * S.x) * em.x * kInvNorm : 0.0f;
-    w.y = (em.y != 0.0f) ? FAST_EXP(-occ * S.y) * em.y * kInvNorm : 0.0f;
+    float w[NS];
+#pragma unroll
+    for (int a = 0; a < NS; ++a) w[a] = (em[a] != 0.0f) ? FAST_EXP(-occ * S[a]) * em[a] * kInvNorm : 0.0f;
     if (active) {
-      if (vec) *reinterpret_cast<v2f *>(out0 + f) = w;
-      else { out0[f] = w.x; if (has1) out0[f + 1] = w.y; }
+      if (vec && NS == 4) *reinterpret_cast<float4 *>(out0 + f) = make_float4(w[0], w[1], w[NS - 2], w[NS - 1]);
+      else if (vec) *reinterpret_cast<v2f *>(out0 + f) = (v2f){w[0], w[1]};
+      else {
+#pragma unroll
+        for (int a = 0; a < NS; ++a) if (has[a]) out0[f + a] = w[a];
+      }
       if (q == 0) valid_num[pix] = (cnt_in != nullptr) ? (int64_t)cnt_in[pix] : (int64_t)L.cnt[p];
     }
     return;
   }
-  // ---- backward: u = g_w * w, suffix sums, then the lane's two columns --------------------------
-  const v2f um = gw * wg;
-  if (in_wg) *reinterpret_cast<v2f *>(Lu + d0) = um;
-  float sx = 0.0f;   // sum of u over the slots behind this lane's pair
+  // ---- backward: u = g_w * w, suffix sums, then the lane's own columns --------------------------
+  float um[NS], usum = 0.0f;
+#pragma unroll
+  for (int a = 0; a < NS; ++a) { um[a] = gw[a] * wg[a]; usum += um[a]; }
+  if (in_wg) {
+#pragma unroll
+    for (int h2 = 0; h2 < NP; ++h2) *reinterpret_cast<v2f *>(Lu + d0 + 2 * h2) = (v2f){um[2 * h2], um[2 * h2 + 1]};
+  }
+  float sx = 0.0f;   // sum of u over the slots behind this lane's group
   {
     float(*sf)[kCompThreads] = reinterpret_cast<float(*)[kCompThreads]>(L.scan);
-    sf[0][tid] = um.x + um.y;
+    sf[0][tid] = usum;
     __syncthreads();
     float x = (q + 1 < LP && in_wg) ? sf[0][tid + 1] : 0.0f;
     int par = 1;
     for (int o = 1; o < LP; o <<= 1) {
       sf[par][tid] = x;
       __syncthreads();
-      if (q + 1 + o < LP && in_wg) x += sf[par][tid + o];
+      if (q + o < LP && in_wg) x += sf[par][tid + o];      // (0 for the pixel's last lane)
       par ^= 1;
     }
     sx = x;
   }
   __syncthreads();
-  v2f ga = splat(0.0f), gl = splat(0.0f), gd = splat(0.0f);
+  float ga[NS], gl[NS], gd[NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) { ga[a] = 0.0f; gl[a] = 0.0f; gd[a] = 0.0f; }
   if (any_e && active) {
-    v2f cPhi, cphi, cphil;     // per column (x: column 2q, y: column 2q+1)
+    float cPhi[NS], cphi[NS], cphil[NS];
     if (sorted) {
-      const v2f rj = (v2f){em.x != 0.0f ? kSat * __builtin_amdgcn_rcpf(sm.x) : 0.0f,
-                           em.y != 0.0f ? kSat * __builtin_amdgcn_rcpf(sm.y) : 0.0f};   // an empty column needs no rows
-      // accumulators over the two rows of a pair: aX* rows behind (incl. self), bX* rows in front
-      v2f aH0, aP0, aL0, aH1, aP1, aL1, bH0 = splat(0.0f), bP0 = splat(0.0f), bL0 = splat(0.0f), bH1, bP1, bL1;
-      {   // diagonal block: row 1 is behind column 0, row 0 in front of column 1
-        const v2f xp = (v2f){gap * sp.x, gap * sp.y};      // (row1, col0), (row0, col1)
-        const v2f g = gauss_pair(xp), h = h_pair(xp);
-        aH0 = (v2f){um.x * h0, um.y * h.x}; aP0 = (v2f){um.x, um.y * g.x}; aL0 = (v2f){0.0f, um.y * g.x * gap};
-        aH1 = (v2f){um.y * h0, 0.0f};       aP1 = (v2f){um.y, 0.0f};       aL1 = splat(0.0f);
-        bH1 = (v2f){um.x * h.y, 0.0f};      bP1 = (v2f){um.x * g.y, 0.0f}; bL1 = (v2f){um.x * g.y * gap, 0.0f};
+      float rj[NS];
+      v2f aH[NS], aP[NS], aL[NS], bH[NS], bP[NS], bL[NS];   // per own column: rows behind (a*) / in front (b*)
+#pragma unroll
+      for (int b2 = 0; b2 < NS; ++b2) {
+        rj[b2] = (em[b2] != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm[b2]) : 0.0f;   // an empty column needs no rows
+        aH[b2] = (v2f){um[b2] * h0, 0.0f}; aP[b2] = (v2f){um[b2], 0.0f}; aL[b2] = splat(0.0f);   // self
+        bH[b2] = splat(0.0f); bP[b2] = splat(0.0f); bL[b2] = splat(0.0f);
       }
-      const v2f lm0 = splat(lm.x), lm1 = splat(lm.y), sp0 = splat(sp.x), sp1 = splat(sp.y);
-      for (int e = d0 + 2;; e += 2) {      // row pairs behind both columns; column 1 is the nearer one
+      // diagonal block: for own slots a < b, row b is behind column a and row a in front of column b
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+#pragma unroll
+        for (int b2 = a + 1; b2 < NS; ++b2) {
+          const float gap = lm[b2] - lm[a];
+          const v2f xp = (v2f){gap * sp[a], gap * sp[b2]};      // (row b, col a), (row a, col b)
+          const v2f g = gauss_pair(xp), h = h_pair(xp);
+          aH[a].y = fmaf(um[b2], h.x, aH[a].y); aP[a].y = fmaf(um[b2], g.x, aP[a].y); aL[a].y = fmaf(um[b2] * g.x, gap, aL[a].y);
+          bH[b2].y = fmaf(um[a], h.y, bH[b2].y); bP[b2].y = fmaf(um[a], g.y, bP[b2].y); bL[b2].y = fmaf(um[a] * g.y, gap, bL[b2].y);
+        }
+      }
+      for (int e = d0 + NS;; e += 2) {     // row pairs behind every own column
         const v2f l2 = ld2(Llen, e), u2 = ld2(Lu, e);
-        const v2f dA = l2 - lm0, dB = l2 - lm1;
-        if (!(dA.x < rj.x) && !(dB.x < rj.y)) break;
-        const v2f xa = dA * sp0, xb = dB * sp1;
-        const v2f ya = u2 * gauss_pair(xa), yb = u2 * gauss_pair(xb);
-        aH0 = pk_fma(u2, h_pair(xa), aH0); aP0 = aP0 + ya; aL0 = pk_fma(ya, dA, aL0);
-        aH1 = pk_fma(u2, h_pair(xb), aH1); aP1 = aP1 + yb; aL1 = pk_fma(yb, dB, aL1);
+        bool need = false;
+#pragma unroll
+        for (int b2 = 0; b2 < NS; ++b2) need = need || (l2.x - lm[b2] < rj[b2]);
+        if (!need) break;
+#pragma unroll
+        for (int b2 = 0; b2 < NS; ++b2) {
+          const v2f d = l2 - splat(lm[b2]);
+          const v2f xp = d * splat(sp[b2]);
+          const v2f y = u2 * gauss_pair(xp);
+          aH[b2] = pk_fma(u2, h_pair(xp), aH[b2]); aP[b2] = aP[b2] + y; aL[b2] = pk_fma(y, d, aL[b2]);
+        }
       }
-      for (int e = d0 - 2;; e -= 2) {      // row pairs in front of both columns; column 0 is the nearer one
+      for (int e = d0 - 2;; e -= 2) {      // row pairs in front of every own column
         const v2f l2 = ld2(Llen, e), u2 = ld2(Lu, e);
-        const v2f dA = lm0 - l2, dB = lm1 - l2;
-        if (!(dA.y < rj.x) && !(dB.y < rj.y)) break;
-        const v2f xa = dA * sp0, xb = dB * sp1;
-        const v2f ya = u2 * gauss_pair(xa), yb = u2 * gauss_pair(xb);
-        bH0 = pk_fma(u2, h_pair(xa), bH0); bP0 = bP0 + ya; bL0 = pk_fma(ya, dA, bL0);
-        bH1 = pk_fma(u2, h_pair(xb), bH1); bP1 = bP1 + yb; bL1 = pk_fma(yb, dB, bL1);
+        bool need = false;
+#pragma unroll
+        for (int b2 = 0; b2 < NS; ++b2) need = need || (lm[b2] - l2.y < rj[b2]);
+        if (!need) break;
+#pragma unroll
+        for (int b2 = 0; b2 < NS; ++b2) {
+          const v2f d = splat(lm[b2]) - l2;
+          const v2f xp = d * splat(sp[b2]);
+          const v2f y = u2 * gauss_pair(xp);
+          bH[b2] = pk_fma(u2, h_pair(xp), bH[b2]); bP[b2] = bP[b2] + y; bL[b2] = pk_fma(y, d, bL[b2]);
+        }
       }
-      const float suf1 = sx + um.y, suf0 = suf1 + um.x;     // inclusive suffix sums of u
-      cPhi = (v2f){(suf0 - (aH0.x + aH0.y)) + (bH0.x + bH0.y), (suf1 - (aH1.x + aH1.y)) + (bH1.x + bH1.y)};
-      cphi = (v2f){(aP0.x + aP0.y) + (bP0.x + bP0.y), (aP1.x + aP1.y) + (bP1.x + bP1.y)} * splat(kRsqrtPi);
-      cphil = (v2f){(aL0.x + aL0.y) - (bL0.x + bL0.y), (aL1.x + aL1.y) - (bL1.x + bL1.y)} * splat(kRsqrtPi);
+      float suf = sx;
+#pragma unroll
+      for (int b2 = NS - 1; b2 >= 0; --b2) {
+        suf += um[b2];                                                   // inclusive suffix sum of u
+        cPhi[b2] = (suf - (aH[b2].x + aH[b2].y)) + (bH[b2].x + bH[b2].y);
+        cphi[b2] = ((aP[b2].x + aP[b2].y) + (bP[b2].x + bP[b2].y)) * kRsqrtPi;
+        cphil[b2] = ((aL[b2].x + aL[b2].y) - (bL[b2].x + bL[b2].y)) * kRsqrtPi;
+      }
     } else {
-      cPhi = splat(0.0f); cphi = splat(0.0f); cphil = splat(0.0f);
+#pragma unroll
+      for (int b2 = 0; b2 < NS; ++b2) { cPhi[b2] = 0.0f; cphi[b2] = 0.0f; cphil[b2] = 0.0f; }
       const int r0 = d0 - k0;
       for (int m = 0; m < K; ++m) {
         const float ur = Lu[r0 + m];
         if (ur == 0.0f) continue;
-        const v2f dl = splat(Llen[r0 + m]) - lm;
-        const v2f xp = dl * sp;
-        const v2f h = h_pair(abs2(xp));
-        const v2f xc = (v2f){fminf(fabsf(xp.x), 16.0f), fminf(fabsf(xp.y), 16.0f)};
-        const v2f ph = splat(ur * kRsqrtPi) * gauss_pair(xc);
-        cPhi.x = fmaf(ur, xp.x >= 0.0f ? 1.0f - h.x : h.x, cPhi.x);
-        cPhi.y = fmaf(ur, xp.y >= 0.0f ? 1.0f - h.y : h.y, cPhi.y);
-        cphi = cphi + ph;
-        cphil = pk_fma(ph, dl, cphil);
+        const float lr = Llen[r0 + m];
+#pragma unroll
+        for (int b2 = 0; b2 < NS; ++b2) {
+          const float dl = lr - lm[b2];
+          const float xp = dl * sp[b2];
+          const float h = h_one(fabsf(xp));
+          const float xc = fminf(fabsf(xp), 16.0f);
+          const float ph = ur * (__builtin_amdgcn_exp2f(-xc * xc) * kRsqrtPi);
+          cPhi[b2] = fmaf(ur, xp >= 0.0f ? 1.0f - h : h, cPhi[b2]);
+          cphi[b2] += ph;
+          cphil[b2] = fmaf(ph, dl, cphil[b2]);
+        }
       }
     }
-    ga = pk_fma(splat(occ) * em, cPhi, -um);
-    gl = splat(-occ) * (um * rterm - em * sm * cphi);
-    gd = splat(-occ) * em * cphil * (v2f){0.5f * __builtin_amdgcn_rcpf(sm.x), 0.5f * __builtin_amdgcn_rcpf(sm.y)};
-    if (em.x == 0.0f) { ga.x = 0.0f; gl.x = 0.0f; gd.x = 0.0f; }
-    if (em.y == 0.0f) { ga.y = 0.0f; gl.y = 0.0f; gd.y = 0.0f; }
+#pragma unroll
+    for (int b2 = 0; b2 < NS; ++b2) {
+      if (em[b2] != 0.0f) {
+        ga[b2] = fmaf(occ * em[b2], cPhi[b2], -um[b2]);
+        gl[b2] = -occ * (um[b2] * rterm[b2] - em[b2] * sm[b2] * cphi[b2]);
+        gd[b2] = -occ * em[b2] * (0.5f * __builtin_amdgcn_rcpf(sm[b2])) * cphil[b2];
+      }
+    }
   }
   if (active) {
-    if (vec) {
-      *reinterpret_cast<v2f *>(out0 + f) = ga; *reinterpret_cast<v2f *>(out1 + f) = gl; *reinterpret_cast<v2f *>(out2 + f) = gd;
+    if (vec && NS == 4) {
+      *reinterpret_cast<float4 *>(out0 + f) = make_float4(ga[0], ga[1], ga[NS - 2], ga[NS - 1]);
+      *reinterpret_cast<float4 *>(out1 + f) = make_float4(gl[0], gl[1], gl[NS - 2], gl[NS - 1]);
+      *reinterpret_cast<float4 *>(out2 + f) = make_float4(gd[0], gd[1], gd[NS - 2], gd[NS - 1]);
+    } else if (vec) {
+      *reinterpret_cast<v2f *>(out0 + f) = (v2f){ga[0], ga[1]};
+      *reinterpret_cast<v2f *>(out1 + f) = (v2f){gl[0], gl[1]};
+      *reinterpret_cast<v2f *>(out2 + f) = (v2f){gd[0], gd[1]};
     } else {
-      out0[f] = ga.x; out1[f] = gl.x; out2[f] = gd.x;
-      if (has1) { out0[f + 1] = ga.y; out1[f + 1] = gl.y; out2[f + 1] = gd.y; }
+#pragma unroll
+      for (int a = 0; a < NS; ++a) if (has[a]) { out0[f + a] = ga[a]; out1[f + a] = gl[a]; out2[f + a] = gd[a]; }
     }
   }
 }
@@ -727,16 +824,23 @@ static int launch_composite(int mode, const int32_t *idx, const float *act, cons
   const int threads = (K <= VOGE_COMP_T) ? VOGE_COMP_T : kCompThreads;
   hipStream_t st = (hipStream_t)stream;
 #ifndef VOGE_COMP_ONE_SLOT
-  if (mode != 1) {   // two slots per lane
-    const int ppw2 = kCompThreads / comp2_lanes(K);
-    const dim3 grid2((unsigned)((npix + ppw2 - 1) / ppw2)), block2(kCompThreads);
-    const size_t lds2 = comp2_lds_bytes(K, mode != 0);
-    if (mode == 2)
-      hipLaunchKernelGGL(composite2_kernel<2>, grid2, block2, lds2, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, npix,
-                         K, ppw2, o0, o1, o2, valid_num);
-    else
-      hipLaunchKernelGGL(composite2_kernel<0>, grid2, block2, lds2, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, npix,
-                         K, ppw2, o0, o1, o2, valid_num);
+#ifndef VOGE_COMP_NS
+#define VOGE_COMP_NS 4
+#endif
+  if (mode != 1) {   // NS slots per lane: 4 when the lists are whole groups of 4, else 2
+#ifndef VOGE_COMP_NS_BWD
+#define VOGE_COMP_NS_BWD 2     // the backward is evaluation-bound, not LDS-bound: 4 slots only cost registers
+#endif
+    const int NS = ((mode == 0 ? VOGE_COMP_NS : VOGE_COMP_NS_BWD) == 4 && (K & 3) == 0) ? 4 : 2;
+    const int ppwn = kCompThreads / compn_lanes(K, NS);
+    const dim3 gridn((unsigned)((npix + ppwn - 1) / ppwn)), blockn(kCompThreads);
+    const size_t ldsn = compn_lds_bytes(K, NS, mode != 0);
+#define VOGE_LAUNCH_COMPN(M, N)                                                                                         \
+    hipLaunchKernelGGL((compositen_kernel<M, N>), gridn, blockn, ldsn, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, \
+                       npix, K, ppwn, o0, o1, o2, valid_num)
+    if (mode == 2) { if (NS == 4) VOGE_LAUNCH_COMPN(2, 4); else VOGE_LAUNCH_COMPN(2, 2); }
+    else { if (NS == 4) VOGE_LAUNCH_COMPN(0, 4); else VOGE_LAUNCH_COMPN(0, 2); }
+#undef VOGE_LAUNCH_COMPN
     return launch_status();
   }
 #endif
