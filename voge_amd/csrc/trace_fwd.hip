@@ -33,7 +33,7 @@ __device__ inline double lambda_min_sym3(double a00, double a11, double a22, dou
 __device__ __forceinline__ void prep_one(const int g, const float *__restrict__ mus, const float *__restrict__ isg,
                                          const float *__restrict__ cam_fwd, const int N, const float thr_act,
                                          const int iso_in, float4 *__restrict__ cull, float4 *__restrict__ evr,
-                                         float4 *__restrict__ ms) {
+                                         float4 *__restrict__ ms, float4 *__restrict__ ell) {
   const float mx = mus[3 * g + 0], my = mus[3 * g + 1], mz = mus[3 * g + 2];
   float A[9];
   if (iso_in) {   // isg holds one scalar per Gaussian: A = a I
@@ -61,6 +61,33 @@ __device__ __forceinline__ void prep_one(const int g, const float *__restrict__ 
     const double r = sqrt(fmax(thr2, 0.0) / lsafe) * (1.0 + 1e-5) + 1e-5 * nm + 1e-30;
     reach = (float)(r * (1.0 + 1e-6));
     if (!(reach >= 0.0f)) reach = INFINITY;  // NaN guard
+    // Anisotropic Gaussians also get the ELLIPSOID every hit must touch: a ray with act < thr_act has
+    // its peak point x = len d inside E = {x : (x-mu)^T S (x-mu) <= thr2}, S = sym(A) (same bound as
+    // above, before lambda_min replaces S).  Record M = thr2 S^-1, so that the support function of E
+    // is h(n) = sqrt(n^T M n); the bin kernels look for a plane that separates E from a ray cone.
+    // The lowest mantissa bit of `reach` says whether the record exists (rounding reach UP is safe).
+    uint32_t rb = __float_as_uint(reach);
+    bool has_ell = false;
+    if (!is_iso(e) && reach < 3e38f) {
+      const double s00 = A[0], s11 = A[4], s22 = A[8], s01 = 0.5 * ((double)A[1] + A[3]),
+                   s02 = 0.5 * ((double)A[2] + A[6]), s12 = 0.5 * ((double)A[5] + A[7]);
+      const double c00 = s11 * s22 - s12 * s12, c01 = s02 * s12 - s01 * s22, c02 = s01 * s12 - s02 * s11;
+      const double c11 = s00 * s22 - s02 * s02, c12 = s01 * s02 - s00 * s12, c22 = s00 * s11 - s01 * s01;
+      const double det = s00 * c00 + s01 * c01 + s02 * c02;
+      const double f = fmax(thr2, 0.0) * (1.0 + 1e-4) / det;
+      const double m00 = c00 * f, m11 = c11 * f, m22 = c22 * f, m01 = c01 * f, m02 = c02 * f, m12 = c12 * f;
+      const double msum = fabs(m00) + fabs(m11) + fabs(m22) + 2.0 * (fabs(m01) + fabs(m02) + fabs(m12));
+      // a positive definite S has det > 0 and positive diagonal cofactors; anything else keeps the sphere only
+      if (det > 0.0 && f > 0.0 && m00 > 0.0 && m11 > 0.0 && m22 > 0.0 && msum < 1e30) {
+        ell[2 * (size_t)g + 0] = make_float4((float)m00, (float)m11, (float)m22, (float)m01);
+        // .z: absolute slack for n^T M n evaluated in fp32 (|n| <= 1.001); .w: additive slack of h
+        ell[2 * (size_t)g + 1] = make_float4((float)m02, (float)m12, (float)(8e-6 * msum) + 1e-30f,
+                                             (float)(1e-5 * nm + 1e-5 * r) + 1e-30f);
+        has_ell = true;
+      }
+    }
+    rb = has_ell ? (rb | 1u) : ((rb + 1u) & ~1u);
+    reach = __uint_as_float(rb);
   }
   if (cam_fwd != nullptr) {
     const float *f = cam_fwd + 3 * (g / N);
@@ -256,13 +283,13 @@ prep_cone_kernel(const float *__restrict__ rays, const int H, const int W, const
                  ConeRec *__restrict__ cones /* [B][nst] */, int *__restrict__ c_count, const int n_count,
                  const float *__restrict__ mus, const float *__restrict__ isg, const float *__restrict__ cam_fwd,
                  const int N, const int P, const float thr_act, const int iso_in, float4 *__restrict__ cull,
-                 float4 *__restrict__ evr, float4 *__restrict__ ms) {
+                 float4 *__restrict__ evr, float4 *__restrict__ ms, float4 *__restrict__ ell) {
   __shared__ float red[16 * 4];
   const int tid = threadIdx.x;
   const int nprep = (P + kBinThreads - 1) / kBinThreads;
   if ((int)blockIdx.x < nprep) {     // record blocks first: they are the longer ones (fp64 eigenvalue)
     const int g = (int)blockIdx.x * kBinThreads + tid;
-    if (g < P) prep_one(g, mus, isg, cam_fwd, N, thr_act, iso_in, cull, evr, ms);
+    if (g < P) prep_one(g, mus, isg, cam_fwd, N, thr_act, iso_in, cull, evr, ms, ell);
     return;
   }
   const int cb = (int)blockIdx.x - nprep;
@@ -530,7 +557,7 @@ bin_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, c
 constexpr int kTileCap = 2048;
 
 __global__ void __launch_bounds__(256)
-bin2_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, const int *__restrict__ bin_count,
+bin2_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, const float *__restrict__ rays, const int *__restrict__ bin_count,
             const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb, const int nstx, const int nst,
             const int N, const int H, const int W, const int TW, const int TH, int *__restrict__ tl_count,
             int32_t *__restrict__ tl_id, float *__restrict__ tl_lb, const int K, int32_t *__restrict__ out_idx,
@@ -577,6 +604,7 @@ bin2_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, con
   const int32_t *src_id = bin_id + (size_t)bin * kBinCap;
   const float *src_lb = bin_lb + (size_t)bin * kBinCap;
   const float4 *cullb = cull + (size_t)b * N;
+  const float4 *ellb = ell + (size_t)b * N * 2;
   int32_t *oid = tl_id + (size_t)tile * kTileCap;
   float *olb = tl_lb + (size_t)tile * kTileCap;
   int total = 0, par = 0;
@@ -593,10 +621,26 @@ bin2_kernel(const float4 *__restrict__ cull, const float *__restrict__ rays, con
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) c[q] = (id[q] >= 0) ? cullb[id[q]] : make_float4(0.f, 0.f, 0.f, -1.f);
+    bool kp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kp[q] = cone_keep(c[q], cone);
+    // anisotropic survivors of the sphere test: the ellipsoid test (two more gathers, all in flight)
+    {
+      float4 e0[4], e1[4];
+      bool el[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        el[q] = kp[q] && cull_has_ell(c[q]);
+        if (el[q]) { e0[q] = ellb[2 * (size_t)id[q]]; e1[q] = ellb[2 * (size_t)id[q] + 1]; }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (el[q]) kp[q] = cone_keep_ell(c[q], e0[q], e1[q], cone);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (base + q * 256 >= bc) break;  // uniform
-      const bool keep = cone_keep(c[q], cone);
+      const bool keep = kp[q];
       const unsigned long long m = __ballot(keep);
       if (lane == 0) wcnt[par][wave] = __popcll(m);
       __syncthreads();
@@ -1338,7 +1382,7 @@ trace_list_fwd_kernel(const float *__restrict__ mus, const float *__restrict__ i
 }
 
 struct TraceWs {
-  float4 *cull, *evr, *ms;
+  float4 *cull, *evr, *ms, *ell;
   int *bin_count;
   int32_t *bin_id;
   float *bin_lb;
@@ -1368,8 +1412,9 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
        *tl = take(ntile * kTileCap * 4);
   const int nst0x = (W + kST0 - 1) / kST0, nst0y = (H + kST0 - 1) / kST0;
   const size_t nreg = (size_t)B * nst0x * nst0y;
-  char *cc = take(nreg * 4), *ci = take(nreg * (size_t)N * 4), *cn = take(nbin * sizeof(ConeRec)), *to = take(ntile * 4);
+  char *cc = take(nreg * 4), *ci = take(nreg * (size_t)N * 4), *cn = take(nbin * sizeof(ConeRec)), *to = take(ntile * 4), *el = take(P * 32);
   if (ws) {
+    ws->ell = reinterpret_cast<float4 *>(el);
     ws->c_count = reinterpret_cast<int *>(cc); ws->c_id = reinterpret_cast<int32_t *>(ci);
     ws->cones = reinterpret_cast<ConeRec *>(cn);
     ws->tile_order = reinterpret_cast<int *>(to);
@@ -1397,7 +1442,7 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid(((W + TW - 1) / TW) * ((H + TH - 1) / TH), B);
-  hipLaunchKernelGGL(bin2_kernel, grid, dim3(256), 0, st, ws.cull, rays, ws.bin_count, ws.bin_id, ws.bin_lb, ws.nstx,
+  hipLaunchKernelGGL(bin2_kernel, grid, dim3(256), 0, st, ws.cull, ws.ell, rays, ws.bin_count, ws.bin_id, ws.bin_lb, ws.nstx,
                      ws.nstx * ws.nsty, N, H, W, TW, TH, ws.tl_count, ws.tl_id, ws.tl_lb, K, idx, len, act, dsd, cnt);
   {
     int rc = launch_status();
@@ -1457,7 +1502,7 @@ static int trace_topk_fwd_impl(const int iso_in, const float *mus, const float *
     const int nprep = (P + kBinThreads - 1) / kBinThreads;
     hipLaunchKernelGGL(prep_cone_kernel, dim3(nst * B + nprep), dim3(kBinThreads), 0, st, rays, H, W, ws.nstx, nst, B,
                        ws.cones, ws.c_count, B * ws.nst0x * ws.nst0y, mus, isigmas, cam_fwd, N, P, thr_act, iso_in, ws.cull,
-                       ws.evr, ws.ms);
+                       ws.evr, ws.ms, ws.ell);
     int rc = launch_status();
     if (rc) return rc;
   }

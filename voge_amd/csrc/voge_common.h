@@ -264,6 +264,45 @@ __device__ __forceinline__ bool cone_keep(const float4 c, const Cone &k) {
   return !k.ok || !(gap > c.w);
 }
 
+// Does the cull record carry an ellipsoid record (trace_fwd.hip, prep_one)?
+__device__ __forceinline__ bool cull_has_ell(const float4 c) { return (__float_as_uint(c.w) & 1u) != 0u && c.w > 0.0f && c.w < 3e38f; }
+
+// Support function of the hit ellipsoid along n (|n| <= ~1), rounded up.  e0 = (M00, M11, M22, M01),
+// e1 = (M02, M12, slack of n^T M n, additive slack).
+__device__ __forceinline__ float ell_support(const float4 e0, const float4 e1, const float nx, const float ny, const float nz) {
+  const float d = fmaf(e0.z * nz, nz, fmaf(e0.y * ny, ny, e0.x * nx * nx));
+  const float o = fmaf(e1.y * ny, nz, fmaf(e1.x * nx, nz, e0.w * nx * ny));
+  const float h2 = fmaxf(fmaf(2.0f, o, d), 0.0f) + e1.z;
+  return fmaf(sqrtf(h2), 1.0f + 1e-5f, e1.w);
+}
+
+// Conservative "no line through the origin with a direction inside the cone touches the
+// ellipsoid": each nappe of the double cone lies behind the plane through the apex with normal
+// n(+-) = cs u -+ sn a (u = unit radial direction of the centre; valid for any cs <= cos, sn >= sin
+// of the cone's half angle), so the ellipsoid misses a nappe when n.mu > h(n).  Only called for
+// candidates the sphere test kept.
+__device__ __forceinline__ bool cone_keep_ell(const float4 c, const float4 e0, const float4 e1, const Cone &k) {
+  if (!k.ok) return true;
+  const float p = fmaf(c.z, k.az, fmaf(c.y, k.ay, c.x * k.ax));
+  const float rx = fmaf(-p, k.ax, c.x), ry = fmaf(-p, k.ay, c.y), rz = fmaf(-p, k.az, c.z);
+  const float q2 = fmaf(rz, rz, fmaf(ry, ry, rx * rx));
+  if (!(q2 > 1e-24f)) return true;       // centre on the axis
+  const float iq = __builtin_amdgcn_rsqf(q2);
+  const float q = q2 * iq;
+  const float ux = rx * iq, uy = ry * iq, uz = rz * iq;
+  const float qc = q * k.cs, ps = p * k.sn;
+  const float err = 4e-6f * (q + fabsf(p));       // rounding of q, p and of the two products
+  bool sep = true;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float sg = s ? -k.sn : k.sn;
+    const float nx = fmaf(-sg, k.ax, k.cs * ux), ny = fmaf(-sg, k.ay, k.cs * uy), nz = fmaf(-sg, k.az, k.cs * uz);
+    const float g = (s ? qc + ps : qc - ps) - err;
+    sep = sep && (g > ell_support(e0, e1, nx, ny, nz));
+  }
+  return !sep;
+}
+
 // ------------------------------------------------------------------------------------------
 // Wave-private accumulation table in LDS: NV4 float4 values per integer key.
 // Only the owning wave touches a table, so slots are claimed with a plain write + read-back and
