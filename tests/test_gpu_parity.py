@@ -119,6 +119,33 @@ def test_trace_fwd_large_frame_coarse_bins_and_tile_order(hip_lib, iso_api):
     assert (ref[0][..., -1] >= 0).mean() > 0.05 and (ref[0][..., 0] < 0).mean() > 0.3   # full lists and empty pixels
 
 
+def test_trace_fwd_strongly_anisotropic_ellipsoid_culling(hip_lib):
+    """Needles and pancakes (A = L L^T with a random lower-triangular L, EfficientCuboidViaOptimization.py:17-18,
+    plus a small skew part) on a frame large enough for all three binning levels: the bin kernels
+    cull these by their hit ellipsoid (separating plane against the tile's ray cone) and bound their
+    depth by the ellipsoid's extent along the tile axis, which must stay conservative.  The brute-force
+    oracle is cropped to a few windows to stay in seconds; behind-the-camera Gaussians are kept (-1 path)."""
+    from voge_amd import scenes
+    N, H, W, K = 30000, 384, 416, 24
+    verts, sig, _ = scenes.random_gaussians(N, seed=5, anisotropic=True, r_lo=0.02, r_hi=0.05, extent=1.2)
+    rng = np.random.default_rng(9)
+    nz = rng.normal(size=sig.shape)
+    sig = (sig + 2e-3 * (nz - nz.swapaxes(-1, -2)) * sig[:, 0:1, 0:1]).astype(np.float32)
+    sc = dict(verts=verts, sigmas=sig, focal=300.0, principal=(W / 2.0, H / 2.0), image_size=(H, W),
+              dist=1.5, elev=20.0, azim=40.0)   # camera inside the cloud: Gaussians on both sides of it
+    mus, isg, rays, _, _ = camera_inputs(sc)
+    thr_act = oracle.thr_act_of(0.01)
+    got = run_trace(mus, isg, rays, K, thr_act)
+    S = 20
+    n_neg = 0
+    for y0, x0 in ((0, 0), (180, 200), (H - S, W - S), (90, 300), (300, 40)):
+        ref = oracle.trace_fwd(mus, isg, np.ascontiguousarray(rays[:, y0:y0 + S, x0:x0 + S]), K, thr_act)
+        compare_trace([g[:, y0:y0 + S, x0:x0 + S] for g in got], ref, thr_act, min_match=0.97)
+        n_neg += int(((ref[1] < 0) & (ref[0] >= 0)).sum())
+        assert (ref[0][..., -1] >= 0).mean() > 0.5          # lists are full: the early exit is exercised
+    assert n_neg > 0                                         # hits behind the camera were part of it
+
+
 def test_trace_fwd_nonsymmetric_and_behind_camera(hip_lib):
     """All 9 entries of isigmas are independent inputs (ray_trace_voge.cu:11-38), and Gaussians
     behind the camera are kept with negative len in the -1 path (no sign test, :197)."""

@@ -60,6 +60,9 @@ for case in range(n_cases):
         rgb = (cols[np.maximum(idx_r, 0)] * (wr * (np.arange(K)[None] < vr[:, None]))[..., None]).sum(1)
         x = rgb + (1 - sil)[:, None]
         e = np.abs(n(img).reshape(-1, 3) - np.minimum(x, 1)).max(); worst["img"] = max(worst.get("img", 0), e); assert e < TOL, ("img", e)
+        if (((np.abs(x - 1) < 1e-5) & (x != 1)).any() or (np.abs(wr.sum(-1) - 1) < 1e-5).any()):
+            print(tag, "-> a pixel sits on the min(., 1) clamp within fp32 rounding; skipping gradient checks")
+            continue
         g_rgb = g_img.reshape(-1, 3) * (x < 1)
         g_sil = -(g_rgb.sum(-1)) * (wr.sum(-1) < 1)
         g_attr, g_w = oracle.merge_bwd(cols, idx_r, wr, vr, g_rgb)
@@ -76,6 +79,10 @@ for case in range(n_cases):
             assert err <= 20 * TOL, (name, err)
     except AssertionError as ex:
         print("FAIL", tag, ex)
+        import os
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez("gpurun_out/stress_fail.npz", mus=mus, isg=isg, rays=rays, cols=cols, K=K, thr_act=thr_act, occ=occ,
+                 g_img=g_img if "g_img" in dir() else 0, iso_api=iso_api)
         raise
     if case % 10 == 9:
         print(f"{case + 1} cases ok; worst relative errors so far:", {k: f"{v:.1e}" for k, v in worst.items()})

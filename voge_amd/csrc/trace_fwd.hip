@@ -183,6 +183,7 @@ struct BinLds {
   uint64_t sorted[kBinCap];   // the same, front to back
   float red[16 * 4];
   int hist[kBuckets];
+  uint32_t bmin[kBuckets];   // per bucket: smallest own len bound of the entries with an ellipsoid record (ord)
   int start[kBuckets + 1];
   int wsum[16];
   int count;
@@ -411,7 +412,7 @@ bin0_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, 
 }
 
 __global__ void __launch_bounds__(kBinThreads)
-bin_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, const int *__restrict__ c_count,
+bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, const ConeRec *__restrict__ cones, const int *__restrict__ c_count,
            const int32_t *__restrict__ c_id, const int nst0x, const int nst0, const int N, const int H,
            const int W, const int nstx, int *__restrict__ bin_count, int32_t *__restrict__ bin_id,
            float *__restrict__ bin_lb) {
@@ -425,7 +426,8 @@ bin_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, c
   if (tid == 0) L.count = 0;
   __syncthreads();
   const float4 *cullb = cull + (size_t)b * N;
-  float rmax = 0.0f;   // largest finite reach among this thread's survivors
+  const float4 *ellb = ell + (size_t)b * N * 2;
+  float rmax = 0.0f;   // largest finite reach among this thread's survivors WITHOUT an ellipsoid record
   constexpr int kScanU = 8;
   // candidates: the parent region's list, or (small problems, no coarse level) every Gaussian
   const int parent = b * nst0 + (y0 / kST0) * nst0x + x0 / kST0;
@@ -442,18 +444,36 @@ bin_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, c
     }
 #pragma unroll
     for (int q = 0; q < kScanU; ++q) c[q] = (gid[q] >= 0) ? cullb[gid[q]] : make_float4(0.f, 0.f, 0.f, -1.f);
+    bool kp[kScanU], el[kScanU];
+#pragma unroll
+    for (int q = 0; q < kScanU; ++q) { kp[q] = cone_keep(c[q], cone); el[q] = kp[q] && cull_has_ell(c[q]); }
+    if (__any(el[0] || el[1] || el[2] || el[3] || el[4] || el[5] || el[6] || el[7])) {
+      // anisotropic survivors of the sphere test: separating-plane test against their ellipsoid
+      float4 e0[kScanU], e1[kScanU];
+#pragma unroll
+      for (int q = 0; q < kScanU; ++q)
+        if (el[q]) { e0[q] = ellb[2 * (size_t)gid[q]]; e1[q] = ellb[2 * (size_t)gid[q] + 1]; }
+#pragma unroll
+      for (int q = 0; q < kScanU; ++q)
+        if (el[q]) kp[q] = cone_keep_ell(c[q], e0[q], e1[q], cone);
+    }
 #pragma unroll
     for (int q = 0; q < kScanU; ++q) {
       const int g = gid[q];
-      const bool keep = cone_keep(c[q], cone);
-      if (keep && c[q].w < 3e38f) rmax = fmaxf(rmax, c[q].w);
+      const bool keep = kp[q];
+      if (keep && !el[q] && c[q].w < 3e38f) rmax = fmaxf(rmax, c[q].w);
       const unsigned long long m = __ballot(keep);
       if (m) {
         int start = 0;
         if (lane == 0) start = atomicAdd(&L.count, __popcll(m));
         start = __shfl(start, 0, 64);
         const int slot = start + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep && slot < kBinCap) L.keys[slot] = ((uint64_t)f2ord(depth_key(c[q], cone)) << 32) | (uint32_t)g;
+        // bit 31 of the id word: the entry has an ellipsoid record (its len bound is its own)
+        // (such an entry is ordered by its centre's depth along the axis: its bound does not depend on the key)
+        if (keep && slot < kBinCap) {
+          const float key = el[q] ? fmaf(c[q].z, cone.az, fmaf(c[q].y, cone.ay, c[q].x * cone.ax)) : depth_key(c[q], cone);
+          L.keys[slot] = ((uint64_t)f2ord(key) << 32) | (uint32_t)g | (el[q] ? 0x80000000u : 0u);
+        }
       }
     }
   }
@@ -478,13 +498,29 @@ bin_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, c
   block_reduce16(L.red, wave, lane, rm, rdummy, d0, d1, 1);
   const float span = fmaxf(hi - lo, 1e-20f);
   const float scale = (float)(kBuckets - 2) / span;
-  for (int i = tid; i < kBuckets; i += kBinThreads) L.hist[i] = 0;
+  for (int i = tid; i < kBuckets; i += kBinThreads) { L.hist[i] = 0; L.bmin[i] = f2ord(INFINITY); }
   __syncthreads();
   for (int i = tid; i < total; i += kBinThreads) {
-    const float v = ord2f((uint32_t)(L.keys[i] >> 32));
+    const uint64_t k = L.keys[i];
+    const float v = ord2f((uint32_t)(k >> 32));
     int q = 0;
     if (v > -INFINITY) q = 1 + min(kBuckets - 2, max(0, (int)((v - lo) * scale)));
     atomicAdd(&L.hist[q], 1);
+    if ((uint32_t)k & 0x80000000u) {
+      // own lower bound of len: the peak point x = len d of a hit lies in the ellipsoid, so
+      // len (d.a) = x.a >= t = mu.a - h(a), and d.a is in [cs, 1]
+      const int g = (int)((uint32_t)k & 0x7fffffffu);
+      const float4 c = cullb[g], e0 = ellb[2 * (size_t)g], e1 = ellb[2 * (size_t)g + 1];
+      float bnd = -INFINITY;
+      if (cone.ok) {
+        const float pa = fmaf(c.z, cone.az, fmaf(c.y, cone.ay, c.x * cone.ax));
+        const float nm1 = fabsf(c.x) + fabsf(c.y) + fabsf(c.z);
+        const float t = pa - ell_support(e0, e1, cone.ax, cone.ay, cone.az) - 4e-6f * nm1;
+        bnd = (t >= 0.0f) ? t : t / cone.cs;
+        bnd = bnd - 1e-5f * fabsf(bnd) - 1e-30f;
+      }
+      atomicMin(&L.bmin[q], f2ord(bnd));
+    }
   }
   __syncthreads();
   // exclusive scan of kBuckets (== kBinThreads) counters: wave scan + wave offsets
@@ -530,6 +566,21 @@ bin_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, c
   // actual len), and every entry carries its bucket's lower edge as the len bound: monotone along
   // the list, which is all the sweep's early exit needs.  The order inside a bucket is whatever
   // the LDS atomics produced; the sweep's top-K is order independent.
+  // suffix minimum over the buckets of the flagged entries' own bounds (tid <-> bucket)
+  {
+    uint32_t x = L.bmin[tid];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_down(x, o, 64);
+      if (lane + o < 64) x = min(x, y);
+    }
+    if (lane == 0) L.wsum[wave] = (int)x;
+    __syncthreads();
+    for (int w = wave + 1; w < kBinThreads / 64; ++w) x = min(x, (uint32_t)L.wsum[w]);
+    __syncthreads();
+    L.bmin[tid] = x;
+  }
+  __syncthreads();
   int32_t *oid = bin_id + (size_t)bin * kBinCap;
   float *olb = bin_lb + (size_t)bin * kBinCap;
   const float slack = 1.13f * rm * (1.0f + 1e-5f);
@@ -538,12 +589,17 @@ bin_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, c
     const uint64_t k = L.sorted[i];
     const float v = ord2f((uint32_t)(k >> 32));
     float edge = -INFINITY;
+    int qb = 0;
     if (v > -INFINITY) {
       const int q = min(kBuckets - 2, max(0, (int)((v - lo) * scale)));
       edge = fminf(v, lo + (float)q * inv_scale - 4e-6f * span);
+      qb = 1 + q;
     }
-    oid[i] = (int32_t)(uint32_t)k;
-    olb[i] = (edge > -INFINITY) ? edge - slack - 1e-5f * fabsf(edge) - 1e-30f : -INFINITY;
+    oid[i] = (int32_t)((uint32_t)k & 0x7fffffffu);
+    // sphere-only entries: bucket edge minus the largest sphere reach; entries with an ellipsoid
+    // record: the smallest own bound from this bucket on.  Both are monotone along the list.
+    const float lb_sphere = (edge > -INFINITY) ? edge - slack - 1e-5f * fabsf(edge) - 1e-30f : -INFINITY;
+    olb[i] = fminf(lb_sphere, ord2f(L.bmin[qb]));
   }
   if (tid == 0) bin_count[bin] = total;
 }
@@ -1510,7 +1566,7 @@ static int trace_topk_fwd_impl(const int iso_in, const float *mus, const float *
     hipLaunchKernelGGL(bin0_kernel, dim3(ws.nst0x * ws.nst0y * kBin0Split, B), dim3(kBinThreads), 0, st, ws.cull, ws.cones,
                        ws.nstx, ws.nsty, N, ws.nst0x, ws.c_count, ws.c_id);
   }
-  hipLaunchKernelGGL(bin_kernel, dim3(ws.nstx * ws.nsty, B), dim3(kBinThreads), 0, st, ws.cull, ws.cones,
+  hipLaunchKernelGGL(bin_kernel, dim3(ws.nstx * ws.nsty, B), dim3(kBinThreads), 0, st, ws.cull, ws.ell, ws.cones,
                      coarse ? ws.c_count : nullptr, ws.c_id, ws.nst0x, ws.nst0x * ws.nst0y, N, H, W, ws.nstx, ws.bin_count,
                      ws.bin_id, ws.bin_lb);
   {
