@@ -411,8 +411,12 @@ bin0_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, 
   }
 }
 
+#ifndef VOGE_ELL_KEY
+#define VOGE_ELL_KEY 0
+#endif
 __global__ void __launch_bounds__(kBinThreads)
-bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, const ConeRec *__restrict__ cones, const int *__restrict__ c_count,
+bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, const float4 *__restrict__ evr,
+           const ConeRec *__restrict__ cones, const int *__restrict__ c_count,
            const int32_t *__restrict__ c_id, const int nst0x, const int nst0, const int N, const int H,
            const int W, const int nstx, int *__restrict__ bin_count, int32_t *__restrict__ bin_id,
            float *__restrict__ bin_lb) {
@@ -447,15 +451,30 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
     bool kp[kScanU], el[kScanU];
 #pragma unroll
     for (int q = 0; q < kScanU; ++q) { kp[q] = cone_keep(c[q], cone); el[q] = kp[q] && cull_has_ell(c[q]); }
+    float gkey[kScanU];
+#pragma unroll
+    for (int q = 0; q < kScanU; ++q) gkey[q] = 0.0f;
     if (__any(el[0] || el[1] || el[2] || el[3] || el[4] || el[5] || el[6] || el[7])) {
       // anisotropic survivors of the sphere test: separating-plane test against their ellipsoid
-      float4 e0[kScanU], e1[kScanU];
+      {
+        float4 e0[kScanU], e1[kScanU];
 #pragma unroll
-      for (int q = 0; q < kScanU; ++q)
-        if (el[q]) { e0[q] = ellb[2 * (size_t)gid[q]]; e1[q] = ellb[2 * (size_t)gid[q] + 1]; }
+        for (int q = 0; q < kScanU; ++q)
+          if (el[q]) { e0[q] = ellb[2 * (size_t)gid[q]]; e1[q] = ellb[2 * (size_t)gid[q] + 1]; }
 #pragma unroll
-      for (int q = 0; q < kScanU; ++q)
-        if (el[q]) kp[q] = cone_keep_ell(c[q], e0[q], e1[q], cone);
+        for (int q = 0; q < kScanU; ++q)
+          if (el[q]) {
+            kp[q] = cone_keep_ell(c[q], e0[q], e1[q], cone);
+            el[q] = kp[q];
+            // order key: VOGE_ELL_KEY 0 = the centre's depth along the axis, 1 = the entry's own lower bound of len
+            const float pa = fmaf(c[q].z, cone.az, fmaf(c[q].y, cone.ay, c[q].x * cone.ax));
+#if VOGE_ELL_KEY == 1
+            gkey[q] = pa - ell_support(e0[q], e1[q], cone.ax, cone.ay, cone.az) + 0.0f;
+#else
+            gkey[q] = pa + 0.0f;
+#endif
+          }
+      }
     }
 #pragma unroll
     for (int q = 0; q < kScanU; ++q) {
@@ -469,9 +488,8 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
         start = __shfl(start, 0, 64);
         const int slot = start + __popcll(m & ((1ull << lane) - 1ull));
         // bit 31 of the id word: the entry has an ellipsoid record (its len bound is its own)
-        // (such an entry is ordered by its centre's depth along the axis: its bound does not depend on the key)
         if (keep && slot < kBinCap) {
-          const float key = el[q] ? fmaf(c[q].z, cone.az, fmaf(c[q].y, cone.ay, c[q].x * cone.ax)) : depth_key(c[q], cone);
+          const float key = el[q] ? gkey[q] : depth_key(c[q], cone);
           L.keys[slot] = ((uint64_t)f2ord(key) << 32) | (uint32_t)g | (el[q] ? 0x80000000u : 0u);
         }
       }
@@ -1015,6 +1033,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   float4 m0r = load_ms(id0);
   int id1 = load_id(T + tid);
   float lb1 = load_lb(T + tid);
+  bool tile_gen = false;      // an anisotropic candidate was staged at some point (workgroup-uniform)
   while (base < src_n) {
     int nbuf = 0;
     bool chunk_iso = true;   // every staged candidate of this buffer is isotropic (wave-uniform)
@@ -1064,6 +1083,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 #ifdef VOGE_SWEEP_STATS
     st_staged += nbuf;
 #endif
+    tile_gen = tile_gen || !chunk_iso;
     __syncthreads();
 #ifdef VOGE_SWEEP_TIMES
     const unsigned long long tsb = wall_clock64();
@@ -1280,7 +1300,72 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     const int ipr = row_items >> 2;
     const int nitem = th * ipr;
     const float inv_ipr = 1.0f / (float)ipr, invK = 1.0f / (float)K;
-    for (int it0 = tid; it0 < nitem; it0 += T * kEpiU) {
+    // Tiles that staged anisotropic candidates: centre and full record (4 gathers per slot) are issued
+    // together for kEpiG items -- one round trip per round instead of "centre, then 3 more per slot".
+    // (pair_eval dispatches on the record, so an isotropic entry in such a tile is still exact.)
+    constexpr int kEpiG = 2;
+    for (int it0 = tid; tile_gen && it0 < nitem; it0 += T * kEpiG) {
+      uint64_t key[kEpiG][4];
+      float4 rc[kEpiG][4], g0[kEpiG][4], g1[kEpiG][4], g2[kEpiG][4];
+      float ex[kEpiG], ey[kEpiG], ez[kEpiG];
+      size_t ob[kEpiG];
+      int nv[kEpiG];
+#pragma unroll
+      for (int u = 0; u < kEpiG; ++u) {
+        const int it = it0 + u * T;
+        nv[u] = -1;
+        ob[u] = 0;
+        ex[u] = ey[u] = ez[u] = 0.0f;
+        if (it < nitem) {
+          const int r = __float2int_rz(((float)it + 0.5f) * inv_ipr);
+          const int j = (it - r * ipr) * 4;
+          const int x = __float2int_rz(((float)j + 0.5f) * invK);
+          const int sl = j - x * K;
+          const int owner = ((x >> 3) + (TW / 8) * (r >> 3)) * 64 + (x & 7) + 8 * (r & 7);
+          const size_t pix = ((size_t)b * H + ty * TH + r) * W + (size_t)tx * TW + x;
+          ob[u] = pix * K + sl;
+          nv[u] = max(0, min(4, L.cnt[owner] - sl));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) key[u][q] = (q < nv[u]) ? keys[(size_t)(sl + q) * TP + owner] : 0ull;
+          if (nv[u] > 0) { ex[u] = rays[pix * 3]; ey[u] = rays[pix * 3 + 1]; ez[u] = rays[pix * 3 + 2]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kEpiG; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          rc[u][q] = g0[u][q] = g1[u][q] = g2[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (q < nv[u]) {
+            const size_t gi = (uint32_t)key[u][q];
+            rc[u][q] = ms[gi]; g0[u][q] = evr[gi * 3]; g1[u][q] = evr[gi * 3 + 1]; g2[u][q] = evr[gi * 3 + 2];
+          }
+        }
+#pragma unroll
+      for (int u = 0; u < kEpiG; ++u) {
+        if (nv[u] < 0) continue;
+        int32_t oi[4];
+        float ol[4], oa[4], od[4];
+        const float qxx = ex[u] * ex[u], qyy = ey[u] * ey[u], qzz = ez[u] * ez[u];
+        const float qxy = ex[u] * ey[u], qxz = ex[u] * ez[u], qyz = ey[u] * ez[u];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          oi[q] = -1; ol[q] = VOGE_SENT_LEN; oa[q] = VOGE_SENT_ACT; od[q] = 0.0f;
+          if (q < nv[u]) {
+            oi[q] = (int32_t)(uint32_t)key[u][q];
+            ol[q] = ord2f((uint32_t)(key[u][q] >> 32));
+            const PairOut o = pair_eval(rc[u][q].x, rc[u][q].y, rc[u][q].z, unpack_eval(g0[u][q], g1[u][q], g2[u][q]),
+                                        ex[u], ey[u], ez[u], qxx, qyy, qzz, qxy, qxz, qyz);
+            oa[q] = o.act;
+            od[q] = o.dsd;
+          }
+        }
+        *reinterpret_cast<int4 *>(out_idx + ob[u]) = make_int4(oi[0], oi[1], oi[2], oi[3]);
+        *reinterpret_cast<float4 *>(out_len + ob[u]) = make_float4(ol[0], ol[1], ol[2], ol[3]);
+        *reinterpret_cast<float4 *>(out_act + ob[u]) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+        *reinterpret_cast<float4 *>(out_dsd + ob[u]) = make_float4(od[0], od[1], od[2], od[3]);
+      }
+    }
+    for (int it0 = tid; !tile_gen && it0 < nitem; it0 += T * kEpiU) {
       uint64_t key[kEpiU][4];
       float4 rec[kEpiU][4];
       float ex[kEpiU], ey[kEpiU], ez[kEpiU];
@@ -1311,12 +1396,31 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           rec[u][q] = (q < nv[u]) ? ms[(uint32_t)key[u][q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      // anisotropic entries (w = NaN) need their full record: 3 more gathers each.  They are issued for
+      // all four slots of an item before any is used (12 in flight per lane instead of 3).
+      bool gen_any = false;
+#pragma unroll
+      for (int u = 0; u < kEpiU; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gen_any = gen_any || ((q < nv[u]) && !(rec[u][q].w == rec[u][q].w));
+      gen_any = __any(gen_any);
 #pragma unroll
       for (int u = 0; u < kEpiU; ++u) {
         if (nv[u] < 0) continue;
         int32_t oi[4];
         float ol[4], oa[4], od[4];
         const float qxx = ex[u] * ex[u], qyy = ey[u] * ey[u], qzz = ez[u] * ez[u];
+        float4 g0[4], g1[4], g2[4];
+        if (gen_any) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            g0[q] = g1[q] = g2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((q < nv[u]) && !(rec[u][q].w == rec[u][q].w)) {
+              const size_t eo = (size_t)(uint32_t)key[u][q] * 3;
+              g0[q] = evr[eo]; g1[q] = evr[eo + 1]; g2[q] = evr[eo + 2];
+            }
+          }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           oi[q] = -1; ol[q] = VOGE_SENT_LEN; oa[q] = VOGE_SENT_ACT; od[q] = 0.0f;
@@ -1327,7 +1431,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             if (rec[u][q].w == rec[u][q].w) {
               o = pair_eval_iso(rec[u][q].x, rec[u][q].y, rec[u][q].z, rec[u][q].w, ex[u], ey[u], ez[u], qxx, qyy, qzz);
             } else {
-              const EvalRec e = unpack_eval(evr[(size_t)oi[q] * 3 + 0], evr[(size_t)oi[q] * 3 + 1], evr[(size_t)oi[q] * 3 + 2]);
+              const EvalRec e = unpack_eval(g0[q], g1[q], g2[q]);
               o = pair_eval(rec[u][q].x, rec[u][q].y, rec[u][q].z, e, ex[u], ey[u], ez[u], qxx, qyy, qzz, ex[u] * ey[u],
                             ex[u] * ez[u], ey[u] * ez[u]);
             }
@@ -1566,7 +1670,7 @@ static int trace_topk_fwd_impl(const int iso_in, const float *mus, const float *
     hipLaunchKernelGGL(bin0_kernel, dim3(ws.nst0x * ws.nst0y * kBin0Split, B), dim3(kBinThreads), 0, st, ws.cull, ws.cones,
                        ws.nstx, ws.nsty, N, ws.nst0x, ws.c_count, ws.c_id);
   }
-  hipLaunchKernelGGL(bin_kernel, dim3(ws.nstx * ws.nsty, B), dim3(kBinThreads), 0, st, ws.cull, ws.ell, ws.cones,
+  hipLaunchKernelGGL(bin_kernel, dim3(ws.nstx * ws.nsty, B), dim3(kBinThreads), 0, st, ws.cull, ws.ell, ws.evr, ws.cones,
                      coarse ? ws.c_count : nullptr, ws.c_id, ws.nst0x, ws.nst0x * ws.nst0y, N, H, W, ws.nstx, ws.bin_count,
                      ws.bin_id, ws.bin_lb);
   {

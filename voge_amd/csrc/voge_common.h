@@ -197,7 +197,11 @@ __device__ __forceinline__ void topk_commit(uint64_t *keys, const int stride, co
   cnt += app ? 1 : 0;
   tail = app ? key : tail;
   worst = (app && cnt == K) ? key : worst;
+#ifdef VOGE_NO_SLOW
+  const bool slow = false;
+#else
   const bool slow = take && !app;
+#endif
   if (__any(slow)) {
     if (slow) {
       if (cnt < K) {   // somewhere in the middle: everything above moves up, the tail stays the tail
