@@ -187,6 +187,7 @@ struct BinLds {
   int start[kBuckets + 1];
   int wsum[16];
   int count;
+  int nflag;      // entries with an ellipsoid record
 };
 
 __device__ __forceinline__ void block_reduce16(float *red, const int wave, const int lane, float &a, float &b,
@@ -427,7 +428,7 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
   const Cone cone = load_cone(cones[(size_t)b * gridDim.x + blockIdx.x]);
 
   // ---- scan all Gaussians of this batch element, keep (bound, id) of the survivors ----
-  if (tid == 0) L.count = 0;
+  if (tid == 0) { L.count = 0; L.nflag = 0; }
   __syncthreads();
   const float4 *cullb = cull + (size_t)b * N;
   const float4 *ellb = ell + (size_t)b * N * 2;
@@ -455,25 +456,28 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
 #pragma unroll
     for (int q = 0; q < kScanU; ++q) gkey[q] = 0.0f;
     if (__any(el[0] || el[1] || el[2] || el[3] || el[4] || el[5] || el[6] || el[7])) {
-      // anisotropic survivors of the sphere test: separating-plane test against their ellipsoid
-      {
-        float4 e0[kScanU], e1[kScanU];
+      // anisotropic survivors of the sphere test: separating-plane test against their ellipsoid,
+      // four at a time (the records of all eight would not fit the 128 registers of a 1024-thread workgroup)
 #pragma unroll
-        for (int q = 0; q < kScanU; ++q)
-          if (el[q]) { e0[q] = ellb[2 * (size_t)gid[q]]; e1[q] = ellb[2 * (size_t)gid[q] + 1]; }
+      for (int h = 0; h < kScanU; h += 4) {
+        float4 e0[4], e1[4];
 #pragma unroll
-        for (int q = 0; q < kScanU; ++q)
-          if (el[q]) {
-            kp[q] = cone_keep_ell(c[q], e0[q], e1[q], cone);
-            el[q] = kp[q];
+        for (int q = 0; q < 4; ++q)
+          if (el[h + q]) { e0[q] = ellb[2 * (size_t)gid[h + q]]; e1[q] = ellb[2 * (size_t)gid[h + q] + 1]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (el[h + q]) {
+            kp[h + q] = cone_keep_ell(c[h + q], e0[q], e1[q], cone);
+            el[h + q] = kp[h + q];
             // order key: VOGE_ELL_KEY 0 = the centre's depth along the axis, 1 = the entry's own lower bound of len
-            const float pa = fmaf(c[q].z, cone.az, fmaf(c[q].y, cone.ay, c[q].x * cone.ax));
+            const float pa = fmaf(c[h + q].z, cone.az, fmaf(c[h + q].y, cone.ay, c[h + q].x * cone.ax));
 #if VOGE_ELL_KEY == 1
-            gkey[q] = pa - ell_support(e0[q], e1[q], cone.ax, cone.ay, cone.az) + 0.0f;
+            gkey[h + q] = pa - ell_support(e0[q], e1[q], cone.ax, cone.ay, cone.az) + 0.0f;
 #else
-            gkey[q] = pa + 0.0f;
+            gkey[h + q] = pa + 0.0f;
 #endif
           }
+        asm volatile("" ::: "memory");
       }
     }
 #pragma unroll
@@ -483,8 +487,12 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
       if (keep && !el[q] && c[q].w < 3e38f) rmax = fmaxf(rmax, c[q].w);
       const unsigned long long m = __ballot(keep);
       if (m) {
+        const bool wave_flag = __any(keep && el[q]);
         int start = 0;
-        if (lane == 0) start = atomicAdd(&L.count, __popcll(m));
+        if (lane == 0) {
+          start = atomicAdd(&L.count, __popcll(m));
+          if (wave_flag) L.nflag = 1;
+        }
         start = __shfl(start, 0, 64);
         const int slot = start + __popcll(m & ((1ull << lane) - 1ull));
         // bit 31 of the id word: the entry has an ellipsoid record (its len bound is its own)
@@ -516,6 +524,7 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
   block_reduce16(L.red, wave, lane, rm, rdummy, d0, d1, 1);
   const float span = fmaxf(hi - lo, 1e-20f);
   const float scale = (float)(kBuckets - 2) / span;
+  const bool flagged = L.nflag != 0;     // any entry with an ellipsoid record (workgroup-uniform)
   for (int i = tid; i < kBuckets; i += kBinThreads) { L.hist[i] = 0; L.bmin[i] = f2ord(INFINITY); }
   __syncthreads();
   for (int i = tid; i < total; i += kBinThreads) {
@@ -585,7 +594,7 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
   // the list, which is all the sweep's early exit needs.  The order inside a bucket is whatever
   // the LDS atomics produced; the sweep's top-K is order independent.
   // suffix minimum over the buckets of the flagged entries' own bounds (tid <-> bucket)
-  {
+  if (flagged) {
     uint32_t x = L.bmin[tid];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -617,7 +626,7 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
     // sphere-only entries: bucket edge minus the largest sphere reach; entries with an ellipsoid
     // record: the smallest own bound from this bucket on.  Both are monotone along the list.
     const float lb_sphere = (edge > -INFINITY) ? edge - slack - 1e-5f * fabsf(edge) - 1e-30f : -INFINITY;
-    olb[i] = fminf(lb_sphere, ord2f(L.bmin[qb]));
+    olb[i] = flagged ? fminf(lb_sphere, ord2f(L.bmin[qb])) : lb_sphere;
   }
   if (tid == 0) bin_count[bin] = total;
 }
@@ -685,31 +694,33 @@ bin2_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   for (int base = 0; base < bc; base += 1024) {
     // four chunks per trip: 4 independent (id -> record) chains in flight per lane
     int id[4];
-    float lbv[4];
     float4 c[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int g = base + q * 256 + tid;
       id[q] = (g < bc) ? src_id[g] : -1;
-      lbv[q] = (g < bc) ? src_lb[g] : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) c[q] = (id[q] >= 0) ? cullb[id[q]] : make_float4(0.f, 0.f, 0.f, -1.f);
     bool kp[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) kp[q] = cone_keep(c[q], cone);
-    // anisotropic survivors of the sphere test: the ellipsoid test (two more gathers, all in flight)
-    {
-      float4 e0[4], e1[4];
-      bool el[4];
+    // anisotropic survivors of the sphere test: the ellipsoid test, two candidates at a time (their
+    // records in flight together; all four would cost the kernel three waves per SIMD of occupancy)
+    bool el[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        el[q] = kp[q] && cull_has_ell(c[q]);
-        if (el[q]) { e0[q] = ellb[2 * (size_t)id[q]]; e1[q] = ellb[2 * (size_t)id[q] + 1]; }
+    for (int q = 0; q < 4; ++q) el[q] = kp[q] && cull_has_ell(c[q]);
+#pragma unroll
+    for (int h = 0; h < 4; h += 2) {
+      if (__any(el[h] || el[h + 1])) {
+        float4 e0[2], e1[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (el[h + q]) { e0[q] = ellb[2 * (size_t)id[h + q]]; e1[q] = ellb[2 * (size_t)id[h + q] + 1]; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (el[h + q]) kp[h + q] = cone_keep_ell(c[h + q], e0[q], e1[q], cone);
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (el[q]) kp[q] = cone_keep_ell(c[q], e0[q], e1[q], cone);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -727,7 +738,7 @@ bin2_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
       }
       if (keep) {
         const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < kTileCap) { oid[pos] = id[q]; olb[pos] = lbv[q]; }
+        if (pos < kTileCap) { oid[pos] = id[q]; olb[pos] = src_lb[base + q * 256 + tid]; }   // (a survivor's bound: loaded only now)
       }
       total += tot;
       par ^= 1;

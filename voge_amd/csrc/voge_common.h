@@ -269,7 +269,11 @@ __device__ __forceinline__ bool cone_keep(const float4 c, const Cone &k) {
 }
 
 // Does the cull record carry an ellipsoid record (trace_fwd.hip, prep_one)?
+#ifdef VOGE_NO_ELL   // build without the ellipsoid tests (bounding spheres only): for A/B timing
+__device__ __forceinline__ bool cull_has_ell(const float4) { return false; }
+#else
 __device__ __forceinline__ bool cull_has_ell(const float4 c) { return (__float_as_uint(c.w) & 1u) != 0u && c.w > 0.0f && c.w < 3e38f; }
+#endif
 
 // Support function of the hit ellipsoid along n (|n| <= ~1), rounded up.  e0 = (M00, M11, M22, M01),
 // e1 = (M02, M12, slack of n^T M n, additive slack).
