@@ -295,7 +295,7 @@ def main():
             # HBM bytes per launch from rocprofv3 PMC passes of this same command (not collectable live)
             traffic = json.load(open(tfile)).get("voge_trace_topk_fwd_bytes")
             traffic_src = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
-        result["roofline"] = {"kernel": "voge_trace_topk_fwd(_iso) = prep + bincone + bin0 + bin + bin2 + trace_fwd_kernel",
+        result["roofline"] = {"kernel": "voge_trace_topk_fwd(_iso) = prep_cone + bin0 + bin + bin2 + tile_order + trace_fwd_kernel",
                               "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                               "algorithmic_bytes": nbytes[dom], "avg_launch_ms": stages[dom]["ms"]}

@@ -8,7 +8,7 @@ import json
 import sys
 from collections import defaultdict
 
-TRACE_FWD = ("prep_kernel", "bincone_kernel", "bin0_kernel", "bin_kernel", "bin2_kernel", "trace_fwd_kernel")
+TRACE_FWD = ("prep_cone_kernel", "bin0_kernel", "bin_kernel", "bin2_kernel", "tile_order_kernel", "trace_fwd_kernel")
 
 
 def collect(d, counter):
