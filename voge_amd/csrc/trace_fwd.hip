@@ -420,7 +420,7 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
            const ConeRec *__restrict__ cones, const int *__restrict__ c_count,
            const int32_t *__restrict__ c_id, const int nst0x, const int nst0, const int N, const int H,
            const int W, const int nstx, int *__restrict__ bin_count, int32_t *__restrict__ bin_id,
-           float *__restrict__ bin_lb) {
+           float *__restrict__ bin_lb, float4 *__restrict__ bin_rec) {
   __shared__ BinLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int stx = blockIdx.x % nstx, sty = blockIdx.x / nstx, b = blockIdx.y;
@@ -610,6 +610,7 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
   __syncthreads();
   int32_t *oid = bin_id + (size_t)bin * kBinCap;
   float *olb = bin_lb + (size_t)bin * kBinCap;
+  float4 *orec = bin_rec + (size_t)bin * kBinCap;
   const float slack = 1.13f * rm * (1.0f + 1e-5f);
   const float inv_scale = span / (float)(kBuckets - 2);
   for (int i = tid; i < total; i += kBinThreads) {
@@ -623,6 +624,9 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
       qb = 1 + q;
     }
     oid[i] = (int32_t)((uint32_t)k & 0x7fffffffu);
+    // the entry's cull record rides along in list order: the 16 sweep tiles of this super-tile then
+    // stream it (16 coalesced bytes per entry) instead of gathering it by id once each
+    orec[i] = cullb[(uint32_t)k & 0x7fffffffu];
     // sphere-only entries: bucket edge minus the largest sphere reach; entries with an ellipsoid
     // record: the smallest own bound from this bucket on.  Both are monotone along the list.
     const float lb_sphere = (edge > -INFINITY) ? edge - slack - 1e-5f * fabsf(edge) - 1e-30f : -INFINITY;
@@ -640,7 +644,7 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
 constexpr int kTileCap = 2048;
 
 __global__ void __launch_bounds__(256)
-bin2_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, const float *__restrict__ rays, const int *__restrict__ bin_count,
+bin2_kernel(const float4 *__restrict__ bin_rec, const float4 *__restrict__ ell, const float *__restrict__ rays, const int *__restrict__ bin_count,
             const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb, const int nstx, const int nst,
             const int N, const int H, const int W, const int TW, const int TH, int *__restrict__ tl_count,
             int32_t *__restrict__ tl_id, float *__restrict__ tl_lb, const int K, int32_t *__restrict__ out_idx,
@@ -658,6 +662,21 @@ bin2_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
     if (tid == 0) tl_count[tile] = -1;
     return;
   }
+  // The first trip's ids and records do not depend on the cone: their two dependent round trips
+  // overlap the ray loads and the two reductions of the cone.
+  const int32_t *src_id = bin_id + (size_t)bin * kBinCap;
+  const float4 *src_rec = bin_rec + (size_t)bin * kBinCap;
+  int id[4];
+  float4 c[4];
+  auto load_trip = [&](const int base) {   // ids and records are both streams: one round trip
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int g = base + q * 256 + tid;
+      id[q] = (g < bc) ? src_id[g] : -1;
+      c[q] = (g < bc) ? src_rec[g] : make_float4(0.f, 0.f, 0.f, -1.f);
+    }
+  };
+  load_trip(0);
   // ---- cone of the tile's rays (thread <-> pixel, clamped at the image border) ----
   const int lx = tid % TW, ly = tid / TW;
   const bool has = ly < TH;
@@ -684,24 +703,14 @@ bin2_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   const Cone cone = cone_finish(ax, ay, az, n, smax, cmin, all_ok);
 
   // ---- ordered filter of the parent list ----
-  const int32_t *src_id = bin_id + (size_t)bin * kBinCap;
   const float *src_lb = bin_lb + (size_t)bin * kBinCap;
-  const float4 *cullb = cull + (size_t)b * N;
   const float4 *ellb = ell + (size_t)b * N * 2;
   int32_t *oid = tl_id + (size_t)tile * kTileCap;
   float *olb = tl_lb + (size_t)tile * kTileCap;
   int total = 0, par = 0;
   for (int base = 0; base < bc; base += 1024) {
     // four chunks per trip: 4 independent (id -> record) chains in flight per lane
-    int id[4];
-    float4 c[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int g = base + q * 256 + tid;
-      id[q] = (g < bc) ? src_id[g] : -1;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) c[q] = (id[q] >= 0) ? cullb[id[q]] : make_float4(0.f, 0.f, 0.f, -1.f);
+    if (base > 0) load_trip(base);
     bool kp[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) kp[q] = cone_keep(c[q], cone);
@@ -1557,6 +1566,7 @@ struct TraceWs {
   int *bin_count;
   int32_t *bin_id;
   float *bin_lb;
+  float4 *bin_rec;     // the cull records of the list entries, in list order (bin2 streams them)
   int *tl_count;
   int32_t *tl_id;
   float *tl_lb;
@@ -1583,9 +1593,10 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
        *tl = take(ntile * kTileCap * 4);
   const int nst0x = (W + kST0 - 1) / kST0, nst0y = (H + kST0 - 1) / kST0;
   const size_t nreg = (size_t)B * nst0x * nst0y;
-  char *cc = take(nreg * 4), *ci = take(nreg * (size_t)N * 4), *cn = take(nbin * sizeof(ConeRec)), *to = take(ntile * 4), *el = take(P * 32);
+  char *cc = take(nreg * 4), *ci = take(nreg * (size_t)N * 4), *cn = take(nbin * sizeof(ConeRec)), *to = take(ntile * 4), *el = take(P * 32), *br = take(nbin * kBinCap * 16);
   if (ws) {
     ws->ell = reinterpret_cast<float4 *>(el);
+    ws->bin_rec = reinterpret_cast<float4 *>(br);
     ws->c_count = reinterpret_cast<int *>(cc); ws->c_id = reinterpret_cast<int32_t *>(ci);
     ws->cones = reinterpret_cast<ConeRec *>(cn);
     ws->tile_order = reinterpret_cast<int *>(to);
@@ -1613,7 +1624,7 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid(((W + TW - 1) / TW) * ((H + TH - 1) / TH), B);
-  hipLaunchKernelGGL(bin2_kernel, grid, dim3(256), 0, st, ws.cull, ws.ell, rays, ws.bin_count, ws.bin_id, ws.bin_lb, ws.nstx,
+  hipLaunchKernelGGL(bin2_kernel, grid, dim3(256), 0, st, ws.bin_rec, ws.ell, rays, ws.bin_count, ws.bin_id, ws.bin_lb, ws.nstx,
                      ws.nstx * ws.nsty, N, H, W, TW, TH, ws.tl_count, ws.tl_id, ws.tl_lb, K, idx, len, act, dsd, cnt);
   {
     int rc = launch_status();
@@ -1683,7 +1694,7 @@ static int trace_topk_fwd_impl(const int iso_in, const float *mus, const float *
   }
   hipLaunchKernelGGL(bin_kernel, dim3(ws.nstx * ws.nsty, B), dim3(kBinThreads), 0, st, ws.cull, ws.ell, ws.evr, ws.cones,
                      coarse ? ws.c_count : nullptr, ws.c_id, ws.nst0x, ws.nst0x * ws.nst0y, N, H, W, ws.nstx, ws.bin_count,
-                     ws.bin_id, ws.bin_lb);
+                     ws.bin_id, ws.bin_lb, ws.bin_rec);
   {
     int rc = launch_status();
     if (rc) return rc;
