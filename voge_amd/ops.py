@@ -10,7 +10,31 @@ from . import _lib
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of the current stream of the current device.  (torch.cuda.current_stream() builds a
+    Stream object and costs ~10 us a call -- several calls per frame on a path whose small frames are
+    host-bound; the raw getter is what torch's own compiled code uses.)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+class _on:
+    """`with _on(device)`: make `device` current for the launches inside.  Unlike torch.cuda.device it
+    does nothing at all (no guard object, no driver call) when the device is already current."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = device.index if device.index is not None else torch._C._cuda_getDevice()
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch._C._cuda_getDevice()
+        if cur != self.idx:
+            self.prev = cur
+            torch._C._cuda_setDevice(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch._C._cuda_setDevice(self.prev)
+        return False
 
 
 def _dev(t, dtype, name):
@@ -58,7 +82,7 @@ class _RayTraceVoGE(torch.autograd.Function):
         sel_act = torch.empty_like(sel_len)
         sel_dsd = torch.empty_like(sel_len)
         cnt = None
-        with torch.cuda.device(dev):
+        with _on(dev):
             if bin_points is not None and bin_points.dtype in (torch.int32, torch.int64):
                 bins = _dev(bin_points, torch.int32, "bin_points")
                 assert bins.dim() == 4 and bins.shape[0] == B
@@ -117,7 +141,7 @@ class _RayTraceVoGE(torch.autograd.Function):
         g_ray = torch.empty_like(rays) if ctx.needs_input_grad[2] else None
         g_mus = torch.empty_like(mus)
         g_isg = torch.empty_like(isg)
-        with torch.cuda.device(rays.device):
+        with _on(rays.device):
             nbytes = lib.voge_trace_bwd_workspace_bytes(P)
             ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=rays.device)
             rc = lib.voge_trace_bwd(_p(mus), _p(isg), _p(rays), _p(sel_idx), _p(ctx.cnt), _p(gl), _p(ga), _p(gd), P,
@@ -150,7 +174,7 @@ class _RayTraceVoGEIso(torch.autograd.Function):
         sel_dsd = torch.empty_like(sel_len)
         cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
         fwd = None if cam_fwd is None else _dev(cam_fwd, torch.float32, "cam_fwd")
-        with torch.cuda.device(dev):
+        with _on(dev):
             nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
             ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
             rc = lib.voge_trace_topk_fwd_iso(
@@ -186,7 +210,7 @@ class _RayTraceVoGEIso(torch.autograd.Function):
         g_ray = torch.empty_like(rays) if ctx.needs_input_grad[2] else None
         g_mus = torch.empty_like(mus)
         g_a = torch.empty_like(a)
-        with torch.cuda.device(rays.device):
+        with _on(rays.device):
             nbytes = lib.voge_trace_bwd_iso_workspace_bytes(P)
             ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=rays.device)
             rc = lib.voge_trace_bwd_iso(_p(mus), _p(a), _p(rays), _p(sel_idx), _p(ctx.cnt), _p(gl), _p(ga), _p(gd), P,
@@ -215,7 +239,7 @@ class _Composite(torch.autograd.Function):
         npix = idx.numel() // max(K, 1)
         weight = torch.empty_like(act)
         valid = torch.empty(idx.shape[:-1], dtype=torch.int64, device=idx.device)
-        with torch.cuda.device(idx.device):
+        with _on(idx.device):
             rc = lib.voge_composite_fwd(_p(idx), _p(cnt), _p(act), _p(ln), _p(dsd), float(occ), npix, K, _p(weight),
                                         _p(valid), _stream())
         _lib.check(rc, "voge_composite_fwd")
@@ -238,7 +262,7 @@ class _Composite(torch.autograd.Function):
         g_act = torch.empty_like(act)
         g_len = torch.empty_like(act)
         g_dsd = torch.empty_like(act)
-        with torch.cuda.device(act.device):
+        with _on(act.device):
             rc = lib.voge_composite_bwd(_p(act), _p(ln), _p(dsd), _p(weight), _p(ctx.cnt), _p(gw), ctx.occ, npix, K, _p(g_act), _p(g_len),
                                         _p(g_dsd), _stream())
         _lib.check(rc, "voge_composite_bwd")
@@ -261,7 +285,7 @@ class _Merge(torch.autograd.Function):
         npix = idx.numel() // max(K, 1)
         Nattr, C = attr_c.shape
         out = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
-        with torch.cuda.device(idx.device):
+        with _on(idx.device):
             rc = lib.voge_merge_fwd(_p(attr_c), _p(idx), _p(w), _p(vn), npix, K, C, Nattr, 1, _p(out), _stream())
         _lib.check(rc, "voge_merge_fwd")
         # idx is an int tensor outside autograd; it is kept as a plain attribute because the in-place
@@ -283,7 +307,7 @@ class _Merge(torch.autograd.Function):
         go = _dev(g_out, torch.float32, "grad_out")
         g_attr = torch.empty_like(attr) if ctx.needs[0] else None
         g_w = torch.empty_like(w) if ctx.needs[1] else None
-        with torch.cuda.device(idx.device):
+        with _on(idx.device):
             Wd = idx.shape[-2] if idx.dim() >= 3 else npix
             rc = lib.voge_merge_bwd(_p(attr), _p(idx), _p(w), _p(vn), _p(go), npix // max(Wd, 1), Wd, K, C, Nattr,
                                     _p(g_attr), _p(g_w), _stream())
@@ -305,7 +329,7 @@ class _Blend(torch.autograd.Function):
         npix = w.numel() // max(K, 1)
         assert bg_c.numel() == C and rgb_c.numel() == npix * C
         out = torch.empty_like(rgb_c)
-        with torch.cuda.device(w.device):
+        with _on(w.device):
             rc = lib.voge_blend_fwd(_p(rgb_c), _p(w), _p(bg_c), float(thr), npix, K, C, _p(out), None, _stream())
         _lib.check(rc, "voge_blend_fwd")
         ctx.save_for_backward(rgb_c, w, bg_c)
@@ -322,7 +346,7 @@ class _Blend(torch.autograd.Function):
         go = _dev(g_out, torch.float32, "grad_out")
         g_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[0] else None
         g_w = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(w.device):
+        with _on(w.device):
             rc = lib.voge_blend_bwd(_p(rgb), _p(w), _p(bg), ctx.thr, _p(go), npix, K, C, _p(g_rgb), _p(g_w), _stream())
         _lib.check(rc, "voge_blend_bwd")
         return g_rgb, g_w, None, None
@@ -348,7 +372,7 @@ class _Shade(torch.autograd.Function):
         rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
         img = torch.empty_like(rgb)
         wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
-        with torch.cuda.device(idx.device):
+        with _on(idx.device):
             rc = lib.voge_shade_fwd(_p(attr_c), _p(idx), _p(w), _p(vn), _p(bg_c), float(thr), npix, K, C, Nattr, 1,
                                     _p(rgb), _p(img), None, _p(wsum), _stream())
         _lib.check(rc, "voge_shade_fwd")
@@ -369,7 +393,7 @@ class _Shade(torch.autograd.Function):
         g_attr = torch.empty_like(attr) if ctx.needs_input_grad[0] else None
         g_w = torch.empty_like(w) if ctx.needs_input_grad[1] else None
         Wd = idx.shape[-2] if idx.dim() >= 3 else npix
-        with torch.cuda.device(idx.device):
+        with _on(idx.device):
             rc = lib.voge_shade_bwd(_p(attr), _p(idx), _p(w), _p(vn), _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go),
                                     npix // max(Wd, 1), Wd, K, C, Nattr, _p(g_attr), _p(g_w), _stream())
         _lib.check(rc, "voge_shade_bwd")
@@ -387,7 +411,7 @@ class _Silhouette(torch.autograd.Function):
         K = w.shape[-1]
         npix = w.numel() // max(K, 1)
         sil = torch.empty(w.shape[:-1], dtype=torch.float32, device=w.device)
-        with torch.cuda.device(w.device):
+        with _on(w.device):
             rc = lib.voge_blend_fwd(None, _p(w), None, -1.0, npix, K, 0, None, _p(sil), _stream())
         _lib.check(rc, "voge_blend_fwd")
         ctx.save_for_backward(w)
@@ -405,7 +429,7 @@ class _Silhouette(torch.autograd.Function):
         bg = torch.full((1,), -1.0, dtype=torch.float32, device=w.device)
         go = _dev(g_sil, torch.float32, "grad_sil").reshape(zero.shape).contiguous()
         g_w = torch.empty_like(w)
-        with torch.cuda.device(w.device):
+        with _on(w.device):
             rc = lib.voge_blend_bwd(_p(zero), _p(w), _p(bg), -1.0, _p(go), npix, K, 1, None, _p(g_w), _stream())
         _lib.check(rc, "voge_blend_bwd")
         return g_w
@@ -424,7 +448,7 @@ class _PixelRays(torch.autograd.Function):
         assert R_c.shape == (B, 3, 3) and T_c.shape == (B, 3) and f_c.shape == (B, 2) and p_c.shape == (B, 2)
         rays = torch.empty((B, h, W, 3), dtype=torch.float32, device=R_c.device)
         origin = torch.empty((B, 3), dtype=torch.float32, device=R_c.device)
-        with torch.cuda.device(R_c.device):
+        with _on(R_c.device):
             rc = lib.voge_rays_fwd(_p(R_c), _p(T_c), _p(f_c), _p(p_c), B, int(row0), int(h), int(W), _p(rays),
                                    _p(origin), _stream())
         _lib.check(rc, "voge_rays_fwd")
@@ -446,7 +470,7 @@ class _PixelRays(torch.autograd.Function):
         g_f = torch.empty_like(f) if need[2] else None
         g_p = torch.empty_like(pp) if need[3] else None
         scratch = torch.empty((B, 16), dtype=torch.float32, device=R.device)
-        with torch.cuda.device(R.device):
+        with _on(R.device):
             rc = lib.voge_rays_bwd(_p(R), _p(T), _p(f), _p(pp), _p(gr), _p(go), B, row0, h, W, _p(scratch), _p(g_R),
                                    _p(g_T), _p(g_f), _p(g_p), _stream())
         _lib.check(rc, "voge_rays_bwd")
@@ -463,7 +487,7 @@ class _RayTraceVoGERay(torch.autograd.Function):
         mus_c, sig_c, rays_c = _dev(mus, torch.float32, "mus"), _dev(sigmas, torch.float32, "sigmas"), _dev(rays, torch.float32, "rays")
         M, N = mus_c.shape[0], rays_c.shape[0]
         out = [torch.empty((N, M), dtype=torch.float32, device=rays_c.device) for _ in range(3)]
-        with torch.cuda.device(rays_c.device):
+        with _on(rays_c.device):
             rc = lib.voge_ray_dense_fwd(_p(mus_c), _p(sig_c), _p(rays_c), M, N, _p(out[0]), _p(out[1]), _p(out[2]), _stream())
         _lib.check(rc, "voge_ray_dense_fwd")
         ctx.save_for_backward(mus_c, sig_c, rays_c)
@@ -477,7 +501,7 @@ class _RayTraceVoGERay(torch.autograd.Function):
         gs = [torch.zeros((N, M), dtype=torch.float32, device=rays.device) if g is None else _dev(g, torch.float32, "grad")
               for g in (g_len, g_act, g_dsd)]
         g_ray, g_mus, g_sig = torch.empty_like(rays), torch.empty_like(mus), torch.empty_like(sig)
-        with torch.cuda.device(rays.device):
+        with _on(rays.device):
             rc = lib.voge_ray_dense_bwd(_p(mus), _p(sig), _p(rays), _p(gs[0]), _p(gs[1]), _p(gs[2]), M, N, _p(g_ray),
                                         _p(g_mus), _p(g_sig), _stream())
         _lib.check(rc, "voge_ray_dense_bwd")
@@ -494,7 +518,7 @@ class _FindNearestK(torch.autograd.Function):
         N, M = l.shape
         idx = torch.empty((N, K), dtype=torch.int32, device=l.device)
         outs = [torch.empty((N, K), dtype=torch.float32, device=l.device) for _ in range(3)]
-        with torch.cuda.device(l.device):
+        with _on(l.device):
             rc = lib.voge_find_nearest_k(_p(l), _p(a), _p(d), float(thr_act), M, int(K), N, _p(idx), _p(outs[0]),
                                          _p(outs[1]), _p(outs[2]), _stream())
         _lib.check(rc, "voge_find_nearest_k")
@@ -511,7 +535,7 @@ class _FindNearestK(torch.autograd.Function):
         gs = [torch.zeros((N, K), dtype=torch.float32, device=idx.device) if g is None else _dev(g, torch.float32, "grad")
               for g in (g_len, g_act, g_dsd)]
         gi = [torch.empty((N, ctx.M), dtype=torch.float32, device=idx.device) for _ in range(3)]
-        with torch.cuda.device(idx.device):
+        with _on(idx.device):
             rc = lib.voge_find_nearest_k_bwd(_p(idx), _p(gs[0]), _p(gs[1]), _p(gs[2]), ctx.M, K, N, _p(gi[0]), _p(gi[1]),
                                              _p(gi[2]), _stream())
         _lib.check(rc, "voge_find_nearest_k_bwd")
@@ -536,7 +560,7 @@ class _ScatterAttr(torch.autograd.Function):
         npix = ix.numel() // max(K, 1)
         Wd = ix.shape[-2] if ix.dim() >= 3 else npix
         out = torch.empty((int(n_vert), C), dtype=torch.float32, device=ix.device)
-        with torch.cuda.device(ix.device):
+        with _on(ix.device):
             rc = lib.voge_merge_bwd(None, _p(ix), _p(w), _p(vn), _p(pa), npix // max(Wd, 1), Wd, K, C, int(n_vert), _p(out),
                                     None, _stream())
         _lib.check(rc, "voge_merge_bwd")
@@ -555,7 +579,7 @@ class _ScatterAttr(torch.autograd.Function):
         nv = go.shape[0]
         g_pa = torch.empty_like(pa) if ctx.needs_input_grad[0] else None
         g_w = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(ix.device):
+        with _on(ix.device):
             if g_pa is not None:   # g_pix_attr = merge(g_out): sum_k w * g_out[idx_k]
                 rc = lib.voge_merge_fwd(_p(go), _p(ix), _p(w), _p(vn), npix, K, C, nv, 0, _p(g_pa), _stream())
                 _lib.check(rc, "voge_merge_fwd")
@@ -575,7 +599,7 @@ def scatter_max(weight, idx, n_vert):
     w = _dev(weight.detach(), torch.float32, "weight")
     ix = _dev(idx, torch.int32, "vert_index")
     out = torch.empty((int(n_vert),), dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         rc = lib.voge_scatter_max(_p(w), _p(ix), w.numel(), int(n_vert), _p(out), _stream())
     _lib.check(rc, "voge_scatter_max")
     return out
