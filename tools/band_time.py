@@ -1,0 +1,43 @@
+"""Per-rank compute of the pixel-row sharding, measured on ONE GPU: forward+backward of a band of H/n
+rows (HIP graph replay, no collectives) for n = 1, 2, 4, 8 -- the part of strong scaling that does
+not depend on xGMI.  usage: python tools/band_time.py [config]"""
+import sys, time, torch
+sys.path.insert(0, ".")
+from voge_amd import scenes
+from voge_amd.Meshes import GaussianMeshes
+from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
+from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
+from voge_amd.distributed import row_band
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_50k_512"
+dev = torch.device("cuda", 0)
+N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[name]
+verts, sig, cols = scenes.random_gaussians(N, seed=0)
+gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
+colors = torch.from_numpy(cols).to(dev).requires_grad_(True)
+R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
+cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), device=dev)
+renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1, max_point_per_bin=-1)).to(dev)
+params = [gm.verts, gm.sigmas, colors]
+base = None
+for n in (1, 2, 4, 8):
+    worst = 0.0
+    per = []
+    for r in range(n):
+        rows = row_band(H, r, n)
+        def step():
+            for p in params: p.grad = None
+            to_white_background(renderer(gm, R=R, T=T, rows=rows), colors).sum().backward()
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3): step()
+        torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g): step()
+        for _ in range(5): g.replay()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(30): g.replay()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
+        per.append(dt * 1e6)
+    worst = max(per)
+    base = base or worst
+    print(f"n={n}: band us per rank {[round(x) for x in per]}  slowest {worst:.0f} us -> compute-only speedup {base / worst:.2f}x (efficiency {base / worst / n:.2f})")

@@ -1676,9 +1676,14 @@ static int trace_topk_fwd_impl(const int iso_in, const float *mus, const float *
   const int P = B * N;
   TraceWs ws;
   trace_ws_layout(B, N, H, W, workspace, &ws);
-  // The coarse level pays off once the per-super-tile scans of all N dominate (nst * N tests);
-  // tiny problems skip its launch.
-  const bool coarse = (size_t)ws.nstx * ws.nsty * (size_t)N >= ((size_t)1 << 21);
+  // The coarse level pays off once the per-super-tile scans of all N dominate: either many
+  // super-tiles (nst * N tests in total) or simply a long scan per workgroup (a band of a sharded
+  // frame has few super-tiles but every one of them would still walk all N: 44 us at N = 50k).
+#ifndef VOGE_COARSE_MIN_N
+#define VOGE_COARSE_MIN_N 16384
+#endif
+  const bool coarse = ((size_t)ws.nstx * ws.nsty * (size_t)N >= ((size_t)1 << 21)) ||
+                      (N >= VOGE_COARSE_MIN_N && ws.nstx * ws.nsty >= 4);
   {
     const int nst = ws.nstx * ws.nsty;
     const int nprep = (P + kBinThreads - 1) / kBinThreads;
