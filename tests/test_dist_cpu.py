@@ -43,6 +43,13 @@ def _worker(rank, world, port, H, W, out):
     assert img.shape == (1, H, W, 3)
     finish = gather_rows_async(band.detach(), H)          # the overlapped form bench.py uses
     assert torch.equal(finish(), img.detach())
+    # explicit (work-balanced) boundaries: same image from very uneven bands
+    bounds = [0, 3, H] if world == 2 else None
+    if bounds is not None:
+        b0, b1 = bounds[rank], bounds[rank + 1]
+        full = img.detach()
+        assert torch.equal(gather_rows(full[:, b0:b1].contiguous(), H, bounds=bounds), full)
+        assert torch.equal(gather_rows_async(full[:, b0:b1].contiguous(), H, bounds=bounds)(), full)
     img[:, r0:r1].sum().backward()          # each rank owns the loss of its band
     allreduce_grads([colors])
     if rank == 0:
@@ -62,3 +69,23 @@ def test_row_sharded_frame_equals_single_rank(tmp_path):
     assert np.abs(got["img"].numpy() - ref["rgb"]).max() < 1e-12
     g_attr, _ = oracle.merge_bwd(sc["colors"], ref["idx"], ref["weight"], ref["valid_num"], np.ones_like(ref["rgb"]))
     assert np.abs(got["g"].numpy() - g_attr).max() < 1e-10
+
+
+def test_balanced_row_bounds():
+    """Work-balanced contiguous bands: equal weight per band, every band non-empty, deterministic."""
+    from voge_amd.distributed import balanced_row_bounds, projected_row_weight
+    w = torch.zeros(100)
+    w[40:60] = 1.0
+    b = balanced_row_bounds(w, 4, floor=0.0)
+    assert b[0] == 0 and b[-1] == 100 and all(b[i] < b[i + 1] for i in range(4))
+    assert b[1:4] == [45, 50, 55]                       # the mass sits in rows 40..59
+    assert balanced_row_bounds(torch.zeros(5), 5) == [0, 1, 2, 3, 4, 5]
+    assert balanced_row_bounds(torch.tensor([0.0, 0, 0, 100, 0, 0]), 3)[-1] == 6
+    uni = balanced_row_bounds(torch.ones(64), 8)
+    assert uni == list(range(0, 65, 8))
+    # a camera looking down -z at points spread in y: rows of the projected centres
+    verts = torch.tensor([[0.0, 0.5, 0.0], [0.0, -0.5, 0.0], [0.0, 0.0, 0.0]])
+    R, T = torch.eye(3), torch.tensor([0.0, 0.0, 2.0])
+    pw = projected_row_weight(verts, R, T, 20.0, 16.0, 32, smooth=1)
+    assert pw.shape == (32,) and float(pw.sum()) == 3.0
+    assert pw[10] == 1 and pw[15] == 1 and pw[20] == 1     # row = py - fy*Y/Z - 0.5

@@ -1,13 +1,13 @@
 """Per-rank compute of the pixel-row sharding, measured on ONE GPU: forward+backward of a band of H/n
 rows (HIP graph replay, no collectives) for n = 1, 2, 4, 8 -- the part of strong scaling that does
 not depend on xGMI.  usage: python tools/band_time.py [config]"""
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0, ".")
 from voge_amd import scenes
 from voge_amd.Meshes import GaussianMeshes
 from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
 from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
-from voge_amd.distributed import row_band
+from voge_amd.distributed import balanced_row_bounds, projected_row_weight, row_band
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_50k_512"
 dev = torch.device("cuda", 0)
 N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[name]
@@ -19,11 +19,16 @@ cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=
 renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1, max_point_per_bin=-1)).to(dev)
 params = [gm.verts, gm.sigmas, colors]
 base = None
+FLOOR = float(os.environ.get("FLOOR", "-1"))       # >= 0: work-balanced bands (balanced_row_bounds) with this floor
+weight = projected_row_weight(verts, R[0], T[0], focal, pp[1], H)
 for n in (1, 2, 4, 8):
     worst = 0.0
     per = []
     for r in range(n):
         rows = row_band(H, r, n)
+        if FLOOR >= 0:
+            b = balanced_row_bounds(weight, n, floor=FLOOR)
+            rows = (b[r], b[r + 1])
         def step():
             for p in params: p.grad = None
             to_white_background(renderer(gm, R=R, T=T, rows=rows), colors).sum().backward()

@@ -18,38 +18,89 @@ def row_band(H, rank, world):
     return r0, r0 + base + (1 if rank < extra else 0)
 
 
+def balanced_row_bounds(row_weight, world, floor=0.1):
+    """Contiguous bands of (nearly) equal WORK instead of equal height: `row_weight` [H] is any
+    non-negative per-row cost estimate (e.g. `projected_row_weight`); every row also costs `floor` x the
+    mean weight, so empty rows are not free.  Returns the world+1 band boundaries [0, ..., H]; band r is
+    rows [b[r], b[r+1]).  Deterministic in its inputs: every rank computes the same partition from the
+    same (replicated) scene, no exchange needed.  Each band gets at least one row."""
+    w = torch.as_tensor(row_weight, dtype=torch.float64).detach().cpu().reshape(-1)
+    H = int(w.numel())
+    world = int(world)
+    assert H >= world >= 1
+    w = w.clamp_min(0.0)
+    w = w + floor * max(float(w.mean()), 1e-30)
+    c = torch.cumsum(w, 0)
+    total = float(c[-1])
+    bounds = [0]
+    for r in range(1, world):
+        b = int(torch.searchsorted(c, torch.tensor(total * r / world - 1e-9 * total, dtype=torch.float64)).item()) + 1
+        b = max(b, bounds[-1] + 1)            # at least one row for band r-1 ...
+        b = min(b, H - (world - r))           # ... and for every band still to come
+        bounds.append(b)
+    bounds.append(H)
+    return bounds
+
+
+def projected_row_weight(verts, R, T, focal_y, principal_y, H, smooth=33):
+    """Per-row work estimate of a frame: how many Gaussian centres project near each pixel row
+    (row i looks along (py - i - 0.5)/fy, the build's ray convention), box-smoothed
+    over `smooth` rows (a Gaussian covers a few rows around its centre).  verts [N,3], R [3,3], T [3]."""
+    v = torch.as_tensor(verts, dtype=torch.float64).detach().cpu().reshape(-1, 3)
+    Rm = torch.as_tensor(R, dtype=torch.float64).detach().cpu().reshape(3, 3)
+    Tm = torch.as_tensor(T, dtype=torch.float64).detach().cpu().reshape(3)
+    view = v @ Rm + Tm                                          # X_view = X_world R + T
+    z = view[:, 2]
+    front = z > 1e-6
+    row = float(principal_y) - float(focal_y) * view[front, 1] / z[front] - 0.5
+    row = row[(row > -smooth) & (row < H + smooth)].clamp(0, H - 1)
+    hist = torch.histc(row, bins=int(H), min=0.0, max=float(H))
+    k = int(smooth) | 1
+    return torch.nn.functional.avg_pool1d(hist[None, None], k, stride=1, padding=k // 2, count_include_pad=False)[0, 0]
+
+
+def _band_of(H, rank, world, bounds):
+    return row_band(H, rank, world) if bounds is None else (int(bounds[rank]), int(bounds[rank + 1]))
+
+
+def _hmax(H, world, bounds):
+    return -(-H // world) if bounds is None else max(int(bounds[r + 1]) - int(bounds[r]) for r in range(world))
+
+
 class _GatherRows(torch.autograd.Function):
     """all_gather of row bands [B,h_r,W,C] -> [B,H,W,C]; backward hands each rank the slice of the
     upstream gradient that belongs to its own band (every rank holds the same full-image loss)."""
 
     @staticmethod
-    def forward(ctx, band, H, group):
+    def forward(ctx, band, H, group, bounds):
         world = dist.get_world_size(group)
         rank = dist.get_rank(group)
         B, h, W, C = band.shape
-        hmax = -(-H // world)
+        hmax = _hmax(H, world, bounds)
+        assert h == _band_of(H, rank, world, bounds)[1] - _band_of(H, rank, world, bounds)[0]
         pad = band.new_zeros((B, hmax, W, C))
         pad[:, :h] = band
         parts = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(parts, pad.contiguous(), group=group)
-        rows = [parts[r][:, : row_band(H, r, world)[1] - row_band(H, r, world)[0]] for r in range(world)]
-        ctx.band = row_band(H, rank, world)
+        rows = [parts[r][:, : _band_of(H, r, world, bounds)[1] - _band_of(H, r, world, bounds)[0]] for r in range(world)]
+        ctx.band = _band_of(H, rank, world, bounds)
         return torch.cat(rows, dim=1)
 
     @staticmethod
     def backward(ctx, g_full):
         r0, r1 = ctx.band
-        return g_full[:, r0:r1].contiguous(), None, None
+        return g_full[:, r0:r1].contiguous(), None, None, None
 
 
-def gather_rows(band, H, group=None):
-    """Assemble the full image from per-rank row bands (single collective)."""
+def gather_rows(band, H, group=None, bounds=None):
+    """Assemble the full image from per-rank row bands (single collective).  `bounds` (world+1 row
+    boundaries, e.g. from balanced_row_bounds) replaces the equal-height bands of row_band."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return band
-    return _GatherRows.apply(band, H, group)
+    return _GatherRows.apply(band, H, group, bounds)
 
 
-def gather_rows_async(band, H, group=None):
+def gather_rows_async(band, H, group=None, bounds=None):
     """Start the all_gather of the row bands and return `finish() -> [B,H,W,C]`.  No autograd (the
     caller's loss is local to its band); the collective runs on the backend's own stream, so
     whatever is launched before finish() -- the band's backward -- overlaps it."""
@@ -57,7 +108,7 @@ def gather_rows_async(band, H, group=None):
         return lambda: band
     world = dist.get_world_size(group)
     B, h, W, C = band.shape
-    hmax = -(-H // world)
+    hmax = _hmax(H, world, bounds)
     if h == hmax:
         pad = band.contiguous()
     else:
@@ -68,7 +119,8 @@ def gather_rows_async(band, H, group=None):
 
     def finish():
         work.wait()
-        return torch.cat([parts[r][:, : row_band(H, r, world)[1] - row_band(H, r, world)[0]] for r in range(world)], dim=1)
+        return torch.cat([parts[r][:, : _band_of(H, r, world, bounds)[1] - _band_of(H, r, world, bounds)[0]]
+                          for r in range(world)], dim=1)
     return finish
 
 
