@@ -1,7 +1,7 @@
 """Strongly anisotropic Gaussians (random_gaussians(anisotropic=True): needles and pancakes) at the cfg3
 size: the full-frame GPU trace against the CPU oracle on a few pixel crops (the oracle is brute force, so
 it is cropped to stay in seconds).  Exercises the ellipsoid culling and its depth bound.
-usage: python tools/aniso_parity.py [n_crops] [N]"""
+usage: python tests/aniso_parity.py [n_crops] [N]"""
 import sys
 import numpy as np
 import torch

@@ -1,6 +1,6 @@
 """Randomised parity sweep on the GPU (not part of the test suite: minutes, not seconds).
 Random (N, H, W, K, B, isotropy, occupancy) -> trace / composite / shade forward AND backward
-against the fp64 oracle, through the public ops.  usage: python tools/stress_parity.py [n_cases] [seed]"""
+against the fp64 oracle, through the public ops.  usage: python tests/stress_parity.py [n_cases] [seed]"""
 import sys
 import numpy as np
 import torch

@@ -1,5 +1,5 @@
-"""Replay the case tools/stress_parity.py saved on failure (gpurun_out/stress_fail.npz), several times,
-and report per-stage errors against the oracle.  usage: python tools/stress_repro.py [file] [repeats]"""
+"""Replay the case tests/stress_parity.py saved on failure (gpurun_out/stress_fail.npz), several times,
+and report per-stage errors against the oracle.  usage: python tests/stress_repro.py [file] [repeats]"""
 import sys
 import numpy as np
 import torch
