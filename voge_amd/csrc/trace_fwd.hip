@@ -920,21 +920,22 @@ __device__ unsigned long long g_sweep_times[8192 * 8];   // per WG: start, after
 #endif
 constexpr int kTrip = VOGE_TRIP;   // candidates evaluated per trip of the sweep's inner loop
 
-template <int T>
+template <int T, bool ISO>
 struct TraceLds {
-  // layout inside dynamic LDS, after the [K][T+1] key array
+  // layout inside dynamic LDS, after the [K][T+1] key array.  ISO (the scalar-sigma entry point: every
+  // candidate is isotropic) stages no full records; with the K = 40 key array that is 22.9 KB per
+  // single-wave workgroup -- seven of them per CU instead of six.
   float4 cull[T > 64 ? T : 1];   // (mu, reach): the per-wave re-test of multi-wave tiles only
   float4 ms[T];         // (mu, s00 | NaN): all an isotropic evaluation needs
-  float4 ev[T * 3];     // full eval record, staged for anisotropic candidates only
-  int32_t id[T];
+  float4 ev[ISO ? 1 : T * 3];    // full eval record, staged for anisotropic candidates only
+  int32_t id[T];        // candidate ids of the staged chunk; per-ray hit counts during the epilogue
   float lb[T];
-  float red[4 * 8];
+  float red[(T / 64) * 8];
   int wcnt[2][4];
-  int cnt[T];
   int done;
 };
 
-template <int WAVES>
+template <int WAVES, bool ISO>
 __global__ void __launch_bounds__(64 * WAVES)
 trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr,
                  const float4 *__restrict__ ms, const float *__restrict__ rays, const int *__restrict__ bin_count,
@@ -952,7 +953,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   constexpr int kCap = T;     // one chunk of the candidate stream is staged at a time
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t *keys = reinterpret_cast<uint64_t *>(smem_raw);
-  TraceLds<T> &L = *reinterpret_cast<TraceLds<T> *>(smem_raw + ((sizeof(uint64_t) * (size_t)(K + 1) * TP + 15) & ~(size_t)15));
+  TraceLds<T, ISO> &L = *reinterpret_cast<TraceLds<T, ISO> *>(smem_raw + ((sizeof(uint64_t) * (size_t)(K + 1) * TP + 15) & ~(size_t)15));
 
 #ifdef VOGE_SWEEP_TIMES
   const unsigned long long ts0 = wall_clock64();
@@ -1057,7 +1058,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   while (base < src_n) {
     int nbuf = 0;
     bool chunk_iso = true;   // every staged candidate of this buffer is isotropic (wave-uniform)
-    bool chunk_gen = true;   // ... or every one is anisotropic
+    bool chunk_gen = !ISO;   // ... or every one is anisotropic
 #ifdef VOGE_SWEEP_TIMES
     const unsigned long long tsa = wall_clock64();
 #endif
@@ -1073,8 +1074,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       lb1 = load_lb(base + 2 * T + tid);
       const bool keep = prefiltered ? (id >= 0) : cone_keep(c, gcone);
       const unsigned long long m = __ballot(keep);
-      chunk_iso = chunk_iso && __all(!keep || (mrec.w == mrec.w));
-      chunk_gen = chunk_gen && __all(!keep || !(mrec.w == mrec.w));
+      if (!ISO) {
+        chunk_iso = chunk_iso && __all(!keep || (mrec.w == mrec.w));
+        chunk_gen = chunk_gen && __all(!keep || !(mrec.w == mrec.w));
+      }
       if (lane == 0) L.wcnt[par][wave] = __popcll(m);
       __syncthreads();
       int off = nbuf, tot = 0;
@@ -1090,7 +1093,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
         L.ms[slot] = mrec;
         L.id[slot] = id;
         L.lb[slot] = lbv;
-        if (!(mrec.w == mrec.w)) {   // anisotropic: the full record (dependent gather, not prefetched)
+        if (!ISO && !(mrec.w == mrec.w)) {   // anisotropic: the full record (dependent gather, not prefetched)
           L.ev[slot * 3 + 0] = evrb[(size_t)id * 3 + 0];
           L.ev[slot * 3 + 1] = evrb[(size_t)id * 3 + 1];
           L.ev[slot * 3 + 2] = evrb[(size_t)id * 3 + 2];
@@ -1128,8 +1131,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             last_batch = true;
           }
         }
-        auto commit = [&](const PairOut &o, const int s, const bool on) {
-          const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)(L.id[s] + b * N);
+        // (gid = the candidate's global id, read from L.id by the caller: the fast loops fetch the ids of a
+        // trip together with its records, so no LDS latency sits between two commits)
+        auto commit = [&](const PairOut &o, const int gid, const bool on) {
+          const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)gid;
           const bool take = on & valid & (o.act < thr_act) & (o.len < VOGE_SENT_LEN) & (key < worst);
 #ifdef VOGE_SWEEP_STATS
           {
@@ -1158,9 +1163,13 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             ++st_trips;
 #endif
             float4 cc[kTrip];
+            int gid[kTrip];
             PairOut o[kTrip];
 #pragma unroll
-            for (int q = 0; q < kTrip; ++q) cc[q] = L.ms[min(s0 + q, s_end - 1)];
+            for (int q = 0; q < kTrip; ++q) {
+              cc[q] = L.ms[min(s0 + q, s_end - 1)];
+              gid[q] = L.id[min(s0 + q, s_end - 1)] + b * N;
+            }
 #pragma unroll
             for (int q = 0; q < kTrip; ++q)
               o[q] = pair_eval_iso(cc[q].x, cc[q].y, cc[q].z, cc[q].w, dx, dy, dz, qxx, qyy, qzz);
@@ -1170,10 +1179,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 #pragma unroll
             for (int q = 0; q < kTrip; ++q) asm volatile("" : "+v"(o[q].len), "+v"(o[q].act));
 #pragma unroll
-            for (int q = 0; q < kTrip; ++q) commit(o[q], min(s0 + q, s_end - 1), s0 + q < s_end);
+            for (int q = 0; q < kTrip; ++q) commit(o[q], gid[q], s0 + q < s_end);
           }
           m = 0ull;
-        } else if (WAVES == 1 && chunk_gen) {
+        } else if (!ISO && WAVES == 1 && chunk_gen) {
           // the same contiguous-range loop for an all-anisotropic chunk (full records from LDS)
           const int s_end = c0 + __popcll(m);
           for (int s0 = c0; s0 < s_end; s0 += kTrip) {
@@ -1181,17 +1190,19 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             ++st_trips;
 #endif
             PairOut o[kTrip];
+            int gid[kTrip];
 #pragma unroll
             for (int q = 0; q < kTrip; ++q) {
               const int sidx = min(s0 + q, s_end - 1);
               const float4 cc = L.ms[sidx];
+              gid[q] = L.id[sidx] + b * N;
               o[q] = pair_eval_gen(cc.x, cc.y, cc.z, unpack_eval(L.ev[sidx * 3], L.ev[sidx * 3 + 1], L.ev[sidx * 3 + 2]), dx, dy,
                                    dz, qxx, qyy, qzz, qxy, qxz, qyz);
             }
 #pragma unroll
             for (int q = 0; q < kTrip; ++q) asm volatile("" : "+v"(o[q].len), "+v"(o[q].act));
 #pragma unroll
-            for (int q = 0; q < kTrip; ++q) commit(o[q], min(s0 + q, s_end - 1), s0 + q < s_end);
+            for (int q = 0; q < kTrip; ++q) commit(o[q], gid[q], s0 + q < s_end);
           }
           m = 0ull;
         }
@@ -1211,16 +1222,18 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
           // made per batch, on scalar registers), so the scheduler interleaves their chains.
           PairOut o[kTrip];
           float4 cc[kTrip], e0[kTrip];
+          int gid[kTrip];
           bool iso = true, any_iso = false;
           bool fiso[kTrip];
 #pragma unroll
           for (int q = 0; q < kTrip; ++q) {
             cc[q] = L.ms[sq[q]];
+            gid[q] = L.id[sq[q]] + b * N;
             const bool f = fiso[q] = (__builtin_amdgcn_readfirstlane(__float_as_uint(cc[q].w)) & 0x7fffffffu) <= 0x7f800000u;
             iso = iso && f;
             any_iso = any_iso || f;
           }
-          if (iso) {
+          if (ISO || iso) {
 #pragma unroll
             for (int q = 0; q < kTrip; ++q)
               o[q] = pair_eval_iso(cc[q].x, cc[q].y, cc[q].z, cc[q].w, dx, dy, dz, qxx, qyy, qzz);
@@ -1247,7 +1260,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             }
           }
 #pragma unroll
-          for (int q = 0; q < kTrip; ++q) commit(o[q], sq[q], q < nt);
+          for (int q = 0; q < kTrip; ++q) commit(o[q], gid[q], q < nt);
         }
         if (last_batch) wdone = true;
       }
@@ -1281,7 +1294,8 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   }
 #endif
   // ---- epilogue: lanes re-mapped to (pixel, slot); act / dsd recomputed with pair_eval ------
-  L.cnt[tid] = cnt;
+  __syncthreads();            // every wave is done with the staged ids: the array now holds the hit counts
+  L.id[tid] = cnt;
 #ifdef VOGE_SWEEP_TIMES
   const int cnt_dbg = (int)__popcll(__ballot(cnt > 0));   // rays of the tile with at least one hit
 #endif
@@ -1293,7 +1307,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
                         float &od) {
     const int owner = ((x >> 3) + (TW / 8) * (r >> 3)) * 64 + (x & 7) + 8 * (r & 7);
     oi = -1; ol = VOGE_SENT_LEN; oa = VOGE_SENT_ACT; od = 0.0f;
-    if (s < L.cnt[owner]) {
+    if (s < L.id[owner]) {
       const uint64_t key = keys[(size_t)s * TP + owner];
       oi = (int32_t)(uint32_t)key;
       const float *ry = rays + pix * 3;
@@ -1344,7 +1358,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
           const int owner = ((x >> 3) + (TW / 8) * (r >> 3)) * 64 + (x & 7) + 8 * (r & 7);
           const size_t pix = ((size_t)b * H + ty * TH + r) * W + (size_t)tx * TW + x;
           ob[u] = pix * K + sl;
-          nv[u] = max(0, min(4, L.cnt[owner] - sl));
+          nv[u] = max(0, min(4, L.id[owner] - sl));
 #pragma unroll
           for (int q = 0; q < 4; ++q) key[u][q] = (q < nv[u]) ? keys[(size_t)(sl + q) * TP + owner] : 0ull;
           if (nv[u] > 0) { ex[u] = rays[pix * 3]; ey[u] = rays[pix * 3 + 1]; ez[u] = rays[pix * 3 + 2]; }
@@ -1405,7 +1419,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
           const int owner = ((x >> 3) + (TW / 8) * (r >> 3)) * 64 + (x & 7) + 8 * (r & 7);
           const size_t pix = ((size_t)b * H + ty * TH + r) * W + (size_t)tx * TW + x;
           ob[u] = pix * K + sl;
-          nv[u] = max(0, min(4, L.cnt[owner] - sl));
+          nv[u] = max(0, min(4, L.id[owner] - sl));
 #pragma unroll
           for (int q = 0; q < 4; ++q) key[u][q] = (q < nv[u]) ? keys[(size_t)(sl + q) * TP + owner] : 0ull;
           if (nv[u] > 0) { ex[u] = rays[pix * 3]; ey[u] = rays[pix * 3 + 1]; ez[u] = rays[pix * 3 + 2]; }
@@ -1611,15 +1625,15 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
   return off;
 }
 
-template <int WAVES>
+template <int WAVES, bool ISO>
 static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int H, int W, int K,
                         float thr_act, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
                         hipStream_t st) {
   constexpr int T = 64 * WAVES;
   constexpr int TW = (WAVES >= 2) ? 16 : 8;
   constexpr int TH = (WAVES == 4) ? 16 : 8;
-  const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + sizeof(TraceLds<T>);
-  auto kern = trace_fwd_kernel<WAVES>;
+  const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + sizeof(TraceLds<T, ISO>);
+  auto kern = trace_fwd_kernel<WAVES, ISO>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -1709,11 +1723,13 @@ static int trace_topk_fwd_impl(const int iso_in, const float *mus, const float *
   // than 16x8 / 16x16 tiles on all three BASELINE configs (no barriers, finer load balance,
   // tighter per-tile candidate lists).  The multi-wave instantiations remain for experiments.
 #ifdef VOGE_FORCE_WAVES
-  return launch_trace<VOGE_FORCE_WAVES>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
+  return launch_trace<VOGE_FORCE_WAVES, false>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
 #endif
-  if (sizeof(uint64_t) * (size_t)(K + 1) * 65 + 16 + sizeof(TraceLds<64>) <= 160 * 1024)
-    return launch_trace<1>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
-  return VOGE_ERR_K_TOO_LARGE;
+  if (sizeof(uint64_t) * (size_t)(K + 1) * 65 + 16 + sizeof(TraceLds<64, false>) > 160 * 1024) return VOGE_ERR_K_TOO_LARGE;
+#ifndef VOGE_NO_ISO_SWEEP
+  if (iso_in) return launch_trace<1, true>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
+#endif
+  return launch_trace<1, false>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
 }
 
 extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const float *rays,
