@@ -134,6 +134,28 @@ int voge_trace_bwd_iso(const float *mus, const float *a, const float *rays, cons
 size_t voge_trace_bwd_iso_workspace_bytes(int P);
 
 /*
+ * The same two calls with the renderer's elementwise preamble folded in (VoGE/Renderer.py:130-137:
+ * `verts - origin` per view and `2 * sigmas` / `2 / sigmas` (inverse_sigma)): the per-Gaussian pass that
+ * reads the inputs anyway applies them, and the backward's per-Gaussian pass applies their chain rule,
+ * so the caller launches no elementwise kernels around the trace.
+ *   verts   [N,3] (shared != 0: one set seen by all B views) or [B*N,3];  sigmas [N] or [B*N]
+ *   origin  [B,3] camera centres, or NULL (no centring);  sigma_mode 0: a = sigma, 1: a = 2 sigma, 2: a = 2/sigma
+ * Forward outputs as voge_trace_topk_fwd (indices are b*N + n).  Backward: g_verts / g_sigmas have the
+ * shapes of verts / sigmas (summed over the views when shared); no gradient is produced for origin --
+ * a caller that needs it (camera pose optimisation) uses the plain calls.  Workspaces as above with P = B*N.
+ */
+int voge_trace_topk_fwd_iso_view(const float *verts, const float *sigmas, const float *origin, int shared,
+                                 int sigma_mode, const float *rays, const float *cam_fwd, int B, int N, int H,
+                                 int W, int K, float thr_act, void *workspace, size_t workspace_bytes,
+                                 int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
+                                 voge_stream_t stream);
+int voge_trace_bwd_iso_view(const float *verts, const float *sigmas, const float *origin, int shared,
+                            int sigma_mode, const float *rays, const int32_t *idx, const int32_t *cnt,
+                            const float *g_len, const float *g_act, const float *g_dsd, int B, int N, long nrows,
+                            int W, int K, void *workspace, size_t workspace_bytes, float *g_ray,
+                            float *g_verts, float *g_sigmas, voge_stream_t stream);
+
+/*
  * Composite forward.  Replaces: VoGE/Aggregation.py:82-107 `aggregation`
  * (get_cross_activation :30-51 + assign2weight :54-79), without any [npix,K,K] temporary.
  *   w_m = exp(-occ * sum_k exp(-act_k) * (erf((len_m-len_k)*sqrt(dsd_k+1e-10)) + 1)/2)

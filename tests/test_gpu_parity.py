@@ -610,3 +610,47 @@ def test_shape_fitting_loop_converges(hip_lib):
     assert np.isfinite(sil).all() and np.isfinite(rgb).all()
     assert sil[-20:].mean() < 0.35 * sil[:5].mean(), (sil[:5].mean(), sil[-20:].mean())
     assert rgb[-20:].mean() < 0.6 * rgb[40:45].mean(), (rgb[40:45].mean(), rgb[-20:].mean())
+
+
+@pytest.mark.parametrize("inverse_sigma", [False, True])
+def test_fused_preamble_equals_reference_ops(hip_lib, inverse_sigma):
+    """Renderer.py:130-137 (`verts - origin`, `2 * sigmas` or `2 / sigmas`) folded into the trace kernels
+    (voge_trace_topk_fwd_iso_view / voge_trace_bwd_iso_view) against the same renderer running those lines
+    as torch ops: identical fragments, same gradients (two views share one Gaussian set: the backward
+    sums over the batch)."""
+    import voge_amd.Renderer as Rm
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
+    N, H, W, K = 1500, 72, 88, 12
+    verts, sig, cols = random_scene(N, seed=21, lo=0.04, hi=0.12)
+    sig = np.ascontiguousarray(sig[:, 0, 0]) if sig.ndim == 3 else sig
+    if inverse_sigma:
+        sig = (1.0 / sig).astype(np.float32)
+    R, T = look_at_view_transform(dist=[3.0, 3.4], elev=[10.0, -20.0], azim=[30.0, 200.0], device="cuda")
+    cams = PerspectiveCameras(focal_length=90.0, principal_point=((W / 2.0, H / 2.0),), image_size=((H, W),), device="cuda")
+    st = Rm.GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1.2,
+                                   inverse_sigma=inverse_sigma, max_point_per_bin=-1)
+    renderer = Rm.GaussianRenderer(cams, st).to("cuda")
+    g_img = torch.randn(2, H, W, 3, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    out = {}
+    for fused in (True, False):
+        Rm.FUSED_PREAMBLE = fused
+        try:
+            gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to("cuda")
+            colors = t(cols, rg=True)
+            frag = renderer(gm, R=R, T=T)
+            img = Rm.to_white_background(frag, colors)
+            (img * g_img).sum().backward()
+            out[fused] = (n(frag.vert_index), n(frag.vert_weight), n(frag.vert_hit_length), n(img),
+                          n(gm.verts.grad), n(gm.sigmas.grad), n(colors.grad))
+        finally:
+            Rm.FUSED_PREAMBLE = True
+    a, b = out[True], out[False]
+    assert (a[0] == b[0]).all()
+    for x, y in zip(a[1:4], b[1:4]):
+        assert np.array_equal(x, y)                      # same arithmetic: bit-identical forward
+    assert (a[1] > 0).mean() > 0.05
+    for name, x, y in zip(("verts", "sigmas", "colors"), a[4:], b[4:]):
+        scale = max(1.0, float(np.abs(y).max()))
+        assert np.abs(x - y).max() <= 2e-5 * scale, name
+    assert np.abs(b[5]).max() > 0

@@ -18,7 +18,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .ops import _FindNearestK, _RayTraceVoGE, _RayTraceVoGEIso, _RayTraceVoGERay
+from .ops import _FindNearestK, _RayTraceVoGE, _RayTraceVoGEIso, _RayTraceVoGEIsoView, _RayTraceVoGERay
 
 inf = 1e8
 
@@ -55,6 +55,19 @@ def ray_tracing_iso(transforms, points, a, rays, image_size, thr: float, n_assig
     candidates = None if max_points_per_bin == -1 else _view_axis(transforms, points)
     thr_act = -math.log(thr + 1 / inf)
     return _RayTraceVoGEIso.apply(points.reshape(-1, 3), a.reshape(-1), rays, candidates, thr_act, n_assign)
+
+
+def ray_tracing_iso_view(transforms, verts, sigmas, origin, rays, image_size, thr: float, n_assign: int,
+                         max_points_per_bin: Optional[int] = None, inverse_sigma: bool = False, inf=1e10, **kwargs):
+    """ray_tracing_iso with the renderer's preamble folded into the kernels: verts [N,3] and sigmas [N]
+    as the user holds them (shared by all B views), origin [B,3] the camera centres; equivalent to
+    ray_tracing_iso(verts[None] - origin[:, None], 2 * sigmas or 2 / sigmas, ...) (Renderer.py:130-137),
+    bit-identical outputs, without the three elementwise launches and their backward.  origin gets no
+    gradient here."""
+    candidates = None if max_points_per_bin == -1 else _view_axis(transforms, origin[:, None])
+    thr_act = -math.log(thr + 1 / inf)
+    return _RayTraceVoGEIsoView.apply(verts, sigmas, origin, rays, candidates, thr_act, n_assign,
+                                      2 if inverse_sigma else 1)
 
 
 def _view_axis(cameras, points):

@@ -4,6 +4,7 @@ to_colored_background (:162-171), to_white_background (:174-176) -- same names, 
 meaning.  Every stage behind these calls is a HIP kernel (voge_amd.ops); a renderer on CPU
 tensors raises instead of falling back.
 """
+import os
 from typing import Tuple, Union
 
 import torch
@@ -11,8 +12,12 @@ import torch.nn as nn
 
 from . import ops
 from .Aggregation import aggregation, expend_sigma, merge_final
-from .RayTracing import ray_tracing, ray_tracing_iso
+from .RayTracing import ray_tracing_iso_view, ray_tracing, ray_tracing_iso
 from .cameras import pixel_rays
+
+# Fold `verts - origin` and `2 * sigmas` into the trace kernels when the inputs allow it (see forward()).
+# VOGE_FUSED_PREAMBLE=0 (or setting this flag) keeps the reference's elementwise torch ops: same results.
+FUSED_PREAMBLE = os.environ.get("VOGE_FUSED_PREAMBLE", "1") != "0"
 
 
 class Fragments(object):
@@ -106,10 +111,21 @@ class GaussianRenderer(nn.Module):
         image_size = st['image_size']
 
         verts, sigmas, _radians = gmeshes()
-        if verts.dim() == 2:
+        shared_verts = verts.dim() == 2
+        if shared_verts:
             verts = verts[None]
 
         rays, origin = pixel_rays(cams, image_size, rows=kwargs.get('rows'))     # [B,h,W,3], [B,3]
+        if sigmas.dim() == 1 and shared_verts and not origin.requires_grad and FUSED_PREAMBLE:
+            # One (verts [N,3], sigmas [N]) set seen by every view, fixed cameras: the centring of
+            # Renderer.py:130 and the 2*sigma / 2/sigma of :133-137 happen inside the trace's per-Gaussian
+            # pass (and their chain rule inside its backward's) -- same values, no elementwise launches.
+            sel_idx, sel_len, sel_act, sel_dsd = ray_tracing_iso_view(
+                cams, verts[0], sigmas, origin, rays, image_size, thr=st['thr_activation'], n_assign=st['max_assign'],
+                max_points_per_bin=st['max_point_per_bin'], inverse_sigma=st['inverse_sigma'])
+            weight, index, valid_num, hit_len = aggregation(sel_idx=sel_idx, sel_act=sel_act, sel_len=sel_len,
+                                                            sel_dsd=sel_dsd, occupation_weight=st['absorptivity'])
+            return Fragments(vert_weight=weight, vert_index=index, valid_num=valid_num, vert_hit_length=hit_len)
         centred = verts - origin[:, None]                                         # Renderer.py:130
         if sigmas.dim() == 1:
             # (N,) sigmas are isotropic: expend_sigma would give sigma * I (Aggregation.py:155-157) and

@@ -415,21 +415,40 @@ trace_bwd_iso_kernel(const float4 *__restrict__ rec /* (mu, a) */, const float *
 }
 
 __global__ void __launch_bounds__(256)
-bwd_pack_iso_kernel(const float *__restrict__ mus, const float *__restrict__ a, const int P,
-                    float4 *__restrict__ rec, float4 *__restrict__ acc) {
+bwd_pack_iso_kernel(const float *__restrict__ mus, const float *__restrict__ a, const int P, const int N,
+                    const IsoView view, float4 *__restrict__ rec, float4 *__restrict__ acc) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= P) return;
-  rec[g] = make_float4(mus[3 * (size_t)g], mus[3 * (size_t)g + 1], mus[3 * (size_t)g + 2], a[g]);
+  const int src = view.shared ? g % N : g;
+  float mx = mus[3 * (size_t)src], my = mus[3 * (size_t)src + 1], mz = mus[3 * (size_t)src + 2];
+  if (view.origin != nullptr) {
+    const float *o = view.origin + 3 * (g / N);
+    mx -= o[0]; my -= o[1]; mz -= o[2];
+  }
+  rec[g] = make_float4(mx, my, mz, iso_view_a(a[src], view.mode));
   acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// acc [P] = (g_mu, g_a) per (batch element, Gaussian)  ->  gradients of what the caller passed in:
+// plain arrays: g_mus [P,3], g_a [P]; view: the chain rule through a = 2 sigma / 2 / sigma, and the sum
+// over the batch when one (verts, sigmas) set is shared by all views.
 __global__ void __launch_bounds__(256)
-bwd_unpack_iso_kernel(const float4 *__restrict__ acc, const int P, float *__restrict__ g_mus, float *__restrict__ g_a) {
+bwd_unpack_iso_kernel(const float4 *__restrict__ acc, const float *__restrict__ a_in, const int P, const int N,
+                      const int B, const IsoView view, float *__restrict__ g_mus, float *__restrict__ g_a) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P) return;
-  const float4 v = acc[g];
+  const int n_out = view.shared ? N : P;
+  if (g >= n_out) return;
+  float4 v = acc[g];
+  if (view.shared)
+    for (int b = 1; b < B; ++b) {
+      const float4 w = acc[(size_t)b * N + g];
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
   g_mus[3 * (size_t)g] = v.x; g_mus[3 * (size_t)g + 1] = v.y; g_mus[3 * (size_t)g + 2] = v.z;
-  g_a[g] = v.w;
+  float ga = v.w;
+  if (view.mode == 1) ga = 2.0f * ga;
+  else if (view.mode == 2) { const float s = a_in[g]; ga = -2.0f * ga / (s * s); }
+  g_a[g] = ga;
 }
 
 }  // namespace voge
@@ -471,10 +490,11 @@ extern "C" int voge_trace_bwd(const float *mus, const float *isigmas, const floa
 
 extern "C" size_t voge_trace_bwd_iso_workspace_bytes(int P) { return P <= 0 ? 0 : (size_t)P * 32; }
 
-extern "C" int voge_trace_bwd_iso(const float *mus, const float *a, const float *rays, const int32_t *idx,
-                                  const int32_t *cnt, const float *g_len, const float *g_act, const float *g_dsd,
-                                  int P, long nrows, int W, int K, void *workspace, size_t workspace_bytes,
-                                  float *g_ray, float *g_mus, float *g_a, voge_stream_t stream) {
+static int trace_bwd_iso_impl(const IsoView view, const float *mus, const float *a, const float *rays, const int32_t *idx,
+                              const int32_t *cnt, const float *g_len, const float *g_act, const float *g_dsd,
+                              int B, int N, long nrows, int W, int K, void *workspace, size_t workspace_bytes,
+                              float *g_ray, float *g_mus, float *g_a, voge_stream_t stream) {
+  const int P = B * N;
   if (P < 0 || nrows < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (P == 0) {
@@ -486,13 +506,32 @@ extern "C" int voge_trace_bwd_iso(const float *mus, const float *a, const float 
   if (nrows * W > 0 && (!rays || !idx || !g_len || !g_act || !g_dsd)) return VOGE_ERR_BAD_ARG;
   float4 *acc = reinterpret_cast<float4 *>(workspace);
   float4 *rec = acc + P;
-  hipLaunchKernelGGL(bwd_pack_iso_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, a, P, rec, acc);
+  hipLaunchKernelGGL(bwd_pack_iso_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, a, P, N, view, rec, acc);
   if (nrows * W > 0) {
     const long tiles = (long)((W + 7) / 8) * ((nrows + kBwdTH - 1) / kBwdTH);
     hipLaunchKernelGGL(trace_bwd_iso_kernel, dim3((unsigned)((tiles + kBwdIWaves - 1) / kBwdIWaves)),
                        dim3(64 * kBwdIWaves), 0, st, rec, rays, idx, cnt, g_len, g_act, g_dsd, P, nrows, W, K, g_ray,
                        reinterpret_cast<float *>(acc));
   }
-  hipLaunchKernelGGL(bwd_unpack_iso_kernel, dim3((P + 255) / 256), dim3(256), 0, st, acc, P, g_mus, g_a);
+  const int n_out = view.shared ? N : P;
+  hipLaunchKernelGGL(bwd_unpack_iso_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, acc, a, P, N, B, view, g_mus, g_a);
   return launch_status();
+}
+
+extern "C" int voge_trace_bwd_iso(const float *mus, const float *a, const float *rays, const int32_t *idx,
+                                  const int32_t *cnt, const float *g_len, const float *g_act, const float *g_dsd,
+                                  int P, long nrows, int W, int K, void *workspace, size_t workspace_bytes,
+                                  float *g_ray, float *g_mus, float *g_a, voge_stream_t stream) {
+  return trace_bwd_iso_impl(IsoView{nullptr, 0, 0}, mus, a, rays, idx, cnt, g_len, g_act, g_dsd, 1, P, nrows, W, K, workspace,
+                            workspace_bytes, g_ray, g_mus, g_a, stream);
+}
+
+extern "C" int voge_trace_bwd_iso_view(const float *verts, const float *sigmas, const float *origin, int shared,
+                                       int sigma_mode, const float *rays, const int32_t *idx, const int32_t *cnt,
+                                       const float *g_len, const float *g_act, const float *g_dsd, int B, int N, long nrows,
+                                       int W, int K, void *workspace, size_t workspace_bytes, float *g_ray,
+                                       float *g_verts, float *g_sigmas, voge_stream_t stream) {
+  if (sigma_mode < 0 || sigma_mode > 2 || B < 0 || N < 0) return VOGE_ERR_BAD_ARG;
+  return trace_bwd_iso_impl(IsoView{origin, shared ? 1 : 0, sigma_mode}, verts, sigmas, rays, idx, cnt, g_len, g_act, g_dsd, B, N,
+                            nrows, W, K, workspace, workspace_bytes, g_ray, g_verts, g_sigmas, stream);
 }

@@ -33,11 +33,18 @@ __device__ inline double lambda_min_sym3(double a00, double a11, double a22, dou
 __device__ __forceinline__ void prep_one(const int g, const float *__restrict__ mus, const float *__restrict__ isg,
                                          const float *__restrict__ cam_fwd, const int N, const float thr_act,
                                          const int iso_in, float4 *__restrict__ cull, float4 *__restrict__ evr,
-                                         float4 *__restrict__ ms, float4 *__restrict__ ell) {
-  const float mx = mus[3 * g + 0], my = mus[3 * g + 1], mz = mus[3 * g + 2];
+                                         float4 *__restrict__ ms, float4 *__restrict__ ell, const IsoView view) {
+  float mx, my, mz;
+  const int src = view.shared ? g % N : g;
+  if (view.origin != nullptr) {   // centring of Renderer.py:130 done here: the same single fp32 subtraction
+    const float *o = view.origin + 3 * (g / N);
+    mx = mus[3 * (size_t)src + 0] - o[0]; my = mus[3 * (size_t)src + 1] - o[1]; mz = mus[3 * (size_t)src + 2] - o[2];
+  } else {
+    mx = mus[3 * (size_t)src + 0]; my = mus[3 * (size_t)src + 1]; mz = mus[3 * (size_t)src + 2];
+  }
   float A[9];
   if (iso_in) {   // isg holds one scalar per Gaussian: A = a I
-    const float a = isg[g];
+    const float a = iso_view_a(isg[src], view.mode);
 #pragma unroll
     for (int i = 0; i < 9; ++i) A[i] = (i % 4 == 0) ? a : 0.0f;
   } else {
@@ -285,13 +292,13 @@ prep_cone_kernel(const float *__restrict__ rays, const int H, const int W, const
                  ConeRec *__restrict__ cones /* [B][nst] */, int *__restrict__ c_count, const int n_count,
                  const float *__restrict__ mus, const float *__restrict__ isg, const float *__restrict__ cam_fwd,
                  const int N, const int P, const float thr_act, const int iso_in, float4 *__restrict__ cull,
-                 float4 *__restrict__ evr, float4 *__restrict__ ms, float4 *__restrict__ ell) {
+                 float4 *__restrict__ evr, float4 *__restrict__ ms, float4 *__restrict__ ell, const IsoView view) {
   __shared__ float red[16 * 4];
   const int tid = threadIdx.x;
   const int nprep = (P + kBinThreads - 1) / kBinThreads;
   if ((int)blockIdx.x < nprep) {     // record blocks first: they are the longer ones (fp64 eigenvalue)
     const int g = (int)blockIdx.x * kBinThreads + tid;
-    if (g < P) prep_one(g, mus, isg, cam_fwd, N, thr_act, iso_in, cull, evr, ms, ell);
+    if (g < P) prep_one(g, mus, isg, cam_fwd, N, thr_act, iso_in, cull, evr, ms, ell, view);
     return;
   }
   const int cb = (int)blockIdx.x - nprep;
@@ -1675,7 +1682,7 @@ extern "C" size_t voge_trace_workspace_bytes(int B, int N, int H, int W) {
   return trace_ws_layout(B, N, H, W, nullptr, nullptr);
 }
 
-static int trace_topk_fwd_impl(const int iso_in, const float *mus, const float *isigmas, const float *rays,
+static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float *mus, const float *isigmas, const float *rays,
                                const float *cam_fwd, int B, int N, int H, int W, int K,
                                float thr_act, void *workspace, size_t workspace_bytes,
                                int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
@@ -1703,7 +1710,7 @@ static int trace_topk_fwd_impl(const int iso_in, const float *mus, const float *
     const int nprep = (P + kBinThreads - 1) / kBinThreads;
     hipLaunchKernelGGL(prep_cone_kernel, dim3(nst * B + nprep), dim3(kBinThreads), 0, st, rays, H, W, ws.nstx, nst, B,
                        ws.cones, ws.c_count, B * ws.nst0x * ws.nst0y, mus, isigmas, cam_fwd, N, P, thr_act, iso_in, ws.cull,
-                       ws.evr, ws.ms, ws.ell);
+                       ws.evr, ws.ms, ws.ell, view);
     int rc = launch_status();
     if (rc) return rc;
   }
@@ -1737,7 +1744,7 @@ extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const
                                    float thr_act, void *workspace, size_t workspace_bytes,
                                    int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
                                    voge_stream_t stream) {
-  return trace_topk_fwd_impl(0, mus, isigmas, rays, cam_fwd, B, N, H, W, K, thr_act, workspace, workspace_bytes, idx, len,
+  return trace_topk_fwd_impl(0, IsoView{nullptr, 0, 0}, mus, isigmas, rays, cam_fwd, B, N, H, W, K, thr_act, workspace, workspace_bytes, idx, len,
                              act, dsd, cnt, stream);
 }
 
@@ -1746,7 +1753,7 @@ extern "C" int voge_trace_topk_fwd_iso(const float *mus, const float *a, const f
                                        float thr_act, void *workspace, size_t workspace_bytes,
                                        int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
                                        voge_stream_t stream) {
-  return trace_topk_fwd_impl(1, mus, a, rays, cam_fwd, B, N, H, W, K, thr_act, workspace, workspace_bytes, idx, len, act,
+  return trace_topk_fwd_impl(1, IsoView{nullptr, 0, 0}, mus, a, rays, cam_fwd, B, N, H, W, K, thr_act, workspace, workspace_bytes, idx, len, act,
                              dsd, cnt, stream);
 }
 
@@ -1769,4 +1776,14 @@ extern "C" int voge_trace_topk_list_fwd(const float *mus, const float *isigmas, 
   hipLaunchKernelGGL(trace_list_fwd_kernel, grid, dim3(64), lds, (hipStream_t)stream, mus, isigmas, rays,
                      bin_points, P, H, W, K, BH, BW, M, bin_size, thr_act, idx, len, act, dsd);
   return launch_status();
+}
+
+extern "C" int voge_trace_topk_fwd_iso_view(const float *verts, const float *sigmas, const float *origin, int shared,
+                                            int sigma_mode, const float *rays, const float *cam_fwd, int B, int N, int H,
+                                            int W, int K, float thr_act, void *workspace, size_t workspace_bytes,
+                                            int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
+                                            voge_stream_t stream) {
+  if (sigma_mode < 0 || sigma_mode > 2) return VOGE_ERR_BAD_ARG;
+  return trace_topk_fwd_impl(1, IsoView{origin, shared ? 1 : 0, sigma_mode}, verts, sigmas, rays, cam_fwd, B, N, H, W, K,
+                             thr_act, workspace, workspace_bytes, idx, len, act, dsd, cnt, stream);
 }

@@ -39,6 +39,16 @@ __device__ __forceinline__ float fast_div(const float a, const float b) { return
 // s01 of an isotropic record carries this NaN bit pattern (never produced by arithmetic)
 constexpr uint32_t kIsoFlag = 0x7fc0a150u;
 
+// How the isotropic "view" entry points read their Gaussians: centre = verts[shared ? n : b*N+n] - origin[b],
+// a = sigma (mode 0), 2 sigma (mode 1) or 2 / sigma (mode 2).  origin == nullptr: plain (mus, a) arrays.
+struct IsoView {
+  const float *origin;
+  int shared, mode;
+};
+__device__ __forceinline__ float iso_view_a(const float s, const int mode) {
+  return mode == 1 ? 2.0f * s : (mode == 2 ? 2.0f / s : s);
+}
+
 struct PairOut {
   float len, act, dsd;
 };

@@ -219,6 +219,79 @@ class _RayTraceVoGEIso(torch.autograd.Function):
         return g_mus, g_a, g_ray, None, None, None
 
 
+class _RayTraceVoGEIsoView(torch.autograd.Function):
+    """_RayTraceVoGEIso with the renderer's elementwise preamble folded into the kernels
+    (Renderer.py:130-137): forward(verts [N,3] | [B,N,3], sigmas [N] | [B,N], origin [B,3], rays [B,H,W,3],
+    cam_fwd | None, thr_act, n_assign, sigma_mode) where the Gaussian seen by view b is
+    (verts - origin[b], a = 2 sigma (mode 1) | 2 / sigma (mode 2) | sigma (mode 0)).  No gradient for
+    origin: callers that optimise the camera use the unfused form."""
+
+    @staticmethod
+    def forward(ctx, verts, sigmas, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode):
+        lib = _lib.load()
+        v_c = _dev(verts, torch.float32, "verts")
+        s_c = _dev(sigmas, torch.float32, "sigmas")
+        o_c = _dev(origin, torch.float32, "origin")
+        rays_c = _dev(rays, torch.float32, "rays")
+        assert rays_c.dim() == 4 and rays_c.shape[3] == 3
+        B, H, W, _ = rays_c.shape
+        shared = v_c.dim() == 2
+        assert v_c.shape[-1] == 3 and (shared or v_c.shape[0] == B) and s_c.shape == v_c.shape[:-1]
+        assert o_c.shape == (B, 3)
+        N, K, dev = v_c.shape[-2], int(n_assign), rays_c.device
+        sel_idx = torch.empty((B, H, W, K), dtype=torch.int32, device=dev)
+        sel_len = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
+        sel_act = torch.empty_like(sel_len)
+        sel_dsd = torch.empty_like(sel_len)
+        cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+        fwd = None if cam_fwd is None else _dev(cam_fwd, torch.float32, "cam_fwd")
+        with _on(dev):
+            nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
+            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+            rc = lib.voge_trace_topk_fwd_iso_view(
+                _p(v_c), _p(s_c), _p(o_c), int(shared), int(sigma_mode), _p(rays_c), _p(fwd), B, N, H, W, K,
+                float(thr_act), _p(ws), nbytes, _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _p(cnt), _stream())
+        _lib.check(rc, "voge_trace_topk_fwd_iso_view")
+        ctx.save_for_backward(v_c, s_c, o_c, rays_c)
+        ctx.sel_idx, ctx.cnt, ctx.mode, ctx.shared = sel_idx, cnt, int(sigma_mode), shared
+        sel_idx.voge_hit_count = cnt
+        ctx.mark_non_differentiable(sel_idx)
+        ctx.set_materialize_grads(False)
+        return sel_idx, sel_len, sel_act, sel_dsd
+
+    @staticmethod
+    def backward(ctx, grad_sel_idx, grad_sel_len, grad_sel_act, grad_sel_dsd):
+        lib = _lib.load()
+        verts, sigmas, origin, rays = ctx.saved_tensors
+        if ctx.needs_input_grad[2]:
+            raise _lib.VogeHipError("the fused view form has no gradient for the camera centre; "
+                                    "use ray_tracing_iso on centred vertices")
+        sel_idx = ctx.sel_idx
+        B, H, W, K = sel_idx.shape
+        N = verts.shape[-2]
+        zeros = None
+
+        def g(t):
+            nonlocal zeros
+            if t is None:
+                if zeros is None:
+                    zeros = torch.zeros(sel_idx.shape, dtype=torch.float32, device=sel_idx.device)
+                return zeros
+            return _dev(t, torch.float32, "grad")
+        gl, ga, gd = g(grad_sel_len), g(grad_sel_act), g(grad_sel_dsd)
+        g_ray = torch.empty_like(rays) if ctx.needs_input_grad[3] else None
+        g_verts = torch.empty_like(verts)
+        g_sig = torch.empty_like(sigmas)
+        with _on(rays.device):
+            nbytes = lib.voge_trace_bwd_iso_workspace_bytes(B * N)
+            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=rays.device)
+            rc = lib.voge_trace_bwd_iso_view(_p(verts), _p(sigmas), _p(origin), int(ctx.shared), ctx.mode, _p(rays),
+                                             _p(sel_idx), _p(ctx.cnt), _p(gl), _p(ga), _p(gd), B, N, B * H, W, K,
+                                             _p(ws), nbytes, _p(g_ray), _p(g_verts), _p(g_sig), _stream())
+        _lib.check(rc, "voge_trace_bwd_iso_view")
+        return g_verts, g_sig, None, g_ray, None, None, None, None
+
+
 class _Composite(torch.autograd.Function):
     """Fused replacement of get_cross_activation + assign2weight (VoGE/Aggregation.py:30-79)
     and of their autograd backward.  (sel_idx, sel_act, sel_len, sel_dsd, occ) -> weight, valid_num."""
