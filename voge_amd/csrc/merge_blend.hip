@@ -178,8 +178,14 @@ shade_fwd4_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx, con
       for (int s = 0; s < 4; ++s) {
         pp[u][s] = raw[s] + (raw[s] < 0);
         take[u][s] = ok[u] && (4 * q + s < vn[u]) && (pp[u][s] >= 0) && (pp[u][s] < Nattr) && (wv[s] != 0.0f);
+        if (C == 3) {   // RGB: the three channels of a Gaussian as ONE 12-byte gather
+          float3 v = make_float3(0.f, 0.f, 0.f);
+          if (take[u][s]) v = *reinterpret_cast<const float3 *>(attr + (size_t)pp[u][s] * 3);
+          a[u][s][0] = v.x; a[u][s][1] = v.y; a[u][s][2] = v.z; a[u][s][3] = 0.0f;
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a[u][s][c] = (take[u][s] && c < nc) ? attr[(size_t)pp[u][s] * C + c0 + c] : 0.0f;
+          for (int c = 0; c < 4; ++c) a[u][s][c] = (take[u][s] && c < nc) ? attr[(size_t)pp[u][s] * C + c0 + c] : 0.0f;
+        }
       }
       if (fix_idx && c0 == 0 && ok[u] && (raw[0] < 0 || raw[1] < 0 || raw[2] < 0 || raw[3] < 0))   // Aggregation.py:131
         *reinterpret_cast<int4 *>(idx + (pixbase + u * 4 + row) * K + 4 * q) =
@@ -341,10 +347,19 @@ shade_bwd_tile_kernel(const float *__restrict__ attr, const int32_t *__restrict_
       }
     }
     float a[kShadeBU][4];
+    if (C == 3 && attr != nullptr) {   // RGB: one 12-byte gather per slot instead of three 4-byte ones
 #pragma unroll
-    for (int u = 0; u < kShadeBU; ++u)
+      for (int u = 0; u < kShadeBU; ++u) {
+        float3 v = make_float3(0.f, 0.f, 0.f);
+        if (p[u] >= 0) v = *reinterpret_cast<const float3 *>(attr + (size_t)p[u] * 3);
+        a[u][0] = v.x; a[u][1] = v.y; a[u][2] = v.z; a[u][3] = 0.0f;
+      }
+    } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) a[u][c] = (attr != nullptr && p[u] >= 0 && c < C) ? attr[(size_t)p[u] * C + c] : 0.0f;
+      for (int u = 0; u < kShadeBU; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[u][c] = (attr != nullptr && p[u] >= 0 && c < C) ? attr[(size_t)p[u] * C + c] : 0.0f;
+    }
 #pragma unroll
     for (int u = 0; u < kShadeBU; ++u) {
       if (g0 + u >= nb) break;  // uniform
