@@ -416,7 +416,10 @@ __host__ __device__ inline size_t compn_lds_bytes(const int K, const int NS, con
 #ifndef VOGE_COMP_WPE
 #define VOGE_COMP_WPE 1
 #endif
-template <int MODE, int NS>   // MODE 0: forward, 2: backward with weights
+// WAVE: every pixel's lanes sit inside ONE wave (64 / LP pixels per wave, the remaining lanes idle), so the
+// per-pixel scans, flags and reductions are wave shuffles / ballots and the kernel has no workgroup barrier at
+// all: each wave runs from its loads to its stores on its own.  (Needs LP <= 64.)
+template <int MODE, int NS, bool WAVE>   // MODE 0: forward, 2: backward with weights
 __global__ void __launch_bounds__(kCompThreads) __attribute__((amdgpu_waves_per_eu(VOGE_COMP_WPE)))
 compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
                   const float *__restrict__ len, const float *__restrict__ dsd,
@@ -435,9 +438,23 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   float *const Lu = LE + rows;      // backward only
   const int tid = threadIdx.x, lane = tid & 63;
   const int LP = compn_lanes(K, NS);
-  const int p = __float2int_rz(((float)tid + 0.5f) * __builtin_amdgcn_rcpf((float)LP)), q = tid - p * LP;
+  int p, q;
+  bool in_wg;
+  if (WAVE) {
+    const int pw = 64 / LP;                       // pixels per wave
+    const int pl = __float2int_rz(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)LP));
+    q = lane - pl * LP;
+    in_wg = pl < pw;
+    p = (tid >> 6) * pw + (in_wg ? pl : 0);
+  } else {
+    p = __float2int_rz(((float)tid + 0.5f) * __builtin_amdgcn_rcpf((float)LP));
+    q = tid - p * LP;
+    in_wg = p < ppw;
+  }
   const long pix = (long)blockIdx.x * ppw + p;
-  const bool in_wg = p < ppw;
+  // lanes of this lane's pixel inside the wave (WAVE: the whole pixel)
+  const int seg_lo = max(0, lane - q), seg_hi = min(63, lane + (LP - 1 - q));
+  const unsigned long long seg = ((seg_hi - seg_lo == 63) ? ~0ull : ((1ull << (seg_hi - seg_lo + 1)) - 1ull) << seg_lo);
   const bool active = in_wg && (pix < npix);
   const int k0 = NS * q;
   const long f = pix * K + k0;
@@ -451,7 +468,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   int lead = K;
   if (cnt_in != nullptr) {
     lead = active ? min(K, max(0, cnt_in[pix])) : 0;
-    if (!__syncthreads_or(lead > 0)) {      // every pixel of the workgroup is empty
+    if (WAVE ? !__any(lead > 0) : !__syncthreads_or(lead > 0)) {      // every pixel of the workgroup (wave) is empty
       if (active) {
 #pragma unroll
         for (int a = 0; a < NS; ++a)
@@ -461,7 +478,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
       return;
     }
   }
-  if (tid < ppw) { L.unsorted[tid] = 0; L.rmaxi[tid] = 0; L.cnt[tid] = 0; }
+  if (!WAVE && tid < ppw) { L.unsorted[tid] = 0; L.rmaxi[tid] = 0; L.cnt[tid] = 0; }
   // what a sentinel slot evaluates to: E = 0, len = 1e10, s = 1e-5
   float lm[NS], sm[NS], em[NS], gw[NS], wg[NS];
   int id[NS];
@@ -527,22 +544,24 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
       }
     }
   }
-  __syncthreads();
+  if (WAVE) __builtin_amdgcn_wave_barrier(); else __syncthreads();
   // sortedness: inside the own group, and the seam to the previous group
+  bool uns = false;
   if (active) {
-    bool uns = (q > 0) && !(Llen[d0 - 1] <= lm[0]);
+    uns = (q > 0) && !(Llen[d0 - 1] <= lm[0]);
 #pragma unroll
     for (int a = 1; a < NS; ++a) uns = uns || (has[a] && !(lm[a - 1] <= lm[a]));
-    if (uns) L.unsorted[p] = 1;
+    if (!WAVE && uns) L.unsorted[p] = 1;
   }
+  const bool wave_unsorted = WAVE && ((__ballot(uns) & seg) != 0ull);
   const bool head = in_wg && (lane == 0 || q == 0);
+  int wave_cnt = 0;
   if (!BWD && cnt_in == nullptr) {   // assigned-slot count: NS ballots, one LDS atomic per (wave, pixel) run
-    const int lo = max(0, lane - q), hi = min(63, lane + (LP - 1 - q));
-    const unsigned long long seg = ((hi - lo == 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull) << lo);
     int c = 0;
 #pragma unroll
     for (int a = 0; a < NS; ++a) c += __popcll(__ballot(id[a] >= 0) & seg);
-    if (head) atomicAdd(&L.cnt[p], c);
+    wave_cnt = c;
+    if (!WAVE && head) atomicAdd(&L.cnt[p], c);
   }
   float mx = 0.0f, esum = 0.0f;
 #pragma unroll
@@ -553,7 +572,21 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   // Exclusive prefix (over the lanes of the pixel) of the per-lane sums of E, Hillis-Steele with the
   // window radius riding along; the association is a function of the lane's index in the pixel only.
   float ex = 0.0f;   // sum of E over the slots in front of this lane's group
-  if (!BWD) {
+  float wave_rmax = 0.0f;
+  if (!BWD && WAVE) {            // the same Hillis-Steele steps on wave shuffles (same association)
+    v2f x = {esum, mx};
+    const v2f y = (v2f){__shfl_up(x.x, 1, 64), __shfl_up(x.y, 1, 64)};
+    x = (q > 0 && in_wg) ? (v2f){y.x, fmaxf(mx, y.y)} : (v2f){0.0f, mx};
+    for (int o = 1; o < LP; o <<= 1) {
+      const v2f z = (v2f){__shfl_up(x.x, o, 64), __shfl_up(x.y, o, 64)};
+      if (q >= o && in_wg) {
+        x.x += z.x;
+        x.y = fmaxf(x.y, z.y);
+      }
+    }
+    ex = x.x;
+    wave_rmax = __shfl(x.y, min(63, seg_lo + LP - 1), 64);      // the pixel's last lane holds the maximum
+  } else if (!BWD) {
     v2f x = {esum, mx};
     L.scan[0][tid] = x;
     __syncthreads();
@@ -578,11 +611,12 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
       const float y = __shfl_down(mx, o, 64);
       if (lane + o < 64 && q + o < LP) mx = fmaxf(mx, y);
     }
-    if (head) atomicMax(&L.rmaxi[p], __float_as_int(mx));
+    if (WAVE) wave_rmax = __shfl(mx, seg_lo, 64);                // the pixel's first lane holds the maximum
+    else if (head) atomicMax(&L.rmaxi[p], __float_as_int(mx));
   }
-  __syncthreads();
-  const float rwin_all = in_wg ? __int_as_float(L.rmaxi[p]) : 0.0f;
-  const bool sorted = active && (L.unsorted[in_wg ? p : 0] == 0);
+  if (!WAVE) __syncthreads();
+  const float rwin_all = WAVE ? (in_wg ? wave_rmax : 0.0f) : (in_wg ? __int_as_float(L.rmaxi[p]) : 0.0f);
+  const bool sorted = active && (WAVE ? !wave_unsorted : (L.unsorted[in_wg ? p : 0] == 0));
   const float rwin = sorted ? rwin_all : 0.0f;
   bool any_e = false;
 #pragma unroll
@@ -674,7 +708,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
 #pragma unroll
         for (int a = 0; a < NS; ++a) if (has[a]) out0[f + a] = w[a];
       }
-      if (q == 0) valid_num[pix] = (cnt_in != nullptr) ? (int64_t)cnt_in[pix] : (int64_t)L.cnt[p];
+      if (q == 0) valid_num[pix] = (cnt_in != nullptr) ? (int64_t)cnt_in[pix] : (int64_t)(WAVE ? wave_cnt : L.cnt[p]);
     }
     return;
   }
@@ -687,7 +721,16 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
     for (int h2 = 0; h2 < NP; ++h2) *reinterpret_cast<v2f *>(Lu + d0 + 2 * h2) = (v2f){um[2 * h2], um[2 * h2 + 1]};
   }
   float sx = 0.0f;   // sum of u over the slots behind this lane's group
-  {
+  if (WAVE) {
+    const float y = __shfl_down(usum, 1, 64);
+    float x = (q + 1 < LP && in_wg) ? y : 0.0f;
+    for (int o = 1; o < LP; o <<= 1) {
+      const float z = __shfl_down(x, o, 64);
+      if (q + o < LP && in_wg) x += z;
+    }
+    sx = x;
+    __builtin_amdgcn_wave_barrier();
+  } else {
     float(*sf)[kCompThreads] = reinterpret_cast<float(*)[kCompThreads]>(L.scan);
     sf[0][tid] = usum;
     __syncthreads();
@@ -701,7 +744,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
     }
     sx = x;
   }
-  __syncthreads();
+  if (!WAVE) __syncthreads();
   float ga[NS], gl[NS], gd[NS];
 #pragma unroll
   for (int a = 0; a < NS; ++a) { ga[a] = 0.0f; gl[a] = 0.0f; gd[a] = 0.0f; }
@@ -832,14 +875,24 @@ static int launch_composite(int mode, const int32_t *idx, const float *act, cons
 #define VOGE_COMP_NS_BWD 2     // the backward is evaluation-bound, not LDS-bound: 4 slots only cost registers
 #endif
     const int NS = ((mode == 0 ? VOGE_COMP_NS : VOGE_COMP_NS_BWD) == 4 && (K & 3) == 0) ? 4 : 2;
-    const int ppwn = kCompThreads / compn_lanes(K, NS);
+    const int LPn = compn_lanes(K, NS);
+#ifndef VOGE_COMP_WAVE          // bit 0: forward, bit 1: backward take the barrier-free one-wave-per-pixel form
+#define VOGE_COMP_WAVE 2        // measured (cfg3): backward 101 -> 95 us; forward 52 -> 59 us (its two-float scan
+#endif                          // costs more as shuffles than as LDS round trips with barriers)
+    const bool wavem = ((VOGE_COMP_WAVE >> (mode == 0 ? 0 : 1)) & 1) && LPn <= 64;   // needs a pixel's lanes inside one wave
+    const int ppwn = wavem ? (kCompThreads / 64) * (64 / LPn) : kCompThreads / LPn;
     const dim3 gridn((unsigned)((npix + ppwn - 1) / ppwn)), blockn(kCompThreads);
     const size_t ldsn = compn_lds_bytes(K, NS, mode != 0);
-#define VOGE_LAUNCH_COMPN(M, N)                                                                                         \
-    hipLaunchKernelGGL((compositen_kernel<M, N>), gridn, blockn, ldsn, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, \
+#define VOGE_LAUNCH_COMPN(M, N, WV)                                                                                     \
+    hipLaunchKernelGGL((compositen_kernel<M, N, WV>), gridn, blockn, ldsn, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, \
                        npix, K, ppwn, o0, o1, o2, valid_num)
-    if (mode == 2) { if (NS == 4) VOGE_LAUNCH_COMPN(2, 4); else VOGE_LAUNCH_COMPN(2, 2); }
-    else { if (NS == 4) VOGE_LAUNCH_COMPN(0, 4); else VOGE_LAUNCH_COMPN(0, 2); }
+    if (wavem) {
+      if (mode == 2) { if (NS == 4) VOGE_LAUNCH_COMPN(2, 4, true); else VOGE_LAUNCH_COMPN(2, 2, true); }
+      else { if (NS == 4) VOGE_LAUNCH_COMPN(0, 4, true); else VOGE_LAUNCH_COMPN(0, 2, true); }
+    } else {
+      if (mode == 2) { if (NS == 4) VOGE_LAUNCH_COMPN(2, 4, false); else VOGE_LAUNCH_COMPN(2, 2, false); }
+      else { if (NS == 4) VOGE_LAUNCH_COMPN(0, 4, false); else VOGE_LAUNCH_COMPN(0, 2, false); }
+    }
 #undef VOGE_LAUNCH_COMPN
     return launch_status();
   }
