@@ -794,11 +794,16 @@ bin2_kernel(const float4 *__restrict__ bin_rec, const float4 *__restrict__ ell, 
 // and a heavy tile that starts late is the kernel's tail; longest-first removes that tail.  The
 // sweep's results do not depend on the order.
 // ------------------------------------------------------------------------------------------
-constexpr int kOrderClasses = 16;
+#ifndef VOGE_ORDER_BITS
+#define VOGE_ORDER_BITS 6
+#endif
+constexpr int kOrderBits = VOGE_ORDER_BITS;
+constexpr int kOrderClasses = 1 << kOrderBits;
 constexpr int kOrderPer = 16;   // counts per thread kept in registers (one memory round trip)
 __global__ void __launch_bounds__(1024)
 tile_order_kernel(const int *__restrict__ tl_count, const int ntile, int *__restrict__ order) {
-  // Partition into 16 classes of the count range, heaviest first, with ballots only (no atomics:
+  // Partition into kOrderClasses (64) classes of the count range, heaviest first (16 -> 64 classes: sweep
+  // 67 -> 64 us at cfg3, the order is closer to longest-first), with ballots only (no atomics:
   // thousands of tiles with near-equal counts would serialise on a handful of LDS addresses).
   // Position = class base + this wave's base within the class + rank inside the ballot: a pure
   // function of the counts (deterministic).  Chunks of 16384 tiles; chunks are ordered one
@@ -842,12 +847,12 @@ tile_order_kernel(const int *__restrict__ tl_count, const int ntile, int *__rest
     }
     const float scale = (float)kOrderClasses / ((float)cmax + 1.0f);
     int cls[kOrderPer];
-    // lanes of the wave that hold the same class as this lane, from the four bit-ballots of the
-    // 4-bit class id (instead of one ballot per class)
+    // lanes of the wave that hold the same class as this lane, from the kOrderBits bit-ballots of the
+    // class id (instead of one ballot per class)
     auto same_class = [&](const int c) {
       unsigned long long same = __ballot(c >= 0);
 #pragma unroll
-      for (int bit = 0; bit < 4; ++bit) {
+      for (int bit = 0; bit < kOrderBits; ++bit) {
         const unsigned long long mb = __ballot((c >> bit) & 1);
         same &= ((c >> bit) & 1) ? mb : ~mb;
       }
@@ -1652,7 +1657,10 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
     if (rc) return rc;
   }
   // ordering only matters when the tiles do not all fit on the chip at once
-  const bool ordered = (size_t)grid.x * grid.y > 2048;
+  #ifndef VOGE_ORDER_MIN_TILES
+#define VOGE_ORDER_MIN_TILES 2048
+#endif
+  const bool ordered = (size_t)grid.x * grid.y > VOGE_ORDER_MIN_TILES;
   if (ordered)
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, ws.tl_count, (int)(grid.x * grid.y), ws.tile_order);
   hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, ws.ms, rays, ws.bin_count, ws.bin_id, ws.bin_lb,
