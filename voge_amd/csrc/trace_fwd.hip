@@ -1052,7 +1052,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
 
   uint64_t *mykeys = keys + tid;
   int cnt = 0;
-  uint64_t worst = ~0ull, tail = 0ull;
+  uint64_t worst = valid ? ((uint64_t)f2ord(VOGE_SENT_LEN) << 32) : 0ull, tail = 0ull;
   bool wdone = false, reported = false;
 #ifdef VOGE_SWEEP_STATS
   unsigned st_staged = 0, st_eval = 0, st_trips = 0, st_slow = 0, st_shift = 0, st_hits = 0, st_batches = 0;
@@ -1147,7 +1147,9 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
         // trip together with its records, so no LDS latency sits between two commits)
         auto commit = [&](const PairOut &o, const int gid, const bool on) {
           const uint64_t key = ((uint64_t)f2ord(o.len) << 32) | (uint32_t)gid;
-          const bool take = on & valid & (o.act < thr_act) & (o.len < VOGE_SENT_LEN) & (key < worst);
+          // (rays outside the image start with worst = 0, the others with the key of len = 1e10: `key < worst`
+          // also says "a ray of the image" and "len below the sentinel")
+          const bool take = on & (o.act < thr_act) & (key < worst);
 #ifdef VOGE_SWEEP_STATS
           {
             const bool app = take && (cnt < K) && (key >= tail);

@@ -200,7 +200,9 @@ __device__ __forceinline__ void topk_insert(uint64_t *keys, const int stride, co
 __device__ __forceinline__ void topk_commit(uint64_t *keys, const int stride, const int K, int &cnt,
                                             uint64_t &worst, uint64_t &tail, const uint64_t key,
                                             const bool take /* key < worst */) {
-  const bool app = take && (cnt < K) && (key >= tail);
+  // (cnt == K implies tail == worst, and take implies key < worst: a full list never appends, so the
+  // count needs no test of its own)
+  const bool app = take && (key >= tail);
   // 32-bit element offset (24-bit multiply): a 64-bit multiply-add per candidate is quarter rate
   const unsigned off = __umul24((unsigned)(app ? cnt : K), (unsigned)stride);
   keys[off] = key;
@@ -212,7 +214,7 @@ __device__ __forceinline__ void topk_commit(uint64_t *keys, const int stride, co
 #else
   const bool slow = take && !app;
 #endif
-  if (__any(slow)) {
+  if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {   // (as a mask test: __any() goes through a VGPR)
     if (slow) {
       if (cnt < K) {   // somewhere in the middle: everything above moves up, the tail stays the tail
         int pos = cnt;
