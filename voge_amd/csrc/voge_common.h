@@ -214,7 +214,8 @@ __device__ __forceinline__ void topk_commit(uint64_t *keys, const int stride, co
 #else
   const bool slow = take && !app;
 #endif
-  if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {   // (as a mask test: __any() goes through a VGPR)
+  // (a divergent `if` is already "skip unless some lane needs it": s_and_saveexec + s_cbranch_execz)
+  {
     if (slow) {
       if (cnt < K) {   // somewhere in the middle: everything above moves up, the tail stays the tail
         int pos = cnt;
