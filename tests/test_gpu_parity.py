@@ -654,3 +654,37 @@ def test_fused_preamble_equals_reference_ops(hip_lib, inverse_sigma):
         scale = max(1.0, float(np.abs(y).max()))
         assert np.abs(x - y).max() <= 2e-5 * scale, name
     assert np.abs(b[5]).max() > 0
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_iso_view_entry_points_batched_inputs(hip_lib, mode):
+    """voge_trace_topk_fwd_iso_view / voge_trace_bwd_iso_view with per-view Gaussian sets ([B,N,3] verts,
+    [B,N] sigmas: shared = 0) and every sigma mode, against the plain isotropic calls on inputs prepared with
+    torch ops (verts - origin, a = sigma | 2 sigma | 2 / sigma)."""
+    from voge_amd import ops
+    rng = np.random.default_rng(31 + mode)
+    B, N, H, W, K = 2, 700, 40, 56, 9
+    verts = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    sig = rng.uniform(60, 250, (B, N)).astype(np.float32)
+    if mode == 2:
+        sig = (1.0 / sig).astype(np.float32)
+    R, T = camera_np.look_at_view_transform([3.2] * B, [12.0] * B, [40.0, 75.0])
+    rays, origin = camera_np.pixel_rays(R, T, 60.0, (W / 2.0, H / 2.0), (H, W))
+    rays, origin = rays.astype(np.float32), origin.astype(np.float32)
+    thr_act = oracle.thr_act_of(0.01)
+    g = [torch.randn(B, H, W, K, device="cuda", generator=torch.Generator("cuda").manual_seed(5 + i)) for i in range(3)]
+    # fused
+    v1, s1 = t(verts, rg=True), t(sig, rg=True)
+    out1 = ops._RayTraceVoGEIsoView.apply(v1, s1, t(origin), t(rays), None, thr_act, K, mode)
+    sum(((o * gi).sum() for o, gi in zip(out1[1:], g))).backward()
+    # reference composition
+    v2, s2 = t(verts, rg=True), t(sig, rg=True)
+    a = s2 if mode == 0 else (2.0 * s2 if mode == 1 else 2.0 / s2)
+    out2 = ops._RayTraceVoGEIso.apply((v2 - t(origin)[:, None]).reshape(-1, 3), a.reshape(-1), t(rays), None, thr_act, K)
+    sum(((o * gi).sum() for o, gi in zip(out2[1:], g))).backward()
+    assert (n(out1[0]) == n(out2[0])).all() and (n(out1[0]) >= 0).mean() > 0.05
+    for x, y in zip(out1[1:], out2[1:]):
+        assert torch.equal(x, y)
+    for name, x, y in (("verts", v1.grad, v2.grad), ("sigmas", s1.grad, s2.grad)):
+        scale = max(1.0, float(y.abs().max()))
+        assert float((x - y).abs().max()) <= 2e-5 * scale, name
