@@ -1639,6 +1639,9 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
   return off;
 }
 
+#ifndef VOGE_SWEEP_LDS_PAD
+#define VOGE_SWEEP_LDS_PAD 0      // (occupancy experiments: extra dynamic LDS per workgroup)
+#endif
 template <int WAVES, bool ISO>
 static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int H, int W, int K,
                         float thr_act, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
@@ -1646,7 +1649,7 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
   constexpr int T = 64 * WAVES;
   constexpr int TW = (WAVES >= 2) ? 16 : 8;
   constexpr int TH = (WAVES == 4) ? 16 : 8;
-  const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + sizeof(TraceLds<T, ISO>);
+  const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + sizeof(TraceLds<T, ISO>) + VOGE_SWEEP_LDS_PAD;
   auto kern = trace_fwd_kernel<WAVES, ISO>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
