@@ -1477,7 +1477,8 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             ol[q] = ord2f((uint32_t)(key[u][q] >> 32));
             PairOut o;
             if (rec[u][q].w == rec[u][q].w) {
-              o = pair_eval_iso(rec[u][q].x, rec[u][q].y, rec[u][q].z, rec[u][q].w, ex[u], ey[u], ez[u], qxx, qyy, qzz);
+              o = pair_eval_iso_at(rec[u][q].x, rec[u][q].y, rec[u][q].z, rec[u][q].w, ol[q], ex[u], ey[u], ez[u],
+                                   (qxx + qyy) + qzz);     // len is in the key: no second division
             } else {
               const EvalRec e = unpack_eval(g0[q], g1[q], g2[q]);
               o = pair_eval(rec[u][q].x, rec[u][q].y, rec[u][q].z, e, ex[u], ey[u], ez[u], qxx, qyy, qzz, ex[u] * ey[u],

@@ -73,6 +73,21 @@ __device__ __forceinline__ PairOut pair_eval_iso(const float mx, const float my,
   return o;
 }
 
+// The same act / dsd from an already known len (the sweep's epilogue has it in the key): the identical
+// fma chain after t, so the values are bit-identical to pair_eval_iso's.
+__device__ __forceinline__ PairOut pair_eval_iso_at(const float mx, const float my, const float mz, const float a,
+                                                    const float t, const float dx, const float dy, const float dz,
+                                                    const float dn2) {
+  PairOut o;
+  const float vx = fmaf(-t, dx, mx);
+  const float vy = fmaf(-t, dy, my);
+  const float vz = fmaf(-t, dz, mz);
+  o.len = t;
+  o.act = a * fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+  o.dsd = a * dn2;
+  return o;
+}
+
 __device__ __forceinline__ PairOut pair_eval_gen(const float mx, const float my, const float mz,
                                                  const EvalRec &e, const float dx, const float dy,
                                                  const float dz, const float qxx, const float qyy,
