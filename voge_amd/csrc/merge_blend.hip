@@ -239,7 +239,7 @@ constexpr int kShadeWaves = VOGE_SHADE_WAVES;
 #define VOGE_SHADE_TH 2
 #endif
 #ifndef VOGE_SHADE_NE
-#define VOGE_SHADE_NE 256
+#define VOGE_SHADE_NE 128
 #endif
 constexpr int kShadeNE = VOGE_SHADE_NE;
 constexpr int kShadeTH = VOGE_SHADE_TH;   // a wave owns an 8 x kShadeTH pixel tile

@@ -267,7 +267,7 @@ bwd_unpack_kernel(const float *__restrict__ acc, const int P, float *__restrict_
 // of the scalar directly instead of a 3x3 block it would reduce again.
 // ------------------------------------------------------------------------------------------
 #ifndef VOGE_BWDI_NE
-#define VOGE_BWDI_NE 256
+#define VOGE_BWDI_NE 128
 #endif
 #ifndef VOGE_BWDI_WAVES
 #define VOGE_BWDI_WAVES 2
