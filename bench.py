@@ -304,9 +304,42 @@ def main():
         result["hits_per_pixel"] = round(hits / npix, 2)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(verts, sig, cols, H, W, K, focal, pp, (dd, el, az), args.cpu_seconds)
+    if rank == 0 and world > 1:
+        # the dominant kernel on rank 0's band of rows (same entry point, shorter image), timed live
+        with torch.no_grad():
+            from voge_amd.cameras import pixel_rays
+            lib = _lib.load()
+            r0, r1 = rows
+            rays_b, origin = pixel_rays(cams, (H, W), rows=rows)
+            h = r1 - r0
+            iso = gm.sigmas.dim() == 1
+            thr_act = -np.log(0.01 + 1e-10)
+            outs = [torch.empty((1, h, W, K), dtype=d, device=dev) for d in (torch.int32, torch.float32, torch.float32, torch.float32)]
+            o_c = torch.empty((1, h, W), dtype=torch.int32, device=dev)
+            ws = torch.empty(lib.voge_trace_workspace_bytes(1, N, h, W), dtype=torch.uint8, device=dev)
+            st = torch.cuda.current_stream().cuda_stream
+            P = lambda x: x.data_ptr()
+            if iso:
+                fn = lambda: lib.voge_trace_topk_fwd_iso_view(P(gm.verts), P(gm.sigmas), P(origin), 1, 1, P(rays_b), None, 1, N, h, W, K,
+                                                              thr_act, P(ws), ws.numel(), *[P(o) for o in outs], P(o_c), st)
+            else:
+                from voge_amd.Aggregation import expend_sigma
+                mus = (gm.verts[None] - origin[:, None]).reshape(-1, 3).contiguous()
+                isg = (2 * expend_sigma(gm.sigmas)).contiguous()
+                fn = lambda: lib.voge_trace_topk_fwd(P(mus), P(isg), P(rays_b), None, 1, N, h, W, K, thr_act, P(ws), ws.numel(),
+                                                     *[P(o) for o in outs], P(o_c), st)
+            t_ms = time_kernel(fn)
+            nb = stage_bytes(N, h * W, K, iso=iso)["trace_fwd"]
+            a = round(nb / 1e9 / (t_ms / 1e3), 1)
+            result["roofline"] = {"kernel": "voge_trace_topk_fwd(_iso) on rank 0's band of rows "
+                                            f"[{r0}, {r1}) = prep_cone + bin0 + bin + bin2 + tile_order + trace_fwd_kernel",
+                                  "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+                                  "algorithmic_bytes": nb, "avg_launch_ms": round(t_ms, 4)}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
