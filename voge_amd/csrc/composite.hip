@@ -406,11 +406,17 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
 // ------------------------------------------------------------------------------------------
 __host__ __device__ inline int compn_lanes(const int K, const int NS) { return (K + NS - 1) / NS; }
 __host__ __device__ inline int compn_stride(const int K, const int NS) { return compn_lanes(K, NS) * NS + 2 * comp_pad(K); }
-__host__ __device__ inline int compn_rows(const int K, const int NS) {
-  return ((kCompThreads / compn_lanes(K, NS)) * compn_stride(K, NS) + 3) & ~3;
+// pixels a workgroup of `threads` lanes holds: workgroup form = threads / LP, wave form = (threads / 64) * (64 / LP)
+__host__ __device__ inline int compn_pixels(const int K, const int NS, const int threads, const bool wave) {
+  const int lp = compn_lanes(K, NS);
+  return wave ? (threads / 64) * (64 / lp) : threads / lp;
 }
-__host__ __device__ inline size_t compn_lds_bytes(const int K, const int NS, const bool bwd) {
-  return sizeof(CompLds) + sizeof(float) * (size_t)compn_rows(K, NS) * (bwd ? 4 : 3);
+__host__ __device__ inline int compn_rows(const int K, const int NS, const int threads, const bool wave) {
+  return (compn_pixels(K, NS, threads, wave) * compn_stride(K, NS) + 3) & ~3;
+}
+// (the wave form keeps no per-workgroup state: no CompLds block in front of the arrays)
+__host__ __device__ inline size_t compn_lds_bytes(const int K, const int NS, const bool bwd, const int threads, const bool wave) {
+  return (wave ? 0 : sizeof(CompLds)) + sizeof(float) * (size_t)compn_rows(K, NS, threads, wave) * (bwd ? 4 : 3);
 }
 
 #ifndef VOGE_COMP_WPE
@@ -430,9 +436,9 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   constexpr bool BWD = MODE != 0;
   constexpr int NP = NS / 2;       // own aligned pairs
   extern __shared__ __attribute__((aligned(16))) unsigned char comp_smem[];
-  CompLds &L = *reinterpret_cast<CompLds *>(comp_smem);
-  const int rows = compn_rows(K, NS);
-  float *const Llen = reinterpret_cast<float *>(comp_smem + sizeof(CompLds));
+  CompLds &L = *reinterpret_cast<CompLds *>(comp_smem);      // (workgroup form only)
+  const int rows = compn_rows(K, NS, (int)blockDim.x, WAVE);
+  float *const Llen = reinterpret_cast<float *>(comp_smem + (WAVE ? 0 : sizeof(CompLds)));
   float *const Lsp = Llen + rows;
   float *const LE = Lsp + rows;     // E (forward) or E * s' (backward)
   float *const Lu = LE + rows;      // backward only
@@ -880,9 +886,14 @@ static int launch_composite(int mode, const int32_t *idx, const float *act, cons
 #define VOGE_COMP_WAVE 2        // measured (cfg3): backward 101 -> 95 us; forward 52 -> 59 us (its two-float scan
 #endif                          // costs more as shuffles than as LDS round trips with barriers)
     const bool wavem = ((VOGE_COMP_WAVE >> (mode == 0 ? 0 : 1)) & 1) && LPn <= 64;   // needs a pixel's lanes inside one wave
-    const int ppwn = wavem ? (kCompThreads / 64) * (64 / LPn) : kCompThreads / LPn;
-    const dim3 gridn((unsigned)((npix + ppwn - 1) / ppwn)), blockn(kCompThreads);
-    const size_t ldsn = compn_lds_bytes(K, NS, mode != 0);
+#ifndef VOGE_COMP_WAVE_T
+#define VOGE_COMP_WAVE_T 64     // waves of the barrier-free form never talk to each other: one-wave workgroups schedule finest
+                                // (cfg3 backward: 256 / 128 / 64 threads -> 92.2 / 89.1 / 86.7 us)
+#endif
+    const int tn = wavem ? VOGE_COMP_WAVE_T : kCompThreads;
+    const int ppwn = compn_pixels(K, NS, tn, wavem);
+    const dim3 gridn((unsigned)((npix + ppwn - 1) / ppwn)), blockn(tn);
+    const size_t ldsn = compn_lds_bytes(K, NS, mode != 0, tn, wavem);
 #define VOGE_LAUNCH_COMPN(M, N, WV)                                                                                     \
     hipLaunchKernelGGL((compositen_kernel<M, N, WV>), gridn, blockn, ldsn, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, \
                        npix, K, ppwn, o0, o1, o2, valid_num)
