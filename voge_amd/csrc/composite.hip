@@ -883,8 +883,8 @@ static int launch_composite(int mode, const int32_t *idx, const float *act, cons
     const int NS = ((mode == 0 ? VOGE_COMP_NS : VOGE_COMP_NS_BWD) == 4 && (K & 3) == 0) ? 4 : 2;
     const int LPn = compn_lanes(K, NS);
 #ifndef VOGE_COMP_WAVE          // bit 0: forward, bit 1: backward take the barrier-free one-wave-per-pixel form
-#define VOGE_COMP_WAVE 2        // measured (cfg3): backward 101 -> 95 us; forward 52 -> 59 us (its two-float scan
-#endif                          // costs more as shuffles than as LDS round trips with barriers)
+#define VOGE_COMP_WAVE 3        // measured (cfg3, one-wave workgroups): backward 101 -> 87 us, forward 52 -> 50 us (the
+#endif                          // forward lost 7 us in this form while it still ran as 256-thread workgroups)
     const bool wavem = ((VOGE_COMP_WAVE >> (mode == 0 ? 0 : 1)) & 1) && LPn <= 64;   // needs a pixel's lanes inside one wave
 #ifndef VOGE_COMP_WAVE_T
 #define VOGE_COMP_WAVE_T 64     // waves of the barrier-free form never talk to each other: one-wave workgroups schedule finest
