@@ -232,7 +232,7 @@ shade_fwd4_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx, con
 // bg == NULL: g_up is the gradient of the merged attributes themselves (interpolate_attr).
 // ------------------------------------------------------------------------------------------
 #ifndef VOGE_SHADE_WAVES
-#define VOGE_SHADE_WAVES 4
+#define VOGE_SHADE_WAVES 1
 #endif
 constexpr int kShadeWaves = VOGE_SHADE_WAVES;
 #ifndef VOGE_SHADE_TH

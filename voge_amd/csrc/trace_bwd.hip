@@ -270,7 +270,7 @@ bwd_unpack_kernel(const float *__restrict__ acc, const int P, float *__restrict_
 #define VOGE_BWDI_NE 128
 #endif
 #ifndef VOGE_BWDI_WAVES
-#define VOGE_BWDI_WAVES 2
+#define VOGE_BWDI_WAVES 1
 #endif
 #ifndef VOGE_BWDI_U
 #define VOGE_BWDI_U 2
