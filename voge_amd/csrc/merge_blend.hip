@@ -144,7 +144,7 @@ shade_fwd4_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx, con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane >> 4, q = lane & 15;
   const bool lane_on = q < (K >> 2);
-  const long pixbase = ((long)blockIdx.x * 4 + wave) * (4 * kSh4P);
+  const long pixbase = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * (4 * kSh4P);
   if (pixbase >= npix) return;
   for (int c0 = 0; c0 < C; c0 += 4) {
     const int nc = min(4, C - c0);
@@ -496,8 +496,11 @@ extern "C" int voge_shade_fwd(const float *attr, int32_t *idx, const float *weig
   if (out_img && !bg) return VOGE_ERR_BAD_ARG;
   const bool aligned = ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(weight)) & 15) == 0;
   if (C > 0 && (K & 3) == 0 && K <= 64 && aligned) {
-    const long per_wg = 4L * 4 * kSh4P;
-    hipLaunchKernelGGL(shade_fwd4_kernel, dim3((unsigned)((npix + per_wg - 1) / per_wg)), dim3(256), 0,
+#ifndef VOGE_SH4_T
+#define VOGE_SH4_T 256
+#endif
+    const long per_wg = (VOGE_SH4_T / 64) * 4L * kSh4P;      // waves are independent: 4 * kSh4P pixels each
+    hipLaunchKernelGGL(shade_fwd4_kernel, dim3((unsigned)((npix + per_wg - 1) / per_wg)), dim3(VOGE_SH4_T), 0,
                        (hipStream_t)stream, attr, idx, weight, valid_num, bg, thr, npix, K, C, Nattr, fix_negative_idx,
                        out_rgb, out_img, out_sil, out_wsum);
     return launch_status();
