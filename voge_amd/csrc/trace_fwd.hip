@@ -354,7 +354,10 @@ __device__ __forceinline__ Cone compose_cones(const ConeRec *__restrict__ ch, co
 // list (~N/10) instead of all N Gaussians: the scan work drops from nst*N to nst0*N + nst*N/10.
 // ------------------------------------------------------------------------------------------
 constexpr int kST0 = 128;
-constexpr int kBin0Split = 8;
+#ifndef VOGE_BIN0_SPLIT
+#define VOGE_BIN0_SPLIT 8
+#endif
+constexpr int kBin0Split = VOGE_BIN0_SPLIT;
 
 __global__ void __launch_bounds__(kBinThreads)
 bin0_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, const int nstx, const int nsty,
