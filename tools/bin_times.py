@@ -1,0 +1,33 @@
+"""Phase timestamps of the bin kernel (debug build: tools/tune_variants.sh bt:"-DVOGE_BIN_TIMES").
+usage on the GPU box: VOGE_HIP_LIB=build/variants/bt.so python tools/bin_times.py [config]"""
+import ctypes, sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from voge_amd import _lib, scenes
+from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
+from voge_amd.Renderer import GaussianRenderSettings, GaussianRenderer
+from voge_amd.Meshes import GaussianMeshes
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_50k_512"
+N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[name]
+verts, sig, colors = scenes.random_gaussians(N, seed=0)
+dev = torch.device("cuda", 0)
+gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
+R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
+cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), device=dev)
+renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1, max_point_per_bin=-1)).to(dev)
+with torch.no_grad():
+    for _ in range(3):
+        renderer(gm, R=R, T=T)
+torch.cuda.synchronize()
+nst = ((W + 31) // 32) * ((H + 31) // 32)
+n = min(nst, 1024)
+buf = (ctypes.c_ulonglong * (8 * n))()
+ctypes.CDLL(_lib.LIB_PATH).voge_debug_bin_times(buf, n)
+t = np.array(list(buf), dtype=np.float64).reshape(n, 8) * 0.01     # us (100 MHz)
+names = ["scan (ids, records, tests, LDS append)", "min/max + reach reductions", "histogram", "bucket scan", "scatter", "output (gather + stores)"]
+d = np.diff(t[:, :7], axis=1)
+print("super-tiles", n, " kernel span", round(t[:, 6].max() - t[:, 0].min(), 1), "us;  per workgroup mean / max (us):")
+for i, nm in enumerate(names):
+    print(f"  {nm:42s} {d[:, i].mean():6.2f} {d[:, i].max():6.2f}")
+print(f"  {'total':42s} {(t[:, 6] - t[:, 0]).mean():6.2f} {(t[:, 6] - t[:, 0]).max():6.2f}   start spread {t[:, 0].max() - t[:, 0].min():.2f}")

@@ -422,6 +422,12 @@ bin0_kernel(const float4 *__restrict__ cull, const ConeRec *__restrict__ cones, 
   }
 }
 
+#ifdef VOGE_BIN_TIMES
+__device__ unsigned long long g_bin_times[1024 * 8];   // per super-tile: start, scan done, reduced, hist, scanned, scattered, end
+#define BIN_TS(k) if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) g_bin_times[8 * blockIdx.x + (k)] = wall_clock64()
+#else
+#define BIN_TS(k)
+#endif
 #ifndef VOGE_ELL_KEY
 #define VOGE_ELL_KEY 0
 #endif
@@ -437,12 +443,14 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
   const int x0 = stx * kST, y0 = sty * kST;
   const Cone cone = load_cone(cones[(size_t)b * gridDim.x + blockIdx.x]);
 
+  BIN_TS(0);
   // ---- scan all Gaussians of this batch element, keep (bound, id) of the survivors ----
   if (tid == 0) { L.count = 0; L.nflag = 0; }
   __syncthreads();
   const float4 *cullb = cull + (size_t)b * N;
   const float4 *ellb = ell + (size_t)b * N * 2;
   float rmax = 0.0f;   // largest finite reach among this thread's survivors WITHOUT an ellipsoid record
+  float klo = INFINITY, khi = -INFINITY;   // extrema of the finite order keys this thread appended
   constexpr int kScanU = 8;
   // candidates: the parent region's list, or (small problems, no coarse level) every Gaussian
   const int parent = b * nst0 + (y0 / kST0) * nst0x + x0 / kST0;
@@ -490,30 +498,41 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
         asm volatile("" ::: "memory");
       }
     }
+    // ONE LDS atomic per wave and trip reserves the slots of all kScanU ballots (it was one per ballot: a chain
+    // of eight LDS round trips per trip); the keys' extrema ride along in registers for the bucket mapping.
+    unsigned long long mq[kScanU];
+    int wtot = 0;
+    bool wave_flag = false;
 #pragma unroll
     for (int q = 0; q < kScanU; ++q) {
-      const int g = gid[q];
-      const bool keep = kp[q];
-      if (keep && !el[q] && c[q].w < 3e38f) rmax = fmaxf(rmax, c[q].w);
-      const unsigned long long m = __ballot(keep);
-      if (m) {
-        const bool wave_flag = __any(keep && el[q]);
-        int start = 0;
-        if (lane == 0) {
-          start = atomicAdd(&L.count, __popcll(m));
-          if (wave_flag) L.nflag = 1;
-        }
-        start = __shfl(start, 0, 64);
-        const int slot = start + __popcll(m & ((1ull << lane) - 1ull));
-        // bit 31 of the id word: the entry has an ellipsoid record (its len bound is its own)
-        if (keep && slot < kBinCap) {
+      mq[q] = __ballot(kp[q]);
+      wtot += __popcll(mq[q]);
+      wave_flag = wave_flag || (kp[q] && el[q]);
+    }
+    wave_flag = __any(wave_flag);
+    if (wtot) {       // uniform
+      int start = 0;
+      if (lane == 0) {
+        start = atomicAdd(&L.count, wtot);
+        if (wave_flag) L.nflag = 1;
+      }
+      start = __shfl(start, 0, 64);
+#pragma unroll
+      for (int q = 0; q < kScanU; ++q) {
+        const int slot = start + __popcll(mq[q] & ((1ull << lane) - 1ull));
+        start += __popcll(mq[q]);
+        if (kp[q]) {
+          if (!el[q] && c[q].w < 3e38f) rmax = fmaxf(rmax, c[q].w);
+          // bit 31 of the id word: the entry has an ellipsoid record (its len bound is its own)
           const float key = el[q] ? gkey[q] : depth_key(c[q], cone);
-          L.keys[slot] = ((uint64_t)f2ord(key) << 32) | (uint32_t)g | (el[q] ? 0x80000000u : 0u);
+          if (key > -INFINITY) { klo = fminf(klo, key); khi = fmaxf(khi, key); }
+          if (slot < kBinCap) L.keys[slot] = ((uint64_t)f2ord(key) << 32) | (uint32_t)gid[q] | (el[q] ? 0x80000000u : 0u);
         }
       }
     }
   }
   __syncthreads();
+  BIN_TS(1);
   const int total = L.count;
   const int bin = b * gridDim.x + blockIdx.x;
   if (total > kBinCap) {
@@ -524,14 +543,15 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
   // sort inside every bucket (a handful of entries each).  Exact order is not needed for
   // correctness (the sweep's top-K insertion is order independent) but it turns nearly every
   // insertion into an append.  Bucket 0 collects the -inf keys (unbounded reach).
-  float lo = INFINITY, hi = -INFINITY, d0 = 0.f, d1 = 1.f;
-  for (int i = tid; i < total; i += kBinThreads) {
-    const float v = ord2f((uint32_t)(L.keys[i] >> 32));
-    if (v > -INFINITY) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+  // one workgroup reduction for (largest key, smallest key, largest sphere reach)
+  float hi = wave_max(khi), lo = wave_min(klo), rm = wave_max(rmax);
+  if (lane == 0) { L.red[wave * 4 + 0] = hi; L.red[wave * 4 + 1] = lo; L.red[wave * 4 + 2] = rm; }
+  __syncthreads();
+  hi = L.red[0]; lo = L.red[1]; rm = L.red[2];
+  for (int w = 1; w < kBinThreads / 64; ++w) {
+    hi = fmaxf(hi, L.red[w * 4 + 0]); lo = fminf(lo, L.red[w * 4 + 1]); rm = fmaxf(rm, L.red[w * 4 + 2]);
   }
-  block_reduce16(L.red, wave, lane, hi, lo, d0, d1, 1);   // a: max, b: min
-  float rm = rmax, rdummy = 0.f;
-  block_reduce16(L.red, wave, lane, rm, rdummy, d0, d1, 1);
+  BIN_TS(2);
   const float span = fmaxf(hi - lo, 1e-20f);
   const float scale = (float)(kBuckets - 2) / span;
   const bool flagged = L.nflag != 0;     // any entry with an ellipsoid record (workgroup-uniform)
@@ -560,6 +580,7 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
     }
   }
   __syncthreads();
+  BIN_TS(3);
   // exclusive scan of kBuckets (== kBinThreads) counters: wave scan + wave offsets
   {
     const int v = L.hist[tid];
@@ -578,6 +599,7 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
     if (tid == kBuckets - 1) L.start[kBuckets] = off + x;
   }
   __syncthreads();
+  BIN_TS(4);
   for (int i = tid; i < total; i += kBinThreads) {
     const uint64_t k = L.keys[i];
     const float v = ord2f((uint32_t)(k >> 32));
@@ -586,6 +608,7 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
     L.sorted[atomicAdd(&L.hist[q], 1)] = k;
   }
   __syncthreads();
+  BIN_TS(5);
 #ifdef VOGE_BIN_FULLSORT
   {  // thread q orders bucket q (keys are unique: the id is in the low word)
     const int s0 = L.start[tid], s1 = L.start[tid + 1];
@@ -642,6 +665,7 @@ bin_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, cons
     const float lb_sphere = (edge > -INFINITY) ? edge - slack - 1e-5f * fabsf(edge) - 1e-30f : -INFINITY;
     olb[i] = flagged ? fminf(lb_sphere, ord2f(L.bmin[qb])) : lb_sphere;
   }
+  BIN_TS(6);
   if (tid == 0) bin_count[bin] = total;
 }
 
@@ -1689,6 +1713,13 @@ extern "C" int voge_debug_sweep_stats(unsigned long long *out16) {
   unsigned long long z[16] = {0};
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(voge::g_sweep_stats), z, sizeof(z));
 }
+#endif
+#ifdef VOGE_BIN_TIMES
+extern "C" int voge_debug_bin_times(unsigned long long *out, int n_wg) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(voge::g_bin_times), sizeof(unsigned long long) * 8 * (size_t)n_wg);
+}
+#endif
+#ifdef VOGE_SWEEP_TIMES
 extern "C" int voge_debug_sweep_times(unsigned long long *out, int n_wg) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(voge::g_sweep_times), sizeof(unsigned long long) * 8 * (size_t)n_wg);
 }
