@@ -283,7 +283,7 @@ def test_composite_golden(hip_lib, name):
         assert np.abs(n(got) - ref).max() <= TOL * max(1.0, np.abs(ref).max()), key
 
 
-@pytest.mark.parametrize("K", [1, 20, 64, 102, 256])
+@pytest.mark.parametrize("K", [1, 20, 64, 102, 250, 256])
 def test_composite_random_vs_oracle(hip_lib, K):
     from voge_amd import ops
     rng = np.random.default_rng(K)
