@@ -269,13 +269,13 @@ def main():
             calls = {
                 "trace_fwd": lambda: trace_fwd_fn(P(mus), P(isg), P(rays), None, 1, N, H, W, K, thr_act, P(ws),
                                                              ws.numel(), P(o_i), P(o_l), P(o_a), P(o_d), P(o_c), st),
-                "composite_fwd": lambda: lib.voge_composite_fwd(None, P(sel[0].voge_hit_count), P(sel[2]), P(sel[1]), P(sel[3]), 1.0, npix, K,
+                "composite_fwd": lambda: lib.voge_composite_fwd(None, P(ops.hit_count_of(sel[0])), P(sel[2]), P(sel[1]), P(sel[3]), 1.0, npix, K,
                                                                 P(g3[0]), P(vn), st),
                 "shade_fwd": lambda: lib.voge_shade_fwd(P(colors), P(idx), P(w), P(vn), P(bg), -1.0, npix, K, 3, N, 1, P(rgb),
                                                         P(out3), None, P(wsum), st),
                 "shade_bwd": lambda: lib.voge_shade_bwd(P(colors), P(idx), P(w), P(vn), P(rgb), P(wsum), P(bg), -1.0, P(g_img), H, W, K,
                                                         3, N, P(g_attr), P(g3[0]), st),
-                "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), P(sel[0].voge_hit_count), P(g_w), 1.0, npix, K, P(g3[0]),
+                "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), P(ops.hit_count_of(sel[0])), P(g_w), 1.0, npix, K, P(g3[0]),
                                                                 P(g3[1]), P(g3[2]), st),
                 "trace_bwd": lambda: trace_bwd_fn(P(mus), P(isg), P(rays), P(sel[0]), P(vn32), P(w), P(w), P(w), N, H, W, K,
                                                         P(ws_b), ws_b.numel(), None, P(g_mu), P(g_A), st),

@@ -83,13 +83,14 @@ int voge_trace_topk_fwd(const float *mus, const float *isigmas, const float *ray
  * Replaces: VoGE._C.ray_trace_voge_fine for an explicit bin_points tensor
  * [B,BH,BW,M] int32, -1 = empty (ray_trace_voge.cu:135-217): pixel (y,x) of batch b
  * scans bin (y/bin_size, x/bin_size).  P = total Gaussians (list entries index [0,P)).
- * Same outputs as above.  Exact ties in len are ordered by index (the reference orders
- * them by list position, which is not deterministic for coarse-rasterised lists).
+ * Same outputs as above (cnt: NULL or [B,H,W] int32, the hits kept per pixel).  Exact ties in
+ * len are ordered by index (the reference orders them by list position, which is not
+ * deterministic for coarse-rasterised lists).
  */
 int voge_trace_topk_list_fwd(const float *mus, const float *isigmas, const float *rays,
                              const int32_t *bin_points, int B, int P, int H, int W, int K,
                              int BH, int BW, int M, int bin_size, float thr_act,
-                             int32_t *idx, float *len, float *act, float *dsd,
+                             int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
                              voge_stream_t stream);
 
 /*

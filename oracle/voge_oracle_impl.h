@@ -110,7 +110,10 @@ void FN(oracle_trace_fwd)(const float *mus, const float *isg, const float *rays,
  * (pixel,k) recompute the three forms, apply the chain rule of :324-326, then
  * scatter the three outer-product gradients.  grad_isg is the raw (not
  * symmetrised) outer-product sum.  The reference accumulates with float
- * atomicAdd in arbitrary order; here the sums run in (pixel,k) order.
+ * atomicAdd in arbitrary order; here pixels run in parallel (OpenMP) and the
+ * per-Gaussian sums use atomic adds as well -- in REAL = double the order
+ * dependence is ~1e-16 relative.  g_ray is pixel-owned (a pixel's K slots run
+ * in order on one thread).
  * Outputs (zeroed here): g_ray [B,H,W,3], g_mus [P,3], g_isg [P,9].
  */
 void FN(oracle_trace_bwd)(const float *mus, const float *isg, const float *rays,
@@ -120,10 +123,11 @@ void FN(oracle_trace_bwd)(const float *mus, const float *isg, const float *rays,
   memset(g_ray, 0, sizeof(REAL) * npix * 3);
   memset(g_mus, 0, sizeof(REAL) * (size_t)P * 3);
   memset(g_isg, 0, sizeof(REAL) * (size_t)P * 9);
-  for (long pid = 0; pid < npix * K; ++pid) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (long r = 0; r < npix; ++r)
+  for (long pid = r * K; pid < (r + 1) * K; ++pid) {
     const int p = idx[pid];
     if (p == -1) continue;
-    const long r = pid / K;
     const float *ray = rays + r * 3, *mu = mus + (long)p * 3, *Bm = isg + (long)p * 9;
     const REAL gl = g_len[pid], ga = g_act[pid], gd = g_dsd[pid];
     const REAL ksk = FN(form3)(ray, Bm, ray);
@@ -132,12 +136,14 @@ void FN(oracle_trace_bwd)(const float *mus, const float *isg, const float *rays,
     const REAL g_msk = (gl - 2 * ga * msk) / ksk;
     const REAL g_msm = ga;
     REAL *gr = g_ray + r * 3, *gm = g_mus + (long)p * 3, *gB = g_isg + (long)p * 9;
-    /* the three (a, c, grad, a-grad target, c-grad target) triples of :328-330 */
+    /* the three (a, c, grad, a-grad target, c-grad target) triples of :328-330; this slot's
+     * contributions are summed locally (same order), then added to the shared per-Gaussian sums */
     const float *av[3] = {ray, mu, mu};
     const float *cv[3] = {ray, ray, mu};
     const REAL gg[3] = {g_ksk, g_msk, g_msm};
-    REAL *ga_out[3] = {gr, gm, gm};
-    REAL *gc_out[3] = {gr, gr, gm};
+    REAL l_ray[3] = {0, 0, 0}, l_mu[3] = {0, 0, 0}, l_B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    REAL *ga_out[3] = {l_ray, l_mu, l_mu};
+    REAL *gc_out[3] = {l_ray, l_ray, l_mu};
     for (int f = 0; f < 3; ++f) {
       const float *a = av[f], *c = cv[f];
       const REAL g = gg[f];
@@ -146,11 +152,20 @@ void FN(oracle_trace_bwd)(const float *mus, const float *isg, const float *rays,
         for (int j = 0; j < 3; ++j) {
           Bc += (REAL)Bm[i * 3 + j] * (REAL)c[j];
           Bta += (REAL)Bm[j * 3 + i] * (REAL)a[j];
-          gB[i * 3 + j] += ((REAL)a[i] * (REAL)c[j]) * g;
+          l_B[i * 3 + j] += ((REAL)a[i] * (REAL)c[j]) * g;
         }
         ga_out[f][i] += Bc * g;
         gc_out[f][i] += Bta * g;
       }
+    }
+    for (int i = 0; i < 3; ++i) gr[i] += l_ray[i];      /* pixel-owned */
+    for (int i = 0; i < 3; ++i) {
+#pragma omp atomic
+      gm[i] += l_mu[i];
+    }
+    for (int i = 0; i < 9; ++i) {
+#pragma omp atomic
+      gB[i] += l_B[i];
     }
   }
 }
@@ -266,6 +281,7 @@ void FN(oracle_merge_bwd)(const REAL *attr, const int32_t *idx, const REAL *weig
                           const int64_t *valid_num, const REAL *g_out, long npix,
                           int K, int C, long Nattr, REAL *g_attr, REAL *g_weight) {
   memset(g_attr, 0, sizeof(REAL) * (size_t)Nattr * C);
+#pragma omp parallel for schedule(dynamic, 64)
   for (long pix = 0; pix < npix; ++pix) {
     for (int k = 0; k < K; ++k) {
       REAL gw = 0;
@@ -275,7 +291,9 @@ void FN(oracle_merge_bwd)(const REAL *attr, const int32_t *idx, const REAL *weig
         const REAL w = weight[pix * K + k];
         for (int c = 0; c < C; ++c) {
           gw += g_out[pix * C + c] * attr[(long)p * C + c];
-          g_attr[(long)p * C + c] += w * g_out[pix * C + c];
+          const REAL add = w * g_out[pix * C + c];
+#pragma omp atomic
+          g_attr[(long)p * C + c] += add;
         }
       }
       g_weight[pix * K + k] = gw;

@@ -25,7 +25,7 @@ def _free_port():
 def _worker(rank, world, port, H, W, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from voge_amd.distributed import allreduce_grads, gather_rows, gather_rows_async, row_band
+    from voge_amd.distributed import FlatGrads, allreduce_grads, gather_rows, gather_rows_async, row_band
     sc = cuboid_scene()
     R, T = camera_np.look_at_view_transform(sc["dist"], sc["elev"], sc["azim"])
     r0, r1 = row_band(H, rank, world)
@@ -51,9 +51,21 @@ def _worker(rank, world, port, H, W, out):
         assert torch.equal(gather_rows(full[:, b0:b1].contiguous(), H, bounds=bounds), full)
         assert torch.equal(gather_rows_async(full[:, b0:b1].contiguous(), H, bounds=bounds)(), full)
     img[:, r0:r1].sum().backward()          # each rank owns the loss of its band
+    local = colors.grad.clone()
     allreduce_grads([colors])
+    # the persistent flat buffer bench.py uses: gradients accumulate into views of it, one collective, no copies
+    extra = torch.ones(5, dtype=torch.float64, requires_grad=True)
+    fg = FlatGrads([colors, extra])
+    assert colors.grad.data_ptr() == fg.flat.data_ptr() and float(fg.flat.abs().sum()) == 0.0
+    for _ in range(2):          # two steps: zero() really resets the accumulation
+        fg.zero()
+        band2 = (colors[torch.tensor(np.maximum(idx, 0)).long()] * (wt * valid)[..., None]).sum(-2)
+        (band2.sum() + (extra * (rank + 1)).sum()).backward()
+        assert torch.equal(colors.grad, local)
+        fg.allreduce()
+    assert torch.equal(extra.grad, torch.full((5,), 3.0, dtype=torch.float64))      # 1 + 2 over the two ranks
     if rank == 0:
-        torch.save({"img": img.detach(), "g": colors.grad}, out)
+        torch.save({"img": img.detach(), "g": colors.grad.clone(), "g_list": local * 0 + colors.grad}, out)
     dist.barrier()
     dist.destroy_process_group()
 

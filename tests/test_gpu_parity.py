@@ -57,7 +57,7 @@ def test_trace_fwd_cuboid_config1(hip_lib):
     thr = oracle.thr_act_of(0.01)
     got = run_trace(mus, isg, rays, sc["K"], thr)
     ref = oracle.trace_fwd(mus, isg, rays, sc["K"], thr)
-    frac = compare_trace(got, ref, thr)
+    frac = compare_trace(got, ref, thr, max_flips=10)
     assert (ref[0] >= 0).sum() > 100000 and frac > 0.999
 
 
@@ -69,7 +69,7 @@ def test_trace_fwd_bunny_config2(hip_lib):
     thr = oracle.thr_act_of(0.01)
     got = run_trace(mus, isg, rays, sc["K"], thr)
     ref = oracle.trace_fwd(mus, isg, rays, sc["K"], thr)
-    compare_trace(got, ref, thr, min_match=0.995)
+    compare_trace(got, ref, thr, min_match=0.995, max_flips=100)
     ref32 = oracle.trace_fwd(mus, isg, rays, sc["K"], thr, precision="f32")
     both = (ref32[0] == ref[0]) & (ref[0] >= 0)
     assert max_rel(ref32[2][both], ref[2][both]) > 10 * TOL  # the reference's fp32 noise floor
@@ -377,7 +377,8 @@ def _render(scene, image_size, B=1, grad=False, rows=None, max_point_per_bin=-1)
                                 max_point_per_bin=max_point_per_bin, batch_size=-1)
     renderer = GaussianRenderer(cameras=cams, render_settings=st).to(DEV)
     gm = GaussianMeshes(t(scene["verts"]), t(scene["sigmas"])).to(DEV)
-    colors = t(scene["colors"], rg=grad)
+    # a batch of B views indexes attribute rows b*N+n (RayTracing.py:24-30): the table is tiled over the batch
+    colors = t(np.tile(scene["colors"], (B, 1)), rg=grad)
     kw = {} if rows is None else dict(rows=rows)
     frag = renderer(gm, R=t(R), T=t(T), **kw)
     img = to_white_background(frag, colors)
@@ -637,7 +638,7 @@ def test_fused_preamble_equals_reference_ops(hip_lib, inverse_sigma):
         Rm.FUSED_PREAMBLE = fused
         try:
             gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to("cuda")
-            colors = t(cols, rg=True)
+            colors = t(np.tile(cols, (2, 1)), rg=True)          # two views: attribute rows b*N+n
             frag = renderer(gm, R=R, T=T)
             img = Rm.to_white_background(frag, colors)
             (img * g_img).sum().backward()
@@ -688,3 +689,49 @@ def test_iso_view_entry_points_batched_inputs(hip_lib, mode):
     for name, x, y in (("verts", v1.grad, v2.grad), ("sigmas", s1.grad, s2.grad)):
         scale = max(1.0, float(y.abs().max()))
         assert float((x - y).abs().max()) <= 2e-5 * scale, name
+
+
+# ------------------------------------------------------------------------------- bookkeeping on the index tensor
+def test_list_path_backward_after_merge_and_index_guards(hip_lib):
+    """(a) Explicit bin lists: merge_final rewrites -1 -> 0 in the fragments' index tensor (Aggregation.py:131); a
+    later backward with a gradient on an EMPTY slot (e.g. a loss on vert_hit_length) must not land on Gaussian 0 --
+    the list kernel's per-pixel hit count marks the filled slots.  (b) A batch of views indexes rows b*N+n: an
+    attribute table with N rows raises like the reference's assert (:120).  (c) Editing sel_idx through torch between
+    ray_tracing and aggregation invalidates the cached hit count (valid_num = sum(sel_idx >= 0), :104)."""
+    from voge_amd import ops
+    from voge_amd.Aggregation import aggregation, merge_final
+    verts, sig, cols = random_scene(300, seed=3, lo=0.05, hi=0.1)
+    H, W, K, bs = 24, 32, 12, 10
+    sc = dict(verts=verts, sigmas=sig, focal=30.0, principal=(16.0, 12.0), image_size=(H, W), dist=3.0, elev=5.0, azim=15.0)
+    mus, isg, rays, _, _ = camera_inputs(sc, B=2)
+    BH, BW = (H - 1) // bs + 1, (W - 1) // bs + 1
+    bins = np.broadcast_to(np.arange(300, dtype=np.int32)[None, None, None], (2, BH, BW, 300)).copy()
+    bins[1] += 300
+    thr_act = oracle.thr_act_of(0.01)
+    tm, tA = t(mus.reshape(-1, 3), rg=True), t(isg.reshape(-1, 3, 3), rg=True)
+    idx, ln, act, dsd = ops.ray_trace_fine(tm, tA, t(rays), t(bins, torch.int32), thr_act, bs, K)
+    empty = n(idx) < 0
+    assert empty.any() and (~empty).any()
+    w, idx2, vn, hl = aggregation(idx, act, ln, dsd, 1.0)
+    with pytest.raises(AssertionError):
+        merge_final(t(cols), w, idx2, vn)                        # (b) 300 rows, indices up to 599
+    rgb = merge_final(t(np.tile(cols, (2, 1))), w, idx2, vn)
+    assert (n(idx2)[empty] == 0).all()                           # the in-place fix has run
+    g_hl = np.ones(idx.shape) * 3.0                              # gradient on every slot, empty ones included
+    (rgb.sum() + (hl * t(g_hl)).sum()).backward()
+    # oracle: the same loss with the gradient of the empty slots masked (sentinels carry no gradient)
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act, bin_points=bins, bin_size=bs)
+    wr, vr = oracle.composite_fwd(ref[0], ref[2], ref[1], ref[3], 1.0)
+    _, g_w = oracle.merge_bwd(np.tile(cols, (2, 1)), ref[0], wr, vr, np.ones(rgb.shape))
+    g_act, g_len, g_dsd = oracle.composite_bwd(ref[2], ref[1], ref[3], g_w, 1.0)
+    _, g_mu, g_A = oracle.trace_bwd(mus, isg, rays, ref[0], g_len + g_hl * (ref[0] >= 0), g_act, g_dsd)
+    assert np.abs(n(tm.grad) - g_mu).max() <= 20 * TOL * max(1.0, np.abs(g_mu).max())
+    assert np.abs(n(tm.grad)[0] - g_mu[0]).max() <= 20 * TOL * max(1.0, np.abs(g_mu).max())      # Gaussian 0 in particular
+    # (c) mask a Gaussian out of the fragments by hand: the count must follow
+    idx3, ln3, act3, dsd3 = ops.ray_trace_fine(t(mus.reshape(-1, 3)), t(isg.reshape(-1, 3, 3)), t(rays), None, thr_act, bs, K)
+    assert ops.hit_count_of(idx3) is not None
+    first = n(idx3)[..., 0] >= 0
+    idx3[..., 0] = -1
+    assert ops.hit_count_of(idx3) is None
+    _, _, vn3, _ = aggregation(idx3, act3, ln3, dsd3, 1.0)
+    assert (n(vn3) == (n(idx3) >= 0).sum(-1)).all() and first.any()

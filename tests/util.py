@@ -24,19 +24,43 @@ def max_rel(a, b):
     return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max())
 
 
-def compare_trace(got, ref, thr_act, min_match=0.999):
+FLIP_LOG = []   # (label, flipped pixels, pixels) of every compare_trace call of the session
+
+
+def _report_flips(label, n_flip, n_pix):
+    """Every trace comparison states how many pixels' index lists actually differed ("print it and
+    assert a ceiling per config"); the lines also go to gpurun_out/parity_flips.txt when that directory exists."""
+    FLIP_LOG.append((label, int(n_flip), int(n_pix)))
+    line = f"[parity] {label}: {int(n_flip)} of {int(n_pix)} pixels have a different index list"
+    print(line)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        try:
+            with open(os.path.join(out, "parity_flips.txt"), "a") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
+
+
+def compare_trace(got, ref, thr_act, min_match=0.999, max_flips=None, label=None):
     """got / ref = (idx, len, act, dsd).  Top-K membership and the act < thr test are
     discontinuous, so a 1-ulp difference may flip a member at isolated pixels (SURVEY.md §7
     "selection discontinuities").  Require: the index lists agree exactly on >= min_match of the
     pixels; on those pixels every value agrees within TOL; on the others the disagreement must be
     explainable by a candidate within TOL of a decision boundary (threshold or K-th depth)."""
+    if label is None:
+        import inspect
+        label = inspect.stack()[1].function
     gi, gl, ga, gd = (np.asarray(x) for x in got)
     ri, rl, ra, rd = (np.asarray(x) for x in ref)
     K = gi.shape[-1]
     gi2, ri2 = gi.reshape(-1, K), ri.reshape(-1, K)
     same = (gi2 == ri2).all(axis=1)
     frac = same.mean() if same.size else 1.0
+    _report_flips(label, (~same).sum(), same.size)
     assert frac >= min_match, f"index lists agree on only {frac:.5f} of pixels"
+    if max_flips is not None:
+        assert (~same).sum() <= max_flips, f"{label}: {(~same).sum()} pixels flipped, ceiling {max_flips}"
     m = same.reshape(gi.shape[:-1])
     valid = (ri >= 0) & m[..., None]
     for name, g, r in (("len", gl, rl), ("act", ga, ra), ("dsd", gd, rd)):

@@ -21,11 +21,14 @@ import torch
 
 
 def _as_b2(v, B, device, dtype=torch.float32):
+    """focal_length / principal_point -> [B,2].  PyTorch3D reads a 1-D tensor of length B as one value per
+    camera (fx = fy); only a [.,2] shape (or a 1-D pair for a single camera) means (x, y)."""
     v = torch.as_tensor(v, dtype=dtype, device=device)
     if v.dim() == 0:
         v = v.reshape(1, 1)
     elif v.dim() == 1:
-        v = v.reshape(1, -1) if v.shape[0] == 2 else v.reshape(-1, 1)
+        per_camera = (v.shape[0] == B and B != 1) if B else False      # [B] scalars, including B == 2
+        v = v.reshape(-1, 1) if (per_camera or v.shape[0] != 2) else v.reshape(1, 2)
     if v.shape[-1] == 1:
         v = v.expand(-1, 2)
     if v.shape[0] != B:

@@ -1564,7 +1564,7 @@ trace_list_fwd_kernel(const float *__restrict__ mus, const float *__restrict__ i
                       const int P, const int H, const int W, const int K, const int BH,
                       const int BW, const int M, const int bin_size, const float thr_act,
                       int32_t *__restrict__ out_idx, float *__restrict__ out_len,
-                      float *__restrict__ out_act, float *__restrict__ out_dsd) {
+                      float *__restrict__ out_act, float *__restrict__ out_dsd, int32_t *__restrict__ out_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t *keys = reinterpret_cast<uint64_t *>(smem_raw);
   const int lane = threadIdx.x;
@@ -1615,6 +1615,7 @@ trace_list_fwd_kernel(const float *__restrict__ mus, const float *__restrict__ i
     out_act[pix * K + s] = oa;
     out_dsd[pix * K + s] = od;
   }
+  if (out_cnt != nullptr) out_cnt[pix] = cnt;
 }
 
 struct TraceWs {
@@ -1679,9 +1680,11 @@ static int launch_trace(const TraceWs &ws, const float *rays, int B, int N, int 
   constexpr int TH = (WAVES == 4) ? 16 : 8;
   const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + sizeof(TraceLds<T, ISO>) + VOGE_SWEEP_LDS_PAD;
   auto kern = trace_fwd_kernel<WAVES, ISO>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  {
+    static DynLdsCache cache;
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, cache);
+    if (rc) return rc;
+  }
   dim3 grid(((W + TW - 1) / TW) * ((H + TH - 1) / TH), B);
   hipLaunchKernelGGL(bin2_kernel, grid, dim3(256), 0, st, ws.bin_rec, ws.ell, rays, ws.bin_count, ws.bin_id, ws.bin_lb, ws.nstx,
                      ws.nstx * ws.nsty, N, H, W, TW, TH, ws.tl_count, ws.tl_id, ws.tl_lb, K, idx, len, act, dsd, cnt);
@@ -1741,6 +1744,8 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   if (!rays || !idx || !len || !act || !dsd || !workspace) return VOGE_ERR_BAD_ARG;
   if (N > 0 && (!mus || !isigmas)) return VOGE_ERR_BAD_ARG;
   if (workspace_bytes < voge_trace_workspace_bytes(B, N, H, W)) return VOGE_ERR_WORKSPACE;
+  // the top-K lists of one 8x8 tile must fit the CU's LDS: validated before anything is enqueued
+  if (sizeof(uint64_t) * (size_t)(K + 1) * 65 + 16 + sizeof(TraceLds<64, false>) > 160 * 1024) return VOGE_ERR_K_TOO_LARGE;
   hipStream_t st = (hipStream_t)stream;
   const int P = B * N;
   TraceWs ws;
@@ -1780,7 +1785,6 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
 #ifdef VOGE_FORCE_WAVES
   return launch_trace<VOGE_FORCE_WAVES, false>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
 #endif
-  if (sizeof(uint64_t) * (size_t)(K + 1) * 65 + 16 + sizeof(TraceLds<64, false>) > 160 * 1024) return VOGE_ERR_K_TOO_LARGE;
 #ifndef VOGE_NO_ISO_SWEEP
   if (iso_in) return launch_trace<1, true>(ws, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
 #endif
@@ -1808,7 +1812,7 @@ extern "C" int voge_trace_topk_fwd_iso(const float *mus, const float *a, const f
 extern "C" int voge_trace_topk_list_fwd(const float *mus, const float *isigmas, const float *rays,
                                         const int32_t *bin_points, int B, int P, int H, int W, int K,
                                         int BH, int BW, int M, int bin_size, float thr_act,
-                                        int32_t *idx, float *len, float *act, float *dsd,
+                                        int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
                                         voge_stream_t stream) {
   if (B < 0 || P < 0 || H < 0 || W < 0 || K <= 0 || BH <= 0 || BW <= 0 || M < 0 || bin_size <= 0)
     return VOGE_ERR_BAD_ARG;
@@ -1817,12 +1821,14 @@ extern "C" int voge_trace_topk_list_fwd(const float *mus, const float *isigmas, 
   if (!rays || !idx || !len || !act || !dsd || (M > 0 && !bin_points)) return VOGE_ERR_BAD_ARG;
   if (P > 0 && (!mus || !isigmas)) return VOGE_ERR_BAD_ARG;
   const size_t lds = sizeof(uint64_t) * (size_t)K * 64;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(trace_list_fwd_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  {
+    static DynLdsCache cache;
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(trace_list_fwd_kernel), lds, cache);
+    if (rc) return rc;
+  }
   dim3 grid(((W + 7) / 8) * ((H + 7) / 8), B);
   hipLaunchKernelGGL(trace_list_fwd_kernel, grid, dim3(64), lds, (hipStream_t)stream, mus, isigmas, rays,
-                     bin_points, P, H, W, K, BH, BW, M, bin_size, thr_act, idx, len, act, dsd);
+                     bin_points, P, H, W, K, BH, BW, M, bin_size, thr_act, idx, len, act, dsd, cnt);
   return launch_status();
 }
 

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "voge_hip.h"
 
 #define VOGE_WAVE 64
@@ -457,5 +459,21 @@ __device__ __forceinline__ float seg_sum_key(float x, const int key, const int l
 }
 
 inline int launch_status() { return (int)hipGetLastError(); }
+
+// The opt-in for more than 64 KB of dynamic LDS is a per-function, per-device attribute.  Set it when the request
+// grows -- not on every call, and not again inside a stream capture once a frame of this size has run.
+struct DynLdsCache {
+  std::atomic<size_t> set[16];
+  DynLdsCache() { for (auto &v : set) v.store(0); }
+};
+inline int ensure_dynamic_lds(const void *func, const size_t lds, DynLdsCache &cache) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+  if (dev >= 0 && lds <= cache.set[dev].load(std::memory_order_relaxed)) return 0;
+  const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  if (dev >= 0) cache.set[dev].store(lds, std::memory_order_relaxed);
+  return 0;
+}
 
 }  // namespace voge

@@ -9,11 +9,20 @@ import torch
 from . import _lib
 
 
+# torch._C._cuda_getCurrentRawStream / _cuda_getDevice / _cuda_setDevice are private (present in torch 1.8 ..
+# 2.10, the version this image ships); fall back to the public API when a build lacks them.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_dev = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+_set_dev = getattr(torch._C, "_cuda_setDevice", None) or torch.cuda.set_device
+
+
 def _stream():
     """Raw handle of the current stream of the current device.  (torch.cuda.current_stream() builds a
     Stream object and costs ~10 us a call -- several calls per frame on a path whose small frames are
     host-bound; the raw getter is what torch's own compiled code uses.)"""
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    if _raw_stream is not None:
+        return _raw_stream(_get_dev())
+    return torch.cuda.current_stream().cuda_stream
 
 
 class _on:
@@ -22,18 +31,18 @@ class _on:
     __slots__ = ("idx", "prev")
 
     def __init__(self, device):
-        self.idx = device.index if device.index is not None else torch._C._cuda_getDevice()
+        self.idx = device.index if device.index is not None else _get_dev()
         self.prev = -1
 
     def __enter__(self):
-        cur = torch._C._cuda_getDevice()
+        cur = _get_dev()
         if cur != self.idx:
             self.prev = cur
-            torch._C._cuda_setDevice(self.idx)
+            _set_dev(self.idx)
 
     def __exit__(self, *exc):
         if self.prev >= 0:
-            torch._C._cuda_setDevice(self.prev)
+            _set_dev(self.prev)
         return False
 
 
@@ -51,6 +60,44 @@ def _dev(t, dtype, name):
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+def _tag_index(sel_idx, cnt, n_index):
+    """Bookkeeping the trace leaves on the index tensor it returns:
+    voge_hit_count  (cnt [B,H,W] int32, torch version of sel_idx when it was written): lets aggregation() skip its
+                    pass over idx and the backwards skip empty slots.  A later in-place edit of sel_idx through
+                    torch (e.g. masking Gaussians out with -1) bumps the version and invalidates the count.
+    voge_index_bound  = number of Gaussians the indices address (B*N): merge_final's range assert
+                    (Aggregation.py:120) becomes a host-side comparison of two shapes."""
+    if cnt is not None:
+        sel_idx.voge_hit_count = (cnt, sel_idx._version)
+    sel_idx.voge_index_bound = int(n_index)
+
+
+def hit_count_of(sel_idx):
+    """The trace's per-pixel hit count if it still describes `sel_idx`, else None."""
+    tag = getattr(sel_idx, "voge_hit_count", None)
+    if tag is None:
+        return None
+    cnt, version = tag
+    if version != sel_idx._version or cnt.shape != sel_idx.shape[:-1] or cnt.device != sel_idx.device:
+        return None
+    return cnt
+
+
+def check_index_range(idx, n_attr):
+    """merge_final's `assert vert_attr.shape[0] > vert_assign.max()` (Aggregation.py:120).  Indices written by
+    the trace carry their range (voge_index_bound = B*N): a host comparison.  Any other index tensor is checked
+    on the device as the reference does (a synchronising reduction), except during stream capture."""
+    bound = getattr(idx, "voge_index_bound", None)
+    if bound is not None:
+        if n_attr < bound:
+            raise AssertionError(
+                f"vert_attr has {n_attr} rows but the fragments index {bound} Gaussians (a batch of B views addresses "
+                f"rows b*N+n: tile the attributes over the batch, as the reference requires -- Aggregation.py:120)")
+        return
+    if idx.numel() and not torch.cuda.is_current_stream_capturing():
+        assert n_attr > int(idx.max()), "vert_attr.shape[0] must exceed vert_assign.max() (Aggregation.py:120)"
 
 
 class _RayTraceVoGE(torch.autograd.Function):
@@ -81,7 +128,9 @@ class _RayTraceVoGE(torch.autograd.Function):
         sel_len = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
         sel_act = torch.empty_like(sel_len)
         sel_dsd = torch.empty_like(sel_len)
-        cnt = None
+        # per-pixel hit count: tells the backward (and aggregation) which slots are filled, so the index tensor
+        # may later be rewritten in place by merge_final (-1 -> 0, Aggregation.py:131) without a defensive copy
+        cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
         with _on(dev):
             if bin_points is not None and bin_points.dtype in (torch.int32, torch.int64):
                 bins = _dev(bin_points, torch.int32, "bin_points")
@@ -89,7 +138,7 @@ class _RayTraceVoGE(torch.autograd.Function):
                 rc = lib.voge_trace_topk_list_fwd(
                     _p(mus_c), _p(isg_c), _p(rays_c), _p(bins), B, P, H, W, K, bins.shape[1], bins.shape[2],
                     bins.shape[3], int(bin_size), float(thr_act), _p(sel_idx), _p(sel_len), _p(sel_act),
-                    _p(sel_dsd), _stream())
+                    _p(sel_dsd), _p(cnt), _stream())
                 _lib.check(rc, "voge_trace_topk_list_fwd")
             else:
                 assert B > 0 and P % B == 0, "mus must hold B*N rows"
@@ -97,23 +146,14 @@ class _RayTraceVoGE(torch.autograd.Function):
                 fwd = None if bin_points is None else _dev(bin_points, torch.float32, "cam_fwd")
                 nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
                 ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
-                cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
                 rc = lib.voge_trace_topk_fwd(
                     _p(mus_c), _p(isg_c), _p(rays_c), _p(fwd), B, N, H, W, K, float(thr_act), _p(ws), nbytes,
                     _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _p(cnt), _stream())
                 _lib.check(rc, "voge_trace_topk_fwd")
-        if cnt is None:
-            # explicit bin lists: the backward recognises empty slots by idx == -1, so the index tensor
-            # must stay untouched until then (autograd's version check enforces it)
-            ctx.save_for_backward(mus_c, isg_c, rays_c, sel_idx)
-        else:
-            # the per-pixel hit count tells the backward which slots are filled, so the index tensor
-            # may later be rewritten in place by merge_final (-1 -> 0) without a defensive copy
-            ctx.save_for_backward(mus_c, isg_c, rays_c)
-            ctx.sel_idx = sel_idx
+        ctx.save_for_backward(mus_c, isg_c, rays_c)
+        ctx.sel_idx = sel_idx
         ctx.cnt = cnt
-        if cnt is not None:
-            sel_idx.voge_hit_count = cnt     # lets aggregation() skip its own pass over idx
+        _tag_index(sel_idx, cnt, P)
         ctx.mark_non_differentiable(sel_idx)
         ctx.set_materialize_grads(False)
         return sel_idx, sel_len, sel_act, sel_dsd
@@ -121,11 +161,8 @@ class _RayTraceVoGE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_sel_idx, grad_sel_len, grad_sel_act, grad_sel_dsd):
         lib = _lib.load()
-        if ctx.cnt is None:
-            mus, isg, rays, sel_idx = ctx.saved_tensors
-        else:
-            mus, isg, rays = ctx.saved_tensors
-            sel_idx = ctx.sel_idx
+        mus, isg, rays = ctx.saved_tensors
+        sel_idx = ctx.sel_idx
         B, H, W, K = sel_idx.shape
         P = mus.shape[0]
         zeros = None
@@ -184,8 +221,7 @@ class _RayTraceVoGEIso(torch.autograd.Function):
         ctx.save_for_backward(mus_c, a_c, rays_c)
         ctx.sel_idx = sel_idx      # may later be rewritten in place by merge_final; cnt marks the filled slots
         ctx.cnt = cnt
-        if cnt is not None:
-            sel_idx.voge_hit_count = cnt     # lets aggregation() skip its own pass over idx
+        _tag_index(sel_idx, cnt, P)
         ctx.mark_non_differentiable(sel_idx)
         ctx.set_materialize_grads(False)
         return sel_idx, sel_len, sel_act, sel_dsd
@@ -254,7 +290,7 @@ class _RayTraceVoGEIsoView(torch.autograd.Function):
         _lib.check(rc, "voge_trace_topk_fwd_iso_view")
         ctx.save_for_backward(v_c, s_c, o_c, rays_c)
         ctx.sel_idx, ctx.cnt, ctx.mode, ctx.shared = sel_idx, cnt, int(sigma_mode), shared
-        sel_idx.voge_hit_count = cnt
+        _tag_index(sel_idx, cnt, B * N)
         ctx.mark_non_differentiable(sel_idx)
         ctx.set_materialize_grads(False)
         return sel_idx, sel_len, sel_act, sel_dsd
@@ -302,9 +338,8 @@ class _Composite(torch.autograd.Function):
         idx = _dev(sel_idx, torch.int32, "sel_idx")
         # the trace forward leaves its per-pixel hit count on the index tensor it returns
         # (voge_hit_count): valid_num then needs no pass over idx
-        cnt = getattr(sel_idx, "voge_hit_count", None)
-        if cnt is not None and (cnt.shape != idx.shape[:-1] or cnt.device != idx.device):
-            cnt = None
+        # (ignored when sel_idx was edited through torch since: hit_count_of compares the version counter)
+        cnt = hit_count_of(sel_idx) if idx is sel_idx else None
         act = _dev(sel_act, torch.float32, "sel_act")
         ln = _dev(sel_len, torch.float32, "sel_len")
         dsd = _dev(sel_dsd, torch.float32, "sel_dsd")
@@ -357,6 +392,7 @@ class _Merge(torch.autograd.Function):
         K = idx.shape[-1]
         npix = idx.numel() // max(K, 1)
         Nattr, C = attr_c.shape
+        check_index_range(idx, Nattr)
         out = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
         with _on(idx.device):
             rc = lib.voge_merge_fwd(_p(attr_c), _p(idx), _p(w), _p(vn), npix, K, C, Nattr, 1, _p(out), _stream())
@@ -442,6 +478,7 @@ class _Shade(torch.autograd.Function):
         npix = idx.numel() // max(K, 1)
         Nattr, C = attr_c.shape
         assert C <= 4 and bg_c.numel() == C
+        check_index_range(idx, Nattr)
         rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
         img = torch.empty_like(rgb)
         wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
