@@ -267,7 +267,7 @@ def main():
             wsum = torch.empty(rgb.shape[:-1], dtype=torch.float32, device=rgb.device)
             P = lambda x: x.data_ptr()
             calls = {
-                "trace_fwd": lambda: trace_fwd_fn(P(mus), P(isg), P(rays), None, 1, N, H, W, K, thr_act, P(ws),
+                "trace_fwd": lambda: trace_fwd_fn(P(mus), P(isg), P(rays), None, P(ops.cones_of(rays, 1, H, W)), 1, N, H, W, K, thr_act, P(ws),
                                                              ws.numel(), P(o_i), P(o_l), P(o_a), P(o_d), P(o_c), st),
                 "composite_fwd": lambda: lib.voge_composite_fwd(None, P(ops.hit_count_of(sel[0])), P(sel[2]), P(sel[1]), P(sel[3]), 1.0, npix, K,
                                                                 P(g3[0]), P(vn), st),
@@ -320,13 +320,13 @@ def main():
             st = torch.cuda.current_stream().cuda_stream
             P = lambda x: x.data_ptr()
             if iso:
-                fn = lambda: lib.voge_trace_topk_fwd_iso_view(P(gm.verts), P(gm.sigmas), P(origin), 1, 1, P(rays_b), None, 1, N, h, W, K,
+                fn = lambda: lib.voge_trace_topk_fwd_iso_view(P(gm.verts), P(gm.sigmas), P(origin), 1, 1, P(rays_b), None, P(ops.cones_of(rays_b, 1, h, W)), 1, N, h, W, K,
                                                               thr_act, P(ws), ws.numel(), *[P(o) for o in outs], P(o_c), st)
             else:
                 from voge_amd.Aggregation import expend_sigma
                 mus = (gm.verts[None] - origin[:, None]).reshape(-1, 3).contiguous()
                 isg = (2 * expend_sigma(gm.sigmas)).contiguous()
-                fn = lambda: lib.voge_trace_topk_fwd(P(mus), P(isg), P(rays_b), None, 1, N, h, W, K, thr_act, P(ws), ws.numel(),
+                fn = lambda: lib.voge_trace_topk_fwd(P(mus), P(isg), P(rays_b), None, P(ops.cones_of(rays_b, 1, h, W)), 1, N, h, W, K, thr_act, P(ws), ws.numel(),
                                                      *[P(o) for o in outs], P(o_c), st)
             t_ms = time_kernel(fn)
             nb = stage_bytes(N, h * W, K, iso=iso)["trace_fwd"]

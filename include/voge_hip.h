@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOGE_ABI_VERSION 1
+#define VOGE_ABI_VERSION 2
 
 #define VOGE_ERR_BAD_ARG (-1)        /* null pointer / non-positive size */
 #define VOGE_ERR_WORKSPACE (-2)      /* workspace smaller than voge_trace_workspace_bytes() */
@@ -71,9 +71,12 @@ size_t voge_trace_workspace_bytes(int B, int N, int H, int W);
  * cam_fwd: NULL, or [B,3] unit view axis in the rays' frame: Gaussians with mu.fwd < 0
  * are skipped, which is the candidate rule of the reference's coarse stage
  * (rasterize_coarse.cu:35, "skip z<0") used when max_points_per_bin != -1.
+ * cones: NULL, or the bounding cones of the rays' 32x32-pixel super-tiles that voge_rays_fwd /
+ * voge_ray_cones produced for exactly this `rays` tensor (voge_cones_floats(B,H,W) floats); they
+ * only steer the conservative candidate culling.  NULL costs one more launch that derives them.
  */
 int voge_trace_topk_fwd(const float *mus, const float *isigmas, const float *rays,
-                        const float *cam_fwd, int B, int N, int H, int W, int K,
+                        const float *cam_fwd, const float *cones, int B, int N, int H, int W, int K,
                         float thr_act, void *workspace, size_t workspace_bytes,
                         int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
                         voge_stream_t stream);
@@ -124,7 +127,7 @@ size_t voge_trace_bwd_workspace_bytes(int P);
  * disappears.  workspace of the backward: >= voge_trace_bwd_iso_workspace_bytes(P).
  */
 int voge_trace_topk_fwd_iso(const float *mus, const float *a, const float *rays,
-                            const float *cam_fwd, int B, int N, int H, int W, int K,
+                            const float *cam_fwd, const float *cones, int B, int N, int H, int W, int K,
                             float thr_act, void *workspace, size_t workspace_bytes,
                             int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
                             voge_stream_t stream);
@@ -146,10 +149,10 @@ size_t voge_trace_bwd_iso_workspace_bytes(int P);
  * a caller that needs it (camera pose optimisation) uses the plain calls.  Workspaces as above with P = B*N.
  */
 int voge_trace_topk_fwd_iso_view(const float *verts, const float *sigmas, const float *origin, int shared,
-                                 int sigma_mode, const float *rays, const float *cam_fwd, int B, int N, int H,
-                                 int W, int K, float thr_act, void *workspace, size_t workspace_bytes,
-                                 int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
-                                 voge_stream_t stream);
+                                 int sigma_mode, const float *rays, const float *cam_fwd, const float *cones,
+                                 int B, int N, int H, int W, int K, float thr_act, void *workspace,
+                                 size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
+                                 int32_t *cnt, voge_stream_t stream);
 int voge_trace_bwd_iso_view(const float *verts, const float *sigmas, const float *origin, int shared,
                             int sigma_mode, const float *rays, const int32_t *idx, const int32_t *cnt,
                             const float *g_len, const float *g_act, const float *g_dsd, int B, int N, long nrows,
@@ -255,9 +258,16 @@ int voge_shade_bwd(const float *attr, const int32_t *idx, const float *weight,
  *   origin = -T @ R^-1          (row vectors, X_view = X_world @ R + T).
  * R [B,3,3], T [B,3], focal [B,2], pp [B,2] (principal point, pixels).  Renders image rows
  * row0 .. row0+h-1 (a pixel-row band): rays [B,h,W,3], origin [B,3].
+ * cones: NULL, or voge_cones_floats(B,h,W) floats receiving the bounding cone (axis, cos, sin of the
+ * half angle, flags) of every 32x32-pixel super-tile of the band: what voge_trace_topk_fwd*'s
+ * `cones` argument takes.  They come out of the same arithmetic as the rays, at no extra launch.
  */
 int voge_rays_fwd(const float *R, const float *T, const float *focal, const float *pp, int B,
-                  int row0, int h, int W, float *rays, float *origin, voge_stream_t stream);
+                  int row0, int h, int W, float *rays, float *origin, float *cones, voge_stream_t stream);
+
+/* The same cones from any rays [B,H,W,3] tensor (no counterpart in the reference: culling aid). */
+size_t voge_cones_floats(int B, int H, int W);
+int voge_ray_cones(const float *rays, int B, int H, int W, float *cones, voge_stream_t stream);
 
 /*
  * Backward of voge_rays_fwd: g_rays [B,h,W,3] (may be NULL) and g_origin [B,3] (may be NULL) ->

@@ -54,7 +54,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_version_errors_and_sizes_without_gpu(lib):
-    assert lib.voge_abi_version() == 1
+    assert lib.voge_abi_version() == 2
     assert lib.voge_error_string(0) == b"success"
     assert b"K exceeds" in lib.voge_error_string(-3)
     assert b"workspace" in lib.voge_error_string(-2)
@@ -64,7 +64,8 @@ def test_version_errors_and_sizes_without_gpu(lib):
     assert lib.voge_trace_bwd_workspace_bytes(1000) == 1000 * 112
     # argument validation happens before any HIP call
     assert lib.voge_composite_fwd(None, None, None, None, None, 1.0, 10, 0, None, None, None) == -1
-    assert lib.voge_trace_topk_fwd(None, None, None, None, 1, 10, 8, 8, 1000, 4.6, None, 0, None, None, None, None, None, None) == -3
+    assert lib.voge_trace_topk_fwd(None, None, None, None, None, 1, 10, 8, 8, 1000, 4.6, None, 0, None, None, None, None, None, None) == -3
+    assert lib.voge_cones_floats(2, 65, 33) == 2 * 3 * 2 * 8
 
 
 def test_missing_library_fails_loudly(monkeypatch):

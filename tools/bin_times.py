@@ -1,4 +1,4 @@
-"""Phase timestamps of the bin kernel (debug build: tools/tune_variants.sh bt:"-DVOGE_BIN_TIMES").
+"""Phase timestamps of the two bin kernels (debug build: tools/tune_variants.sh bt:"-DVOGE_BIN_TIMES").
 usage on the GPU box: VOGE_HIP_LIB=build/variants/bt.so python tools/bin_times.py [config]"""
 import ctypes, sys
 import numpy as np
@@ -20,14 +20,21 @@ with torch.no_grad():
     for _ in range(3):
         renderer(gm, R=R, T=T)
 torch.cuda.synchronize()
+lib = ctypes.CDLL(_lib.LIB_PATH)
 nst = ((W + 31) // 32) * ((H + 31) // 32)
-n = min(nst, 1024)
-buf = (ctypes.c_ulonglong * (8 * n))()
-ctypes.CDLL(_lib.LIB_PATH).voge_debug_bin_times(buf, n)
-t = np.array(list(buf), dtype=np.float64).reshape(n, 8) * 0.01     # us (100 MHz)
-names = ["scan (ids, records, tests, LDS append)", "min/max + reach reductions", "histogram", "bucket scan", "scatter", "output (gather + stores)"]
-d = np.diff(t[:, :7], axis=1)
-print("super-tiles", n, " kernel span", round(t[:, 6].max() - t[:, 0].min(), 1), "us;  per workgroup mean / max (us):")
-for i, nm in enumerate(names):
-    print(f"  {nm:42s} {d[:, i].mean():6.2f} {d[:, i].max():6.2f}")
-print(f"  {'total':42s} {(t[:, 6] - t[:, 0]).mean():6.2f} {(t[:, 6] - t[:, 0]).max():6.2f}   start spread {t[:, 0].max() - t[:, 0].min():.2f}")
+nreg = ((W + 127) // 128) * ((H + 127) // 128) * 16
+for which, n, names in ((0, min(nreg, 1024), ["first loads + region cone", "region test + compaction (round 1)", "child tests + id stores", "(barrier)", "(further rounds)"]),
+                        (1, min(nst * 4, 1024), ["gather + keys", "reduce + hist + scan", "scatter (+flag suffix)", "tile filter (all waves)", "slots + spill + sentinel tiles"])):
+    buf = (ctypes.c_ulonglong * (8 * n))()
+    lib.voge_debug_bin_times(buf, which, n)
+    t = np.array(list(buf), dtype=np.float64).reshape(n, 8) * 0.01     # us (100 MHz)
+    k = len(names) + 1
+    d = np.diff(t[:, :k], axis=1)
+    print(["binA", "binB"][which], "workgroups", n, " kernel span", round(t[:, k - 1].max() - t[:, 0].min(), 1), "us;  per workgroup mean / max (us):")
+    for i, nm in enumerate(names):
+        print(f"  {nm:42s} {d[:, i].mean():6.2f} {d[:, i].max():6.2f}")
+    tot = t[:, k - 1] - t[:, 0]
+    print(f"  {'total':42s} {tot.mean():6.2f} {tot.max():6.2f}   start spread {t[:, 0].max() - t[:, 0].min():.2f}; first stamp after kernel start")
+    if which == 1:
+        o = np.argsort(-tot)[:5]
+        print("  slowest workgroups:", [(int(i), [round(float(x), 1) for x in d[i]]) for i in o])

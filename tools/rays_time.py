@@ -18,6 +18,6 @@ for H in (512, 1024):
     f = torch.tensor([[600.0, 600.0]], device=dev); pp = torch.tensor([[H/2, H/2]], device=dev)
     st = torch.cuda.current_stream().cuda_stream
     e0.record()
-    for _ in range(20): lib.voge_rays_fwd(Rc.data_ptr(), Tc.data_ptr(), f.data_ptr(), pp.data_ptr(), 1, 0, H, H, rays.data_ptr(), o.data_ptr(), st)
+    for _ in range(20): lib.voge_rays_fwd(Rc.data_ptr(), Tc.data_ptr(), f.data_ptr(), pp.data_ptr(), 1, 0, H, H, rays.data_ptr(), o.data_ptr(), None, st)
     e1.record(); torch.cuda.synchronize()
     print(H, "voge_rays_fwd us", e0.elapsed_time(e1) * 1000 / 20)

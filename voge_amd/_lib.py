@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VOGE_HIP_LIB points at another build of the same ABI (kernel tuning variants)
 LIB_PATH = os.environ.get("VOGE_HIP_LIB") or os.path.join(_HERE, "libvoge_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_void_p = ctypes.c_void_p
 _c_int = ctypes.c_int
@@ -22,16 +22,16 @@ SIGNATURES = {
     "voge_abi_version": (_c_int, []),
     "voge_error_string": (ctypes.c_char_p, [_c_int]),
     "voge_trace_workspace_bytes": (_c_size_t, [_c_int] * 4),
-    "voge_trace_topk_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_float, _c_void_p, _c_size_t]
+    "voge_trace_topk_fwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_float, _c_void_p, _c_size_t]
                             + [_c_void_p] * 6),
     "voge_trace_topk_list_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 9 + [_c_float] + [_c_void_p] * 6),
     "voge_trace_bwd": (_c_int, [_c_void_p] * 8 + [_c_int, _c_long, _c_int, _c_int, _c_void_p, _c_size_t] + [_c_void_p] * 4),
     "voge_trace_bwd_workspace_bytes": (_c_size_t, [_c_int]),
-    "voge_trace_topk_fwd_iso": (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_float, _c_void_p, _c_size_t]
+    "voge_trace_topk_fwd_iso": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_float, _c_void_p, _c_size_t]
                                 + [_c_void_p] * 6),
     "voge_trace_bwd_iso": (_c_int, [_c_void_p] * 8 + [_c_int, _c_long, _c_int, _c_int, _c_void_p, _c_size_t] + [_c_void_p] * 4),
     "voge_trace_bwd_iso_workspace_bytes": (_c_size_t, [_c_int]),
-    "voge_trace_topk_fwd_iso_view": (_c_int, [_c_void_p] * 3 + [_c_int] * 2 + [_c_void_p] * 2 + [_c_int] * 5
+    "voge_trace_topk_fwd_iso_view": (_c_int, [_c_void_p] * 3 + [_c_int] * 2 + [_c_void_p] * 3 + [_c_int] * 5
                                      + [_c_float, _c_void_p, _c_size_t] + [_c_void_p] * 6),
     "voge_trace_bwd_iso_view": (_c_int, [_c_void_p] * 3 + [_c_int] * 2 + [_c_void_p] * 6
                                 + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_void_p, _c_size_t] + [_c_void_p] * 4),
@@ -42,7 +42,9 @@ SIGNATURES = {
     "voge_blend_fwd": (_c_int, [_c_void_p] * 3 + [_c_float, _c_long, _c_int, _c_int] + [_c_void_p] * 3),
     "voge_shade_fwd": (_c_int, [_c_void_p] * 5 + [_c_float, _c_long, _c_int, _c_int, _c_long, _c_int] + [_c_void_p] * 5),
     "voge_shade_bwd": (_c_int, [_c_void_p] * 7 + [_c_float, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_long] + [_c_void_p] * 3),
-    "voge_rays_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p] * 3),
+    "voge_rays_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p] * 4),
+    "voge_cones_floats": (_c_size_t, [_c_int] * 3),
+    "voge_ray_cones": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "voge_rays_bwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_void_p] * 6),
     "voge_ray_dense_fwd": (_c_int, [_c_void_p] * 3 + [_c_int, _c_long] + [_c_void_p] * 4),
     "voge_ray_dense_bwd": (_c_int, [_c_void_p] * 6 + [_c_int, _c_long] + [_c_void_p] * 4),

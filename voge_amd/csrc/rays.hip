@@ -34,10 +34,39 @@ __device__ __forceinline__ Mat3 inv3(const float *R) {
 __global__ void __launch_bounds__(256)
 rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const float *__restrict__ focal,
                 const float *__restrict__ pp, const int row0, const int h, const int W,
-                float *__restrict__ rays, float *__restrict__ origin) {
+                float *__restrict__ rays, float *__restrict__ origin, const int ray_blocks,
+                ConeRec *__restrict__ cones /* NULL | [B][nsty][nstx] */) {
   const int b = blockIdx.y;
   const Mat3 Ri = inv3(R + 9 * b);
   const float fx = focal[2 * b], fy = focal[2 * b + 1], px = pp[2 * b], py = pp[2 * b + 1];
+  if ((int)blockIdx.x >= ray_blocks) {
+    // The workgroups behind the ray blocks: one per 32x32-pixel super-tile, its bounding cone for the trace's
+    // binning (voge_trace_topk_fwd*'s `cones`).  The directions are recomputed with the arithmetic below (no loads),
+    // so the cones cost the frame nothing: the trace otherwise reads every ray once more to derive them.
+    __shared__ float red[4 * 8];
+    const int nstx = (W + kST - 1) / kST;
+    const int st = (int)blockIdx.x - ray_blocks;
+    const int x0 = (st % nstx) * kST, y0 = (st / nstx) * kST;
+    const int ly = threadIdx.x >> 3, lx0 = (threadIdx.x & 7) * 4;
+    const float ifx = 1.0f / fx, ify = 1.0f / fy;
+    float cx[4], cy[4], cz[4];
+    unsigned has = 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = x0 + lx0 + u, i = y0 + ly;
+      has |= (j < W && i < h) ? (1u << u) : 0u;
+      const float vx = (px - ((float)j + 0.5f)) * ifx;
+      const float vy = (py - ((float)(row0 + i) + 0.5f)) * ify;
+      const float wx = vx * Ri.m[0] + vy * Ri.m[3] + Ri.m[6];
+      const float wy = vx * Ri.m[1] + vy * Ri.m[4] + Ri.m[7];
+      const float wz = vx * Ri.m[2] + vy * Ri.m[5] + Ri.m[8];
+      const float inv = __builtin_amdgcn_rsqf(wx * wx + wy * wy + wz * wz);
+      cx[u] = wx * inv; cy[u] = wy * inv; cz[u] = wz * inv;
+    }
+    const ConeRec rec = block_cone256<4>(cx, cy, cz, has, min(kST, W - x0) * min(kST, h - y0), red);
+    if (threadIdx.x == 0) cones[(size_t)b * (gridDim.x - ray_blocks) + st] = rec;
+    return;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // (static indices only: a lane-dependent index into Ri makes the compiler park the matrix in LDS)
     const float *t = T + 3 * b;
@@ -51,7 +80,7 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
   // four consecutive pixels per thread: 48 contiguous bytes leave as three 16-byte stores
   const int n4 = (n + 3) >> 2;
   const bool aligned = (reinterpret_cast<uintptr_t>(ob) & 15) == 0;
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += gridDim.x * blockDim.x) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += ray_blocks * blockDim.x) {
     float o[12];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -76,6 +105,26 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
       for (int u = 0; u < 4 && 4 * q + u < n; ++u) { ob[(size_t)(4 * q + u) * 3] = o[3 * u]; ob[(size_t)(4 * q + u) * 3 + 1] = o[3 * u + 1]; ob[(size_t)(4 * q + u) * 3 + 2] = o[3 * u + 2]; }
     }
   }
+}
+
+// The same cones from a ray tensor the caller built any other way (the trace's fallback when it is given none).
+__global__ void __launch_bounds__(256)
+cones_kernel(const float *__restrict__ rays, const int H, const int W, ConeRec *__restrict__ cones) {
+  __shared__ float red[4 * 8];
+  const int b = blockIdx.y, nstx = (W + kST - 1) / kST;
+  const int x0 = ((int)blockIdx.x % nstx) * kST, y0 = ((int)blockIdx.x / nstx) * kST;
+  const int ly = threadIdx.x >> 3, lx0 = (threadIdx.x & 7) * 4;
+  float cx[4], cy[4], cz[4];
+  unsigned has = 0u;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = x0 + lx0 + u, i = y0 + ly;
+    has |= (j < W && i < H) ? (1u << u) : 0u;
+    const float *r = rays + (((size_t)b * H + min(i, H - 1)) * W + min(j, W - 1)) * 3;
+    cx[u] = r[0]; cy[u] = r[1]; cz[u] = r[2];
+  }
+  const ConeRec rec = block_cone256<4>(cx, cy, cz, has, min(kST, W - x0) * min(kST, H - y0), red);
+  if (threadIdx.x == 0) cones[(size_t)b * gridDim.x + blockIdx.x] = rec;
 }
 
 // Backward, stage 1: per-batch sums over pixels.  part[b][0..8] = d_view^T g_dw (gradient of
@@ -166,7 +215,7 @@ __global__ void rays_bwd_finish_kernel(const float *__restrict__ R, const float 
 using namespace voge;
 
 extern "C" int voge_rays_fwd(const float *R, const float *T, const float *focal, const float *pp, int B,
-                             int row0, int h, int W, float *rays, float *origin, voge_stream_t stream) {
+                             int row0, int h, int W, float *rays, float *origin, float *cones, voge_stream_t stream) {
   if (B < 0 || h < 0 || W < 0) return VOGE_ERR_BAD_ARG;
   if (B == 0) return 0;
   if (!R || !T || !focal || !pp || !origin || ((size_t)h * W > 0 && !rays)) return VOGE_ERR_BAD_ARG;
@@ -174,8 +223,23 @@ extern "C" int voge_rays_fwd(const float *R, const float *T, const float *focal,
   int blocks = ((n + 3) / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(rays_fwd_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, R, T, focal, pp, row0, h, W,
-                     rays, origin);
+  const int nst = (cones != nullptr && n > 0) ? ((W + kST - 1) / kST) * ((h + kST - 1) / kST) : 0;
+  hipLaunchKernelGGL(rays_fwd_kernel, dim3(blocks + nst, B), dim3(256), 0, (hipStream_t)stream, R, T, focal, pp, row0, h, W,
+                     rays, origin, blocks, reinterpret_cast<ConeRec *>(cones));
+  return launch_status();
+}
+
+extern "C" size_t voge_cones_floats(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return (size_t)B * ((W + kST - 1) / kST) * ((H + kST - 1) / kST) * (sizeof(ConeRec) / sizeof(float));
+}
+
+extern "C" int voge_ray_cones(const float *rays, int B, int H, int W, float *cones, voge_stream_t stream) {
+  if (B < 0 || H < 0 || W < 0) return VOGE_ERR_BAD_ARG;
+  if ((size_t)B * H * W == 0) return 0;
+  if (!rays || !cones) return VOGE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cones_kernel, dim3(((W + kST - 1) / kST) * ((H + kST - 1) / kST), B), dim3(256), 0, (hipStream_t)stream,
+                     rays, H, W, reinterpret_cast<ConeRec *>(cones));
   return launch_status();
 }
 

@@ -1,0 +1,724 @@
+// Candidate binning in front of the fine-trace sweep (gfx950): two launches.
+//
+//   binA  (one 1024-thread workgroup per 128x128-pixel REGION and Gaussian slice): the region's cone as the
+//         conservative union of its <= 16 super-tile cones (32x32 pixels each; the cones come with the rays --
+//         voge_rays_fwd / voge_ray_cones), then every Gaussian of the slice against the region cone and -- survivors
+//         only, compacted in LDS -- against the 16 child cones.  Survivors are appended to per-(super-tile, slice)
+//         SEGMENTS whose positions come from ballots and in-wave prefix sums: no global atomics, no zero-initialised
+//         counters, and the list order is a pure function of the inputs.  The scalar-sigma entry points also derive
+//         the per-Gaussian records here (ISO_PREP), so the chain in front of the sweep is binA -> binB.
+//   binB  (one 1024-thread workgroup per super-tile): gathers the <= 16 segments, orders the survivors front to
+//         back (counting sort on a depth key, LDS), and then each of its 16 waves filters the ordered list --
+//         still in LDS, records included -- with the bounding cone of its own 8x8-pixel sweep tile and writes the
+//         tile's candidate list.  It also fixes the sweep's launch order without any exchange: super-tiles by
+//         descending candidate count (every workgroup ranks itself against the segment counts of all), tiles inside
+//         a super-tile by descending list length.
+//
+// What this replaces (round 1): prep_cone -> bin0 -> bin -> bin2 -> tile_order, five dependent launches
+// (75 us at 50k Gaussians / 512^2) that exchanged region lists, super-tile lists and their records through HBM.
+// Both tests are conservative (cone_keep / cone_keep_ell, voge_common.h), so the sweep's result equals the
+// brute-force "-1" candidate list of VoGE/RayTracing.py:22-26.
+#pragma once
+#include "voge_common.h"
+
+namespace voge {
+
+constexpr int kST0 = 128;          // region edge
+constexpr int kCh = kST0 / kST;    // super-tiles per region side
+constexpr int kBinThreads = 1024;
+constexpr int kParts = 16;         // Gaussian slices per region (chunks of 1024 Gaussians dealt round-robin)
+constexpr int kSegCap = 512;       // entries of one (super-tile, slice) segment (ids + their cull records)
+constexpr int kTileCap = 2048;     // entries of a sweep tile's list
+constexpr int kTilesPerBin = (kST / 8) * (kST / 8);   // sweep tiles (8x8 pixels) of a super-tile
+constexpr int kRankMaxBins = 4096;  // beyond this many super-tiles (a batch of big frames) the sweep keeps the spatial order
+static_assert(kCh * kCh == kBinThreads / 64, "one wave per super-tile of a region / per sweep tile of a super-tile");
+
+// Depth key of a candidate for the front-to-back order of a bin: kappa = +|mu| for a Gaussian in
+// front of the camera, -|mu| otherwise (behind it, or too close / cone too wide to tell), and
+// -inf for an unbounded reach.  For every UNIT ray d of the cone that can hit the Gaussian
+// (its line passes within `reach` R of mu): len = mu.d - v.d with |v| <= R, hence
+//   front (|mu| > 4R, mu.axis > 0): len >= sqrt(|mu|^2 - R^2) - R >= kappa - 1.13 R
+//   otherwise                     : len >= -|mu| - R               = kappa - R
+// so  kappa - 1.13 * Rmax  (Rmax = largest finite reach in the bin) is a lower bound of len that
+// is MONOTONE in kappa -- what the sweep's early exit needs.
+__device__ __forceinline__ float depth_key(const float4 c, const Cone &k) {
+  const float nm = sqrtf(fmaf(c.z, c.z, fmaf(c.y, c.y, c.x * c.x)));
+  const float R = c.w;
+  if (!(R < 3e38f) || !(nm < 3e38f)) return -INFINITY;
+  float kappa = -nm;
+  if (k.ok && k.cs >= 0.5f && nm > 4.0f * R) {
+    const float p = fmaf(c.z, k.az, fmaf(c.y, k.ay, c.x * k.ax));
+    if (p > 0.0f) kappa = nm;
+  }
+  return kappa;
+}
+
+// The cull record of an isotropic Gaussian (A = a I) from (centre, a): the fp32 form of prep_one's reach with the
+// margins doubled to cover the fp32 rounding of the square root and the division (a conservative reach only ever
+// keeps more candidates).  act = a |v|^2 >= a dist^2, so a hit needs dist^2 < thr_act / a.
+__device__ __forceinline__ float4 iso_cull_record(const float mx, const float my, const float mz, const float a,
+                                                  const float thr_act) {
+  float reach = INFINITY;
+  if (a > 0.0f && a < 3e38f) {
+    const float nm = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx)));
+    const float r = sqrtf(fmaxf(thr_act, 0.0f) / (a * (1.0f - 4e-6f))) * (1.0f + 2e-5f) + 2e-5f * nm + 1e-30f;
+    reach = r;
+    if (!(reach >= 0.0f)) reach = INFINITY;  // NaN guard
+    // the lowest mantissa bit of a finite reach says "has an ellipsoid record": never for A = a I (round up to even)
+    if (reach < 3e38f) reach = __uint_as_float((__float_as_uint(reach) + 1u) & ~1u);
+  }
+  return make_float4(mx, my, mz, reach);
+}
+
+#ifdef VOGE_BIN_TIMES   // debug builds (tools/bin_times.py): per-workgroup phase timestamps of binA (0) and binB (1)
+__device__ unsigned long long g_bin_times[2][1024 * 8];
+__device__ unsigned long long g_bin_wave[1024 * 16 * 4];   // binB: per (workgroup, wave): filter start, filter end, registered, done; count in [3] low bits
+#define BIN_WTS(k) \
+  if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 1024) g_bin_wave[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 4 + (k)] = wall_clock64()
+#define BIN_TS(which, k) \
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) g_bin_times[which][8 * blockIdx.x + (k)] = wall_clock64()
+#else
+#define BIN_TS(which, k)
+#define BIN_WTS(k)
+#endif
+
+// ------------------------------------------------------------------------------------------
+// binA
+// ------------------------------------------------------------------------------------------
+constexpr int kRoundChunks = 4;                           // 1024-Gaussian chunks a workgroup tests per round
+constexpr int kRoundCap = kRoundChunks * kBinThreads;     // candidates (hence at most survivors) of a round
+
+struct BinALds {
+  float4 srec[kRoundCap];      // survivors of the region test, this round: record ...
+  int sid[kRoundCap];          // ... and Gaussian id, in (chunk, wave, lane) order
+  ConeRec child[kCh * kCh];
+  ConeRec region;
+  int cnt0[kRoundChunks][16];  // [chunk][wave] survivors of the region test -> exclusive prefix
+  int base[kCh * kCh];         // entries written so far per child
+  int nS;
+};
+
+// Gaussian g of batch element b as (centre, reach) -- from the prepared records, or derived on the fly from the
+// scalar-sigma inputs (ISO_PREP), in which case `a_out` also receives a.
+template <bool ISO_PREP>
+__device__ __forceinline__ float4 binA_record(const int g, const int b, const int N, const float4 *__restrict__ cull,
+                                              const float *__restrict__ mus, const float *__restrict__ isg,
+                                              const float *__restrict__ cam_fwd, const float thr_act, const IsoView view,
+                                              float &a_out) {
+  if (!ISO_PREP) return cull[(size_t)b * N + g];
+  const size_t src = view.shared ? (size_t)g : (size_t)b * N + g;
+  float mx = mus[3 * src + 0], my = mus[3 * src + 1], mz = mus[3 * src + 2];
+  if (view.origin != nullptr) {   // centring of Renderer.py:130: the same single fp32 subtraction
+    const float *o = view.origin + 3 * b;
+    mx -= o[0]; my -= o[1]; mz -= o[2];
+  }
+  const float a = iso_view_a(isg[src], view.mode);
+  a_out = a;
+  float4 c = iso_cull_record(mx, my, mz, a, thr_act);
+  if (cam_fwd != nullptr) {
+    const float *f = cam_fwd + 3 * b;
+    if (fmaf(mz, f[2], fmaf(my, f[1], mx * f[0])) < 0.0f) c.w = -1.0f;   // rasterize_coarse.cu:35 ("skip z < 0")
+  }
+  return c;
+}
+
+template <bool ISO_PREP>
+__global__ void __launch_bounds__(kBinThreads)
+binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, const int nsty, const int nst0x,
+            const float *__restrict__ mus, const float *__restrict__ isg, const float *__restrict__ cam_fwd, const int N,
+            const float thr_act, const IsoView view, float4 *__restrict__ cull, float4 *__restrict__ ms,
+            int *__restrict__ seg_count /* [B*nst][kParts] */, int32_t *__restrict__ seg_id /* [B*nst][kParts][kSegCap] */,
+            float4 *__restrict__ seg_rec /* the same shape: the entries' cull records */) {
+  __shared__ BinALds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int region = blockIdx.x / kParts, part = blockIdx.x - region * kParts, b = blockIdx.y;
+  const int rx = region % nst0x, ry = region / nst0x;
+  const int nst = nstx * nsty;
+  if (tid < kCh * kCh) L.base[tid] = 0;
+  BIN_TS(0, 0);
+  const int nchunks = (N + kBinThreads - 1) / kBinThreads;
+  const bool writes_records = ISO_PREP && region == 0;   // region 0's slices cover every Gaussian exactly once
+  // the first round's candidates do not depend on the cones: their loads go out first
+  float4 c[kRoundChunks];
+  float av[kRoundChunks];
+  int gq[kRoundChunks];
+  auto load_round = [&](const int j0) {
+#pragma unroll
+    for (int q = 0; q < kRoundChunks; ++q) {
+      const int g = (j0 + q * kParts) * kBinThreads + tid;
+      gq[q] = (j0 + q * kParts < nchunks && g < N) ? g : -1;
+      av[q] = 0.f;
+      c[q] = (gq[q] >= 0) ? binA_record<ISO_PREP>(g, b, N, cull, mus, isg, cam_fwd, thr_act, view, av[q])
+                          : make_float4(0.f, 0.f, 0.f, -1.f);
+    }
+  };
+  load_round(part);
+  // ---- the region's child cones, and its own cone as their conservative union (wave 0, lane <-> child): a ray of
+  // child i makes at most alpha_i + theta_i with the parent axis (alpha_i = angle between the axes), so
+  //   cos >= cos(alpha_i) cs_i - sin(alpha_i) sn_i ,   sin <= sin(alpha_i) + cos(alpha_i) sn_i .
+  if (wave == 0) {
+    const int cc = lane & (kCh * kCh - 1);
+    const int cx = rx * kCh + (cc & (kCh - 1)), cy = ry * kCh + cc / kCh;
+    ConeRec r = {0.f, 0.f, 1.f, 1.f, 0.f, -1.f, 0.f, 0.f};      // ok = -1: no such super-tile
+    if (cx < nstx && cy < nsty) r = cones[(size_t)b * nst + cy * nstx + cx];
+    if (lane < kCh * kCh) L.child[lane] = r;
+    const bool present = lane < kCh * kCh && r.ok >= 0.f;
+    const float sx = wave_sum(present ? r.ax : 0.f), sy = wave_sum(present ? r.ay : 0.f), sz = wave_sum(present ? r.az : 0.f);
+    const float npres = wave_sum(present ? 1.f : 0.f);
+    bool ok = __all(!present || r.ok > 0.f);
+    const float n = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
+    const float ax = sx / n, ay = sy / n, az = sz / n;
+    float smax = 0.f, cmin = 1.f;
+    if (present) {
+      const float ca = fmaf(r.az, az, fmaf(r.ay, ay, r.ax * ax));
+      const float qx = fmaf(-ca, ax, r.ax), qy = fmaf(-ca, ay, r.ay), qz = fmaf(-ca, az, r.az);
+      const float sa = sqrtf(fmaf(qz, qz, fmaf(qy, qy, qx * qx))) * (1.0f + 1e-6f) + 1e-7f;
+      const float cl = fminf(ca, 1.0f) - 1e-7f;
+      if (!(cl > 0.0f)) ok = false;
+      cmin = fmaf(cl, r.cs, -sa * r.sn);
+      smax = fmaf(fminf(ca + 1e-7f, 1.0f), r.sn, sa);
+    }
+    ok = __all(ok);
+    smax = wave_max(smax); cmin = wave_min(cmin);
+    const Cone cn = cone_finish(ax, ay, az, n / fmaxf(npres, 1.f), smax, cmin, ok);
+    if (lane == 0) L.region = ConeRec{cn.ax, cn.ay, cn.az, cn.cs, cn.sn, cn.ok ? 1.f : 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const Cone rcone = load_cone(L.region);
+  BIN_TS(0, 1);
+
+  // ---- the slice's Gaussians: chunks of 1024 dealt round-robin to the kParts slices (so a spatially ordered
+  // input, e.g. mesh vertices, still spreads evenly over the segments), kRoundChunks chunks per round ----
+  for (int j0 = part; j0 < nchunks; j0 += kParts * kRoundChunks) {
+    // (1) every candidate of the round against the region's cone; the survivors' records go to LDS in a fixed order
+    if (j0 != part) load_round(j0);
+    bool k0[kRoundChunks];
+#pragma unroll
+    for (int q = 0; q < kRoundChunks; ++q) {
+      if (writes_records && gq[q] >= 0) {
+        cull[(size_t)b * N + gq[q]] = c[q];
+        ms[(size_t)b * N + gq[q]] = make_float4(c[q].x, c[q].y, c[q].z, av[q]);
+      }
+      k0[q] = cone_keep(c[q], rcone);     // (a padding record has reach -1: never kept)
+    }
+    unsigned long long m0[kRoundChunks];
+#pragma unroll
+    for (int q = 0; q < kRoundChunks; ++q) {
+      m0[q] = __ballot(k0[q]);
+      if (lane == 0) L.cnt0[q][wave] = __popcll(m0[q]);
+    }
+    __syncthreads();
+    if (wave == 0) {     // lane <-> (chunk, wave): exclusive prefix of the 64 counts
+      static_assert(kRoundChunks * 16 == 64, "one lane per (chunk, wave)");
+      const int v = (&L.cnt0[0][0])[lane];
+      int x = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+      }
+      (&L.cnt0[0][0])[lane] = x - v;
+      if (lane == 63) L.nS = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kRoundChunks; ++q)
+      if (k0[q]) {
+        const int pos = L.cnt0[q][wave] + __popcll(m0[q] & ((1ull << lane) - 1ull));
+        L.srec[pos] = c[q];
+        L.sid[pos] = gq[q];
+      }
+    __syncthreads();
+    BIN_TS(0, 2);
+    // (2) survivors x children: wave cc walks ALL survivors against child cc's cone (in registers), four 64-survivor
+    // batches per trip.  It is the only writer of that child's segment, so its running count IS the fill position:
+    // one pass, no counters in LDS, no barrier, and the order is a pure function of the inputs.
+    const int nS = L.nS;
+    {
+      const int cc = wave;
+      const ConeRec cr = L.child[cc];
+      if (cr.ok >= 0.f) {                // (uniform) the super-tile exists
+        const Cone ck = load_cone(cr);
+        const int ccx = rx * kCh + (cc & (kCh - 1)), ccy = ry * kCh + cc / kCh;
+        const size_t seg0 = (((size_t)b * nst + ccy * nstx + ccx) * kParts + part) * kSegCap;
+        int32_t *seg = seg_id + seg0;
+        float4 *segr = seg_rec + seg0;      // (the record rides along: binB then streams it instead of gathering by id)
+        int fill = L.base[cc];
+        constexpr int kU = 4;
+        for (int s0 = 0; s0 < nS; s0 += 64 * kU) {
+          float4 r[kU];
+          int id[kU];
+#pragma unroll
+          for (int q = 0; q < kU; ++q) {
+            const int si = s0 + q * 64 + lane;
+            r[q] = (si < nS) ? L.srec[si] : make_float4(0.f, 0.f, 0.f, -1.f);
+            id[q] = (si < nS) ? L.sid[si] : -1;
+          }
+          bool kp[kU];
+#pragma unroll
+          for (int q = 0; q < kU; ++q) kp[q] = cone_keep(r[q], ck);      // (padding: reach -1, never kept)
+#pragma unroll
+          for (int q = 0; q < kU; ++q) {
+            const unsigned long long m = __ballot(kp[q]);
+            if (kp[q]) {
+              const int pos = fill + __popcll(m & ((1ull << lane) - 1ull));
+              if (pos < kSegCap) { seg[pos] = id[q]; segr[pos] = r[q]; }
+            }
+            fill += __popcll(m);
+          }
+        }
+        if (lane == 0) L.base[cc] = fill;
+      }
+    }
+    BIN_TS(0, 3);
+    __syncthreads();     // srec / sid / cnt are rewritten by the next round
+    BIN_TS(0, 4);
+  }
+  BIN_TS(0, 5);
+  if (tid < kCh * kCh) {
+    const int ccx = rx * kCh + (tid & (kCh - 1)), ccy = ry * kCh + tid / kCh;
+    if (ccx < nstx && ccy < nsty)
+      seg_count[((size_t)b * nst + ccy * nstx + ccx) * kParts + part] = (L.base[tid] > kSegCap) ? -1 : L.base[tid];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// binB: one 256-thread workgroup per QUAD (16x16 pixels = 2x2 sweep tiles, a quarter of a super-tile), one wave
+// per sweep tile.  A whole super-tile per workgroup (round 2's first form) left the chip as imbalanced as the
+// scene: the 16 tile filters of a central super-tile (5000 candidates) kept ONE CU busy for 18 us while the
+// others idled.  A quad's workgroup first cuts the super-tile's candidates down with the quad's own cone (~40 %
+// survive), so its sort and its four tile filters touch a fraction of the list, and four times as many
+// workgroups share the work.
+// ------------------------------------------------------------------------------------------
+constexpr int kQuad = 16;           // quad edge (pixels)
+constexpr int kQT = 256;            // threads: 4 waves <-> the quad's 2x2 sweep tiles
+constexpr int kQCap = 3008;         // entries of a quad's ordered list (LDS sort capacity; 39.5 KB of LDS: 4 workgroups per CU)
+constexpr int kQRec = kQCap / 2;       // ... whose cull records are kept in LDS for the tile filters (the rest: gathered)
+constexpr int kBuckets = 512;       // depth buckets of the counting sort
+constexpr int kTilesPerQuad = 4;
+struct BinLds {
+  union {
+    uint64_t keys[kQCap];     // (ord(depth key) << 32 | flag << 31 | id) of the quad's candidates, unordered
+    float4 rec[kQRec];        // after the sort: cull records of the ordered list's first kQRec entries
+  };
+  uint32_t sorted[kQCap];     // (flag << 31 | id), front to back (an entry's depth key is recomputed from its record)
+  float red[4 * 8];
+  int hist[kBuckets];
+  uint32_t bmin[kBuckets];   // per bucket: smallest own len bound of the entries with an ellipsoid record (ord)
+  int wsum[8];
+  int segn[kParts + 1];      // exclusive prefix of the segment counts
+  int count;
+  int nflag;      // entries with an ellipsoid record
+  int spill;      // a tile list overflowed kTileCap: the quad's ordered list goes to memory as its fallback
+};
+
+#ifndef VOGE_ELL_KEY
+#define VOGE_ELL_KEY 0
+#endif
+
+__global__ void __launch_bounds__(kQT)
+binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, const int *__restrict__ seg_count,
+            const int32_t *__restrict__ seg_id, const float4 *__restrict__ seg_rec, const float *__restrict__ rays,
+            const int N, const int H, const int W,
+            const int nstx, const int nsty, const int nbin_total,
+            int *__restrict__ q_count, int32_t *__restrict__ q_id, float *__restrict__ q_lb,
+            int *__restrict__ tl_count, int32_t *__restrict__ tl_id, float *__restrict__ tl_lb,
+            int2 *__restrict__ order /* [nbin_total][16]: (tile, list length) by launch rank */,
+            const int K, int32_t *__restrict__ out_idx, float *__restrict__ out_len, float *__restrict__ out_act,
+            float *__restrict__ out_dsd, int32_t *__restrict__ out_cnt) {
+  __shared__ BinLds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int binl = blockIdx.x >> 2, qq = blockIdx.x & 3;            // super-tile of this batch element, quad inside it
+  const int stx = binl % nstx, sty = binl / nstx;
+  const int bin = b * nstx * nsty + binl;
+  const int quad = bin * 4 + qq;
+  const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+  // this wave's sweep tile
+  const int tx = stx * (kST / 8) + (qq & 1) * 2 + (wave & 1), ty = sty * (kST / 8) + (qq >> 1) * 2 + (wave >> 1);
+  const bool tile_ok = tx < tiles_x && ty < tiles_y;
+  const int tile = b * tiles_x * tiles_y + ty * tiles_x + tx;
+
+  // ---- this thread's ray -> the wave's tile cone, and the quad's cone over all four waves ----
+  const int px = min(tx * 8 + (lane & 7), W - 1), py = min(ty * 8 + (lane >> 3), H - 1);
+  const bool has = tile_ok && (tx * 8 + (lane & 7) < W) && (ty * 8 + (lane >> 3) < H);
+  RayDir u;
+  {
+    const float *r = rays + (((size_t)b * H + min(py, H - 1)) * W + min(px, W - 1)) * 3;
+    u = ray_dir(r[0], r[1], r[2]);
+  }
+  Cone tcone, qcone;
+  {
+    const float wsx = wave_sum((has && u.ok) ? u.ux : 0.f), wsy = wave_sum((has && u.ok) ? u.uy : 0.f),
+                wsz = wave_sum((has && u.ok) ? u.uz : 0.f);
+    const bool wok = __all(!has || u.ok);
+    {
+      const float n = sqrtf(fmaf(wsz, wsz, fmaf(wsy, wsy, wsx * wsx)));
+      const float ax = wsx / n, ay = wsy / n, az = wsz / n;
+      float smax = 0.f, cmin = 1.f;
+      if (has) cone_partial(u, ax, ay, az, smax, cmin);
+      tcone = cone_finish(ax, ay, az, n, wave_max(smax), wave_min(cmin), wok);
+    }
+    if (lane == 0) { L.red[wave * 8 + 0] = wsx; L.red[wave * 8 + 1] = wsy; L.red[wave * 8 + 2] = wsz; L.red[wave * 8 + 3] = wok ? 1.f : 0.f; }
+    if (tid == 0) { L.count = 0; L.nflag = 0; L.spill = 0; }
+    if (tid == 0) {
+      int run = 0, bad = 0;
+      for (int p = 0; p < kParts; ++p) {
+        const int c = seg_count[(size_t)bin * kParts + p];
+        L.segn[p] = run;
+        if (c < 0) bad = 1; else run += c;
+      }
+      L.segn[kParts] = bad ? -1 : run;
+    }
+    __syncthreads();
+    const float gx = L.red[0] + L.red[8] + L.red[16] + L.red[24], gy = L.red[1] + L.red[9] + L.red[17] + L.red[25],
+                gz = L.red[2] + L.red[10] + L.red[18] + L.red[26];
+    const bool gok = (L.red[3] != 0.f) && (L.red[11] != 0.f) && (L.red[19] != 0.f) && (L.red[27] != 0.f);
+    const float n = sqrtf(fmaf(gz, gz, fmaf(gy, gy, gx * gx)));
+    const float ax = gx / n, ay = gy / n, az = gz / n;
+    float smax = 0.f, cmin = 1.f;
+    if (has) cone_partial(u, ax, ay, az, smax, cmin);
+    smax = wave_max(smax); cmin = wave_min(cmin);
+    if (lane == 0) { L.red[wave * 8 + 4] = smax; L.red[wave * 8 + 5] = cmin; }
+    __syncthreads();
+    smax = fmaxf(fmaxf(L.red[4], L.red[12]), fmaxf(L.red[20], L.red[28]));
+    cmin = fminf(fminf(L.red[5], L.red[13]), fminf(L.red[21], L.red[29]));
+    qcone = cone_finish(ax, ay, az, n, smax, cmin, gok);
+  }
+  BIN_TS(1, 0);
+
+  // ---- launch rank of the super-tile among all of them: by descending candidate count, estimated from the first
+  // four segments of every super-tile (a quarter of the Gaussians, dealt round-robin: proportional to the total).
+  // Every workgroup derives the rank from the same numbers, so the ranks are a permutation: no exchange.  The sweep's
+  // workgroup number lin then finds its tile (and the length of its list) in order[lin]: one load. ----
+  int rank = bin;
+  {
+    auto estimate = [&](const int q) {
+      const int4 v = *reinterpret_cast<const int4 *>(seg_count + (size_t)q * kParts);
+      // (an overflowed segment counts as full: such super-tiles go first)
+      return (v.x < 0 ? kSegCap : v.x) + (v.y < 0 ? kSegCap : v.y) + (v.z < 0 ? kSegCap : v.z) + (v.w < 0 ? kSegCap : v.w);
+    };
+    if (nbin_total <= kRankMaxBins) {
+      const int mine = estimate(bin);
+      int ahead = 0;
+      for (int q = tid; q < nbin_total; q += kQT) {
+        const int e = estimate(q);
+        ahead += (e > mine || (e == mine && q < bin)) ? 1 : 0;
+      }
+      ahead = (int)wave_sum((float)ahead);      // (< 2^24: exact in fp32)
+      if (lane == 0) L.wsum[wave] = ahead;
+      __syncthreads();
+      rank = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+      __syncthreads();
+    }
+  }
+  int2 *my_order = order + (size_t)rank * kTilesPerBin + qq * kTilesPerQuad;     // this quad's four launch slots
+  const int n_src = L.segn[kParts];
+  // ---- the super-tile's segments against the quad's cone; survivors' keys are compacted in LDS.  Anisotropic
+  // candidates are tested with their ellipsoid as well (binA tested bounding spheres only). ----
+  const float4 *cullb = cull + (size_t)b * N;
+  const float4 *ellb = ell + (size_t)b * N * 2;
+  const int32_t *segs = seg_id + (size_t)bin * kParts * kSegCap;
+  const float4 *segr = seg_rec + (size_t)bin * kParts * kSegCap;
+  float rmax = 0.0f;   // largest finite reach among this thread's survivors WITHOUT an ellipsoid record
+  float klo = INFINITY, khi = -INFINITY;   // extrema of the finite order keys of this thread's entries
+  bool any_el = false;
+  constexpr int kGU = 8;      // gathers in flight per thread
+  for (int base = 0; base < n_src; base += kQT * kGU) {
+    int gid[kGU];
+    float4 c[kGU];
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {     // ids and records are two streams: one round trip, nothing dependent
+      const int i = base + j * kQT + tid;
+      gid[j] = -1;
+      c[j] = make_float4(0.f, 0.f, 0.f, -1.f);
+      if (i < n_src) {
+        int p = 0;
+#pragma unroll
+        for (int q = 1; q < kParts; ++q) p += (i >= L.segn[q]) ? 1 : 0;
+        const int o = p * kSegCap + (i - L.segn[p]);
+        gid[j] = segs[o];
+        c[j] = segr[o];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      if (base + j * kQT >= n_src) break;     // uniform
+      bool kp = cone_keep(c[j], qcone);         // (padding: reach -1, never kept)
+      bool el = kp && cull_has_ell(c[j]);
+      float gkey = 0.0f;
+      if (__any(el)) {
+        if (el) {
+          const float4 e0 = ellb[2 * (size_t)gid[j]], e1 = ellb[2 * (size_t)gid[j] + 1];
+          kp = cone_keep_ell(c[j], e0, e1, qcone);
+          el = kp;
+          // order key: VOGE_ELL_KEY 0 = the centre's depth along the axis, 1 = the entry's own lower bound of len
+          const float pa = fmaf(c[j].z, qcone.az, fmaf(c[j].y, qcone.ay, c[j].x * qcone.ax));
+#if VOGE_ELL_KEY == 1
+          gkey = pa - ell_support(e0, e1, qcone.ax, qcone.ay, qcone.az) + 0.0f;
+#else
+          gkey = pa + 0.0f;
+#endif
+        }
+      }
+      const unsigned long long m = __ballot(kp);
+      if (m == 0ull) continue;     // uniform
+      int start = 0;
+      if (lane == 0) start = atomicAdd(&L.count, __popcll(m));
+      start = __shfl(start, 0, 64);
+      if (kp) {
+        const int slot = start + __popcll(m & ((1ull << lane) - 1ull));
+        if (!el && c[j].w < 3e38f) rmax = fmaxf(rmax, c[j].w);
+        // bit 31 of the id word: the entry has an ellipsoid record (its len bound is its own)
+        const float kv = el ? gkey : depth_key(c[j], qcone);
+        if (kv > -INFINITY) { klo = fminf(klo, kv); khi = fmaxf(khi, kv); }
+        if (slot < kQCap) L.keys[slot] = ((uint64_t)f2ord(kv) << 32) | (uint32_t)gid[j] | (el ? 0x80000000u : 0u);
+        any_el = any_el || el;
+      }
+    }
+  }
+  BIN_TS(1, 1);
+  if (__any(any_el) && lane == 0) L.nflag = 1;
+  // ---- order the survivors front to back: counting sort on the depth key.  Exact order is not needed for
+  // correctness (the sweep's top-K insertion is order independent) but it turns nearly every insertion into an
+  // append.  Bucket 0 collects the -inf keys (unbounded reach).
+  float hi = wave_max(khi), lo = wave_min(klo), rm = wave_max(rmax);
+  if (lane == 0) { L.red[wave * 8 + 0] = hi; L.red[wave * 8 + 1] = lo; L.red[wave * 8 + 2] = rm; }
+  for (int i = tid; i < kBuckets; i += kQT) { L.hist[i] = 0; L.bmin[i] = f2ord(INFINITY); }
+  __syncthreads();
+  const int total = L.count;
+  if (n_src < 0 || total > kQCap) {
+    // a segment or the quad's list overflowed: the sweep walks every Gaussian of the batch element for these tiles
+    if (tid == 0) q_count[quad] = -1;
+    if (lane == 0) {
+      if (tile_ok) tl_count[tile] = -1;
+      my_order[wave] = make_int2(tile_ok ? tile : -1, -1);
+    }
+    return;
+  }
+  hi = fmaxf(fmaxf(L.red[0], L.red[8]), fmaxf(L.red[16], L.red[24]));
+  lo = fminf(fminf(L.red[1], L.red[9]), fminf(L.red[17], L.red[25]));
+  rm = fmaxf(fmaxf(L.red[2], L.red[10]), fmaxf(L.red[18], L.red[26]));
+  const float span = fmaxf(hi - lo, 1e-20f);
+  const float scale = (float)(kBuckets - 2) / span;
+  const bool flagged = L.nflag != 0;     // any entry with an ellipsoid record (workgroup-uniform)
+  auto bucket_of = [&](const uint64_t k) {
+    const float v = ord2f((uint32_t)(k >> 32));
+    return (v > -INFINITY) ? 1 + min(kBuckets - 2, max(0, (int)((v - lo) * scale))) : 0;
+  };
+  for (int i = tid; i < total; i += kQT) {
+    const uint64_t kk = L.keys[i];
+    const int q = bucket_of(kk);
+    atomicAdd(&L.hist[q], 1);
+    if ((uint32_t)kk & 0x80000000u) {
+      // own lower bound of len: the peak point x = len d of a hit lies in the ellipsoid, so
+      // len (d.a) = x.a >= t = mu.a - h(a), and d.a is in [cs, 1]
+      const size_t g = (uint32_t)kk & 0x7fffffffu;
+      const float4 cj = cullb[g], e0 = ellb[2 * g], e1 = ellb[2 * g + 1];
+      float bnd = -INFINITY;
+      if (qcone.ok) {
+        const float pa = fmaf(cj.z, qcone.az, fmaf(cj.y, qcone.ay, cj.x * qcone.ax));
+        const float nm1 = fabsf(cj.x) + fabsf(cj.y) + fabsf(cj.z);
+        const float t = pa - ell_support(e0, e1, qcone.ax, qcone.ay, qcone.az) - 4e-6f * nm1;
+        bnd = (t >= 0.0f) ? t : t / qcone.cs;
+        bnd = bnd - 1e-5f * fabsf(bnd) - 1e-30f;
+      }
+      atomicMin(&L.bmin[q], f2ord(bnd));
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the kBuckets counters: two consecutive buckets per thread, wave scan, wave offsets
+  {
+    static_assert(kBuckets == 2 * kQT, "two buckets per thread");
+    const int2 v = *reinterpret_cast<const int2 *>(&L.hist[2 * tid]);
+    const int s4 = v.x + v.y;
+    int x = s4;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) L.wsum[wave] = x;
+    __syncthreads();
+    int off = x - s4;
+    for (int w = 0; w < wave; ++w) off += L.wsum[w];
+    *reinterpret_cast<int2 *>(&L.hist[2 * tid]) = make_int2(off, off + v.x);
+  }
+  __syncthreads();
+  BIN_TS(1, 2);
+  for (int i = tid; i < total; i += kQT) {
+    const uint64_t kk = L.keys[i];
+    L.sorted[atomicAdd(&L.hist[bucket_of(kk)], 1)] = (uint32_t)kk;
+  }
+  // Entries are ordered by BUCKET only (1022 buckets over the quad's depth range, i.e. a few thousandths of a scene
+  // unit each -- far finer than the reach that separates kappa from the actual len), and every entry carries its
+  // bucket's lower edge as the len bound: monotone along the list, which is all the sweep's early exit needs.
+  // The order inside a bucket is whatever the LDS atomics produced; the sweep's top-K is order independent.
+  // Suffix minimum over the buckets of the flagged entries' own bounds (thread <-> two buckets).
+  if (flagged) {
+    __syncthreads();
+    uint32_t m4[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) m4[q] = L.bmin[2 * tid + q];
+    m4[0] = min(m4[0], m4[1]);
+    uint32_t x = m4[0];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_down(x, o, 64);
+      if (lane + o < 64) x = min(x, y);
+    }
+    if (lane == 0) L.wsum[4 + wave] = (int)x;
+    __syncthreads();
+    // x = minimum from this thread's first bucket to the end of the wave; beyond: the later waves' minima
+    uint32_t later = 0xffffffffu;      // minimum over the lanes / waves behind this thread
+    {
+      const uint32_t nxt = __shfl_down(x, 1, 64);
+      later = (lane < 63) ? nxt : 0xffffffffu;
+      for (int w = wave + 1; w < 4; ++w) later = min(later, (uint32_t)L.wsum[4 + w]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) L.bmin[2 * tid + q] = min(m4[q], later);
+  }
+  __syncthreads();
+  // the cull records of the list's first kQRec entries, in list order, over the (now dead) unordered keys
+  for (int i0 = 0; i0 < min(total, kQRec); i0 += kQT * kGU) {
+    float4 c[kGU];
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      const int i = i0 + j * kQT + tid;
+      c[j] = (i < min(total, kQRec)) ? cullb[L.sorted[i] & 0x7fffffffu] : make_float4(0.f, 0.f, 0.f, -1.f);
+    }
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      const int i = i0 + j * kQT + tid;
+      if (i < min(total, kQRec)) L.rec[i] = c[j];
+    }
+  }
+  __syncthreads();
+  BIN_TS(1, 3);
+  // the len bound of list entry `k` (its bucket's lower edge, see above)
+  const float slack = 1.13f * rm * (1.0f + 1e-5f);
+  const float inv_scale = span / (float)(kBuckets - 2);
+  auto len_bound = [&](const uint32_t word, const float4 cr) {
+    // the entry's depth key, as the gather computed it (same record, same cone: the same bits)
+    const float v = (word & 0x80000000u) ? fmaf(cr.z, qcone.az, fmaf(cr.y, qcone.ay, cr.x * qcone.ax)) + 0.0f
+                                         : depth_key(cr, qcone);
+    float edge = -INFINITY;
+    int qb = 0;
+    if (v > -INFINITY) {
+      const int q = min(kBuckets - 2, max(0, (int)((v - lo) * scale)));
+      edge = fminf(v, lo + (float)q * inv_scale - 4e-6f * span);
+      qb = 1 + q;
+    }
+    // sphere-only entries: bucket edge minus the largest sphere reach; entries with an ellipsoid record: the
+    // smallest own bound from this bucket on.  Both are monotone along the list.
+    const float lb_sphere = (edge > -INFINITY) ? edge - slack - 1e-5f * fabsf(edge) - 1e-30f : -INFINITY;
+    return flagged ? fminf(lb_sphere, ord2f(L.bmin[qb])) : lb_sphere;
+  };
+
+  // ---- the four sweep tiles: wave w filters the ordered list (in LDS, records included) with the bounding cone of
+  // its own 8x8 pixels, keeping the order; four 64-entry batches per trip (their LDS reads and tests are independent)
+  int kept = 0;
+  if (tile_ok) {
+    int32_t *oid = tl_id + (size_t)tile * kTileCap;
+    float *olb = tl_lb + (size_t)tile * kTileCap;
+    BIN_WTS(0);
+    constexpr int kFU = 4;
+    for (int base = 0; base < total; base += 64 * kFU) {
+      uint32_t k[kFU];
+      float4 cr[kFU];
+#pragma unroll
+      for (int q = 0; q < kFU; ++q) {
+        const int i = base + q * 64 + lane;
+        k[q] = (i < total) ? L.sorted[i] : 0u;
+        cr[q] = make_float4(0.f, 0.f, 0.f, -1.f);
+        if (i < total) cr[q] = (i < kQRec) ? L.rec[i] : cullb[k[q] & 0x7fffffffu];
+      }
+      bool kp[kFU];
+#pragma unroll
+      for (int q = 0; q < kFU; ++q) kp[q] = cone_keep(cr[q], tcone);     // (padding: reach -1, never kept)
+#pragma unroll
+      for (int q = 0; q < kFU; ++q) {
+        if (base + q * 64 >= total) break;      // uniform
+        const uint32_t word = k[q];
+        const bool el = kp[q] && (word & 0x80000000u);      // sphere survivors with an ellipsoid record: that test too
+        if (__any(el)) {
+          if (el) {
+            const size_t g = word & 0x7fffffffu;
+            kp[q] = cone_keep_ell(cr[q], ellb[2 * g], ellb[2 * g + 1], tcone);
+          }
+        }
+        const unsigned long long m = __ballot(kp[q]);
+        if (kp[q]) {
+          const int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
+          if (pos < kTileCap) { oid[pos] = (int32_t)(word & 0x7fffffffu); olb[pos] = len_bound(word, cr[q]); }
+        }
+        kept += __popcll(m);
+      }
+    }
+    BIN_WTS(1);
+    if (lane == 0) {
+      if (kept > kTileCap) { tl_count[tile] = -1; L.spill = 1; }
+      else tl_count[tile] = kept;
+    }
+  }
+  // launch slots of the four tiles inside the quad: longest list first (an overflowed one counts as longest), tiles
+  // outside the image last
+  if (lane == 0) L.wsum[wave] = tile_ok ? min(kept, kTileCap + 1) : -1;
+  __syncthreads();
+  BIN_TS(1, 4);
+  if (lane == 0) {
+    const int mine = L.wsum[wave];
+    int slot = 0;
+    for (int w = 0; w < kTilesPerQuad; ++w) {
+      const int o = L.wsum[w];
+      slot += (o > mine || (o == mine && w < wave)) ? 1 : 0;
+    }
+    my_order[slot] = make_int2(tile_ok ? tile : -1, (mine > kTileCap) ? -1 : mine);
+  }
+  // a tile list overflowed: its sweep falls back to the quad's ordered list, which now has to exist in memory
+  if (L.spill) {
+    int32_t *oid = q_id + (size_t)quad * kQCap;
+    float *olb = q_lb + (size_t)quad * kQCap;
+    for (int i = tid; i < total; i += kQT) {
+      const uint32_t word = L.sorted[i];
+      oid[i] = (int32_t)(word & 0x7fffffffu);
+      olb[i] = len_bound(word, (i < kQRec) ? L.rec[i] : cullb[word & 0x7fffffffu]);
+    }
+  }
+  if (tid == 0) q_count[quad] = L.spill ? total : -2;     // (-2: never read -- every tile of this quad has its own list)
+  // Tiles nothing can hit get their all-sentinel outputs (ray_trace_voge.cu:244-247) here, written by the whole
+  // workgroup: 40 KB per tile at K = 40, 62 MB per frame at cfg3 -- HBM-write-bound wherever it happens.  The
+  // quads with empty tiles are the ones with short lists, i.e. the workgroups that would otherwise finish long
+  // before the kernel does; the sweep (a few waves per CU, latency-bound) never sees these tiles.
+  for (int w = 0; w < kTilesPerQuad; ++w) {
+    if (L.wsum[w] != 0) continue;      // uniform
+    const int ftx = stx * (kST / 8) + (qq & 1) * 2 + (w & 1), fty = sty * (kST / 8) + (qq >> 1) * 2 + (w >> 1);
+    const int tw = min(8, W - ftx * 8), th = min(8, H - fty * 8);
+    const int row_items = tw * K;
+    if ((K & 3) == 0) {
+      const int ipr = row_items >> 2;
+      for (int it = tid; it < th * ipr; it += kQT) {
+        const int rr = it / ipr, j4 = it - rr * ipr;
+        const size_t o = (((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8) * K + (size_t)j4 * 4;
+        *reinterpret_cast<int4 *>(out_idx + o) = make_int4(-1, -1, -1, -1);
+        *reinterpret_cast<float4 *>(out_len + o) = make_float4(VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN);
+        *reinterpret_cast<float4 *>(out_act + o) = make_float4(VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT);
+        *reinterpret_cast<float4 *>(out_dsd + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      for (int it = tid; it < th * row_items; it += kQT) {
+        const int rr = it / row_items, j = it - rr * row_items;
+        const size_t o = (((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8) * K + j;
+        out_idx[o] = -1; out_len[o] = VOGE_SENT_LEN; out_act[o] = VOGE_SENT_ACT; out_dsd[o] = 0.0f;
+      }
+    }
+    if (out_cnt != nullptr && tid < th * 8) {
+      const int rr = tid >> 3, x = tid & 7;
+      if (x < tw) out_cnt[((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8 + x] = 0;
+    }
+  }
+  BIN_TS(1, 5);
+}
+
+}  // namespace voge

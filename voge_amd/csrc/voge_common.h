@@ -298,6 +298,101 @@ __device__ __forceinline__ bool cone_keep(const float4 c, const Cone &k) {
   return !k.ok || !(gap > c.w);
 }
 
+constexpr int kST = 32;            // super-tile edge (pixels): the unit of the bounding cones
+
+// ------------------------------------------------------------------------------------------
+// Bounding cone of a set of rays (used by the bin kernels and the sweep).
+// ------------------------------------------------------------------------------------------
+struct RayDir {
+  float ux, uy, uz;
+  bool ok;      // finite, non-zero direction
+  bool unit;    // |d| == 1 within 1e-4 (the depth bound of the early exit assumes unit rays)
+};
+__device__ __forceinline__ RayDir ray_dir(const float dx, const float dy, const float dz) {
+  RayDir r;
+  const float dn2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  const float inv = 1.0f / sqrtf(dn2);
+  r.ok = (dn2 > 0.0f) && (inv < 3e38f) && (inv == inv);
+  r.unit = fabsf(dn2 - 1.0f) < 1e-4f;
+  r.ux = dx * inv; r.uy = dy * inv; r.uz = dz * inv;
+  return r;
+}
+// Partial (per-lane) extrema of one ray w.r.t. a given axis; finish with cone_finish().
+__device__ __forceinline__ void cone_partial(const RayDir &u, const float ax, const float ay, const float az,
+                                             float &smax, float &cmin) {
+  const float cl = fmaf(u.uz, az, fmaf(u.uy, ay, u.ux * ax));
+  const float rx = fmaf(-cl, ax, u.ux), ry = fmaf(-cl, ay, u.uy), rz = fmaf(-cl, az, u.uz);
+  const float sl = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx * rx)));
+  smax = fmaxf(smax, u.ok ? sl : 2.0f);
+  cmin = fminf(cmin, u.ok ? cl : -1.0f);
+}
+__device__ __forceinline__ Cone cone_finish(const float ax, const float ay, const float az, const float n,
+                                            const float smax, const float cmin, const bool all_ok) {
+  Cone c;
+  c.ax = ax; c.ay = ay; c.az = az;
+  c.sn = smax * (1.0f + 1e-5f) + 1e-7f;
+  c.cs = cmin - 1e-6f;
+  c.ok = all_ok && (n > 1e-3f) && (cmin > 0.05f) && (c.sn == c.sn);
+  return c;
+}
+
+// ok: 1 = usable, 0 = nothing may be culled against it, -1 = no such super-tile (outside the image)
+struct ConeRec {
+  float ax, ay, az, cs, sn, ok, pad0, pad1;
+};
+__device__ __forceinline__ Cone load_cone(const ConeRec &r) {
+  Cone c;
+  c.ax = r.ax; c.ay = r.ay; c.az = r.az; c.cs = r.cs; c.sn = r.sn; c.ok = r.ok > 0.f;
+  return c;
+}
+
+// Bounding cone of up to NR rays per thread of a 256-thread workgroup (`has` bit k: ray k exists).  Pass 1: axis =
+// direction of the plain vector sum (any axis gives a valid cone; rays of a pinhole camera have near-equal lengths,
+// so this is the mean direction).  Pass 2: extrema of the axial cosine and of the SQUARED radial sine -- one v_rsq
+// per ray, one sqrt per cone.  red: 4 * 8 floats of LDS.  Every thread returns the cone.
+template <int NR>
+__device__ __forceinline__ ConeRec block_cone256(const float (&rx)[NR], const float (&ry)[NR], const float (&rz)[NR],
+                                                 const unsigned has, const int npx, float *red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float sx = 0.f, sy = 0.f, sz = 0.f, okf = 1.f;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const float dn2 = fmaf(rz[k], rz[k], fmaf(ry[k], ry[k], rx[k] * rx[k]));
+    const bool on = (has >> k) & 1u, fin = dn2 > 1e-30f && dn2 < 1e30f;
+    sx += (on && fin) ? rx[k] : 0.f; sy += (on && fin) ? ry[k] : 0.f; sz += (on && fin) ? rz[k] : 0.f;
+    okf = (on && !fin) ? 0.f : okf;
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); okf = wave_min(okf);
+  if (lane == 0) { red[wave * 8 + 0] = sx; red[wave * 8 + 1] = sy; red[wave * 8 + 2] = sz; red[wave * 8 + 3] = okf; }
+  __syncthreads();
+  sx = red[0] + red[8] + red[16] + red[24];
+  sy = red[1] + red[9] + red[17] + red[25];
+  sz = red[2] + red[10] + red[18] + red[26];
+  okf = fminf(fminf(red[3], red[11]), fminf(red[19], red[27]));
+  const float n = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
+  const float ax = sx / n, ay = sy / n, az = sz / n;
+  float s2max = 0.f, cmin = 1.f;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const float dn2 = fmaf(rz[k], rz[k], fmaf(ry[k], ry[k], rx[k] * rx[k]));
+    const bool on = (has >> k) & 1u, fin = dn2 > 1e-30f && dn2 < 1e30f;
+    const float inv = __builtin_amdgcn_rsqf(dn2);
+    const float da = fmaf(rz[k], az, fmaf(ry[k], ay, rx[k] * ax));
+    const float qx = fmaf(-da, ax, rx[k]), qy = fmaf(-da, ay, ry[k]), qz = fmaf(-da, az, rz[k]);
+    const float s2 = fmaf(qz, qz, fmaf(qy, qy, qx * qx)) * (inv * inv);
+    s2max = on ? fmaxf(s2max, fin ? s2 : 4.0f) : s2max;
+    cmin = on ? fminf(cmin, fin ? da * inv : -1.0f) : cmin;
+  }
+  s2max = wave_max(s2max); cmin = wave_min(cmin);
+  if (lane == 0) { red[wave * 8 + 4] = s2max; red[wave * 8 + 5] = cmin; }
+  __syncthreads();
+  s2max = fmaxf(fmaxf(red[4], red[12]), fmaxf(red[20], red[28]));
+  cmin = fminf(fminf(red[5], red[13]), fminf(red[21], red[29]));
+  // v_rsq is good to ~1 ulp: pad the bounds by 4e-7 relative on top of cone_finish's margins
+  const Cone c = cone_finish(ax, ay, az, n / (float)max(npx, 1), sqrtf(s2max) * (1.0f + 4e-7f) + 4e-7f, cmin - 4e-7f, okf != 0.f);
+  return ConeRec{c.ax, c.ay, c.az, c.cs, c.sn, c.ok ? 1.f : 0.f, 0.f, 0.f};
+}
+
 // Does the cull record carry an ellipsoid record (trace_fwd.hip, prep_one)?
 #ifdef VOGE_NO_ELL   // build without the ellipsoid tests (bounding spheres only): for A/B timing
 __device__ __forceinline__ bool cull_has_ell(const float4) { return false; }

@@ -74,6 +74,18 @@ def _tag_index(sel_idx, cnt, n_index):
     sel_idx.voge_index_bound = int(n_index)
 
 
+def cones_of(rays, B, H, W):
+    """The super-tile cones pixel_rays() left on the ray tensor it returned, if they still describe it (same
+    tensor, not modified through torch since), else None -- the trace then derives them itself."""
+    tag = getattr(rays, "voge_cones", None)
+    if tag is None:
+        return None
+    cones, version = tag
+    if version != rays._version or cones.device != rays.device or tuple(rays.shape) != (B, H, W, 3):
+        return None
+    return cones
+
+
 def hit_count_of(sel_idx):
     """The trace's per-pixel hit count if it still describes `sel_idx`, else None."""
     tag = getattr(sel_idx, "voge_hit_count", None)
@@ -147,7 +159,7 @@ class _RayTraceVoGE(torch.autograd.Function):
                 nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
                 ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
                 rc = lib.voge_trace_topk_fwd(
-                    _p(mus_c), _p(isg_c), _p(rays_c), _p(fwd), B, N, H, W, K, float(thr_act), _p(ws), nbytes,
+                    _p(mus_c), _p(isg_c), _p(rays_c), _p(fwd), _p(cones_of(rays_c, B, H, W)), B, N, H, W, K, float(thr_act), _p(ws), nbytes,
                     _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _p(cnt), _stream())
                 _lib.check(rc, "voge_trace_topk_fwd")
         ctx.save_for_backward(mus_c, isg_c, rays_c)
@@ -215,7 +227,7 @@ class _RayTraceVoGEIso(torch.autograd.Function):
             nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
             ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
             rc = lib.voge_trace_topk_fwd_iso(
-                _p(mus_c), _p(a_c), _p(rays_c), _p(fwd), B, N, H, W, K, float(thr_act), _p(ws), nbytes,
+                _p(mus_c), _p(a_c), _p(rays_c), _p(fwd), _p(cones_of(rays_c, B, H, W)), B, N, H, W, K, float(thr_act), _p(ws), nbytes,
                 _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _p(cnt), _stream())
         _lib.check(rc, "voge_trace_topk_fwd_iso")
         ctx.save_for_backward(mus_c, a_c, rays_c)
@@ -285,7 +297,7 @@ class _RayTraceVoGEIsoView(torch.autograd.Function):
             nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
             ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
             rc = lib.voge_trace_topk_fwd_iso_view(
-                _p(v_c), _p(s_c), _p(o_c), int(shared), int(sigma_mode), _p(rays_c), _p(fwd), B, N, H, W, K,
+                _p(v_c), _p(s_c), _p(o_c), int(shared), int(sigma_mode), _p(rays_c), _p(fwd), _p(cones_of(rays_c, B, H, W)), B, N, H, W, K,
                 float(thr_act), _p(ws), nbytes, _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _p(cnt), _stream())
         _lib.check(rc, "voge_trace_topk_fwd_iso_view")
         ctx.save_for_backward(v_c, s_c, o_c, rays_c)
@@ -558,16 +570,19 @@ class _PixelRays(torch.autograd.Function):
         assert R_c.shape == (B, 3, 3) and T_c.shape == (B, 3) and f_c.shape == (B, 2) and p_c.shape == (B, 2)
         rays = torch.empty((B, h, W, 3), dtype=torch.float32, device=R_c.device)
         origin = torch.empty((B, 3), dtype=torch.float32, device=R_c.device)
+        # bounding cones of the band's 32x32-pixel super-tiles: the trace's culling aid, made here for free
+        cones = torch.empty((max(int(lib.voge_cones_floats(B, int(h), int(W))), 1),), dtype=torch.float32, device=R_c.device)
         with _on(R_c.device):
             rc = lib.voge_rays_fwd(_p(R_c), _p(T_c), _p(f_c), _p(p_c), B, int(row0), int(h), int(W), _p(rays),
-                                   _p(origin), _stream())
+                                   _p(origin), _p(cones), _stream())
         _lib.check(rc, "voge_rays_fwd")
         ctx.save_for_backward(R_c, T_c, f_c, p_c)
         ctx.geom = (int(row0), int(h), int(W))
-        return rays, origin
+        ctx.mark_non_differentiable(cones)
+        return rays, origin, cones
 
     @staticmethod
-    def backward(ctx, g_rays, g_origin):
+    def backward(ctx, g_rays, g_origin, _g_cones):
         lib = _lib.load()
         R, T, f, pp = ctx.saved_tensors
         row0, h, W = ctx.geom
@@ -716,7 +731,9 @@ def scatter_max(weight, idx, n_vert):
 
 
 def pixel_rays(R, T, focal, pp, row0, h, W):
-    return _PixelRays.apply(R, T, focal, pp, row0, h, W)
+    rays, origin, cones = _PixelRays.apply(R, T, focal, pp, row0, h, W)
+    rays.voge_cones = (cones, rays._version)      # see cones_of()
+    return rays, origin
 
 
 def ray_trace_fine(mus, isigmas, rays, bin_points, thr_act, bin_size, n_assign):
