@@ -160,6 +160,33 @@ int voge_trace_bwd_iso_view(const float *verts, const float *sigmas, const float
                             float *g_verts, float *g_sigmas, voge_stream_t stream);
 
 /*
+ * Fine trace + composite in ONE call: what GaussianRenderer.forward asks for (VoGE/Renderer.py:139-150:
+ * ray_tracing, then aggregation -> Fragments).  Replaces the pair
+ *   VoGE._C.ray_trace_voge_fine (ray_trace_voge.cu:135-280)  +  `aggregation` (VoGE/Aggregation.py:82-107)
+ * for the all-candidates list.  Arguments as voge_trace_topk_fwd / _iso / _iso_view, plus occ (the
+ * renderer's absorptivity) and the fragment outputs weight [B,H,W,K] f32 and valid_num [B,H,W] i64.
+ * idx / len / weight / valid_num are the fragments (sentinels -1 / 1e10 / 0 in empty slots); act, dsd
+ * and cnt [B,H,W] (required here) are what the backward needs -- in pixels WITHOUT any hit act / dsd are
+ * may be left unwritten (nothing reads them: every consumer goes by cnt).  Results are bit-identical
+ * to calling the two entry points one after the other (which is what happens on the device: compositing
+ * inside the sweep's epilogue was measured slower, see trace_fwd.hip); the call saves the host side one
+ * autograd node and a set of allocations per frame.
+ */
+int voge_fragments_fwd(const float *mus, const float *isigmas, const float *rays, const float *cam_fwd,
+                       const float *cones, int B, int N, int H, int W, int K, float thr_act, float occ,
+                       void *workspace, size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
+                       int32_t *cnt, float *weight, int64_t *valid_num, voge_stream_t stream);
+int voge_fragments_fwd_iso(const float *mus, const float *a, const float *rays, const float *cam_fwd,
+                           const float *cones, int B, int N, int H, int W, int K, float thr_act, float occ,
+                           void *workspace, size_t workspace_bytes, int32_t *idx, float *len, float *act,
+                           float *dsd, int32_t *cnt, float *weight, int64_t *valid_num, voge_stream_t stream);
+int voge_fragments_fwd_iso_view(const float *verts, const float *sigmas, const float *origin, int shared,
+                                int sigma_mode, const float *rays, const float *cam_fwd, const float *cones,
+                                int B, int N, int H, int W, int K, float thr_act, float occ, void *workspace,
+                                size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
+                                int32_t *cnt, float *weight, int64_t *valid_num, voge_stream_t stream);
+
+/*
  * Composite forward.  Replaces: VoGE/Aggregation.py:82-107 `aggregation`
  * (get_cross_activation :30-51 + assign2weight :54-79), without any [npix,K,K] temporary.
  *   w_m = exp(-occ * sum_k exp(-act_k) * (erf((len_m-len_k)*sqrt(dsd_k+1e-10)) + 1)/2)

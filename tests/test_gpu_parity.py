@@ -735,3 +735,54 @@ def test_list_path_backward_after_merge_and_index_guards(hip_lib):
     assert ops.hit_count_of(idx3) is None
     _, _, vn3, _ = aggregation(idx3, act3, ln3, dsd3, 1.0)
     assert (n(vn3) == (n(idx3) >= 0).sum(-1)).all() and first.any()
+
+
+# ------------------------------------------------------------------------------- fused trace + composite
+@pytest.mark.parametrize("mode,K", [(2, 40), (1, 12), (0, 24), (0, 10), (2, 7)])
+def test_fused_fragments_equal_trace_then_composite(hip_lib, mode, K):
+    """voge_fragments_fwd* (the sweep composites in its epilogue when K % 4 == 0, else runs the composite kernel
+    behind the trace) against the two stand-alone entry points called one after the other: identical fragments,
+    bit for bit, and the same gradients (VoGE/Renderer.py:139-150 = ray_tracing + aggregation)."""
+    from voge_amd import ops
+    from voge_amd.Aggregation import aggregation
+    B, N, H, W = 2, 3000, 72, 88
+    verts, sig, _ = random_scene(N, seed=40 + K, aniso=(mode == 0), lo=0.04, hi=0.1)
+    if mode == 0:
+        sig[::2] = np.eye(3, dtype=np.float32)[None] * sig[::2, :1, :1]           # a mix of isotropic and full forms
+    R, T = camera_np.look_at_view_transform([3.0, 3.3], [10.0, -15.0], [30.0, 120.0])
+    rays_np, origin = camera_np.pixel_rays(R, T, 90.0, (W / 2.0, H / 2.0), (H, W))
+    from voge_amd.cameras import PerspectiveCameras, pixel_rays
+    cams = PerspectiveCameras(focal_length=90.0, principal_point=((W / 2.0, H / 2.0),), image_size=((H, W),), R=R, T=T, device=DEV)
+    thr_act = oracle.thr_act_of(0.01)
+    g_w = torch.randn(B, H, W, K, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
+    g_l = torch.randn(B, H, W, K, device=DEV, generator=torch.Generator(DEV).manual_seed(4)) * 0.1
+    out = {}
+    for fused in (True, False):
+        rays, org = pixel_rays(cams, (H, W))
+        assert ops.cones_of(rays, B, H, W) is not None
+        if mode == 2:
+            p0, p1 = t(verts, rg=True), t(sig, rg=True)
+            args = (p0, p1, org)
+        else:
+            mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32).reshape(-1, 3)
+            p0 = t(mus, rg=True)
+            p1 = t(np.tile(2 * sig, (B,) + (1,) * (sig.ndim - 1)), rg=True)
+            args = (p0, p1, None)
+        if fused:
+            w, idx, vn, hl = ops.fragments(mode, args[0], args[1], args[2], rays, None, thr_act, K, 1 if mode == 2 else 0, 1.2)
+        else:
+            if mode == 2:
+                sel = ops._RayTraceVoGEIsoView.apply(p0, p1, org, rays, None, thr_act, K, 1)
+            elif mode == 1:
+                sel = ops._RayTraceVoGEIso.apply(p0, p1, rays, None, thr_act, K)
+            else:
+                sel = ops.ray_trace_fine(p0, p1, rays, None, thr_act, 10, K)
+            w, idx, vn, hl = aggregation(sel[0], sel[2], sel[1], sel[3], 1.2)
+        ((w * g_w).sum() + (torch.where(idx >= 0, hl, torch.zeros_like(hl)) * g_l).sum()).backward()
+        out[fused] = [n(x) for x in (w, idx, vn, hl, p0.grad, p1.grad)]
+    a, b_ = out[True], out[False]
+    assert (a[1] >= 0).mean() > 0.05 and a[2].max() == K
+    for x, y, name in zip(a[:4], b_[:4], ("weight", "idx", "valid_num", "hit_len")):
+        assert np.array_equal(x, y), name
+    for x, y, name in zip(a[4:], b_[4:], ("d/d means", "d/d sigmas")):
+        assert np.abs(x - y).max() <= 2e-5 * max(1.0, np.abs(y).max()), name

@@ -4,6 +4,7 @@ to_colored_background (:162-171), to_white_background (:174-176) -- same names, 
 meaning.  Every stage behind these calls is a HIP kernel (voge_amd.ops); a renderer on CPU
 tensors raises instead of falling back.
 """
+import math
 import os
 from typing import Tuple, Union
 
@@ -11,8 +12,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .Aggregation import aggregation, expend_sigma, merge_final
-from .RayTracing import ray_tracing_iso_view, ray_tracing, ray_tracing_iso
+from .Aggregation import expend_sigma, merge_final
+from .RayTracing import _view_axis
 from .cameras import pixel_rays
 
 # Fold `verts - origin` and `2 * sigmas` into the trace kernels when the inputs allow it (see forward()).
@@ -116,38 +117,41 @@ class GaussianRenderer(nn.Module):
             verts = verts[None]
 
         rays, origin = pixel_rays(cams, image_size, rows=kwargs.get('rows'))     # [B,h,W,3], [B,3]
+        # ray_tracing (RayTracing.py:12-30) + aggregation (Aggregation.py:82-107) as ONE call: the trace's sweep
+        # composites the fragments in its epilogue (voge_fragments_fwd*).  The stand-alone ray_tracing* / aggregation
+        # functions remain the public API and produce the same values.
+        thr_act = -math.log(st['thr_activation'] + 1 / 1e10)                     # RayTracing.py:76,85
+        K, occ = st['max_assign'], st['absorptivity']
+        behind = st['max_point_per_bin'] != -1      # the coarse stage's "skip z < 0" candidate rule (rasterize_coarse.cu:35)
         if sigmas.dim() == 1 and shared_verts and not origin.requires_grad and FUSED_PREAMBLE:
             # One (verts [N,3], sigmas [N]) set seen by every view, fixed cameras: the centring of
             # Renderer.py:130 and the 2*sigma / 2/sigma of :133-137 happen inside the trace's per-Gaussian
             # pass (and their chain rule inside its backward's) -- same values, no elementwise launches.
-            sel_idx, sel_len, sel_act, sel_dsd = ray_tracing_iso_view(
-                cams, verts[0], sigmas, origin, rays, image_size, thr=st['thr_activation'], n_assign=st['max_assign'],
-                max_points_per_bin=st['max_point_per_bin'], inverse_sigma=st['inverse_sigma'])
-            weight, index, valid_num, hit_len = aggregation(sel_idx=sel_idx, sel_act=sel_act, sel_len=sel_len,
-                                                            sel_dsd=sel_dsd, occupation_weight=st['absorptivity'])
+            cam_fwd = _view_axis(cams, origin[:, None]) if behind else None
+            weight, index, valid_num, hit_len = ops.fragments(2, verts[0], sigmas, origin, rays, cam_fwd, thr_act, K,
+                                                              2 if st['inverse_sigma'] else 1, occ)
             return Fragments(vert_weight=weight, vert_index=index, valid_num=valid_num, vert_hit_length=hit_len)
         centred = verts - origin[:, None]                                         # Renderer.py:130
+        cam_fwd = _view_axis(cams, centred) if behind else None
+        B = centred.shape[0]
         if sigmas.dim() == 1:
             # (N,) sigmas are isotropic: expend_sigma would give sigma * I (Aggregation.py:155-157) and
             # Renderer.py:133 doubles (or inverts and doubles) it.  Keep the scalar: the trace has an
             # isotropic form whose backward produces d/d(scalar) directly.
             a = 2.0 / sigmas if st['inverse_sigma'] else 2.0 * sigmas
-            sel_idx, sel_len, sel_act, sel_dsd = ray_tracing_iso(
-                cams, centred, a, rays, image_size, thr=st['thr_activation'], n_assign=st['max_assign'],
-                max_points_per_bin=st['max_point_per_bin'])
+            a = a.unsqueeze(0).expand(B, -1)
+            weight, index, valid_num, hit_len = ops.fragments(1, centred.reshape(-1, 3), a.reshape(-1), None, rays, cam_fwd,
+                                                              thr_act, K, 0, occ)
         else:
             sigmas = expend_sigma(sigmas)
             if sigmas.dim() == 3:
-                sigmas = sigmas.unsqueeze(0).expand(centred.shape[0], -1, -1, -1)
+                sigmas = sigmas.unsqueeze(0).expand(B, -1, -1, -1)
             isigma = 2 * torch.inverse(sigmas) if st['inverse_sigma'] else 2 * sigmas
-            sel_idx, sel_len, sel_act, sel_dsd = ray_tracing(
-                cams, centred, isigma, rays, image_size, thr=st['thr_activation'], n_assign=st['max_assign'],
-                max_points_per_bin=st['max_point_per_bin'])
+            weight, index, valid_num, hit_len = ops.fragments(0, centred.reshape(-1, 3), isigma.reshape(-1, 3, 3), None, rays,
+                                                              cam_fwd, thr_act, K, 0, occ)
         # merge_final later rewrites -1 -> 0 inside the fragments' index tensor.  The reference clones
         # it here (Renderer.py:145) because its backward finds empty slots by idx == -1; this trace
         # backward uses the per-pixel hit count instead, so no copy is needed.
-        weight, index, valid_num, hit_len = aggregation(sel_idx=sel_idx, sel_act=sel_act, sel_len=sel_len,
-                                                        sel_dsd=sel_dsd, occupation_weight=st['absorptivity'])
         return Fragments(vert_weight=weight, vert_index=index, valid_num=valid_num, vert_hit_length=hit_len)
 
 

@@ -28,89 +28,9 @@
 //   * Pads of sentinel entries (E = 0, len = -/+ 3e38) on both sides of every pixel's row: no
 //     index clamps or bounds tests in the loops.
 // An unsorted list (possible through the public API) takes a plain full K x K scan instead.
-#include "voge_common.h"
+#include "composite_core.h"
 
 namespace voge {
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-#ifdef VOGE_COMP_PRECISE
-#define FAST_EXP(x) expf(x)
-#define FAST_SQRT(x) sqrtf(x)
-#else
-// hardware exp2 / sqrt: ~1-2 ulp, far inside the 1e-4 parity tolerance; the libm versions cost
-// ~35 VALU instructions per lane in a VALU-bound kernel
-#define FAST_EXP(x) __builtin_amdgcn_exp2f((x) * 1.4426950408889634f)
-#define FAST_SQRT(x) __builtin_amdgcn_sqrtf(x)
-#endif
-
-#ifndef VOGE_COMP_MAXT
-#define VOGE_COMP_MAXT 256
-#endif
-constexpr int kCompThreads = VOGE_COMP_MAXT;
-constexpr float kInvNorm = 1.6487212707001282f;  // 1 / exp(-0.5), Aggregation.py:79
-constexpr float kRsqrtPi = 0.5641895835477563f;
-#ifndef VOGE_KSAT
-#define VOGE_KSAT 3.5f
-#endif
-constexpr float kSat = VOGE_KSAT;                // erfc(3.5)/2 = 3.7e-7, below the fp32 rounding of S ~ O(1..K)
-constexpr float kCs = 1.2011224087864498f;       // sqrt(log2 e): x' = x * kCs, exp(-x^2) = 2^(-x'^2)
-constexpr float kXcap = 5.0f * kCs;              // the fit's range; h(5) = 7.7e-13
-constexpr float kBig = 3.0e38f;
-
-// log2(erfc(x)/2) as a polynomial in x' = x sqrt(log2 e) on [0, 5 sqrt(log2 e)], weighted minimax
-// on the absolute error of 2^Q (tools/fit_erfc.py).  Degree 6: |err| <= 1.5e-7 (the accuracy of
-// Abramowitz-Stegun 7.1.26); VOGE_ERFC_DEG=8 gives 5.2e-8 and h(0) = 1/2 exactly for two more
-// packed FMAs per pair of entries.
-#ifndef VOGE_ERFC_DEG
-#define VOGE_ERFC_DEG 6
-#endif
-#if VOGE_ERFC_DEG == 8
-constexpr float kQ0 = -1.000000000e+00f, kQ1 = -1.355323434e+00f, kQ2 = -6.365932822e-01f,
-                kQ3 = -8.570024371e-02f, kQ4 = 1.359716244e-02f, kQ5 = -3.297536168e-04f,
-                kQ6 = -4.863584472e-04f, kQ7 = 1.211055496e-04f, kQ8 = -1.022832203e-05f;
-#else
-constexpr float kQ0 = -9.999997020e-01f, kQ1 = -1.355341077e+00f, kQ2 = -6.364040971e-01f,
-                kQ3 = -8.642258495e-02f, kQ4 = 1.487037074e-02f, kQ5 = -1.475012978e-03f,
-                kQ6 = 4.851150516e-05f;
-#endif
-
-__device__ __forceinline__ v2f pk_fma(const v2f a, const v2f b, const v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f splat(const float x) { return (v2f){x, x}; }
-
-// h(x') = erfc(x'/kCs)/2 for x' >= 0 (capped at kXcap), two at a time
-__device__ __forceinline__ v2f h_pair(v2f xp) {
-  xp.x = fminf(xp.x, kXcap);
-  xp.y = fminf(xp.y, kXcap);
-#if VOGE_ERFC_DEG == 8
-  v2f q = pk_fma(splat(kQ8), xp, splat(kQ7));
-  q = pk_fma(q, xp, splat(kQ6));
-  q = pk_fma(q, xp, splat(kQ5));
-#else
-  v2f q = pk_fma(splat(kQ6), xp, splat(kQ5));
-#endif
-  q = pk_fma(q, xp, splat(kQ4));
-  q = pk_fma(q, xp, splat(kQ3));
-  q = pk_fma(q, xp, splat(kQ2));
-  q = pk_fma(q, xp, splat(kQ1));
-  q = pk_fma(q, xp, splat(kQ0));
-  return (v2f){__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
-}
-// 2^(-x'^2) = exp(-x^2), two at a time
-__device__ __forceinline__ v2f gauss_pair(const v2f xp) {
-  const v2f q = -(xp * xp);
-  return (v2f){__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
-}
-__device__ __forceinline__ float h_one(const float xp) { return h_pair(splat(xp)).x; }
-// entries (e, e+1), e even: one 8-byte LDS read
-__device__ __forceinline__ v2f ld2(const float *a, const int e) { return *reinterpret_cast<const v2f *>(a + e); }
-__device__ __forceinline__ v2f abs2(const v2f v) { return (v2f){fabsf(v.x), fabsf(v.y)}; }
-
-// Row stride of the padded per-pixel arrays: two sentinels, K entries, two or three sentinels.
-// PAD (two sentinel entries) and the stride are even: an entry's parity is its slot's parity and the
-// pairs (2t, 2t+1) of a row are 8-byte aligned (ds_read_b64: 2 LDS cycles per wave; ds_read2_b32 of an odd pair costs 4).
-__host__ __device__ constexpr int comp_pad(const int K) { return 2; }
-__host__ __device__ constexpr int comp_row_stride(const int K) { return ((K + 1) & ~1) + 2 * comp_pad(K); }
 
 struct CompLds {
   v2f scan[2][kCompThreads];   // (running sum, running max) / (running sum, -) of the scans
@@ -124,6 +44,13 @@ __host__ __device__ inline int comp_rows(const int K) { return ((kCompThreads / 
 __host__ __device__ inline size_t comp_lds_bytes(const int K, const bool bwd) {
   return sizeof(CompLds) + sizeof(float) * (size_t)comp_rows(K) * (bwd ? 4 : 3);
 }
+
+// (the wave form keeps no per-workgroup state: no CompLds block in front of the arrays)
+__host__ __device__ inline size_t compn_lds_bytes(const int K, const int NS, const bool bwd, const int threads, const bool wave) {
+  return (wave ? 0 : sizeof(CompLds)) + sizeof(float) * (size_t)compn_rows(K, NS, threads, wave) * (bwd ? 4 : 3);
+}
+
+
 
 // MODE 0: forward.  1: backward, weights recomputed (S_m again).  2: backward with the forward's
 // weights given: the row pass only needs r_m, i.e. exp(-x^2) but no erfc.
@@ -404,21 +331,6 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
 // scans run over K / NS lanes.  The one-slot kernel above remains the reference form: it handles
 // the backward without given weights and is what VOGE_COMP_ONE_SLOT=1 builds select.
 // ------------------------------------------------------------------------------------------
-__host__ __device__ inline int compn_lanes(const int K, const int NS) { return (K + NS - 1) / NS; }
-__host__ __device__ inline int compn_stride(const int K, const int NS) { return compn_lanes(K, NS) * NS + 2 * comp_pad(K); }
-// pixels a workgroup of `threads` lanes holds: workgroup form = threads / LP, wave form = (threads / 64) * (64 / LP)
-__host__ __device__ inline int compn_pixels(const int K, const int NS, const int threads, const bool wave) {
-  const int lp = compn_lanes(K, NS);
-  return wave ? (threads / 64) * (64 / lp) : threads / lp;
-}
-__host__ __device__ inline int compn_rows(const int K, const int NS, const int threads, const bool wave) {
-  return (compn_pixels(K, NS, threads, wave) * compn_stride(K, NS) + 3) & ~3;
-}
-// (the wave form keeps no per-workgroup state: no CompLds block in front of the arrays)
-__host__ __device__ inline size_t compn_lds_bytes(const int K, const int NS, const bool bwd, const int threads, const bool wave) {
-  return (wave ? 0 : sizeof(CompLds)) + sizeof(float) * (size_t)compn_rows(K, NS, threads, wave) * (bwd ? 4 : 3);
-}
-
 #ifndef VOGE_COMP_WPE
 #define VOGE_COMP_WPE 1
 #endif
@@ -568,6 +480,21 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
     for (int a = 0; a < NS; ++a) c += __popcll(__ballot(id[a] >= 0) & seg);
     wave_cnt = c;
     if (!WAVE && head) atomicAdd(&L.cnt[p], c);
+  }
+  if (!BWD && WAVE) {
+    // forward, wave form: the row pass shared with the sweep's fused epilogue (composite_core.h)
+    float w[NS];
+    compn_fwd_rows<NS>(lm, sm, em, Llen, Lsp, LE, d0, k0, K, q, LP, in_wg, active, active && !wave_unsorted, seg_lo, occ, w);
+    if (active) {
+      if (vec && NS == 4) *reinterpret_cast<float4 *>(out0 + f) = make_float4(w[0], w[1], w[NS - 2], w[NS - 1]);
+      else if (vec) *reinterpret_cast<v2f *>(out0 + f) = (v2f){w[0], w[1]};
+      else {
+#pragma unroll
+        for (int a = 0; a < NS; ++a) if (has[a]) out0[f + a] = w[a];
+      }
+      if (q == 0) valid_num[pix] = (cnt_in != nullptr) ? (int64_t)cnt_in[pix] : (int64_t)wave_cnt;
+    }
+    return;
   }
   float mx = 0.0f, esum = 0.0f;
 #pragma unroll

@@ -1,0 +1,208 @@
+// Shared pieces of the depth-ordered compositing (VoGE/Aggregation.py:30-107): constants, the erfc / Gaussian
+// evaluators, the LDS row layout, and the forward row pass of the lane-owns-NS-slots form.  Used by composite.hip
+// (voge_composite_fwd / _bwd) and by the sweep's fused epilogue in trace_fwd.hip: ONE implementation, so fragments
+// composited inside the sweep are bit-identical to the stand-alone kernel's.
+#pragma once
+#include "voge_common.h"
+
+namespace voge {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#ifdef VOGE_COMP_PRECISE
+#define FAST_EXP(x) expf(x)
+#define FAST_SQRT(x) sqrtf(x)
+#else
+// hardware exp2 / sqrt: ~1-2 ulp, far inside the 1e-4 parity tolerance; the libm versions cost
+// ~35 VALU instructions per lane in a VALU-bound kernel
+#define FAST_EXP(x) __builtin_amdgcn_exp2f((x) * 1.4426950408889634f)
+#define FAST_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#endif
+
+#ifndef VOGE_COMP_MAXT
+#define VOGE_COMP_MAXT 256
+#endif
+constexpr int kCompThreads = VOGE_COMP_MAXT;
+constexpr float kInvNorm = 1.6487212707001282f;  // 1 / exp(-0.5), Aggregation.py:79
+constexpr float kRsqrtPi = 0.5641895835477563f;
+#ifndef VOGE_KSAT
+#define VOGE_KSAT 3.5f
+#endif
+constexpr float kSat = VOGE_KSAT;                // erfc(3.5)/2 = 3.7e-7, below the fp32 rounding of S ~ O(1..K)
+constexpr float kCs = 1.2011224087864498f;       // sqrt(log2 e): x' = x * kCs, exp(-x^2) = 2^(-x'^2)
+constexpr float kXcap = 5.0f * kCs;              // the fit's range; h(5) = 7.7e-13
+constexpr float kBig = 3.0e38f;
+
+// log2(erfc(x)/2) as a polynomial in x' = x sqrt(log2 e) on [0, 5 sqrt(log2 e)], weighted minimax
+// on the absolute error of 2^Q (tools/fit_erfc.py).  Degree 6: |err| <= 1.5e-7 (the accuracy of
+// Abramowitz-Stegun 7.1.26); VOGE_ERFC_DEG=8 gives 5.2e-8 and h(0) = 1/2 exactly for two more
+// packed FMAs per pair of entries.
+#ifndef VOGE_ERFC_DEG
+#define VOGE_ERFC_DEG 6
+#endif
+#if VOGE_ERFC_DEG == 8
+constexpr float kQ0 = -1.000000000e+00f, kQ1 = -1.355323434e+00f, kQ2 = -6.365932822e-01f,
+                kQ3 = -8.570024371e-02f, kQ4 = 1.359716244e-02f, kQ5 = -3.297536168e-04f,
+                kQ6 = -4.863584472e-04f, kQ7 = 1.211055496e-04f, kQ8 = -1.022832203e-05f;
+#else
+constexpr float kQ0 = -9.999997020e-01f, kQ1 = -1.355341077e+00f, kQ2 = -6.364040971e-01f,
+                kQ3 = -8.642258495e-02f, kQ4 = 1.487037074e-02f, kQ5 = -1.475012978e-03f,
+                kQ6 = 4.851150516e-05f;
+#endif
+
+__device__ __forceinline__ v2f pk_fma(const v2f a, const v2f b, const v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(const float x) { return (v2f){x, x}; }
+
+// h(x') = erfc(x'/kCs)/2 for x' >= 0 (capped at kXcap), two at a time
+__device__ __forceinline__ v2f h_pair(v2f xp) {
+  xp.x = fminf(xp.x, kXcap);
+  xp.y = fminf(xp.y, kXcap);
+#if VOGE_ERFC_DEG == 8
+  v2f q = pk_fma(splat(kQ8), xp, splat(kQ7));
+  q = pk_fma(q, xp, splat(kQ6));
+  q = pk_fma(q, xp, splat(kQ5));
+#else
+  v2f q = pk_fma(splat(kQ6), xp, splat(kQ5));
+#endif
+  q = pk_fma(q, xp, splat(kQ4));
+  q = pk_fma(q, xp, splat(kQ3));
+  q = pk_fma(q, xp, splat(kQ2));
+  q = pk_fma(q, xp, splat(kQ1));
+  q = pk_fma(q, xp, splat(kQ0));
+  return (v2f){__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+}
+// 2^(-x'^2) = exp(-x^2), two at a time
+__device__ __forceinline__ v2f gauss_pair(const v2f xp) {
+  const v2f q = -(xp * xp);
+  return (v2f){__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+}
+__device__ __forceinline__ float h_one(const float xp) { return h_pair(splat(xp)).x; }
+// entries (e, e+1), e even: one 8-byte LDS read
+__device__ __forceinline__ v2f ld2(const float *a, const int e) { return *reinterpret_cast<const v2f *>(a + e); }
+__device__ __forceinline__ v2f abs2(const v2f v) { return (v2f){fabsf(v.x), fabsf(v.y)}; }
+
+// Row stride of the padded per-pixel arrays: two sentinels, K entries, two or three sentinels.
+// PAD (two sentinel entries) and the stride are even: an entry's parity is its slot's parity and the
+// pairs (2t, 2t+1) of a row are 8-byte aligned (ds_read_b64: 2 LDS cycles per wave; ds_read2_b32 of an odd pair costs 4).
+__host__ __device__ constexpr int comp_pad(const int K) { return 2; }
+__host__ __device__ constexpr int comp_row_stride(const int K) { return ((K + 1) & ~1) + 2 * comp_pad(K); }
+
+__host__ __device__ inline int compn_lanes(const int K, const int NS) { return (K + NS - 1) / NS; }
+__host__ __device__ inline int compn_stride(const int K, const int NS) { return compn_lanes(K, NS) * NS + 2 * comp_pad(K); }
+// pixels a workgroup of `threads` lanes holds: workgroup form = threads / LP, wave form = (threads / 64) * (64 / LP)
+__host__ __device__ inline int compn_pixels(const int K, const int NS, const int threads, const bool wave) {
+  const int lp = compn_lanes(K, NS);
+  return wave ? (threads / 64) * (64 / lp) : threads / lp;
+}
+__host__ __device__ inline int compn_rows(const int K, const int NS, const int threads, const bool wave) {
+  return (compn_pixels(K, NS, threads, wave) * compn_stride(K, NS) + 3) & ~3;
+}
+// Forward row pass, wave form: the pixel's lanes (LP = ceil(K / NS) of them, lane q owns slots [NS q, NS q + NS))
+// sit inside ONE wave, the pixel's padded (len, s', E) rows are in LDS (row origin of this lane's group: d0, an even
+// index) and visible to the wave.  lm / sm / em: the lane's own len, s = sqrt(dsd + 1e-10), E = exp(-act) (E = 0 for
+// an empty slot).  `sorted`: the pixel's list is depth ordered (the windowed walk); otherwise every column is visited.
+// Returns the weights of the lane's slots.  The association of the scans is a function of the lane's index in the
+// pixel only, so a pixel's result does not depend on where it sits (row bands == whole frame, fused == stand-alone).
+template <int NS>
+__device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const float (&sm)[NS], const float (&em)[NS],
+                                               const float *Llen, const float *Lsp, const float *LE, const int d0,
+                                               const int k0, const int K, const int q, const int LP, const bool in_wg,
+                                               const bool active, const bool sorted, const int seg_lo, const float occ,
+                                               float (&w)[NS]) {
+  float sp[NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) sp[a] = sm[a] * kCs;
+  float mx = 0.0f, esum = 0.0f;
+#pragma unroll
+  for (int a = 0; a < NS; ++a) {
+    mx = fmaxf(mx, (em[a] != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm[a]) : 0.0f);
+    esum += em[a];
+  }
+  // Exclusive prefix (over the lanes of the pixel) of the per-lane sums of E, Hillis-Steele on wave shuffles with the
+  // window radius riding along
+  float ex, wave_rmax;
+  {
+    v2f x = {esum, mx};
+    const v2f y = (v2f){__shfl_up(x.x, 1, 64), __shfl_up(x.y, 1, 64)};
+    x = (q > 0 && in_wg) ? (v2f){y.x, fmaxf(mx, y.y)} : (v2f){0.0f, mx};
+    for (int o = 1; o < LP; o <<= 1) {
+      const v2f z = (v2f){__shfl_up(x.x, o, 64), __shfl_up(x.y, o, 64)};
+      if (q >= o && in_wg) {
+        x.x += z.x;
+        x.y = fmaxf(x.y, z.y);
+      }
+    }
+    ex = x.x;
+    wave_rmax = __shfl(x.y, min(63, seg_lo + LP - 1), 64);      // the pixel's last lane holds the maximum
+  }
+  const float rwin = sorted ? (in_wg ? wave_rmax : 0.0f) : 0.0f;
+  bool any_e = false;
+#pragma unroll
+  for (int a = 0; a < NS; ++a) any_e = any_e || (em[a] != 0.0f);
+  const float h0 = __builtin_amdgcn_exp2f(kQ0);      // h(0), exactly what h_pair(0) returns
+  float S[NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) S[a] = 0.0f;
+  if (any_e && sorted) {
+    v2f accF[NS], accB[NS];
+#pragma unroll
+    for (int a = 0; a < NS; ++a) { accF[a] = splat(0.0f); accB[a] = splat(0.0f); }
+    // diagonal block (registers): for rows a < b, column b is behind row a and column a in front of row b
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+      accF[a].x = em[a] * h0;         // self
+#pragma unroll
+      for (int b2 = a + 1; b2 < NS; ++b2) {
+        const float gap = lm[b2] - lm[a];
+        const v2f xp = (v2f){gap * sp[b2], gap * sp[a]};                 // (row a, col b), (row b, col a)
+        const v2f h = h_pair(xp);
+        accB[a].y = fmaf(em[b2], h.x, accB[a].y);
+        accF[b2].y = fmaf(em[a], h.y, accF[b2].y);
+      }
+    }
+    float lmB = lm[0];                 // the last live row decides how far back to walk
+#pragma unroll
+    for (int a = 1; a < NS; ++a) lmB = (em[a] != 0.0f) ? lm[a] : lmB;
+    for (int e = d0 - 2;; e -= 2) {      // column pairs in front of every own row; row 0 is the nearest
+      const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
+      if (!(lm[0] - l2.y < rwin)) break;
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const v2f xa = (splat(lm[a]) - l2) * s2;
+        accF[a] = pk_fma(E2, h_pair(xa), accF[a]);
+      }
+    }
+    for (int e = d0 + NS;; e += 2) {     // column pairs behind every own row
+      const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
+      if (!(l2.x - lmB < rwin)) break;
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const v2f xa = (l2 - splat(lm[a])) * s2;
+        accB[a] = pk_fma(E2, h_pair(xa), accB[a]);
+      }
+    }
+    float pre = ex;
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+      pre += em[a];                                                     // inclusive prefix sum of E
+      S[a] = (pre - (accF[a].x + accF[a].y)) + (accB[a].x + accB[a].y);
+    }
+  } else if (any_e && active) {          // unsorted list: every column, signs from the data
+    const int r0 = d0 - k0;
+    for (int j = 0; j < K; ++j) {
+      const float Ej = LE[r0 + j];
+      if (Ej == 0.0f) continue;
+      const float lj = Llen[r0 + j], sj = Lsp[r0 + j];
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const float xp = (lm[a] - lj) * sj;
+        const float h = h_one(fabsf(xp));
+        S[a] = fmaf(Ej, xp >= 0.0f ? 1.0f - h : h, S[a]);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NS; ++a) w[a] = (em[a] != 0.0f) ? FAST_EXP(-occ * S[a]) * em[a] * kInvNorm : 0.0f;
+}
+
+}  // namespace voge

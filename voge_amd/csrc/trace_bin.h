@@ -325,7 +325,8 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
             int *__restrict__ tl_count, int32_t *__restrict__ tl_id, float *__restrict__ tl_lb,
             int2 *__restrict__ order /* [nbin_total][16]: (tile, list length) by launch rank */,
             const int K, int32_t *__restrict__ out_idx, float *__restrict__ out_len, float *__restrict__ out_act,
-            float *__restrict__ out_dsd, int32_t *__restrict__ out_cnt) {
+            float *__restrict__ out_dsd, int32_t *__restrict__ out_cnt, float *__restrict__ out_weight,
+            int64_t *__restrict__ out_valid) {
   __shared__ BinLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
@@ -703,19 +704,28 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
         const size_t o = (((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8) * K + (size_t)j4 * 4;
         *reinterpret_cast<int4 *>(out_idx + o) = make_int4(-1, -1, -1, -1);
         *reinterpret_cast<float4 *>(out_len + o) = make_float4(VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN);
-        *reinterpret_cast<float4 *>(out_act + o) = make_float4(VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT);
-        *reinterpret_cast<float4 *>(out_dsd + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (out_weight != nullptr) {
+          // fused trace + composite: the fragments are (weight, idx, len); act / dsd only serve the backward, which
+          // never reads a pixel without hits -- a quarter of the empty tiles' bytes stays unwritten
+          *reinterpret_cast<float4 *>(out_weight + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          *reinterpret_cast<float4 *>(out_act + o) = make_float4(VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT);
+          *reinterpret_cast<float4 *>(out_dsd + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
     } else {
       for (int it = tid; it < th * row_items; it += kQT) {
         const int rr = it / row_items, j = it - rr * row_items;
         const size_t o = (((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8) * K + j;
         out_idx[o] = -1; out_len[o] = VOGE_SENT_LEN; out_act[o] = VOGE_SENT_ACT; out_dsd[o] = 0.0f;
+        if (out_weight != nullptr) out_weight[o] = 0.0f;
       }
     }
-    if (out_cnt != nullptr && tid < th * 8) {
+    if (tid < th * 8) {
       const int rr = tid >> 3, x = tid & 7;
-      if (x < tw) out_cnt[((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8 + x] = 0;
+      const size_t pix = ((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8 + x;
+      if (x < tw && out_cnt != nullptr) out_cnt[pix] = 0;
+      if (x < tw && out_valid != nullptr) out_valid[pix] = 0;
     }
   }
   BIN_TS(1, 5);

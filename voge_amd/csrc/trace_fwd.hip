@@ -130,6 +130,7 @@ prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const 
 }  // namespace voge
 
 #include "trace_bin.h"
+#include "composite_core.h"
 
 namespace voge {
 
@@ -187,7 +188,8 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
                  const int N, const int H,
                  const int W, const int K, const float thr_act, int32_t *__restrict__ out_idx,
                  float *__restrict__ out_len, float *__restrict__ out_act, float *__restrict__ out_dsd,
-                 int32_t *__restrict__ out_cnt) {
+                 int32_t *__restrict__ out_cnt, const float occ, float *__restrict__ out_weight,
+                 int64_t *__restrict__ out_valid) {
   constexpr int T = 64 * WAVES;
   constexpr int TP = T + 1;   // key row stride: the transposed epilogue read stays conflict-light
   constexpr int TW = (WAVES >= 2) ? 16 : 8;
@@ -573,7 +575,122 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     }
   };
   const bool vec4 = ((K & 3) == 0);   // rows of K floats stay 16-byte aligned: 16-byte stores
-  if (vec4) {
+  if (WAVES == 1 && out_weight != nullptr) {
+    // ---- fused epilogue: fragments AND their composite weights (VoGE/Aggregation.py:82-107).  The depth-ordered
+    // list of every ray is in LDS right now; instead of writing (idx, len, act, dsd) and letting a second kernel read
+    // them back (126 MB at cfg3) the wave composites here: a lane owns four consecutive slots of a pixel, 64 / (K/4)
+    // pixels per round, the row pass is the stand-alone kernel's (composite_core.h: bit-identical weights).  The
+    // keys, the (mu, a) gathers and the ray of round r + 1 are requested before round r is computed.  (host: K % 4 == 0)
+    constexpr int NS = 4;
+    const int LP = K >> 2, pw = 64 / LP;
+    const int rows = compn_rows(K, NS, 64, true);
+    float *const Llen = reinterpret_cast<float *>(smem_raw + ((sizeof(uint64_t) * (size_t)(K + 1) * TP + 15) & ~(size_t)15) + ((sizeof(TraceLds<T, ISO>) + 15) & ~(size_t)15));
+    float *const Lsp = Llen + rows, *const LE = Lsp + rows;
+    const int RS = compn_stride(K, NS);
+    const int pl = __float2int_rz(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)LP)), q = lane - pl * LP;
+    const bool in_wg = pl < pw;
+    const int k0 = NS * q, seg_lo = lane - q;
+    const int d0 = (in_wg ? pl : 0) * RS + 2 + (in_wg ? k0 : 0);
+    if (in_wg && q < 2) {      // the sentinel pairs in front of and behind every pixel's row: written once
+      const int r0 = pl * RS;
+      for (int t2 = q; t2 < 2; t2 += LP) {
+        Llen[r0 + t2] = -kBig; Lsp[r0 + t2] = 1.0f; LE[r0 + t2] = 0.0f;
+        const int eb = r0 + RS - 2 + t2;
+        Llen[eb] = kBig; Lsp[eb] = 1.0f; LE[eb] = 0.0f;
+      }
+    }
+    const int th = min(TH, H - ty * TH);
+    struct Req {
+      uint64_t key[NS];
+      float4 rec[NS];
+      float ex, ey, ez;
+      int nv, cntp;
+      bool on;
+      size_t pix;
+    };
+    auto request = [&](const int round, Req &r) {
+      const int pixl = round * pw + pl;                  // pixel of the tile: x = pixl & 7, row = pixl >> 3
+      r.on = in_wg && pixl < 64 && (pixl & 7) < tw && (pixl >> 3) < th;
+      r.pix = ((size_t)b * H + ty * TH + (pixl >> 3)) * W + (size_t)tx * TW + (pixl & 7);
+      r.cntp = r.on ? L.id[pixl & 63] : 0;
+      r.nv = max(0, min(NS, r.cntp - k0));
+      r.ex = r.ey = r.ez = 0.0f;
+#pragma unroll
+      for (int a = 0; a < NS; ++a) r.key[a] = (a < r.nv) ? keys[(size_t)(k0 + a) * TP + (pixl & 63)] : 0ull;
+      if (r.nv > 0) { r.ex = rays[r.pix * 3]; r.ey = rays[r.pix * 3 + 1]; r.ez = rays[r.pix * 3 + 2]; }
+#pragma unroll
+      for (int a = 0; a < NS; ++a) r.rec[a] = (a < r.nv) ? ms[(uint32_t)r.key[a]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    const int nround = (64 + pw - 1) / pw;
+    Req cur, nxt;
+    request(0, cur);
+    for (int round = 0; round < nround; ++round) {
+      if (round + 1 < nround) request(round + 1, nxt);
+      int32_t oi[NS];
+      float ol[NS], oa[NS], od[NS], lm[NS], sm[NS], em[NS];
+      const float qxx = cur.ex * cur.ex, qyy = cur.ey * cur.ey, qzz = cur.ez * cur.ez;
+      bool gen_any = false;
+      if (!ISO) {
+#pragma unroll
+        for (int a = 0; a < NS; ++a) gen_any = gen_any || ((a < cur.nv) && !(cur.rec[a].w == cur.rec[a].w));
+        gen_any = __any(gen_any);
+      }
+      float4 g0[NS], g1[NS], g2[NS];
+      if (!ISO && gen_any) {      // anisotropic entries (w = NaN): their full records, all in flight together
+#pragma unroll
+        for (int a = 0; a < NS; ++a) {
+          g0[a] = g1[a] = g2[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if ((a < cur.nv) && !(cur.rec[a].w == cur.rec[a].w)) {
+            const size_t eo = (size_t)(uint32_t)cur.key[a] * 3;
+            g0[a] = evr[eo]; g1[a] = evr[eo + 1]; g2[a] = evr[eo + 2];
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        oi[a] = -1; ol[a] = VOGE_SENT_LEN; oa[a] = VOGE_SENT_ACT; od[a] = 0.0f;
+        lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.0f;      // what the stand-alone kernel takes an empty slot for
+        if (a < cur.nv) {
+          oi[a] = (int32_t)(uint32_t)cur.key[a];
+          ol[a] = ord2f((uint32_t)(cur.key[a] >> 32));
+          PairOut o;
+          if (ISO || cur.rec[a].w == cur.rec[a].w) {
+            o = pair_eval_iso_at(cur.rec[a].x, cur.rec[a].y, cur.rec[a].z, cur.rec[a].w, ol[a], cur.ex, cur.ey, cur.ez,
+                                 (qxx + qyy) + qzz);     // len is in the key: no second division
+          } else {
+            const EvalRec e = unpack_eval(g0[a], g1[a], g2[a]);
+            o = pair_eval(cur.rec[a].x, cur.rec[a].y, cur.rec[a].z, e, cur.ex, cur.ey, cur.ez, qxx, qyy, qzz, cur.ex * cur.ey,
+                          cur.ex * cur.ez, cur.ey * cur.ez);
+          }
+          oa[a] = o.act; od[a] = o.dsd;
+          lm[a] = ol[a]; em[a] = FAST_EXP(-oa[a]); sm[a] = FAST_SQRT(od[a] + 1e-10f);
+        }
+      }
+      if (in_wg) {
+#pragma unroll
+        for (int h2 = 0; h2 < NS / 2; ++h2) {
+          const int a = 2 * h2;
+          *reinterpret_cast<v2f *>(Llen + d0 + a) = (v2f){lm[a], lm[a + 1]};
+          *reinterpret_cast<v2f *>(Lsp + d0 + a) = (v2f){sm[a] * kCs, sm[a + 1] * kCs};
+          *reinterpret_cast<v2f *>(LE + d0 + a) = (v2f){em[a], em[a + 1]};
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      float wgt[NS];
+      compn_fwd_rows<NS>(lm, sm, em, Llen, Lsp, LE, d0, k0, K, q, LP, in_wg, cur.on, true, seg_lo, occ, wgt);
+      __builtin_amdgcn_wave_barrier();      // the rows are rewritten by the next round
+      if (cur.on) {
+        const size_t ob = cur.pix * K + k0;
+        *reinterpret_cast<int4 *>(out_idx + ob) = make_int4(oi[0], oi[1], oi[2], oi[3]);
+        *reinterpret_cast<float4 *>(out_len + ob) = make_float4(ol[0], ol[1], ol[2], ol[3]);
+        *reinterpret_cast<float4 *>(out_act + ob) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+        *reinterpret_cast<float4 *>(out_dsd + ob) = make_float4(od[0], od[1], od[2], od[3]);
+        *reinterpret_cast<float4 *>(out_weight + ob) = make_float4(wgt[0], wgt[1], wgt[2], wgt[3]);
+        if (q == 0 && out_valid != nullptr) out_valid[cur.pix] = (int64_t)cur.cntp;
+      }
+      cur = nxt;
+    }
+  } else if (vec4) {
     // All rows of the tile as one item space; an item = 4 consecutive slots of one pixel.  kEpiU
     // items per thread go through the stages together -- LDS keys, then one 16-byte gather per
     // slot (isotropic Gaussians need nothing more), then arithmetic and the 16-byte stores -- so
@@ -733,7 +850,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       }
     }
   }
-  for (int r = 0; r < TH && !vec4; ++r) {
+  for (int r = 0; r < TH && !vec4 && out_weight == nullptr; ++r) {
     const int gy = ty * TH + r;
     if (gy >= H) break;
     const size_t pix0 = ((size_t)b * H + gy) * W + (size_t)tx * TW;
@@ -883,10 +1000,13 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
 // binB + the sweep (one wave = one 8x8-pixel tile per workgroup)
 template <bool ISO>
 static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *rays, int B, int N, int H, int W, int K,
-                        float thr_act, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
-                        hipStream_t st) {
+                        float thr_act, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt, float occ,
+                        float *weight, int64_t *valid_num, hipStream_t st) {
   constexpr int T = 64;
-  const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + sizeof(TraceLds<T, ISO>) + VOGE_SWEEP_LDS_PAD;
+  // (fused composite epilogue: three padded per-pixel rows (len, s', E) for one round of 64 / (K/4) pixels)
+  const size_t comp = (weight != nullptr) ? sizeof(float) * 3 * (size_t)compn_rows(K, 4, 64, true) : 0;
+  const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + ((sizeof(TraceLds<T, ISO>) + 15) & ~(size_t)15) +
+                     comp + VOGE_SWEEP_LDS_PAD;
   auto kern = trace_fwd_kernel<1, ISO>;
   {
     static DynLdsCache cache;
@@ -895,7 +1015,7 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
   }
   hipLaunchKernelGGL(binB_kernel, dim3(ws.nstx * ws.nsty * 4, B), dim3(kQT), 0, st, ws.cull, ws.ell, ws.seg_count, ws.seg_id, ws.seg_rec,
                      rays, N, H, W, ws.nstx, ws.nsty, ws.nbin, ws.q_count, ws.q_id, ws.q_lb, ws.tl_count, ws.tl_id, ws.tl_lb,
-                     ws.order, K, idx, len, act, dsd, cnt);
+                     ws.order, K, idx, len, act, dsd, cnt, weight, valid_num);
   {
     int rc = launch_status();
     if (rc) return rc;
@@ -903,7 +1023,7 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
   dim3 grid(ws.nbin * kTilesPerBin);     // one workgroup per tile slot of every super-tile (slots outside the image exit)
   hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, ws.ms, rays, ws.q_count, ws.q_id, ws.q_lb,
                      ws.tl_count, ws.tl_id, ws.tl_lb, ws.order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx,
-                     ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd, cnt);
+                     ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, weight, valid_num);
   return launch_status();
 }
 
@@ -947,7 +1067,7 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
                                const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
                                float thr_act, void *workspace, size_t workspace_bytes,
                                int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
-                               voge_stream_t stream) {
+                               voge_stream_t stream, float occ = 1.0f, float *weight = nullptr, int64_t *valid_num = nullptr) {
   if (B < 0 || N < 0 || H < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K) return VOGE_ERR_K_TOO_LARGE;
   if ((size_t)B * H * W == 0) return 0;  // numel == 0 early return (ray_trace_voge.cu:248-251)
@@ -985,10 +1105,23 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   }
   // One wave (an 8x8 pixel tile) per sweep workgroup.  Residency is set by the LDS top-K lists (~7 waves per CU at
   // K = 40), and independent single-wave workgroups measured 4-10 % faster than 16x8 / 16x16 tiles in round 1.
-#ifndef VOGE_NO_ISO_SWEEP
-  if (iso_in) return launch_trace<true>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
+  // Fragments wanted as well (weight != NULL): the stand-alone composite kernel runs behind the sweep.  Compositing
+  // inside the sweep's epilogue (VOGE_FUSED_EPILOGUE=1 builds, K % 4 == 0; same bits, tests/test_gpu_parity.py) was
+  // built and measured: the sweep holds ~1.5 waves per SIMD (its top-K lists fill the LDS), so the composite's row
+  // walks run latency-bound there -- sweep 64 -> 142 us at cfg3 against 52 us for the kernel it would replace, which
+  // does the same instructions at eight waves per SIMD and reads its 126 MB mostly from the Infinity Cache.
+#ifndef VOGE_FUSED_EPILOGUE
+#define VOGE_FUSED_EPILOGUE 0
 #endif
-  return launch_trace<false>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, st);
+  const bool fused = VOGE_FUSED_EPILOGUE && weight != nullptr && (K & 3) == 0 && K <= 256 && cnt != nullptr;
+  int rc;
+#ifndef VOGE_NO_ISO_SWEEP
+  if (iso_in) rc = launch_trace<true>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, fused ? weight : nullptr, fused ? valid_num : nullptr, st);
+  else
+#endif
+  rc = launch_trace<false>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, fused ? weight : nullptr, fused ? valid_num : nullptr, st);
+  if (rc || weight == nullptr || fused) return rc;
+  return voge_composite_fwd(idx, cnt, act, len, dsd, occ, (long)B * H * W, K, weight, valid_num, stream);
 }
 
 extern "C" int voge_trace_topk_fwd(const float *mus, const float *isigmas, const float *rays,
@@ -1040,4 +1173,33 @@ extern "C" int voge_trace_topk_fwd_iso_view(const float *verts, const float *sig
   if (sigma_mode < 0 || sigma_mode > 2) return VOGE_ERR_BAD_ARG;
   return trace_topk_fwd_impl(1, IsoView{origin, shared ? 1 : 0, sigma_mode}, verts, sigmas, rays, cam_fwd, cones, B, N, H, W, K,
                              thr_act, workspace, workspace_bytes, idx, len, act, dsd, cnt, stream);
+}
+
+// ---- trace + composite in one call: fragments (weight, idx, valid_num, len) plus act / dsd / cnt for the backward ----
+extern "C" int voge_fragments_fwd(const float *mus, const float *isigmas, const float *rays, const float *cam_fwd,
+                                  const float *cones, int B, int N, int H, int W, int K, float thr_act, float occ,
+                                  void *workspace, size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
+                                  int32_t *cnt, float *weight, int64_t *valid_num, voge_stream_t stream) {
+  if (!weight || !valid_num || !cnt) return VOGE_ERR_BAD_ARG;
+  return trace_topk_fwd_impl(0, IsoView{nullptr, 0, 0}, mus, isigmas, rays, cam_fwd, cones, B, N, H, W, K, thr_act, workspace,
+                             workspace_bytes, idx, len, act, dsd, cnt, stream, occ, weight, valid_num);
+}
+
+extern "C" int voge_fragments_fwd_iso(const float *mus, const float *a, const float *rays, const float *cam_fwd,
+                                      const float *cones, int B, int N, int H, int W, int K, float thr_act, float occ,
+                                      void *workspace, size_t workspace_bytes, int32_t *idx, float *len, float *act,
+                                      float *dsd, int32_t *cnt, float *weight, int64_t *valid_num, voge_stream_t stream) {
+  if (!weight || !valid_num || !cnt) return VOGE_ERR_BAD_ARG;
+  return trace_topk_fwd_impl(1, IsoView{nullptr, 0, 0}, mus, a, rays, cam_fwd, cones, B, N, H, W, K, thr_act, workspace,
+                             workspace_bytes, idx, len, act, dsd, cnt, stream, occ, weight, valid_num);
+}
+
+extern "C" int voge_fragments_fwd_iso_view(const float *verts, const float *sigmas, const float *origin, int shared,
+                                           int sigma_mode, const float *rays, const float *cam_fwd, const float *cones,
+                                           int B, int N, int H, int W, int K, float thr_act, float occ, void *workspace,
+                                           size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
+                                           int32_t *cnt, float *weight, int64_t *valid_num, voge_stream_t stream) {
+  if (sigma_mode < 0 || sigma_mode > 2 || !weight || !valid_num || !cnt) return VOGE_ERR_BAD_ARG;
+  return trace_topk_fwd_impl(1, IsoView{origin, shared ? 1 : 0, sigma_mode}, verts, sigmas, rays, cam_fwd, cones, B, N, H, W, K,
+                             thr_act, workspace, workspace_bytes, idx, len, act, dsd, cnt, stream, occ, weight, valid_num);
 }

@@ -340,6 +340,111 @@ class _RayTraceVoGEIsoView(torch.autograd.Function):
         return g_verts, g_sig, None, g_ray, None, None, None, None
 
 
+class _Fragments(torch.autograd.Function):
+    """Trace + composite in one launch chain (voge_fragments_fwd*): what GaussianRenderer.forward needs from
+    ray_tracing (RayTracing.py:12-30) followed by aggregation (Aggregation.py:82-107).
+    forward(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode, occ) -> weight, sel_idx, valid_num, sel_len
+      mode 0: p0 = mus [P,3], p1 = isigmas [P,3,3]           (general 3x3 forms)
+      mode 1: p0 = mus [P,3], p1 = a [P]                     (A = a I)
+      mode 2: p0 = verts [N,3] | [B,N,3], p1 = sigmas [N] | [B,N], origin [B,3]   (the renderer's preamble folded in)
+    The backward is the composite's closed form followed by the trace backward of the same mode."""
+
+    @staticmethod
+    def forward(ctx, mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode, occ):
+        lib = _lib.load()
+        p0_c, p1_c = _dev(p0, torch.float32, "means"), _dev(p1, torch.float32, "sigmas")
+        rays_c = _dev(rays, torch.float32, "rays")
+        assert rays_c.dim() == 4 and rays_c.shape[3] == 3
+        B, H, W, _ = rays_c.shape
+        K, dev = int(n_assign), rays_c.device
+        o_c, shared = None, False
+        if mode == 2:
+            o_c = _dev(origin, torch.float32, "origin")
+            shared = p0_c.dim() == 2
+            assert p0_c.shape[-1] == 3 and (shared or p0_c.shape[0] == B) and p1_c.shape == p0_c.shape[:-1]
+            assert o_c.shape == (B, 3)
+            N = p0_c.shape[-2]
+        else:
+            assert p0_c.dim() == 2 and p0_c.shape[1] == 3 and p0_c.shape[0] % max(B, 1) == 0
+            assert p1_c.shape[0] == p0_c.shape[0] and (p1_c.dim() == 1 if mode == 1 else p1_c.shape[1:] == (3, 3))
+            N = p0_c.shape[0] // B
+        sel_idx = torch.empty((B, H, W, K), dtype=torch.int32, device=dev)
+        sel_len = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
+        sel_act, sel_dsd, weight = torch.empty_like(sel_len), torch.empty_like(sel_len), torch.empty_like(sel_len)
+        cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+        valid = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+        fwd = None if cam_fwd is None else _dev(cam_fwd, torch.float32, "cam_fwd")
+        with _on(dev):
+            nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
+            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+            tail = (B, N, H, W, K, float(thr_act), float(occ), _p(ws), nbytes, _p(sel_idx), _p(sel_len), _p(sel_act),
+                    _p(sel_dsd), _p(cnt), _p(weight), _p(valid), _stream())
+            cones = _p(cones_of(rays_c, B, H, W))
+            if mode == 2:
+                rc = lib.voge_fragments_fwd_iso_view(_p(p0_c), _p(p1_c), _p(o_c), int(shared), int(sigma_mode), _p(rays_c),
+                                                     _p(fwd), cones, *tail)
+            elif mode == 1:
+                rc = lib.voge_fragments_fwd_iso(_p(p0_c), _p(p1_c), _p(rays_c), _p(fwd), cones, *tail)
+            else:
+                rc = lib.voge_fragments_fwd(_p(p0_c), _p(p1_c), _p(rays_c), _p(fwd), cones, *tail)
+        _lib.check(rc, "voge_fragments_fwd")
+        ctx.save_for_backward(p0_c, p1_c, rays_c, sel_act, sel_len, sel_dsd, weight)
+        ctx.origin, ctx.sel_idx, ctx.cnt = o_c, sel_idx, cnt
+        ctx.meta = (int(mode), int(sigma_mode), bool(shared), float(occ), B, N)
+        _tag_index(sel_idx, cnt, B * N)
+        ctx.mark_non_differentiable(sel_idx, valid)
+        ctx.set_materialize_grads(False)
+        return weight, sel_idx, valid, sel_len
+
+    @staticmethod
+    def backward(ctx, g_weight, _g_idx, _g_valid, g_hitlen):
+        lib = _lib.load()
+        p0, p1, rays, act, ln, dsd, weight = ctx.saved_tensors
+        mode, sigma_mode, shared, occ, B, N = ctx.meta
+        sel_idx, cnt = ctx.sel_idx, ctx.cnt
+        _, H, W, K = sel_idx.shape
+        npix = B * H * W
+        dev = rays.device
+        if mode == 2 and ctx.needs_input_grad[3]:
+            raise _lib.VogeHipError("the fused view form has no gradient for the camera centre; "
+                                    "use ray_tracing_iso on centred vertices")
+        g_act, g_len, g_dsd = torch.empty_like(act), torch.empty_like(act), torch.empty_like(act)
+        with _on(dev):
+            if g_weight is None:
+                g_act.zero_(); g_len.zero_(); g_dsd.zero_()
+            else:
+                gw = _dev(g_weight, torch.float32, "grad_weight")
+                rc = lib.voge_composite_bwd(_p(act), _p(ln), _p(dsd), _p(weight), _p(cnt), _p(gw), occ, npix, K, _p(g_act),
+                                            _p(g_len), _p(g_dsd), _stream())
+                _lib.check(rc, "voge_composite_bwd")
+            if g_hitlen is not None:      # vert_hit_length is the trace's len itself (Aggregation.py:107)
+                g_len = g_len + _dev(g_hitlen, torch.float32, "grad_hit_length")
+            g_ray = torch.empty_like(rays) if ctx.needs_input_grad[4] else None
+            g0, g1 = torch.empty_like(p0), torch.empty_like(p1)
+            if mode == 2:
+                nbytes = lib.voge_trace_bwd_iso_workspace_bytes(B * N)
+                ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+                rc = lib.voge_trace_bwd_iso_view(_p(p0), _p(p1), _p(ctx.origin), int(shared), sigma_mode, _p(rays), _p(sel_idx),
+                                                 _p(cnt), _p(g_len), _p(g_act), _p(g_dsd), B, N, B * H, W, K, _p(ws), nbytes,
+                                                 _p(g_ray), _p(g0), _p(g1), _stream())
+            elif mode == 1:
+                nbytes = lib.voge_trace_bwd_iso_workspace_bytes(B * N)
+                ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+                rc = lib.voge_trace_bwd_iso(_p(p0), _p(p1), _p(rays), _p(sel_idx), _p(cnt), _p(g_len), _p(g_act), _p(g_dsd), B * N,
+                                            B * H, W, K, _p(ws), nbytes, _p(g_ray), _p(g0), _p(g1), _stream())
+            else:
+                nbytes = lib.voge_trace_bwd_workspace_bytes(B * N)
+                ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+                rc = lib.voge_trace_bwd(_p(p0), _p(p1), _p(rays), _p(sel_idx), _p(cnt), _p(g_len), _p(g_act), _p(g_dsd), B * N,
+                                        B * H, W, K, _p(ws), nbytes, _p(g_ray), _p(g0), _p(g1), _stream())
+        _lib.check(rc, "voge_trace_bwd")
+        return None, g0, g1, None, g_ray, None, None, None, None, None
+
+
+def fragments(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode=0, occ=1.0):
+    return _Fragments.apply(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode, occ)
+
+
 class _Composite(torch.autograd.Function):
     """Fused replacement of get_cross_activation + assign2weight (VoGE/Aggregation.py:30-79)
     and of their autograd backward.  (sel_idx, sel_act, sel_len, sel_dsd, occ) -> weight, valid_num."""
