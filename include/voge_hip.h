@@ -160,6 +160,20 @@ int voge_trace_bwd_iso_view(const float *verts, const float *sigmas, const float
                             float *g_verts, float *g_sigmas, voge_stream_t stream);
 
 /*
+ * The reference's coarse stage, for callers that want ITS candidate lists (the default render path does
+ * not need them: see voge_trace_topk_fwd).  Replaces: VoGE._C.rasterize_points_coarse
+ * (rasterize_coarse.h:18-25; rasterize_coarse.cu:20-42,44-188,254-305): points [P,3] f32 = (x_ndc, y_ndc,
+ * view z), radius [P,2] f32 (half extents in NDC units), cloud_to_packed_first_idx / num_points_per_cloud
+ * [B] int64 -> bin_elems [B,BH,BW,M] int32, -1 padded (BH = 1 + (H-1)/bin_size, BW likewise; both < 66).
+ * A point is listed in every bin its bbox overlaps (half-pixel pad), unless z < 0; points are taken in
+ * chunks of 512 and a chunk that no longer fits a bin's M slots is dropped.  Unlike the reference the
+ * chunks are taken in ascending order: lists are ascending in index and deterministic.
+ */
+int voge_bin_gaussians(const float *points, const int64_t *cloud_to_packed_first_idx,
+                       const int64_t *num_points_per_cloud, int B, int P, int H, int W, const float *radius,
+                       int bin_size, int max_points_per_bin, int32_t *bin_elems, voge_stream_t stream);
+
+/*
  * Fine trace + composite in ONE call: what GaussianRenderer.forward asks for (VoGE/Renderer.py:139-150:
  * ray_tracing, then aggregation -> Fragments).  Replaces the pair
  *   VoGE._C.ray_trace_voge_fine (ray_trace_voge.cu:135-280)  +  `aggregation` (VoGE/Aggregation.py:82-107)

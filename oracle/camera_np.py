@@ -73,6 +73,25 @@ def look_at_view_transform(dist=1.0, elev=0.0, azim=0.0, degrees=True, at=(0, 0,
     return R.astype(np.float32), T.astype(np.float32)
 
 
+def look_at_rotation(camera_position, at=(0, 0, 0), up=(0, 1, 0)):
+    """PyTorch3D's look_at_rotation (same published convention as look_at_view_transform above): R with columns
+    x = norm(up x z), y = norm(z x x), z = norm(at - C); a degenerate x (up parallel to z) is replaced by norm(y x z).
+    Restated from the documentation: PyTorch3D is absent here, so this row stays "parity unpinned"."""
+    C = np.asarray(camera_position, np.float64).reshape(-1, 3)
+    at = np.broadcast_to(np.asarray(at, np.float64).reshape(-1, 3), C.shape)
+    up = np.broadcast_to(np.asarray(up, np.float64).reshape(-1, 3), C.shape)
+
+    def nrm(v):
+        return v / np.maximum(np.linalg.norm(v, axis=-1, keepdims=True), 1e-5)
+    z = nrm(at - C)
+    x = nrm(np.cross(up, z))
+    y = nrm(np.cross(z, x))
+    bad = np.all(np.isclose(x, 0, atol=5e-3), axis=-1)
+    if bad.any():
+        x[bad] = nrm(np.cross(y, z))[bad]
+    return np.stack([x, y, z], axis=-1)
+
+
 def expand_sigma(sigma):
     """Aggregation.py:144-175 without a rotation: (N,)->s*I, (N,3)->diag, (N,3,3) passthrough."""
     sigma = np.asarray(sigma)

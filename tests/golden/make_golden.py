@@ -170,6 +170,130 @@ def gen_trace_known_answer():
     print("known answer:", mu.grad.tolist(), isg.grad.tolist(), ray.grad.tolist())
 
 
+def gen_converters_more(Cub, Conv):
+    """cuboid_mesh (Cuboid.py:70-159, arrays form) and normal_mesh_converter (Converters.py:35-71).  The latter
+    calls pytorch3d's look_at_rotation, which is absent here: the generator hands the reference the oracle's
+    restatement of it (oracle/camera_np.look_at_rotation), so the fixture pins the converter's own arithmetic
+    (edge lengths, sigma scale, R diag(1,1,shape_ratio) R^T, auto_fix, max_sig_rate) and leaves the PyTorch3D
+    convention itself "unpinned", as everywhere."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import camera_np
+    out = {}
+    v, f = Cub.cuboid_mesh((-1, 1), (-1, 1), (-1, 1), 1000)
+    out["mesh_verts"], out["mesh_faces"] = v, f.astype(np.int32)
+    v2, f2, c2 = Cub.cuboid_mesh((-1, 2), (0, 1), (-0.5, 0.5), 300, colors=np.arange(18.).reshape(6, 3))
+    out["mesh2_verts"], out["mesh2_faces"], out["mesh2_colors"] = v2, f2.astype(np.int32), c2
+    Conv.look_at_rotation = lambda pos: torch.from_numpy(camera_np.look_at_rotation(pos.numpy()).astype(np.float32))
+    rng = np.random.default_rng(11)
+    nrm = rng.normal(size=v2.shape)
+    nrm[3] = [0.0, 1.0, 0.0]          # up-parallel normal: the degenerate branch of look_at_rotation
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    vv, isg, rad = Conv.normal_mesh_converter(v2.astype(np.float64), f2, nrm.astype(np.float32), percentage=0.6, shape_ratio=0.3)
+    assert rad is None
+    out["nm_normals"], out["nm_isigma"] = nrm.astype(np.float32), isg
+    _, isg2, _ = Conv.normal_mesh_converter(v2.astype(np.float64), f2, nrm.astype(np.float32), percentage=0.5, shape_ratio=0.5,
+                                            max_sig_rate=1.5)
+    out["nm_isigma_capped"] = isg2
+    np.savez_compressed(os.path.join(OUT, "converters_more.npz"), **out)
+    print("cuboid_mesh", v.shape, f.shape, "normal_mesh isigma", isg.shape, float(np.abs(isg).max()))
+
+
+def gen_host_logic(Ren):
+    """The reference's own host logic around the fine kernel, RUN: GaussianRenderer.forward (Renderer.py:102-150) and
+    ray_tracing (RayTracing.py:12-30) execute here with
+      * VoGE._C.ray_trace_voge_fine replaced by a recorder that keeps the arguments the reference passes to its
+        kernel (centred means, 2*sigma / 2*inverse, rays, the "-1" candidate list, thr_act, bin_size, K) and answers
+        with the oracle's trace on exactly those arguments (explicit bin list), and
+      * a stand-in ray sampler (oracle/camera_np.pixel_rays: the PyTorch3D convention itself stays unpinned).
+    The fixture holds the inputs, the recorded kernel arguments and the Fragments the reference's aggregation made.
+    (Image heights do not exceed the widths: the "-1" list is built as [B, BW, BW, P] -- point_idx_size[1] twice,
+    RayTracing.py:25 -- so a taller-than-wide image would make the reference's own kernel read past its rows.)"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import oracle
+    from oracle import camera_np
+    import VoGE.RayTracing as RT
+    rec = {}
+
+    def fake_fine(mus, isigmas, rays, bin_points, thr_act, bin_size, K):
+        rec.update(mus=mus.numpy().copy(), isigmas=isigmas.numpy().copy(), rays=rays.numpy().copy(), thr_act=float(thr_act),
+                   bin_size=int(bin_size), K=int(K), bin_shape=np.array(bin_points.shape), bin_dtype=str(bin_points.dtype))
+        B, P = rays.shape[0], mus.shape[0]
+        want = (torch.arange(P // B).view(1, 1, 1, -1) + torch.arange(B).view(-1, 1, 1, 1) * (P // B)).expand(bin_points.shape)
+        rec["bin_is_arange_plus_bP"] = bool(torch.equal(bin_points.long(), want))
+        o = oracle.trace_fwd(mus.numpy(), isigmas.numpy(), rays.numpy(), K, thr_act, bin_points=bin_points.numpy(),
+                             bin_size=bin_size, precision="f32")
+        return tuple(torch.from_numpy(np.ascontiguousarray(x)) for x in o)
+    RT._C.ray_trace_voge_fine = fake_fine
+
+    class Bundle:
+        pass
+
+    class Sampler:
+        def __init__(self, image_width, image_height, unit_directions, n_pts_per_ray, min_depth, max_depth):
+            assert unit_directions and n_pts_per_ray == 1
+            self.size = (image_height, image_width)
+
+        def __call__(self, cameras):
+            d, o = camera_np.pixel_rays(cameras.R.numpy(), cameras.T.numpy(), cameras.focal_length.numpy(),
+                                        cameras.principal_point.numpy(), self.size)
+            b = Bundle()
+            b.directions = torch.from_numpy(d)
+            b.origins = torch.from_numpy(o.astype(np.float32))[:, None, None, :].expand(-1, self.size[0], self.size[1], -1)
+            return b
+    Ren.NDCMultinomialRaysampler = Sampler
+
+    class Cams:
+        device = "cpu"
+
+        def __init__(self, focal, pp):
+            self.focal_length = torch.tensor(focal, dtype=torch.float32).reshape(1, -1)
+            self.principal_point = torch.tensor(pp, dtype=torch.float32).reshape(1, 2)
+            self.R = self.T = None
+
+        def in_ndc(self):
+            return False
+
+        def to(self, device):
+            return self
+
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = {
+        "a": dict(N=300, size=(40, 48), K=8, B=1, sig="scalar", inv=False, thr=0.01, occ=1.0),
+        "b": dict(N=200, size=(30, 44), K=5, B=2, sig="full", inv=True, thr=0.0, occ=1.3),
+    }
+    for name, c in cases.items():
+        N, (H, W), B = c["N"], c["size"], c["B"]
+        verts = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+        r = rng.uniform(0.1, 0.25, N)
+        s = (1.0 / (r * r / (2 * np.log(1 / 0.6)))).astype(np.float32)
+        if c["sig"] == "full":      # inverse_sigma=True: the user passes covariances, the renderer inverts
+            L = np.tril(rng.uniform(-1, 1, (N, 3, 3)))
+            L[:, [0, 1, 2], [0, 1, 2]] = np.abs(L[:, [0, 1, 2], [0, 1, 2]]) + 0.5
+            sig = ((L @ L.transpose(0, 2, 1)) / s[:, None, None]).astype(np.float32)
+        else:
+            sig = s
+        R, T = camera_np.look_at_view_transform([3.0] * B, [10.0, -20.0][:B], [30.0, 140.0][:B])
+        focal, pp = 0.9 * max(H, W), (W / 2.0 + 1.5, H / 2.0 - 0.5)
+        st = Ren.GaussianRenderSettings(image_size=(H, W), max_assign=c["K"], thr_activation=c["thr"], absorptivity=c["occ"],
+                                        inverse_sigma=c["inv"], max_point_per_bin=-1)
+        renderer = Ren.GaussianRenderer(Cams([focal], pp), st)
+        gm = lambda v=verts, g=sig: (torch.from_numpy(v), torch.from_numpy(g), None)
+        rec.clear()
+        frag = renderer(gm, R=torch.from_numpy(R), T=torch.from_numpy(T))
+        assert rec["bin_is_arange_plus_bP"]
+        out.update({f"{name}_verts": verts, f"{name}_sigmas": sig, f"{name}_R": R, f"{name}_T": T, f"{name}_focal": focal,
+                    f"{name}_pp": np.array(pp), f"{name}_size": np.array([H, W]), f"{name}_K": c["K"], f"{name}_thr": c["thr"],
+                    f"{name}_occ": c["occ"], f"{name}_inverse_sigma": c["inv"],
+                    f"{name}_k_mus": rec["mus"], f"{name}_k_isigmas": rec["isigmas"], f"{name}_k_thr_act": rec["thr_act"],
+                    f"{name}_k_bin_size": rec["bin_size"], f"{name}_k_bin_shape": rec["bin_shape"],
+                    f"{name}_weight": frag.vert_weight.numpy(), f"{name}_index": frag.vert_index.numpy(),
+                    f"{name}_valid_num": frag.valid_num.numpy(), f"{name}_hit_length": frag.vert_hit_length.numpy()})
+        print("host logic", name, "bin_size", rec["bin_size"], "thr_act", rec["thr_act"], "bin list", rec["bin_shape"],
+              rec["bin_dtype"], "hits", int((frag.vert_index >= 0).sum()))
+    np.savez_compressed(os.path.join(OUT, "host_logic.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     mods = import_reference()
@@ -177,3 +301,5 @@ if __name__ == "__main__":
     gen_merge_blend(mods[0], mods[1])
     gen_misc(*mods)
     gen_trace_known_answer()
+    gen_converters_more(mods[2], mods[3])
+    gen_host_logic(mods[1])

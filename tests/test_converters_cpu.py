@@ -61,3 +61,32 @@ def test_off_goff_round_trip(tmp_path):
         IO.save_goff(str(tmp_path / "g.goff"), v, sig, radians=rng.uniform(size=7).astype(np.float32))
         p, s, r = IO.load_goff(str(tmp_path / "g.goff"))
         assert np.allclose(p, v) and np.allclose(np.squeeze(s), sig) and r.shape == (7,)
+
+
+def test_cuboid_mesh_and_normal_mesh_converter_match_reference():
+    """VoGE/Converter/Cuboid.py:70-159 and Converters.py:35-71 against fixtures the imported reference produced
+    (tests/golden/make_golden.py: gen_converters_more; look_at_rotation there is the oracle's restatement of the
+    PyTorch3D function, here it is voge_amd.cameras.look_at_rotation)."""
+    from VoGE.Converter.Converters import naive_vertices_converter, normal_mesh_converter   # the demos' import line
+    from VoGE.Converter.Cuboid import cuboid_gauss, cuboid_mesh                              # noqa: F401
+    g = np.load(os.path.join(GOLDEN, "converters_more.npz"))
+    v, f = cuboid_mesh((-1, 1), (-1, 1), (-1, 1), 1000)
+    assert np.array_equal(v, g["mesh_verts"]) and np.array_equal(f, g["mesh_faces"])
+    v2, f2, c2 = cuboid_mesh((-1, 2), (0, 1), (-0.5, 0.5), 300, colors=np.arange(18.).reshape(6, 3))
+    assert np.array_equal(v2, g["mesh2_verts"]) and np.array_equal(f2, g["mesh2_faces"]) and np.array_equal(c2, g["mesh2_colors"])
+    assert f2.max() < len(v2) and (np.bincount(f2.ravel(), minlength=len(v2)) > 0).all()      # every vertex is in a face
+    vv, isg, rad = normal_mesh_converter(v2.astype(np.float64), f2, g["nm_normals"], percentage=0.6, shape_ratio=0.3)
+    assert rad is None and isg.shape == (len(v2), 3, 3)
+    scale = np.abs(g["nm_isigma"]).max()
+    assert np.abs(isg - g["nm_isigma"]).max() < 2e-6 * scale
+    # the normal is the flattened axis: n^T A n = shape_ratio * s, any tangent t: t^T A t = s
+    n = g["nm_normals"].astype(np.float64)
+    s_iso = naive_vertices_converter(v2.astype(np.float64), f2, percentage=0.6)[1]
+    ratio = np.einsum("ni,nij,nj->n", n, isg, n) / s_iso
+    assert np.abs(np.delete(ratio, 3) / 0.3 - 1).max() < 1e-4
+    # vertex 3's normal is parallel to `up`: look_at_rotation degenerates, det = 0, auto_fix makes it isotropic (:61-63)
+    assert abs(ratio[3] - 1) < 1e-6
+    _, capped, _ = normal_mesh_converter(v2.astype(np.float64), f2, g["nm_normals"], percentage=0.5, shape_ratio=0.5, max_sig_rate=1.5)
+    assert np.abs(capped - g["nm_isigma_capped"]).max() < 2e-6 * scale
+    vt, it, _ = normal_mesh_converter(torch.from_numpy(v2).float(), torch.from_numpy(f2), torch.from_numpy(g["nm_normals"]))
+    assert it.dtype == torch.float32 and it.shape == (len(v2), 3, 3)

@@ -130,3 +130,95 @@ def test_texture_extraction_demo(hip_lib):
     assert float(r["seen"].float().mean()) > 0.9
     assert r["mean_abs_err"] < 0.03, r["mean_abs_err"]
     assert torch.isfinite(r["novel"]).all() and float((r["novel"] < 0.99).float().mean()) > 0.1
+
+
+# ------------------------------------------------------------------------------- f-1: the coarse stage's semantics
+def _scene_inputs(sc):
+    R, T = camera_np.look_at_view_transform(sc["dist"], sc["elev"], sc["azim"])
+    rays, origin = camera_np.pixel_rays(R, T, sc["focal"], sc["principal"], sc["image_size"])
+    mus = (sc["verts"][None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = (2 * camera_np.expand_sigma(sc["sigmas"])).astype(np.float32)[None]
+    return R, T, rays, mus, isg
+
+
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2"])
+def test_default_settings_equal_the_reference_candidate_semantics(hip_lib, cfg):
+    """BASELINE configs 1 and 2 with the DEFAULT max_point_per_bin=None (what demo Quick Start / RenderBunny use).  The
+    reference then takes its candidates from the coarse stage: convert_to_box + bbox/bin overlap + skip z < 0, M =
+    min(max(10 K, N/10), N) per bin (RayTracing.py:18-19,33-73; rasterize_coarse.cu:20-188), restated in
+    oracle/coarse_np.py.  This path culls conservatively inside the trace instead.  Compared: the HIP frame against the
+    oracle run on the REFERENCE's candidate lists -- number of pixels whose index list differs, largest image
+    difference -- and the same against the oracle on ALL candidates (the two oracles agree exactly on these scenes:
+    no bin overflows, nothing behind the camera, the boxes cover the hit regions)."""
+    from oracle import coarse_np
+    from util import bunny_scene, _report_flips
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
+    from voge_amd.cameras import PerspectiveCameras
+    sc = cuboid_scene() if cfg == "cfg1" else bunny_scene()
+    R, T, rays, mus, isg = _scene_inputs(sc)
+    K, size = sc["K"], sc["image_size"]
+    bins, bs = coarse_np.reference_candidate_lists(mus, isg, R, T, sc["focal"], sc["principal"], size, 0.01, K)
+    thr_act = oracle.thr_act_of(0.01)
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act, bin_points=bins, bin_size=bs)
+    allc = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    assert (ref[0] == allc[0]).all(), "the reference's coarse lists lose a candidate on this scene"
+    assert (bins >= 0).sum(-1).max() < bins.shape[-1]                     # no bin is full: nothing was dropped
+    w, vn = oracle.composite_fwd(ref[0], ref[2], ref[1], ref[3], 1.0)
+    img_ref, _ = oracle.blend_fwd(oracle.merge_fwd(sc["colors"], ref[0], w, vn), w)
+    cams = PerspectiveCameras(focal_length=sc["focal"], principal_point=(sc["principal"],), image_size=(size,), device=DEV)
+    renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=size, max_assign=K)).to(DEV)       # max_point_per_bin=None
+    frag = renderer(GaussianMeshes(t(sc["verts"]), t(sc["sigmas"])).to(DEV), R=t(R), T=t(T))
+    img = to_white_background(frag, t(sc["colors"]))
+    same = (n(frag.vert_index) == np.where(ref[0] < 0, 0, ref[0])).all(-1)
+    _report_flips(f"{cfg} default bins vs reference candidate lists", (~same).sum(), same.size)
+    diff = np.abs(n(img) - img_ref).max()
+    print(f"[parity] {cfg} default settings: largest image difference to the reference-candidate oracle {diff:.2e}")
+    assert (~same).sum() <= (10 if cfg == "cfg1" else 100) and diff < 0.05
+    assert np.abs(n(img)[same] - img_ref[same]).max() < TOL
+
+
+def test_reference_coarse_lists_exact_mode(hip_lib):
+    """voge_bin_gaussians (= VoGE._C.rasterize_points_coarse) on the oracle's projected points is the oracle's list,
+    element for element -- including a bin capacity small enough to drop chunks; the torch statement of the projection
+    (RayTracing.rasterize_coarse) matches the oracle's; and REFERENCE_CANDIDATES = True renders with those lists."""
+    from oracle import coarse_np
+    from util import bunny_scene
+    import voge_amd.RayTracing as RT
+    from voge_amd import ops
+    sc = bunny_scene()
+    R, T, rays, mus, isg = _scene_inputs(sc)
+    size, K = sc["image_size"], sc["K"]
+    pts, rad = coarse_np.project_for_coarse(mus, isg, R, T, sc["focal"], sc["principal"], size, 0.01)
+    first, num = np.zeros(1, np.int64), np.full(1, mus.shape[1], np.int64)
+    for M in (817, 60):
+        want = coarse_np.rasterize_points_coarse(pts.reshape(-1, 3), first, num, size, rad.reshape(-1, 2), 10, M)
+        got = n(ops.rasterize_points_coarse(t(pts.reshape(-1, 3)), t(first, torch.int64), t(num, torch.int64), size,
+                                            t(rad.reshape(-1, 2)), 10, M))
+        assert np.array_equal(got, want), M
+    assert ((want >= 0).sum(-1) < (coarse_np.rasterize_points_coarse(pts.reshape(-1, 3), first, num, size, rad.reshape(-1, 2), 10, 817) >= 0).sum(-1)).any()
+    # the host's projection against the oracle's
+    from voge_amd.cameras import PerspectiveCameras
+    cams = PerspectiveCameras(focal_length=sc["focal"], principal_point=(sc["principal"],), image_size=(size,), R=R, T=T, device=DEV)
+    bins = n(RT.rasterize_coarse(cams, t(mus), t(isg), size, 0.01, 10, 817))
+    ref_bins = coarse_np.rasterize_points_coarse(pts.reshape(-1, 3), first, num, size, rad.reshape(-1, 2), 10, 817)
+    assert (bins != ref_bins).any(-1).mean() < 0.02          # fp32 torch vs fp64 numpy projection: a bbox edge on a bin border
+    # rendering with the reference's (here: lossy, M = 60) lists: the list kernel on them equals the oracle on them
+    thr_act = oracle.thr_act_of(0.01)
+    lossy = coarse_np.rasterize_points_coarse(pts.reshape(-1, 3), first, num, size, rad.reshape(-1, 2), 10, 60)
+    from util import compare_trace
+    got = [n(x) for x in ops.ray_trace_fine(t(mus).reshape(-1, 3), t(isg).reshape(-1, 3, 3), t(rays), t(lossy, torch.int32), thr_act, 10, K)]
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act, bin_points=lossy, bin_size=10)
+    compare_trace(got, ref, thr_act, min_match=0.995, label="reference coarse lists (M=60) through the list kernel")
+    full = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    assert ((ref[0] != full[0]).any(-1)).mean() > 0.01       # ... and they DO lose candidates: the reference's documented drop
+    RT.REFERENCE_CANDIDATES = True
+    try:
+        from voge_amd.Meshes import GaussianMeshes
+        from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings
+        renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=size, max_assign=K, max_point_per_bin=60)).to(DEV)
+        frag = renderer(GaussianMeshes(t(sc["verts"]), t(sc["sigmas"])).to(DEV), R=t(R), T=t(T))
+        same = (n(frag.vert_index) == ref[0]).all(-1)
+        assert same.mean() > 0.97
+    finally:
+        RT.REFERENCE_CANDIDATES = False

@@ -786,3 +786,32 @@ def test_fused_fragments_equal_trace_then_composite(hip_lib, mode, K):
         assert np.array_equal(x, y), name
     for x, y, name in zip(a[4:], b_[4:], ("d/d means", "d/d sigmas")):
         assert np.abs(x - y).max() <= 2e-5 * max(1.0, np.abs(y).max()), name
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_renderer_against_the_running_reference_host_logic(hip_lib, case):
+    """tests/golden/host_logic.npz (the imported reference's GaussianRenderer.forward + ray_tracing run with a recording
+    stand-in for its CUDA kernel, answered by the oracle): this renderer, given the same (verts, sigmas, R, T, camera,
+    settings), returns the same Fragments -- scalar sigmas, and full covariances with inverse_sigma=True on two views."""
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings
+    from voge_amd.cameras import PerspectiveCameras
+    g = np.load(os.path.join(GOLDEN, "host_logic.npz"))
+    c = case
+    H, W = (int(x) for x in g[c + "_size"])
+    cams = PerspectiveCameras(focal_length=float(g[c + "_focal"]), principal_point=(tuple(g[c + "_pp"].tolist()),),
+                              image_size=((H, W),), device=DEV)
+    st = GaussianRenderSettings(image_size=(H, W), max_assign=int(g[c + "_K"]), thr_activation=float(g[c + "_thr"]),
+                                absorptivity=float(g[c + "_occ"]), inverse_sigma=bool(g[c + "_inverse_sigma"]), max_point_per_bin=-1)
+    renderer = GaussianRenderer(cams, st).to(DEV)
+    gm = GaussianMeshes(t(g[c + "_verts"]), t(g[c + "_sigmas"])).to(DEV)
+    frag = renderer(gm, R=t(g[c + "_R"]), T=t(g[c + "_T"]))
+    idx = n(frag.vert_index)
+    same = (idx == g[c + "_index"]).all(-1)
+    from util import _report_flips
+    _report_flips(f"host logic {case}", (~same).sum(), same.size)
+    assert (~same).sum() <= 0.004 * same.size            # the reference's kernel stand-in computes in fp32: boundary flips
+    assert (n(frag.valid_num)[same] == g[c + "_valid_num"][same]).all()
+    assert np.abs(n(frag.vert_weight)[same] - g[c + "_weight"][same]).max() < 3e-4
+    hit = (g[c + "_index"] >= 0) & same[..., None]
+    assert np.abs(n(frag.vert_hit_length)[hit] - g[c + "_hit_length"][hit]).max() < 4e-4

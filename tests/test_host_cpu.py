@@ -98,3 +98,39 @@ def test_row_bands_partition_the_image():
             assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
             sizes = [b[1] - b[0] for b in bands]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_host_logic_against_the_running_reference():
+    """tests/golden/host_logic.npz: GaussianRenderer.forward (Renderer.py:102-150) and ray_tracing (RayTracing.py:12-30)
+    of the IMPORTED reference were run with a recording stand-in for _C.ray_trace_voge_fine.  What the reference handed
+    its kernel -- bin_size, thr_act, the shape of the "-1" list, camera-centred means, 2*sigma / 2*inverse(sigma) --
+    equals what this repo's host rules and its oracle produce, and the oracle's frame reproduces the Fragments the
+    reference's aggregation made from the recorded call."""
+    import oracle
+    from oracle import camera_np
+    from voge_amd.RayTracing import default_bin_size
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_logic.npz"))
+    for c in ("a", "b"):
+        H, W = (int(x) for x in g[c + "_size"])
+        K, thr, occ = int(g[c + "_K"]), float(g[c + "_thr"]), float(g[c + "_occ"])
+        assert default_bin_size((H, W)) == int(g[c + "_k_bin_size"])
+        assert abs(oracle.thr_act_of(thr) - float(g[c + "_k_thr_act"])) < 1e-12
+        B, N = g[c + "_R"].shape[0], g[c + "_verts"].shape[0]
+        bs = int(g[c + "_k_bin_size"])
+        # the reference sizes both bin axes by the image WIDTH (RayTracing.py:25) and lists all P Gaussians per bin
+        assert tuple(g[c + "_k_bin_shape"]) == (B, (W - 1) // bs + 1, (W - 1) // bs + 1, N)
+        rays, origin = camera_np.pixel_rays(g[c + "_R"], g[c + "_T"], float(g[c + "_focal"]), g[c + "_pp"], (H, W))
+        mus = (g[c + "_verts"][None] - origin[:, None].astype(np.float32)).astype(np.float32)
+        assert np.array_equal(mus.reshape(-1, 3), g[c + "_k_mus"])                       # Renderer.py:130
+        sig = camera_np.expand_sigma(g[c + "_sigmas"])
+        isg = 2 * np.linalg.inv(sig) if bool(g[c + "_inverse_sigma"]) else 2 * sig      # Renderer.py:133-137
+        want = g[c + "_k_isigmas"].reshape(B, N, 3, 3)
+        assert np.abs(isg[None] - want).max() <= 2e-5 * np.abs(want).max()
+        # the frame: oracle trace (fp64) on the recorded kernel arguments -> composite == the reference's aggregation
+        idx, ln, act, dsd = oracle.trace_fwd(g[c + "_k_mus"], g[c + "_k_isigmas"], rays, K, float(g[c + "_k_thr_act"]))
+        w, vn = oracle.composite_fwd(idx, act, ln, dsd, occ)
+        same = (idx == g[c + "_index"]).all(-1)
+        assert same.mean() > 0.995 and (vn[same] == g[c + "_valid_num"][same]).all()
+        assert np.abs(w[same] - g[c + "_weight"][same]).max() < 2e-4
+        hit = (idx >= 0) & same[..., None]
+        assert np.abs(ln[hit] - g[c + "_hit_length"][hit]).max() < 1e-4 * 4

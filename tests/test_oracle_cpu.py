@@ -204,3 +204,46 @@ def test_next_row_restatements_are_self_consistent():
     g_img, g_w = extras_np.sample_voge_bwd(image, w, ix, gF, gW)
     assert abs((feat * gF).sum() - (image * g_img).sum()) < 1e-10          # linear in image
     assert abs((feat * gF).sum() + (wsum * gW).sum() - (w * g_w).sum()) < 1e-10  # and in w
+
+
+def test_coarse_stage_restatement():
+    """oracle/coarse_np.py (RayTracing.py:33-73, rasterize_coarse.cu:20-188): the bin test against a direct per-bin
+    evaluation, the half-pixel pad, the z < 0 skip, ascending lists, and the chunk-drop overflow rule."""
+    from oracle import coarse_np
+    rng = np.random.default_rng(0)
+    P, H, W, bs = 1300, 50, 70, 10
+    pts = np.stack([rng.uniform(-1.6, 1.6, P), rng.uniform(-1.2, 1.2, P), rng.uniform(-0.5, 4, P)], 1).astype(np.float32)
+    rad = rng.uniform(0.01, 0.3, (P, 2)).astype(np.float32)
+    rad[5] = np.nan                                                     # negative column sum in convert_to_box
+    first, num = np.array([0, 700], np.int64), np.array([700, 600], np.int64)
+    bins = coarse_np.rasterize_points_coarse(pts, first, num, (H, W), rad, bs, 2000)
+    assert bins.shape == (2, 5, 7, 2000)
+    # direct evaluation of one bin: NDC x range is 2 * W / H wide (W > H), pixel centres at half-pixel offsets
+    by, bx = 2, 4
+    xr, yr = 2.0 * W / H, 2.0
+    x0, x1 = -xr / 2 + xr * (bx * bs) / W, -xr / 2 + xr * ((bx + 1) * bs) / W
+    y0, y1 = -yr / 2 + yr * (by * bs) / H, -yr / 2 + yr * ((by + 1) * bs) / H
+    e = np.arange(700)
+    with np.errstate(invalid="ignore"):
+        hit = ((pts[e, 0] - rad[e, 0] <= x1 + 1e-6) & (x0 - 1e-6 < pts[e, 0] + rad[e, 0]) & (pts[e, 1] - rad[e, 1] <= y1 + 1e-6)
+               & (y0 - 1e-6 < pts[e, 1] + rad[e, 1]) & ~(pts[e, 2] < 0))
+    got = bins[0, by, bx]
+    got = got[got >= 0]
+    assert np.array_equal(got, np.sort(got)) and set(got.tolist()) <= set(e[hit].tolist())
+    assert len(set(e[hit].tolist()) - set(got.tolist())) <= 2          # (only the 1e-6 slack of this check)
+    assert 5 not in bins[0] and (bins[1][bins[1] >= 0] >= 700).all()   # NaN radius never listed; batch 1 lists its own points
+    assert not np.isin(np.nonzero(pts[:, 2] < 0)[0], bins).any()
+    # overflow: a bin holds M = 40 entries; the chunk (512 points) that does not fit is dropped entirely
+    small = coarse_np.rasterize_points_coarse(pts, first, num, (H, W), rad, bs, 40)
+    full_cnt, small_cnt = (bins[0] >= 0).sum(-1), (small[0] >= 0).sum(-1)
+    assert (small_cnt <= full_cnt).all() and (small_cnt < full_cnt).any()
+    chunk0 = (bins[0] >= 0) & (bins[0] < 512)
+    fits = chunk0.sum(-1) <= 40
+    assert ((small_cnt >= chunk0.sum(-1)) | ~fits).all()               # the first chunk is kept whenever it fits
+    # projection: an isotropic Gaussian straight ahead projects to the principal point with radius sqrt(-ln thr / a) f 2/s / Z
+    R, T = np.eye(3)[None], np.array([[0.0, 0.0, 4.0]])
+    p, r = coarse_np.project_for_coarse(np.array([[[0.0, 0.0, 4.0], [0.4, 0.0, 4.0]]]), np.eye(3)[None, None] * np.array([50.0, 50.0])[None, :, None, None],
+                                        R, T, 100.0, (35.0, 25.0), (50, 70), 0.01)
+    assert np.allclose(p[0, 0], [(35 - 35) * 2 / 50, (25 - 25) * 2 / 50, 4.0])
+    assert np.allclose(p[0, 1, 0], (35 - 100 * 0.4 / 4 - 35) * 2 / 50)              # +X is left: the column decreases
+    assert np.allclose(r[0, 0], np.sqrt(-np.log(0.01) / 50.0) * 100 * 2 / 50 / 4.0, rtol=1e-5)

@@ -49,6 +49,34 @@ def naive_vertices_converter(vertices, faces, percentage=0.5, max_sig_rate=-1):
     return vertices, isigma, None
 
 
+def normal_mesh_converter(vertices, faces, normals, percentage=0.5, shape_ratio=0.5, max_sig_rate=-1, auto_fix=True):
+    """One Gaussian per mesh vertex, flattened along the vertex normal (Converters.py:35-71): in the frame whose third
+    axis is the normal, Sigma^-1 = s * diag(1, 1, shape_ratio) with s the isotropic scale of naive_vertices_converter;
+    the frame is look_at_rotation(-normal) (third column = normal; PyTorch3D's convention, cameras.look_at_rotation
+    here).  Returns (verts, isigma [n,3,3], None)."""
+    from ..cameras import look_at_rotation
+    is_torch = torch.is_tensor(vertices)
+    if is_torch:
+        vertices, faces = vertices.numpy(), faces.numpy()
+    else:
+        normals = torch.from_numpy(np.asarray(normals))
+    default_l = 10 * np.sum((vertices.max(axis=0) - vertices.min(axis=0)) ** 2) ** 0.5 / vertices.shape[0]
+    base = _iso_from_length(get_vert_edge_length(vertices, faces, default_l), percentage)
+    n2 = (normals ** 2).sum(-1)
+    assert torch.max(n2) < 1.1 and torch.min(n2) > 0.9
+    shape = np.array([[1, 0, 0], [0, 1, 0], [0, 0, shape_ratio]])[None] * base.reshape(-1, 1, 1)
+    rot = look_at_rotation(-normals.type(torch.float32)).numpy()
+    isigma = rot @ shape @ rot.transpose(0, 2, 1)
+    if auto_fix:
+        flat = np.linalg.det(isigma) == 0
+        isigma[flat] = np.eye(3)[None] * base[flat].reshape(-1, 1, 1)
+    if max_sig_rate > 0:
+        isigma = np.minimum(isigma, np.mean(isigma) * max_sig_rate)
+    if is_torch:
+        return torch.from_numpy(vertices).type(torch.float32), torch.from_numpy(isigma).type(torch.float32), None
+    return vertices, isigma, None
+
+
 def fixed_pointcloud_converter(points, radius, percentage=0.5):
     """Isotropic Gaussians of a given radius per point (Converters.py:125-139)."""
     to_np = not torch.is_tensor(points)

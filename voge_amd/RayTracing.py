@@ -10,7 +10,10 @@ all-Gaussians list per bin (max_points_per_bin == -1) or runs a lossy coarse ras
 (bin overflow drops candidates, rasterize_coarse.cu:154-170).  Here every setting runs the
 same exact sweep -- culling happens inside the kernel and is conservative -- and
 max_points_per_bin != -1 only adds the coarse stage's "skip Gaussians behind the camera"
-rule (rasterize_coarse.cu:35).
+rule (rasterize_coarse.cu:35).  On BASELINE configs 1 and 2 that yields the reference's fragments
+exactly (tests/test_gpu_next_rows.py).  REFERENCE_CANDIDATES = True switches to the reference's
+own candidate lists (rasterize_coarse below: its bounding boxes, bins and chunk-overflow drop),
+for scenes where its lossy lists are the behaviour wanted.
 """
 import math
 from typing import Optional
@@ -21,6 +24,9 @@ import torch
 from .ops import _FindNearestK, _RayTraceVoGE, _RayTraceVoGEIso, _RayTraceVoGEIsoView, _RayTraceVoGERay
 
 inf = 1e8
+
+# False: conservative in-kernel culling (+ the "skip z < 0" rule); True: the reference's coarse candidate lists
+REFERENCE_CANDIDATES = False
 
 
 def default_bin_size(image_size):
@@ -34,8 +40,12 @@ def ray_tracing(transforms, points, isigmas, rays, image_size, thr: float, n_ass
     sel_act, sel_dsd, each [B,H,W,n_assign]."""
     if bin_size is None:
         bin_size = default_bin_size(image_size)
+    if max_points_per_bin is None and REFERENCE_CANDIDATES:
+        max_points_per_bin = min(int(max(n_assign * 10, (points.shape[1]) / 10)), points.shape[1])      # RayTracing.py:19
     if max_points_per_bin == -1:
         candidates = None
+    elif REFERENCE_CANDIDATES:
+        candidates = rasterize_coarse(transforms, points, isigmas, image_size, thr, bin_size, max_points_per_bin, **kwargs)
     else:
         # coarse-stage candidate rule kept: view-space z >= 0 (rasterize_coarse.cu:35).  The view
         # axis in the rays' (world-aligned) frame is the third column of R (X_view = X_world @ R + T).
@@ -68,6 +78,49 @@ def ray_tracing_iso_view(transforms, verts, sigmas, origin, rays, image_size, th
     thr_act = -math.log(thr + 1 / inf)
     return _RayTraceVoGEIsoView.apply(verts, sigmas, origin, rays, candidates, thr_act, n_assign,
                                       2 if inverse_sigma else 1)
+
+
+def convert_to_box(isigmas, thr, z, matrix):
+    """RayTracing.py:33-39: per-axis half extents sqrt(colsum(-ln(thr) F A2^-1 F)) * z, A2 the upper-left 2x2 block of
+    the view-space precision (the block's inverse, not the marginal: exact for isotropic A), F = matrix[:, :2, :2]."""
+    get = -np.log(thr) * matrix[:, None, :2, :2] @ torch.inverse(isigmas[:, :, :2, :2]) @ matrix[:, None, :2, :2]
+    return (torch.ones((*isigmas.shape[0:2], 1, 2), device=isigmas.device) @ get).pow(.5).squeeze(2) * z.unsqueeze(-1)
+
+
+def rasterize_coarse(cameras, points, isigmas, image_size, thr, bin_size, max_points_per_bin, cloud_to_point=None,
+                     num_points_per_cloud=None):
+    """The reference's coarse stage (RayTracing.py:42-73): camera-centred points [B,N,3] and A [B,N,3,3] -> candidate
+    lists [B,BH,BW,M] int32.  The PyTorch3D transforms it composes (get_full_projection_transform, then
+    get_ndc_camera_transform, negated) are written out for the screen-space pinhole camera: with view axes +X left /
+    +Y up the centre projects to column px - fx X/Z, row py - fy Y/Z, and the negated NDC is (col - W/2) 2/s,
+    (row - H/2) 2/s, s = min(H, W); F = diag(-2 fx/s, -2 fy/s)."""
+    from . import ops
+    from .cameras import _as_b2
+    B, N = points.shape[0], points.shape[1]
+    dev = points.device
+    R = torch.as_tensor(cameras.R, dtype=torch.float32, device=dev).reshape(-1, 3, 3).expand(B, 3, 3)
+    T = torch.as_tensor(cameras.T, dtype=torch.float32, device=dev).reshape(-1, 3).expand(B, 3)
+    f, pp = _as_b2(cameras.focal_length, B, dev), _as_b2(cameras.principal_point, B, dev)
+    H, W = int(image_size[0]), int(image_size[1])
+    s = float(min(H, W))
+    C = -torch.matmul(torch.inverse(R.transpose(1, 2)), T[:, :, None])                  # :45
+    world = points + C.view(-1, 1, 3)                                                    # :46
+    view = world @ R + T[:, None]                                                         # X_view = X_world R + T
+    z = view[..., 2]
+    cols = pp[:, None, 0] - f[:, None, 0] * view[..., 0] / z
+    rows = pp[:, None, 1] - f[:, None, 1] * view[..., 1] / z
+    points_ndc = torch.stack([(cols - W / 2.0) * (2.0 / s), (rows - H / 2.0) * (2.0 / s), z], dim=-1)      # :50, :57
+    rot = R[:, None].expand(-1, N, -1, -1)
+    isig_view = rot.transpose(2, 3) @ isigmas @ rot                                      # :52-53
+    F = torch.zeros((B, 4, 4), dtype=torch.float32, device=dev)
+    F[:, 0, 0], F[:, 1, 1] = -2.0 * f[:, 0] / s, -2.0 * f[:, 1] / s
+    boxes = convert_to_box(isig_view, thr, 1.0 / z, F)                                   # :55 (z argument = -ndc z = 1/Z)
+    if cloud_to_point is None:
+        cloud_to_point = torch.arange(B, dtype=torch.long, device=dev) * N
+    if num_points_per_cloud is None:
+        num_points_per_cloud = torch.ones(B, dtype=torch.long, device=dev) * N
+    return ops.rasterize_points_coarse(points_ndc.reshape(-1, 3), cloud_to_point, num_points_per_cloud, (H, W),
+                                       boxes.reshape(-1, 2), bin_size, max_points_per_bin)
 
 
 def _view_axis(cameras, points):

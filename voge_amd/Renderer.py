@@ -12,7 +12,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .Aggregation import expend_sigma, merge_final
+from .Aggregation import aggregation, expend_sigma, merge_final
+from . import RayTracing
 from .RayTracing import _view_axis
 from .cameras import pixel_rays
 
@@ -123,6 +124,18 @@ class GaussianRenderer(nn.Module):
         thr_act = -math.log(st['thr_activation'] + 1 / 1e10)                     # RayTracing.py:76,85
         K, occ = st['max_assign'], st['absorptivity']
         behind = st['max_point_per_bin'] != -1      # the coarse stage's "skip z < 0" candidate rule (rasterize_coarse.cu:35)
+        if behind and RayTracing.REFERENCE_CANDIDATES:
+            # the reference's own coarse candidate lists (lossy on purpose): explicit lists, unfused calls
+            sig3 = expend_sigma(sigmas)
+            if sig3.dim() == 3:
+                sig3 = sig3.unsqueeze(0).expand(verts.shape[0] if not shared_verts else origin.shape[0], -1, -1, -1)
+            isigma = 2 * torch.inverse(sig3) if st['inverse_sigma'] else 2 * sig3
+            centred = verts - origin[:, None]
+            sel_idx, sel_len, sel_act, sel_dsd = RayTracing.ray_tracing(
+                cams, centred, isigma.contiguous(), rays, image_size, thr=st['thr_activation'], n_assign=K,
+                max_points_per_bin=st['max_point_per_bin'])
+            weight, index, valid_num, hit_len = aggregation(sel_idx, sel_act, sel_len, sel_dsd, occ)
+            return Fragments(vert_weight=weight, vert_index=index, valid_num=valid_num, vert_hit_length=hit_len)
         if sigmas.dim() == 1 and shared_verts and not origin.requires_grad and FUSED_PREAMBLE:
             # One (verts [N,3], sigmas [N]) set seen by every view, fixed cameras: the centring of
             # Renderer.py:130 and the 2*sigma / 2/sigma of :133-137 happen inside the trace's per-Gaussian

@@ -1,4 +1,6 @@
 // Rows "next" of SURVEY.md §8f that reuse the path's arithmetic:
+//   coarse stage     VoGE/csrc/rasterize_coarse/rasterize_coarse.cu:20-188 (EllipseBoundingBoxKernel +
+//                    RasterizeCoarseCudaKernel): the reference's own candidate lists, for callers that want them
 //   dense ray API    VoGE/csrc/voge_ray_tracing_ray/voge_ray_tracing_ray.cu:114-239
 //                    (RayTraceVogeRayKernel, RayTraceVogeRayBackwardKernel, FindNearestKKernel)
 //   scatter_max      VoGE/csrc/sample_voge/sample_voge.cu:69-92 (ScatterMaxKernel)
@@ -175,6 +177,74 @@ static inline unsigned flat_grid(long items) {
   return (unsigned)b;
 }
 
+// ---- the reference's coarse stage (rasterize_points_coarse): bbox = centre -+ radius, skipped when z < 0
+// (rasterize_coarse.cu:20-42); a point is listed in every bin its bbox overlaps, bins padded by half a pixel
+// (:111-135); points are taken in chunks of 512 and a chunk that no longer fits a bin's M slots is dropped while the
+// bin's counter still advances (:154-170).  One workgroup per (bin, batch element) walks the chunks in ascending
+// order, so the lists are ascending in index and deterministic -- the reference's order between chunks is whatever
+// its atomicAdd race produced.  NaN radii (negative column sums in convert_to_box) never overlap, as there.
+__device__ inline float ndc_range(const int S1, const int S2) {      // rasterization_utils.cuh:15-23
+  float range = 2.0f;
+  if (S1 > S2) range = (S1 * range) / S2;
+  return range;
+}
+__device__ inline float pix_to_ndc(const int i, const int S1, const int S2) {      // rasterization_utils.cuh:36-42
+  const float range = ndc_range(S1, S2);
+  const float offset = range / 2.0f;
+  return -offset + (range * i + offset) / S1;
+}
+
+constexpr int kCoarseChunk = 512;
+
+__global__ void __launch_bounds__(256)
+coarse_bin_kernel(const float *__restrict__ points /* [P,3] */, const float *__restrict__ radius /* [P,2] */,
+                  const int64_t *__restrict__ first_idx, const int64_t *__restrict__ num_points, const int P, const int H,
+                  const int W, const int bin_size, const int M, int32_t *__restrict__ bin_elems /* [B,BH,BW,M], -1 filled here */) {
+  __shared__ int wcnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nbx = 1 + (W - 1) / bin_size;
+  const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx, b = blockIdx.y;
+  int32_t *out = bin_elems + ((size_t)b * gridDim.x + blockIdx.x) * M;
+  const float half_x = ndc_range(W, H) / 2.0f / W, half_y = ndc_range(H, W) / 2.0f / H;
+  const float bin_x_min = pix_to_ndc(bx * bin_size, W, H) - half_x, bin_x_max = pix_to_ndc((bx + 1) * bin_size - 1, W, H) + half_x;
+  const float bin_y_min = pix_to_ndc(by * bin_size, H, W) - half_y, bin_y_max = pix_to_ndc((by + 1) * bin_size - 1, H, W) + half_y;
+  const long e0 = first_idx[b], e1 = e0 + num_points[b];
+  int run = 0;      // the bin's counter (elems_per_bin), workgroup-uniform
+  for (int lo = 0; lo < P; lo += kCoarseChunk) {
+    bool in[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = lo + u * 256 + tid;
+      in[u] = false;
+      if (e < P && e >= e0 && e < e1) {
+        const float x = points[3 * (size_t)e], y = points[3 * (size_t)e + 1], z = points[3 * (size_t)e + 2];
+        const float rx = radius[2 * (size_t)e], ry = radius[2 * (size_t)e + 1];
+        const float xmin = x - rx, xmax = x + rx, ymin = y - ry, ymax = y + ry;
+        in[u] = !(z < 0) && (ymin <= bin_y_max) && (bin_y_min < ymax) && (xmin <= bin_x_max) && (bin_x_min < xmax);
+      }
+    }
+    const unsigned long long m0 = __ballot(in[0]), m1 = __ballot(in[1]);
+    __syncthreads();      // wcnt of the previous chunk consumed
+    if (lane == 0) wcnt[wave] = __popcll(m0) | (__popcll(m1) << 16);
+    __syncthreads();
+    // order inside the chunk: element index = u * 256 + wave * 64 + lane
+    int before[2] = {0, 0}, total = 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      for (int w = 0; w < 4; ++w) {
+        const int c = (wcnt[w] >> (16 * u)) & 0xffff;
+        if (w < wave) before[u] += c;
+        total += c;
+      }
+    const int c0 = (wcnt[0] & 0xffff) + (wcnt[1] & 0xffff) + (wcnt[2] & 0xffff) + (wcnt[3] & 0xffff);
+    const int start = run;
+    run += total;
+    if (start + total > M) continue;      // this chunk does not fit: dropped, the counter keeps its advance
+    if (in[0]) out[start + before[0] + __popcll(m0 & ((1ull << lane) - 1ull))] = lo + tid;
+    if (in[1]) out[start + c0 + before[1] + __popcll(m1 & ((1ull << lane) - 1ull))] = lo + 256 + tid;
+  }
+}
+
 }  // namespace voge
 
 using namespace voge;
@@ -256,5 +326,22 @@ extern "C" int voge_scatter_max(const float *weight, const int32_t *idx, long n,
   if (n == 0 || Nv == 0) return 0;
   if (!weight || !idx) return VOGE_ERR_BAD_ARG;
   hipLaunchKernelGGL(scatter_max_kernel, dim3(flat_grid(n)), dim3(256), 0, st, weight, idx, n, Nv, out);
+  return launch_status();
+}
+
+extern "C" int voge_bin_gaussians(const float *points, const int64_t *cloud_to_packed_first_idx,
+                                  const int64_t *num_points_per_cloud, int B, int P, int H, int W, const float *radius,
+                                  int bin_size, int max_points_per_bin, int32_t *bin_elems, voge_stream_t stream) {
+  if (B < 0 || P < 0 || H <= 0 || W <= 0 || bin_size <= 0 || max_points_per_bin < 0) return VOGE_ERR_BAD_ARG;
+  const int nbx = 1 + (W - 1) / bin_size, nby = 1 + (H - 1) / bin_size;
+  if (nbx >= 66 || nby >= 66) return VOGE_ERR_BAD_ARG;      // kMaxItemsPerBin (rasterize_coarse.cu:213-219)
+  const size_t n = (size_t)B * nby * nbx * max_points_per_bin;
+  if (n == 0) return 0;
+  if (!bin_elems || !cloud_to_packed_first_idx || !num_points_per_cloud || (P > 0 && (!points || !radius))) return VOGE_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const hipError_t e = hipMemsetAsync(bin_elems, 0xff, n * sizeof(int32_t), st);      // at::full(-1), :222
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(coarse_bin_kernel, dim3(nbx * nby, B), dim3(256), 0, st, points, radius, cloud_to_packed_first_idx,
+                     num_points_per_cloud, P, H, W, bin_size, max_points_per_bin, bin_elems);
   return launch_status();
 }

@@ -820,6 +820,27 @@ class _ScatterAttr(torch.autograd.Function):
         return g_pa, g_w, None, None, None
 
 
+def rasterize_points_coarse(points, cloud_to_packed_first_idx, num_points_per_cloud, image_size, radius, bin_size,
+                            max_points_per_bin):
+    """The reference's coarse stage (VoGE._C.rasterize_points_coarse, rasterize_coarse.h:18-25) -> bin_elems
+    [B,BH,BW,M] int32, -1 padded.  No gradient, like the reference (RayTracing.py:126-151)."""
+    lib = _lib.load()
+    pts = _dev(points.detach(), torch.float32, "points")
+    rad = _dev(radius.detach(), torch.float32, "radius")
+    first = _dev(cloud_to_packed_first_idx, torch.int64, "cloud_to_packed_first_idx")
+    num = _dev(num_points_per_cloud, torch.int64, "num_points_per_cloud")
+    assert pts.dim() == 2 and pts.shape[1] == 3 and rad.shape == (pts.shape[0], 2)
+    H, W = int(image_size[0]), int(image_size[1])
+    B = first.shape[0]
+    out = torch.empty((B, 1 + (H - 1) // int(bin_size), 1 + (W - 1) // int(bin_size), int(max_points_per_bin)),
+                      dtype=torch.int32, device=pts.device)
+    with _on(pts.device):
+        rc = lib.voge_bin_gaussians(_p(pts), _p(first), _p(num), B, pts.shape[0], H, W, _p(rad), int(bin_size),
+                                    int(max_points_per_bin), _p(out), _stream())
+    _lib.check(rc, "voge_bin_gaussians")
+    return out
+
+
 def scatter_attr(pix_attr, weight, idx, valid_num, n_vert):
     return _ScatterAttr.apply(pix_attr, weight, idx, valid_num, n_vert)
 
