@@ -5,27 +5,27 @@ A "step" is one forward+backward frame of BASELINE.json's metric config (config 
 synthetic Gaussians, 512x512, K=40, max_point_per_bin=-1):
     frag = renderer(gaussians, R=R, T=T); img = to_white_background(frag, colors); img.sum().backward()
 with gradients to verts [N,3], sigmas [N] and colours [N,3].  Inputs are resident in HBM before
-the timed region.  With --gpus N > 1 (one process per GPU, torchrun) the frame's pixel rows are
-sharded over the ranks: each rank traces / composites its own row band, the image is assembled
-by ONE all-gather (RCCL) and the per-Gaussian gradients by ONE all-reduce -> total work is
-fixed, "scaling": "strong".
+the timed region.  With --gpus N > 1 (one process per GPU) the frame's pixel rows are sharded over the
+ranks: each rank traces / composites its own row band, the image is assembled by ONE all-gather (RCCL) and
+the per-Gaussian gradients by ONE all-reduce -> total work is fixed, "scaling": "strong".
+`python bench.py --gpus N` from a bare shell starts its own N ranks (torch.distributed.run as a child
+process, before this process touches a GPU); under torchrun it is one of the ranks.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L3_BYTES = 256 << 20   # Infinity Cache: stage timings rotate over buffer sets larger than this
+TRACE_KERNELS = "voge_trace_topk_fwd(_iso) = binA + binB + trace_fwd_kernel (super-tile cones come with the rays)"
 
 
 def parse():
@@ -34,12 +34,30 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3_50k_512")
+    ap.add_argument("--anisotropic", action="store_true", help="full [N,3,3] Sigma^-1 (L L^T) instead of scalar sigmas")
+    ap.add_argument("--default-bins", action="store_true", help="max_point_per_bin=None (the demos' default) instead of -1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the anisotropic / default-bins variant frames")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--split-graph", action="store_true",
                     help="single GPU: use the multi-GPU launch scheme (forward graph / eager exchange / backward graph)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU oracle work for cpu_baseline")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run as a
+    CHILD process and pass its output through.  Nothing here has touched a GPU yet (no torch.cuda call), and the
+    parent only waits: no process that initialised HIP is ever replaced."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def stage_bytes(P, npix, K, C=3, iso=False):
@@ -57,30 +75,19 @@ def stage_bytes(P, npix, K, C=3, iso=False):
     }
 
 
-def time_kernel(fn, iters=20, warm=3):
-    """Average duration (ms) of `fn` with HIP events on torch's current stream -- the stream
-    every voge_* entry point is launched on."""
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
-
-
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the VoGE hot path has no CPU fallback")
     # VOGE_BENCH_BACKEND=gloo lets several ranks share one GPU (a functional check of the multi-GPU
@@ -100,46 +107,28 @@ def main():
     from voge_amd.Meshes import GaussianMeshes
     from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
     from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
-    from voge_amd.distributed import allreduce_grads, gather_rows, gather_rows_async, row_band
+    from voge_amd.distributed import FlatGrads, gather_rows, gather_rows_async, row_band
     _lib.load()
 
     N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[args.config]
-    verts, sig, cols = scenes.random_gaussians(N, seed=0)
-    gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
-    colors = torch.from_numpy(cols).to(dev).requires_grad_(True)
     R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
     cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), device=dev)
-    settings = GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1,
-                                      max_point_per_bin=-1)
-    renderer = GaussianRenderer(cams, settings).to(dev)
     rows = row_band(H, rank, world) if world > 1 else None
-    params = [gm.verts, gm.sigmas, colors]
 
-    def step():
-        for p in params:
-            p.grad = None
-        frag = renderer(gm, R=R, T=T, **({} if rows is None else {"rows": rows}))
-        band = to_white_background(frag, colors)
-        img = gather_rows(band, H)
-        if world > 1:
-            r0, r1 = rows
-            img[:, r0:r1].sum().backward()   # each rank owns the loss of its band; grads are summed below
-            allreduce_grads(params)
-        else:
-            img.sum().backward()
-        return img
+    def make_frame(anisotropic, default_bins):
+        """(step function, parameters) of one forward+backward frame of the config."""
+        verts, sig, cols = scenes.random_gaussians(N, seed=0, anisotropic=anisotropic)
+        gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
+        colors = torch.from_numpy(cols).to(dev).requires_grad_(True)
+        settings = GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1,
+                                          max_point_per_bin=None if default_bins else -1)
+        renderer = GaussianRenderer(cams, settings).to(dev)
+        params = [gm.verts, gm.sigmas, colors]
+        kw = {} if rows is None else {"rows": rows}
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # The frame is launch-bound on the host (~35 kernels of 5-220 us): capture one forward+backward
-    # into a HIP graph and replay it per step.  Every replay runs exactly the kernels of an eager
-    # step on the same (static) tensors; eager launches remain available with --no-graph.
-    run = step
-    graphed = False
-    launch = "eager"
+        def fwd():
+            return to_white_background(renderer(gm, R=R, T=T, **kw), colors)
+        return fwd, params, gm, colors, (verts, sig, cols)
 
     def warm_side_stream(fn):
         side = torch.cuda.Stream()
@@ -150,7 +139,15 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
-    if not args.no_graph and world == 1 and not args.split_graph:
+    def graphed_step(fwd, params):
+        """One frame as a HIP graph replay (every replay runs exactly the kernels of an eager step on the same static
+        tensors); eager on capture failure or --no-graph.  Returns (callable, launch description)."""
+        def step():
+            for p in params:
+                p.grad = None
+            fwd().sum().backward()
+        if args.no_graph:
+            return step, "eager"
         try:
             warm_side_stream(step)
             graph = torch.cuda.CUDAGraph()
@@ -158,78 +155,120 @@ def main():
                 step()
             graph.replay()
             torch.cuda.synchronize()
-            run, graphed, launch = graph.replay, True, "hip graph replay"
+            return graph.replay, "hip graph replay"
         except Exception as e:  # pragma: no cover - depends on the runtime
             print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
-            run = step
-    elif not args.no_graph:
-        # Multi-GPU: the local compute is two HIP graphs -- band forward, band backward -- and the
-        # two exchanges (all_gather of image rows -- asynchronous, overlapping the backward graph --
-        # and all_reduce of the gradients) run eagerly, so no collective is ever captured.  The loss is sum(image): every rank
-        # owns the loss of its band, whose upstream gradient is a constant tensor of ones.
-        try:
-            def fwd_only():
-                frag = renderer(gm, R=R, T=T, **({} if rows is None else {"rows": rows}))
-                return to_white_background(frag, colors)
+            return step, "eager"
 
-            def eager_once():
-                b = fwd_only()
-                torch.autograd.grad(b, params, torch.ones_like(b))
-            warm_side_stream(eager_once)
-            g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            # thread_local: RCCL's watchdog thread polls events while we capture
-            with torch.cuda.graph(g_fwd, capture_error_mode="thread_local"):
-                band_static = fwd_only()
-            ones_static = torch.ones_like(band_static)
-            with torch.cuda.graph(g_bwd, pool=g_fwd.pool(), capture_error_mode="thread_local"):
-                grads_static = torch.autograd.grad(band_static, params, ones_static)
-            for p_, g_ in zip(params, grads_static):
-                p_.grad = g_
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-            def run_split():
-                g_fwd.replay()
-                finish = gather_rows_async(band_static.detach(), H)   # all_gather starts (no-op on one GPU) ...
-                g_bwd.replay()                                          # ... and overlaps the band's backward
-                if world > 1:
-                    allreduce_grads(params)                             # eager all_reduce, in place on .grad
-                return finish().sum()                                   # the full-image loss every rank holds
-            run_split()
-            torch.cuda.synchronize()
-            run, graphed = run_split, True
-            launch = "hip graphs (band forward, band backward) + eager all_gather / all_reduce"
-        except Exception as e:  # pragma: no cover - depends on the runtime
-            print(f"[bench] split HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            torch.cuda.synchronize()
-            for p_ in params:
-                p_.grad = None
-            run = step
+    def timed(run, steps, warmup):
+        for _ in range(warmup):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
 
-    for _ in range(args.warmup):
-        run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    fwd, params, gm, colors, host_scene = make_frame(args.anisotropic, args.default_bins)
+    if world == 1 and not args.split_graph:
+        run, launch = graphed_step(fwd, params)
+    else:
+        # Multi-GPU: the local compute is two HIP graphs -- band forward, band backward -- and the two exchanges
+        # (all_gather of image rows, asynchronous, overlapping the backward graph; all_reduce of the gradients) run
+        # eagerly, so no collective is ever captured.  The loss is sum(image): every rank owns the loss of its band,
+        # whose upstream gradient is a constant tensor of ones.  The gradients live in ONE persistent flat buffer
+        # (FlatGrads): the backward graph accumulates into views of it, the all_reduce runs on it in place.
+        flat = FlatGrads(params)
+
+        def eager_once():
+            flat.zero()
+            b = fwd()
+            torch.autograd.backward(b, torch.ones_like(b))
+        run, launch = None, "eager"
+        if not args.no_graph:
+            try:
+                warm_side_stream(eager_once)
+                g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                # thread_local: RCCL's watchdog thread polls events while we capture
+                with torch.cuda.graph(g_fwd, capture_error_mode="thread_local"):
+                    band_static = fwd()
+                ones_static = torch.ones_like(band_static)
+                with torch.cuda.graph(g_bwd, pool=g_fwd.pool(), capture_error_mode="thread_local"):
+                    flat.zero()
+                    torch.autograd.backward(band_static, ones_static)
+
+                def run_split():
+                    g_fwd.replay()
+                    finish = gather_rows_async(band_static.detach(), H)   # all_gather starts (no-op on one GPU) ...
+                    g_bwd.replay()                                          # ... and overlaps the band's backward
+                    flat.allreduce()                                        # one eager all_reduce, in place
+                    return finish().sum()                                   # the full-image loss every rank holds
+                run_split()
+                torch.cuda.synchronize()
+                run = run_split
+                launch = "hip graphs (band forward, band backward) + eager all_gather_into_tensor / all_reduce (flat buffer)"
+            except Exception as e:  # pragma: no cover - depends on the runtime
+                print(f"[bench] split HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                torch.cuda.synchronize()
+        if run is None:
+            def run():
+                flat.zero()
+                band = fwd()
+                img = gather_rows(band, H)
+                r0, r1 = rows if rows is not None else (0, H)
+                img[:, r0:r1].sum().backward()      # each rank owns the loss of its band; grads are summed below
+                flat.allreduce()
+                return img
+
+    dt = timed(run, args.steps, args.warmup)
     ms = dt / args.steps * 1e3
     fps = args.steps / dt
 
+    sig_kind = "[N,3,3] L L^T sigmas" if args.anisotropic else "scalar sigmas"
+    bins_kind = "None (default)" if args.default_bins else "-1"
     result = {
         "metric": "forward+backward frames/sec at 512^2, 50k Gaussians; ray-trace HBM GB/s vs peak",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.config}: {N} random Gaussians, {H}x{W}, K={K}, max_point_per_bin=-1, "
+        "config": {"workload": f"{args.config}: {N} random Gaussians ({sig_kind}), {H}x{W}, K={K}, max_point_per_bin={bins_kind}, "
                                f"fwd+bwd (grads to verts, sigmas, colors)",
                    "launch": launch,
                    "parallelism": "1 gpu" if world == 1 else f"pixel-row bands x{world}, all_gather(image)+all_reduce(grads)"},
     }
+
+    lib = _lib.load()
+    P_ = lambda x: None if x is None else x.data_ptr()
+    thr_act = -np.log(0.01 + 1e-10)
+
+    def rotating(make_set, fn_of_set, bytes_per_call, iters=20, warm=3):
+        """Average duration (ms) of one call with HIP events on torch's current stream -- the stream every voge_*
+        entry point is launched on -- cycling over enough independent buffer sets that no call finds its operands in the
+        256 MB Infinity Cache (a replay on ONE set of buffers would: at cfg3 every stage's working set fits)."""
+        nset = int(min(8, max(2, -(-3 * L3_BYTES // max(bytes_per_call, 1)))))
+        sets = [make_set() for _ in range(nset)]
+        for i in range(warm):
+            fn_of_set(sets[i % nset])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            fn_of_set(sets[i % nset])
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters, nset
 
     if rank == 0 and world == 1:
         # ---- per-stage kernel timings on the same inputs (HIP events, current stream) --------
@@ -237,102 +276,126 @@ def main():
             from voge_amd.cameras import pixel_rays
             from voge_amd.Aggregation import expend_sigma
             rays, origin = pixel_rays(cams, (H, W))
+            cones = ops.cones_of(rays, 1, H, W)
             mus = (gm.verts[None] - origin[:, None]).reshape(-1, 3).contiguous()
             iso = gm.sigmas.dim() == 1     # the renderer keeps (N,) sigmas in scalar form (A = a I)
             isg = (2 * gm.sigmas).contiguous() if iso else (2 * expend_sigma(gm.sigmas)).contiguous()
-            thr_act = -np.log(0.01 + 1e-10)
             if iso:
                 sel = ops._RayTraceVoGEIso.apply(mus, isg, rays, None, thr_act, K)
             else:
                 sel = ops.ray_trace_fine(mus, isg, rays, None, thr_act, 16, K)
+            cnt = ops.hit_count_of(sel[0])
             w, vn = ops.composite(sel[0], sel[2], sel[1], sel[3], 1.0)
             idx = sel[0].clone()
-            vn32 = vn.to(torch.int32).contiguous()
             rgb = ops.merge(colors.detach(), w, idx, vn)
             bg = torch.ones(3, device=dev)
-            g_img = torch.ones_like(rgb)
-            lib = _lib.load()
+            wsum = w.sum(-1)
             st = torch.cuda.current_stream().cuda_stream
             npix = H * W
-            ws = torch.empty(lib.voge_trace_workspace_bytes(1, N, H, W), dtype=torch.uint8, device=dev)
-            ws_b = torch.empty(lib.voge_trace_bwd_workspace_bytes(N), dtype=torch.uint8, device=dev)
             trace_fwd_fn = lib.voge_trace_topk_fwd_iso if iso else lib.voge_trace_topk_fwd
             trace_bwd_fn = lib.voge_trace_bwd_iso if iso else lib.voge_trace_bwd
-            o_i, o_l, o_a, o_d = (torch.empty_like(x) for x in sel)
-            o_c = torch.empty((1, H, W), dtype=torch.int32, device=dev)
-            g3 = [torch.empty_like(w) for _ in range(3)]
-            g_w = torch.rand_like(w)
-            g_ray, g_mu, g_A = torch.empty_like(rays), torch.empty_like(mus), torch.empty_like(isg)
-            out3, g_attr = torch.empty_like(rgb), torch.empty_like(colors)
-            wsum = torch.empty(rgb.shape[:-1], dtype=torch.float32, device=rgb.device)
-            P = lambda x: x.data_ptr()
-            calls = {
-                "trace_fwd": lambda: trace_fwd_fn(P(mus), P(isg), P(rays), None, P(ops.cones_of(rays, 1, H, W)), 1, N, H, W, K, thr_act, P(ws),
-                                                             ws.numel(), P(o_i), P(o_l), P(o_a), P(o_d), P(o_c), st),
-                "composite_fwd": lambda: lib.voge_composite_fwd(None, P(ops.hit_count_of(sel[0])), P(sel[2]), P(sel[1]), P(sel[3]), 1.0, npix, K,
-                                                                P(g3[0]), P(vn), st),
-                "shade_fwd": lambda: lib.voge_shade_fwd(P(colors), P(idx), P(w), P(vn), P(bg), -1.0, npix, K, 3, N, 1, P(rgb),
-                                                        P(out3), None, P(wsum), st),
-                "shade_bwd": lambda: lib.voge_shade_bwd(P(colors), P(idx), P(w), P(vn), P(rgb), P(wsum), P(bg), -1.0, P(g_img), H, W, K,
-                                                        3, N, P(g_attr), P(g3[0]), st),
-                "composite_bwd": lambda: lib.voge_composite_bwd(P(sel[2]), P(sel[1]), P(sel[3]), P(w), P(ops.hit_count_of(sel[0])), P(g_w), 1.0, npix, K, P(g3[0]),
-                                                                P(g3[1]), P(g3[2]), st),
-                "trace_bwd": lambda: trace_bwd_fn(P(mus), P(isg), P(rays), P(sel[0]), P(vn32), P(w), P(w), P(w), N, H, W, K,
-                                                        P(ws_b), ws_b.numel(), None, P(g_mu), P(g_A), st),
+            nws = lib.voge_trace_workspace_bytes(1, N, H, W)
+            nws_b = lib.voge_trace_bwd_iso_workspace_bytes(N) if iso else lib.voge_trace_bwd_workspace_bytes(N)
+            E = lambda ref: torch.empty_like(ref)
+            C_ = lambda ref: ref.clone()
+            g_rand = torch.rand_like(w)
+            stage_defs = {
+                # name: (make_set, call)
+                "trace_fwd": (lambda: dict(ws=torch.empty(nws, dtype=torch.uint8, device=dev), o=[E(x) for x in sel],
+                                           c=torch.empty((1, H, W), dtype=torch.int32, device=dev)),
+                              lambda s: trace_fwd_fn(P_(mus), P_(isg), P_(rays), None, P_(cones), 1, N, H, W, K, thr_act, P_(s["ws"]), nws,
+                                                     P_(s["o"][0]), P_(s["o"][1]), P_(s["o"][2]), P_(s["o"][3]), P_(s["c"]), st)),
+                "composite_fwd": (lambda: dict(a=C_(sel[2]), l=C_(sel[1]), d=C_(sel[3]), c=C_(cnt), w=E(w), v=E(vn)),
+                                  lambda s: lib.voge_composite_fwd(None, P_(s["c"]), P_(s["a"]), P_(s["l"]), P_(s["d"]), 1.0, npix, K,
+                                                                   P_(s["w"]), P_(s["v"]), st)),
+                "shade_fwd": (lambda: dict(i=C_(idx), w=C_(w), v=C_(vn), rgb=E(rgb), img=E(rgb), ws=E(wsum)),
+                              lambda s: lib.voge_shade_fwd(P_(colors), P_(s["i"]), P_(s["w"]), P_(s["v"]), P_(bg), -1.0, npix, K, 3, N, 1,
+                                                           P_(s["rgb"]), P_(s["img"]), None, P_(s["ws"]), st)),
+                "shade_bwd": (lambda: dict(i=C_(idx), w=C_(w), v=C_(vn), rgb=C_(rgb), ws=C_(wsum), g=torch.ones_like(rgb),
+                                           ga=torch.empty_like(colors), gw=E(w)),
+                              lambda s: lib.voge_shade_bwd(P_(colors), P_(s["i"]), P_(s["w"]), P_(s["v"]), P_(s["rgb"]), P_(s["ws"]), P_(bg),
+                                                           -1.0, P_(s["g"]), H, W, K, 3, N, P_(s["ga"]), P_(s["gw"]), st)),
+                "composite_bwd": (lambda: dict(a=C_(sel[2]), l=C_(sel[1]), d=C_(sel[3]), w=C_(w), c=C_(cnt), g=C_(g_rand),
+                                               o=[E(w) for _ in range(3)]),
+                                  lambda s: lib.voge_composite_bwd(P_(s["a"]), P_(s["l"]), P_(s["d"]), P_(s["w"]), P_(s["c"]), P_(s["g"]), 1.0,
+                                                                   npix, K, P_(s["o"][0]), P_(s["o"][1]), P_(s["o"][2]), st)),
+                "trace_bwd": (lambda: dict(i=C_(sel[0]), c=C_(cnt), g=[C_(g_rand) for _ in range(3)],
+                                           ws=torch.empty(nws_b, dtype=torch.uint8, device=dev), gm=E(mus), gA=E(isg)),
+                              lambda s: trace_bwd_fn(P_(mus), P_(isg), P_(rays), P_(s["i"]), P_(s["c"]), P_(s["g"][0]), P_(s["g"][1]),
+                                                     P_(s["g"][2]), N, H, W, K, P_(s["ws"]), nws_b, None, P_(s["gm"]), P_(s["gA"]), st)),
             }
             nbytes = stage_bytes(N, npix, K, iso=iso)
             stages = {}
-            for name, fn in calls.items():
-                t_ms = time_kernel(fn)
+            for name, (mk, call) in stage_defs.items():
+                t_ms, nset = rotating(mk, call, nbytes[name])
+                one = mk()
+                t_same, _ = rotating(lambda one=one: one, call, 1 << 40)      # the same call replayed on ONE buffer set
                 stages[name] = {"ms": round(t_ms, 4), "algo_MB": round(nbytes[name] / 1e6, 1),
-                                "GBps": round(nbytes[name] / 1e9 / (t_ms / 1e3), 1)}
+                                "GBps": round(nbytes[name] / 1e9 / (t_ms / 1e3), 1), "buffer_sets": nset,
+                                "ms_same_buffers": round(t_same, 4)}
+                del one
             hits = int((sel[0] >= 0).sum().item())
+            del stage_defs
+            torch.cuda.empty_cache()
         dom = "trace_fwd"  # the sweep BASELINE.json's metric names
         a = stages[dom]["GBps"]
         traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if args.config == "cfg3_50k_512" and os.path.exists(tfile):
-            # HBM bytes per launch from rocprofv3 PMC passes of this same command (not collectable live)
-            traffic = json.load(open(tfile)).get("voge_trace_topk_fwd_bytes")
-            traffic_src = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
-        result["roofline"] = {"kernel": "voge_trace_topk_fwd(_iso) = prep_cone + bin0 + bin + bin2 + tile_order + trace_fwd_kernel",
-                              "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        tfile = os.path.join(ROOT, "profiles", "r2_traffic.json")
+        if os.path.exists(tfile) and not args.anisotropic:
+            # HBM bytes per launch from rocprofv3 PMC passes of this same command (not collectable from inside the run)
+            traffic = json.load(open(tfile)).get(args.config, {}).get("voge_trace_topk_fwd_bytes")
+            if traffic is not None:
+                traffic_src = ("profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2: "
+                               "tools/refresh_profiles.sh)")
+        result["roofline"] = {"kernel": TRACE_KERNELS, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                               "algorithmic_bytes": nbytes[dom], "avg_launch_ms": stages[dom]["ms"]}
         result["stages"] = stages
+        result["stages_note"] = ("ms / GBps: the call cycling over `buffer_sets` independent sets of operands (> 3 x the 256 MB "
+                                 "Infinity Cache in total), i.e. served from HBM; ms_same_buffers: replayed on one set (L3-assisted)")
         result["frame_kernel_ms_sum"] = round(sum(s["ms"] for s in stages.values()), 4)
         result["hits_per_pixel"] = round(hits / npix, 2)
+        if not args.no_variants and not args.anisotropic and not args.default_bins:
+            # the same step on the metric's stated variants: full 3x3 forms; the demos' default bins
+            variants = {}
+            for vname, (an, db) in (("anisotropic_3x3", (True, False)), ("max_point_per_bin_None", (False, True))):
+                del fwd, params, gm, colors
+                torch.cuda.empty_cache()
+                fwd, params, gm, colors, _ = make_frame(an, db)
+                vrun, vlaunch = graphed_step(fwd, params)
+                vdt = timed(vrun, max(10, args.steps // 2), 3)
+                variants[vname] = {"value": round(max(10, args.steps // 2) / vdt, 1), "unit": "frames/s", "launch": vlaunch}
+            result["variants"] = variants
         if not args.no_cpu_baseline:
+            verts, sig, cols = host_scene
             result["cpu_baseline"] = cpu_baseline(verts, sig, cols, H, W, K, focal, pp, (dd, el, az), args.cpu_seconds)
     if rank == 0 and world > 1:
         # the dominant kernel on rank 0's band of rows (same entry point, shorter image), timed live
         with torch.no_grad():
             from voge_amd.cameras import pixel_rays
-            lib = _lib.load()
             r0, r1 = rows
             rays_b, origin = pixel_rays(cams, (H, W), rows=rows)
+            cones = ops.cones_of(rays_b, 1, r1 - r0, W)
             h = r1 - r0
             iso = gm.sigmas.dim() == 1
-            thr_act = -np.log(0.01 + 1e-10)
-            outs = [torch.empty((1, h, W, K), dtype=d, device=dev) for d in (torch.int32, torch.float32, torch.float32, torch.float32)]
-            o_c = torch.empty((1, h, W), dtype=torch.int32, device=dev)
-            ws = torch.empty(lib.voge_trace_workspace_bytes(1, N, h, W), dtype=torch.uint8, device=dev)
             st = torch.cuda.current_stream().cuda_stream
-            P = lambda x: x.data_ptr()
+            nws = lib.voge_trace_workspace_bytes(1, N, h, W)
+            mk = lambda: dict(ws=torch.empty(nws, dtype=torch.uint8, device=dev),
+                              o=[torch.empty((1, h, W, K), dtype=d, device=dev) for d in (torch.int32, torch.float32, torch.float32, torch.float32)],
+                              c=torch.empty((1, h, W), dtype=torch.int32, device=dev))
             if iso:
-                fn = lambda: lib.voge_trace_topk_fwd_iso_view(P(gm.verts), P(gm.sigmas), P(origin), 1, 1, P(rays_b), None, P(ops.cones_of(rays_b, 1, h, W)), 1, N, h, W, K,
-                                                              thr_act, P(ws), ws.numel(), *[P(o) for o in outs], P(o_c), st)
+                call = lambda s: lib.voge_trace_topk_fwd_iso_view(P_(gm.verts), P_(gm.sigmas), P_(origin), 1, 1, P_(rays_b), None, P_(cones), 1, N, h, W,
+                                                                  K, thr_act, P_(s["ws"]), nws, *[P_(o) for o in s["o"]], P_(s["c"]), st)
             else:
                 from voge_amd.Aggregation import expend_sigma
                 mus = (gm.verts[None] - origin[:, None]).reshape(-1, 3).contiguous()
                 isg = (2 * expend_sigma(gm.sigmas)).contiguous()
-                fn = lambda: lib.voge_trace_topk_fwd(P(mus), P(isg), P(rays_b), None, P(ops.cones_of(rays_b, 1, h, W)), 1, N, h, W, K, thr_act, P(ws), ws.numel(),
-                                                     *[P(o) for o in outs], P(o_c), st)
-            t_ms = time_kernel(fn)
+                call = lambda s: lib.voge_trace_topk_fwd(P_(mus), P_(isg), P_(rays_b), None, P_(cones), 1, N, h, W, K, thr_act, P_(s["ws"]), nws,
+                                                         *[P_(o) for o in s["o"]], P_(s["c"]), st)
             nb = stage_bytes(N, h * W, K, iso=iso)["trace_fwd"]
+            t_ms, _ = rotating(mk, call, nb)
             a = round(nb / 1e9 / (t_ms / 1e3), 1)
-            result["roofline"] = {"kernel": "voge_trace_topk_fwd(_iso) on rank 0's band of rows "
-                                            f"[{r0}, {r1}) = prep_cone + bin0 + bin + bin2 + tile_order + trace_fwd_kernel",
+            result["roofline"] = {"kernel": TRACE_KERNELS + f" on rank 0's band of rows [{r0}, {r1})",
                                   "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                                   "algorithmic_bytes": nb, "avg_launch_ms": round(t_ms, 4)}
@@ -347,6 +410,7 @@ def cpu_baseline(verts, sig, cols, H, W, K, focal, pp, view, target_s):
     """The CPU oracle (a C/OpenMP port of the reference algorithm, fp64) timed on this host on a
     bounded sample: `nrows` pixel rows around the image centre, forward + backward, scaled to a
     whole frame by H / nrows.  nrows is calibrated on a 2-row probe to give ~target_s of work."""
+    import numpy as np
     import oracle
     from oracle import camera_np
     oracle.build()
@@ -378,8 +442,8 @@ def cpu_baseline(verts, sig, cols, H, W, K, focal, pp, view, target_s):
     scale = H / nrows
     return {"value": 1.0 / (t_all * scale), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"{nrows} of {H} pixel rows (rows {r0}..{r0 + nrows - 1}) of the same frame, fwd+bwd, "
-                      f"oracle/voge_oracle.c fp64, OpenMP over pixels ({os.cpu_count()} threads; the two backward "
-                      f"scatter stages are serial); {t_all:.2f} s measured (fwd {t_fwd:.2f} s), scaled x{scale:.1f}"}
+                      f"oracle/voge_oracle.c fp64, OpenMP over pixels in every stage ({os.cpu_count()} threads; the two backward "
+                      f"scatters use atomic adds); {t_all:.2f} s measured (fwd {t_fwd:.2f} s), scaled x{scale:.1f}"}
 
 
 if __name__ == "__main__":

@@ -1,23 +1,26 @@
 #!/bin/bash
 # On the GPU box: regenerate everything under profiles/ for the current build (outputs land in
 # gpurun_out/refresh/, which gpurun merges back; copy them into profiles/ locally afterwards).
-# usage: tools/refresh_profiles.sh <round-tag, e.g. r1>
-TAG=${1:-r1}
+# usage: tools/refresh_profiles.sh <round-tag, e.g. r2>
+TAG=${1:-r2}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
-B="python3 bench.py --no-graph --no-cpu-baseline --steps 10 --warmup 3"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > /dev/null 2>&1
-python tools/traffic_json.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_traffic.json
+for CFG in cfg3_50k_512 cfg4_200k_1024; do
+  B="python3 bench.py --no-graph --no-cpu-baseline --no-variants --steps 10 --warmup 3 --config $CFG"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > /dev/null 2>&1
+  python tools/traffic_json.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_traffic.json $CFG
+  if [ $CFG = cfg3_50k_512 ]; then python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/${TAG}_pmc_fetch_write_size.txt 2>/dev/null; fi
+  rm -rf $OUT/pmc_fetch $OUT/pmc_write
+done
 cp $OUT/${TAG}_traffic.json profiles/${TAG}_traffic.json     # bench.py reads it for roofline.traffic
-python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/${TAG}_pmc_fetch_write_size.txt 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -- python3 bench.py --no-graph --no-cpu-baseline --steps 30 --warmup 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -- python3 bench.py --no-graph --no-cpu-baseline --no-variants --steps 30 --warmup 5 > /dev/null 2>&1
 python tools/rocprof_summary.py $OUT/ktrace $OUT/${TAG}_kernel_trace_summary.txt > /dev/null
+rm -rf $OUT/ktrace
 python bench.py | tail -1 > $OUT/${TAG}_bench_line.json
-python bench.py --no-graph --no-cpu-baseline | tail -1 > $OUT/${TAG}_bench_line_eager.json
-python bench.py --config cfg4_200k_1024 --no-cpu-baseline --steps 20 | tail -1 > $OUT/${TAG}_bench_line_cfg4.json
-python bench.py --config cfg5_shapefit_128 --no-cpu-baseline --steps 50 | tail -1 > $OUT/${TAG}_bench_line_cfg5.json
-rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/ktrace
-head -c 600 $OUT/${TAG}_bench_line.json; echo; grep -E "voge" $OUT/${TAG}_kernel_trace_summary.txt | cut -c1-60,90-150
+python bench.py --no-graph --no-cpu-baseline --no-variants | tail -1 > $OUT/${TAG}_bench_line_eager.json
+python bench.py --config cfg4_200k_1024 --no-cpu-baseline --no-variants --steps 20 | tail -1 > $OUT/${TAG}_bench_line_cfg4.json
+python bench.py --config cfg5_shapefit_128 --no-cpu-baseline --no-variants --steps 50 | tail -1 > $OUT/${TAG}_bench_line_cfg5.json
+head -c 700 $OUT/${TAG}_bench_line.json; echo; grep -E "voge" $OUT/${TAG}_kernel_trace_summary.txt | cut -c1-60,90-150

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""profiles/r1_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
-as MI355X_MICROARCH.md's HBM section prescribes).  usage: traffic_json.py <fetch_dir> <write_dir> <out.json>
+"""profiles/<tag>_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
+as MI355X_MICROARCH.md's HBM section prescribes).
+usage: traffic_json.py <fetch_dir> <write_dir> <out.json> <config name>   (entries of other configs in out.json are kept)
 Units: counters are KiB; FETCH_SIZE x2 on gfx950 for wide coalesced reads (same guide); per launch averages."""
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
 
-TRACE_FWD = ("prep_cone_kernel", "bin0_kernel", "bin_kernel", "bin2_kernel", "tile_order_kernel", "trace_fwd_kernel")
+TRACE_FWD = ("cones_kernel", "prep_kernel", "binA_kernel", "binB_kernel", "trace_fwd_kernel")
 
 
 def collect(d, counter):
@@ -23,20 +25,20 @@ def collect(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-def main(fetch_dir, write_dir, out):
+def main(fetch_dir, write_dir, out, config):
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fe) | set(wr)):
         f, w = fe.get(k, 0.0), wr.get(k, 0.0)
         kernels[k] = {"fetch_KiB_raw": round(f), "write_KiB": round(w), "hbm_bytes": int((2 * f + w) * 1024)}
     total = sum(v["hbm_bytes"] for k, v in kernels.items() if k.split("<")[0] in TRACE_FWD)
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --no-graph (cfg3). "
-                       "Units KiB per launch; hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of "
-                       "MI355X_MICROARCH.md's HBM section).",
-               "kernels": kernels, "voge_trace_topk_fwd_kernels": list(TRACE_FWD),
-               "voge_trace_topk_fwd_bytes": total}, open(out, "w"), indent=1)
-    print("voge_trace_topk_fwd_bytes", total)
+    doc = json.load(open(out)) if os.path.exists(out) else {}
+    doc["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --no-graph. Units KiB per launch; "
+                   "hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of MI355X_MICROARCH.md's HBM section).")
+    doc[config] = {"kernels": kernels, "voge_trace_topk_fwd_kernels": list(TRACE_FWD), "voge_trace_topk_fwd_bytes": total}
+    json.dump(doc, open(out, "w"), indent=1)
+    print(config, "voge_trace_topk_fwd_bytes", total)
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
