@@ -179,6 +179,8 @@ int voge_bin_gaussians(const float *points, const int64_t *cloud_to_packed_first
  *   VoGE._C.ray_trace_voge_fine (ray_trace_voge.cu:135-280)  +  `aggregation` (VoGE/Aggregation.py:82-107)
  * for the all-candidates list.  Arguments as voge_trace_topk_fwd / _iso / _iso_view, plus occ (the
  * renderer's absorptivity) and the fragment outputs weight [B,H,W,K] f32 and valid_num [B,H,W] i64.
+ * records (iso forms): NULL, or [B*N,4] floats receiving the per-Gaussian (centred mean, a) pairs the trace
+ * derives anyway -- the fused backward (voge_fragment_shade_bwd_iso) reads them instead of packing its own.
  * idx / len / weight / valid_num are the fragments (sentinels -1 / 1e10 / 0 in empty slots); act, dsd
  * and cnt [B,H,W] (required here) are what the backward needs -- in pixels WITHOUT any hit act / dsd are
  * may be left unwritten (nothing reads them: every consumer goes by cnt).  Results are bit-identical
@@ -193,12 +195,34 @@ int voge_fragments_fwd(const float *mus, const float *isigmas, const float *rays
 int voge_fragments_fwd_iso(const float *mus, const float *a, const float *rays, const float *cam_fwd,
                            const float *cones, int B, int N, int H, int W, int K, float thr_act, float occ,
                            void *workspace, size_t workspace_bytes, int32_t *idx, float *len, float *act,
-                           float *dsd, int32_t *cnt, float *weight, int64_t *valid_num, voge_stream_t stream);
+                           float *dsd, int32_t *cnt, float *weight, int64_t *valid_num, float *records,
+                           voge_stream_t stream);
 int voge_fragments_fwd_iso_view(const float *verts, const float *sigmas, const float *origin, int shared,
                                 int sigma_mode, const float *rays, const float *cam_fwd, const float *cones,
                                 int B, int N, int H, int W, int K, float thr_act, float occ, void *workspace,
                                 size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
-                                int32_t *cnt, float *weight, int64_t *valid_num, voge_stream_t stream);
+                                int32_t *cnt, float *weight, int64_t *valid_num, float *records, voge_stream_t stream);
+
+/*
+ * Fused backward of the fragment pipeline for isotropic Gaussians: shade (merge_final + get_silhouette +
+ * to_colored_background, VoGE/Aggregation.py:111-141, VoGE/Renderer.py:157-171) -> aggregation
+ * (VoGE/Aggregation.py:30-107) -> fine trace (ray_trace_voge.cu:283-332), in ONE pass over the fragments:
+ * what voge_shade_bwd, voge_composite_bwd and voge_trace_bwd_iso(_view) compute one after the other, without
+ * their exchanges through memory (g_weight; g_len / g_act / g_dsd) and with one accumulation table per wave.
+ * records [B*N,4] = the (centred mean, a) pairs the forward kept (the `records` argument of
+ * voge_fragments_fwd_iso / _iso_view); sigmas / shared / sigma_mode as in voge_trace_bwd_iso_view (pass the a
+ * array, 0, 0 for plain (mus, a) inputs); rgb / wsum = voge_shade_fwd's out_rgb / out_wsum; g_img [nrows*W,C] the
+ * gradient of the image.  Writes g_verts, g_sigmas (both or neither) and g_colors [Nattr,C].  K even, <= 128;
+ * C <= 4; cnt required.  workspace: >= voge_fragment_bwd_workspace_bytes(B*N) bytes.
+ */
+size_t voge_fragment_bwd_workspace_bytes(int P);
+int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
+                                const float *rays, const float *colors, const int32_t *idx, const int32_t *cnt,
+                                const float *weight, const float *act, const float *len, const float *dsd,
+                                const float *rgb, const float *wsum, const float *bg, float thr,
+                                const float *g_img, float occ, int B, int N, long nrows, int W, int K, int C,
+                                long Nattr, void *workspace, size_t workspace_bytes, float *g_verts,
+                                float *g_sigmas, float *g_colors, voge_stream_t stream);
 
 /*
  * Composite forward.  Replaces: VoGE/Aggregation.py:82-107 `aggregation`

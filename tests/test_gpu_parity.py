@@ -815,3 +815,44 @@ def test_renderer_against_the_running_reference_host_logic(hip_lib, case):
     assert np.abs(n(frag.vert_weight)[same] - g[c + "_weight"][same]).max() < 3e-4
     hit = (g[c + "_index"] >= 0) & same[..., None]
     assert np.abs(n(frag.vert_hit_length)[hit] - g[c + "_hit_length"][hit]).max() < 4e-4
+
+
+@pytest.mark.parametrize("K,B,inverse", [(40, 1, False), (12, 2, True), (26, 1, False)])
+def test_fused_fragment_backward_equals_the_three_kernels(hip_lib, K, B, inverse):
+    """voge_fragment_shade_bwd_iso (shade -> composite -> trace backward in one kernel, taken by to_colored_background
+    on this renderer's fragments) against the three stand-alone backward kernels on the same frame -- with a second
+    consumer of the weights (a silhouette loss, which keeps flowing through _Fragments.backward) and a loss on
+    vert_hit_length, whose gradients must simply add up."""
+    from voge_amd import ops
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, get_silhouette, to_colored_background
+    from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
+    N, H, W = 2500, 70, 90
+    verts, sig, cols = random_scene(N, seed=60 + K, lo=0.04, hi=0.1)
+    if inverse:
+        sig = (1.0 / sig).astype(np.float32)
+    R, T = look_at_view_transform(dist=[3.0, 3.4][:B], elev=[10.0, -20.0][:B], azim=[30.0, 200.0][:B], device=DEV)
+    cams = PerspectiveCameras(focal_length=95.0, principal_point=((W / 2.0, H / 2.0),), image_size=((H, W),), device=DEV)
+    st = GaussianRenderSettings(image_size=(H, W), max_assign=K, absorptivity=1.1, inverse_sigma=inverse, max_point_per_bin=-1)
+    renderer = GaussianRenderer(cams, st).to(DEV)
+    gen = torch.Generator(DEV).manual_seed(9)
+    g_img = torch.randn(B, H, W, 3, device=DEV, generator=gen)
+    g_sil = torch.randn(B, H, W, device=DEV, generator=gen)
+    out = {}
+    for fused in (True, False):
+        gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(DEV)
+        colors = t(np.tile(cols, (B, 1)), rg=True)
+        frag = renderer(gm, R=R, T=T)
+        assert hasattr(frag.vert_weight, "voge_through")
+        if not fused:
+            del frag.vert_weight.voge_through
+        img = to_colored_background(frag, colors, background_color=(0.9, 0.8, 1.0))
+        assert (type(img.grad_fn).__name__ == "_ShadeThroughBackward") == fused
+        hl = torch.where(frag.vert_index >= 0, frag.vert_hit_length, torch.zeros_like(frag.vert_hit_length))
+        ((img * g_img).sum() + (get_silhouette(frag) * g_sil).sum() + 0.01 * hl.sum()).backward()
+        out[fused] = [n(x) for x in (img, gm.verts.grad, gm.sigmas.grad, colors.grad)]
+    assert np.array_equal(out[True][0], out[False][0])
+    for name, x, y in zip(("verts", "sigmas", "colors"), out[True][1:], out[False][1:]):
+        scale = max(1.0, float(np.abs(y).max()))
+        assert np.abs(x - y).max() <= 3e-5 * scale, (name, float(np.abs(x - y).max()), scale)
+    assert np.abs(out[False][1]).max() > 0 and np.abs(out[False][2]).max() > 0

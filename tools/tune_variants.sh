@@ -11,7 +11,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-
 pids=()
 for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
-  /opt/rocm/bin/hipcc $FLAGS $defs -shared -o "$OUT/$name.so" trace_fwd.hip trace_bwd.hip composite.hip merge_blend.hip rays.hip extras.hip &
+  /opt/rocm/bin/hipcc $FLAGS $defs -shared -o "$OUT/$name.so" trace_fwd.hip trace_bwd.hip composite.hip merge_blend.hip rays.hip extras.hip fragment_bwd.hip &
   pids+=($!)
   if [ ${#pids[@]} -ge 4 ]; then wait "${pids[0]}"; pids=("${pids[@]:1}"); fi
 done

@@ -196,7 +196,11 @@ def to_colored_background(fragments: Fragments, colors: torch.Tensor,
         background_color = _background_tensor(background_color, colors.device)
     background_color = background_color.to(colors.device)
     if colors.dim() == 2 and colors.shape[1] <= 4:
-        # merge + silhouette + blend fused in one kernel (and one backward kernel)
+        # merge + silhouette + blend fused in one kernel; on fragments of this renderer the backward of the whole
+        # pipeline (this blend, the composite, the trace) is one kernel as well (ops._ShadeThrough)
+        img = ops.shade_through(colors, fragments.vert_weight, fragments.vert_index, fragments.valid_num, background_color, thr)
+        if img is not None:
+            return img
         return ops.shade(colors, fragments.vert_weight, fragments.vert_index, fragments.valid_num, background_color, thr)
     rgb = interpolate_attr(fragments, colors)
     return ops.blend(rgb, fragments.vert_weight, background_color, thr)

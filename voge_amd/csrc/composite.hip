@@ -481,6 +481,29 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
     wave_cnt = c;
     if (!WAVE && head) atomicAdd(&L.cnt[p], c);
   }
+  if (BWD && WAVE) {
+    // backward, wave form: shared with the fused fragment backward (composite_core.h, fragment_bwd.hip)
+    float um[NS], ga[NS], gl[NS], gd[NS];
+#pragma unroll
+    for (int a = 0; a < NS; ++a) um[a] = gw[a] * wg[a];
+    compn_bwd_wave<NS>(lm, sm, em, um, Llen, Lsp, LE, Lu, d0, k0, K, q, LP, in_wg, active, active && !wave_unsorted, seg_lo, occ,
+                       ga, gl, gd);
+    if (active) {
+      if (vec && NS == 4) {
+        *reinterpret_cast<float4 *>(out0 + f) = make_float4(ga[0], ga[1], ga[NS - 2], ga[NS - 1]);
+        *reinterpret_cast<float4 *>(out1 + f) = make_float4(gl[0], gl[1], gl[NS - 2], gl[NS - 1]);
+        *reinterpret_cast<float4 *>(out2 + f) = make_float4(gd[0], gd[1], gd[NS - 2], gd[NS - 1]);
+      } else if (vec) {
+        *reinterpret_cast<v2f *>(out0 + f) = (v2f){ga[0], ga[1]};
+        *reinterpret_cast<v2f *>(out1 + f) = (v2f){gl[0], gl[1]};
+        *reinterpret_cast<v2f *>(out2 + f) = (v2f){gd[0], gd[1]};
+      } else {
+#pragma unroll
+        for (int a = 0; a < NS; ++a) if (has[a]) { out0[f + a] = ga[a]; out1[f + a] = gl[a]; out2[f + a] = gd[a]; }
+      }
+    }
+    return;
+  }
   if (!BWD && WAVE) {
     // forward, wave form: the row pass shared with the sweep's fused epilogue (composite_core.h)
     float w[NS];

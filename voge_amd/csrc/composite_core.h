@@ -205,4 +205,201 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
   for (int a = 0; a < NS; ++a) w[a] = (em[a] != 0.0f) ? FAST_EXP(-occ * S[a]) * em[a] * kInvNorm : 0.0f;
 }
 
+// Backward, wave form, with the forward's weights given (u_m = g_m w_m comes from the caller): the closed-form
+// gradients of the lane's own slots (header of composite.hip).  The pixel's padded rows len / s' / E s' are in LDS
+// (the sentinel pads' u entries are zero); this routine stores u into Lu itself.  Same conventions as compn_fwd_rows.
+template <int NS>
+__device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const float (&sm)[NS], const float (&em)[NS],
+                                               const float (&um)[NS], const float *Llen, const float *Lsp, const float *LE,
+                                               float *Lu, const int d0, const int k0, const int K, const int q, const int LP,
+                                               const bool in_wg, const bool active, const bool sorted, const int seg_lo,
+                                               const float occ, float (&ga)[NS], float (&gl)[NS], float (&gd)[NS]) {
+  constexpr int NP = NS / 2;
+  const int lane = threadIdx.x & 63;
+  float sp[NS], Es[NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) { sp[a] = sm[a] * kCs; Es[a] = em[a] * sp[a]; }
+  float mx = 0.0f;
+#pragma unroll
+  for (int a = 0; a < NS; ++a) mx = fmaxf(mx, (em[a] != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm[a]) : 0.0f);
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float y = __shfl_down(mx, o, 64);
+    if (lane + o < 64 && q + o < LP) mx = fmaxf(mx, y);
+  }
+  const float wave_rmax = __shfl(mx, seg_lo, 64);                // the pixel's first lane holds the maximum
+  const float rwin = sorted ? (in_wg ? wave_rmax : 0.0f) : 0.0f;
+  bool any_e = false;
+#pragma unroll
+  for (int a = 0; a < NS; ++a) any_e = any_e || (em[a] != 0.0f);
+  const float h0 = __builtin_amdgcn_exp2f(kQ0);      // h(0), exactly what h_pair(0) returns
+  // ---- rows = the lane's own slots: r_m = sum over the window of E_j s_j phi_mj ----
+  float rterm[NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) rterm[a] = 0.0f;
+  if (any_e && sorted) {
+    v2f accR[NS];
+#pragma unroll
+    for (int a = 0; a < NS; ++a) accR[a] = splat(0.0f);
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+      accR[a].x = Es[a];         // self
+#pragma unroll
+      for (int b2 = a + 1; b2 < NS; ++b2) {
+        const float gap = lm[b2] - lm[a];
+        const v2f xp = (v2f){gap * sp[b2], gap * sp[a]};                 // (row a, col b), (row b, col a)
+        const v2f g = gauss_pair(xp);
+        accR[a].y = fmaf(Es[b2], g.x, accR[a].y);
+        accR[b2].y = fmaf(Es[a], g.y, accR[b2].y);
+      }
+    }
+    float lmB = lm[0];                 // the last live row decides how far back to walk
+#pragma unroll
+    for (int a = 1; a < NS; ++a) lmB = (em[a] != 0.0f) ? lm[a] : lmB;
+    for (int e = d0 - 2;; e -= 2) {      // column pairs in front of every own row; row 0 is the nearest
+      const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
+      if (!(lm[0] - l2.y < rwin)) break;
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const v2f xa = (splat(lm[a]) - l2) * s2;
+        accR[a] = pk_fma(E2, gauss_pair(xa), accR[a]);
+      }
+    }
+    for (int e = d0 + NS;; e += 2) {     // column pairs behind every own row
+      const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
+      if (!(l2.x - lmB < rwin)) break;
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const v2f xa = (l2 - splat(lm[a])) * s2;
+        accR[a] = pk_fma(E2, gauss_pair(xa), accR[a]);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NS; ++a) rterm[a] = (accR[a].x + accR[a].y) * (kRsqrtPi / kCs);
+  } else if (any_e && active) {          // unsorted list: every column
+    const int r0 = d0 - k0;
+    for (int j = 0; j < K; ++j) {
+      const float Ej = LE[r0 + j];
+      if (Ej == 0.0f) continue;
+      const float lj = Llen[r0 + j], sj = Lsp[r0 + j];
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const float xp = (lm[a] - lj) * sj;
+        const float xc = fminf(fabsf(xp), 16.0f);
+        rterm[a] = fmaf(Ej * (kRsqrtPi / kCs), __builtin_amdgcn_exp2f(-xc * xc), rterm[a]);
+      }
+    }
+  }
+  // ---- u, its suffix sums over the pixel, then the lane's own columns ----
+  float usum = 0.0f;
+#pragma unroll
+  for (int a = 0; a < NS; ++a) usum += um[a];
+  if (in_wg) {
+#pragma unroll
+    for (int h2 = 0; h2 < NP; ++h2) *reinterpret_cast<v2f *>(Lu + d0 + 2 * h2) = (v2f){um[2 * h2], um[2 * h2 + 1]};
+  }
+  float sx;   // sum of u over the slots behind this lane's group
+  {
+    const float y = __shfl_down(usum, 1, 64);
+    float x = (q + 1 < LP && in_wg) ? y : 0.0f;
+    for (int o = 1; o < LP; o <<= 1) {
+      const float z = __shfl_down(x, o, 64);
+      if (q + o < LP && in_wg) x += z;
+    }
+    sx = x;
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int a = 0; a < NS; ++a) { ga[a] = 0.0f; gl[a] = 0.0f; gd[a] = 0.0f; }
+  if (any_e && active) {
+    float cPhi[NS], cphi[NS], cphil[NS];
+    if (sorted) {
+      float rj[NS];
+      v2f aH[NS], aP[NS], aL[NS], bH[NS], bP[NS], bL[NS];   // per own column: rows behind (a*) / in front (b*)
+#pragma unroll
+      for (int b2 = 0; b2 < NS; ++b2) {
+        rj[b2] = (em[b2] != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm[b2]) : 0.0f;   // an empty column needs no rows
+        aH[b2] = (v2f){um[b2] * h0, 0.0f}; aP[b2] = (v2f){um[b2], 0.0f}; aL[b2] = splat(0.0f);   // self
+        bH[b2] = splat(0.0f); bP[b2] = splat(0.0f); bL[b2] = splat(0.0f);
+      }
+      // diagonal block: for own slots a < b, row b is behind column a and row a in front of column b
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+#pragma unroll
+        for (int b2 = a + 1; b2 < NS; ++b2) {
+          const float gap = lm[b2] - lm[a];
+          const v2f xp = (v2f){gap * sp[a], gap * sp[b2]};      // (row b, col a), (row a, col b)
+          const v2f g = gauss_pair(xp), h = h_pair(xp);
+          aH[a].y = fmaf(um[b2], h.x, aH[a].y); aP[a].y = fmaf(um[b2], g.x, aP[a].y); aL[a].y = fmaf(um[b2] * g.x, gap, aL[a].y);
+          bH[b2].y = fmaf(um[a], h.y, bH[b2].y); bP[b2].y = fmaf(um[a], g.y, bP[b2].y); bL[b2].y = fmaf(um[a] * g.y, gap, bL[b2].y);
+        }
+      }
+      for (int e = d0 + NS;; e += 2) {     // row pairs behind every own column
+        const v2f l2 = ld2(Llen, e), u2 = ld2(Lu, e);
+        bool need = false;
+#pragma unroll
+        for (int b2 = 0; b2 < NS; ++b2) need = need || (l2.x - lm[b2] < rj[b2]);
+        if (!need) break;
+#pragma unroll
+        for (int b2 = 0; b2 < NS; ++b2) {
+          const v2f d = l2 - splat(lm[b2]);
+          const v2f xp = d * splat(sp[b2]);
+          const v2f y = u2 * gauss_pair(xp);
+          aH[b2] = pk_fma(u2, h_pair(xp), aH[b2]); aP[b2] = aP[b2] + y; aL[b2] = pk_fma(y, d, aL[b2]);
+        }
+      }
+      for (int e = d0 - 2;; e -= 2) {      // row pairs in front of every own column
+        const v2f l2 = ld2(Llen, e), u2 = ld2(Lu, e);
+        bool need = false;
+#pragma unroll
+        for (int b2 = 0; b2 < NS; ++b2) need = need || (lm[b2] - l2.y < rj[b2]);
+        if (!need) break;
+#pragma unroll
+        for (int b2 = 0; b2 < NS; ++b2) {
+          const v2f d = splat(lm[b2]) - l2;
+          const v2f xp = d * splat(sp[b2]);
+          const v2f y = u2 * gauss_pair(xp);
+          bH[b2] = pk_fma(u2, h_pair(xp), bH[b2]); bP[b2] = bP[b2] + y; bL[b2] = pk_fma(y, d, bL[b2]);
+        }
+      }
+      float suf = sx;
+#pragma unroll
+      for (int b2 = NS - 1; b2 >= 0; --b2) {
+        suf += um[b2];                                                   // inclusive suffix sum of u
+        cPhi[b2] = (suf - (aH[b2].x + aH[b2].y)) + (bH[b2].x + bH[b2].y);
+        cphi[b2] = ((aP[b2].x + aP[b2].y) + (bP[b2].x + bP[b2].y)) * kRsqrtPi;
+        cphil[b2] = ((aL[b2].x + aL[b2].y) - (bL[b2].x + bL[b2].y)) * kRsqrtPi;
+      }
+    } else {
+#pragma unroll
+      for (int b2 = 0; b2 < NS; ++b2) { cPhi[b2] = 0.0f; cphi[b2] = 0.0f; cphil[b2] = 0.0f; }
+      const int r0 = d0 - k0;
+      for (int m = 0; m < K; ++m) {
+        const float ur = Lu[r0 + m];
+        if (ur == 0.0f) continue;
+        const float lr = Llen[r0 + m];
+#pragma unroll
+        for (int b2 = 0; b2 < NS; ++b2) {
+          const float dl = lr - lm[b2];
+          const float xp = dl * sp[b2];
+          const float h = h_one(fabsf(xp));
+          const float xc = fminf(fabsf(xp), 16.0f);
+          const float ph = ur * (__builtin_amdgcn_exp2f(-xc * xc) * kRsqrtPi);
+          cPhi[b2] = fmaf(ur, xp >= 0.0f ? 1.0f - h : h, cPhi[b2]);
+          cphi[b2] += ph;
+          cphil[b2] = fmaf(ph, dl, cphil[b2]);
+        }
+      }
+    }
+#pragma unroll
+    for (int b2 = 0; b2 < NS; ++b2) {
+      if (em[b2] != 0.0f) {
+        ga[b2] = fmaf(occ * em[b2], cPhi[b2], -um[b2]);
+        gl[b2] = -occ * (um[b2] * rterm[b2] - em[b2] * sm[b2] * cphi[b2]);
+        gd[b2] = -occ * em[b2] * (0.5f * __builtin_amdgcn_rcpf(sm[b2])) * cphil[b2];
+      }
+    }
+  }
+}
+
 }  // namespace voge

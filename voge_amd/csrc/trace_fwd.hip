@@ -1067,7 +1067,8 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
                                const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
                                float thr_act, void *workspace, size_t workspace_bytes,
                                int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
-                               voge_stream_t stream, float occ = 1.0f, float *weight = nullptr, int64_t *valid_num = nullptr) {
+                               voge_stream_t stream, float occ = 1.0f, float *weight = nullptr, int64_t *valid_num = nullptr,
+                               float *records = nullptr) {
   if (B < 0 || N < 0 || H < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K) return VOGE_ERR_K_TOO_LARGE;
   if ((size_t)B * H * W == 0) return 0;  // numel == 0 early return (ray_trace_voge.cu:248-251)
@@ -1080,6 +1081,7 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   const int P = B * N;
   TraceWs ws;
   trace_ws_layout(B, N, H, W, workspace, &ws);
+  if (records != nullptr) ws.ms = reinterpret_cast<float4 *>(records);      // the caller keeps the (centre, a) records (backward)
   // super-tile cones: the caller's (voge_rays_fwd makes them while it makes the rays), or one more launch here
   const ConeRec *cones = reinterpret_cast<const ConeRec *>(cones_in);
   if (cones == nullptr) {
@@ -1188,18 +1190,20 @@ extern "C" int voge_fragments_fwd(const float *mus, const float *isigmas, const 
 extern "C" int voge_fragments_fwd_iso(const float *mus, const float *a, const float *rays, const float *cam_fwd,
                                       const float *cones, int B, int N, int H, int W, int K, float thr_act, float occ,
                                       void *workspace, size_t workspace_bytes, int32_t *idx, float *len, float *act,
-                                      float *dsd, int32_t *cnt, float *weight, int64_t *valid_num, voge_stream_t stream) {
+                                      float *dsd, int32_t *cnt, float *weight, int64_t *valid_num, float *records,
+                                      voge_stream_t stream) {
   if (!weight || !valid_num || !cnt) return VOGE_ERR_BAD_ARG;
   return trace_topk_fwd_impl(1, IsoView{nullptr, 0, 0}, mus, a, rays, cam_fwd, cones, B, N, H, W, K, thr_act, workspace,
-                             workspace_bytes, idx, len, act, dsd, cnt, stream, occ, weight, valid_num);
+                             workspace_bytes, idx, len, act, dsd, cnt, stream, occ, weight, valid_num, records);
 }
 
 extern "C" int voge_fragments_fwd_iso_view(const float *verts, const float *sigmas, const float *origin, int shared,
                                            int sigma_mode, const float *rays, const float *cam_fwd, const float *cones,
                                            int B, int N, int H, int W, int K, float thr_act, float occ, void *workspace,
                                            size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
-                                           int32_t *cnt, float *weight, int64_t *valid_num, voge_stream_t stream) {
+                                           int32_t *cnt, float *weight, int64_t *valid_num, float *records,
+                                           voge_stream_t stream) {
   if (sigma_mode < 0 || sigma_mode > 2 || !weight || !valid_num || !cnt) return VOGE_ERR_BAD_ARG;
   return trace_topk_fwd_impl(1, IsoView{origin, shared ? 1 : 0, sigma_mode}, verts, sigmas, rays, cam_fwd, cones, B, N, H, W, K,
-                             thr_act, workspace, workspace_bytes, idx, len, act, dsd, cnt, stream, occ, weight, valid_num);
+                             thr_act, workspace, workspace_bytes, idx, len, act, dsd, cnt, stream, occ, weight, valid_num, records);
 }

@@ -373,20 +373,22 @@ class _Fragments(torch.autograd.Function):
         sel_act, sel_dsd, weight = torch.empty_like(sel_len), torch.empty_like(sel_len), torch.empty_like(sel_len)
         cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
         valid = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+        # scalar forms: the per-Gaussian (centred mean, a) records outlive the call -- the fused backward reads them
+        records = torch.empty((B * N, 4), dtype=torch.float32, device=dev) if mode != 0 else None
         fwd = None if cam_fwd is None else _dev(cam_fwd, torch.float32, "cam_fwd")
         with _on(dev):
             nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
             ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
             tail = (B, N, H, W, K, float(thr_act), float(occ), _p(ws), nbytes, _p(sel_idx), _p(sel_len), _p(sel_act),
-                    _p(sel_dsd), _p(cnt), _p(weight), _p(valid), _stream())
+                    _p(sel_dsd), _p(cnt), _p(weight), _p(valid))
             cones = _p(cones_of(rays_c, B, H, W))
             if mode == 2:
                 rc = lib.voge_fragments_fwd_iso_view(_p(p0_c), _p(p1_c), _p(o_c), int(shared), int(sigma_mode), _p(rays_c),
-                                                     _p(fwd), cones, *tail)
+                                                     _p(fwd), cones, *tail, _p(records), _stream())
             elif mode == 1:
-                rc = lib.voge_fragments_fwd_iso(_p(p0_c), _p(p1_c), _p(rays_c), _p(fwd), cones, *tail)
+                rc = lib.voge_fragments_fwd_iso(_p(p0_c), _p(p1_c), _p(rays_c), _p(fwd), cones, *tail, _p(records), _stream())
             else:
-                rc = lib.voge_fragments_fwd(_p(p0_c), _p(p1_c), _p(rays_c), _p(fwd), cones, *tail)
+                rc = lib.voge_fragments_fwd(_p(p0_c), _p(p1_c), _p(rays_c), _p(fwd), cones, *tail, _stream())
         _lib.check(rc, "voge_fragments_fwd")
         ctx.save_for_backward(p0_c, p1_c, rays_c, sel_act, sel_len, sel_dsd, weight)
         ctx.origin, ctx.sel_idx, ctx.cnt = o_c, sel_idx, cnt
@@ -394,6 +396,11 @@ class _Fragments(torch.autograd.Function):
         _tag_index(sel_idx, cnt, B * N)
         ctx.mark_non_differentiable(sel_idx, valid)
         ctx.set_materialize_grads(False)
+        # what a later to_colored_background needs to run the whole backward in one kernel (see _ShadeThrough)
+        ctx.through = None if mode == 0 else dict(mode=int(mode), sigma_mode=int(sigma_mode), shared=bool(shared), occ=float(occ),
+                                                  B=B, N=N, records=records, rays=rays_c, act=sel_act, dsd=sel_dsd, len=sel_len,
+                                                  cnt=cnt, idx=sel_idx, sigmas=p1_c)
+        _Fragments._last_through = ctx.through
         return weight, sel_idx, valid, sel_len
 
     @staticmethod
@@ -401,6 +408,8 @@ class _Fragments(torch.autograd.Function):
         lib = _lib.load()
         p0, p1, rays, act, ln, dsd, weight = ctx.saved_tensors
         mode, sigma_mode, shared, occ, B, N = ctx.meta
+        if g_weight is None and g_hitlen is None:      # nothing reached the fragments (e.g. _ShadeThrough took the frame)
+            return (None,) * 10
         sel_idx, cnt = ctx.sel_idx, ctx.cnt
         _, H, W, K = sel_idx.shape
         npix = B * H * W
@@ -442,7 +451,89 @@ class _Fragments(torch.autograd.Function):
 
 
 def fragments(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode=0, occ=1.0):
-    return _Fragments.apply(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode, occ)
+    """-> weight, sel_idx, valid_num, sel_len.  The weight tensor carries `voge_through`: the inputs and saved tensors
+    of this call, which lets a later to_colored_background(fragments, colors) run shade + composite + trace backward
+    as ONE kernel (_ShadeThrough)."""
+    _Fragments._last_through = None
+    out = _Fragments.apply(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode, occ)
+    th = _Fragments._last_through
+    _Fragments._last_through = None
+    if th is not None and (p0.requires_grad or p1.requires_grad) and torch.is_grad_enabled():
+        th = dict(th, p0=p0, p1=p1, weight_version=out[0]._version)
+        out[0].voge_through = th
+    return out
+
+
+class _ShadeThrough(torch.autograd.Function):
+    """to_colored_background on fragments this renderer made, for isotropic Gaussians: the forward is _Shade's, the
+    backward runs shade -> composite -> trace as ONE kernel (voge_fragment_shade_bwd_iso) and hands the gradients
+    straight to the colours AND to the Gaussians' (verts | means, sigmas | a), which are inputs of this node for that
+    purpose; the weights get no gradient from here.  Every stage is linear in the gradient of the weights, so whatever
+    else consumes the same weights (a silhouette loss, a second image) still flows through _Fragments.backward and the
+    contributions add up in the parameters' .grad exactly as with separate nodes."""
+
+    @staticmethod
+    def forward(ctx, attr, weight, p0, p1, th, idx, valid_num, bg, thr):
+        lib = _lib.load()
+        attr_c = _dev(attr, torch.float32, "colors")
+        w = _dev(weight, torch.float32, "weight")
+        vn = _dev(valid_num, torch.int64, "valid_num")
+        bg_c = _dev(bg, torch.float32, "background_color")
+        K = idx.shape[-1]
+        npix = idx.numel() // max(K, 1)
+        Nattr, C = attr_c.shape
+        assert C <= 4 and bg_c.numel() == C
+        check_index_range(idx, Nattr)
+        rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
+        img = torch.empty_like(rgb)
+        wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
+        with _on(idx.device):
+            rc = lib.voge_shade_fwd(_p(attr_c), _p(idx), _p(w), _p(vn), _p(bg_c), float(thr), npix, K, C, Nattr, 1,
+                                    _p(rgb), _p(img), None, _p(wsum), _stream())
+        _lib.check(rc, "voge_shade_fwd")
+        ctx.save_for_backward(attr_c, w, rgb, bg_c, wsum)
+        ctx.th, ctx.idx, ctx.thr = th, idx, float(thr)
+        return img
+
+    @staticmethod
+    def backward(ctx, g_img):
+        lib = _lib.load()
+        attr, w, rgb, bg, wsum = ctx.saved_tensors
+        th, idx = ctx.th, ctx.idx
+        B, H, W, K = idx.shape
+        Nattr, C = attr.shape
+        go = _dev(g_img, torch.float32, "grad_image")
+        g_attr = torch.empty_like(attr)
+        p0, p1 = th["p0"], th["p1"]
+        g0 = torch.empty(p0.shape, dtype=torch.float32, device=idx.device)
+        g1 = torch.empty(p1.shape, dtype=torch.float32, device=idx.device)
+        P = th["B"] * th["N"]
+        with _on(idx.device):
+            nbytes = lib.voge_fragment_bwd_workspace_bytes(P)
+            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=idx.device)
+            rc = lib.voge_fragment_shade_bwd_iso(
+                _p(th["records"]), _p(th["sigmas"]), int(th["shared"]), th["sigma_mode"], _p(th["rays"]), _p(attr), _p(idx),
+                _p(th["cnt"]), _p(w), _p(th["act"]), _p(th["len"]), _p(th["dsd"]), _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go),
+                th["occ"], th["B"], th["N"], B * H, W, K, C, Nattr, _p(ws), nbytes, _p(g0), _p(g1), _p(g_attr), _stream())
+        _lib.check(rc, "voge_fragment_shade_bwd_iso")
+        need = ctx.needs_input_grad
+        return (g_attr if need[0] else None), None, (g0 if need[2] else None), (g1 if need[3] else None), None, None, None, None, None
+
+
+def shade_through(attr, fragments_weight, idx, valid_num, bg, thr):
+    """The fused-backward form of shade() when `fragments_weight` still is the untouched output of fragments() (scalar
+    sigmas, K even and <= 128, <= 4 channels, nobody watching the weights' own gradient); None otherwise."""
+    th = getattr(fragments_weight, "voge_through", None)
+    if th is None or not torch.is_grad_enabled():
+        return None
+    K = idx.shape[-1]
+    if (K & 1) or K > 128 or attr.dim() != 2 or attr.shape[1] > 4 or idx is not th["idx"] or hit_count_of(idx) is None:
+        return None
+    if fragments_weight._version != th["weight_version"] or fragments_weight.retains_grad or fragments_weight._backward_hooks:
+        return None
+    if th["len"]._version != 0 or th["rays"].requires_grad:
+        return None
+    return _ShadeThrough.apply(attr, fragments_weight, th["p0"], th["p1"], th, idx, valid_num, bg, thr)
 
 
 class _Composite(torch.autograd.Function):
