@@ -486,8 +486,8 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
     float um[NS], ga[NS], gl[NS], gd[NS];
 #pragma unroll
     for (int a = 0; a < NS; ++a) um[a] = gw[a] * wg[a];
-    compn_bwd_wave<NS>(lm, sm, em, um, Llen, Lsp, LE, Lu, d0, k0, K, q, LP, in_wg, active, active && !wave_unsorted, seg_lo, occ,
-                       ga, gl, gd);
+    compn_bwd_wave<NS>(lm, sm, em, um, Llen, Lsp, LE, Lu, d0, k0, K, q, LP, LP, in_wg, active, active && !wave_unsorted, seg_lo,
+                       occ, ga, gl, gd);
     if (active) {
       if (vec && NS == 4) {
         *reinterpret_cast<float4 *>(out0 + f) = make_float4(ga[0], ga[1], ga[NS - 2], ga[NS - 1]);
@@ -507,7 +507,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   if (!BWD && WAVE) {
     // forward, wave form: the row pass shared with the sweep's fused epilogue (composite_core.h)
     float w[NS];
-    compn_fwd_rows<NS>(lm, sm, em, Llen, Lsp, LE, d0, k0, K, q, LP, in_wg, active, active && !wave_unsorted, seg_lo, occ, w);
+    compn_fwd_rows<NS>(lm, sm, em, Llen, Lsp, LE, d0, k0, K, q, LP, LP, in_wg, active, active && !wave_unsorted, seg_lo, occ, w);
     if (active) {
       if (vec && NS == 4) *reinterpret_cast<float4 *>(out0 + f) = make_float4(w[0], w[1], w[NS - 2], w[NS - 1]);
       else if (vec) *reinterpret_cast<v2f *>(out0 + f) = (v2f){w[0], w[1]};

@@ -101,14 +101,16 @@ __host__ __device__ inline int compn_rows(const int K, const int NS, const int t
 // sit inside ONE wave, the pixel's padded (len, s', E) rows are in LDS (row origin of this lane's group: d0, an even
 // index) and visible to the wave.  lm / sm / em: the lane's own len, s = sqrt(dsd + 1e-10), E = exp(-act) (E = 0 for
 // an empty slot).  `sorted`: the pixel's list is depth ordered (the windowed walk); otherwise every column is visited.
+// LP, q, seg_lo, d0, k0, K are PER-LANE values (pixels of different lane counts may share a wave: the packed kernels);
+// LPmax is a wave-uniform upper bound of LP (the trip count of the scans).
 // Returns the weights of the lane's slots.  The association of the scans is a function of the lane's index in the
 // pixel only, so a pixel's result does not depend on where it sits (row bands == whole frame, fused == stand-alone).
 template <int NS>
 __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const float (&sm)[NS], const float (&em)[NS],
                                                const float *Llen, const float *Lsp, const float *LE, const int d0,
-                                               const int k0, const int K, const int q, const int LP, const bool in_wg,
-                                               const bool active, const bool sorted, const int seg_lo, const float occ,
-                                               float (&w)[NS]) {
+                                               const int k0, const int K, const int q, const int LP, const int LPmax,
+                                               const bool in_wg, const bool active, const bool sorted, const int seg_lo,
+                                               const float occ, float (&w)[NS]) {
   float sp[NS];
 #pragma unroll
   for (int a = 0; a < NS; ++a) sp[a] = sm[a] * kCs;
@@ -125,7 +127,7 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
     v2f x = {esum, mx};
     const v2f y = (v2f){__shfl_up(x.x, 1, 64), __shfl_up(x.y, 1, 64)};
     x = (q > 0 && in_wg) ? (v2f){y.x, fmaxf(mx, y.y)} : (v2f){0.0f, mx};
-    for (int o = 1; o < LP; o <<= 1) {
+    for (int o = 1; o < LPmax; o <<= 1) {
       const v2f z = (v2f){__shfl_up(x.x, o, 64), __shfl_up(x.y, o, 64)};
       if (q >= o && in_wg) {
         x.x += z.x;
@@ -212,8 +214,9 @@ template <int NS>
 __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const float (&sm)[NS], const float (&em)[NS],
                                                const float (&um)[NS], const float *Llen, const float *Lsp, const float *LE,
                                                float *Lu, const int d0, const int k0, const int K, const int q, const int LP,
-                                               const bool in_wg, const bool active, const bool sorted, const int seg_lo,
-                                               const float occ, float (&ga)[NS], float (&gl)[NS], float (&gd)[NS]) {
+                                               const int LPmax, const bool in_wg, const bool active, const bool sorted,
+                                               const int seg_lo, const float occ, float (&ga)[NS], float (&gl)[NS],
+                                               float (&gd)[NS]) {
   constexpr int NP = NS / 2;
   const int lane = threadIdx.x & 63;
   float sp[NS], Es[NS];
@@ -302,7 +305,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
   {
     const float y = __shfl_down(usum, 1, 64);
     float x = (q + 1 < LP && in_wg) ? y : 0.0f;
-    for (int o = 1; o < LP; o <<= 1) {
+    for (int o = 1; o < LPmax; o <<= 1) {
       const float z = __shfl_down(x, o, 64);
       if (q + o < LP && in_wg) x += z;
     }
@@ -400,6 +403,50 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Lane packing by hit count.  With the trace's per-pixel hit count at hand a pixel needs ceil(count / NS) lanes, not
+// ceil(K / NS): at cfg3 the lit pixels hold 18 of K = 40 slots on average and 40 % of the pixels none, so a wave laid
+// out for K idles more than half of its lanes through every scan, window walk and table update.  The packed kernels
+// give a wave a GROUP of G <= 64 pixels (lane g < G holds pixel g's lane need) and walk it in rounds; a round takes
+// the longest run of consecutive pixels whose lanes fit the wave.  A pixel's lanes stay adjacent and in slot order,
+// so everything per pixel (scan association, window walks) is what the K-strided layout computes: bit-identical.
+struct PackLane {
+  int p;      // the lane's pixel inside the group (-1: idle lane)
+  int s0;     // first lane of that pixel
+  int np;     // its lanes
+  int ord;    // its ordinal among the round's non-empty pixels (row origins in LDS)
+};
+// inclusive prefix sum over the wave
+__device__ __forceinline__ int wave_incl_scan(int v, const int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(v, o, 64);
+    if (lane >= o) v += y;
+  }
+  return v;
+}
+// One round: pixels [pc, pe) of the group (pe returned; uniform), `off` = lanes consumed by earlier rounds.
+// need / incl: lane g's pixel need and its inclusive prefix (lanes >= G: need 0).  np_max: the longest pixel of the round.
+__device__ __forceinline__ int pack_round(const int need, const int incl, const int G, const int lane, const int pc,
+                                          const int off, PackLane &pl, int &np_max) {
+  const unsigned long long fit = __ballot(lane >= pc && lane < G && incl - off <= 64);
+  const int pe = pc + __popcll(fit);      // (incl is monotone: the fitting pixels are a run; need <= 64: never empty)
+  pl.p = -1; pl.s0 = 0; pl.np = 0; pl.ord = 0;
+  int c = 0, nm = 0;
+  const int excl = incl - need;
+  for (int p = pc; p < pe; ++p) {         // uniform
+    const int n = __builtin_amdgcn_readlane(need, p);
+    if (n == 0) continue;
+    const int s = __builtin_amdgcn_readlane(excl, p) - off;
+    if (lane >= s) { pl.p = p; pl.s0 = s; pl.np = n; pl.ord = c; }
+    ++c;
+    nm = max(nm, n);
+  }
+  if (lane >= pl.s0 + pl.np) pl.p = -1;   // lanes behind the round's last pixel
+  np_max = nm;
+  return pe;
 }
 
 }  // namespace voge

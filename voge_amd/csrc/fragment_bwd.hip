@@ -26,87 +26,86 @@ namespace voge {
 #define VOGE_FB_NE 128
 #endif
 constexpr int kFbNE = VOGE_FB_NE;  // table entries per wave
-// A wave's block of pixels: COLS rounds (of 64 / (K/2) pixels each) along x, ROWS image rows.  Swept on MI355X at cfg3
-// (backward of the frame, us): 4x4 253, 3x3 219, 4x2 208, 2x4 203, 3x2 196, 1x1 194, 4x1 191, 1x4 187, 2x2 185 -- more,
-// shorter waves beat table reuse (a 64-entry table: 213).
-#ifndef VOGE_FB_COLS
-#define VOGE_FB_COLS 2
+// A wave's group of pixels: GW x GH (<= 64 pixels; lane g of the wave holds pixel (g % GW, g / GW)'s hit count).  The
+// lanes are handed out by those counts (composite_core.h, "Lane packing by hit count"): ceil(count / 2) lanes per
+// pixel, as many consecutive pixels per round as fit the wave.
+#ifndef VOGE_FB_GW
+#define VOGE_FB_GW 4
 #endif
-#ifndef VOGE_FB_ROWS
-#define VOGE_FB_ROWS 2
+#ifndef VOGE_FB_GH
+#define VOGE_FB_GH 3
 #endif
-constexpr int kFbColsPerRow = VOGE_FB_COLS;  // rounds per image row of a wave's block
-constexpr int kFbRows = VOGE_FB_ROWS;        // image rows of a wave's block
+constexpr int kFbGW = VOGE_FB_GW, kFbGH = VOGE_FB_GH, kFbG = kFbGW * kFbGH;
+static_assert(kFbG <= 64 && (kFbGW & (kFbGW - 1)) == 0, "a group's pixels are the lanes of one wave; GW a power of two");
+constexpr int kFbRowsLds = 2 * 64 + 4 * kFbG;      // a round's padded rows: 64 lanes' slots + two sentinel pairs per pixel
 
 struct FragBwdLds {
   WaveTable<kFbNE, 2> tab;        // key = Gaussian index; values = (g_mu, g_a), (w g_rgb, -)
+  float len[kFbRowsLds], sp[kFbRowsLds], E[kFbRowsLds], u[kFbRowsLds];
 };
 
-#ifndef VOGE_FB_WPE
-#define VOGE_FB_WPE 4      // 126 VGPRs; capping them at 96 / 80 (5 / 6 waves per SIMD) spills: 208 -> 220 / 246 us of backward
+#ifndef VOGE_FB_ABL
+#define VOGE_FB_ABL 0
 #endif
+#ifndef VOGE_FB_WPE
+#define VOGE_FB_WPE 4      // capping the registers for 5 / 6 waves per SIMD spills and is slower
+#endif
+// C: colour channels (1..4); OffT: uint32_t when every element offset of the [pix][K] arrays fits 30 bits (the loads
+// then take scalar base + 32-bit lane offset and the address arithmetic leaves the vector unit), else size_t.
+template <int C, typename OffT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VOGE_FB_WPE)))
 fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */, const float *__restrict__ rays,
                         const float *__restrict__ colors, const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt,
                         const float *__restrict__ weight, const float *__restrict__ act, const float *__restrict__ len,
                         const float *__restrict__ dsd, const float *__restrict__ rgb, const float *__restrict__ wsum,
                         const float *__restrict__ bg, const float thr, const float *__restrict__ g_img, const float occ,
-                        const int P, const long nrows, const int W, const int K, const int C, const long Nattr,
+                        const int P, const long nrows, const int W, const int K, const long Nattr,
                         float *__restrict__ acc /* [P][8], zeroed */) {
   constexpr int NS = 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
-  FragBwdLds &L = *reinterpret_cast<FragBwdLds *>(fb_smem);
+  __shared__ __attribute__((aligned(16))) FragBwdLds L;
+  float *const Llen = L.len, *const Lsp = L.sp, *const LE = L.E, *const Lu = L.u;
   const int lane = threadIdx.x;
-  const int LP = compn_lanes(K, NS), pw = 64 / LP;
-  const int rows = compn_rows(K, NS, 64, true);
-  float *const Llen = reinterpret_cast<float *>(fb_smem + ((sizeof(FragBwdLds) + 15) & ~(size_t)15));
-  float *const Lsp = Llen + rows, *const LE = Lsp + rows, *const Lu = LE + rows;
-  const int RS = compn_stride(K, NS);
-  const int pl = __float2int_rz(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)LP)), q = lane - pl * LP;
-  const bool in_wg = pl < pw;
-  const int k0 = NS * q, seg_lo = lane - q;
-  const int d0 = (in_wg ? pl : 0) * RS + 2 + (in_wg ? k0 : 0);
-  // block of this wave: kFbRows rows x (pw * kFbColsPerRow) columns
-  const int bw = pw * kFbColsPerRow;
-  const int blocks_x = (W + bw - 1) / bw;
+  const int blocks_x = (W + kFbGW - 1) / kFbGW;
   const long blk = blockIdx.x;
-  const int x0 = (int)(blk % blocks_x) * bw;
-  const long y0 = (blk / blocks_x) * kFbRows;
-  if (y0 >= nrows) return;
-  // the sentinel pairs in front of and behind every pixel's row: written once (u = 0 there, always)
-  if (in_wg && q < 2) {
-    const int r0 = pl * RS;
-    for (int t2 = q; t2 < 2; t2 += LP) {
-      Llen[r0 + t2] = -kBig; Lsp[r0 + t2] = 1.0f; LE[r0 + t2] = 0.0f; Lu[r0 + t2] = 0.0f;
-      const int eb = r0 + RS - 2 + t2;
-      Llen[eb] = kBig; Lsp[eb] = 1.0f; LE[eb] = 0.0f; Lu[eb] = 0.0f;
-    }
-  }
-  bool table_used = false;
-  for (int round = 0; round < kFbRows * kFbColsPerRow; ++round) {
-    const int ry = round / kFbColsPerRow, rx = round - ry * kFbColsPerRow;
-    const long y = y0 + ry;
-    const int x = x0 + rx * pw + pl;
-    const bool on = in_wg && y < nrows && x < W;
-    const long pix = on ? y * W + x : 0;
-    const int lead = on ? min(K, max(0, cnt[pix])) : 0;
-    if (!__any(lead > 0)) continue;     // (uniform) nothing was hit in these pixels
-    if (!table_used) { wt_clear(L.tab, lane); table_used = true; }
-    const long f = pix * K + k0;
+  const int x0 = (int)(blk % blocks_x) * kFbGW;
+  const long y0 = (blk / blocks_x) * kFbGH;
+  // the group's hit counts -> lanes per pixel
+  const int gx = x0 + (lane & (kFbGW - 1));
+  const long gy = y0 + lane / kFbGW;
+  const bool pv = lane < kFbG && gx < W && gy < nrows;
+  const int lead_g = pv ? min(K, max(0, cnt[gy * W + gx])) : 0;
+  const int need = (lead_g + NS - 1) / NS;
+  const int incl = wave_incl_scan(need, lane);
+  if (__builtin_amdgcn_readlane(incl, 63) == 0) return;     // nothing was hit in these pixels
+  wt_clear(L.tab, lane);
+  int pc = 0, off = 0;
+  while (pc < kFbG) {
+    PackLane pk;
+    int npm;
+    const int pe = pack_round(need, incl, kFbG, lane, pc, off, pk, npm);
+    off = __builtin_amdgcn_readlane(incl, pe - 1);
+    pc = pe;
+    if (npm == 0) continue;       // (uniform) a run of empty pixels
+    const bool on = pk.p >= 0;
+    const int q = on ? lane - pk.s0 : 0, LP = on ? pk.np : 1;
+    const int lead = __shfl(lead_g, on ? pk.p : 0, 64);
+    const int k0 = NS * q;
+    const OffT pix = on ? (OffT)((y0 + pk.p / kFbGW) * W + x0 + (pk.p & (kFbGW - 1))) : (OffT)0;
+    const OffT f = pix * (OffT)K + (OffT)k0;
+    const int r0 = NS * pk.s0 + 4 * pk.ord, RS = NS * LP + 4;
+    const int d0 = on ? r0 + 2 + k0 : 2;
     // ---- the lane's two slots ----
     int id[NS];
     float wv[NS], lm[NS], sm[NS], em[NS];
     bool live[NS];
 #pragma unroll
     for (int a = 0; a < NS; ++a) { id[a] = -1; wv[a] = 0.f; lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.f; live[a] = on && (k0 + a < lead); }
-    if (live[1]) {              // both slots: 8-byte accesses (K is even: the pair is aligned)
+    if (live[0]) {              // 8-byte accesses (K is even: the pair is aligned and inside the pixel's row)
       const int2 i2 = *reinterpret_cast<const int2 *>(idx + f);
       const v2f w2 = *reinterpret_cast<const v2f *>(weight + f), a2 = *reinterpret_cast<const v2f *>(act + f),
                 l2 = *reinterpret_cast<const v2f *>(len + f), d2 = *reinterpret_cast<const v2f *>(dsd + f);
-      id[0] = i2.x; id[1] = i2.y; wv[0] = w2.x; wv[1] = w2.y; lm[0] = l2.x; lm[1] = l2.y;
-      em[0] = FAST_EXP(-a2.x); em[1] = FAST_EXP(-a2.y); sm[0] = FAST_SQRT(d2.x + 1e-10f); sm[1] = FAST_SQRT(d2.y + 1e-10f);
-    } else if (live[0]) {
-      id[0] = idx[f]; wv[0] = weight[f]; lm[0] = len[f]; em[0] = FAST_EXP(-act[f]); sm[0] = FAST_SQRT(dsd[f] + 1e-10f);
+      id[0] = i2.x; wv[0] = w2.x; lm[0] = l2.x; em[0] = FAST_EXP(-a2.x); sm[0] = FAST_SQRT(d2.x + 1e-10f);
+      if (live[1]) { id[1] = i2.y; wv[1] = w2.y; lm[1] = l2.y; em[1] = FAST_EXP(-a2.y); sm[1] = FAST_SQRT(d2.y + 1e-10f); }
     }
     // gathers: the slots' colours and (mu, a); the pixel's ray, upstream gradient and forward sums
     float col[NS][4];
@@ -115,22 +114,28 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
       const bool ok = live[a] && id[a] >= 0 && id[a] < P;
       live[a] = ok;
       col[a][0] = col[a][1] = col[a][2] = col[a][3] = 0.0f;
-      if (ok && id[a] < Nattr) {
+      if (ok && id[a] < Nattr && !(VOGE_FB_ABL & 4)) {
+        const unsigned o = (unsigned)id[a] * C;      // (Nattr * C < 2^32: host)
         if (C == 3) {
-          const float3 v = *reinterpret_cast<const float3 *>(colors + (size_t)id[a] * 3);
+          const float3 v = *reinterpret_cast<const float3 *>(colors + o);
           col[a][0] = v.x; col[a][1] = v.y; col[a][2] = v.z;
+        } else if (C == 4) {
+          const float4 v = *reinterpret_cast<const float4 *>(colors + o);
+          col[a][0] = v.x; col[a][1] = v.y; col[a][2] = v.z; col[a][3] = v.w;
         } else {
-          for (int c = 0; c < C; ++c) col[a][c] = colors[(size_t)id[a] * C + c];
+#pragma unroll
+          for (int c = 0; c < C; ++c) col[a][c] = colors[o + c];
         }
       }
     }
     float gr[4] = {0.f, 0.f, 0.f, 0.f}, g_sum_w = 0.0f, dx = 0.f, dy = 0.f, dz = 0.f;
-    if (on && lead > 0) {
+    if (on) {
       const float ws = wsum[pix];
       float sil = fminf(ws, 1.0f);
       const float pass_s = (thr > 0.0f) ? 0.0f : (ws < 1.0f ? 1.0f : (ws == 1.0f ? 0.5f : 0.0f));
       if (thr > 0.0f) sil = sil > thr ? 1.0f : 0.0f;
       float g_mask = 0.0f;
+#pragma unroll
       for (int c = 0; c < C; ++c) {
         const float xc = fmaf(1.0f - sil, bg[c], rgb[pix * C + c]);
         gr[c] = g_img[pix * C + c] * (xc < 1.0f ? 1.0f : (xc == 1.0f ? 0.5f : 0.0f));     // min(x, 1) passes like torch.min
@@ -147,21 +152,32 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
       um[a] = gw * wv[a];
     }
     // ---- composite backward (closed form, composite_core.h) ----
-    if (in_wg) {
+    if (on) {
       *reinterpret_cast<v2f *>(Llen + d0) = (v2f){lm[0], lm[1]};
       *reinterpret_cast<v2f *>(Lsp + d0) = (v2f){sm[0] * kCs, sm[1] * kCs};
       *reinterpret_cast<v2f *>(LE + d0) = (v2f){em[0] * (sm[0] * kCs), em[1] * (sm[1] * kCs)};
       *reinterpret_cast<v2f *>(Lu + d0) = splat(0.0f);
+      if (q < 2) {      // the sentinel pair in front of the pixel's row and the one behind it
+        for (int t2 = q; t2 < 2; t2 += LP) {
+          Llen[r0 + t2] = -kBig; Lsp[r0 + t2] = 1.0f; LE[r0 + t2] = 0.0f; Lu[r0 + t2] = 0.0f;
+          const int eb = r0 + RS - 2 + t2;
+          Llen[eb] = kBig; Lsp[eb] = 1.0f; LE[eb] = 0.0f; Lu[eb] = 0.0f;
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier();
     float ga[NS], gl[NS], gd[NS];
-    compn_bwd_wave<NS>(lm, sm, em, um, Llen, Lsp, LE, Lu, d0, k0, K, q, LP, in_wg, on, true, seg_lo, occ, ga, gl, gd);
+#if VOGE_FB_ABL & 2       // (timing experiment: no composite)
+    for (int a = 0; a < NS; ++a) { ga[a] = um[a]; gl[a] = um[a] * sm[a]; gd[a] = um[a] * em[a]; }
+#else
+    compn_bwd_wave<NS>(lm, sm, em, um, Llen, Lsp, LE, Lu, d0, k0, NS * LP, q, LP, npm, on, on, true, pk.s0, occ, ga, gl, gd);
+#endif
     __builtin_amdgcn_wave_barrier();      // the rows are rewritten by the next round
     // ---- trace backward terms (isotropic: trace_bwd.hip) + the colour term, one table entry per Gaussian.  (The
     // (mu, a) records are gathered only now: held across the composite they cost the kernel a wave per SIMD.) ----
     float4 rc[NS];
 #pragma unroll
-    for (int a = 0; a < NS; ++a) rc[a] = live[a] ? rec[id[a]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < NS; ++a) rc[a] = (live[a] && !(VOGE_FB_ABL & 8)) ? rec[id[a]] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float dn2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float idn = __builtin_amdgcn_rcpf(dn2);
 #pragma unroll
@@ -180,6 +196,10 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
               val[1].z != 0.f || val[1].w != 0.f);
       }
       if (!__any(go)) continue;     // uniform
+#if VOGE_FB_ABL & 1       // (timing experiment: no table, nothing accumulated)
+      if (go && val[0].x == 1.2345f && val[1].y == 3.21f) acc[id[a]] = val[0].w + val[1].x;
+      continue;
+#endif
       const int slot = wt_find(L.tab, id[a], go);
       wt_add(L.tab, slot, val, go && slot >= 0, lane);
       if (go && slot < 0) {         // table full: rare, straight to memory
@@ -189,7 +209,6 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
       }
     }
   }
-  if (!table_used) return;
   {   // flush: 8 adjacent lanes per entry -> the 32 bytes of acc[p]: lane-coalesced atomics
     const int c = lane & 7;
     const float *vals = reinterpret_cast<const float *>(L.tab.vals);
@@ -256,12 +275,22 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
   float *acc = reinterpret_cast<float *>(workspace);
   hipError_t e = hipMemsetAsync(acc, 0, (size_t)P * 32, st);
   if (e != hipSuccess) return (int)e;
-  const int LP = compn_lanes(K, 2), pw = 64 / LP;
-  const int bw = pw * kFbColsPerRow;
-  const long blocks = (long)((W + bw - 1) / bw) * ((nrows + kFbRows - 1) / kFbRows);
-  const size_t lds = ((sizeof(FragBwdLds) + 15) & ~(size_t)15) + sizeof(float) * 4 * (size_t)compn_rows(K, 2, 64, true);
-  hipLaunchKernelGGL(fragment_bwd_iso_kernel, dim3((unsigned)blocks), dim3(64), lds, st, reinterpret_cast<const float4 *>(records),
-                     rays, colors, idx, cnt, weight, act, len, dsd, rgb, wsum, bg, thr, g_img, occ, P, nrows, W, K, C, Nattr, acc);
+  const long blocks = (long)((W + kFbGW - 1) / kFbGW) * ((nrows + kFbGH - 1) / kFbGH);
+  if (Nattr * C >= (1l << 32)) return VOGE_ERR_BAD_ARG;
+  const bool small = (double)nrows * W * K < (double)(1l << 30);
+#define VOGE_LAUNCH_FB(CC, OT)                                                                                            \
+  hipLaunchKernelGGL((fragment_bwd_iso_kernel<CC, OT>), dim3((unsigned)blocks), dim3(64), 0, st,                          \
+                     reinterpret_cast<const float4 *>(records), rays, colors, idx, cnt, weight, act, len, dsd, rgb, wsum, bg, thr, \
+                     g_img, occ, P, nrows, W, K, Nattr, acc)
+#define VOGE_LAUNCH_FB_C(CC) do { if (small) VOGE_LAUNCH_FB(CC, uint32_t); else VOGE_LAUNCH_FB(CC, size_t); } while (0)
+  switch (C) {
+    case 1: VOGE_LAUNCH_FB_C(1); break;
+    case 2: VOGE_LAUNCH_FB_C(2); break;
+    case 3: VOGE_LAUNCH_FB_C(3); break;
+    default: VOGE_LAUNCH_FB_C(4); break;
+  }
+#undef VOGE_LAUNCH_FB_C
+#undef VOGE_LAUNCH_FB
   const long n_fin = (Nattr > P) ? Nattr : P;
   hipLaunchKernelGGL(fragment_bwd_finish_kernel, dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, st, acc, sigmas, P, N, B,
                      IsoView{nullptr, shared ? 1 : 0, sigma_mode}, C, Nattr, g_verts, g_sigmas, g_colors);

@@ -677,7 +677,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       }
       __builtin_amdgcn_wave_barrier();
       float wgt[NS];
-      compn_fwd_rows<NS>(lm, sm, em, Llen, Lsp, LE, d0, k0, K, q, LP, in_wg, cur.on, true, seg_lo, occ, wgt);
+      compn_fwd_rows<NS>(lm, sm, em, Llen, Lsp, LE, d0, k0, K, q, LP, LP, in_wg, cur.on, true, seg_lo, occ, wgt);
       __builtin_amdgcn_wave_barrier();      // the rows are rewritten by the next round
       if (cur.on) {
         const size_t ob = cur.pix * K + k0;
