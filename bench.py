@@ -337,7 +337,7 @@ def main():
                                  gc=torch.empty_like(colors)),
                     lambda s: lib.voge_fragment_shade_bwd_iso(P_(recs), P_(isg), 0, 0, P_(rays), P_(colors), P_(s["i"]), P_(s["c"]), P_(s["w"]),
                                                               P_(s["a"]), P_(s["l"]), P_(s["d"]), P_(s["rgb"]), P_(s["ws"]), P_(bg), -1.0,
-                                                              P_(s["g"]), 1.0, 1, N, H, W, K, 3, N, P_(s["wk"]), nfb, P_(s["gv"]),
+                                                              P_(s["g"]), 3, 1, 1.0, 1, N, H, W, K, 3, N, P_(s["wk"]), nfb, P_(s["gv"]),
                                                               P_(s["gs"]), P_(s["gc"]), st))
             nbytes = stage_bytes(N, npix, K, iso=iso)
             stages = {}

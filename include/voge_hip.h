@@ -211,8 +211,10 @@ int voge_fragments_fwd_iso_view(const float *verts, const float *sigmas, const f
  * their exchanges through memory (g_weight; g_len / g_act / g_dsd) and with one accumulation table per wave.
  * records [B*N,4] = the (centred mean, a) pairs the forward kept (the `records` argument of
  * voge_fragments_fwd_iso / _iso_view); sigmas / shared / sigma_mode as in voge_trace_bwd_iso_view (pass the a
- * array, 0, 0 for plain (mus, a) inputs); rgb / wsum = voge_shade_fwd's out_rgb / out_wsum; g_img [nrows*W,C] the
- * gradient of the image.  Writes g_verts, g_sigmas (both or neither) and g_colors [Nattr,C].  K even, <= 128;
+ * array, 0, 0 for plain (mus, a) inputs); rgb / wsum = voge_shade_fwd's out_rgb / out_wsum; g_img = the gradient of
+ * the image, element (pixel p, channel c) at g_img[p * g_stride_pix + c * g_stride_c]: (C, 1) for a contiguous
+ * [nrows*W,C] array, (0, 0) for the one broadcast scalar autograd hands back for sum() / mean() losses (no
+ * materialised copy of it is needed).  Writes g_verts, g_sigmas (both or neither) and g_colors [Nattr,C].  K even, <= 128;
  * C <= 4; cnt required.  workspace: >= voge_fragment_bwd_workspace_bytes(B*N) bytes.
  */
 size_t voge_fragment_bwd_workspace_bytes(int P);
@@ -220,8 +222,8 @@ int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int s
                                 const float *rays, const float *colors, const int32_t *idx, const int32_t *cnt,
                                 const float *weight, const float *act, const float *len, const float *dsd,
                                 const float *rgb, const float *wsum, const float *bg, float thr,
-                                const float *g_img, float occ, int B, int N, long nrows, int W, int K, int C,
-                                long Nattr, void *workspace, size_t workspace_bytes, float *g_verts,
+                                const float *g_img, long g_stride_pix, long g_stride_c, float occ, int B, int N,
+                                long nrows, int W, int K, int C, long Nattr, void *workspace, size_t workspace_bytes, float *g_verts,
                                 float *g_sigmas, float *g_colors, voge_stream_t stream);
 
 /*

@@ -856,3 +856,31 @@ def test_fused_fragment_backward_equals_the_three_kernels(hip_lib, K, B, inverse
         scale = max(1.0, float(np.abs(y).max()))
         assert np.abs(x - y).max() <= 3e-5 * scale, (name, float(np.abs(x - y).max()), scale)
     assert np.abs(out[False][1]).max() > 0 and np.abs(out[False][2]).max() > 0
+
+
+def test_fused_fragment_backward_reads_a_broadcast_gradient_in_place(hip_lib):
+    """sum() / mean() losses hand the fused backward ONE scalar broadcast over the image (all strides zero); it is read in
+    place (g_stride_pix = g_stride_c = 0) and must give what the materialised gradient gives."""
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
+    from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
+    N, H, W, K = 3000, 64, 80, 20
+    verts, sig, cols = random_scene(N, seed=77, lo=0.04, hi=0.1)
+    R, T = look_at_view_transform(dist=3.0, elev=10.0, azim=30.0, device=DEV)
+    cams = PerspectiveCameras(focal_length=95.0, principal_point=((W / 2.0, H / 2.0),), image_size=((H, W),), device=DEV)
+    renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=(H, W), max_assign=K, max_point_per_bin=-1)).to(DEV)
+    out = []
+    for broadcast in (True, False):
+        gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(DEV)
+        colors = t(cols, rg=True)
+        img = to_white_background(renderer(gm, R=R, T=T), colors)
+        assert type(img.grad_fn).__name__ == "_ShadeThroughBackward"
+        if broadcast:
+            (0.5 * img.mean()).backward()
+        else:
+            img.backward(torch.full_like(img, 0.5 / img.numel()))
+        out.append([n(x) for x in (gm.verts.grad, gm.sigmas.grad, colors.grad)])
+    for name, x, y in zip(("verts", "sigmas", "colors"), out[0], out[1]):
+        scale = max(1e-6, float(np.abs(y).max()))
+        assert np.abs(x - y).max() <= 2e-5 * scale, (name, float(np.abs(x - y).max()), scale)
+    assert np.abs(out[1][0]).max() > 0

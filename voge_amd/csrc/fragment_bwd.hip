@@ -58,7 +58,8 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
                         const float *__restrict__ colors, const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt,
                         const float *__restrict__ weight, const float *__restrict__ act, const float *__restrict__ len,
                         const float *__restrict__ dsd, const float *__restrict__ rgb, const float *__restrict__ wsum,
-                        const float *__restrict__ bg, const float thr, const float *__restrict__ g_img, const float occ,
+                        const float *__restrict__ bg, const float thr, const float *__restrict__ g_img, const long gs_pix,
+                        const long gs_c, const float occ,
                         const int P, const long nrows, const int W, const int K, const long Nattr,
                         float *__restrict__ acc /* [P][8], zeroed */) {
   constexpr int NS = 2;
@@ -138,7 +139,7 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const float xc = fmaf(1.0f - sil, bg[c], rgb[pix * C + c]);
-        gr[c] = g_img[pix * C + c] * (xc < 1.0f ? 1.0f : (xc == 1.0f ? 0.5f : 0.0f));     // min(x, 1) passes like torch.min
+        gr[c] = g_img[(long)pix * gs_pix + c * gs_c] * (xc < 1.0f ? 1.0f : (xc == 1.0f ? 0.5f : 0.0f));     // min(x, 1) passes like torch.min
         g_mask = fmaf(-gr[c], bg[c], g_mask);
       }
       g_sum_w = g_mask * pass_s;
@@ -256,8 +257,8 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
                                            const float *rays, const float *colors, const int32_t *idx, const int32_t *cnt,
                                            const float *weight, const float *act, const float *len, const float *dsd,
                                            const float *rgb, const float *wsum, const float *bg, float thr,
-                                           const float *g_img, float occ, int B, int N, long nrows, int W, int K, int C,
-                                           long Nattr, void *workspace, size_t workspace_bytes, float *g_verts,
+                                           const float *g_img, long g_stride_pix, long g_stride_c, float occ, int B, int N,
+                                           long nrows, int W, int K, int C, long Nattr, void *workspace, size_t workspace_bytes, float *g_verts,
                                            float *g_sigmas, float *g_colors, voge_stream_t stream) {
   if (B < 0 || N < 0 || nrows < 0 || W < 0 || K <= 0 || C <= 0 || C > 4 || Nattr < 0 || sigma_mode < 0 || sigma_mode > 2)
     return VOGE_ERR_BAD_ARG;
@@ -281,7 +282,7 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
 #define VOGE_LAUNCH_FB(CC, OT)                                                                                            \
   hipLaunchKernelGGL((fragment_bwd_iso_kernel<CC, OT>), dim3((unsigned)blocks), dim3(64), 0, st,                          \
                      reinterpret_cast<const float4 *>(records), rays, colors, idx, cnt, weight, act, len, dsd, rgb, wsum, bg, thr, \
-                     g_img, occ, P, nrows, W, K, Nattr, acc)
+                     g_img, g_stride_pix, g_stride_c, occ, P, nrows, W, K, Nattr, acc)
 #define VOGE_LAUNCH_FB_C(CC) do { if (small) VOGE_LAUNCH_FB(CC, uint32_t); else VOGE_LAUNCH_FB(CC, size_t); } while (0)
   switch (C) {
     case 1: VOGE_LAUNCH_FB_C(1); break;

@@ -502,7 +502,11 @@ class _ShadeThrough(torch.autograd.Function):
         th, idx = ctx.th, ctx.idx
         B, H, W, K = idx.shape
         Nattr, C = attr.shape
-        go = _dev(g_img, torch.float32, "grad_image")
+        # the gradient as it comes: a contiguous image, or autograd's broadcast scalar (sum / mean losses) read in place
+        if g_img.dtype == torch.float32 and g_img.is_cuda and all(s == 0 for s in g_img.stride()):
+            go, gs_pix, gs_c = g_img, 0, 0
+        else:
+            go, gs_pix, gs_c = _dev(g_img, torch.float32, "grad_image"), C, 1
         g_attr = torch.empty_like(attr)
         p0, p1 = th["p0"], th["p1"]
         g0 = torch.empty(p0.shape, dtype=torch.float32, device=idx.device)
@@ -514,7 +518,7 @@ class _ShadeThrough(torch.autograd.Function):
             rc = lib.voge_fragment_shade_bwd_iso(
                 _p(th["records"]), _p(th["sigmas"]), int(th["shared"]), th["sigma_mode"], _p(th["rays"]), _p(attr), _p(idx),
                 _p(th["cnt"]), _p(w), _p(th["act"]), _p(th["len"]), _p(th["dsd"]), _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go),
-                th["occ"], th["B"], th["N"], B * H, W, K, C, Nattr, _p(ws), nbytes, _p(g0), _p(g1), _p(g_attr), _stream())
+                gs_pix, gs_c, th["occ"], th["B"], th["N"], B * H, W, K, C, Nattr, _p(ws), nbytes, _p(g0), _p(g1), _p(g_attr), _stream())
         _lib.check(rc, "voge_fragment_shade_bwd_iso")
         need = ctx.needs_input_grad
         return (g_attr if need[0] else None), None, (g0 if need[2] else None), (g1 if need[3] else None), None, None, None, None, None
