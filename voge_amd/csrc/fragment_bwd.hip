@@ -50,8 +50,12 @@ struct FragBwdLds {
 #ifndef VOGE_FB_WPE
 #define VOGE_FB_WPE 4      // capping the registers for 5 / 6 waves per SIMD spills and is slower
 #endif
-// C: colour channels (1..4); OffT: uint32_t when every element offset of the [pix][K] arrays fits 30 bits (the loads
+// C: colour channels (1..4); OffT: uint32_t when every BYTE offset into the [pix][K] arrays fits 32 bits (the loads
 // then take scalar base + 32-bit lane offset and the address arithmetic leaves the vector unit), else size_t.
+template <typename T, typename OffT>
+__device__ __forceinline__ const T &at_bytes(const void *base, const OffT byte_off) {
+  return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
 template <int C, typename OffT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VOGE_FB_WPE)))
 fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */, const float *__restrict__ rays,
@@ -92,7 +96,7 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
     const int lead = __shfl(lead_g, on ? pk.p : 0, 64);
     const int k0 = NS * q;
     const OffT pix = on ? (OffT)((y0 + pk.p / kFbGW) * W + x0 + (pk.p & (kFbGW - 1))) : (OffT)0;
-    const OffT f = pix * (OffT)K + (OffT)k0;
+    const OffT fb = (pix * (OffT)K + (OffT)k0) * (OffT)4;      // byte offset of the lane's pair in the [pix][K] arrays
     const int r0 = NS * pk.s0 + 4 * pk.ord, RS = NS * LP + 4;
     const int d0 = on ? r0 + 2 + k0 : 2;
     // ---- the lane's two slots ----
@@ -102,9 +106,8 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
 #pragma unroll
     for (int a = 0; a < NS; ++a) { id[a] = -1; wv[a] = 0.f; lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.f; live[a] = on && (k0 + a < lead); }
     if (live[0]) {              // 8-byte accesses (K is even: the pair is aligned and inside the pixel's row)
-      const int2 i2 = *reinterpret_cast<const int2 *>(idx + f);
-      const v2f w2 = *reinterpret_cast<const v2f *>(weight + f), a2 = *reinterpret_cast<const v2f *>(act + f),
-                l2 = *reinterpret_cast<const v2f *>(len + f), d2 = *reinterpret_cast<const v2f *>(dsd + f);
+      const int2 i2 = at_bytes<int2>(idx, fb);
+      const v2f w2 = at_bytes<v2f>(weight, fb), a2 = at_bytes<v2f>(act, fb), l2 = at_bytes<v2f>(len, fb), d2 = at_bytes<v2f>(dsd, fb);
       id[0] = i2.x; wv[0] = w2.x; lm[0] = l2.x; em[0] = FAST_EXP(-a2.x); sm[0] = FAST_SQRT(d2.x + 1e-10f);
       if (live[1]) { id[1] = i2.y; wv[1] = w2.y; lm[1] = l2.y; em[1] = FAST_EXP(-a2.y); sm[1] = FAST_SQRT(d2.y + 1e-10f); }
     }
@@ -116,34 +119,36 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
       live[a] = ok;
       col[a][0] = col[a][1] = col[a][2] = col[a][3] = 0.0f;
       if (ok && id[a] < Nattr && !(VOGE_FB_ABL & 4)) {
-        const unsigned o = (unsigned)id[a] * C;      // (Nattr * C < 2^32: host)
+        const uint32_t o = (uint32_t)id[a] * (uint32_t)(4 * C);      // (bytes; Nattr * C < 2^30: host)
         if (C == 3) {
-          const float3 v = *reinterpret_cast<const float3 *>(colors + o);
+          const float3 v = at_bytes<float3>(colors, o);
           col[a][0] = v.x; col[a][1] = v.y; col[a][2] = v.z;
         } else if (C == 4) {
-          const float4 v = *reinterpret_cast<const float4 *>(colors + o);
+          const float4 v = at_bytes<float4>(colors, o);
           col[a][0] = v.x; col[a][1] = v.y; col[a][2] = v.z; col[a][3] = v.w;
         } else {
 #pragma unroll
-          for (int c = 0; c < C; ++c) col[a][c] = colors[o + c];
+          for (int c = 0; c < C; ++c) col[a][c] = at_bytes<float>(colors, o + 4u * c);
         }
       }
     }
     float gr[4] = {0.f, 0.f, 0.f, 0.f}, g_sum_w = 0.0f, dx = 0.f, dy = 0.f, dz = 0.f;
     if (on) {
-      const float ws = wsum[pix];
+      const OffT pb = pix * (OffT)4;
+      const float ws = at_bytes<float>(wsum, pb);
       float sil = fminf(ws, 1.0f);
       const float pass_s = (thr > 0.0f) ? 0.0f : (ws < 1.0f ? 1.0f : (ws == 1.0f ? 0.5f : 0.0f));
       if (thr > 0.0f) sil = sil > thr ? 1.0f : 0.0f;
       float g_mask = 0.0f;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const float xc = fmaf(1.0f - sil, bg[c], rgb[pix * C + c]);
+        const float xc = fmaf(1.0f - sil, bg[c], at_bytes<float>(rgb, pb * (OffT)C + (OffT)(4 * c)));
         gr[c] = g_img[(long)pix * gs_pix + c * gs_c] * (xc < 1.0f ? 1.0f : (xc == 1.0f ? 0.5f : 0.0f));     // min(x, 1) passes like torch.min
         g_mask = fmaf(-gr[c], bg[c], g_mask);
       }
       g_sum_w = g_mask * pass_s;
-      dx = rays[pix * 3]; dy = rays[pix * 3 + 1]; dz = rays[pix * 3 + 2];
+      const float3 dv = at_bytes<float3>(rays, pb * (OffT)3);
+      dx = dv.x; dy = dv.y; dz = dv.z;
     }
     // ---- shade backward: g_w of the slots; u = g_w w ----
     float um[NS];
@@ -178,7 +183,8 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
     // (mu, a) records are gathered only now: held across the composite they cost the kernel a wave per SIMD.) ----
     float4 rc[NS];
 #pragma unroll
-    for (int a = 0; a < NS; ++a) rc[a] = (live[a] && !(VOGE_FB_ABL & 8)) ? rec[id[a]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < NS; ++a)
+      rc[a] = (live[a] && !(VOGE_FB_ABL & 8)) ? at_bytes<float4>(rec, (uint32_t)id[a] * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);   // (P < 2^28: host)
     const float dn2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float idn = __builtin_amdgcn_rcpf(dn2);
 #pragma unroll
@@ -277,7 +283,7 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
   hipError_t e = hipMemsetAsync(acc, 0, (size_t)P * 32, st);
   if (e != hipSuccess) return (int)e;
   const long blocks = (long)((W + kFbGW - 1) / kFbGW) * ((nrows + kFbGH - 1) / kFbGH);
-  if (Nattr * C >= (1l << 32)) return VOGE_ERR_BAD_ARG;
+  if (Nattr * C >= (1l << 30) || P >= (1 << 28)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
   const bool small = (double)nrows * W * K < (double)(1l << 30);
 #define VOGE_LAUNCH_FB(CC, OT)                                                                                            \
   hipLaunchKernelGGL((fragment_bwd_iso_kernel<CC, OT>), dim3((unsigned)blocks), dim3(64), 0, st,                          \
