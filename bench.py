@@ -150,6 +150,9 @@ def main():
                 p.grad = None
             fwd().sum().backward()
         if args.no_graph:
+            for _ in range(60):      # allocator pools, lazily loaded code objects, clocks: what graph capture warms on the way
+                step()
+            torch.cuda.synchronize()
             return step, "eager"
         try:
             warm_side_stream(step)
