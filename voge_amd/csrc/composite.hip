@@ -337,7 +337,7 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
 // WAVE: every pixel's lanes sit inside ONE wave (64 / LP pixels per wave, the remaining lanes idle), so the
 // per-pixel scans, flags and reductions are wave shuffles / ballots and the kernel has no workgroup barrier at
 // all: each wave runs from its loads to its stores on its own.  (Needs LP <= 64.)
-template <int MODE, int NS, bool WAVE>   // MODE 0: forward, 2: backward with weights
+template <int MODE, int NS, bool WAVE, typename OffT>   // MODE 0: forward, 2: backward with weights; OffT: composite_core.h at_bytes
 __global__ void __launch_bounds__(kCompThreads) __attribute__((amdgpu_waves_per_eu(VOGE_COMP_WPE)))
 compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
                   const float *__restrict__ len, const float *__restrict__ dsd,
@@ -376,6 +376,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   const bool active = in_wg && (pix < npix);
   const int k0 = NS * q;
   const long f = pix * K + k0;
+  const OffT fb = (OffT)f * (OffT)4;      // byte offset of the lane's group in the [npix][K] arrays
   const int RS = compn_stride(K, NS);
   const int PAD = comp_pad(K);
   const int d0 = (in_wg ? p : 0) * RS + PAD + (in_wg ? k0 : 0);   // own group in the padded arrays (even index)
@@ -406,22 +407,22 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
     if (vec && k0 + NS <= lead) {        // the whole group is live: one wide access per array
       float av[NS], lv[NS], dv[NS];
       if (NS == 4) {
-        const float4 a4 = *reinterpret_cast<const float4 *>(act + f), l4 = *reinterpret_cast<const float4 *>(len + f),
-                     d4 = *reinterpret_cast<const float4 *>(dsd + f);
+        const float4 a4 = at_bytes<float4>(act, fb), l4 = at_bytes<float4>(len, fb),
+                     d4 = at_bytes<float4>(dsd, fb);
         av[0] = a4.x; av[1] = a4.y; av[NS - 2] = a4.z; av[NS - 1] = a4.w;
         lv[0] = l4.x; lv[1] = l4.y; lv[NS - 2] = l4.z; lv[NS - 1] = l4.w;
         dv[0] = d4.x; dv[1] = d4.y; dv[NS - 2] = d4.z; dv[NS - 1] = d4.w;
         if (BWD) {
-          const float4 g4 = *reinterpret_cast<const float4 *>(g_weight + f), w4 = *reinterpret_cast<const float4 *>(w_in + f);
+          const float4 g4 = at_bytes<float4>(g_weight, fb), w4 = at_bytes<float4>(w_in, fb);
           gw[0] = g4.x; gw[1] = g4.y; gw[NS - 2] = g4.z; gw[NS - 1] = g4.w;
           wg[0] = w4.x; wg[1] = w4.y; wg[NS - 2] = w4.z; wg[NS - 1] = w4.w;
         }
       } else {
-        const v2f a2 = *reinterpret_cast<const v2f *>(act + f), l2 = *reinterpret_cast<const v2f *>(len + f),
-                  d2 = *reinterpret_cast<const v2f *>(dsd + f);
+        const v2f a2 = at_bytes<v2f>(act, fb), l2 = at_bytes<v2f>(len, fb),
+                  d2 = at_bytes<v2f>(dsd, fb);
         av[0] = a2.x; av[1] = a2.y; lv[0] = l2.x; lv[1] = l2.y; dv[0] = d2.x; dv[1] = d2.y;
         if (BWD) {
-          const v2f g2 = *reinterpret_cast<const v2f *>(g_weight + f), w2 = *reinterpret_cast<const v2f *>(w_in + f);
+          const v2f g2 = at_bytes<v2f>(g_weight, fb), w2 = at_bytes<v2f>(w_in, fb);
           gw[0] = g2.x; gw[1] = g2.y; wg[0] = w2.x; wg[1] = w2.y;
         }
       }
@@ -490,13 +491,13 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
                        occ, ga, gl, gd);
     if (active) {
       if (vec && NS == 4) {
-        *reinterpret_cast<float4 *>(out0 + f) = make_float4(ga[0], ga[1], ga[NS - 2], ga[NS - 1]);
-        *reinterpret_cast<float4 *>(out1 + f) = make_float4(gl[0], gl[1], gl[NS - 2], gl[NS - 1]);
-        *reinterpret_cast<float4 *>(out2 + f) = make_float4(gd[0], gd[1], gd[NS - 2], gd[NS - 1]);
+        at_bytes_w<float4>(out0, fb) = make_float4(ga[0], ga[1], ga[NS - 2], ga[NS - 1]);
+        at_bytes_w<float4>(out1, fb) = make_float4(gl[0], gl[1], gl[NS - 2], gl[NS - 1]);
+        at_bytes_w<float4>(out2, fb) = make_float4(gd[0], gd[1], gd[NS - 2], gd[NS - 1]);
       } else if (vec) {
-        *reinterpret_cast<v2f *>(out0 + f) = (v2f){ga[0], ga[1]};
-        *reinterpret_cast<v2f *>(out1 + f) = (v2f){gl[0], gl[1]};
-        *reinterpret_cast<v2f *>(out2 + f) = (v2f){gd[0], gd[1]};
+        at_bytes_w<v2f>(out0, fb) = (v2f){ga[0], ga[1]};
+        at_bytes_w<v2f>(out1, fb) = (v2f){gl[0], gl[1]};
+        at_bytes_w<v2f>(out2, fb) = (v2f){gd[0], gd[1]};
       } else {
 #pragma unroll
         for (int a = 0; a < NS; ++a) if (has[a]) { out0[f + a] = ga[a]; out1[f + a] = gl[a]; out2[f + a] = gd[a]; }
@@ -509,8 +510,8 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
     float w[NS];
     compn_fwd_rows<NS>(lm, sm, em, Llen, Lsp, LE, d0, k0, K, q, LP, LP, in_wg, active, active && !wave_unsorted, seg_lo, occ, w);
     if (active) {
-      if (vec && NS == 4) *reinterpret_cast<float4 *>(out0 + f) = make_float4(w[0], w[1], w[NS - 2], w[NS - 1]);
-      else if (vec) *reinterpret_cast<v2f *>(out0 + f) = (v2f){w[0], w[1]};
+      if (vec && NS == 4) at_bytes_w<float4>(out0, fb) = make_float4(w[0], w[1], w[NS - 2], w[NS - 1]);
+      else if (vec) at_bytes_w<v2f>(out0, fb) = (v2f){w[0], w[1]};
       else {
 #pragma unroll
         for (int a = 0; a < NS; ++a) if (has[a]) out0[f + a] = w[a];
@@ -658,8 +659,8 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
 #pragma unroll
     for (int a = 0; a < NS; ++a) w[a] = (em[a] != 0.0f) ? FAST_EXP(-occ * S[a]) * em[a] * kInvNorm : 0.0f;
     if (active) {
-      if (vec && NS == 4) *reinterpret_cast<float4 *>(out0 + f) = make_float4(w[0], w[1], w[NS - 2], w[NS - 1]);
-      else if (vec) *reinterpret_cast<v2f *>(out0 + f) = (v2f){w[0], w[1]};
+      if (vec && NS == 4) at_bytes_w<float4>(out0, fb) = make_float4(w[0], w[1], w[NS - 2], w[NS - 1]);
+      else if (vec) at_bytes_w<v2f>(out0, fb) = (v2f){w[0], w[1]};
       else {
 #pragma unroll
         for (int a = 0; a < NS; ++a) if (has[a]) out0[f + a] = w[a];
@@ -795,13 +796,13 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   }
   if (active) {
     if (vec && NS == 4) {
-      *reinterpret_cast<float4 *>(out0 + f) = make_float4(ga[0], ga[1], ga[NS - 2], ga[NS - 1]);
-      *reinterpret_cast<float4 *>(out1 + f) = make_float4(gl[0], gl[1], gl[NS - 2], gl[NS - 1]);
-      *reinterpret_cast<float4 *>(out2 + f) = make_float4(gd[0], gd[1], gd[NS - 2], gd[NS - 1]);
+      at_bytes_w<float4>(out0, fb) = make_float4(ga[0], ga[1], ga[NS - 2], ga[NS - 1]);
+      at_bytes_w<float4>(out1, fb) = make_float4(gl[0], gl[1], gl[NS - 2], gl[NS - 1]);
+      at_bytes_w<float4>(out2, fb) = make_float4(gd[0], gd[1], gd[NS - 2], gd[NS - 1]);
     } else if (vec) {
-      *reinterpret_cast<v2f *>(out0 + f) = (v2f){ga[0], ga[1]};
-      *reinterpret_cast<v2f *>(out1 + f) = (v2f){gl[0], gl[1]};
-      *reinterpret_cast<v2f *>(out2 + f) = (v2f){gd[0], gd[1]};
+      at_bytes_w<v2f>(out0, fb) = (v2f){ga[0], ga[1]};
+      at_bytes_w<v2f>(out1, fb) = (v2f){gl[0], gl[1]};
+      at_bytes_w<v2f>(out2, fb) = (v2f){gd[0], gd[1]};
     } else {
 #pragma unroll
       for (int a = 0; a < NS; ++a) if (has[a]) { out0[f + a] = ga[a]; out1[f + a] = gl[a]; out2[f + a] = gd[a]; }
@@ -844,9 +845,16 @@ static int launch_composite(int mode, const int32_t *idx, const float *act, cons
     const int ppwn = compn_pixels(K, NS, tn, wavem);
     const dim3 gridn((unsigned)((npix + ppwn - 1) / ppwn)), blockn(tn);
     const size_t ldsn = compn_lds_bytes(K, NS, mode != 0, tn, wavem);
+    const bool small = (double)npix * K < (double)(1l << 30);      // every byte offset fits 32 bits
 #define VOGE_LAUNCH_COMPN(M, N, WV)                                                                                     \
-    hipLaunchKernelGGL((compositen_kernel<M, N, WV>), gridn, blockn, ldsn, st, idx, act, len, dsd, w_in, g_weight, cnt_in, occ, \
-                       npix, K, ppwn, o0, o1, o2, valid_num)
+    do {                                                                                                                \
+      if (small)                                                                                                        \
+        hipLaunchKernelGGL((compositen_kernel<M, N, WV, uint32_t>), gridn, blockn, ldsn, st, idx, act, len, dsd, w_in, g_weight,    \
+                           cnt_in, occ, npix, K, ppwn, o0, o1, o2, valid_num);                                          \
+      else                                                                                                              \
+        hipLaunchKernelGGL((compositen_kernel<M, N, WV, size_t>), gridn, blockn, ldsn, st, idx, act, len, dsd, w_in, g_weight,      \
+                           cnt_in, occ, npix, K, ppwn, o0, o1, o2, valid_num);                                          \
+    } while (0)
     if (wavem) {
       if (mode == 2) { if (NS == 4) VOGE_LAUNCH_COMPN(2, 4, true); else VOGE_LAUNCH_COMPN(2, 2, true); }
       else { if (NS == 4) VOGE_LAUNCH_COMPN(0, 4, true); else VOGE_LAUNCH_COMPN(0, 2, true); }

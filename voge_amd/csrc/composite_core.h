@@ -81,6 +81,18 @@ __device__ __forceinline__ float h_one(const float xp) { return h_pair(splat(xp)
 __device__ __forceinline__ v2f ld2(const float *a, const int e) { return *reinterpret_cast<const v2f *>(a + e); }
 __device__ __forceinline__ v2f abs2(const v2f v) { return (v2f){fabsf(v.x), fabsf(v.y)}; }
 
+// Element at a BYTE offset from a base pointer.  With a 32-bit unsigned offset the compiler emits the scalar-base form
+// (global_load v, voff, s[base:base+1]) and keeps the address arithmetic off the vector unit; kernels take the offset
+// type as a template parameter and the host picks uint32_t when every byte offset of the launch fits.
+template <typename T, typename OffT>
+__device__ __forceinline__ const T &at_bytes(const void *base, const OffT byte_off) {
+  return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <typename T, typename OffT>
+__device__ __forceinline__ T &at_bytes_w(void *base, const OffT byte_off) {
+  return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off);
+}
+
 // Row stride of the padded per-pixel arrays: two sentinels, K entries, two or three sentinels.
 // PAD (two sentinel entries) and the stride are even: an entry's parity is its slot's parity and the
 // pairs (2t, 2t+1) of a row are 8-byte aligned (ds_read_b64: 2 LDS cycles per wave; ds_read2_b32 of an odd pair costs 4).

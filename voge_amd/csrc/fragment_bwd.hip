@@ -52,10 +52,6 @@ struct FragBwdLds {
 #endif
 // C: colour channels (1..4); OffT: uint32_t when every BYTE offset into the [pix][K] arrays fits 32 bits (the loads
 // then take scalar base + 32-bit lane offset and the address arithmetic leaves the vector unit), else size_t.
-template <typename T, typename OffT>
-__device__ __forceinline__ const T &at_bytes(const void *base, const OffT byte_off) {
-  return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
-}
 template <int C, typename OffT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VOGE_FB_WPE)))
 fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */, const float *__restrict__ rays,
