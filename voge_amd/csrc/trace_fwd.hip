@@ -976,7 +976,7 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
        *sc = take(nbin * kParts * 4), *si = take(nbin * kParts * (size_t)kSegCap * 4), *bc = take(nbin * 4 * 4),
        *bi = take(nbin * 4 * kQCap * 4), *bl = take(nbin * 4 * kQCap * 4), *tc = take(ntile * 4),
        *ti = take(ntile * kTileCap * 4), *tl = take(ntile * kTileCap * 4), *sr = take(nbin * kParts * (size_t)kSegCap * 16),
-       *cq = take(nbin * kTilesPerBin * 8);
+       *cq = take(nbin * kTilesPerBin * 8 * 2);      // (second half: the exactly sorted copy of VOGE_EXACT_ORDER builds)
   if (ws) {
     ws->cull = reinterpret_cast<float4 *>(c); ws->evr = reinterpret_cast<float4 *>(e);
     ws->ms = reinterpret_cast<float4 *>(m4); ws->ell = reinterpret_cast<float4 *>(el);
@@ -992,6 +992,41 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
     ws->nbin = (int)nbin;
   }
   return off;
+}
+
+#ifndef VOGE_EXACT_ORDER
+#define VOGE_EXACT_ORDER 0        // (experiment) re-sort the launch order exactly by list length with one extra launch
+#endif
+// One workgroup: counting sort of the n launch slots by descending list length (overflowed lists first, empty tiles
+// and slots outside the image last).
+__global__ void __launch_bounds__(1024) order_sort_kernel(const int2 *__restrict__ in, int2 *__restrict__ out, const int n) {
+  constexpr int NB = 3072;      // >= kTileCap + 3 buckets, 3 per thread
+  __shared__ int hist[NB];
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < NB; i += 1024) hist[i] = 0;
+  __syncthreads();
+  auto bucket = [](const int2 v) { return (v.x < 0 || v.y == 0) ? kTileCap + 2 : (v.y < 0 ? 0 : 1 + (kTileCap - min(v.y, kTileCap))); };
+  for (int i = tid; i < n; i += 1024) atomicAdd(&hist[bucket(in[i])], 1);
+  __syncthreads();
+  const int a = hist[3 * tid], b = hist[3 * tid + 1], c = hist[3 * tid + 2];
+  int x = a + b + c;
+  const int own = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  int off = x - own;
+  for (int w = 0; w < wave; ++w) off += wsum[w];
+  hist[3 * tid] = off; hist[3 * tid + 1] = off + a; hist[3 * tid + 2] = off + a + b;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const int2 v = in[i];
+    out[atomicAdd(&hist[bucket(v)], 1)] = v;
+  }
 }
 
 #ifndef VOGE_SWEEP_LDS_PAD
@@ -1020,9 +1055,14 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
     int rc = launch_status();
     if (rc) return rc;
   }
+  const int2 *order = ws.order;
+#if VOGE_EXACT_ORDER
+  hipLaunchKernelGGL(order_sort_kernel, dim3(1), dim3(1024), 0, st, ws.order, ws.order + (size_t)ws.nbin * kTilesPerBin, ws.nbin * kTilesPerBin);
+  order = ws.order + (size_t)ws.nbin * kTilesPerBin;
+#endif
   dim3 grid(ws.nbin * kTilesPerBin);     // one workgroup per tile slot of every super-tile (slots outside the image exit)
   hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, ws.ms, rays, ws.q_count, ws.q_id, ws.q_lb,
-                     ws.tl_count, ws.tl_id, ws.tl_lb, ws.order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx,
+                     ws.tl_count, ws.tl_id, ws.tl_lb, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx,
                      ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, weight, valid_num);
   return launch_status();
 }
