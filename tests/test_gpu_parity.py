@@ -11,7 +11,7 @@ import torch
 
 import oracle
 from oracle import camera_np
-from util import GOLDEN, TOL, bunny_scene, close, compare_trace, cuboid_scene, max_rel, random_scene
+from util import GOLDEN, TOL, bunny_scene, close, compare_trace, cuboid_scene, grad_close, max_rel, random_scene
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -115,7 +115,7 @@ def test_trace_fwd_large_frame_coarse_bins_and_tile_order(hip_lib, iso_api):
     else:
         got = run_trace(mus, isg, rays, K, thr_act)
     ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
-    compare_trace(got, ref, thr_act, min_match=0.999)
+    compare_trace(got, ref, thr_act, min_match=0.9999, max_flips=30)
     assert (ref[0][..., -1] >= 0).mean() > 0.05 and (ref[0][..., 0] < 0).mean() > 0.3   # full lists and empty pixels
 
 
@@ -140,7 +140,7 @@ def test_trace_fwd_strongly_anisotropic_ellipsoid_culling(hip_lib):
     n_neg = 0
     for y0, x0 in ((0, 0), (180, 200), (H - S, W - S), (90, 300), (300, 40)):
         ref = oracle.trace_fwd(mus, isg, np.ascontiguousarray(rays[:, y0:y0 + S, x0:x0 + S]), K, thr_act)
-        compare_trace([g[:, y0:y0 + S, x0:x0 + S] for g in got], ref, thr_act, min_match=0.97)
+        compare_trace([g[:, y0:y0 + S, x0:x0 + S] for g in got], ref, thr_act, min_match=0.99, max_flips=3)
         n_neg += int(((ref[1] < 0) & (ref[0] >= 0)).sum())
         assert (ref[0][..., -1] >= 0).mean() > 0.5          # lists are full: the early exit is exercised
     assert n_neg > 0                                         # hits behind the camera were part of it
@@ -159,7 +159,7 @@ def test_trace_fwd_nonsymmetric_and_behind_camera(hip_lib):
     thr_act = oracle.thr_act_of(0.01)
     got = run_trace(mus, isg, rays, K, thr_act)
     ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
-    compare_trace(got, ref, thr_act, min_match=0.98)
+    compare_trace(got, ref, thr_act, min_match=0.99, max_flips=4)
     assert (ref[1][ref[0] >= 0] < 0).any(), "scene must contain hits behind the camera"
     # coarse-stage candidate rule (rasterize_coarse.cu:35): view-space z < 0 skipped
     from voge_amd import ops
@@ -168,7 +168,7 @@ def test_trace_fwd_nonsymmetric_and_behind_camera(hip_lib):
     front = np.nonzero((mus[0] @ R[0][:, 2]) >= 0)[0].astype(np.int32)
     bins = np.broadcast_to(front[None, None, None, :], (1, 1, 1, front.size))
     ref2 = oracle.trace_fwd(mus, isg, rays, K, thr_act, bin_points=bins, bin_size=max(H, W))
-    compare_trace(got2, ref2, thr_act, min_match=0.98)
+    compare_trace(got2, ref2, thr_act, min_match=0.99, max_flips=4)
 
 
 def test_trace_fwd_explicit_bin_lists(hip_lib):
@@ -189,7 +189,47 @@ def test_trace_fwd_explicit_bin_lists(hip_lib):
     thr_act = oracle.thr_act_of(0.01)
     got = run_trace(mus, isg, rays, K, thr_act, bins=t(bins, torch.int32), bin_size=bs)
     ref = oracle.trace_fwd(mus, isg, rays, K, thr_act, bin_points=bins, bin_size=bs)
-    compare_trace(got, ref, thr_act, min_match=0.99)
+    compare_trace(got, ref, thr_act, min_match=0.998, max_flips=10)
+
+
+def test_explicit_bin_lists_tie_break_deviation(hip_lib):
+    """The one documented ordering deviation, measured (include/voge_hip.h, voge_trace_topk_list_fwd): EXACT ties in len
+    inside an explicit candidate list are kept in ascending index order here, in list order by the reference
+    (ray_trace_voge.cu:197-212 inserts with a strict `<` while walking the list).  Exact ties need bit-identical
+    Gaussians, so the scene is 60 Gaussians listed twice (indices i and i + 60) in DESCENDING index order: the oracle
+    (reference rule) then puts i + 60 in front of i, the kernel i in front of i + 60.  Everything else -- which
+    Gaussians are kept up to the twin, every len / act / dsd value, and the composite built from them -- is identical."""
+    n0 = 60
+    verts, sig, _ = random_scene(n0, seed=21, lo=0.08, hi=0.15)
+    verts, sig = np.concatenate([verts, verts]), np.concatenate([sig, sig])
+    H, W, K, bs = 32, 40, 12, 10
+    sc = dict(verts=verts, sigmas=sig, focal=40.0, principal=(20.0, 16.0), image_size=(H, W), dist=3.0, elev=5.0, azim=15.0)
+    mus, isg, rays, _, _ = camera_inputs(sc, B=1)
+    BH, BW = (H - 1) // bs + 1, (W - 1) // bs + 1
+    bins = np.broadcast_to(np.arange(2 * n0 - 1, -1, -1, dtype=np.int32)[None, None, None], (1, BH, BW, 2 * n0)).copy()
+    thr_act = oracle.thr_act_of(0.01)
+    got = run_trace(mus, isg, rays, K, thr_act, bins=t(bins, torch.int32), bin_size=bs)
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act, bin_points=bins, bin_size=bs)
+    gi, ri = np.asarray(got[0]), np.asarray(ref[0])
+    live = ri >= 0
+    assert ((gi >= 0) == live).all()
+    assert (gi[live] % n0 == ri[live] % n0).all()                       # the same Gaussian up to its twin, slot by slot
+    for g, r in zip(got[1:], ref[1:]):                                   # and the same values in every slot
+        assert close(np.asarray(g)[live], np.asarray(r)[live]).all()
+    differs = (gi != ri).any(-1)
+    print(f"[parity] explicit lists, exact ties: {int(differs.sum())} of {differs.size} pixels order a tied pair differently")
+    assert differs.any()                                                 # the deviation is real ...
+    g2, r2, lv = gi.reshape(-1, K), ri.reshape(-1, K), live.reshape(-1, K)
+    both = lv[:, :-1] & lv[:, 1:]
+    tw_g = both & (g2[:, :-1] % n0 == g2[:, 1:] % n0)                    # slots k and k + 1 hold twins
+    tw_r = both & (r2[:, :-1] % n0 == r2[:, 1:] % n0)
+    assert tw_g.any() and (g2[:, :-1][tw_g] < g2[:, 1:][tw_g]).all()     # ... ascending index here
+    assert tw_r.any() and (r2[:, :-1][tw_r] > r2[:, 1:][tw_r]).all()     # list order (descending indices) there
+    # twins are interchangeable downstream: the composite weights agree slot by slot
+    from voge_amd import ops
+    w, _ = ops.composite(t(gi, torch.int32), t(got[2]), t(got[1]), t(got[3]), 1.0)
+    wr, _ = oracle.composite_fwd(ri, ref[2], ref[1], ref[3], 1.0)
+    assert np.abs(n(w) - wr).max() < TOL
 
 
 def test_trace_fwd_empty_inputs(hip_lib):
@@ -254,7 +294,7 @@ def test_trace_iso_scalar_form_vs_oracle(hip_lib):
     tm, ta, tr = t(mus.reshape(-1, 3), rg=True), t(a.reshape(-1), rg=True), t(rays, rg=True)
     idx, ln, act, dsd = ops._RayTraceVoGEIso.apply(tm, ta, tr, None, thr_act, K)
     ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
-    compare_trace([n(x) for x in (idx, ln, act, dsd)], ref, thr_act, min_match=0.995)
+    compare_trace([n(x) for x in (idx, ln, act, dsd)], ref, thr_act, min_match=0.998, max_flips=8)
     rng = np.random.default_rng(5)
     valid = n(idx) >= 0
     gl, ga, gd = (rng.normal(size=idx.shape) * valid for _ in range(3))
@@ -412,8 +452,7 @@ def test_whole_frame_config1_vs_oracle(hip_lib):
     g_ray, g_mu, g_A = oracle.trace_bwd(ref["mus"], ref["isg"], ref["rays"], ref["idx"], g_len, g_act, g_dsd)
     g_sig = 2 * np.einsum("nii->n", g_A)                      # isigma = 2 * s * I
     for name, got, want in (("colors", colors.grad, g_attr), ("verts", gm.verts.grad, g_mu), ("sigmas", gm.sigmas.grad, g_sig)):
-        err = np.abs(n(got).astype(np.float64) - want).max()
-        assert err <= 20 * TOL * max(1.0, np.abs(want).max()), f"{name}: {err:.3e} / {np.abs(want).max():.3e}"
+        grad_close("whole frame cfg1 " + name, n(got), want, TOL)
 
 
 def test_row_bands_equal_whole_frame_and_default_bins(hip_lib):
@@ -545,9 +584,7 @@ def test_camera_pose_gradient_end_to_end(hip_lib):
     r64, o64 = _rays_torch64(cR, cT, f64, p64, *size)
     ((r64 * torch.tensor(g_ray)).sum() + (o64 * torch.tensor(-g_mu.sum(0, keepdims=True))).sum()).backward()
     for name, got, want in (("R", Rv.grad, cR.grad), ("T", Tv.grad, cT.grad)):
-        w = want.numpy()
-        err = np.abs(n(got) - w).max()
-        assert err <= 20 * TOL * max(1.0, np.abs(w).max()), f"{name}: {err:.3e} / {np.abs(w).max():.3e}"
+        grad_close("camera pose " + name, n(got), want.numpy(), TOL)
 
 
 # ------------------------------------------------------------------------------- row sharding, 2 processes
@@ -725,8 +762,8 @@ def test_list_path_backward_after_merge_and_index_guards(hip_lib):
     _, g_w = oracle.merge_bwd(np.tile(cols, (2, 1)), ref[0], wr, vr, np.ones(rgb.shape))
     g_act, g_len, g_dsd = oracle.composite_bwd(ref[2], ref[1], ref[3], g_w, 1.0)
     _, g_mu, g_A = oracle.trace_bwd(mus, isg, rays, ref[0], g_len + g_hl * (ref[0] >= 0), g_act, g_dsd)
-    assert np.abs(n(tm.grad) - g_mu).max() <= 20 * TOL * max(1.0, np.abs(g_mu).max())
-    assert np.abs(n(tm.grad)[0] - g_mu[0]).max() <= 20 * TOL * max(1.0, np.abs(g_mu).max())      # Gaussian 0 in particular
+    grad_close("list path after merge, g_mu", n(tm.grad), g_mu, TOL)
+    assert np.abs(n(tm.grad)[0] - g_mu[0]).max() <= TOL * max(1.0, np.abs(g_mu).max())      # Gaussian 0 in particular
     # (c) mask a Gaussian out of the fragments by hand: the count must follow
     idx3, ln3, act3, dsd3 = ops.ray_trace_fine(t(mus.reshape(-1, 3)), t(isg.reshape(-1, 3, 3)), t(rays), None, thr_act, bs, K)
     assert ops.hit_count_of(idx3) is not None

@@ -42,6 +42,24 @@ def _report_flips(label, n_flip, n_pix):
             pass
 
 
+def grad_close(label, got, want, tol):
+    """|got - want| <= tol * max(1, |want|_max); the measured ratio goes to the same log as the flip counts, so the
+    tolerances in the tests can be seen against what the kernels actually deliver."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    scale = max(1.0, float(np.abs(want).max())) if want.size else 1.0
+    err = float(np.abs(got - want).max()) if want.size else 0.0
+    line = f"[parity] {label}: max gradient error {err / scale:.2e} of scale (tolerance {tol:.1e})"
+    print(line)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        try:
+            with open(os.path.join(out, "parity_flips.txt"), "a") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
+    assert err <= tol * scale, f"{label}: {err:.3e} vs scale {scale:.3e} (tolerance {tol:.1e})"
+
+
 def compare_trace(got, ref, thr_act, min_match=0.999, max_flips=None, label=None):
     """got / ref = (idx, len, act, dsd).  Top-K membership and the act < thr test are
     discontinuous, so a 1-ulp difference may flip a member at isolated pixels (SURVEY.md §7
