@@ -349,6 +349,17 @@ def main():
                                                               P_(s["a"]), P_(s["l"]), P_(s["d"]), P_(s["rgb"]), P_(s["ws"]), P_(bg), -1.0,
                                                               P_(s["g"]), 3, 1, 1.0, 1, N, H, W, K, 3, N, P_(s["wk"]), nfb, P_(s["gv"]),
                                                               P_(s["gs"]), P_(s["gc"]), st))
+            else:
+                # the general path's fused backward (voge_fragment_shade_bwd): full 3x3 forms
+                nfb = lib.voge_fragment_bwd_workspace_bytes(N)
+                stage_defs["fragment_bwd"] = (
+                    lambda: dict(i=C_(idx), c=C_(cnt), w=C_(w), a=C_(sel[2]), l=C_(sel[1]), d=C_(sel[3]), rgb=C_(rgb), ws=C_(wsum),
+                                 g=torch.ones_like(rgb), wk=torch.empty(nfb, dtype=torch.uint8, device=dev), gv=E(mus), gs=E(isg),
+                                 gc=torch.empty_like(colors)),
+                    lambda s: lib.voge_fragment_shade_bwd(P_(mus), P_(isg), P_(rays), P_(colors), P_(s["i"]), P_(s["c"]), P_(s["w"]),
+                                                          P_(s["a"]), P_(s["l"]), P_(s["d"]), P_(s["rgb"]), P_(s["ws"]), P_(bg), -1.0,
+                                                          P_(s["g"]), 3, 1, 1.0, N, H, W, K, 3, N, P_(s["wk"]), nfb, P_(s["gv"]),
+                                                          P_(s["gs"]), P_(s["gc"]), st))
             nbytes = stage_bytes(N, npix, K, iso=iso)
             stages = {}
             for name, (mk, call) in stage_defs.items():

@@ -218,6 +218,15 @@ int voge_fragments_fwd_iso_view(const float *verts, const float *sigmas, const f
  * C <= 4; cnt required.  workspace: >= voge_fragment_bwd_workspace_bytes(B*N) bytes.
  */
 size_t voge_fragment_bwd_workspace_bytes(int P);
+/* The same for full 3x3 forms (mus [P,3], isigmas [P,3,3] as given to voge_fragments_fwd; P = B*N): writes g_mus
+ * [P,3], g_isigmas [P,3,3] (the raw, unsymmetrised outer-product sums of ray_trace_voge.cu:324-326, as voge_trace_bwd)
+ * -- both or neither -- and g_colors [Nattr,C].  Same constraints and workspace as the isotropic form. */
+int voge_fragment_shade_bwd(const float *mus, const float *isigmas, const float *rays, const float *colors,
+                            const int32_t *idx, const int32_t *cnt, const float *weight, const float *act,
+                            const float *len, const float *dsd, const float *rgb, const float *wsum, const float *bg,
+                            float thr, const float *g_img, long g_stride_pix, long g_stride_c, float occ, int P,
+                            long nrows, int W, int K, int C, long Nattr, void *workspace, size_t workspace_bytes,
+                            float *g_mus, float *g_isigmas, float *g_colors, voge_stream_t stream);
 int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
                                 const float *rays, const float *colors, const int32_t *idx, const int32_t *cnt,
                                 const float *weight, const float *act, const float *len, const float *dsd,

@@ -854,8 +854,9 @@ def test_renderer_against_the_running_reference_host_logic(hip_lib, case):
     assert np.abs(n(frag.vert_hit_length)[hit] - g[c + "_hit_length"][hit]).max() < 4e-4
 
 
-@pytest.mark.parametrize("K,B,inverse", [(40, 1, False), (12, 2, True), (26, 1, False)])
-def test_fused_fragment_backward_equals_the_three_kernels(hip_lib, K, B, inverse):
+@pytest.mark.parametrize("K,B,inverse,aniso", [(40, 1, False, False), (12, 2, True, False), (26, 1, False, False),
+                                               (20, 1, False, True), (8, 2, False, True)])
+def test_fused_fragment_backward_equals_the_three_kernels(hip_lib, K, B, inverse, aniso):
     """voge_fragment_shade_bwd_iso (shade -> composite -> trace backward in one kernel, taken by to_colored_background
     on this renderer's fragments) against the three stand-alone backward kernels on the same frame -- with a second
     consumer of the weights (a silhouette loss, which keeps flowing through _Fragments.backward) and a loss on
@@ -865,7 +866,7 @@ def test_fused_fragment_backward_equals_the_three_kernels(hip_lib, K, B, inverse
     from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, get_silhouette, to_colored_background
     from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
     N, H, W = 2500, 70, 90
-    verts, sig, cols = random_scene(N, seed=60 + K, lo=0.04, hi=0.1)
+    verts, sig, cols = random_scene(N, seed=60 + K, lo=0.04, hi=0.1, aniso=aniso)      # aniso: [N,3,3] forms, general kernels
     if inverse:
         sig = (1.0 / sig).astype(np.float32)
     R, T = look_at_view_transform(dist=[3.0, 3.4][:B], elev=[10.0, -20.0][:B], azim=[30.0, 200.0][:B], device=DEV)

@@ -39,8 +39,11 @@ constexpr int kFbGW = VOGE_FB_GW, kFbGH = VOGE_FB_GH, kFbG = kFbGW * kFbGH;
 static_assert(kFbG <= 64 && (kFbGW & (kFbGW - 1)) == 0, "a group's pixels are the lanes of one wave; GW a power of two");
 constexpr int kFbRowsLds = 2 * 64 + 4 * kFbG;      // a round's padded rows: 64 lanes' slots + two sentinel pairs per pixel
 
+template <int NV4>
 struct FragBwdLds {
-  WaveTable<kFbNE, 2> tab;        // key = Gaussian index; values = (g_mu, g_a), (w g_rgb, -)
+  // key = Gaussian index; values: (g_mu, g_a), (w g_rgb, -) for A = a I [NV4 = 2];
+  //                               (g_mu, g_A[0]), g_A[1..4], g_A[5..8], (w g_rgb, -) for a full 3x3 A [NV4 = 4]
+  WaveTable<kFbNE, NV4> tab;
   float len[kFbRowsLds], sp[kFbRowsLds], E[kFbRowsLds], u[kFbRowsLds];
 };
 
@@ -52,18 +55,20 @@ struct FragBwdLds {
 #endif
 // C: colour channels (1..4); OffT: uint32_t when every BYTE offset into the [pix][K] arrays fits 32 bits (the loads
 // then take scalar base + 32-bit lane offset and the address arithmetic leaves the vector unit), else size_t.
-template <int C, typename OffT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VOGE_FB_WPE)))
-fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */, const float *__restrict__ rays,
+// ISO: every Gaussian is A = a I (rec = [P] (mu, a)); otherwise rec = [P][3] packed (mu, A) as in trace_bwd.hip.
+template <int C, typename OffT, bool ISO>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISO ? VOGE_FB_WPE : 3)))
+fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
                         const float *__restrict__ colors, const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt,
                         const float *__restrict__ weight, const float *__restrict__ act, const float *__restrict__ len,
                         const float *__restrict__ dsd, const float *__restrict__ rgb, const float *__restrict__ wsum,
                         const float *__restrict__ bg, const float thr, const float *__restrict__ g_img, const long gs_pix,
                         const long gs_c, const float occ,
                         const int P, const long nrows, const int W, const int K, const long Nattr,
-                        float *__restrict__ acc /* [P][8], zeroed */) {
+                        float *__restrict__ acc /* [P][8] (ISO) | [P][16], zeroed */) {
   constexpr int NS = 2;
-  __shared__ __attribute__((aligned(16))) FragBwdLds L;
+  constexpr int NV4 = ISO ? 2 : 4, NACC = 4 * NV4;
+  __shared__ __attribute__((aligned(16))) FragBwdLds<NV4> L;
   float *const Llen = L.len, *const Lsp = L.sp, *const LE = L.E, *const Lu = L.u;
   const int lane = threadIdx.x;
   const int blocks_x = (W + kFbGW - 1) / kFbGW;
@@ -177,26 +182,65 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
     __builtin_amdgcn_wave_barrier();      // the rows are rewritten by the next round
     // ---- trace backward terms (isotropic: trace_bwd.hip) + the colour term, one table entry per Gaussian.  (The
     // (mu, a) records are gathered only now: held across the composite they cost the kernel a wave per SIMD.) ----
-    float4 rc[NS];
+    float4 rc[NS][ISO ? 1 : 3];
 #pragma unroll
     for (int a = 0; a < NS; ++a)
-      rc[a] = (live[a] && !(VOGE_FB_ABL & 8)) ? at_bytes<float4>(rec, (uint32_t)id[a] * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);   // (P < 2^28: host)
+#pragma unroll
+      for (int r = 0; r < (ISO ? 1 : 3); ++r)
+        rc[a][r] = (live[a] && !(VOGE_FB_ABL & 8)) ? at_bytes<float4>(rec, (uint32_t)id[a] * (ISO ? 16u : 48u) + 16u * r)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);   // (P < 2^26: host)
     const float dn2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float idn = __builtin_amdgcn_rcpf(dn2);
 #pragma unroll
     for (int a = 0; a < NS; ++a) {
-      float4 val[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+      float4 val[NV4];
+#pragma unroll
+      for (int r = 0; r < NV4; ++r) val[r] = make_float4(0.f, 0.f, 0.f, 0.f);
       bool go = live[a];
       if (go) {
-        const float mx = rc[a].x, my = rc[a].y, mz = rc[a].z, aa = rc[a].w;
-        const float t = fmaf(mz, dz, fmaf(my, dy, mx * dx)) * idn;
-        const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
-        const float c1 = gl[a] * idn, c2 = 2.0f * aa * ga[a];
-        val[0] = make_float4(fmaf(c1, dx, c2 * vx), fmaf(c1, dy, c2 * vy), fmaf(c1, dz, c2 * vz),
-                             fmaf(ga[a], fmaf(vz, vz, fmaf(vy, vy, vx * vx)), gd[a] * dn2));
-        val[1] = make_float4(wv[a] * gr[0], wv[a] * gr[1], wv[a] * gr[2], wv[a] * gr[3]);
-        go = (val[0].x != 0.f || val[0].y != 0.f || val[0].z != 0.f || val[0].w != 0.f || val[1].x != 0.f || val[1].y != 0.f ||
-              val[1].z != 0.f || val[1].w != 0.f);
+        if (ISO) {
+          const float mx = rc[a][0].x, my = rc[a][0].y, mz = rc[a][0].z, aa = rc[a][0].w;
+          const float t = fmaf(mz, dz, fmaf(my, dy, mx * dx)) * idn;
+          const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
+          const float c1 = gl[a] * idn, c2 = 2.0f * aa * ga[a];
+          val[0] = make_float4(fmaf(c1, dx, c2 * vx), fmaf(c1, dy, c2 * vy), fmaf(c1, dz, c2 * vz),
+                               fmaf(ga[a], fmaf(vz, vz, fmaf(vy, vy, vx * vx)), gd[a] * dn2));
+        } else {
+          // the merged per-target terms of trace_bwd.hip (header there): g_mu (3) and the unsymmetrised g_A (9)
+          const float4 r0 = rc[a][0], r1 = rc[a][ISO ? 0 : 1], r2 = rc[a][ISO ? 0 : 2];
+          const float mx = r0.x, my = r0.y, mz = r0.z;
+          const float A[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+          const float adx = fmaf(A[2], dz, fmaf(A[1], dy, A[0] * dx)), ady = fmaf(A[5], dz, fmaf(A[4], dy, A[3] * dx)),
+                      adz = fmaf(A[8], dz, fmaf(A[7], dy, A[6] * dx));
+          const float tdx = fmaf(A[6], dz, fmaf(A[3], dy, A[0] * dx)), tdy = fmaf(A[7], dz, fmaf(A[4], dy, A[1] * dx)),
+                      tdz = fmaf(A[8], dz, fmaf(A[5], dy, A[2] * dx));
+          const float ksk = fmaf(dz, adz, fmaf(dy, ady, dx * adx)), msk = fmaf(mz, adz, fmaf(my, ady, mx * adx));
+          const float ik = __builtin_amdgcn_rcpf(ksk);
+          const float t = msk * ik;
+          const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
+          const float avx = fmaf(A[2], vz, fmaf(A[1], vy, A[0] * vx)), avy = fmaf(A[5], vz, fmaf(A[4], vy, A[3] * vx)),
+                      avz = fmaf(A[8], vz, fmaf(A[7], vy, A[6] * vx));
+          const float tvx = fmaf(A[6], vz, fmaf(A[3], vy, A[0] * vx)), tvy = fmaf(A[7], vz, fmaf(A[4], vy, A[1] * vx)),
+                      tvz = fmaf(A[8], vz, fmaf(A[5], vy, A[2] * vx));
+          const float c1 = gl[a] * ik, g_a = ga[a], g_d = gd[a];
+          float o[12];
+          o[0] = fmaf(c1, adx, g_a * (avx + tvx + t * (tdx - adx)));
+          o[1] = fmaf(c1, ady, g_a * (avy + tvy + t * (tdy - ady)));
+          o[2] = fmaf(c1, adz, g_a * (avz + tvz + t * (tdz - adz)));
+          const float d[3] = {dx, dy, dz}, v[3] = {vx, vy, vz};
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              o[3 + 3 * i + c] = fmaf(g_a, fmaf(v[i], v[c], t * (d[i] * v[c] - v[i] * d[c])), fmaf(g_d, d[i] * d[c], c1 * (v[i] * d[c])));
+          val[0] = make_float4(o[0], o[1], o[2], o[3]);
+          val[ISO ? 0 : 1] = make_float4(o[4], o[5], o[6], o[7]);
+          val[ISO ? 0 : 2] = make_float4(o[8], o[9], o[10], o[11]);
+        }
+        val[NV4 - 1] = make_float4(wv[a] * gr[0], wv[a] * gr[1], wv[a] * gr[2], wv[a] * gr[3]);
+        go = false;
+#pragma unroll
+        for (int r = 0; r < NV4; ++r) go = go || (val[r].x != 0.f || val[r].y != 0.f || val[r].z != 0.f || val[r].w != 0.f);
       }
       if (!__any(go)) continue;     // uniform
 #if VOGE_FB_ABL & 1       // (timing experiment: no table, nothing accumulated)
@@ -206,20 +250,23 @@ fragment_bwd_iso_kernel(const float4 *__restrict__ rec /* [P] (centred mu, a) */
       const int slot = wt_find(L.tab, id[a], go);
       wt_add(L.tab, slot, val, go && slot >= 0, lane);
       if (go && slot < 0) {         // table full: rare, straight to memory
-        const float o[8] = {val[0].x, val[0].y, val[0].z, val[0].w, val[1].x, val[1].y, val[1].z, val[1].w};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) unsafeAtomicAdd(acc + 8 * (size_t)id[a] + c, o[c]);
+        for (int r = 0; r < NV4; ++r) {
+          const float o[4] = {val[r].x, val[r].y, val[r].z, val[r].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) unsafeAtomicAdd(acc + NACC * (size_t)id[a] + 4 * r + c, o[c]);
+        }
       }
     }
   }
-  {   // flush: 8 adjacent lanes per entry -> the 32 bytes of acc[p]: lane-coalesced atomics
-    const int c = lane & 7;
+  {   // flush: NACC (8 | 16) adjacent lanes per entry -> the 32 | 64 bytes of acc[p]: lane-coalesced atomics
+    const int c = lane & (NACC - 1);
     const float *vals = reinterpret_cast<const float *>(L.tab.vals);
     const int n = wt_compact(L.tab, lane);
     const volatile int *list = L.tab.owner;
-    for (int i = lane >> 3; i < n; i += 8) {
+    for (int i = lane / NACC; i < n; i += 64 / NACC) {
       const int s = list[i];
-      unsafeAtomicAdd(acc + 8 * (size_t)L.tab.keys[s] + c, vals[s * 8 + c]);
+      unsafeAtomicAdd(acc + NACC * (size_t)L.tab.keys[s] + c, vals[s * NACC + c]);
     }
   }
 }
@@ -249,11 +296,39 @@ fragment_bwd_finish_kernel(const float *__restrict__ acc, const float *__restric
   g_a[g] = ga;
 }
 
+// General 3x3 forms: mus [P,3] + isigmas [P,9] -> 3 x float4 per Gaussian (one gather stream), acc [P][16] zeroed
+__global__ void __launch_bounds__(256)
+fragment_bwd_pack_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const int P, float4 *__restrict__ rec,
+                         float4 *__restrict__ acc) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[4 * (size_t)g + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float *m = mus + 3 * (size_t)g, *A = isg + 9 * (size_t)g;
+  rec[3 * (size_t)g + 0] = make_float4(m[0], m[1], m[2], A[0]);
+  rec[3 * (size_t)g + 1] = make_float4(A[1], A[2], A[3], A[4]);
+  rec[3 * (size_t)g + 2] = make_float4(A[5], A[6], A[7], A[8]);
+}
+// acc [P][16] -> g_mus [P,3], g_isigmas [P,9], g_colors [Nattr,C]
+__global__ void __launch_bounds__(256)
+fragment_bwd_finish_general_kernel(const float *__restrict__ acc, const int P, const int C, const long Nattr,
+                                   float *__restrict__ g_mus, float *__restrict__ g_isg, float *__restrict__ g_colors) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long g = t >> 4;
+  const int c = (int)(t & 15);
+  if (g >= P && g >= Nattr) return;
+  const float v = (g < P) ? acc[t] : 0.0f;
+  if (c < 3) { if (g < P && g_mus != nullptr) g_mus[3 * g + c] = v; }
+  else if (c < 12) { if (g < P && g_isg != nullptr) g_isg[9 * g + (c - 3)] = v; }
+  else if (c - 12 < C && g < Nattr && g_colors != nullptr) g_colors[g * C + (c - 12)] = v;
+}
+
 }  // namespace voge
 
 using namespace voge;
 
-extern "C" size_t voge_fragment_bwd_workspace_bytes(int P) { return P <= 0 ? 0 : (size_t)P * 32; }
+// (the isotropic form uses the first 32 bytes per Gaussian; the general one 48 of packed records + 64 of sums)
+extern "C" size_t voge_fragment_bwd_workspace_bytes(int P) { return P <= 0 ? 0 : (size_t)P * 112; }
 
 extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
                                            const float *rays, const float *colors, const int32_t *idx, const int32_t *cnt,
@@ -274,15 +349,15 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
   if (!records || !rays || !colors || !idx || !cnt || !weight || !act || !len || !dsd || !rgb || !wsum || !bg || !g_img || !workspace)
     return VOGE_ERR_BAD_ARG;
   if ((g_verts == nullptr) != (g_sigmas == nullptr) || (sigma_mode == 2 && g_sigmas && !sigmas)) return VOGE_ERR_BAD_ARG;
-  if (workspace_bytes < voge_fragment_bwd_workspace_bytes(P)) return VOGE_ERR_WORKSPACE;
+  if (workspace_bytes < (size_t)P * 32) return VOGE_ERR_WORKSPACE;
   float *acc = reinterpret_cast<float *>(workspace);
   hipError_t e = hipMemsetAsync(acc, 0, (size_t)P * 32, st);
   if (e != hipSuccess) return (int)e;
   const long blocks = (long)((W + kFbGW - 1) / kFbGW) * ((nrows + kFbGH - 1) / kFbGH);
-  if (Nattr * C >= (1l << 30) || P >= (1 << 28)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
+  if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
   const bool small = (double)nrows * W * K < (double)(1l << 30);
 #define VOGE_LAUNCH_FB(CC, OT)                                                                                            \
-  hipLaunchKernelGGL((fragment_bwd_iso_kernel<CC, OT>), dim3((unsigned)blocks), dim3(64), 0, st,                          \
+  hipLaunchKernelGGL((fragment_bwd_kernel<CC, OT, true>), dim3((unsigned)blocks), dim3(64), 0, st,                        \
                      reinterpret_cast<const float4 *>(records), rays, colors, idx, cnt, weight, act, len, dsd, rgb, wsum, bg, thr, \
                      g_img, g_stride_pix, g_stride_c, occ, P, nrows, W, K, Nattr, acc)
 #define VOGE_LAUNCH_FB_C(CC) do { if (small) VOGE_LAUNCH_FB(CC, uint32_t); else VOGE_LAUNCH_FB(CC, size_t); } while (0)
@@ -297,5 +372,49 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
   const long n_fin = (Nattr > P) ? Nattr : P;
   hipLaunchKernelGGL(fragment_bwd_finish_kernel, dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, st, acc, sigmas, P, N, B,
                      IsoView{nullptr, shared ? 1 : 0, sigma_mode}, C, Nattr, g_verts, g_sigmas, g_colors);
+  return launch_status();
+}
+
+extern "C" int voge_fragment_shade_bwd(const float *mus, const float *isigmas, const float *rays, const float *colors,
+                                       const int32_t *idx, const int32_t *cnt, const float *weight, const float *act,
+                                       const float *len, const float *dsd, const float *rgb, const float *wsum,
+                                       const float *bg, float thr, const float *g_img, long g_stride_pix, long g_stride_c,
+                                       float occ, int P, long nrows, int W, int K, int C, long Nattr, void *workspace,
+                                       size_t workspace_bytes, float *g_mus, float *g_isigmas, float *g_colors,
+                                       voge_stream_t stream) {
+  if (P < 0 || nrows < 0 || W < 0 || K <= 0 || C <= 0 || C > 4 || Nattr < 0) return VOGE_ERR_BAD_ARG;
+  if ((K & 1) != 0 || K > 128) return VOGE_ERR_K_TOO_LARGE;
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 0 || nrows * W == 0) {
+    if (g_colors && Nattr > 0) return (int)hipMemsetAsync(g_colors, 0, sizeof(float) * (size_t)Nattr * C, st);
+    return 0;
+  }
+  if (!mus || !isigmas || !rays || !colors || !idx || !cnt || !weight || !act || !len || !dsd || !rgb || !wsum || !bg || !g_img ||
+      !workspace)
+    return VOGE_ERR_BAD_ARG;
+  if ((g_mus == nullptr) != (g_isigmas == nullptr)) return VOGE_ERR_BAD_ARG;
+  if (workspace_bytes < voge_fragment_bwd_workspace_bytes(P)) return VOGE_ERR_WORKSPACE;
+  if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
+  float4 *rec = reinterpret_cast<float4 *>(workspace);
+  float *acc = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (size_t)P * 48);
+  hipLaunchKernelGGL(fragment_bwd_pack_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, mus, isigmas, P, rec,
+                     reinterpret_cast<float4 *>(acc));
+  const long blocks = (long)((W + kFbGW - 1) / kFbGW) * ((nrows + kFbGH - 1) / kFbGH);
+  const bool small = (double)nrows * W * K < (double)(1l << 30);
+#define VOGE_LAUNCH_FBG(CC, OT)                                                                                           \
+  hipLaunchKernelGGL((fragment_bwd_kernel<CC, OT, false>), dim3((unsigned)blocks), dim3(64), 0, st, rec, rays, colors, idx, cnt,   \
+                     weight, act, len, dsd, rgb, wsum, bg, thr, g_img, g_stride_pix, g_stride_c, occ, P, nrows, W, K, Nattr, acc)
+#define VOGE_LAUNCH_FBG_C(CC) do { if (small) VOGE_LAUNCH_FBG(CC, uint32_t); else VOGE_LAUNCH_FBG(CC, size_t); } while (0)
+  switch (C) {
+    case 1: VOGE_LAUNCH_FBG_C(1); break;
+    case 2: VOGE_LAUNCH_FBG_C(2); break;
+    case 3: VOGE_LAUNCH_FBG_C(3); break;
+    default: VOGE_LAUNCH_FBG_C(4); break;
+  }
+#undef VOGE_LAUNCH_FBG_C
+#undef VOGE_LAUNCH_FBG
+  const long n_fin = (Nattr > P) ? Nattr : P;
+  hipLaunchKernelGGL(fragment_bwd_finish_general_kernel, dim3((unsigned)((n_fin * 16 + 255) / 256)), dim3(256), 0, st, acc, P, C,
+                     Nattr, g_mus, g_isigmas, g_colors);
   return launch_status();
 }

@@ -397,9 +397,9 @@ class _Fragments(torch.autograd.Function):
         ctx.mark_non_differentiable(sel_idx, valid)
         ctx.set_materialize_grads(False)
         # what a later to_colored_background needs to run the whole backward in one kernel (see _ShadeThrough)
-        ctx.through = None if mode == 0 else dict(mode=int(mode), sigma_mode=int(sigma_mode), shared=bool(shared), occ=float(occ),
-                                                  B=B, N=N, records=records, rays=rays_c, act=sel_act, dsd=sel_dsd, len=sel_len,
-                                                  cnt=cnt, idx=sel_idx, sigmas=p1_c)
+        ctx.through = dict(mode=int(mode), sigma_mode=int(sigma_mode), shared=bool(shared), occ=float(occ), B=B, N=N,
+                           records=records, rays=rays_c, act=sel_act, dsd=sel_dsd, len=sel_len, cnt=cnt, idx=sel_idx,
+                           sigmas=p1_c, means=p0_c)
         _Fragments._last_through = ctx.through
         return weight, sel_idx, valid, sel_len
 
@@ -465,8 +465,9 @@ def fragments(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode
 
 
 class _ShadeThrough(torch.autograd.Function):
-    """to_colored_background on fragments this renderer made, for isotropic Gaussians: the forward is _Shade's, the
-    backward runs shade -> composite -> trace as ONE kernel (voge_fragment_shade_bwd_iso) and hands the gradients
+    """to_colored_background on fragments this renderer made: the forward is _Shade's, the
+    backward runs shade -> composite -> trace as ONE kernel (voge_fragment_shade_bwd_iso for scalar sigmas,
+    voge_fragment_shade_bwd for full 3x3 forms) and hands the gradients
     straight to the colours AND to the Gaussians' (verts | means, sigmas | a), which are inputs of this node for that
     purpose; the weights get no gradient from here.  Every stage is linear in the gradient of the weights, so whatever
     else consumes the same weights (a silhouette loss, a second image) still flows through _Fragments.backward and the
@@ -515,11 +516,18 @@ class _ShadeThrough(torch.autograd.Function):
         with _on(idx.device):
             nbytes = lib.voge_fragment_bwd_workspace_bytes(P)
             ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=idx.device)
-            rc = lib.voge_fragment_shade_bwd_iso(
-                _p(th["records"]), _p(th["sigmas"]), int(th["shared"]), th["sigma_mode"], _p(th["rays"]), _p(attr), _p(idx),
-                _p(th["cnt"]), _p(w), _p(th["act"]), _p(th["len"]), _p(th["dsd"]), _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go),
-                gs_pix, gs_c, th["occ"], th["B"], th["N"], B * H, W, K, C, Nattr, _p(ws), nbytes, _p(g0), _p(g1), _p(g_attr), _stream())
-        _lib.check(rc, "voge_fragment_shade_bwd_iso")
+            if th["mode"] == 0:      # full 3x3 forms: gradients of (mus, isigmas) as given
+                rc = lib.voge_fragment_shade_bwd(
+                    _p(th["means"]), _p(th["sigmas"]), _p(th["rays"]), _p(attr), _p(idx), _p(th["cnt"]), _p(w), _p(th["act"]),
+                    _p(th["len"]), _p(th["dsd"]), _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go), gs_pix, gs_c, th["occ"], P, B * H, W, K,
+                    C, Nattr, _p(ws), nbytes, _p(g0), _p(g1), _p(g_attr), _stream())
+            else:
+                rc = lib.voge_fragment_shade_bwd_iso(
+                    _p(th["records"]), _p(th["sigmas"]), int(th["shared"]), th["sigma_mode"], _p(th["rays"]), _p(attr), _p(idx),
+                    _p(th["cnt"]), _p(w), _p(th["act"]), _p(th["len"]), _p(th["dsd"]), _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go),
+                    gs_pix, gs_c, th["occ"], th["B"], th["N"], B * H, W, K, C, Nattr, _p(ws), nbytes, _p(g0), _p(g1), _p(g_attr),
+                    _stream())
+        _lib.check(rc, "voge_fragment_shade_bwd")
         need = ctx.needs_input_grad
         return (g_attr if need[0] else None), None, (g0 if need[2] else None), (g1 if need[3] else None), None, None, None, None, None
 
