@@ -188,6 +188,11 @@ int voge_bin_gaussians(const float *points, const int64_t *cloud_to_packed_first
  * inside the sweep's epilogue was measured slower, see trace_fwd.hip); the call saves the host side one
  * autograd node and a set of allocations per frame.
  */
+/* Scalar-sigma forms (_iso, _iso_view) only: act and dsd may BOTH be NULL.  The sweep then writes index and len alone
+ * (no per-slot gather in its epilogue), the composite derives act / dsd from the (mean, a) records with the same
+ * operations (voge_composite_fwd_iso), and so does voge_fragment_shade_bwd_iso when handed NULL for them: 168 MB per
+ * frame at 50k Gaussians / 512^2 / K = 40 that are neither written nor read.  Weights are bit-identical either way.
+ * voge_fragment_act_dsd_iso materialises them afterwards for consumers that want the arrays (K must be even). */
 int voge_fragments_fwd(const float *mus, const float *isigmas, const float *rays, const float *cam_fwd,
                        const float *cones, int B, int N, int H, int W, int K, float thr_act, float occ,
                        void *workspace, size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
@@ -218,6 +223,15 @@ int voge_fragments_fwd_iso_view(const float *verts, const float *sigmas, const f
  * C <= 4; cnt required.  workspace: >= voge_fragment_bwd_workspace_bytes(B*N) bytes.
  */
 size_t voge_fragment_bwd_workspace_bytes(int P);
+/* act / dsd [npix,K] of scalar-sigma fragments that were traced without them (see voge_fragments_fwd_iso): records
+ * [P,4] = the (centred mean, a) pairs of that call, idx / len / cnt its outputs.  Sentinels (1e10, 0) in empty slots. */
+int voge_fragment_act_dsd_iso(const float *records, const float *rays, const int32_t *idx, const float *len,
+                              const int32_t *cnt, long npix, int K, int P, float *act, float *dsd, voge_stream_t stream);
+/* Composite forward from (idx, len) and the records instead of (act, len, dsd): what voge_fragments_fwd_iso* runs behind
+ * its sweep when act / dsd are omitted.  cnt required, K even. */
+int voge_composite_fwd_iso(const int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                           const float *rays, float occ, long npix, int K, float *weight, int64_t *valid_num,
+                           voge_stream_t stream);
 /* The same for full 3x3 forms (mus [P,3], isigmas [P,3,3] as given to voge_fragments_fwd; P = B*N): writes g_mus
  * [P,3], g_isigmas [P,3,3] (the raw, unsymmetrised outer-product sums of ray_trace_voge.cu:324-326, as voge_trace_bwd)
  * -- both or neither -- and g_colors [Nattr,C].  Same constraints and workspace as the isotropic form. */

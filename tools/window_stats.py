@@ -19,7 +19,9 @@ R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
 cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), device=dev)
 renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1, max_point_per_bin=-1)).to(dev)
 frag = renderer(gm, R=R, T=T)
+from voge_amd import ops
 th = frag.vert_weight.voge_through
+ops._act_dsd(th)                      # (scalar sigmas: act / dsd are not kept by the forward; derived on request)
 ln, dsd, act, idx = (th[k].reshape(-1, K) for k in ("len", "dsd", "act", "idx"))
 live = idx >= 0
 n = live.sum(-1)

@@ -344,7 +344,8 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
                   const float *__restrict__ w_in, const float *__restrict__ g_weight,
                   const int32_t *__restrict__ cnt_in, const float occ, const long npix, const int K, const int ppw,
                   float *__restrict__ out0 /* weight | g_act */, float *__restrict__ out1 /* g_len */,
-                  float *__restrict__ out2 /* g_dsd */, int64_t *__restrict__ valid_num) {
+                  float *__restrict__ out2 /* g_dsd */, int64_t *__restrict__ valid_num,
+                  const float4 *__restrict__ rec /* forward with act == NULL: [P] (mu, a) */, const float *__restrict__ rays) {
   constexpr bool BWD = MODE != 0;
   constexpr int NP = NS / 2;       // own aligned pairs
   extern __shared__ __attribute__((aligned(16))) unsigned char comp_smem[];
@@ -403,7 +404,37 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   int id[NS];
 #pragma unroll
   for (int a = 0; a < NS; ++a) { lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.0f; gw[a] = 0.0f; wg[a] = 0.0f; id[a] = -1; }
-  if (active) {
+  if (!BWD && act == nullptr) {
+    // Fragments without act / dsd in memory (voge_fragments_fwd_iso*): the sweep wrote index and len only; act and dsd
+    // of A = a I are re-derived here from the SAME records with the SAME operations its epilogue would have used
+    // (pair_eval_iso_at), so the weights are bit-identical to the two-call form.  (host: counts given, K % NS == 0)
+    if (active && k0 < lead) {
+      const float3 d = at_bytes<float3>(rays, (OffT)pix * (OffT)12);
+      const float dn2 = (d.x * d.x + d.y * d.y) + d.z * d.z;
+      int iv[NS];
+      float lv[NS];
+      if (NS == 4) {
+        const int4 i4 = at_bytes<int4>(idx, fb);
+        const float4 l4 = at_bytes<float4>(len, fb);
+        iv[0] = i4.x; iv[1] = i4.y; iv[NS - 2] = i4.z; iv[NS - 1] = i4.w;
+        lv[0] = l4.x; lv[1] = l4.y; lv[NS - 2] = l4.z; lv[NS - 1] = l4.w;
+      } else {
+        const int2 i2 = at_bytes<int2>(idx, fb);
+        const v2f l2 = at_bytes<v2f>(len, fb);
+        iv[0] = i2.x; iv[1] = i2.y; lv[0] = l2.x; lv[1] = l2.y;
+      }
+      float4 rc[NS];
+#pragma unroll
+      for (int a = 0; a < NS; ++a) rc[a] = (k0 + a < lead) ? at_bytes<float4>(rec, (uint32_t)iv[a] * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        if (k0 + a < lead) {
+          const PairOut o = pair_eval_iso_at(rc[a].x, rc[a].y, rc[a].z, rc[a].w, lv[a], d.x, d.y, d.z, dn2);
+          em[a] = FAST_EXP(-o.act); lm[a] = lv[a]; sm[a] = FAST_SQRT(o.dsd + 1e-10f);
+        }
+      }
+    }
+  } else if (active) {
     if (vec && k0 + NS <= lead) {        // the whole group is live: one wide access per array
       float av[NS], lv[NS], dv[NS];
       if (NS == 4) {
@@ -816,7 +847,8 @@ using namespace voge;
 
 static int launch_composite(int mode, const int32_t *idx, const float *act, const float *len, const float *dsd,
                             const float *w_in, const float *g_weight, const int32_t *cnt_in, float occ, long npix, int K, float *o0, float *o1,
-                            float *o2, int64_t *valid_num, voge_stream_t stream) {
+                            float *o2, int64_t *valid_num, voge_stream_t stream, const float *rec = nullptr,
+                            const float *rays = nullptr) {
 #ifndef VOGE_COMP_T
 #define VOGE_COMP_T 256
 #endif
@@ -850,10 +882,10 @@ static int launch_composite(int mode, const int32_t *idx, const float *act, cons
     do {                                                                                                                \
       if (small)                                                                                                        \
         hipLaunchKernelGGL((compositen_kernel<M, N, WV, uint32_t>), gridn, blockn, ldsn, st, idx, act, len, dsd, w_in, g_weight,    \
-                           cnt_in, occ, npix, K, ppwn, o0, o1, o2, valid_num);                                          \
+                           cnt_in, occ, npix, K, ppwn, o0, o1, o2, valid_num, reinterpret_cast<const float4 *>(rec), rays); \
       else                                                                                                              \
         hipLaunchKernelGGL((compositen_kernel<M, N, WV, size_t>), gridn, blockn, ldsn, st, idx, act, len, dsd, w_in, g_weight,      \
-                           cnt_in, occ, npix, K, ppwn, o0, o1, o2, valid_num);                                          \
+                           cnt_in, occ, npix, K, ppwn, o0, o1, o2, valid_num, reinterpret_cast<const float4 *>(rec), rays); \
     } while (0)
     if (wavem) {
       if (mode == 2) { if (NS == 4) VOGE_LAUNCH_COMPN(2, 4, true); else VOGE_LAUNCH_COMPN(2, 2, true); }
@@ -889,6 +921,19 @@ extern "C" int voge_composite_fwd(const int32_t *idx, const int32_t *cnt, const 
   if (npix == 0) return 0;
   if ((!idx && !cnt) || !act || !len || !dsd || !weight || !valid_num) return VOGE_ERR_BAD_ARG;
   return launch_composite(0, idx, act, len, dsd, nullptr, nullptr, cnt, occ, npix, K, weight, nullptr, nullptr, valid_num, stream);
+}
+
+// Composite forward for A = a I straight from the sweep's keys: act / dsd are derived from the (mu, a) records instead of
+// being read (see compositen_kernel).  K even; cnt required.
+extern "C" int voge_composite_fwd_iso(const int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                                      const float *rays, float occ, long npix, int K, float *weight, int64_t *valid_num,
+                                      voge_stream_t stream) {
+  if (npix < 0 || K <= 0 || (K & 1)) return VOGE_ERR_BAD_ARG;
+  if (K > VOGE_MAX_K || K > kCompThreads) return VOGE_ERR_K_TOO_LARGE;
+  if (npix == 0) return 0;
+  if (!idx || !cnt || !len || !records || !rays || !weight || !valid_num) return VOGE_ERR_BAD_ARG;
+  return launch_composite(0, idx, nullptr, len, nullptr, nullptr, nullptr, cnt, occ, npix, K, weight, nullptr, nullptr, valid_num,
+                          stream, records, rays);
 }
 
 extern "C" int voge_composite_bwd(const float *act, const float *len, const float *dsd, const float *weight,

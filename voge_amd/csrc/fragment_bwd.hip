@@ -56,7 +56,9 @@ struct FragBwdLds {
 // C: colour channels (1..4); OffT: uint32_t when every BYTE offset into the [pix][K] arrays fits 32 bits (the loads
 // then take scalar base + 32-bit lane offset and the address arithmetic leaves the vector unit), else size_t.
 // ISO: every Gaussian is A = a I (rec = [P] (mu, a)); otherwise rec = [P][3] packed (mu, A) as in trace_bwd.hip.
-template <int C, typename OffT, bool ISO>
+// NOAD (ISO only): the forward kept no act / dsd (voge_fragments_fwd_iso* with act = dsd = NULL); they are re-derived
+// from the records, the ray and len with the forward's own operations (pair_eval_iso_at): 8 bytes per slot less to read.
+template <int C, typename OffT, bool ISO, bool NOAD>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISO ? VOGE_FB_WPE : 3)))
 fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
                         const float *__restrict__ colors, const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt,
@@ -106,11 +108,34 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     bool live[NS];
 #pragma unroll
     for (int a = 0; a < NS; ++a) { id[a] = -1; wv[a] = 0.f; lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.f; live[a] = on && (k0 + a < lead); }
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (on) {
+      const float3 dv = at_bytes<float3>(rays, pix * (OffT)12);
+      dx = dv.x; dy = dv.y; dz = dv.z;
+    }
+    float4 rc[NS][ISO ? 1 : 3];
     if (live[0]) {              // 8-byte accesses (K is even: the pair is aligned and inside the pixel's row)
       const int2 i2 = at_bytes<int2>(idx, fb);
-      const v2f w2 = at_bytes<v2f>(weight, fb), a2 = at_bytes<v2f>(act, fb), l2 = at_bytes<v2f>(len, fb), d2 = at_bytes<v2f>(dsd, fb);
-      id[0] = i2.x; wv[0] = w2.x; lm[0] = l2.x; em[0] = FAST_EXP(-a2.x); sm[0] = FAST_SQRT(d2.x + 1e-10f);
-      if (live[1]) { id[1] = i2.y; wv[1] = w2.y; lm[1] = l2.y; em[1] = FAST_EXP(-a2.y); sm[1] = FAST_SQRT(d2.y + 1e-10f); }
+      const v2f w2 = at_bytes<v2f>(weight, fb), l2 = at_bytes<v2f>(len, fb);
+      id[0] = i2.x; wv[0] = w2.x; lm[0] = l2.x;
+      if (live[1]) { id[1] = i2.y; wv[1] = w2.y; lm[1] = l2.y; }
+      if (!NOAD) {
+        const v2f a2 = at_bytes<v2f>(act, fb), d2 = at_bytes<v2f>(dsd, fb);
+        em[0] = FAST_EXP(-a2.x); sm[0] = FAST_SQRT(d2.x + 1e-10f);
+        if (live[1]) { em[1] = FAST_EXP(-a2.y); sm[1] = FAST_SQRT(d2.y + 1e-10f); }
+      }
+    }
+    if (NOAD) {                 // act / dsd from the records (gathered here once, used again by the trace terms below)
+      const float dn2f = (dx * dx + dy * dy) + dz * dz;      // the forward's association
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const bool ok = live[a] && id[a] >= 0 && id[a] < P;
+        rc[a][0] = ok ? at_bytes<float4>(rec, (uint32_t)id[a] * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+          const PairOut o = pair_eval_iso_at(rc[a][0].x, rc[a][0].y, rc[a][0].z, rc[a][0].w, lm[a], dx, dy, dz, dn2f);
+          em[a] = FAST_EXP(-o.act); sm[a] = FAST_SQRT(o.dsd + 1e-10f);
+        }
+      }
     }
     // gathers: the slots' colours and (mu, a); the pixel's ray, upstream gradient and forward sums
     float col[NS][4];
@@ -133,7 +158,7 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
         }
       }
     }
-    float gr[4] = {0.f, 0.f, 0.f, 0.f}, g_sum_w = 0.0f, dx = 0.f, dy = 0.f, dz = 0.f;
+    float gr[4] = {0.f, 0.f, 0.f, 0.f}, g_sum_w = 0.0f;
     if (on) {
       const OffT pb = pix * (OffT)4;
       const float ws = at_bytes<float>(wsum, pb);
@@ -148,8 +173,6 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
         g_mask = fmaf(-gr[c], bg[c], g_mask);
       }
       g_sum_w = g_mask * pass_s;
-      const float3 dv = at_bytes<float3>(rays, pb * (OffT)3);
-      dx = dv.x; dy = dv.y; dz = dv.z;
     }
     // ---- shade backward: g_w of the slots; u = g_w w ----
     float um[NS];
@@ -182,7 +205,7 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     __builtin_amdgcn_wave_barrier();      // the rows are rewritten by the next round
     // ---- trace backward terms (isotropic: trace_bwd.hip) + the colour term, one table entry per Gaussian.  (The
     // (mu, a) records are gathered only now: held across the composite they cost the kernel a wave per SIMD.) ----
-    float4 rc[NS][ISO ? 1 : 3];
+    if (!NOAD)
 #pragma unroll
     for (int a = 0; a < NS; ++a)
 #pragma unroll
@@ -323,9 +346,42 @@ fragment_bwd_finish_general_kernel(const float *__restrict__ acc, const int P, c
   else if (c - 12 < C && g < Nattr && g_colors != nullptr) g_colors[g * C + (c - 12)] = v;
 }
 
+// act / dsd of fragments that were traced without them (A = a I): the sweep epilogue's own operations per live slot,
+// the trace's sentinels elsewhere.  One thread per slot.
+__global__ void __launch_bounds__(256)
+fragment_act_dsd_iso_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays, const int32_t *__restrict__ idx,
+                            const float *__restrict__ len, const int32_t *__restrict__ cnt, const long npix, const int K,
+                            const int P, float *__restrict__ act, float *__restrict__ dsd) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npix * K) return;
+  const long pix = t / K;
+  const int k = (int)(t - pix * K);
+  float a = VOGE_SENT_ACT, d = 0.0f;
+  const int id = idx[t];
+  if (k < cnt[pix] && id >= 0 && id < P) {
+    const float4 r = rec[id];
+    const float dx = rays[pix * 3], dy = rays[pix * 3 + 1], dz = rays[pix * 3 + 2];
+    const PairOut o = pair_eval_iso_at(r.x, r.y, r.z, r.w, len[t], dx, dy, dz, (dx * dx + dy * dy) + dz * dz);
+    a = o.act; d = o.dsd;
+  }
+  act[t] = a; dsd[t] = d;
+}
+
 }  // namespace voge
 
 using namespace voge;
+
+extern "C" int voge_fragment_act_dsd_iso(const float *records, const float *rays, const int32_t *idx, const float *len,
+                                         const int32_t *cnt, long npix, int K, int P, float *act, float *dsd,
+                                         voge_stream_t stream) {
+  if (npix < 0 || K <= 0 || P < 0) return VOGE_ERR_BAD_ARG;
+  if (npix == 0) return 0;
+  if (!records || !rays || !idx || !len || !cnt || !act || !dsd) return VOGE_ERR_BAD_ARG;
+  const long n = npix * K;
+  hipLaunchKernelGGL(fragment_act_dsd_iso_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4 *>(records), rays, idx, len, cnt, npix, K, P, act, dsd);
+  return launch_status();
+}
 
 // (the isotropic form uses the first 32 bytes per Gaussian; the general one 48 of packed records + 64 of sums)
 extern "C" size_t voge_fragment_bwd_workspace_bytes(int P) { return P <= 0 ? 0 : (size_t)P * 112; }
@@ -346,8 +402,9 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
     if (g_colors && Nattr > 0) return (int)hipMemsetAsync(g_colors, 0, sizeof(float) * (size_t)Nattr * C, st);
     return 0;
   }
-  if (!records || !rays || !colors || !idx || !cnt || !weight || !act || !len || !dsd || !rgb || !wsum || !bg || !g_img || !workspace)
+  if (!records || !rays || !colors || !idx || !cnt || !weight || !len || !rgb || !wsum || !bg || !g_img || !workspace)
     return VOGE_ERR_BAD_ARG;
+  if ((act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;      // both or neither (neither: re-derived from the records)
   if ((g_verts == nullptr) != (g_sigmas == nullptr) || (sigma_mode == 2 && g_sigmas && !sigmas)) return VOGE_ERR_BAD_ARG;
   if (workspace_bytes < (size_t)P * 32) return VOGE_ERR_WORKSPACE;
   float *acc = reinterpret_cast<float *>(workspace);
@@ -356,11 +413,15 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
   const long blocks = (long)((W + kFbGW - 1) / kFbGW) * ((nrows + kFbGH - 1) / kFbGH);
   if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
   const bool small = (double)nrows * W * K < (double)(1l << 30);
-#define VOGE_LAUNCH_FB(CC, OT)                                                                                            \
-  hipLaunchKernelGGL((fragment_bwd_kernel<CC, OT, true>), dim3((unsigned)blocks), dim3(64), 0, st,                        \
+#define VOGE_LAUNCH_FB(CC, OT, NA)                                                                                            \
+  hipLaunchKernelGGL((fragment_bwd_kernel<CC, OT, true, NA>), dim3((unsigned)blocks), dim3(64), 0, st,                    \
                      reinterpret_cast<const float4 *>(records), rays, colors, idx, cnt, weight, act, len, dsd, rgb, wsum, bg, thr, \
                      g_img, g_stride_pix, g_stride_c, occ, P, nrows, W, K, Nattr, acc)
-#define VOGE_LAUNCH_FB_C(CC) do { if (small) VOGE_LAUNCH_FB(CC, uint32_t); else VOGE_LAUNCH_FB(CC, size_t); } while (0)
+#define VOGE_LAUNCH_FB_C(CC)                                                                                               \
+  do {                                                                                                                    \
+    if (act == nullptr) { if (small) VOGE_LAUNCH_FB(CC, uint32_t, true); else VOGE_LAUNCH_FB(CC, size_t, true); }         \
+    else { if (small) VOGE_LAUNCH_FB(CC, uint32_t, false); else VOGE_LAUNCH_FB(CC, size_t, false); }                      \
+  } while (0)
   switch (C) {
     case 1: VOGE_LAUNCH_FB_C(1); break;
     case 2: VOGE_LAUNCH_FB_C(2); break;
@@ -402,7 +463,7 @@ extern "C" int voge_fragment_shade_bwd(const float *mus, const float *isigmas, c
   const long blocks = (long)((W + kFbGW - 1) / kFbGW) * ((nrows + kFbGH - 1) / kFbGH);
   const bool small = (double)nrows * W * K < (double)(1l << 30);
 #define VOGE_LAUNCH_FBG(CC, OT)                                                                                           \
-  hipLaunchKernelGGL((fragment_bwd_kernel<CC, OT, false>), dim3((unsigned)blocks), dim3(64), 0, st, rec, rays, colors, idx, cnt,   \
+  hipLaunchKernelGGL((fragment_bwd_kernel<CC, OT, false, false>), dim3((unsigned)blocks), dim3(64), 0, st, rec, rays, colors, idx, cnt,   \
                      weight, act, len, dsd, rgb, wsum, bg, thr, g_img, g_stride_pix, g_stride_c, occ, P, nrows, W, K, Nattr, acc)
 #define VOGE_LAUNCH_FBG_C(CC) do { if (small) VOGE_LAUNCH_FBG(CC, uint32_t); else VOGE_LAUNCH_FBG(CC, size_t); } while (0)
   switch (C) {

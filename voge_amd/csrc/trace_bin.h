@@ -708,7 +708,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
           // fused trace + composite: the fragments are (weight, idx, len); act / dsd only serve the backward, which
           // never reads a pixel without hits -- a quarter of the empty tiles' bytes stays unwritten
           *reinterpret_cast<float4 *>(out_weight + o) = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
+        } else if (out_act != nullptr) {      // (NULL: the scalar-sigma fragment entry points keep no act / dsd)
           *reinterpret_cast<float4 *>(out_act + o) = make_float4(VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT);
           *reinterpret_cast<float4 *>(out_dsd + o) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -717,7 +717,8 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
       for (int it = tid; it < th * row_items; it += kQT) {
         const int rr = it / row_items, j = it - rr * row_items;
         const size_t o = (((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8) * K + j;
-        out_idx[o] = -1; out_len[o] = VOGE_SENT_LEN; out_act[o] = VOGE_SENT_ACT; out_dsd[o] = 0.0f;
+        out_idx[o] = -1; out_len[o] = VOGE_SENT_LEN;
+        if (out_act != nullptr) { out_act[o] = VOGE_SENT_ACT; out_dsd[o] = 0.0f; }
         if (out_weight != nullptr) out_weight[o] = 0.0f;
       }
     }

@@ -768,7 +768,35 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
         *reinterpret_cast<float4 *>(out_dsd + ob[u]) = make_float4(od[0], od[1], od[2], od[3]);
       }
     }
-    for (int it0 = tid; !tile_gen && it0 < nitem; it0 += T * kEpiU) {
+    // Fragment mode without act / dsd (out_act == NULL; voge_fragments_fwd_iso*): index and len are the key itself --
+    // no gather, no ray, no arithmetic; the composite kernel behind the sweep derives act / dsd from the same
+    // records with the same operations (composite.hip), at its own, much higher residency.
+    const bool want_ad = out_act != nullptr;
+    for (int it0 = tid; !tile_gen && !want_ad && it0 < nitem; it0 += T * kEpiU) {
+#pragma unroll
+      for (int u = 0; u < kEpiU; ++u) {
+        const int it = it0 + u * T;
+        if (it >= nitem) break;
+        const int r = __float2int_rz(((float)it + 0.5f) * inv_ipr);
+        const int j = (it - r * ipr) * 4;
+        const int x = __float2int_rz(((float)j + 0.5f) * invK);
+        const int sl = j - x * K;
+        const int owner = ((x >> 3) + (TW / 8) * (r >> 3)) * 64 + (x & 7) + 8 * (r & 7);
+        const size_t pix = ((size_t)b * H + ty * TH + r) * W + (size_t)tx * TW + x;
+        const int nv = max(0, min(4, L.id[owner] - sl));
+        int32_t oi[4];
+        float ol[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint64_t key = (q < nv) ? keys[(size_t)(sl + q) * TP + owner] : 0ull;
+          oi[q] = (q < nv) ? (int32_t)(uint32_t)key : -1;
+          ol[q] = (q < nv) ? ord2f((uint32_t)(key >> 32)) : VOGE_SENT_LEN;
+        }
+        *reinterpret_cast<int4 *>(out_idx + pix * K + sl) = make_int4(oi[0], oi[1], oi[2], oi[3]);
+        *reinterpret_cast<float4 *>(out_len + pix * K + sl) = make_float4(ol[0], ol[1], ol[2], ol[3]);
+      }
+    }
+    for (int it0 = tid; !tile_gen && want_ad && it0 < nitem; it0 += T * kEpiU) {
       uint64_t key[kEpiU][4];
       float4 rec[kEpiU][4];
       float ex[kEpiU], ey[kEpiU], ez[kEpiU];
@@ -863,8 +891,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
         const size_t o = pix0 * K + j;
         out_idx[o] = oi;
         out_len[o] = ol;
-        out_act[o] = oa;
-        out_dsd[o] = od;
+        if (out_act != nullptr) { out_act[o] = oa; out_dsd[o] = od; }
       }
     }
   }
@@ -1102,6 +1129,9 @@ extern "C" size_t voge_trace_workspace_bytes(int B, int N, int H, int W) {
 }
 
 extern "C" int voge_ray_cones(const float *rays, int B, int H, int W, float *cones, voge_stream_t stream);   // rays.hip
+extern "C" int voge_composite_fwd_iso(const int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                                      const float *rays, float occ, long npix, int K, float *weight, int64_t *valid_num,
+                                      voge_stream_t stream);                                                     // composite.hip
 
 static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float *mus, const float *isigmas, const float *rays,
                                const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
@@ -1112,7 +1142,9 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   if (B < 0 || N < 0 || H < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K) return VOGE_ERR_K_TOO_LARGE;
   if ((size_t)B * H * W == 0) return 0;  // numel == 0 early return (ray_trace_voge.cu:248-251)
-  if (!rays || !idx || !len || !act || !dsd || !workspace) return VOGE_ERR_BAD_ARG;
+  if (!rays || !idx || !len || !workspace || (act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;
+  // act / dsd may be omitted by the scalar-sigma fragment entry points only (they are re-derived where needed)
+  if (act == nullptr && !(iso_in && weight != nullptr && cnt != nullptr && (K & 1) == 0)) return VOGE_ERR_BAD_ARG;
   if (N > 0 && (!mus || !isigmas)) return VOGE_ERR_BAD_ARG;
   if (workspace_bytes < voge_trace_workspace_bytes(B, N, H, W)) return VOGE_ERR_WORKSPACE;
   // the top-K lists of one 8x8 tile must fit the CU's LDS: validated before anything is enqueued
@@ -1163,6 +1195,9 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
 #endif
   rc = launch_trace<false>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, fused ? weight : nullptr, fused ? valid_num : nullptr, st);
   if (rc || weight == nullptr || fused) return rc;
+  if (act == nullptr)
+    return voge_composite_fwd_iso(idx, cnt, len, reinterpret_cast<const float *>(ws.ms), rays, occ, (long)B * H * W, K, weight,
+                                  valid_num, stream);
   return voge_composite_fwd(idx, cnt, act, len, dsd, occ, (long)B * H * W, K, weight, valid_num, stream);
 }
 

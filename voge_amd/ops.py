@@ -4,6 +4,8 @@ torch is used here for device memory, streams and autograd bookkeeping only; eve
 computation on the path is a HIP kernel in libvoge_hip.so.  Ownership follows SURVEY.md §8b:
 the caller (these Functions) allocates every output; the library never allocates.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -370,7 +372,12 @@ class _Fragments(torch.autograd.Function):
             N = p0_c.shape[0] // B
         sel_idx = torch.empty((B, H, W, K), dtype=torch.int32, device=dev)
         sel_len = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
-        sel_act, sel_dsd, weight = torch.empty_like(sel_len), torch.empty_like(sel_len), torch.empty_like(sel_len)
+        weight = torch.empty_like(sel_len)
+        # scalar sigmas, K even: act / dsd are not materialised at all -- every consumer re-derives them from the records
+        # (composite forward, fused backward) or asks for them once (_act_dsd: the three-kernel backward)
+        lean = mode != 0 and K % 2 == 0 and os.environ.get("VOGE_FRAGMENTS_KEEP_ACT_DSD", "0") != "1"
+        sel_act = None if lean else torch.empty_like(sel_len)
+        sel_dsd = None if lean else torch.empty_like(sel_len)
         cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
         valid = torch.empty((B, H, W), dtype=torch.int64, device=dev)
         # scalar forms: the per-Gaussian (centred mean, a) records outlive the call -- the fused backward reads them
@@ -390,7 +397,7 @@ class _Fragments(torch.autograd.Function):
             else:
                 rc = lib.voge_fragments_fwd(_p(p0_c), _p(p1_c), _p(rays_c), _p(fwd), cones, *tail, _stream())
         _lib.check(rc, "voge_fragments_fwd")
-        ctx.save_for_backward(p0_c, p1_c, rays_c, sel_act, sel_len, sel_dsd, weight)
+        ctx.save_for_backward(p0_c, p1_c, rays_c, sel_len, weight)
         ctx.origin, ctx.sel_idx, ctx.cnt = o_c, sel_idx, cnt
         ctx.meta = (int(mode), int(sigma_mode), bool(shared), float(occ), B, N)
         _tag_index(sel_idx, cnt, B * N)
@@ -400,17 +407,19 @@ class _Fragments(torch.autograd.Function):
         ctx.through = dict(mode=int(mode), sigma_mode=int(sigma_mode), shared=bool(shared), occ=float(occ), B=B, N=N,
                            records=records, rays=rays_c, act=sel_act, dsd=sel_dsd, len=sel_len, cnt=cnt, idx=sel_idx,
                            sigmas=p1_c, means=p0_c)
+        ctx.th = ctx.through
         _Fragments._last_through = ctx.through
         return weight, sel_idx, valid, sel_len
 
     @staticmethod
     def backward(ctx, g_weight, _g_idx, _g_valid, g_hitlen):
         lib = _lib.load()
-        p0, p1, rays, act, ln, dsd, weight = ctx.saved_tensors
+        p0, p1, rays, ln, weight = ctx.saved_tensors
         mode, sigma_mode, shared, occ, B, N = ctx.meta
         if g_weight is None and g_hitlen is None:      # nothing reached the fragments (e.g. _ShadeThrough took the frame)
             return (None,) * 10
         sel_idx, cnt = ctx.sel_idx, ctx.cnt
+        act, dsd = _act_dsd(ctx.th)
         _, H, W, K = sel_idx.shape
         npix = B * H * W
         dev = rays.device
@@ -448,6 +457,22 @@ class _Fragments(torch.autograd.Function):
                                         B * H, W, K, _p(ws), nbytes, _p(g_ray), _p(g0), _p(g1), _stream())
         _lib.check(rc, "voge_trace_bwd")
         return None, g0, g1, None, g_ray, None, None, None, None, None
+
+
+def _act_dsd(th):
+    """act / dsd of a fragments() call: what it kept, or (scalar sigmas) derived now from its records -- once; the
+    arrays then stay with the call's bookkeeping."""
+    if th["act"] is None:
+        lib = _lib.load()
+        ln, idx = th["len"], th["idx"]
+        act, dsd = torch.empty_like(ln), torch.empty_like(ln)
+        K = idx.shape[-1]
+        with _on(ln.device):
+            rc = lib.voge_fragment_act_dsd_iso(_p(th["records"]), _p(th["rays"]), _p(idx), _p(ln), _p(th["cnt"]), idx.numel() // K, K,
+                                               th["B"] * th["N"], _p(act), _p(dsd), _stream())
+        _lib.check(rc, "voge_fragment_act_dsd_iso")
+        th["act"], th["dsd"] = act, dsd
+    return th["act"], th["dsd"]
 
 
 def fragments(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode=0, occ=1.0):
