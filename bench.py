@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--default-bins", action="store_true", help="max_point_per_bin=None (the demos' default) instead of -1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the anisotropic / default-bins variant frames")
+    ap.add_argument("--only-stage", default=None,
+                    help="profiling aid: launch nothing but this stage's entry point (no frame), e.g. trace_fwd for the PMC passes; "
+                         "'frame': the frame's steps alone")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--split-graph", action="store_true",
                     help="single GPU: use the multi-GPU launch scheme (forward graph / eager exchange / backward graph)")
@@ -190,7 +193,9 @@ def main():
         return dt
 
     fwd, params, gm, colors, host_scene = make_frame(args.anisotropic, args.default_bins)
-    if world == 1 and not args.split_graph:
+    if args.only_stage and args.only_stage != "frame":      # ("frame": the frame alone, no stand-alone stage calls)
+        run, launch = (lambda: None), "none (--only-stage)"
+    elif world == 1 and not args.split_graph:
         run, launch = graphed_step(fwd, params)
     else:
         # Multi-GPU: the local compute is two HIP graphs -- band forward, band backward -- and the two exchanges
@@ -373,6 +378,8 @@ def main():
             nbytes = stage_bytes(N, npix, K, iso=iso)
             stages = {}
             for name, (mk, call) in stage_defs.items():
+                if args.only_stage and name != args.only_stage:
+                    continue
                 t_ms, nset = rotating(mk, call, nbytes[name])
                 one = mk()
                 t_same, _ = rotating(lambda one=one: one, call, 1 << 40)      # the same call replayed on ONE buffer set
@@ -383,6 +390,9 @@ def main():
             hits = int((sel[0] >= 0).sum().item())
             del stage_defs
             torch.cuda.empty_cache()
+        if args.only_stage:
+            print(json.dumps({"only_stage": args.only_stage, "stages": stages}))
+            return
         dom = "trace_fwd"  # the sweep BASELINE.json's metric names
         a = stages[dom]["GBps"]
         traffic, traffic_src = None, None

@@ -8,10 +8,16 @@ cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
 for CFG in cfg3_50k_512 cfg4_200k_1024; do
+  # pass 1: nothing but the stand-alone trace entry point (the roofline's kernel chain, act / dsd included);
+  # pass 2: the frame as bench.py launches it (scalar sigmas: fragments without act / dsd, fused backward)
   B="python3 bench.py --no-graph --no-cpu-baseline --no-variants --steps 10 --warmup 3 --config $CFG"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > /dev/null 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --only-stage trace_fwd > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B --only-stage trace_fwd > /dev/null 2>&1
   python tools/traffic_json.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_traffic.json $CFG
+  rm -rf $OUT/pmc_fetch $OUT/pmc_write
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --only-stage frame > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B --only-stage frame > /dev/null 2>&1
+  python tools/traffic_json.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_traffic.json $CFG frame
   if [ $CFG = cfg3_50k_512 ]; then python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/${TAG}_pmc_fetch_write_size.txt 2>/dev/null; fi
   rm -rf $OUT/pmc_fetch $OUT/pmc_write
 done

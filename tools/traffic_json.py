@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/<tag>_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
 as MI355X_MICROARCH.md's HBM section prescribes).
-usage: traffic_json.py <fetch_dir> <write_dir> <out.json> <config name>   (entries of other configs in out.json are kept)
+usage: traffic_json.py <fetch_dir> <write_dir> <out.json> <config name> [frame]   (other entries of out.json are kept;
+"frame": the passes ran the whole bench frame -> stored as <config>["frame_kernels"], the trace entry's total untouched)
 Units: counters are KiB; FETCH_SIZE x2 on gfx950 for wide coalesced reads (same guide); per launch averages."""
 import csv
 import glob
@@ -25,7 +26,7 @@ def collect(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-def main(fetch_dir, write_dir, out, config):
+def main(fetch_dir, write_dir, out, config, what="trace"):
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fe) | set(wr)):
@@ -35,10 +36,15 @@ def main(fetch_dir, write_dir, out, config):
     doc = json.load(open(out)) if os.path.exists(out) else {}
     doc["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --no-graph. Units KiB per launch; "
                    "hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of MI355X_MICROARCH.md's HBM section).")
-    doc[config] = {"kernels": kernels, "voge_trace_topk_fwd_kernels": list(TRACE_FWD), "voge_trace_topk_fwd_bytes": total}
+    if what == "frame":
+        doc.setdefault(config, {})["frame_kernels"] = kernels
+        doc[config]["frame_hbm_bytes"] = sum(v["hbm_bytes"] for v in kernels.values())
+        print(config, "frame_hbm_bytes", doc[config]["frame_hbm_bytes"])
+    else:
+        doc[config] = {"kernels": kernels, "voge_trace_topk_fwd_kernels": list(TRACE_FWD), "voge_trace_topk_fwd_bytes": total}
+        print(config, "voge_trace_topk_fwd_bytes", total)
     json.dump(doc, open(out, "w"), indent=1)
-    print(config, "voge_trace_topk_fwd_bytes", total)
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
