@@ -922,3 +922,41 @@ def test_fused_fragment_backward_reads_a_broadcast_gradient_in_place(hip_lib):
         scale = max(1e-6, float(np.abs(y).max()))
         assert np.abs(x - y).max() <= 2e-5 * scale, (name, float(np.abs(x - y).max()), scale)
     assert np.abs(out[1][0]).max() > 0
+
+
+def test_fragments_without_act_dsd_equal_the_kept_form(hip_lib, monkeypatch):
+    """Scalar-sigma fragments keep no act / dsd by default (voge_fragments_fwd_iso* with NULL for both; composite and
+    fused backward derive them from the records).  Against VOGE_FRAGMENTS_KEEP_ACT_DSD=1 (the reference's layout):
+    identical fragments bit for bit, act / dsd materialised on request (voge_fragment_act_dsd_iso) identical to the kept
+    arrays wherever a slot is live, gradients of both backward routes within tolerance."""
+    from voge_amd import ops
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, get_silhouette, to_white_background
+    from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
+    N, H, W, K = 3000, 72, 88, 24
+    verts, sig, cols = random_scene(N, seed=91, lo=0.04, hi=0.1)
+    R, T = look_at_view_transform(dist=[3.0, 3.3], elev=[10.0, -15.0], azim=[30.0, 160.0], device=DEV)
+    cams = PerspectiveCameras(focal_length=95.0, principal_point=((W / 2.0, H / 2.0),), image_size=((H, W),), device=DEV)
+    renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=(H, W), max_assign=K, max_point_per_bin=-1)).to(DEV)
+    gen = torch.Generator(DEV).manual_seed(3)
+    g_sil = torch.randn(2, H, W, device=DEV, generator=gen)
+    out = {}
+    for keep in ("1", "0"):
+        monkeypatch.setenv("VOGE_FRAGMENTS_KEEP_ACT_DSD", keep)
+        gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(DEV)
+        colors = t(np.tile(cols, (2, 1)), rg=True)
+        frag = renderer(gm, R=R, T=T)
+        th = frag.vert_weight.voge_through
+        assert (th["act"] is None) == (keep == "0")
+        img = to_white_background(frag, colors)
+        # the image through the fused backward, the silhouette through _Fragments.backward (which asks for act / dsd)
+        (img.sum() + (get_silhouette(frag) * g_sil).sum()).backward()
+        act, dsd = ops._act_dsd(th)
+        out[keep] = [n(x) for x in (frag.vert_weight, frag.vert_index, frag.vert_hit_length, frag.valid_num, img, act, dsd,
+                                    gm.verts.grad, gm.sigmas.grad, colors.grad)]
+    for a, b in zip(out["1"][:5], out["0"][:5]):
+        assert np.array_equal(a, b)
+    live = np.arange(K)[None, None, None, :] < out["1"][3][..., None]
+    assert live.any() and np.array_equal(out["1"][5][live], out["0"][5][live]) and np.array_equal(out["1"][6][live], out["0"][6][live])
+    for name, a, b in zip(("verts", "sigmas", "colors"), out["1"][7:], out["0"][7:]):
+        grad_close("lean vs kept act/dsd, " + name, b, a, TOL)
