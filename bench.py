@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--default-bins", action="store_true", help="max_point_per_bin=None (the demos' default) instead of -1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the anisotropic / default-bins variant frames")
+    ap.add_argument("--balance-rounds", type=int, default=4,
+                    help="multi-GPU: measure -> rebalance rounds of the row bands before the timed region (0: equal-height bands)")
     ap.add_argument("--only-stage", default=None,
                     help="profiling aid: launch nothing but this stage's entry point (no frame), e.g. trace_fwd for the PMC passes; "
                          "'frame': the frame's steps alone")
@@ -115,13 +117,15 @@ def main():
     from voge_amd.Meshes import GaussianMeshes
     from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
     from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
-    from voge_amd.distributed import FlatGrads, gather_rows, gather_rows_async, row_band
+    from voge_amd.distributed import FlatGrads, gather_rows, gather_rows_async, rebalance_bounds, row_band
     _lib.load()
 
     N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[args.config]
     R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
     cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), device=dev)
-    rows = row_band(H, rank, world) if world > 1 else None
+    # row bands of the ranks: band r = rows [bounds[r], bounds[r + 1]); equal heights to start with
+    bands = {"bounds": [row_band(H, r, world)[0] for r in range(world)] + [H]} if world > 1 else None
+    rows = (bands["bounds"][rank], bands["bounds"][rank + 1]) if world > 1 else None
 
     def make_frame(anisotropic, default_bins):
         """(step function, parameters) of one forward+backward frame of the config."""
@@ -132,9 +136,9 @@ def main():
                                           max_point_per_bin=None if default_bins else -1)
         renderer = GaussianRenderer(cams, settings).to(dev)
         params = [gm.verts, gm.sigmas, colors]
-        kw = {} if rows is None else {"rows": rows}
 
         def fwd():
+            kw = {} if bands is None else {"rows": (bands["bounds"][rank], bands["bounds"][rank + 1])}
             return to_white_background(renderer(gm, R=R, T=T, **kw), colors)
         return fwd, params, gm, colors, (verts, sig, cols)
 
@@ -193,6 +197,7 @@ def main():
         return dt
 
     fwd, params, gm, colors, host_scene = make_frame(args.anisotropic, args.default_bins)
+    balance_log = []
     if args.only_stage and args.only_stage != "frame":      # ("frame": the frame alone, no stand-alone stage calls)
         run, launch = (lambda: None), "none (--only-stage)"
     elif world == 1 and not args.split_graph:
@@ -209,6 +214,37 @@ def main():
             flat.zero()
             b = fwd()
             torch.autograd.backward(b, torch.ones_like(b))
+        # Measured load balancing (stationary scene): every rank times its band's local compute, the times are exchanged
+        # once per round and every rank moves the boundaries the same way (distributed.rebalance_bounds).  Setup, untimed.
+        if world > 1 and bands is not None and args.balance_rounds > 0:
+            fixed = None
+            side = torch.cuda.Stream()      # (like every eager run in front of a capture: never on the default stream)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for it in range(args.balance_rounds + 1):
+                    for _w in range(3):
+                        eager_once()
+                    side.synchronize()
+                    t0 = time.perf_counter()
+                    for _w in range(8):
+                        eager_once()
+                    side.synchronize()
+                    mine = (time.perf_counter() - t0) / 8 * 1e6
+                    times = [None] * world
+                    dist.all_gather_object(times, float(mine))
+                    balance_log.append({"bounds": list(bands["bounds"]), "band_us": [round(t) for t in times]})
+                    if it == args.balance_rounds:
+                        break
+                    if fixed is None:
+                        fixed = 0.5 * min(times)      # what a nearly empty band still costs: latency, not work
+                    bands["bounds"] = rebalance_bounds(bands["bounds"], times, fixed=fixed, damping=0.8, min_rows=8)
+            # the best partition actually measured (the equal-height start included): noise cannot make things worse
+            best = min(balance_log, key=lambda e: max(e["band_us"]))
+            bands["bounds"] = list(best["bounds"])
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            rows = (bands["bounds"][rank], bands["bounds"][rank + 1])
+        gb = None if bands is None else bands["bounds"]
         run, launch = None, "eager"
         if not args.no_graph:
             try:
@@ -224,7 +260,7 @@ def main():
 
                 def run_split():
                     g_fwd.replay()
-                    finish = gather_rows_async(band_static.detach(), H)   # all_gather starts (no-op on one GPU) ...
+                    finish = gather_rows_async(band_static.detach(), H, bounds=gb)   # all_gather starts (no-op on one GPU) ...
                     g_bwd.replay()                                          # ... and overlaps the band's backward
                     flat.allreduce()                                        # one eager all_reduce, in place
                     return finish().sum()                                   # the full-image loss every rank holds
@@ -239,7 +275,7 @@ def main():
             def run():
                 flat.zero()
                 band = fwd()
-                img = gather_rows(band, H)
+                img = gather_rows(band, H, bounds=gb)
                 r0, r1 = rows if rows is not None else (0, H)
                 img[:, r0:r1].sum().backward()      # each rank owns the loss of its band; grads are summed below
                 flat.allreduce()
@@ -269,6 +305,9 @@ def main():
                    "parallelism": "1 gpu" if world == 1 else f"pixel-row bands x{world}, all_gather(image)+all_reduce(grads)"},
     }
 
+    if world > 1:
+        result["config"]["bands"] = list(bands["bounds"])      # rows [b[r], b[r+1]) of rank r, after the measured balancing
+        result["band_balance"] = balance_log                      # (setup, untimed) what every round measured
     lib = _lib.load()
     P_ = lambda x: None if x is None else x.data_ptr()
     thr_act = -np.log(0.01 + 1e-10)

@@ -101,3 +101,21 @@ def test_balanced_row_bounds():
     pw = projected_row_weight(verts, R, T, 20.0, 16.0, 32, smooth=1)
     assert pw.shape == (32,) and float(pw.sum()) == 3.0
     assert pw[10] == 1 and pw[15] == 1 and pw[20] == 1     # row = py - fy*Y/Z - 0.5
+
+
+def test_measured_rebalancing_converges():
+    """distributed.rebalance_bounds: boundaries follow MEASURED band times.  Simulated frame: a per-row cost profile (a
+    dense centre, empty borders) plus a fixed cost per band; a few measure -> rebalance rounds level the bands."""
+    import numpy as np
+    from voge_amd.distributed import rebalance_bounds, row_band
+    H, n, fixed = 512, 8, 90.0
+    y = np.arange(H)
+    row_cost = 0.05 + 2.4 * np.exp(-((y - 270) / 130.0) ** 2)          # us per row
+    measure = lambda b: [fixed + row_cost[b[r]:b[r + 1]].sum() for r in range(n)]
+    bounds = [row_band(H, r, n)[0] for r in range(n)] + [H]
+    t0 = measure(bounds)
+    for _ in range(5):
+        bounds = rebalance_bounds(bounds, measure(bounds), fixed=0.5 * min(t0), damping=0.8, min_rows=8)
+        assert bounds[0] == 0 and bounds[-1] == H and all(b1 - b0 >= 8 for b0, b1 in zip(bounds, bounds[1:]))
+    t = measure(bounds)
+    assert max(t) < 0.9 * max(t0) and max(t) / (sum(t) / n) < 1.05

@@ -42,6 +42,33 @@ def balanced_row_bounds(row_weight, world, floor=0.1):
     return bounds
 
 
+def rebalance_bounds(bounds, times, fixed=0.0, damping=1.0, min_rows=1):
+    """Band boundaries that equalise MEASURED cost: `times[r]` is what band r = rows [bounds[r], bounds[r+1]) just took
+    (any unit), `fixed` the part of it that does not shrink with the band (launch chain, per-Gaussian passes).  The rest
+    is spread evenly over the band's rows, the boundaries move to the equal-cost quantiles of that profile (times
+    `damping`), every band keeps at least `min_rows` rows.  Deterministic in its inputs: every rank computes the same
+    partition from the same all-gathered times, no further exchange.  A few measure -> rebalance rounds converge (the
+    per-row cost inside a band is not uniform, so one round is not exact)."""
+    n = len(times)
+    assert len(bounds) == n + 1 and n >= 1
+    H = int(bounds[-1])
+    cost = torch.zeros(H, dtype=torch.float64)
+    for r in range(n):
+        r0, r1 = int(bounds[r]), int(bounds[r + 1])
+        cost[r0:r1] = max(float(times[r]) - float(fixed), 1e-9) / max(r1 - r0, 1)
+    c = torch.cumsum(cost, 0)
+    total = float(c[-1])
+    out = [0]
+    for r in range(1, n):
+        tgt = int(torch.searchsorted(c, torch.tensor(total * r / n, dtype=torch.float64)).item()) + 1
+        b = int(round(bounds[r] + damping * (tgt - bounds[r])))
+        b = max(b, out[-1] + min_rows)
+        b = min(b, H - (n - r) * min_rows)
+        out.append(b)
+    out.append(H)
+    return out
+
+
 def projected_row_weight(verts, R, T, focal_y, principal_y, H, smooth=33):
     """Per-row work estimate of a frame: how many Gaussian centres project near each pixel row
     (row i looks along (py - i - 0.5)/fy, the build's ray convention), box-smoothed
