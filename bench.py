@@ -283,9 +283,14 @@ def main():
 
     # settle (untimed, before the contract's W warmup steps): a fresh box ramps its clocks and pools over the first
     # tenths of a second of load; K steps of a 0.4 ms frame would otherwise be timed on the ramp
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 0.3:
-        for _ in range(20):
+    if world == 1:
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < 0.3:
+            for _ in range(20):
+                run()
+            torch.cuda.synchronize()
+    else:                                  # (collectives inside: every rank must run the SAME number of steps)
+        for _ in range(300):
             run()
         torch.cuda.synchronize()
     dt = timed(run, args.steps, args.warmup)
