@@ -114,7 +114,8 @@ class GaussianRenderer(nn.Module):
 
         verts, sigmas, _radians = gmeshes()
         shared_verts = verts.dim() == 2
-        if shared_verts:
+        verts2d = verts                      # (the [N,3] parameter itself: indexing it back out of verts[None] would put a
+        if shared_verts:                     #  select + zero-fill + copy into every backward)
             verts = verts[None]
 
         rays, origin = pixel_rays(cams, image_size, rows=kwargs.get('rows'))     # [B,h,W,3], [B,3]
@@ -141,7 +142,7 @@ class GaussianRenderer(nn.Module):
             # Renderer.py:130 and the 2*sigma / 2/sigma of :133-137 happen inside the trace's per-Gaussian
             # pass (and their chain rule inside its backward's) -- same values, no elementwise launches.
             cam_fwd = _view_axis(cams, origin[:, None]) if behind else None
-            weight, index, valid_num, hit_len = ops.fragments(2, verts[0], sigmas, origin, rays, cam_fwd, thr_act, K,
+            weight, index, valid_num, hit_len = ops.fragments(2, verts2d, sigmas, origin, rays, cam_fwd, thr_act, K,
                                                               2 if st['inverse_sigma'] else 1, occ)
             return Fragments(vert_weight=weight, vert_index=index, valid_num=valid_num, vert_hit_length=hit_len)
         centred = verts - origin[:, None]                                         # Renderer.py:130
