@@ -375,7 +375,8 @@ class _Fragments(torch.autograd.Function):
         weight = torch.empty_like(sel_len)
         # scalar sigmas, K even: act / dsd are not materialised at all -- every consumer re-derives them from the records
         # (composite forward, fused backward) or asks for them once (_act_dsd: the three-kernel backward)
-        lean = mode != 0 and K % 2 == 0 and os.environ.get("VOGE_FRAGMENTS_KEEP_ACT_DSD", "0") != "1"
+        lean = (mode != 0 and K % 2 == 0 and B * N < (1 << 26)      # (32-bit byte offsets of the record gathers)
+                and os.environ.get("VOGE_FRAGMENTS_KEEP_ACT_DSD", "0") != "1")
         sel_act = None if lean else torch.empty_like(sel_len)
         sel_dsd = None if lean else torch.empty_like(sel_len)
         cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
@@ -569,6 +570,8 @@ def shade_through(attr, fragments_weight, idx, valid_num, bg, thr):
     if fragments_weight._version != th["weight_version"] or fragments_weight.retains_grad or fragments_weight._backward_hooks:
         return None
     if th["len"]._version != 0 or th["rays"].requires_grad:
+        return None
+    if th["B"] * th["N"] >= (1 << 26) or attr.numel() >= (1 << 30):      # 32-bit byte offsets of the kernel's gathers
         return None
     return _ShadeThrough.apply(attr, fragments_weight, th["p0"], th["p1"], th, idx, valid_num, bg, thr)
 
