@@ -960,3 +960,36 @@ def test_fragments_without_act_dsd_equal_the_kept_form(hip_lib, monkeypatch):
     assert live.any() and np.array_equal(out["1"][5][live], out["0"][5][live]) and np.array_equal(out["1"][6][live], out["0"][6][live])
     for name, a, b in zip(("verts", "sigmas", "colors"), out["1"][7:], out["0"][7:]):
         grad_close("lean vs kept act/dsd, " + name, b, a, TOL)
+
+
+@pytest.mark.parametrize("N,H,W,K,B,aniso,fused", [
+    (0, 16, 16, 8, 1, False, True), (1, 1, 1, 1, 1, False, False), (5, 3, 7, 3, 1, False, False),
+    (300, 33, 47, 7, 1, False, False), (300, 33, 47, 8, 2, False, True), (300, 20, 20, 130, 1, False, False),
+    (300, 20, 20, 128, 1, False, True), (200, 17, 9, 6, 1, True, True), (0, 8, 8, 4, 1, True, True),
+    (3000, 64, 64, 256, 1, False, False)])
+def test_renderer_edge_shapes(hip_lib, N, H, W, K, B, aniso, fused):
+    """Shapes at the edges of every fast path of the renderer (no Gaussians at all, a 1x1 image, odd K, K beyond the
+    fused backward's 128, K at the library's 256, batches, full 3x3 forms): the frame runs forward and backward, every
+    output is finite, an empty scene renders the background, and the fused backward is taken exactly where it applies
+    (K even and <= 128)."""
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, get_silhouette, to_white_background
+    from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
+    g = torch.Generator().manual_seed(1)
+    verts = torch.rand(N, 3, generator=g) * 2 - 1
+    sig = torch.full((N,), 800.0) if not aniso else torch.eye(3)[None].repeat(N, 1, 1) * 800.0
+    gm = GaussianMeshes(verts, sig).to(DEV)
+    colors = torch.rand(N * B, 3, generator=g).to(DEV).requires_grad_(True)
+    R, T = look_at_view_transform(dist=[3.0] * B, elev=[10.0] * B, azim=[30.0 + 20 * b for b in range(B)], device=DEV)
+    cams = PerspectiveCameras(focal_length=float(max(H, W)), principal_point=((W / 2.0, H / 2.0),), image_size=((H, W),), device=DEV)
+    renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=(H, W), max_assign=K, max_point_per_bin=-1)).to(DEV)
+    frag = renderer(gm, R=R, T=T)
+    img = to_white_background(frag, colors)
+    assert (type(img.grad_fn).__name__ == "_ShadeThroughBackward") == fused
+    (img.sum() + get_silhouette(frag).sum()).backward()
+    torch.cuda.synchronize()
+    assert img.shape == (B, H, W, 3) and torch.isfinite(img).all() and torch.isfinite(colors.grad).all()
+    if N:
+        assert torch.isfinite(gm.verts.grad).all() and torch.isfinite(gm.sigmas.grad).all()
+    else:
+        assert (img == 1).all() and (frag.valid_num == 0).all()

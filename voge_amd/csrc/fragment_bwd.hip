@@ -376,7 +376,7 @@ extern "C" int voge_fragment_act_dsd_iso(const float *records, const float *rays
                                          voge_stream_t stream) {
   if (npix < 0 || K <= 0 || P < 0) return VOGE_ERR_BAD_ARG;
   if (npix == 0) return 0;
-  if (!records || !rays || !idx || !len || !cnt || !act || !dsd) return VOGE_ERR_BAD_ARG;
+  if ((!records && P > 0) || !rays || !idx || !len || !cnt || !act || !dsd) return VOGE_ERR_BAD_ARG;
   const long n = npix * K;
   hipLaunchKernelGGL(fragment_act_dsd_iso_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float4 *>(records), rays, idx, len, cnt, npix, K, P, act, dsd);

@@ -492,7 +492,8 @@ extern "C" int voge_shade_fwd(const float *attr, int32_t *idx, const float *weig
   if (npix < 0 || K <= 0 || C < 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
   if (npix == 0) return 0;
   if (!weight) return VOGE_ERR_BAD_ARG;
-  if (C > 0 && (!attr || !idx || !valid_num)) return VOGE_ERR_BAD_ARG;
+  if (C > 0 && ((!attr && Nattr > 0) || !idx || !valid_num)) return VOGE_ERR_BAD_ARG;
+  if (C > 0 && Nattr == 0 && !attr) attr = weight;      // an empty attribute table: never gathered from, but "not NULL" means "merge"
   if (out_img && !bg) return VOGE_ERR_BAD_ARG;
   const bool aligned = ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(weight)) & 15) == 0;
   if (C > 0 && (K & 3) == 0 && K <= 64 && aligned) {
