@@ -228,7 +228,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
                                                float *Lu, const int d0, const int k0, const int K, const int q, const int LP,
                                                const int LPmax, const bool in_wg, const bool active, const bool sorted,
                                                const int seg_lo, const float occ, float (&ga)[NS], float (&gl)[NS],
-                                               float (&gd)[NS]) {
+                                               float (&gd)[NS], unsigned *Lcell = nullptr) {
   constexpr int NP = NS / 2;
   const int lane = threadIdx.x & 63;
   float sp[NS], Es[NS];
@@ -237,12 +237,24 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
   float mx = 0.0f;
 #pragma unroll
   for (int a = 0; a < NS; ++a) mx = fmaxf(mx, (em[a] != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm[a]) : 0.0f);
+  float wave_rmax;
+  if (Lcell != nullptr) {
+    // the pixel's window radius through ONE LDS cell (the pixel's own; radii are >= 0, so their bit patterns order
+    // like unsigned integers): zero, max, read -- three LDS operations in the wave's in-order LDS queue instead of a
+    // chain of seven dependent cross-lane shuffles
+    if (in_wg && q == 0) *Lcell = 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (in_wg && mx > 0.0f) atomicMax(Lcell, __float_as_uint(mx));
+    __builtin_amdgcn_wave_barrier();
+    wave_rmax = in_wg ? __uint_as_float(*reinterpret_cast<volatile unsigned *>(Lcell)) : 0.0f;
+  } else {
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float y = __shfl_down(mx, o, 64);
-    if (lane + o < 64 && q + o < LP) mx = fmaxf(mx, y);
+    for (int o = 1; o < 64; o <<= 1) {
+      const float y = __shfl_down(mx, o, 64);
+      if (lane + o < 64 && q + o < LP) mx = fmaxf(mx, y);
+    }
+    wave_rmax = __shfl(mx, seg_lo, 64);                // the pixel's first lane holds the maximum
   }
-  const float wave_rmax = __shfl(mx, seg_lo, 64);                // the pixel's first lane holds the maximum
   const float rwin = sorted ? (in_wg ? wave_rmax : 0.0f) : 0.0f;
   bool any_e = false;
 #pragma unroll

@@ -45,10 +45,14 @@ struct FragBwdLds {
   //                               (g_mu, g_A[0]), g_A[1..4], g_A[5..8], (w g_rgb, -) for a full 3x3 A [NV4 = 4]
   WaveTable<kFbNE, NV4> tab;
   float len[kFbRowsLds], sp[kFbRowsLds], E[kFbRowsLds], u[kFbRowsLds];
+  unsigned rmax[kFbG];            // per pixel of the round: its window radius (compn_bwd_wave)
 };
 
 #ifndef VOGE_FB_ABL
 #define VOGE_FB_ABL 0
+#endif
+#ifndef VOGE_FB_LDS_RMAX
+#define VOGE_FB_LDS_RMAX 1
 #endif
 #ifndef VOGE_FB_WPE
 #define VOGE_FB_WPE 4      // capping the registers for 5 / 6 waves per SIMD spills and is slower
@@ -200,7 +204,8 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
 #if VOGE_FB_ABL & 2       // (timing experiment: no composite)
     for (int a = 0; a < NS; ++a) { ga[a] = um[a]; gl[a] = um[a] * sm[a]; gd[a] = um[a] * em[a]; }
 #else
-    compn_bwd_wave<NS>(lm, sm, em, um, Llen, Lsp, LE, Lu, d0, k0, NS * LP, q, LP, npm, on, on, true, pk.s0, occ, ga, gl, gd);
+    compn_bwd_wave<NS>(lm, sm, em, um, Llen, Lsp, LE, Lu, d0, k0, NS * LP, q, LP, npm, on, on, true, pk.s0, occ, ga, gl, gd,
+                       VOGE_FB_LDS_RMAX ? &L.rmax[on ? pk.ord : 0] : nullptr);
 #endif
     __builtin_amdgcn_wave_barrier();      // the rows are rewritten by the next round
     // ---- trace backward terms (isotropic: trace_bwd.hip) + the colour term, one table entry per Gaussian.  (The
