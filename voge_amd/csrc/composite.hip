@@ -47,7 +47,8 @@ __host__ __device__ inline size_t comp_lds_bytes(const int K, const bool bwd) {
 
 // (the wave form keeps no per-workgroup state: no CompLds block in front of the arrays)
 __host__ __device__ inline size_t compn_lds_bytes(const int K, const int NS, const bool bwd, const int threads, const bool wave) {
-  return (wave ? 0 : sizeof(CompLds)) + sizeof(float) * (size_t)compn_rows(K, NS, threads, wave) * (bwd ? 4 : 3);
+  // (+ one cell per pixel of a wave: the window radius, composite_core.h)
+  return (wave ? 0 : sizeof(CompLds)) + sizeof(float) * (size_t)compn_rows(K, NS, threads, wave) * (bwd ? 4 : 3) + (wave ? 64 * sizeof(unsigned) : 0);
 }
 
 
@@ -334,6 +335,9 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
 #ifndef VOGE_COMP_WPE
 #define VOGE_COMP_WPE 1
 #endif
+#ifndef VOGE_COMP_LDS_RMAX
+#define VOGE_COMP_LDS_RMAX 1
+#endif
 // WAVE: every pixel's lanes sit inside ONE wave (64 / LP pixels per wave, the remaining lanes idle), so the
 // per-pixel scans, flags and reductions are wave shuffles / ballots and the kernel has no workgroup barrier at
 // all: each wave runs from its loads to its stores on its own.  (Needs LP <= 64.)
@@ -539,7 +543,9 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   if (!BWD && WAVE) {
     // forward, wave form: the row pass shared with the sweep's fused epilogue (composite_core.h)
     float w[NS];
-    compn_fwd_rows<NS>(lm, sm, em, Llen, Lsp, LE, d0, k0, K, q, LP, LP, in_wg, active, active && !wave_unsorted, seg_lo, occ, w);
+    unsigned *const Lcells = reinterpret_cast<unsigned *>(LE + rows);      // (forward: three row arrays, then the cells)
+    compn_fwd_rows<NS>(lm, sm, em, Llen, Lsp, LE, d0, k0, K, q, LP, LP, in_wg, active, active && !wave_unsorted, seg_lo, occ, w,
+                       (VOGE_COMP_LDS_RMAX && blockDim.x == 64) ? Lcells + (in_wg ? p : 0) : nullptr);      // (one-wave workgroups)
     if (active) {
       if (vec && NS == 4) at_bytes_w<float4>(out0, fb) = make_float4(w[0], w[1], w[NS - 2], w[NS - 1]);
       else if (vec) at_bytes_w<v2f>(out0, fb) = (v2f){w[0], w[1]};

@@ -122,7 +122,7 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
                                                const float *Llen, const float *Lsp, const float *LE, const int d0,
                                                const int k0, const int K, const int q, const int LP, const int LPmax,
                                                const bool in_wg, const bool active, const bool sorted, const int seg_lo,
-                                               const float occ, float (&w)[NS]) {
+                                               const float occ, float (&w)[NS], unsigned *Lcell = nullptr) {
   float sp[NS];
 #pragma unroll
   for (int a = 0; a < NS; ++a) sp[a] = sm[a] * kCs;
@@ -135,7 +135,21 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
   // Exclusive prefix (over the lanes of the pixel) of the per-lane sums of E, Hillis-Steele on wave shuffles with the
   // window radius riding along
   float ex, wave_rmax;
-  {
+  if (Lcell != nullptr) {
+    // the window radius through the pixel's LDS cell (compn_bwd_wave), the prefix sum alone through the shuffles
+    if (in_wg && q == 0) *Lcell = 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (in_wg && mx > 0.0f) atomicMax(Lcell, __float_as_uint(mx));
+    const float y = __shfl_up(esum, 1, 64);
+    float x = (q > 0 && in_wg) ? y : 0.0f;
+    for (int o = 1; o < LPmax; o <<= 1) {
+      const float z = __shfl_up(x, o, 64);
+      if (q >= o && in_wg) x += z;
+    }
+    ex = x;
+    __builtin_amdgcn_wave_barrier();
+    wave_rmax = in_wg ? __uint_as_float(*reinterpret_cast<volatile unsigned *>(Lcell)) : 0.0f;
+  } else {
     v2f x = {esum, mx};
     const v2f y = (v2f){__shfl_up(x.x, 1, 64), __shfl_up(x.y, 1, 64)};
     x = (q > 0 && in_wg) ? (v2f){y.x, fmaxf(mx, y.y)} : (v2f){0.0f, mx};
