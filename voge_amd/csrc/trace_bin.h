@@ -163,8 +163,8 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
     if (cx < nstx && cy < nsty) r = cones[(size_t)b * nst + cy * nstx + cx];
     if (lane < kCh * kCh) L.child[lane] = r;
     const bool present = lane < kCh * kCh && r.ok >= 0.f;
-    const float sx = wave_sum(present ? r.ax : 0.f), sy = wave_sum(present ? r.ay : 0.f), sz = wave_sum(present ? r.az : 0.f);
-    const float npres = wave_sum(present ? 1.f : 0.f);
+    const float sx = wave_sum_dpp(present ? r.ax : 0.f), sy = wave_sum_dpp(present ? r.ay : 0.f), sz = wave_sum_dpp(present ? r.az : 0.f);
+    const float npres = wave_sum_dpp(present ? 1.f : 0.f);
     bool ok = __all(!present || r.ok > 0.f);
     const float n = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
     const float ax = sx / n, ay = sy / n, az = sz / n;
@@ -350,8 +350,8 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   }
   Cone tcone, qcone;
   {
-    const float wsx = wave_sum((has && u.ok) ? u.ux : 0.f), wsy = wave_sum((has && u.ok) ? u.uy : 0.f),
-                wsz = wave_sum((has && u.ok) ? u.uz : 0.f);
+    const float wsx = wave_sum_dpp((has && u.ok) ? u.ux : 0.f), wsy = wave_sum_dpp((has && u.ok) ? u.uy : 0.f),
+                wsz = wave_sum_dpp((has && u.ok) ? u.uz : 0.f);
     const bool wok = __all(!has || u.ok);
     {
       const float n = sqrtf(fmaf(wsz, wsz, fmaf(wsy, wsy, wsx * wsx)));
@@ -406,7 +406,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
         const int e = estimate(q);
         ahead += (e > mine || (e == mine && q < bin)) ? 1 : 0;
       }
-      ahead = (int)wave_sum((float)ahead);      // (< 2^24: exact in fp32)
+      ahead = (int)wave_sum_dpp((float)ahead);      // (< 2^24: exact in fp32)
       if (lane == 0) L.wsum[wave] = ahead;
       __syncthreads();
       rank = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];

@@ -226,7 +226,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   const RayDir u = ray_dir(dx, dy, dz);
   const bool wave_dirs_ok = __all(u.ok);
   const bool unit_rays = __all(!u.ok || u.unit);
-  const float wsx = wave_sum(u.ok ? u.ux : 0.f), wsy = wave_sum(u.ok ? u.uy : 0.f), wsz = wave_sum(u.ok ? u.uz : 0.f);
+  const float wsx = wave_sum_dpp(u.ok ? u.ux : 0.f), wsy = wave_sum_dpp(u.ok ? u.uy : 0.f), wsz = wave_sum_dpp(u.ok ? u.uz : 0.f);
   Cone wcone, gcone;
   {
     const float n = sqrtf(fmaf(wsz, wsz, fmaf(wsy, wsy, wsx * wsx)));

@@ -267,15 +267,32 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Wave-wide max / min / sum without a chain of six dependent LDS-crossbar shuffles: four DPP steps (VALU operands, a few
+// cycles each) reduce every aligned row of 16 lanes, four v_readlane + three operations combine the rows.  Max and min do
+// not depend on the order (same bits as the shuffle form); the sum's association differs from wave_sum's, so
+// wave_sum_dpp is used only where the value is not part of a result (bounding-cone axes, counts).
+#define VOGE_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+#define VOGE_LANE(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l))
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, VOGE_DPP(v, 0xB1));     // quad_perm [1,0,3,2]
+  v = fmaxf(v, VOGE_DPP(v, 0x4E));     // quad_perm [2,3,0,1]
+  v = fmaxf(v, VOGE_DPP(v, 0x141));    // row_half_mirror
+  v = fmaxf(v, VOGE_DPP(v, 0x140));    // row_mirror
+  return fmaxf(fmaxf(VOGE_LANE(v, 0), VOGE_LANE(v, 16)), fmaxf(VOGE_LANE(v, 32), VOGE_LANE(v, 48)));
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fminf(v, VOGE_DPP(v, 0xB1));
+  v = fminf(v, VOGE_DPP(v, 0x4E));
+  v = fminf(v, VOGE_DPP(v, 0x141));
+  v = fminf(v, VOGE_DPP(v, 0x140));
+  return fminf(fminf(VOGE_LANE(v, 0), VOGE_LANE(v, 16)), fminf(VOGE_LANE(v, 32), VOGE_LANE(v, 48)));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += VOGE_DPP(v, 0xB1);
+  v += VOGE_DPP(v, 0x4E);
+  v += VOGE_DPP(v, 0x141);
+  v += VOGE_DPP(v, 0x140);
+  return (VOGE_LANE(v, 0) + VOGE_LANE(v, 16)) + (VOGE_LANE(v, 32) + VOGE_LANE(v, 48));
 }
 
 // A bounding cone of a set of unit directions: axis a, cos/sin of the half angle with the
@@ -362,7 +379,7 @@ __device__ __forceinline__ ConeRec block_cone256(const float (&rx)[NR], const fl
     sx += (on && fin) ? rx[k] : 0.f; sy += (on && fin) ? ry[k] : 0.f; sz += (on && fin) ? rz[k] : 0.f;
     okf = (on && !fin) ? 0.f : okf;
   }
-  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); okf = wave_min(okf);
+  sx = wave_sum_dpp(sx); sy = wave_sum_dpp(sy); sz = wave_sum_dpp(sz); okf = wave_min(okf);
   if (lane == 0) { red[wave * 8 + 0] = sx; red[wave * 8 + 1] = sy; red[wave * 8 + 2] = sz; red[wave * 8 + 3] = okf; }
   __syncthreads();
   sx = red[0] + red[8] + red[16] + red[24];
