@@ -458,11 +458,15 @@ struct PackLane {
 };
 // inclusive prefix sum over the wave
 __device__ __forceinline__ int wave_incl_scan(int v, const int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int y = __shfl_up(v, o, 64);
-    if (lane >= o) v += y;
-  }
+  // DPP steps (VALU operands) instead of six dependent LDS-crossbar shuffles: shifts by 1, 2, 4, 8 inside every row of
+  // 16 lanes (zeros shifted in), then lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows 2 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+  (void)lane;
   return v;
 }
 // One round: pixels [pc, pe) of the group (pe returned; uniform), `off` = lanes consumed by earlier rounds.
