@@ -53,17 +53,21 @@ t = np.array(list(buf), dtype=np.float64).reshape(nwg, 8)
 t0 = t[:, 0].min()
 tick = 0.01  # us per tick (100 MHz)
 start, cones, fill, cons, loop_end, end, ev = [(t[:, i]) for i in range(7)]
-print("kernel span us", (end.max() - t0) * tick)
-act = ev > 0
-for nm, sel in (("active", act), ("empty", ~act)):
-    if sel.sum() == 0:
-        continue
-    print(f"{nm}: n={sel.sum()} start(mean/max)={(start[sel]-t0).mean()*tick:.1f}/{(start[sel]-t0).max()*tick:.1f} "
-          f"prologue={(cones-start)[sel].mean()*tick:.1f} fill={fill[sel].mean()*tick:.1f} consume={cons[sel].mean()*tick:.1f} "
-          f"loop={(loop_end-cones)[sel].mean()*tick:.1f} epilogue={(end-loop_end)[sel].mean()*tick:.1f} "
-          f"total={(end-start)[sel].mean()*tick:.1f} max_total={(end-start)[sel].max()*tick:.1f} evals={ev[sel].mean():.0f}")
-# histogram of start times: dispatch rounds
-h, edges = np.histogram((start - t0) * tick, bins=12)
-print("start-time histogram (us):", list(zip(np.round(edges[:-1], 1), h)))
-h, edges = np.histogram((end - t0) * tick, bins=12)
-print("end-time histogram (us):", list(zip(np.round(edges[:-1], 1), h)))
+ran = start > 0                      # tiles the sweep actually worked on (binB wrote the others; they never stamp)
+t0 = start[ran].min()
+print("tiles swept", int(ran.sum()), "of", nwg, " kernel span us", (end[ran].max() - t0) * tick)
+tot = (end - start)[ran] * tick
+print(f"per tile (us): prologue {((cones - start)[ran] * tick).mean():.1f}  fill {(fill[ran] * tick).mean():.1f}  consume {(cons[ran] * tick).mean():.1f}"
+      f"  epilogue {((end - loop_end)[ran] * tick).mean():.1f}  total mean {tot.mean():.1f}  max {tot.max():.1f}")
+o = np.argsort(-tot)[:8]
+idx = np.nonzero(ran)[0]
+for i in o:
+    j = idx[i]
+    print(f"  tile {j}: start +{(start[j] - t0) * tick:.1f}  prologue {(cones[j] - start[j]) * tick:.1f} fill {fill[j] * tick:.1f} consume {cons[j] * tick:.1f}"
+          f" epilogue {(end[j] - loop_end[j]) * tick:.1f} total {tot[i]:.1f} end +{(end[j] - t0) * tick:.1f}")
+h, edges = np.histogram((start[ran] - t0) * tick, bins=10)
+print("start-time histogram (us):", [(round(float(a), 1), int(b)) for a, b in zip(edges[:-1], h)])
+h, edges = np.histogram((end[ran] - t0) * tick, bins=10)
+print("end-time histogram (us):", [(round(float(a), 1), int(b)) for a, b in zip(edges[:-1], h)])
+h, edges = np.histogram(tot, bins=10)
+print("tile-duration histogram (us):", [(round(float(a), 1), int(b)) for a, b in zip(edges[:-1], h)])
