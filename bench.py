@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--split-graph", action="store_true",
                     help="single GPU: use the multi-GPU launch scheme (forward graph / eager exchange / backward graph)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU oracle work for cpu_baseline")
+    ap.add_argument("--loop", action="store_true",
+                    help="BASELINE config 5 as a loop: a step = ONE ShapeFitting iteration (5 views batched, interpolate_attr + "
+                         "get_silhouette MSE losses, backward, SGD step); implies --config cfg5_shapefit_128")
     return ap.parse_args()
 
 
@@ -85,8 +88,108 @@ def stage_bytes(P, npix, K, C=3, iso=False):
     }
 
 
+def loop_bench(args):
+    """BASELINE.json config 5 ("ShapeFitting.py end-to-end optimisation loop ... wall-clock vs CPU baseline") as a
+    measured loop.  A step = one iteration of demo/ShapeFitting.py (reference loop: demo/ShapeFitting.py:250-296): five of
+    twenty views, rendered as one batched call, image = interpolate_attr(frag, colours), silhouette = get_silhouette(frag),
+    two MSE losses, backward (ONE pass over the fragments: voge_fragment_bwd_iso), SGD(lr 0.8, momentum 0.9) step on the
+    vertices and the colours.  Timed three ways: the batched iteration replayed as a HIP graph (`value`), the batched
+    iteration launched eagerly, and the reference's own structure (one renderer call per view, eager)."""
+    import importlib.util
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the VoGE hot path has no CPU fallback")
+    spec = importlib.util.spec_from_file_location("shape_fitting_demo", os.path.join(ROOT, "demo", "ShapeFitting.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    dev = torch.device("cuda", 0)
+    B, V, K, size = 5, 20, 25, 128
+    steps, warm = max(args.steps, 1), max(args.warmup, 0)
+    out = {}
+    for name, kw in (("graph", dict(graph=True)), ("eager", dict()), ("per_view_eager", dict(per_view=True))):
+        if name == "graph" and args.no_graph:
+            continue
+        demo.fit(iters=warm + 20, quiet=True, rgb_on=0, **kw)                     # settle: pools, code objects, clocks
+        h = demo.fit(iters=steps, quiet=True, rgb_on=0, **kw)
+        out[name] = h["sec_per_iter"] * 1e3
+        sil = np.asarray(h["silhouette"])
+        assert np.isfinite(sil).all() and sil[-1] < sil[0], "the loop must run and descend"
+    best = "graph" if "graph" in out else "eager"
+    ms = out[best]
+    N = 2562
+    result = {
+        "metric": "ShapeFitting iterations/sec (BASELINE config 5: 5 views fwd+bwd + SGD step per iteration)",
+        "value": 1e3 / ms, "unit": "iterations/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "frames_per_s": B * 1e3 / ms,
+        "config": {"workload": f"cfg5_shapefit_128 loop: {N} Gaussians (ico-sphere 4), {size}x{size}, K={K}, {B} of {V} views per "
+                               f"iteration as one batch, interpolate_attr + get_silhouette, MSE losses, SGD momentum step",
+                   "launch": {"graph": "hip graph replay of the whole iteration (views gathered on the device)",
+                              "eager": "eager"}[best], "parallelism": "1 gpu"},
+        "ms_per_iteration": {k: round(v, 4) for k, v in out.items()},
+        "ms_per_iteration_note": "graph / eager: the batched iteration (demo/ShapeFitting.py BatchedIteration); per_view_eager: one "
+                                 "renderer call per view as the reference's loop is written (ShapeFitting.py:258-259)",
+    }
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_loop(demo, B, K, size)
+    print(json.dumps(result))
+
+
+def cpu_baseline_loop(demo, B, K, size):
+    """One ShapeFitting iteration (5 views: trace, composite, merge, silhouette, two MSE losses, the whole backward
+    chain, the SGD update) in the CPU oracle (C / OpenMP fp64 port), whole iteration, no sampling."""
+    import numpy as np
+    import oracle
+    from oracle import camera_np
+    oracle.build()
+    v, _ = demo.ico_sphere(4)
+    N = v.shape[0]
+    gv, _, gc = demo.ground_truth_shape(4)
+    sig = np.full(N, 1.0 / (0.05 ** 2 / (2 * np.log(1 / 0.6))), np.float32)
+    cols = np.full((N, 3), 0.5, np.float32)
+    elev, azim = np.linspace(0, 360, 20)[:B], np.linspace(-180, 180, 20)[:B]
+    R, T = camera_np.look_at_view_transform([2.7] * B, list(elev), list(azim))
+    focal, pp = 126.0 * size / 128.0, (size / 2.0, size / 2.0)
+    tgt_rgb = np.zeros((B, size, size, 3))
+    tgt_sil = np.zeros((B, size, size))
+    thr_act = oracle.thr_act_of(0.01)
+
+    def iteration(verts):
+        rays, origin = camera_np.pixel_rays(R, T, focal, pp, (size, size))
+        mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+        isg = np.ascontiguousarray(np.broadcast_to((2 * camera_np.expand_sigma(sig)).astype(np.float32)[None], (B, N, 3, 3)))
+        idx, ln, act, dsd = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+        w, vn = oracle.composite_fwd(idx, act, ln, dsd, 1.0)
+        colsB = np.tile(cols, (B, 1))
+        rgb = oracle.merge_fwd(colsB, idx, w, vn)
+        wsum = w.sum(-1)
+        sil = np.minimum(wsum, 1)
+        g_rgb = 2 * (rgb - tgt_rgb) / rgb.size
+        g_sil = 2 * (sil - tgt_sil) / sil.size * (wsum < 1)
+        g_attr, g_w = oracle.merge_bwd(colsB, idx, w, vn, g_rgb)
+        live = np.arange(K)[None, None, None] < vn[..., None]
+        g_act, g_len, g_dsd = oracle.composite_bwd(act, ln, dsd, g_w + g_sil[..., None] * live, 1.0)
+        _, g_mu, _ = oracle.trace_bwd(mus, isg, rays, idx, g_len, g_act, g_dsd)
+        return verts - 0.8 * g_mu.reshape(B, N, 3).sum(0).astype(np.float32), cols - 0.8 * g_attr.reshape(B, N, 3).sum(0)
+
+    verts = np.asarray(v, np.float32)
+    iteration(verts)
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or time.perf_counter() - t0 < 8.0:
+        iteration(verts)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": 1.0 / dt, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"the whole iteration ({B} views of {size}x{size}, {N} Gaussians, K={K}: trace, composite, merge, silhouette, "
+                      f"losses, backward chain, SGD update), oracle/voge_oracle.c fp64 with OpenMP ({os.cpu_count()} threads), "
+                      f"{reps} repetitions, {dt * 1e3:.1f} ms each"}
+
+
 def main():
     args = parse()
+    if args.loop:
+        return loop_bench(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))
 

@@ -81,9 +81,78 @@ def gauss_renderer(render, gmesh, R, T, color):
     return torch.cat((interpolate_attr(frag, color).squeeze(0), get_silhouette(frag).squeeze(0).unsqueeze(-1)), dim=-1)
 
 
+class BatchedIteration:
+    """One SGD iteration of the loop (ShapeFitting.py:250-296) with its `views_per_iter` views rendered as ONE batched
+    renderer call: rays, trace, composite, interpolate_attr, get_silhouette, the two MSE losses, backward and the
+    optimizer step are each ONE launch chain over B views instead of B chains, and -- with `graph=True` -- the whole
+    iteration is captured once into a HIP graph and replayed (the views of an iteration are gathered ON THE DEVICE
+    from the stacked cameras / targets by an index tensor, so nothing about an iteration depends on the host).
+    The mean over a [B,H,W(,3)] batch equals the reference's sum over views of per-view means / B."""
+
+    def __init__(self, render, gsrc, vert_color, optimizer, R_all, T_all, target_rgb, target_silhouette, views_per_iter,
+                 graph=False):
+        self.render, self.gsrc, self.vert_color, self.optimizer = render, gsrc, vert_color, optimizer
+        self.R_all, self.T_all = R_all.contiguous(), T_all.contiguous()
+        self.tgt_rgb, self.tgt_sil = torch.stack(list(target_rgb)), torch.stack(list(target_silhouette))
+        dev, B = self.R_all.device, views_per_iter
+        self.B = B
+        self.sel = torch.zeros(B, dtype=torch.long, device=dev)            # this iteration's views
+        self.w_rgb = torch.zeros((), device=dev)                            # the rgb loss' weight (0 until rgb_on)
+        self.losses = torch.zeros(2, device=dev)                            # (silhouette, rgb) of the last iteration
+        self.graph = None
+        if graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                state = [p.detach().clone() for p in self._params()]
+                for _ in range(3):                                          # momentum buffers, allocator pools, code objects
+                    self._iteration()
+                for p, q in zip(self._params(), state):                     # the warm-up must not move the optimisation
+                    p.data.copy_(q)
+                for st in optimizer.state.values():
+                    if "momentum_buffer" in st and st["momentum_buffer"] is not None:
+                        st["momentum_buffer"].zero_()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.graph):
+                self._iteration()
+
+    def _params(self):
+        return [p for g in self.optimizer.param_groups for p in g["params"]]
+
+    def _iteration(self):
+        B, N = self.B, self.vert_color.shape[0]
+        self.optimizer.zero_grad(set_to_none=True)
+        R, T = self.R_all.index_select(0, self.sel), self.T_all.index_select(0, self.sel)
+        frag = self.render(self.gsrc, R=R, T=T)
+        rgb = interpolate_attr(frag, self.vert_color.repeat(B, 1))          # indices address rows b * N + n (RayTracing.py:24-30)
+        sil = get_silhouette(frag)
+        l_sil = ((sil - self.tgt_sil.index_select(0, self.sel)) ** 2).mean()
+        l_rgb = ((rgb - self.tgt_rgb.index_select(0, self.sel)) ** 2).mean()
+        (l_sil + self.w_rgb * l_rgb).backward()
+        self.optimizer.step()
+        self.losses.copy_(torch.stack((l_sil.detach(), l_rgb.detach())))
+
+    def __call__(self, views, rgb_weight):
+        """views: LongTensor [B] on the device (or a list of ints: one small host-to-device copy)."""
+        if not torch.is_tensor(views):
+            views = torch.tensor(views, dtype=torch.long)
+        self.sel.copy_(views, non_blocking=True)
+        self.w_rgb.fill_(float(rgb_weight))
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._iteration()
+        return self.losses
+
+
 def fit(iters=2000, level=4, size=128, num_views=20, views_per_iter=5, max_assign=25, rgb_on=400, seed=0,
-        device="cuda:0", log_every=100, save=None, quiet=False):
-    """Runs the optimisation; returns {"silhouette": [...], "rgb": [...], "sec_per_iter": s}."""
+        device="cuda:0", log_every=100, save=None, quiet=False, per_view=False, graph=False):
+    """Runs the optimisation; returns {"silhouette": [...], "rgb": [...], "sec_per_iter": s}.
+    per_view=True renders the views of an iteration one at a time, as the reference's loop is written (:258-259);
+    the default renders them as one batch (BatchedIteration; graph=True replays the iteration as a HIP graph)."""
     device = torch.device(device)
     rng = np.random.RandomState(seed)
     focal, pp = 126.0 * size / 128.0, (size / 2.0, size / 2.0)
@@ -112,27 +181,36 @@ def fit(iters=2000, level=4, size=128, num_views=20, views_per_iter=5, max_assig
     optimizer = torch.optim.SGD(list(gsrc.grad_parameters()) + [vert_color], lr=0.8, momentum=0.9)
     weights = {"rgb": 0.0, "silhouette": 1.0}
     history = {"rgb": [], "silhouette": []}
+    step = None if per_view else BatchedIteration(render, gsrc, vert_color, optimizer, R, T, target_rgb, target_silhouette,
+                                                  views_per_iter, graph=graph)
+    trace = torch.zeros((iters, 2), device=device)                     # losses stay on the device: no per-iteration sync
 
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for i in range(iters):
-        optimizer.zero_grad()
-        loss = {k: torch.zeros((), device=device) for k in weights}
-        for j in rng.permutation(num_views).tolist()[:views_per_iter]:
-            pred = gauss_renderer(render, gsrc, R[None, j, ...], T[None, j, ...], vert_color)
-            loss["silhouette"] = loss["silhouette"] + ((pred[..., 3] - target_silhouette[j]) ** 2).mean() / views_per_iter
-            loss["rgb"] = loss["rgb"] + ((pred[..., :3] - target_rgb[j]) ** 2).mean() / views_per_iter
         if i == rgb_on:
             weights["rgb"] = 1.0
-        total = sum(loss[k] * weights[k] for k in weights)
-        total.backward()
-        optimizer.step()
-        for k in history:
-            history[k].append(float(loss[k].detach()))
+        views = rng.permutation(num_views).tolist()[:views_per_iter]
+        if step is not None:
+            trace[i].copy_(step(views, weights["rgb"]))
+        else:
+            optimizer.zero_grad()
+            loss = {k: torch.zeros((), device=device) for k in weights}
+            for j in views:
+                pred = gauss_renderer(render, gsrc, R[None, j, ...], T[None, j, ...], vert_color)
+                loss["silhouette"] = loss["silhouette"] + ((pred[..., 3] - target_silhouette[j]) ** 2).mean() / views_per_iter
+                loss["rgb"] = loss["rgb"] + ((pred[..., :3] - target_rgb[j]) ** 2).mean() / views_per_iter
+            total = sum(loss[k] * weights[k] for k in weights)
+            total.backward()
+            optimizer.step()
+            trace[i].copy_(torch.stack((loss["silhouette"].detach(), loss["rgb"].detach())))
         if not quiet and (i % log_every == 0 or i == iters - 1):
-            print(f"iter {i:5d}  silhouette {history['silhouette'][-1]:.6f}  rgb {history['rgb'][-1]:.6f}", flush=True)
+            sl, rl = trace[i].tolist()
+            print(f"iter {i:5d}  silhouette {sl:.6f}  rgb {rl:.6f}", flush=True)
     torch.cuda.synchronize(device)
     history["sec_per_iter"] = (time.perf_counter() - t0) / max(iters, 1)
+    tr = trace.cpu().numpy()
+    history["silhouette"], history["rgb"] = tr[:, 0].tolist(), tr[:, 1].tolist()
     if save:
         os.makedirs(save, exist_ok=True)
         with torch.no_grad():
@@ -150,8 +228,10 @@ if __name__ == "__main__":
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--rgb-on", type=int, default=400)
     ap.add_argument("--save", default=None)
+    ap.add_argument("--per-view", action="store_true", help="one renderer call per view, as the reference's loop is written")
+    ap.add_argument("--graph", action="store_true", help="replay the batched iteration as a HIP graph")
     a = ap.parse_args()
-    h = fit(iters=a.iters, level=a.level, size=a.size, rgb_on=a.rgb_on, save=a.save)
+    h = fit(iters=a.iters, level=a.level, size=a.size, rgb_on=a.rgb_on, save=a.save, per_view=a.per_view, graph=a.graph)
     n = max(1, len(h["silhouette"]) // 20)
     print(f"silhouette loss {np.mean(h['silhouette'][:n]):.5f} -> {np.mean(h['silhouette'][-n:]):.5f}; "
           f"rgb loss {np.mean(h['rgb'][:n]):.5f} -> {np.mean(h['rgb'][-n:]):.5f}; "

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOGE_ABI_VERSION 2
+#define VOGE_ABI_VERSION 3
 
 #define VOGE_ERR_BAD_ARG (-1)        /* null pointer / non-positive size */
 #define VOGE_ERR_WORKSPACE (-2)      /* workspace smaller than voge_trace_workspace_bytes() */
@@ -192,7 +192,7 @@ int voge_bin_gaussians(const float *points, const int64_t *cloud_to_packed_first
  * (no per-slot gather in its epilogue), the composite derives act / dsd from the (mean, a) records with the same
  * operations (voge_composite_fwd_iso), and so does voge_fragment_shade_bwd_iso when handed NULL for them: 168 MB per
  * frame at 50k Gaussians / 512^2 / K = 40 that are neither written nor read.  Weights are bit-identical either way.
- * voge_fragment_act_dsd_iso materialises them afterwards for consumers that want the arrays (K must be even). */
+ * voge_fragment_act_dsd_iso materialises them afterwards for consumers that want the arrays. */
 int voge_fragments_fwd(const float *mus, const float *isigmas, const float *rays, const float *cam_fwd,
                        const float *cones, int B, int N, int H, int W, int K, float thr_act, float occ,
                        void *workspace, size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
@@ -219,7 +219,7 @@ int voge_fragments_fwd_iso_view(const float *verts, const float *sigmas, const f
  * array, 0, 0 for plain (mus, a) inputs); rgb / wsum = voge_shade_fwd's out_rgb / out_wsum; g_img = the gradient of
  * the image, element (pixel p, channel c) at g_img[p * g_stride_pix + c * g_stride_c]: (C, 1) for a contiguous
  * [nrows*W,C] array, (0, 0) for the one broadcast scalar autograd hands back for sum() / mean() losses (no
- * materialised copy of it is needed).  Writes g_verts, g_sigmas (both or neither) and g_colors [Nattr,C].  K even, <= 128;
+ * materialised copy of it is needed).  Writes g_verts, g_sigmas (both or neither) and g_colors [Nattr,C].  K <= 128;
  * C <= 4; cnt required.  workspace: >= voge_fragment_bwd_workspace_bytes(B*N) bytes.
  */
 size_t voge_fragment_bwd_workspace_bytes(int P);
@@ -228,7 +228,7 @@ size_t voge_fragment_bwd_workspace_bytes(int P);
 int voge_fragment_act_dsd_iso(const float *records, const float *rays, const int32_t *idx, const float *len,
                               const int32_t *cnt, long npix, int K, int P, float *act, float *dsd, voge_stream_t stream);
 /* Composite forward from (idx, len) and the records instead of (act, len, dsd): what voge_fragments_fwd_iso* runs behind
- * its sweep when act / dsd are omitted.  cnt required, K even. */
+ * its sweep when act / dsd are omitted.  cnt required. */
 int voge_composite_fwd_iso(const int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                            const float *rays, float occ, long npix, int K, float *weight, int64_t *valid_num,
                            voge_stream_t stream);
@@ -248,6 +248,36 @@ int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int s
                                 const float *g_img, long g_stride_pix, long g_stride_c, float occ, int B, int N,
                                 long nrows, int W, int K, int C, long Nattr, void *workspace, size_t workspace_bytes, float *g_verts,
                                 float *g_sigmas, float *g_colors, voge_stream_t stream);
+
+/*
+ * The same single pass driven by the gradient of the WEIGHTS, whoever produced it: the backward of
+ * `aggregation` (VoGE/Aggregation.py:30-107, autograd in the reference) followed by the fine trace's
+ * (ray_trace_voge.cu:283-332) for fragments made by voge_fragments_fwd*.  This is what the reference's own training
+ * loops need -- they differentiate through interpolate_attr (merge_final) and get_silhouette, not through
+ * to_colored_background (demo/ShapeFitting.py:217,295; demo/ReasonOcclusion.py:106-109;
+ * demo/EfficientCuboidViaOptimization.py:109-112).  Replaces voge_composite_bwd + voge_trace_bwd*(_iso, _iso_view) and
+ * their exchange of g_len / g_act / g_dsd through memory; act / dsd may be NULL for scalar-sigma fragments that were
+ * traced without them.
+ *   g_weight: element (pixel p, slot k) at g_weight[p * gw_stride_pix + k * gw_stride_k] -- (K, 1) for a contiguous
+ *             [nrows*W,K] array, (1, 0) for a per-pixel value broadcast over the slots (the gradient a silhouette
+ *             loss alone hands back); NULL = zero.
+ *   g_hitlen: NULL, or [nrows*W,K] contiguous: the gradient of vert_hit_length (= the trace's len, Aggregation.py:107).
+ * Any K <= VOGE_MAX_K (odd K too; lists of more than 128 slots put four slots on a lane).  cnt required.
+ * Writes g_verts / g_sigmas (iso: through the view's chain rule, as voge_trace_bwd_iso_view) or g_mus [P,3] /
+ * g_isigmas [P,3,3] (raw outer-product sums, as voge_trace_bwd).  No ray gradient: callers that optimise the rays
+ * themselves use voge_composite_bwd + voge_trace_bwd.  workspace: >= voge_fragment_bwd_workspace_bytes(B*N) bytes.
+ */
+int voge_fragment_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode, const float *rays,
+                          const int32_t *idx, const int32_t *cnt, const float *weight, const float *act,
+                          const float *len, const float *dsd, const float *g_weight, long gw_stride_pix,
+                          long gw_stride_k, const float *g_hitlen, float occ, int B, int N, long nrows, int W, int K,
+                          void *workspace, size_t workspace_bytes, float *g_verts, float *g_sigmas,
+                          voge_stream_t stream);
+int voge_fragment_bwd(const float *mus, const float *isigmas, const float *rays, const int32_t *idx,
+                      const int32_t *cnt, const float *weight, const float *act, const float *len,
+                      const float *dsd, const float *g_weight, long gw_stride_pix, long gw_stride_k,
+                      const float *g_hitlen, float occ, int P, long nrows, int W, int K, void *workspace,
+                      size_t workspace_bytes, float *g_mus, float *g_isigmas, voge_stream_t stream);
 
 /*
  * Composite forward.  Replaces: VoGE/Aggregation.py:82-107 `aggregation`
@@ -305,6 +335,15 @@ int voge_merge_bwd(const float *attr, const int32_t *idx, const float *weight,
 int voge_blend_fwd(const float *rgb, const float *weight, const float *bg, float thr,
                    long npix, int K, int C, float *out, float *sil_out,
                    voge_stream_t stream);
+
+/*
+ * get_silhouette alone (VoGE/Renderer.py:157-159): sil [npix] = min(sum_k weight, 1); wsum [npix] (may be NULL) = the
+ * unclamped sum, which the backward needs.  Backward: g_pix [npix] = g_sil * [wsum < 1] (1/2 at wsum == 1, as
+ * torch.min splits ties) -- the gradient of EVERY slot of the pixel, so the [npix,K] gradient of the weights is this
+ * array viewed with stride 0 along K (voge_fragment_bwd* reads it that way: gw_stride_pix = 1, gw_stride_k = 0).
+ */
+int voge_silhouette_fwd(const float *weight, long npix, int K, float *sil, float *wsum, voge_stream_t stream);
+int voge_silhouette_bwd(const float *wsum, const float *g_sil, long npix, float *g_pix, voge_stream_t stream);
 
 /*
  * Background blend backward: g_out [npix,C] -> g_rgb [npix,C] and the additive term

@@ -48,7 +48,7 @@ def run_trace(mus, isg, rays, K, thr_act, bins=None, bin_size=0):
 def test_abi_loaded_is_in_tree(hip_lib):
     from voge_amd import _lib
     assert os.path.samefile(os.path.dirname(_lib.LIB_PATH), os.path.join(os.path.dirname(GOLDEN), "..", "voge_amd"))
-    assert hip_lib.voge_abi_version() == 2
+    assert hip_lib.voge_abi_version() == 3
 
 
 def test_trace_fwd_cuboid_config1(hip_lib):
@@ -856,7 +856,7 @@ def test_renderer_against_the_running_reference_host_logic(hip_lib, case):
 
 @pytest.mark.parametrize("K,B,inverse,aniso", [(40, 1, False, False), (12, 2, True, False), (26, 1, False, False),
                                                (20, 1, False, True), (8, 2, False, True)])
-def test_fused_fragment_backward_equals_the_three_kernels(hip_lib, K, B, inverse, aniso):
+def test_fused_fragment_backward_equals_the_three_kernels(hip_lib, K, B, inverse, aniso, monkeypatch):
     """voge_fragment_shade_bwd_iso (shade -> composite -> trace backward in one kernel, taken by to_colored_background
     on this renderer's fragments) against the three stand-alone backward kernels on the same frame -- with a second
     consumer of the weights (a silhouette loss, which keeps flowing through _Fragments.backward) and a loss on
@@ -884,6 +884,8 @@ def test_fused_fragment_backward_equals_the_three_kernels(hip_lib, K, B, inverse
         assert hasattr(frag.vert_weight, "voge_through")
         if not fused:
             del frag.vert_weight.voge_through
+        # the comparison chain: voge_shade_bwd -> voge_composite_bwd -> voge_trace_bwd*, act / dsd materialised
+        monkeypatch.setattr(ops, "THREE_KERNEL_BACKWARD", not fused)
         img = to_colored_background(frag, colors, background_color=(0.9, 0.8, 1.0))
         assert (type(img.grad_fn).__name__ == "_ShadeThroughBackward") == fused
         hl = torch.where(frag.vert_index >= 0, frag.vert_hit_length, torch.zeros_like(frag.vert_hit_length))
@@ -951,7 +953,7 @@ def test_fragments_without_act_dsd_equal_the_kept_form(hip_lib, monkeypatch):
         img = to_white_background(frag, colors)
         # the image through the fused backward, the silhouette through _Fragments.backward (which asks for act / dsd)
         (img.sum() + (get_silhouette(frag) * g_sil).sum()).backward()
-        act, dsd = ops._act_dsd(th)
+        act, dsd = ops._act_dsd([th["act"], th["dsd"]], th["records"], th["rays"], th["idx"], th["len"], th["cnt"], th["B"] * th["N"])
         out[keep] = [n(x) for x in (frag.vert_weight, frag.vert_index, frag.vert_hit_length, frag.valid_num, img, act, dsd,
                                     gm.verts.grad, gm.sigmas.grad, colors.grad)]
     for a, b in zip(out["1"][:5], out["0"][:5]):
@@ -963,15 +965,15 @@ def test_fragments_without_act_dsd_equal_the_kept_form(hip_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("N,H,W,K,B,aniso,fused", [
-    (0, 16, 16, 8, 1, False, True), (1, 1, 1, 1, 1, False, False), (5, 3, 7, 3, 1, False, False),
-    (300, 33, 47, 7, 1, False, False), (300, 33, 47, 8, 2, False, True), (300, 20, 20, 130, 1, False, False),
+    (0, 16, 16, 8, 1, False, True), (1, 1, 1, 1, 1, False, True), (5, 3, 7, 3, 1, False, True),
+    (300, 33, 47, 7, 1, False, True), (300, 33, 47, 8, 2, False, True), (300, 20, 20, 130, 1, False, False),
     (300, 20, 20, 128, 1, False, True), (200, 17, 9, 6, 1, True, True), (0, 8, 8, 4, 1, True, True),
     (3000, 64, 64, 256, 1, False, False)])
 def test_renderer_edge_shapes(hip_lib, N, H, W, K, B, aniso, fused):
     """Shapes at the edges of every fast path of the renderer (no Gaussians at all, a 1x1 image, odd K, K beyond the
     fused backward's 128, K at the library's 256, batches, full 3x3 forms): the frame runs forward and backward, every
-    output is finite, an empty scene renders the background, and the fused backward is taken exactly where it applies
-    (K even and <= 128)."""
+    output is finite, an empty scene renders the background, and the shade-through backward is taken exactly where it
+    applies (K <= 128; beyond that the image takes voge_shade_bwd and the fragments the one-pass voge_fragment_bwd*)."""
     from voge_amd.Meshes import GaussianMeshes
     from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, get_silhouette, to_white_background
     from voge_amd.cameras import PerspectiveCameras, look_at_view_transform

@@ -1,0 +1,332 @@
+"""GPU parity of the call pattern the reference's own training loops use: they differentiate through
+interpolate_attr (merge_final) and get_silhouette -- never through to_white_background
+(demo/ShapeFitting.py:217,262-271,295; demo/ReasonOcclusion.py:106-109; demo/EfficientCuboidViaOptimization.py:109-112).
+The gradient of the weights then reaches _Fragments.backward, which runs the composite's and the trace's backward as
+ONE pass (voge_fragment_bwd_iso / voge_fragment_bwd) for any K <= 256, odd K included.
+
+Everything here is checked against the fp64 oracle chain (composite_bwd -> trace_bwd), not against other kernels of
+this repo.
+"""
+import gc
+import weakref
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import camera_np
+from util import TOL, grad_close, random_scene, _report_flips
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(a, dtype=torch.float32, rg=False):
+    return torch.tensor(np.asarray(a), dtype=dtype, device=DEV, requires_grad=rg)
+
+
+def n(x):
+    return x.detach().cpu().numpy()
+
+
+def oracle_frame(verts, sigmas, R, T, focal, pp, size, K, thr=0.01, occ=1.0, inverse=False):
+    """Forward chain of the oracle up to the weights.  sigmas [N] | [N,3] | [N,3,3] as the user passes them."""
+    rays, origin = camera_np.pixel_rays(R, T, focal, pp, size)
+    B = rays.shape[0]
+    mus = (np.asarray(verts, np.float32)[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    sig3 = camera_np.expand_sigma(np.asarray(sigmas, np.float32))
+    isg = (2 * np.linalg.inv(sig3.astype(np.float64))).astype(np.float32) if inverse else (2 * sig3).astype(np.float32)
+    isg = np.ascontiguousarray(np.broadcast_to(isg[None], (B,) + isg.shape))
+    thr_act = oracle.thr_act_of(thr)
+    idx, ln, act, dsd = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    w, vn = oracle.composite_fwd(idx, act, ln, dsd, occ)
+    return dict(rays=rays, mus=mus, isg=isg, idx=idx, len=ln, act=act, dsd=dsd, weight=w, valid_num=vn, occ=occ)
+
+
+def oracle_param_grads(ref, sigmas, g_w, g_hitlen=None):
+    """(g_weight [, g_hit_length]) -> gradients of the user's verts [N,3] and sigmas (their own shape; 2*sigma rule of
+    Renderer.py:133: d/d sigma of A = 2 expand(sigma)), summed over the views that share the Gaussians."""
+    g_act, g_len, g_dsd = oracle.composite_bwd(ref["act"], ref["len"], ref["dsd"], g_w, ref["occ"])
+    if g_hitlen is not None:
+        g_len = g_len + g_hitlen
+    _, g_mu, g_A = oracle.trace_bwd(ref["mus"], ref["isg"], ref["rays"], ref["idx"], g_len, g_act, g_dsd)
+    B = ref["rays"].shape[0]
+    N = ref["mus"].shape[1]
+    g_mu = g_mu.reshape(B, N, 3).sum(0)
+    g_A = g_A.reshape(B, N, 3, 3).sum(0)
+    sigmas = np.asarray(sigmas)
+    if sigmas.ndim == 1:
+        g_sig = 2 * np.einsum("nii->n", g_A)
+    elif sigmas.ndim == 2:
+        g_sig = 2 * np.einsum("nii->ni", g_A)
+    else:
+        g_sig = 2 * g_A
+    return g_mu, g_sig
+
+
+def same_lists(frag, ref, label, max_flips):
+    idx = n(frag.vert_index)
+    same = (idx == np.where(ref["idx"] < 0, 0, ref["idx"])).all(-1) | (idx == ref["idx"]).all(-1)
+    _report_flips(label, (~same).sum(), same.size)
+    assert (~same).sum() <= max_flips, f"{label}: {(~same).sum()} of {same.size} pixels flipped (ceiling {max_flips})"
+    assert np.abs(n(frag.vert_weight)[same] - ref["weight"][same]).max(initial=0.0) < TOL
+    return same
+
+
+def renderer_for(H, W, K, focal, thr=0.01, occ=1.0, inverse=False, mppb=-1):
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings
+    from voge_amd.cameras import PerspectiveCameras
+    cams = PerspectiveCameras(focal_length=focal, principal_point=((W / 2.0, H / 2.0),), image_size=((H, W),), device=DEV)
+    st = GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=thr, absorptivity=occ, inverse_sigma=inverse,
+                                max_point_per_bin=mppb)
+    return GaussianRenderer(cams, st).to(DEV)
+
+
+def forbid_three_kernel_chain(monkeypatch):
+    """Make the stand-alone backward kernels unreachable: a test that passes took the one-pass kernel."""
+    from voge_amd import _lib
+    lib = _lib.load()
+
+    def boom(*a):
+        raise AssertionError("the three-kernel backward chain was taken")
+    for name in ("voge_composite_bwd", "voge_trace_bwd", "voge_trace_bwd_iso", "voge_trace_bwd_iso_view", "voge_fragment_act_dsd_iso"):
+        monkeypatch.setattr(lib, name, boom, raising=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,B,form,inverse", [
+    (25, 1, "scalar", False), (40, 2, "scalar", False), (7, 1, "scalar", True), (1, 1, "scalar", False),
+    (130, 1, "scalar", False), (131, 1, "scalar", False), (256, 1, "scalar", False),
+    (25, 1, "full", False), (12, 2, "full", False), (102, 1, "full", False), (133, 1, "full", False),
+    (9, 1, "diag", False), (20, 2, "diag", False)])
+def test_fragment_backward_from_a_weight_gradient_vs_oracle(hip_lib, monkeypatch, K, B, form, inverse):
+    """Random gradients on vert_weight AND vert_hit_length -> verts / sigmas, against the oracle chain: scalar sigmas
+    (voge_fragment_bwd_iso, fragments without act / dsd), full [N,3,3] forms and (N,3) diagonals (voge_fragment_bwd);
+    odd K, K > 128 (four slots per lane), batches of views that share the Gaussians."""
+    from voge_amd.Meshes import GaussianMeshes
+    forbid_three_kernel_chain(monkeypatch)
+    N, H, W = (900, 40, 56) if K > 64 else (2000, 56, 72)
+    lo, hi = (0.15, 0.3) if K > 64 else (0.05, 0.12)
+    verts, sig, _ = random_scene(N, seed=300 + K, lo=lo, hi=hi, aniso=(form == "full"))
+    if form == "diag":
+        rng = np.random.default_rng(K)
+        sig = (sig[:, None] * rng.uniform(0.6, 1.6, (N, 3))).astype(np.float32)
+    if inverse:
+        sig = (1.0 / sig).astype(np.float32)
+    R, T = camera_np.look_at_view_transform([3.0, 3.3][:B], [10.0, -20.0][:B], [30.0, 200.0][:B])
+    occ = 1.1
+    renderer = renderer_for(H, W, K, 80.0, occ=occ, inverse=inverse)
+    gm = GaussianMeshes(t(verts), t(sig)).to(DEV)
+    frag = renderer(gm, R=t(R), T=t(T))
+    ref = oracle_frame(verts, sig, R, T, 80.0, (W / 2.0, H / 2.0), (H, W), K, occ=occ, inverse=inverse)
+    same = same_lists(frag, ref, f"weight-gradient form K={K} B={B} {form}", max_flips=12)
+    assert (ref["valid_num"] == K).any() or K > 100
+    rng = np.random.default_rng(7)
+    live = (np.arange(K)[None, None, None] < ref["valid_num"][..., None]) & same[..., None]
+    g_w = rng.normal(size=ref["weight"].shape) * live
+    g_h = 0.05 * rng.normal(size=ref["weight"].shape) * live
+    ((frag.vert_weight * t(g_w)).sum() + (frag.vert_hit_length * t(g_h)).sum()).backward()
+    g_mu, g_sig = oracle_param_grads(ref, sig, g_w, g_h)
+    if inverse:      # A = 2 / s: d/ds = -2 / s^2 d/dA (scalar)
+        g_sig = -g_sig / (np.asarray(sig, np.float64) ** 2)
+    grad_close(f"fragment_bwd K={K} B={B} {form} verts", n(gm.verts.grad), g_mu, 2 * TOL)
+    grad_close(f"fragment_bwd K={K} B={B} {form} sigmas", n(gm.sigmas.grad), g_sig, 2 * TOL)
+    assert np.abs(g_mu).max() > 0 and np.abs(g_sig).max() > 0
+
+
+def test_silhouette_only_gradient_is_read_in_place(hip_lib, monkeypatch):
+    """get_silhouette as the weights' only consumer: its backward hands ONE value per pixel, expanded over the slots
+    with stride 0, and voge_fragment_bwd_iso reads that view in place (gw_stride_pix = 1, gw_stride_k = 0)."""
+    from voge_amd import ops
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import get_silhouette
+    forbid_three_kernel_chain(monkeypatch)
+    N, H, W, K = 1500, 48, 64, 25
+    verts, sig, _ = random_scene(N, seed=11, lo=0.05, hi=0.1)
+    R, T = camera_np.look_at_view_transform(3.0, 10.0, 30.0)
+    renderer = renderer_for(H, W, K, 80.0)
+    gm = GaussianMeshes(t(verts), t(sig)).to(DEV)
+    frag = renderer(gm, R=t(R), T=t(T))
+    ref = oracle_frame(verts, sig, R, T, 80.0, (W / 2.0, H / 2.0), (H, W), K)
+    same = same_lists(frag, ref, "silhouette only", max_flips=6)
+    seen = {}
+    real = ops._grad_weight_layout
+
+    def spy(g, K_):
+        out = real(g, K_)
+        seen["strides"] = out[1:]
+        return out
+    monkeypatch.setattr(ops, "_grad_weight_layout", spy)
+    tgt = np.random.default_rng(3).uniform(0, 1, same.shape)
+    sil = get_silhouette(frag)
+    (((sil - t(tgt)) ** 2) * t(same.astype(np.float32))).sum().backward()
+    assert seen["strides"] == (1, 0), "the expanded per-pixel gradient must be read in place"
+    wsum = ref["weight"].sum(-1)
+    assert np.abs(n(sil) - np.minimum(wsum, 1))[same].max() < TOL
+    g_pix = 2 * (np.minimum(wsum, 1) - tgt) * (wsum < 1) * same
+    g_mu, g_sig = oracle_param_grads(ref, sig, np.broadcast_to(g_pix[..., None], ref["weight"].shape) *
+                                     (np.arange(K)[None, None, None] < ref["valid_num"][..., None]))
+    grad_close("silhouette-only verts", n(gm.verts.grad), g_mu, 2 * TOL)
+    grad_close("silhouette-only sigmas", n(gm.sigmas.grad), g_sig, 2 * TOL)
+
+
+# ----------------------------------------------------------------------------------------------- cfg5, the loop's ops
+def test_config5_shapefit_iteration_interpolate_attr_and_silhouette(hip_lib, monkeypatch):
+    """BASELINE config 5 at its real size with the loop's REAL op mix (demo/ShapeFitting.py:214-219,258-271,295):
+    2562 Gaussians, 128x128, max_assign 25, five views rendered as ONE batch, image = interpolate_attr(frag, colours),
+    silhouette = get_silhouette(frag), two MSE losses, one backward.  The one-pass backward must be the node that runs
+    (the stand-alone chain is made unreachable) and the gradients of colours / verts / sigmas must match the oracle."""
+    import importlib.util
+    import os
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import get_silhouette, interpolate_attr
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("shape_fitting_demo", os.path.join(root, "demo", "ShapeFitting.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    v, _ = demo.ico_sphere(4)
+    rng = np.random.default_rng(5)
+    verts = (np.asarray(v, np.float32) * (1.0 + 0.05 * rng.normal(size=(2562, 1)))).astype(np.float32)
+    sig = (np.full(2562, 1.0 / (0.05 ** 2 / (2 * np.log(1 / 0.6)))) * rng.uniform(0.8, 1.25, 2562)).astype(np.float32)
+    cols = rng.uniform(0, 1, (2562, 3)).astype(np.float32)
+    H = W = 128
+    K, B = 25, 5
+    R5, T5 = camera_np.look_at_view_transform([2.7] * 5, [0.0, 30.0, -20.0, 10.0, 45.0], [-180.0, -120.0, -40.0, 60.0, 160.0])
+    forbid_three_kernel_chain(monkeypatch)
+    renderer = renderer_for(H, W, K, 126.0)
+    gm = GaussianMeshes(t(verts), t(sig)).to(DEV)
+    colors = t(cols, rg=True)
+    frag = renderer(gm, R=t(R5), T=t(T5))                     # five views, one call
+    assert type(frag.vert_weight.grad_fn).__name__ == "_FragmentsBackward"
+    img = interpolate_attr(frag, colors.repeat(B, 1))        # indices address rows b*N+n (RayTracing.py:24-30)
+    sil = get_silhouette(frag)
+    ref = oracle_frame(verts, sig, R5, T5, 126.0, (64.0, 64.0), (H, W), K)
+    same = same_lists(frag, ref, "cfg5 5 views 128^2 K=25 (interpolate_attr + get_silhouette)", max_flips=12)
+    colsB = np.tile(cols, (B, 1))
+    rgb_ref = oracle.merge_fwd(colsB, ref["idx"], ref["weight"], ref["valid_num"])
+    wsum = ref["weight"].sum(-1)
+    assert np.abs(n(img) - rgb_ref)[same].max() < TOL and np.abs(n(sil) - np.minimum(wsum, 1))[same].max() < TOL
+    assert (ref["valid_num"] > 0).mean() > 0.3
+    tgt_rgb = rng.uniform(0, 1, rgb_ref.shape)
+    tgt_sil = (rng.uniform(0, 1, wsum.shape) > 0.5).astype(np.float64)
+    keep = t(same.astype(np.float32))
+    loss = ((((img - t(tgt_rgb)) ** 2) * keep[..., None]).sum() / tgt_rgb[0].size
+            + (((sil - t(tgt_sil)) ** 2) * keep).sum() / tgt_sil[0].size) / B
+    loss.backward()
+    g_rgb = 2 * (rgb_ref - tgt_rgb) / tgt_rgb[0].size / B * same[..., None]
+    g_silh = 2 * (np.minimum(wsum, 1) - tgt_sil) / tgt_sil[0].size / B * same * (wsum < 1)
+    g_attr, g_w = oracle.merge_bwd(colsB, ref["idx"], ref["weight"], ref["valid_num"], g_rgb)
+    live = np.arange(K)[None, None, None] < ref["valid_num"][..., None]
+    g_mu, g_sig = oracle_param_grads(ref, sig, g_w + g_silh[..., None] * live)
+    want = (g_attr.reshape(B, 2562, 3).sum(0), g_mu, g_sig)
+    for name, g, wv in zip(("colors", "verts", "sigmas"), (colors.grad, gm.verts.grad, gm.sigmas.grad), want):
+        err = np.abs(n(g).astype(np.float64) - wv).max()
+        print(f"[parity] cfg5 loop ops {name}: max err {err:.3e}, largest entry {np.abs(wv).max():.3e}")
+        assert err <= 2 * TOL * np.abs(wv).max(), f"cfg5 {name}: {err:.3e} vs largest entry {np.abs(wv).max():.3e}"
+
+
+# ------------------------------------------------------------------------------- EfficientCuboidViaOptimization's settings
+@pytest.mark.parametrize("form", ["tril", "diag"])
+def test_efficient_cuboid_settings_general_forms_vs_oracle(hip_lib, monkeypatch, form):
+    """demo/EfficientCuboidViaOptimization.py:75-79,104-112: max_assign = the number of Gaussians (102), thr_activation = 0,
+    max_point_per_bin = -1, sigmas = L L^T from a trainable lower-triangular L ([N,3,3] forms through GaussianRenderer),
+    a SIX-channel attribute through interpolate_attr, L1 loss, gradients to the sigmas (and verts).  Also the (N,3)
+    diagonal form (Aggregation.py:169-173).  Against the full oracle chain."""
+    from voge_amd.Meshes import GaussianMeshesNaive
+    from voge_amd.Renderer import interpolate_attr
+    forbid_three_kernel_chain(monkeypatch)
+    N, H, W, K = 102, 48, 64, 102
+    rng = np.random.default_rng(17)
+    # six faces of a cuboid, 17 Gaussians each, as the demo's efficient_cuboid() lays them out
+    face = rng.integers(0, 6, N)
+    verts = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+    verts[np.arange(N), face % 3] = np.where(face < 3, 1.0, -1.0)
+    if form == "tril":
+        L0 = (np.eye(3)[None] * 2.0 + np.tril(rng.uniform(-0.4, 0.4, (N, 3, 3)))).astype(np.float32)
+        L = t(L0, rg=True)
+        sig_t = L @ L.transpose(1, 2)                                  # to_sym of the demo
+    else:
+        L0 = rng.uniform(2.0, 6.0, (N, 3)).astype(np.float32)
+        L = t(L0, rg=True)
+        sig_t = L
+    sig = n(sig_t)
+    verts_t = t(verts, rg=True)
+    attr = np.eye(6, dtype=np.float32)[face]                          # idx_ of the demo: one-hot face labels, C = 6
+    R, T = camera_np.look_at_view_transform(5.0, 25.0, 40.0)
+    renderer = renderer_for(H, W, K, 60.0, thr=0.0)
+    frag = renderer(GaussianMeshesNaive(verts_t, sig_t), R=t(R), T=t(T))
+    ref = oracle_frame(verts, sig, R, T, 60.0, (W / 2.0, H / 2.0), (H, W), K, thr=0.0)
+    same = same_lists(frag, ref, f"EfficientCuboid settings ({form})", max_flips=8)
+    assert ref["valid_num"].max() > 32 and ref["valid_num"].mean() > 8      # thr_activation = 0: long lists, far from full
+    img = interpolate_attr(frag, t(attr))
+    rgb_ref = oracle.merge_fwd(attr, ref["idx"], ref["weight"], ref["valid_num"])
+    assert np.abs(n(img) - rgb_ref)[same].max() < TOL
+    tgt = rng.uniform(0, 1, rgb_ref.shape)
+    (((img - t(tgt)).abs()) * t(same.astype(np.float32))[..., None]).sum().backward()      # L1Loss (sum-reduced)
+    g_rgb = np.sign(rgb_ref - tgt) * same[..., None]
+    _, g_w = oracle.merge_bwd(attr, ref["idx"], ref["weight"], ref["valid_num"], g_rgb)
+    g_mu, g_sig = oracle_param_grads(ref, sig, g_w)
+    grad_close(f"EfficientCuboid ({form}) verts", n(verts_t.grad), g_mu, 2 * TOL)
+    if form == "tril":      # d/dL of L L^T: (G + G^T) L
+        g_L = (g_sig + g_sig.transpose(0, 2, 1)) @ L0.astype(np.float64)
+        grad_close("EfficientCuboid (tril) L", n(L.grad), g_L, 2 * TOL)
+    else:
+        grad_close("EfficientCuboid (diag) sigmas", n(L.grad), g_sig, 2 * TOL)
+
+
+# ----------------------------------------------------------------------------------------------- host robustness
+def test_frame_buffers_are_released_by_refcount(hip_lib):
+    """nothing differentiable may hang on ctx as a plain attribute -- with the cyclic collector disabled the
+    frame's tensors must die as soon as the last reference goes."""
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import get_silhouette, to_white_background
+    verts, sig, cols = random_scene(800, seed=4, lo=0.05, hi=0.1)
+    R, T = camera_np.look_at_view_transform(3.0, 10.0, 30.0)
+    renderer = renderer_for(32, 32, 12, 50.0)
+    gm = GaussianMeshes(t(verts), t(sig)).to(DEV)
+    colors = t(cols, rg=True)
+    gc.collect()
+    gc.disable()
+    try:
+        for with_backward in (False, True):
+            frag = renderer(gm, R=t(R), T=t(T))
+            img = to_white_background(frag, colors)
+            sil = get_silhouette(frag)
+            refs = [weakref.ref(x) for x in (frag.vert_hit_length, frag.vert_weight, frag.vert_index, img, sil)]
+            if with_backward:
+                (img.sum() + sil.sum()).backward()
+            del frag, img, sil
+            assert all(r() is None for r in refs), [r() is None for r in refs]
+    finally:
+        gc.enable()
+
+
+def test_fragment_views_keep_the_fast_paths(hip_lib, monkeypatch):
+    """Fragments.copy() / squeeze() / unsqueeze() return views of the same memory (RenderBunny.py:45 renders
+    to_white_background(frag.copy(), ...)): they must stay on the shade-through path and must not fall back to the
+    synchronising idx.max() range check."""
+    from voge_amd import ops
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import interpolate_attr, to_white_background
+    verts, sig, cols = random_scene(800, seed=5, lo=0.05, hi=0.1)
+    R, T = camera_np.look_at_view_transform(3.0, 10.0, 30.0)
+    renderer = renderer_for(32, 40, 12, 50.0)
+    gm = GaussianMeshes(t(verts), t(sig)).to(DEV)
+    colors = t(cols, rg=True)
+
+    def no_sync(*a, **k):
+        raise AssertionError("index range fell back to the device reduction")
+    frag = renderer(gm, R=t(R), T=t(T))
+    base = to_white_background(frag, colors)
+    monkeypatch.setattr(torch.Tensor, "max", no_sync)
+    for name, f in (("copy", frag.copy()), ("squeeze", frag.squeeze()), ("squeeze.unsqueeze", frag.squeeze().unsqueeze())):
+        img = to_white_background(f, colors)
+        assert type(img.grad_fn).__name__ in ("_ShadeThroughBackward", "ViewBackward0"), (name, type(img.grad_fn).__name__)
+        assert torch.equal(img.reshape(base.shape), base), name
+        assert ops.hit_count_of(f.vert_index) is not None, name
+        interpolate_attr(f, colors)
+    monkeypatch.undo()
+    # an in-place edit through torch invalidates the bookkeeping: the slow, checked path is taken again
+    frag.vert_index[0, 0, 0, 0] = 0
+    assert ops.hit_count_of(frag.vert_index) is None and ops.through_of(frag.vert_weight, frag.vert_index) is None

@@ -34,7 +34,9 @@ class Fragments(object):
         self.vert_hit_length = vert_hit_length
 
     def _map(self, fn):
-        return Fragments(**{k: fn(getattr(self, k)) for k in self._fields})
+        # (views of the same memory keep the trace's bookkeeping -- ops.carry_tags -- so frag.copy(), frag.squeeze()
+        #  and frag.unsqueeze() stay on the fast paths, as RenderBunny.py:45's to_white_background(frag.copy(), ...))
+        return Fragments(**{k: ops.carry_tags(getattr(self, k), fn(getattr(self, k))) for k in self._fields})
 
     def __getitem__(self, item):
         assert len(self.valid_num.shape) == 3, 'Index access is only available when batched.'

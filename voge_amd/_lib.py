@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VOGE_HIP_LIB points at another build of the same ABI (kernel tuning variants)
 LIB_PATH = os.environ.get("VOGE_HIP_LIB") or os.path.join(_HERE, "libvoge_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_void_p = ctypes.c_void_p
 _c_int = ctypes.c_int
@@ -47,6 +47,10 @@ SIGNATURES = {
                                 + [_c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),
     "voge_fragment_shade_bwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 11 + [_c_float, _c_void_p, _c_long, _c_long, _c_float]
                                     + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),
+    "voge_fragment_bwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 8 + [_c_long, _c_long, _c_void_p, _c_float]
+                              + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_void_p, _c_size_t] + [_c_void_p] * 3),
+    "voge_fragment_bwd": (_c_int, [_c_void_p] * 10 + [_c_long, _c_long, _c_void_p, _c_float]
+                          + [_c_int, _c_long, _c_int, _c_int, _c_void_p, _c_size_t] + [_c_void_p] * 3),
     "voge_composite_fwd": (_c_int, [_c_void_p] * 5 + [_c_float, _c_long, _c_int] + [_c_void_p] * 3),
     "voge_composite_bwd": (_c_int, [_c_void_p] * 6 + [_c_float, _c_long, _c_int] + [_c_void_p] * 4),
     "voge_merge_fwd": (_c_int, [_c_void_p] * 4 + [_c_long, _c_int, _c_int, _c_long, _c_int] + [_c_void_p] * 2),
@@ -63,6 +67,8 @@ SIGNATURES = {
     "voge_find_nearest_k": (_c_int, [_c_void_p] * 3 + [_c_float, _c_int, _c_int, _c_long] + [_c_void_p] * 5),
     "voge_find_nearest_k_bwd": (_c_int, [_c_void_p] * 4 + [_c_int, _c_int, _c_long] + [_c_void_p] * 4),
     "voge_scatter_max": (_c_int, [_c_void_p] * 2 + [_c_long, _c_long] + [_c_void_p] * 2),
+    "voge_silhouette_fwd": (_c_int, [_c_void_p, _c_long, _c_int] + [_c_void_p] * 3),
+    "voge_silhouette_bwd": (_c_int, [_c_void_p] * 2 + [_c_long] + [_c_void_p] * 2),
     "voge_blend_bwd": (_c_int, [_c_void_p] * 3 + [_c_float, _c_void_p, _c_long, _c_int, _c_int] + [_c_void_p] * 3),
 }
 

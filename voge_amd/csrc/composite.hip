@@ -411,13 +411,19 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   if (!BWD && act == nullptr) {
     // Fragments without act / dsd in memory (voge_fragments_fwd_iso*): the sweep wrote index and len only; act and dsd
     // of A = a I are re-derived here from the SAME records with the SAME operations its epilogue would have used
-    // (pair_eval_iso_at), so the weights are bit-identical to the two-call form.  (host: counts given, K % NS == 0)
+    // (pair_eval_iso_at), so the weights are bit-identical to the two-call form.  (host: counts given)
     if (active && k0 < lead) {
       const float3 d = at_bytes<float3>(rays, (OffT)pix * (OffT)12);
       const float dn2 = (d.x * d.x + d.y * d.y) + d.z * d.z;
       int iv[NS];
       float lv[NS];
-      if (NS == 4) {
+      if (!vec) {                 // K not a multiple of NS (odd K): the group is read slot by slot
+#pragma unroll
+        for (int a = 0; a < NS; ++a) {
+          iv[a] = 0; lv[a] = 0.0f;
+          if (k0 + a < lead) { iv[a] = idx[f + a]; lv[a] = len[f + a]; }
+        }
+      } else if (NS == 4) {
         const int4 i4 = at_bytes<int4>(idx, fb);
         const float4 l4 = at_bytes<float4>(len, fb);
         iv[0] = i4.x; iv[1] = i4.y; iv[NS - 2] = i4.z; iv[NS - 1] = i4.w;
@@ -930,11 +936,11 @@ extern "C" int voge_composite_fwd(const int32_t *idx, const int32_t *cnt, const 
 }
 
 // Composite forward for A = a I straight from the sweep's keys: act / dsd are derived from the (mu, a) records instead of
-// being read (see compositen_kernel).  K even; cnt required.
+// being read (see compositen_kernel).  cnt required.
 extern "C" int voge_composite_fwd_iso(const int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                                       const float *rays, float occ, long npix, int K, float *weight, int64_t *valid_num,
                                       voge_stream_t stream) {
-  if (npix < 0 || K <= 0 || (K & 1)) return VOGE_ERR_BAD_ARG;
+  if (npix < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K || K > kCompThreads) return VOGE_ERR_K_TOO_LARGE;
   if (npix == 0) return 0;
   if (!idx || !cnt || !len || !records || !rays || !weight || !valid_num) return VOGE_ERR_BAD_ARG;

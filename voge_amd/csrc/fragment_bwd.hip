@@ -37,14 +37,14 @@ constexpr int kFbNE = VOGE_FB_NE;  // table entries per wave
 #endif
 constexpr int kFbGW = VOGE_FB_GW, kFbGH = VOGE_FB_GH, kFbG = kFbGW * kFbGH;
 static_assert(kFbG <= 64 && (kFbGW & (kFbGW - 1)) == 0, "a group's pixels are the lanes of one wave; GW a power of two");
-constexpr int kFbRowsLds = 2 * 64 + 4 * kFbG;      // a round's padded rows: 64 lanes' slots + two sentinel pairs per pixel
-
-template <int NV4>
+template <int NV4, int NS>
 struct FragBwdLds {
   // key = Gaussian index; values: (g_mu, g_a), (w g_rgb, -) for A = a I [NV4 = 2];
-  //                               (g_mu, g_A[0]), g_A[1..4], g_A[5..8], (w g_rgb, -) for a full 3x3 A [NV4 = 4]
+  //                               (g_mu, g_A[0]), g_A[1..4], g_A[5..8], (w g_rgb, -) for a full 3x3 A [NV4 = 4];
+  //                               without the colour term (SRC = 1): NV4 = 1 | 3
+  static constexpr int kRows = NS * 64 + 4 * kFbG;      // a round's padded rows: 64 lanes' slots + two sentinel pairs per pixel
   WaveTable<kFbNE, NV4> tab;
-  float len[kFbRowsLds], sp[kFbRowsLds], E[kFbRowsLds], u[kFbRowsLds];
+  float len[kRows], sp[kRows], E[kRows], u[kRows];
   unsigned rmax[kFbG];            // per pixel of the round: its window radius (compn_bwd_wave)
 };
 
@@ -57,30 +57,41 @@ struct FragBwdLds {
 #ifndef VOGE_FB_WPE
 #define VOGE_FB_WPE 4      // capping the registers for 5 / 6 waves per SIMD spills and is slower
 #endif
-// C: colour channels (1..4); OffT: uint32_t when every BYTE offset into the [pix][K] arrays fits 32 bits (the loads
+// SRC: where the gradient of the weights comes from.
+//   0: the shade stage is part of the pass (colours, rgb, wsum, bg, g_img given): g_w = <g_rgb, colour> + g_sum_w, and the
+//      colours' own gradient w g_rgb rides in the table (C: colour channels, 1..4);
+//   1: g_weight [pix][K] is given by whoever consumed the weights (merge_final, get_silhouette, any torch expression),
+//      element (p, k) at g_weight[p * gw_stride_pix + k * gw_stride_k] (K, 1 contiguous; (1, 0) for a per-pixel value
+//      broadcast over the slots, which is what a silhouette loss alone produces), plus the gradient of vert_hit_length
+//      (g_hitlen, contiguous or NULL) added to the trace's g_len; C = 0, no colour term.
+// NS: slots per lane (2; 4 for lists of more than 128 slots, so that a pixel's lanes still fit one wave).
+// OffT: uint32_t when every BYTE offset into the [pix][K] arrays fits 32 bits (the loads
 // then take scalar base + 32-bit lane offset and the address arithmetic leaves the vector unit), else size_t.
 // ISO: every Gaussian is A = a I (rec = [P] (mu, a)); otherwise rec = [P][3] packed (mu, A) as in trace_bwd.hip.
 // NOAD (ISO only): the forward kept no act / dsd (voge_fragments_fwd_iso* with act = dsd = NULL); they are re-derived
 // from the records, the ray and len with the forward's own operations (pair_eval_iso_at): 8 bytes per slot less to read.
-template <int C, typename OffT, bool ISO, bool NOAD>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISO ? VOGE_FB_WPE : 3)))
+// K need not be a multiple of NS: `vec` (uniform) says whether a lane's group is aligned and inside its pixel's row
+// (wide loads) or is read slot by slot.
+template <int SRC, int C, int NS, typename OffT, bool ISO, bool NOAD>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS == 4 ? 2 : (ISO ? VOGE_FB_WPE : 3))))
 fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
                         const float *__restrict__ colors, const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt,
                         const float *__restrict__ weight, const float *__restrict__ act, const float *__restrict__ len,
                         const float *__restrict__ dsd, const float *__restrict__ rgb, const float *__restrict__ wsum,
                         const float *__restrict__ bg, const float thr, const float *__restrict__ g_img, const long gs_pix,
-                        const long gs_c, const float occ,
+                        const long gs_c, const float *__restrict__ g_hitlen, const float occ,
                         const int P, const long nrows, const int W, const int K, const long Nattr,
-                        float *__restrict__ acc /* [P][8] (ISO) | [P][16], zeroed */) {
-  constexpr int NS = 2;
-  constexpr int NV4 = ISO ? 2 : 4, NACC = 4 * NV4;
-  __shared__ __attribute__((aligned(16))) FragBwdLds<NV4> L;
+                        float *__restrict__ acc /* [P][NACC], zeroed */) {
+  static_assert(NS == 2 || NS == 4, "a lane owns one or two aligned pairs of slots");
+  constexpr int NV4 = SRC == 0 ? (ISO ? 2 : 4) : (ISO ? 1 : 3), NACC = 4 * NV4;
+  __shared__ __attribute__((aligned(16))) FragBwdLds<NV4, NS> L;
   float *const Llen = L.len, *const Lsp = L.sp, *const LE = L.E, *const Lu = L.u;
   const int lane = threadIdx.x;
   const int blocks_x = (W + kFbGW - 1) / kFbGW;
   const long blk = blockIdx.x;
   const int x0 = (int)(blk % blocks_x) * kFbGW;
   const long y0 = (blk / blocks_x) * kFbGH;
+  const bool vec = (K % NS) == 0;
   // the group's hit counts -> lanes per pixel
   const int gx = x0 + (lane & (kFbGW - 1));
   const long gy = y0 + lane / kFbGW;
@@ -103,30 +114,69 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     const int lead = __shfl(lead_g, on ? pk.p : 0, 64);
     const int k0 = NS * q;
     const OffT pix = on ? (OffT)((y0 + pk.p / kFbGW) * W + x0 + (pk.p & (kFbGW - 1))) : (OffT)0;
-    const OffT fb = (pix * (OffT)K + (OffT)k0) * (OffT)4;      // byte offset of the lane's pair in the [pix][K] arrays
+    const OffT fb = (pix * (OffT)K + (OffT)k0) * (OffT)4;      // byte offset of the lane's group in the [pix][K] arrays
     const int r0 = NS * pk.s0 + 4 * pk.ord, RS = NS * LP + 4;
     const int d0 = on ? r0 + 2 + k0 : 2;
-    // ---- the lane's two slots ----
+    // ---- the lane's slots ----
     int id[NS];
-    float wv[NS], lm[NS], sm[NS], em[NS];
+    float wv[NS], lm[NS], sm[NS], em[NS], gwv[NS];
     bool live[NS];
 #pragma unroll
-    for (int a = 0; a < NS; ++a) { id[a] = -1; wv[a] = 0.f; lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.f; live[a] = on && (k0 + a < lead); }
+    for (int a = 0; a < NS; ++a) {
+      id[a] = -1; wv[a] = 0.f; lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.f; gwv[a] = 0.f;
+      live[a] = on && (k0 + a < lead);
+    }
     float dx = 0.f, dy = 0.f, dz = 0.f;
     if (on) {
       const float3 dv = at_bytes<float3>(rays, pix * (OffT)12);
       dx = dv.x; dy = dv.y; dz = dv.z;
     }
     float4 rc[NS][ISO ? 1 : 3];
-    if (live[0]) {              // 8-byte accesses (K is even: the pair is aligned and inside the pixel's row)
-      const int2 i2 = at_bytes<int2>(idx, fb);
-      const v2f w2 = at_bytes<v2f>(weight, fb), l2 = at_bytes<v2f>(len, fb);
-      id[0] = i2.x; wv[0] = w2.x; lm[0] = l2.x;
-      if (live[1]) { id[1] = i2.y; wv[1] = w2.y; lm[1] = l2.y; }
+    float av[NS], dv2[NS];
+#pragma unroll
+    for (int a = 0; a < NS; ++a) { av[a] = 0.f; dv2[a] = 0.f; }
+    if (live[0]) {
+      if (vec) {                // wide accesses: the group is aligned and inside the pixel's row
+#pragma unroll
+        for (int h2 = 0; h2 < NS / 2; ++h2) {
+          const OffT fo = fb + (OffT)(8 * h2);
+          if (h2 > 0 && !live[2 * h2]) break;
+          const int2 i2 = at_bytes<int2>(idx, fo);
+          const v2f w2 = at_bytes<v2f>(weight, fo), l2 = at_bytes<v2f>(len, fo);
+          id[2 * h2] = i2.x; wv[2 * h2] = w2.x; lm[2 * h2] = l2.x;
+          if (live[2 * h2 + 1]) { id[2 * h2 + 1] = i2.y; wv[2 * h2 + 1] = w2.y; lm[2 * h2 + 1] = l2.y; }
+          if (!NOAD) {
+            const v2f a2 = at_bytes<v2f>(act, fo), d2 = at_bytes<v2f>(dsd, fo);
+            av[2 * h2] = a2.x; av[2 * h2 + 1] = a2.y; dv2[2 * h2] = d2.x; dv2[2 * h2 + 1] = d2.y;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < NS; ++a) {
+          if (!live[a]) break;
+          const OffT fo = fb + (OffT)(4 * a);
+          id[a] = at_bytes<int>(idx, fo); wv[a] = at_bytes<float>(weight, fo); lm[a] = at_bytes<float>(len, fo);
+          if (!NOAD) { av[a] = at_bytes<float>(act, fo); dv2[a] = at_bytes<float>(dsd, fo); }
+        }
+      }
       if (!NOAD) {
-        const v2f a2 = at_bytes<v2f>(act, fb), d2 = at_bytes<v2f>(dsd, fb);
-        em[0] = FAST_EXP(-a2.x); sm[0] = FAST_SQRT(d2.x + 1e-10f);
-        if (live[1]) { em[1] = FAST_EXP(-a2.y); sm[1] = FAST_SQRT(d2.y + 1e-10f); }
+#pragma unroll
+        for (int a = 0; a < NS; ++a)
+          if (live[a]) { em[a] = FAST_EXP(-av[a]); sm[a] = FAST_SQRT(dv2[a] + 1e-10f); }
+      }
+      if (SRC == 1 && g_img != nullptr) {      // the consumers' gradient of the weights
+        if (vec && gs_c == 1 && gs_pix == (long)K) {
+#pragma unroll
+          for (int h2 = 0; h2 < NS / 2; ++h2) {
+            if (h2 > 0 && !live[2 * h2]) break;
+            const v2f g2 = at_bytes<v2f>(g_img, fb + (OffT)(8 * h2));
+            gwv[2 * h2] = g2.x; gwv[2 * h2 + 1] = g2.y;
+          }
+        } else {
+#pragma unroll
+          for (int a = 0; a < NS; ++a)
+            if (live[a]) gwv[a] = g_img[(long)pix * gs_pix + (long)(k0 + a) * gs_c];
+        }
       }
     }
     if (NOAD) {                 // act / dsd from the records (gathered here once, used again by the trace terms below)
@@ -148,7 +198,7 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
       const bool ok = live[a] && id[a] >= 0 && id[a] < P;
       live[a] = ok;
       col[a][0] = col[a][1] = col[a][2] = col[a][3] = 0.0f;
-      if (ok && id[a] < Nattr && !(VOGE_FB_ABL & 4)) {
+      if (SRC == 0 && ok && id[a] < Nattr && !(VOGE_FB_ABL & 4)) {
         const uint32_t o = (uint32_t)id[a] * (uint32_t)(4 * C);      // (bytes; Nattr * C < 2^30: host)
         if (C == 3) {
           const float3 v = at_bytes<float3>(colors, o);
@@ -163,7 +213,7 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
       }
     }
     float gr[4] = {0.f, 0.f, 0.f, 0.f}, g_sum_w = 0.0f;
-    if (on) {
+    if (SRC == 0 && on) {
       const OffT pb = pix * (OffT)4;
       const float ws = at_bytes<float>(wsum, pb);
       float sil = fminf(ws, 1.0f);
@@ -182,15 +232,21 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     float um[NS];
 #pragma unroll
     for (int a = 0; a < NS; ++a) {
-      const float gw = live[a] ? fmaf(gr[3], col[a][3], fmaf(gr[2], col[a][2], fmaf(gr[1], col[a][1], fmaf(gr[0], col[a][0], g_sum_w)))) : 0.0f;
+      float gw;
+      if (SRC == 0) gw = live[a] ? fmaf(gr[3], col[a][3], fmaf(gr[2], col[a][2], fmaf(gr[1], col[a][1], fmaf(gr[0], col[a][0], g_sum_w)))) : 0.0f;
+      else gw = live[a] ? gwv[a] : 0.0f;
       um[a] = gw * wv[a];
     }
     // ---- composite backward (closed form, composite_core.h) ----
     if (on) {
-      *reinterpret_cast<v2f *>(Llen + d0) = (v2f){lm[0], lm[1]};
-      *reinterpret_cast<v2f *>(Lsp + d0) = (v2f){sm[0] * kCs, sm[1] * kCs};
-      *reinterpret_cast<v2f *>(LE + d0) = (v2f){em[0] * (sm[0] * kCs), em[1] * (sm[1] * kCs)};
-      *reinterpret_cast<v2f *>(Lu + d0) = splat(0.0f);
+#pragma unroll
+      for (int h2 = 0; h2 < NS / 2; ++h2) {
+        const int a = 2 * h2;
+        *reinterpret_cast<v2f *>(Llen + d0 + a) = (v2f){lm[a], lm[a + 1]};
+        *reinterpret_cast<v2f *>(Lsp + d0 + a) = (v2f){sm[a] * kCs, sm[a + 1] * kCs};
+        *reinterpret_cast<v2f *>(LE + d0 + a) = (v2f){em[a] * (sm[a] * kCs), em[a + 1] * (sm[a + 1] * kCs)};
+        *reinterpret_cast<v2f *>(Lu + d0 + a) = splat(0.0f);
+      }
       if (q < 2) {      // the sentinel pair in front of the pixel's row and the one behind it
         for (int t2 = q; t2 < 2; t2 += LP) {
           Llen[r0 + t2] = -kBig; Lsp[r0 + t2] = 1.0f; LE[r0 + t2] = 0.0f; Lu[r0 + t2] = 0.0f;
@@ -208,6 +264,11 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
                        VOGE_FB_LDS_RMAX ? &L.rmax[on ? pk.ord : 0] : nullptr);
 #endif
     __builtin_amdgcn_wave_barrier();      // the rows are rewritten by the next round
+    if (SRC == 1 && g_hitlen != nullptr) {      // vert_hit_length is the trace's len itself (Aggregation.py:107)
+#pragma unroll
+      for (int a = 0; a < NS; ++a)
+        if (live[a]) gl[a] += at_bytes<float>(g_hitlen, fb + (OffT)(4 * a));
+    }
     // ---- trace backward terms (isotropic: trace_bwd.hip) + the colour term, one table entry per Gaussian.  (The
     // (mu, a) records are gathered only now: held across the composite they cost the kernel a wave per SIMD.) ----
     if (!NOAD)
@@ -265,14 +326,14 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
           val[ISO ? 0 : 1] = make_float4(o[4], o[5], o[6], o[7]);
           val[ISO ? 0 : 2] = make_float4(o[8], o[9], o[10], o[11]);
         }
-        val[NV4 - 1] = make_float4(wv[a] * gr[0], wv[a] * gr[1], wv[a] * gr[2], wv[a] * gr[3]);
+        if (SRC == 0) val[NV4 - 1] = make_float4(wv[a] * gr[0], wv[a] * gr[1], wv[a] * gr[2], wv[a] * gr[3]);
         go = false;
 #pragma unroll
         for (int r = 0; r < NV4; ++r) go = go || (val[r].x != 0.f || val[r].y != 0.f || val[r].z != 0.f || val[r].w != 0.f);
       }
       if (!__any(go)) continue;     // uniform
 #if VOGE_FB_ABL & 1       // (timing experiment: no table, nothing accumulated)
-      if (go && val[0].x == 1.2345f && val[1].y == 3.21f) acc[id[a]] = val[0].w + val[1].x;
+      if (go && val[0].x == 1.2345f && val[NV4 - 1].y == 3.21f) acc[id[a]] = val[0].w + val[NV4 - 1].x;
       continue;
 #endif
       const int slot = wt_find(L.tab, id[a], go);
@@ -287,34 +348,36 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
       }
     }
   }
-  {   // flush: NACC (8 | 16) adjacent lanes per entry -> the 32 | 64 bytes of acc[p]: lane-coalesced atomics
-    const int c = lane & (NACC - 1);
+  {   // flush: NACC (4 | 8 | 12 | 16) adjacent lanes per entry -> the bytes of acc[p]: lane-coalesced atomics
+    constexpr int EPI = 64 / NACC;      // entries per iteration (12 sums: five entries, four idle lanes)
+    const int e = lane / NACC, c = lane - e * NACC;
     const float *vals = reinterpret_cast<const float *>(L.tab.vals);
     const int n = wt_compact(L.tab, lane);
     const volatile int *list = L.tab.owner;
-    for (int i = lane / NACC; i < n; i += 64 / NACC) {
+    for (int i = e; i < n && e < EPI; i += EPI) {
       const int s = list[i];
       unsafeAtomicAdd(acc + NACC * (size_t)L.tab.keys[s] + c, vals[s * NACC + c]);
     }
   }
 }
 
-// acc [P][8] -> the gradients of what the caller passed in: verts / sigmas through the view's chain rule (and the sum
-// over the batch when one Gaussian set is shared by all views), colours [Nattr][C].
+// acc [P][S] (S = 8: (g_mu, g_a | w g_rgb), S = 4: (g_mu, g_a)) -> the gradients of what the caller passed in: verts /
+// sigmas through the view's chain rule (and the sum over the batch when one Gaussian set is shared by all views),
+// colours [Nattr][C].
 __global__ void __launch_bounds__(256)
-fragment_bwd_finish_kernel(const float *__restrict__ acc, const float *__restrict__ a_in, const int P, const int N, const int B,
-                           const IsoView view, const int C, const long Nattr, float *__restrict__ g_mus,
+fragment_bwd_finish_kernel(const float *__restrict__ acc, const int S, const float *__restrict__ a_in, const int P, const int N,
+                           const int B, const IsoView view, const int C, const long Nattr, float *__restrict__ g_mus,
                            float *__restrict__ g_a, float *__restrict__ g_colors) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g_colors != nullptr && g < Nattr) {
-    for (int c = 0; c < C; ++c) g_colors[(size_t)g * C + c] = (g < P) ? acc[8 * (size_t)g + 4 + c] : 0.0f;
+    for (int c = 0; c < C; ++c) g_colors[(size_t)g * C + c] = (g < P) ? acc[S * (size_t)g + 4 + c] : 0.0f;
   }
   const int n_out = view.shared ? N : P;
   if (g >= n_out || g_mus == nullptr) return;
-  float4 v = *reinterpret_cast<const float4 *>(acc + 8 * (size_t)g);
+  float4 v = *reinterpret_cast<const float4 *>(acc + S * (size_t)g);
   if (view.shared)
     for (int b = 1; b < B; ++b) {
-      const float4 w = *reinterpret_cast<const float4 *>(acc + 8 * ((size_t)b * N + g));
+      const float4 w = *reinterpret_cast<const float4 *>(acc + S * ((size_t)b * N + g));
       v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
     }
   g_mus[3 * (size_t)g] = v.x; g_mus[3 * (size_t)g + 1] = v.y; g_mus[3 * (size_t)g + 2] = v.z;
@@ -327,25 +390,24 @@ fragment_bwd_finish_kernel(const float *__restrict__ acc, const float *__restric
 // General 3x3 forms: mus [P,3] + isigmas [P,9] -> 3 x float4 per Gaussian (one gather stream), acc [P][16] zeroed
 __global__ void __launch_bounds__(256)
 fragment_bwd_pack_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const int P, float4 *__restrict__ rec,
-                         float4 *__restrict__ acc) {
+                         float4 *__restrict__ acc, const int S4 /* float4s of sums per Gaussian: 4 | 3 */) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= P) return;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) acc[4 * (size_t)g + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = 0; q < S4; ++q) acc[S4 * (size_t)g + q] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float *m = mus + 3 * (size_t)g, *A = isg + 9 * (size_t)g;
   rec[3 * (size_t)g + 0] = make_float4(m[0], m[1], m[2], A[0]);
   rec[3 * (size_t)g + 1] = make_float4(A[1], A[2], A[3], A[4]);
   rec[3 * (size_t)g + 2] = make_float4(A[5], A[6], A[7], A[8]);
 }
-// acc [P][16] -> g_mus [P,3], g_isigmas [P,9], g_colors [Nattr,C]
+// acc [P][S] (S = 16 with the colour term, 12 without) -> g_mus [P,3], g_isigmas [P,9], g_colors [Nattr,C]
 __global__ void __launch_bounds__(256)
-fragment_bwd_finish_general_kernel(const float *__restrict__ acc, const int P, const int C, const long Nattr,
+fragment_bwd_finish_general_kernel(const float *__restrict__ acc, const int S, const int P, const int C, const long Nattr,
                                    float *__restrict__ g_mus, float *__restrict__ g_isg, float *__restrict__ g_colors) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long g = t >> 4;
   const int c = (int)(t & 15);
-  if (g >= P && g >= Nattr) return;
-  const float v = (g < P) ? acc[t] : 0.0f;
+  if ((g >= P && g >= Nattr) || c >= S) return;
+  const float v = (g < P) ? acc[g * S + c] : 0.0f;
   if (c < 3) { if (g < P && g_mus != nullptr) g_mus[3 * g + c] = v; }
   else if (c < 12) { if (g < P && g_isg != nullptr) g_isg[9 * g + (c - 3)] = v; }
   else if (c - 12 < C && g < Nattr && g_colors != nullptr) g_colors[g * C + (c - 12)] = v;
@@ -388,8 +450,41 @@ extern "C" int voge_fragment_act_dsd_iso(const float *records, const float *rays
   return launch_status();
 }
 
-// (the isotropic form uses the first 32 bytes per Gaussian; the general one 48 of packed records + 64 of sums)
+// (the isotropic forms use the first 32 | 16 bytes per Gaussian; the general ones 48 of packed records + 64 | 48 of sums)
 extern "C" size_t voge_fragment_bwd_workspace_bytes(int P) { return P <= 0 ? 0 : (size_t)P * 112; }
+
+namespace {
+struct FbArgs {      // what every form of the fused backward hands its kernel
+  const float4 *rec; const float *rays, *colors; const int32_t *idx, *cnt; const float *weight, *act, *len, *dsd, *rgb, *wsum, *bg;
+  float thr; const float *g; long gs_pix, gs_c; const float *g_hitlen; float occ; int P; long nrows; int W, K; long Nattr; float *acc;
+};
+template <int SRC, int C, int NS, typename OffT, bool ISO, bool NOAD>
+void fb_launch(const FbArgs &a, hipStream_t st) {
+  const long blocks = (long)((a.W + kFbGW - 1) / kFbGW) * ((a.nrows + kFbGH - 1) / kFbGH);
+  hipLaunchKernelGGL((fragment_bwd_kernel<SRC, C, NS, OffT, ISO, NOAD>), dim3((unsigned)blocks), dim3(64), 0, st, a.rec, a.rays,
+                     a.colors, a.idx, a.cnt, a.weight, a.act, a.len, a.dsd, a.rgb, a.wsum, a.bg, a.thr, a.g, a.gs_pix, a.gs_c,
+                     a.g_hitlen, a.occ, a.P, a.nrows, a.W, a.K, a.Nattr, a.acc);
+}
+template <int SRC, int C, int NS, bool ISO>
+void fb_launch_off(const FbArgs &a, hipStream_t st) {
+  const bool small = (double)a.nrows * a.W * a.K < (double)(1l << 30);      // every byte offset fits 32 bits
+  if (ISO && a.act == nullptr) { if (small) fb_launch<SRC, C, NS, uint32_t, ISO, ISO>(a, st); else fb_launch<SRC, C, NS, size_t, ISO, ISO>(a, st); }
+  else { if (small) fb_launch<SRC, C, NS, uint32_t, ISO, false>(a, st); else fb_launch<SRC, C, NS, size_t, ISO, false>(a, st); }
+}
+template <bool ISO>
+void fb_launch_shade(const FbArgs &a, int C, hipStream_t st) {
+  switch (C) {
+    case 1: fb_launch_off<0, 1, 2, ISO>(a, st); break;
+    case 2: fb_launch_off<0, 2, 2, ISO>(a, st); break;
+    case 3: fb_launch_off<0, 3, 2, ISO>(a, st); break;
+    default: fb_launch_off<0, 4, 2, ISO>(a, st); break;
+  }
+}
+template <bool ISO>
+void fb_launch_gw(const FbArgs &a, hipStream_t st) {
+  if (a.K <= 128) fb_launch_off<1, 0, 2, ISO>(a, st); else fb_launch_off<1, 0, 4, ISO>(a, st);
+}
+}  // namespace
 
 extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
                                            const float *rays, const float *colors, const int32_t *idx, const int32_t *cnt,
@@ -400,7 +495,7 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
                                            float *g_sigmas, float *g_colors, voge_stream_t stream) {
   if (B < 0 || N < 0 || nrows < 0 || W < 0 || K <= 0 || C <= 0 || C > 4 || Nattr < 0 || sigma_mode < 0 || sigma_mode > 2)
     return VOGE_ERR_BAD_ARG;
-  if ((K & 1) != 0 || K > 128) return VOGE_ERR_K_TOO_LARGE;      // a lane owns an aligned pair of slots; a pixel fits a wave
+  if (K > 128) return VOGE_ERR_K_TOO_LARGE;      // a lane owns a pair of slots; a pixel's lanes fit one wave
   const int P = B * N;
   hipStream_t st = (hipStream_t)stream;
   if (P == 0 || nrows * W == 0) {
@@ -412,31 +507,15 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
   if ((act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;      // both or neither (neither: re-derived from the records)
   if ((g_verts == nullptr) != (g_sigmas == nullptr) || (sigma_mode == 2 && g_sigmas && !sigmas)) return VOGE_ERR_BAD_ARG;
   if (workspace_bytes < (size_t)P * 32) return VOGE_ERR_WORKSPACE;
+  if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
   float *acc = reinterpret_cast<float *>(workspace);
   hipError_t e = hipMemsetAsync(acc, 0, (size_t)P * 32, st);
   if (e != hipSuccess) return (int)e;
-  const long blocks = (long)((W + kFbGW - 1) / kFbGW) * ((nrows + kFbGH - 1) / kFbGH);
-  if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
-  const bool small = (double)nrows * W * K < (double)(1l << 30);
-#define VOGE_LAUNCH_FB(CC, OT, NA)                                                                                            \
-  hipLaunchKernelGGL((fragment_bwd_kernel<CC, OT, true, NA>), dim3((unsigned)blocks), dim3(64), 0, st,                    \
-                     reinterpret_cast<const float4 *>(records), rays, colors, idx, cnt, weight, act, len, dsd, rgb, wsum, bg, thr, \
-                     g_img, g_stride_pix, g_stride_c, occ, P, nrows, W, K, Nattr, acc)
-#define VOGE_LAUNCH_FB_C(CC)                                                                                               \
-  do {                                                                                                                    \
-    if (act == nullptr) { if (small) VOGE_LAUNCH_FB(CC, uint32_t, true); else VOGE_LAUNCH_FB(CC, size_t, true); }         \
-    else { if (small) VOGE_LAUNCH_FB(CC, uint32_t, false); else VOGE_LAUNCH_FB(CC, size_t, false); }                      \
-  } while (0)
-  switch (C) {
-    case 1: VOGE_LAUNCH_FB_C(1); break;
-    case 2: VOGE_LAUNCH_FB_C(2); break;
-    case 3: VOGE_LAUNCH_FB_C(3); break;
-    default: VOGE_LAUNCH_FB_C(4); break;
-  }
-#undef VOGE_LAUNCH_FB_C
-#undef VOGE_LAUNCH_FB
+  const FbArgs a{reinterpret_cast<const float4 *>(records), rays, colors, idx, cnt, weight, act, len, dsd, rgb, wsum, bg, thr, g_img,
+                 g_stride_pix, g_stride_c, nullptr, occ, P, nrows, W, K, Nattr, acc};
+  fb_launch_shade<true>(a, C, st);
   const long n_fin = (Nattr > P) ? Nattr : P;
-  hipLaunchKernelGGL(fragment_bwd_finish_kernel, dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, st, acc, sigmas, P, N, B,
+  hipLaunchKernelGGL(fragment_bwd_finish_kernel, dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, st, acc, 8, sigmas, P, N, B,
                      IsoView{nullptr, shared ? 1 : 0, sigma_mode}, C, Nattr, g_verts, g_sigmas, g_colors);
   return launch_status();
 }
@@ -449,7 +528,7 @@ extern "C" int voge_fragment_shade_bwd(const float *mus, const float *isigmas, c
                                        size_t workspace_bytes, float *g_mus, float *g_isigmas, float *g_colors,
                                        voge_stream_t stream) {
   if (P < 0 || nrows < 0 || W < 0 || K <= 0 || C <= 0 || C > 4 || Nattr < 0) return VOGE_ERR_BAD_ARG;
-  if ((K & 1) != 0 || K > 128) return VOGE_ERR_K_TOO_LARGE;
+  if (K > 128) return VOGE_ERR_K_TOO_LARGE;
   hipStream_t st = (hipStream_t)stream;
   if (P == 0 || nrows * W == 0) {
     if (g_colors && Nattr > 0) return (int)hipMemsetAsync(g_colors, 0, sizeof(float) * (size_t)Nattr * C, st);
@@ -464,23 +543,76 @@ extern "C" int voge_fragment_shade_bwd(const float *mus, const float *isigmas, c
   float4 *rec = reinterpret_cast<float4 *>(workspace);
   float *acc = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (size_t)P * 48);
   hipLaunchKernelGGL(fragment_bwd_pack_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, mus, isigmas, P, rec,
-                     reinterpret_cast<float4 *>(acc));
-  const long blocks = (long)((W + kFbGW - 1) / kFbGW) * ((nrows + kFbGH - 1) / kFbGH);
-  const bool small = (double)nrows * W * K < (double)(1l << 30);
-#define VOGE_LAUNCH_FBG(CC, OT)                                                                                           \
-  hipLaunchKernelGGL((fragment_bwd_kernel<CC, OT, false, false>), dim3((unsigned)blocks), dim3(64), 0, st, rec, rays, colors, idx, cnt,   \
-                     weight, act, len, dsd, rgb, wsum, bg, thr, g_img, g_stride_pix, g_stride_c, occ, P, nrows, W, K, Nattr, acc)
-#define VOGE_LAUNCH_FBG_C(CC) do { if (small) VOGE_LAUNCH_FBG(CC, uint32_t); else VOGE_LAUNCH_FBG(CC, size_t); } while (0)
-  switch (C) {
-    case 1: VOGE_LAUNCH_FBG_C(1); break;
-    case 2: VOGE_LAUNCH_FBG_C(2); break;
-    case 3: VOGE_LAUNCH_FBG_C(3); break;
-    default: VOGE_LAUNCH_FBG_C(4); break;
-  }
-#undef VOGE_LAUNCH_FBG_C
-#undef VOGE_LAUNCH_FBG
+                     reinterpret_cast<float4 *>(acc), 4);
+  const FbArgs a{rec, rays, colors, idx, cnt, weight, act, len, dsd, rgb, wsum, bg, thr, g_img, g_stride_pix, g_stride_c, nullptr, occ,
+                 P, nrows, W, K, Nattr, acc};
+  fb_launch_shade<false>(a, C, st);
   const long n_fin = (Nattr > P) ? Nattr : P;
-  hipLaunchKernelGGL(fragment_bwd_finish_general_kernel, dim3((unsigned)((n_fin * 16 + 255) / 256)), dim3(256), 0, st, acc, P, C,
+  hipLaunchKernelGGL(fragment_bwd_finish_general_kernel, dim3((unsigned)((n_fin * 16 + 255) / 256)), dim3(256), 0, st, acc, 16, P, C,
                      Nattr, g_mus, g_isigmas, g_colors);
+  return launch_status();
+}
+
+// ---- the same pass driven by the gradient of the weights itself (any consumer) ----
+extern "C" int voge_fragment_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode, const float *rays,
+                                     const int32_t *idx, const int32_t *cnt, const float *weight, const float *act,
+                                     const float *len, const float *dsd, const float *g_weight, long gw_stride_pix,
+                                     long gw_stride_k, const float *g_hitlen, float occ, int B, int N, long nrows, int W, int K,
+                                     void *workspace, size_t workspace_bytes, float *g_verts, float *g_sigmas,
+                                     voge_stream_t stream) {
+  if (B < 0 || N < 0 || nrows < 0 || W < 0 || K <= 0 || sigma_mode < 0 || sigma_mode > 2) return VOGE_ERR_BAD_ARG;
+  if (K > VOGE_MAX_K) return VOGE_ERR_K_TOO_LARGE;
+  const int P = B * N;
+  hipStream_t st = (hipStream_t)stream;
+  const long n_out = shared ? N : P;
+  if (n_out == 0) return 0;      // no Gaussians: nothing to write
+  if (!g_verts || !g_sigmas) return VOGE_ERR_BAD_ARG;
+  if (P == 0 || nrows * W == 0) {
+    hipError_t e0 = hipMemsetAsync(g_verts, 0, sizeof(float) * 3 * (size_t)n_out, st);
+    if (e0 == hipSuccess) e0 = hipMemsetAsync(g_sigmas, 0, sizeof(float) * (size_t)n_out, st);
+    return (int)e0;
+  }
+  if (!records || !rays || !idx || !cnt || !weight || !len || !workspace) return VOGE_ERR_BAD_ARG;
+  if ((act == nullptr) != (dsd == nullptr) || (sigma_mode == 2 && !sigmas)) return VOGE_ERR_BAD_ARG;
+  if (workspace_bytes < (size_t)P * 16) return VOGE_ERR_WORKSPACE;
+  if (P >= (1 << 26)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the record gathers
+  float *acc = reinterpret_cast<float *>(workspace);
+  hipError_t e = hipMemsetAsync(acc, 0, (size_t)P * 16, st);
+  if (e != hipSuccess) return (int)e;
+  const FbArgs a{reinterpret_cast<const float4 *>(records), rays, nullptr, idx, cnt, weight, act, len, dsd, nullptr, nullptr, nullptr,
+                 -1.0f, g_weight, gw_stride_pix, gw_stride_k, g_hitlen, occ, P, nrows, W, K, 0, acc};
+  fb_launch_gw<true>(a, st);
+  hipLaunchKernelGGL(fragment_bwd_finish_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, acc, 4, sigmas, P, N, B,
+                     IsoView{nullptr, shared ? 1 : 0, sigma_mode}, 0, 0l, g_verts, g_sigmas, (float *)nullptr);
+  return launch_status();
+}
+
+extern "C" int voge_fragment_bwd(const float *mus, const float *isigmas, const float *rays, const int32_t *idx,
+                                 const int32_t *cnt, const float *weight, const float *act, const float *len,
+                                 const float *dsd, const float *g_weight, long gw_stride_pix, long gw_stride_k,
+                                 const float *g_hitlen, float occ, int P, long nrows, int W, int K, void *workspace,
+                                 size_t workspace_bytes, float *g_mus, float *g_isigmas, voge_stream_t stream) {
+  if (P < 0 || nrows < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
+  if (K > VOGE_MAX_K) return VOGE_ERR_K_TOO_LARGE;
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 0) return 0;      // no Gaussians: nothing to write
+  if (!g_mus || !g_isigmas) return VOGE_ERR_BAD_ARG;
+  if (nrows * W == 0) {
+    hipError_t e0 = hipMemsetAsync(g_mus, 0, sizeof(float) * 3 * (size_t)P, st);
+    if (e0 == hipSuccess) e0 = hipMemsetAsync(g_isigmas, 0, sizeof(float) * 9 * (size_t)P, st);
+    return (int)e0;
+  }
+  if (!mus || !isigmas || !rays || !idx || !cnt || !weight || !act || !len || !dsd || !workspace) return VOGE_ERR_BAD_ARG;
+  if (workspace_bytes < voge_fragment_bwd_workspace_bytes(P)) return VOGE_ERR_WORKSPACE;
+  if (P >= (1 << 26)) return VOGE_ERR_BAD_ARG;
+  float4 *rec = reinterpret_cast<float4 *>(workspace);
+  float *acc = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (size_t)P * 48);
+  hipLaunchKernelGGL(fragment_bwd_pack_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, mus, isigmas, P, rec,
+                     reinterpret_cast<float4 *>(acc), 3);
+  const FbArgs a{rec, rays, nullptr, idx, cnt, weight, act, len, dsd, nullptr, nullptr, nullptr, -1.0f, g_weight, gw_stride_pix,
+                 gw_stride_k, g_hitlen, occ, P, nrows, W, K, 0, acc};
+  fb_launch_gw<false>(a, st);
+  hipLaunchKernelGGL(fragment_bwd_finish_general_kernel, dim3((unsigned)(((long)P * 16 + 255) / 256)), dim3(256), 0, st, acc, 12, P, 0,
+                     0l, g_mus, g_isigmas, (float *)nullptr);
   return launch_status();
 }

@@ -468,6 +468,15 @@ blend_bwd_kernel(const float *__restrict__ rgb, const float *__restrict__ weight
   }
 }
 
+// get_silhouette backward (VoGE/Renderer.py:157-159): d min(sum_k w_k, 1) / d w_k = pass(sum w), the same for every
+// slot of the pixel -- ONE value per pixel; the caller hands it to autograd as a [.., K] view with stride 0.
+__global__ void __launch_bounds__(256)
+silhouette_bwd_kernel(const float *__restrict__ wsum, const float *__restrict__ g_sil, const long npix,
+                      float *__restrict__ g_pix) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < npix) g_pix[p] = g_sil[p] * clamp1_pass(wsum[p]);
+}
+
 static inline unsigned shade_grid(long npix) {   // blend_bwd_kernel: kShadePixPerWave pixels per wave
   const long waves = (npix + kShadePixPerWave - 1) / kShadePixPerWave;
   long b = (waves + 3) / 4;
@@ -578,6 +587,24 @@ extern "C" int voge_blend_bwd(const float *rgb, const float *weight, const float
   if (!rgb || !weight || !bg || !g_out) return VOGE_ERR_BAD_ARG;
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(shade_grid(npix)), dim3(256), 0, (hipStream_t)stream, rgb, weight, bg,
                      thr, g_out, npix, K, C, g_rgb, g_weight_add);
+  return launch_status();
+}
+
+extern "C" int voge_silhouette_fwd(const float *weight, long npix, int K, float *sil, float *wsum, voge_stream_t stream) {
+  if (npix < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
+  if (npix == 0) return 0;
+  if (!weight || !sil) return VOGE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(shade_fwd_kernel, dim3(run_grid(npix)), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr,
+                     weight, nullptr, nullptr, nullptr, -1.0f, npix, K, 0, 0L, 0, nullptr, nullptr, sil, wsum);
+  return launch_status();
+}
+
+extern "C" int voge_silhouette_bwd(const float *wsum, const float *g_sil, long npix, float *g_pix, voge_stream_t stream) {
+  if (npix < 0) return VOGE_ERR_BAD_ARG;
+  if (npix == 0) return 0;
+  if (!wsum || !g_sil || !g_pix) return VOGE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(silhouette_bwd_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wsum,
+                     g_sil, npix, g_pix);
   return launch_status();
 }
 

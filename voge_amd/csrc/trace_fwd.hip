@@ -1144,7 +1144,7 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   if ((size_t)B * H * W == 0) return 0;  // numel == 0 early return (ray_trace_voge.cu:248-251)
   if (!rays || !idx || !len || !workspace || (act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;
   // act / dsd may be omitted by the scalar-sigma fragment entry points only (they are re-derived where needed)
-  if (act == nullptr && !(iso_in && weight != nullptr && cnt != nullptr && (K & 1) == 0 && (long)B * N < (1l << 26)))
+  if (act == nullptr && !(iso_in && weight != nullptr && cnt != nullptr && (long)B * N < (1l << 26)))
     return VOGE_ERR_BAD_ARG;
   if (N > 0 && (!mus || !isigmas)) return VOGE_ERR_BAD_ARG;
   if (workspace_bytes < voge_trace_workspace_bytes(B, N, H, W)) return VOGE_ERR_WORKSPACE;

@@ -64,16 +64,51 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_WS = {}
+
+
+def _workspace(dev, nbytes):
+    """Scratch for one entry point: one buffer per (device, stream), grown on demand and reused by later calls.
+    Everything the library does is stream-ordered, so consecutive calls on a stream may share their scratch
+    (the trace's lists are ~135 MB per 512^2 view: allocating them per call put that much churn on every frame).
+    During stream capture the buffer comes from the graph's own pool (a fresh allocation, not cached)."""
+    nbytes = max(int(nbytes), 16)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    key = (dev.index if dev.index is not None else _get_dev(), _stream())
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS[key] = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    return ws
+
+
 def _tag_index(sel_idx, cnt, n_index):
     """Bookkeeping the trace leaves on the index tensor it returns:
     voge_hit_count  (cnt [B,H,W] int32, torch version of sel_idx when it was written): lets aggregation() skip its
                     pass over idx and the backwards skip empty slots.  A later in-place edit of sel_idx through
                     torch (e.g. masking Gaussians out with -1) bumps the version and invalidates the count.
-    voge_index_bound  = number of Gaussians the indices address (B*N): merge_final's range assert
-                    (Aggregation.py:120) becomes a host-side comparison of two shapes."""
+    voge_index_bound  = (number of Gaussians the indices address (B*N), version): merge_final's range assert
+                    (Aggregation.py:120) becomes a host-side comparison of two shapes while the tensor is unmodified."""
     if cnt is not None:
         sel_idx.voge_hit_count = (cnt, sel_idx._version)
-    sel_idx.voge_index_bound = int(n_index)
+    sel_idx.voge_index_bound = (int(n_index), sel_idx._version)
+
+
+def carry_tags(src, dst):
+    """A reshaped view of a fragment tensor (Fragments.unsqueeze / squeeze / [0] of a one-view batch / copy) still is
+    the same memory: hand the trace's bookkeeping on, so the view keeps the fast paths (no synchronising range check,
+    hit counts, the fused backward).  A true slice or a copy gets nothing."""
+    if dst is src or not (isinstance(dst, torch.Tensor) and dst.is_cuda and dst.is_contiguous()
+                          and dst.data_ptr() == src.data_ptr() and dst.numel() == src.numel() and dst.dtype == src.dtype):
+        return dst
+    tag = getattr(src, "voge_hit_count", None)
+    if tag is not None:
+        dst.voge_hit_count = (tag[0].view(dst.shape[:-1]), tag[1])
+    for name in ("voge_index_bound", "voge_through"):
+        tag = getattr(src, name, None)
+        if tag is not None:
+            setattr(dst, name, tag)
+    return dst
 
 
 def cones_of(rays, B, H, W):
@@ -101,13 +136,15 @@ def hit_count_of(sel_idx):
 
 def check_index_range(idx, n_attr):
     """merge_final's `assert vert_attr.shape[0] > vert_assign.max()` (Aggregation.py:120).  Indices written by
-    the trace carry their range (voge_index_bound = B*N): a host comparison.  Any other index tensor is checked
-    on the device as the reference does (a synchronising reduction), except during stream capture."""
-    bound = getattr(idx, "voge_index_bound", None)
-    if bound is not None:
-        if n_attr < bound:
+    the trace carry their range (voge_index_bound = B*N) while nobody has edited them through torch: a host comparison
+    (stricter than the reference's: it fails whenever the table is shorter than B*N rows, hit or not -- INTEGRATION.md
+    section 4).  Any other index tensor is checked on the device as the reference does (a synchronising reduction),
+    except during stream capture."""
+    tag = getattr(idx, "voge_index_bound", None)
+    if tag is not None and tag[1] == idx._version:
+        if n_attr < tag[0]:
             raise AssertionError(
-                f"vert_attr has {n_attr} rows but the fragments index {bound} Gaussians (a batch of B views addresses "
+                f"vert_attr has {n_attr} rows but the fragments index {tag[0]} Gaussians (a batch of B views addresses "
                 f"rows b*N+n: tile the attributes over the batch, as the reference requires -- Aggregation.py:120)")
         return
     if idx.numel() and not torch.cuda.is_current_stream_capturing():
@@ -159,7 +196,7 @@ class _RayTraceVoGE(torch.autograd.Function):
                 N = P // B
                 fwd = None if bin_points is None else _dev(bin_points, torch.float32, "cam_fwd")
                 nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
-                ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+                ws = _workspace(dev, nbytes)
                 rc = lib.voge_trace_topk_fwd(
                     _p(mus_c), _p(isg_c), _p(rays_c), _p(fwd), _p(cones_of(rays_c, B, H, W)), B, N, H, W, K, float(thr_act), _p(ws), nbytes,
                     _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _p(cnt), _stream())
@@ -194,7 +231,7 @@ class _RayTraceVoGE(torch.autograd.Function):
         g_isg = torch.empty_like(isg)
         with _on(rays.device):
             nbytes = lib.voge_trace_bwd_workspace_bytes(P)
-            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=rays.device)
+            ws = _workspace(rays.device, nbytes)
             rc = lib.voge_trace_bwd(_p(mus), _p(isg), _p(rays), _p(sel_idx), _p(ctx.cnt), _p(gl), _p(ga), _p(gd), P,
                                     B * H, W, K, _p(ws), nbytes, _p(g_ray), _p(g_mus), _p(g_isg), _stream())
         _lib.check(rc, "voge_trace_bwd")
@@ -227,7 +264,7 @@ class _RayTraceVoGEIso(torch.autograd.Function):
         fwd = None if cam_fwd is None else _dev(cam_fwd, torch.float32, "cam_fwd")
         with _on(dev):
             nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
-            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+            ws = _workspace(dev, nbytes)
             rc = lib.voge_trace_topk_fwd_iso(
                 _p(mus_c), _p(a_c), _p(rays_c), _p(fwd), _p(cones_of(rays_c, B, H, W)), B, N, H, W, K, float(thr_act), _p(ws), nbytes,
                 _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _p(cnt), _stream())
@@ -262,7 +299,7 @@ class _RayTraceVoGEIso(torch.autograd.Function):
         g_a = torch.empty_like(a)
         with _on(rays.device):
             nbytes = lib.voge_trace_bwd_iso_workspace_bytes(P)
-            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=rays.device)
+            ws = _workspace(rays.device, nbytes)
             rc = lib.voge_trace_bwd_iso(_p(mus), _p(a), _p(rays), _p(sel_idx), _p(ctx.cnt), _p(gl), _p(ga), _p(gd), P,
                                         B * H, W, K, _p(ws), nbytes, _p(g_ray), _p(g_mus), _p(g_a), _stream())
         _lib.check(rc, "voge_trace_bwd_iso")
@@ -297,7 +334,7 @@ class _RayTraceVoGEIsoView(torch.autograd.Function):
         fwd = None if cam_fwd is None else _dev(cam_fwd, torch.float32, "cam_fwd")
         with _on(dev):
             nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
-            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+            ws = _workspace(dev, nbytes)
             rc = lib.voge_trace_topk_fwd_iso_view(
                 _p(v_c), _p(s_c), _p(o_c), int(shared), int(sigma_mode), _p(rays_c), _p(fwd), _p(cones_of(rays_c, B, H, W)), B, N, H, W, K,
                 float(thr_act), _p(ws), nbytes, _p(sel_idx), _p(sel_len), _p(sel_act), _p(sel_dsd), _p(cnt), _stream())
@@ -334,7 +371,7 @@ class _RayTraceVoGEIsoView(torch.autograd.Function):
         g_sig = torch.empty_like(sigmas)
         with _on(rays.device):
             nbytes = lib.voge_trace_bwd_iso_workspace_bytes(B * N)
-            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=rays.device)
+            ws = _workspace(rays.device, nbytes)
             rc = lib.voge_trace_bwd_iso_view(_p(verts), _p(sigmas), _p(origin), int(ctx.shared), ctx.mode, _p(rays),
                                              _p(sel_idx), _p(ctx.cnt), _p(gl), _p(ga), _p(gd), B, N, B * H, W, K,
                                              _p(ws), nbytes, _p(g_ray), _p(g_verts), _p(g_sig), _stream())
@@ -342,14 +379,37 @@ class _RayTraceVoGEIsoView(torch.autograd.Function):
         return g_verts, g_sig, None, g_ray, None, None, None, None
 
 
+# VOGE_THREE_KERNEL_BACKWARD=1: _Fragments.backward runs voge_composite_bwd + voge_trace_bwd* (the round-1 chain, with
+# act / dsd materialised and g_len / g_act / g_dsd exchanged through memory) instead of the one-pass voge_fragment_bwd*.
+THREE_KERNEL_BACKWARD = os.environ.get("VOGE_THREE_KERNEL_BACKWARD", "0") == "1"
+
+
+def _grad_weight_layout(g, K):
+    """How voge_fragment_bwd* should read a gradient of the weights: (tensor, stride_pix, stride_k) in elements.
+    Contiguous [.., K] -> (K, 1); a per-pixel value expanded over the slots (what _Silhouette.backward returns when
+    nothing else consumed the weights) -> (1, 0), read in place; anything else is made contiguous."""
+    if g is None:
+        return None, 0, 0
+    if g.dtype == torch.float32 and g.is_cuda:
+        if g.is_contiguous():
+            return g, K, 1
+        if g.stride(-1) == 0 and g[..., 0].is_contiguous():
+            return g, 1, 0
+    return _dev(g, torch.float32, "grad_weight"), K, 1
+
+
 class _Fragments(torch.autograd.Function):
     """Trace + composite in one launch chain (voge_fragments_fwd*): what GaussianRenderer.forward needs from
     ray_tracing (RayTracing.py:12-30) followed by aggregation (Aggregation.py:82-107).
-    forward(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode, occ) -> weight, sel_idx, valid_num, sel_len
+    forward(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode, occ)
+        -> weight, sel_idx, valid_num, sel_len | cnt, records, act, dsd  (the call's bookkeeping, non-differentiable)
       mode 0: p0 = mus [P,3], p1 = isigmas [P,3,3]           (general 3x3 forms)
       mode 1: p0 = mus [P,3], p1 = a [P]                     (A = a I)
       mode 2: p0 = verts [N,3] | [B,N,3], p1 = sigmas [N] | [B,N], origin [B,3]   (the renderer's preamble folded in)
-    The backward is the composite's closed form followed by the trace backward of the same mode."""
+    The backward is ONE pass over the fragments (voge_fragment_bwd*: the composite's closed form and the trace's chain
+    rule, nothing exchanged through memory) for whatever gradient reaches the weights and vert_hit_length -- the
+    reference's training loops differentiate through interpolate_attr + get_silhouette (demo/ShapeFitting.py:217,295).
+    Only a caller that needs the gradient of the RAYS takes the stand-alone composite + trace backward kernels."""
 
     @staticmethod
     def forward(ctx, mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode, occ):
@@ -373,9 +433,9 @@ class _Fragments(torch.autograd.Function):
         sel_idx = torch.empty((B, H, W, K), dtype=torch.int32, device=dev)
         sel_len = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
         weight = torch.empty_like(sel_len)
-        # scalar sigmas, K even: act / dsd are not materialised at all -- every consumer re-derives them from the records
+        # scalar sigmas: act / dsd are not materialised at all -- every consumer re-derives them from the records
         # (composite forward, fused backward) or asks for them once (_act_dsd: the three-kernel backward)
-        lean = (mode != 0 and K % 2 == 0 and B * N < (1 << 26)      # (32-bit byte offsets of the record gathers)
+        lean = (mode != 0 and B * N < (1 << 26)      # (32-bit byte offsets of the record gathers)
                 and os.environ.get("VOGE_FRAGMENTS_KEEP_ACT_DSD", "0") != "1")
         sel_act = None if lean else torch.empty_like(sel_len)
         sel_dsd = None if lean else torch.empty_like(sel_len)
@@ -386,7 +446,7 @@ class _Fragments(torch.autograd.Function):
         fwd = None if cam_fwd is None else _dev(cam_fwd, torch.float32, "cam_fwd")
         with _on(dev):
             nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
-            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+            ws = _workspace(dev, nbytes)
             tail = (B, N, H, W, K, float(thr_act), float(occ), _p(ws), nbytes, _p(sel_idx), _p(sel_len), _p(sel_act),
                     _p(sel_dsd), _p(cnt), _p(weight), _p(valid))
             cones = _p(cones_of(rays_c, B, H, W))
@@ -399,34 +459,56 @@ class _Fragments(torch.autograd.Function):
                 rc = lib.voge_fragments_fwd(_p(p0_c), _p(p1_c), _p(rays_c), _p(fwd), cones, *tail, _stream())
         _lib.check(rc, "voge_fragments_fwd")
         ctx.save_for_backward(p0_c, p1_c, rays_c, sel_len, weight)
-        ctx.origin, ctx.sel_idx, ctx.cnt = o_c, sel_idx, cnt
+        # (only tensors that are NOT differentiable outputs of this node may hang on ctx as plain attributes: an output
+        # with a grad_fn kept here would close the cycle ctx -> tensor -> grad_fn -> ctx and leave the frame's buffers to
+        # the cyclic garbage collector)
+        ctx.origin, ctx.sel_idx, ctx.cnt, ctx.records = o_c, sel_idx, cnt, records
+        ctx.act_dsd = [sel_act, sel_dsd]
         ctx.meta = (int(mode), int(sigma_mode), bool(shared), float(occ), B, N)
         _tag_index(sel_idx, cnt, B * N)
-        ctx.mark_non_differentiable(sel_idx, valid)
+        ctx.mark_non_differentiable(sel_idx, valid, cnt)
+        if records is not None:
+            ctx.mark_non_differentiable(records)
+        if sel_act is not None:
+            ctx.mark_non_differentiable(sel_act, sel_dsd)
         ctx.set_materialize_grads(False)
-        # what a later to_colored_background needs to run the whole backward in one kernel (see _ShadeThrough)
-        ctx.through = dict(mode=int(mode), sigma_mode=int(sigma_mode), shared=bool(shared), occ=float(occ), B=B, N=N,
-                           records=records, rays=rays_c, act=sel_act, dsd=sel_dsd, len=sel_len, cnt=cnt, idx=sel_idx,
-                           sigmas=p1_c, means=p0_c)
-        ctx.th = ctx.through
-        _Fragments._last_through = ctx.through
-        return weight, sel_idx, valid, sel_len
+        return weight, sel_idx, valid, sel_len, cnt, records, sel_act, sel_dsd
 
     @staticmethod
-    def backward(ctx, g_weight, _g_idx, _g_valid, g_hitlen):
+    def backward(ctx, g_weight, _g_idx, _g_valid, g_hitlen, *_unused):
         lib = _lib.load()
         p0, p1, rays, ln, weight = ctx.saved_tensors
         mode, sigma_mode, shared, occ, B, N = ctx.meta
         if g_weight is None and g_hitlen is None:      # nothing reached the fragments (e.g. _ShadeThrough took the frame)
             return (None,) * 10
         sel_idx, cnt = ctx.sel_idx, ctx.cnt
-        act, dsd = _act_dsd(ctx.th)
         _, H, W, K = sel_idx.shape
         npix = B * H * W
         dev = rays.device
         if mode == 2 and ctx.needs_input_grad[3]:
             raise _lib.VogeHipError("the fused view form has no gradient for the camera centre; "
                                     "use ray_tracing_iso on centred vertices")
+        g0, g1 = torch.empty_like(p0), torch.empty_like(p1)
+        if not (ctx.needs_input_grad[4] or THREE_KERNEL_BACKWARD or B * N >= (1 << 26)):
+            # ONE pass: composite backward + trace backward per slot in registers, per-Gaussian sums in a wave-private
+            # table (fragment_bwd.hip, SRC = 1).  No act / dsd arrays, no g_len / g_act / g_dsd.
+            gw, gs_pix, gs_k = _grad_weight_layout(g_weight, K)
+            gh = None if g_hitlen is None else _dev(g_hitlen, torch.float32, "grad_hit_length")
+            act, dsd = ctx.act_dsd
+            with _on(dev):
+                nbytes = lib.voge_fragment_bwd_workspace_bytes(B * N)
+                ws = _workspace(dev, nbytes)
+                if mode == 0:
+                    rc = lib.voge_fragment_bwd(_p(p0), _p(p1), _p(rays), _p(sel_idx), _p(cnt), _p(weight), _p(act), _p(ln), _p(dsd),
+                                               _p(gw), gs_pix, gs_k, _p(gh), occ, B * N, B * H, W, K, _p(ws), nbytes, _p(g0), _p(g1),
+                                               _stream())
+                else:
+                    rc = lib.voge_fragment_bwd_iso(_p(ctx.records), _p(p1), int(shared), sigma_mode, _p(rays), _p(sel_idx), _p(cnt),
+                                                   _p(weight), _p(act), _p(ln), _p(dsd), _p(gw), gs_pix, gs_k, _p(gh), occ, B, N,
+                                                   B * H, W, K, _p(ws), nbytes, _p(g0), _p(g1), _stream())
+            _lib.check(rc, "voge_fragment_bwd")
+            return None, g0, g1, None, None, None, None, None, None, None
+        act, dsd = _act_dsd(ctx.act_dsd, ctx.records, rays, sel_idx, ln, cnt, B * N)
         g_act, g_len, g_dsd = torch.empty_like(act), torch.empty_like(act), torch.empty_like(act)
         with _on(dev):
             if g_weight is None:
@@ -439,55 +521,57 @@ class _Fragments(torch.autograd.Function):
             if g_hitlen is not None:      # vert_hit_length is the trace's len itself (Aggregation.py:107)
                 g_len = g_len + _dev(g_hitlen, torch.float32, "grad_hit_length")
             g_ray = torch.empty_like(rays) if ctx.needs_input_grad[4] else None
-            g0, g1 = torch.empty_like(p0), torch.empty_like(p1)
             if mode == 2:
                 nbytes = lib.voge_trace_bwd_iso_workspace_bytes(B * N)
-                ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+                ws = _workspace(dev, nbytes)
                 rc = lib.voge_trace_bwd_iso_view(_p(p0), _p(p1), _p(ctx.origin), int(shared), sigma_mode, _p(rays), _p(sel_idx),
                                                  _p(cnt), _p(g_len), _p(g_act), _p(g_dsd), B, N, B * H, W, K, _p(ws), nbytes,
                                                  _p(g_ray), _p(g0), _p(g1), _stream())
             elif mode == 1:
                 nbytes = lib.voge_trace_bwd_iso_workspace_bytes(B * N)
-                ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+                ws = _workspace(dev, nbytes)
                 rc = lib.voge_trace_bwd_iso(_p(p0), _p(p1), _p(rays), _p(sel_idx), _p(cnt), _p(g_len), _p(g_act), _p(g_dsd), B * N,
                                             B * H, W, K, _p(ws), nbytes, _p(g_ray), _p(g0), _p(g1), _stream())
             else:
                 nbytes = lib.voge_trace_bwd_workspace_bytes(B * N)
-                ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+                ws = _workspace(dev, nbytes)
                 rc = lib.voge_trace_bwd(_p(p0), _p(p1), _p(rays), _p(sel_idx), _p(cnt), _p(g_len), _p(g_act), _p(g_dsd), B * N,
                                         B * H, W, K, _p(ws), nbytes, _p(g_ray), _p(g0), _p(g1), _stream())
         _lib.check(rc, "voge_trace_bwd")
         return None, g0, g1, None, g_ray, None, None, None, None, None
 
 
-def _act_dsd(th):
-    """act / dsd of a fragments() call: what it kept, or (scalar sigmas) derived now from its records -- once; the
-    arrays then stay with the call's bookkeeping."""
-    if th["act"] is None:
+def _act_dsd(cell, records, rays, idx, ln, cnt, P):
+    """act / dsd of a fragments() call: what it kept (cell = [act, dsd]), or (scalar sigmas) derived now from its records
+    -- once; the arrays then stay in the cell."""
+    if cell[0] is None:
         lib = _lib.load()
-        ln, idx = th["len"], th["idx"]
         act, dsd = torch.empty_like(ln), torch.empty_like(ln)
         K = idx.shape[-1]
         with _on(ln.device):
-            rc = lib.voge_fragment_act_dsd_iso(_p(th["records"]), _p(th["rays"]), _p(idx), _p(ln), _p(th["cnt"]), idx.numel() // K, K,
-                                               th["B"] * th["N"], _p(act), _p(dsd), _stream())
+            rc = lib.voge_fragment_act_dsd_iso(_p(records), _p(rays), _p(idx), _p(ln), _p(cnt), idx.numel() // K, K, P,
+                                               _p(act), _p(dsd), _stream())
         _lib.check(rc, "voge_fragment_act_dsd_iso")
-        th["act"], th["dsd"] = act, dsd
-    return th["act"], th["dsd"]
+        cell[0], cell[1] = act, dsd
+    return cell[0], cell[1]
 
 
 def fragments(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode=0, occ=1.0):
-    """-> weight, sel_idx, valid_num, sel_len.  The weight tensor carries `voge_through`: the inputs and saved tensors
-    of this call, which lets a later to_colored_background(fragments, colors) run shade + composite + trace backward
-    as ONE kernel (_ShadeThrough)."""
-    _Fragments._last_through = None
-    out = _Fragments.apply(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode, occ)
-    th = _Fragments._last_through
-    _Fragments._last_through = None
-    if th is not None and (p0.requires_grad or p1.requires_grad) and torch.is_grad_enabled():
-        th = dict(th, p0=p0, p1=p1, weight_version=out[0]._version)
-        out[0].voge_through = th
-    return out
+    """-> weight, sel_idx, valid_num, sel_len.  The weight tensor carries `voge_through`: the inputs and bookkeeping
+    of this call (detached: nothing in it has a grad_fn), which lets a later to_colored_background(fragments, colors)
+    run shade + composite + trace backward as ONE kernel (_ShadeThrough)."""
+    weight, sel_idx, valid, sel_len, cnt, records, sel_act, sel_dsd = _Fragments.apply(
+        mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode, occ)
+    if (p0.requires_grad or p1.requires_grad) and torch.is_grad_enabled():
+        B = rays.shape[0]
+        N = p0.shape[-2] if mode == 2 else p0.shape[0] // max(B, 1)
+        rays_d, len_d = rays.detach(), sel_len.detach()      # (same storage and version counter, no grad_fn)
+        weight.voge_through = dict(
+            mode=int(mode), sigma_mode=int(sigma_mode), shared=bool(mode == 2 and p0.dim() == 2), occ=float(occ), B=B, N=N,
+            records=records, rays=rays_d, act=sel_act, dsd=sel_dsd, len=len_d, cnt=cnt, idx=sel_idx,
+            sigmas=p1.detach(), means=p0.detach(), p0=p0, p1=p1, rays_requires_grad=bool(rays.requires_grad),
+            versions=(weight._version, len_d._version, rays_d._version, sel_idx._version))
+    return weight, sel_idx, valid, sel_len
 
 
 class _ShadeThrough(torch.autograd.Function):
@@ -527,6 +611,10 @@ class _ShadeThrough(torch.autograd.Function):
         lib = _lib.load()
         attr, w, rgb, bg, wsum = ctx.saved_tensors
         th, idx = ctx.th, ctx.idx
+        # what the kernel reads outside save_for_backward must still be what the forward saw
+        if (th["len"]._version, th["rays"]._version) != th["versions"][1:3]:
+            raise RuntimeError("vert_hit_length or the rays were modified in place after to_colored_background: "
+                               "the fused backward would read the changed values (as autograd's own check for saved tensors)")
         B, H, W, K = idx.shape
         Nattr, C = attr.shape
         # the gradient as it comes: a contiguous image, or autograd's broadcast scalar (sum / mean losses) read in place
@@ -541,7 +629,7 @@ class _ShadeThrough(torch.autograd.Function):
         P = th["B"] * th["N"]
         with _on(idx.device):
             nbytes = lib.voge_fragment_bwd_workspace_bytes(P)
-            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=idx.device)
+            ws = _workspace(idx.device, nbytes)
             if th["mode"] == 0:      # full 3x3 forms: gradients of (mus, isigmas) as given
                 rc = lib.voge_fragment_shade_bwd(
                     _p(th["means"]), _p(th["sigmas"]), _p(th["rays"]), _p(attr), _p(idx), _p(th["cnt"]), _p(w), _p(th["act"]),
@@ -558,22 +646,40 @@ class _ShadeThrough(torch.autograd.Function):
         return (g_attr if need[0] else None), None, (g0 if need[2] else None), (g1 if need[3] else None), None, None, None, None, None
 
 
-def shade_through(attr, fragments_weight, idx, valid_num, bg, thr):
-    """The fused-backward form of shade() when `fragments_weight` still is the untouched output of fragments() (scalar
-    sigmas, K even and <= 128, <= 4 channels, nobody watching the weights' own gradient); None otherwise."""
+def through_of(fragments_weight, idx):
+    """The bookkeeping fragments() left on the weights, if it still describes (fragments_weight, idx): same memory, not
+    modified through torch since.  None otherwise."""
     th = getattr(fragments_weight, "voge_through", None)
-    if th is None or not torch.is_grad_enabled():
+    if th is None:
+        return None
+    tidx = th["idx"]
+    if idx is not tidx and not (idx.data_ptr() == tidx.data_ptr() and idx.numel() == tidx.numel() and idx.is_contiguous()
+                                and idx.dtype == tidx.dtype):
+        return None
+    v = th["versions"]
+    if fragments_weight._version != v[0] or th["len"]._version != v[1] or th["rays"]._version != v[2] or tidx._version != v[3]:
+        return None
+    return th
+
+
+def shade_through(attr, fragments_weight, idx, valid_num, bg, thr):
+    """The fused-backward form of shade() when `fragments_weight` still is the untouched output of fragments() (K <= 128,
+    <= 4 channels, nobody watching the weights' own gradient); None otherwise.  VOGE_SHADE_THROUGH=0 disables it (e.g. to
+    take torch.autograd.grad with respect to the weights themselves: this node hands them no gradient)."""
+    if not torch.is_grad_enabled() or os.environ.get("VOGE_SHADE_THROUGH", "1") == "0":
+        return None
+    th = through_of(fragments_weight, idx)
+    if th is None:
         return None
     K = idx.shape[-1]
-    if (K & 1) or K > 128 or attr.dim() != 2 or attr.shape[1] > 4 or idx is not th["idx"] or hit_count_of(idx) is None:
+    if K > 128 or attr.dim() != 2 or attr.shape[1] > 4 or th["cnt"] is None:
         return None
-    if fragments_weight._version != th["weight_version"] or fragments_weight.retains_grad or fragments_weight._backward_hooks:
-        return None
-    if th["len"]._version != 0 or th["rays"].requires_grad:
+    if fragments_weight.retains_grad or fragments_weight._backward_hooks or th["rays_requires_grad"]:
         return None
     if th["B"] * th["N"] >= (1 << 26) or attr.numel() >= (1 << 30):      # 32-bit byte offsets of the kernel's gathers
         return None
-    return _ShadeThrough.apply(attr, fragments_weight, th["p0"], th["p1"], th, idx, valid_num, bg, thr)
+    img = _ShadeThrough.apply(attr, fragments_weight, th["p0"], th["p1"], th, th["idx"], valid_num, bg, thr)
+    return img if idx is th["idx"] else img.view(idx.shape[:-1] + (attr.shape[1],))
 
 
 class _Composite(torch.autograd.Function):
@@ -759,8 +865,9 @@ class _Shade(torch.autograd.Function):
 
 
 class _Silhouette(torch.autograd.Function):
-    """get_silhouette (VoGE/Renderer.py:157-159): min(sum_k w_k, 1), via the blend kernels with a
-    zero background and a one-channel zero image (out is discarded, sil_out is the result)."""
+    """get_silhouette (VoGE/Renderer.py:157-159): min(sum_k w_k, 1).  The backward is one value per pixel
+    (g_sil * [sum w < 1]), returned as a [.., K] view with stride 0 along the slots: nothing of size [.., K] is
+    written, and voge_fragment_bwd* reads the view in place when the silhouette is the weights' only consumer."""
 
     @staticmethod
     def forward(ctx, weight):
@@ -769,28 +876,24 @@ class _Silhouette(torch.autograd.Function):
         K = w.shape[-1]
         npix = w.numel() // max(K, 1)
         sil = torch.empty(w.shape[:-1], dtype=torch.float32, device=w.device)
+        wsum = torch.empty_like(sil)
         with _on(w.device):
-            rc = lib.voge_blend_fwd(None, _p(w), None, -1.0, npix, K, 0, None, _p(sil), _stream())
-        _lib.check(rc, "voge_blend_fwd")
-        ctx.save_for_backward(w)
+            rc = lib.voge_silhouette_fwd(_p(w), npix, K, _p(sil), _p(wsum), _stream())
+        _lib.check(rc, "voge_silhouette_fwd")
+        ctx.save_for_backward(wsum)
+        ctx.K = K
         return sil
 
     @staticmethod
     def backward(ctx, g_sil):
         lib = _lib.load()
-        (w,) = ctx.saved_tensors
-        K = w.shape[-1]
-        npix = w.numel() // max(K, 1)
-        # d sil / d w_k = [sum w < 1]: reuse blend_bwd with rgb = 0, bg = -1, one channel:
-        # out = min(0 + (1 - sil) * (-1), 1) -> g_mask = +g_out, g_w = g_out * pass(sum w)
-        zero = torch.zeros(w.shape[:-1] + (1,), dtype=torch.float32, device=w.device)
-        bg = torch.full((1,), -1.0, dtype=torch.float32, device=w.device)
-        go = _dev(g_sil, torch.float32, "grad_sil").reshape(zero.shape).contiguous()
-        g_w = torch.empty_like(w)
-        with _on(w.device):
-            rc = lib.voge_blend_bwd(_p(zero), _p(w), _p(bg), -1.0, _p(go), npix, K, 1, None, _p(g_w), _stream())
-        _lib.check(rc, "voge_blend_bwd")
-        return g_w
+        (wsum,) = ctx.saved_tensors
+        go = _dev(g_sil, torch.float32, "grad_sil")
+        g_pix = torch.empty_like(wsum)
+        with _on(wsum.device):
+            rc = lib.voge_silhouette_bwd(_p(wsum), _p(go), wsum.numel(), _p(g_pix), _stream())
+        _lib.check(rc, "voge_silhouette_bwd")
+        return g_pix.unsqueeze(-1).expand(*wsum.shape, ctx.K)
 
 
 class _PixelRays(torch.autograd.Function):
