@@ -294,6 +294,26 @@ def gen_host_logic(Ren):
     np.savez_compressed(os.path.join(OUT, "host_logic.npz"), **out)
 
 
+def gen_ray_camera_space(Agg):
+    """The one piece of ray-generation arithmetic the reference carries itself: get_ray_camera_space
+    (VoGE/Aggregation.py:11-27), RUN here.  It states the view-space sign convention of the path's rays
+    (x = -(col - px) / fx, y = -(row - py) / fy, z = 1, normalised; `principle` is (row, col) ordered) with pixel
+    CORNERS as sample points; PyTorch3D's sampler, which the renderer uses, takes pixel CENTRES (a half-pixel shift).
+    The fixture pins oracle/camera_np.pixel_rays and voge_rays_fwd to it: same directions once the principal point is
+    shifted by half a pixel."""
+    out = {}
+    for name, (hw, principle, focal) in dict(a=((5, 7), (2.0, 3.0), 9.0), b=((32, 48), (15.5, 23.25), torch.tensor([40.0, 44.0])),
+                                             c=((16, 16), (8.0, 8.0), torch.tensor([[21.0, 21.0]]))).items():
+        d = Agg.get_ray_camera_space(hw, principle, focal if not isinstance(focal, float) else float(focal))
+        out[name + "_dirs"] = d.numpy()
+        out[name + "_size"] = np.array(hw)
+        out[name + "_principle_row_col"] = np.array(principle, np.float64)
+        f = np.array([focal, focal], np.float64) if isinstance(focal, float) else focal.numpy().astype(np.float64).reshape(-1)
+        out[name + "_focal_row_col"] = f
+    np.savez_compressed(os.path.join(OUT, "ray_camera_space.npz"), **out)
+    print("ray_camera_space", {k: v.shape for k, v in out.items() if k.endswith("dirs")})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     mods = import_reference()
@@ -303,3 +323,4 @@ if __name__ == "__main__":
     gen_trace_known_answer()
     gen_converters_more(mods[2], mods[3])
     gen_host_logic(mods[1])
+    gen_ray_camera_space(mods[0])

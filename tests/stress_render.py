@@ -1,34 +1,68 @@
-"""Randomised parity sweep THROUGH THE RENDERER on the GPU (not part of the suite: a minute or two): random scenes,
-image sizes, K, scalar / 3x3 sigmas -> GaussianRenderer + to_white_background forward and backward (fragments without
-act / dsd, fused backward where it applies) against the fp64 oracle chain.  usage: python tests/stress_render.py [n] [seed]"""
+"""Randomised parity sweep THROUGH THE RENDERER on the GPU: random scenes, image sizes, K (odd, > 128 too), scalar /
+(N,3) / 3x3 sigmas -> GaussianRenderer + either to_white_background (shade-through backward) or the training pattern
+interpolate_attr + get_silhouette (one-pass fragment backward), forward and backward against the fp64 oracle chain.
+`run(n_cases, seed)` is what the suite calls (tests/test_gpu_stress.py); as a script:
+usage: python tests/stress_render.py [n] [seed]"""
+import os
 import sys
+
 import numpy as np
 import torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import oracle
 import test_gpu_configs as C
 from util import TOL, random_scene
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-worst = {"image": 0.0, "colors": 0.0, "verts": 0.0, "sigmas": 0.0}
-for case in range(n_cases):
-    N = int(rng.integers(50, 2500)); H = int(rng.integers(8, 80)); W = int(rng.integers(8, 80))
-    K = int(rng.choice([2, 4, 6, 8, 12, 16, 20, 26, 40, 64, 128, 7, 25]))
-    aniso = bool(rng.integers(0, 3) == 0)
-    verts, sig, cols = random_scene(N, seed=int(rng.integers(1 << 30)), aniso=aniso, lo=0.05, hi=0.2)
-    if aniso:
-        sig = (0.5 * (sig + sig.transpose(0, 2, 1))).astype(np.float32)
-    sc = dict(verts=verts, sigmas=sig, colors=cols, focal=float(rng.uniform(0.7, 1.4)) * max(H, W), principal=(W / 2.0, H / 2.0),
-              image_size=(H, W), dist=float(rng.uniform(2.6, 4.0)), elev=float(rng.uniform(-40, 40)), azim=float(rng.uniform(0, 360)), K=K)
-    frag, img, gm, colors, (R, T) = C._render(sc)
-    ref = C._oracle_frame(sc, R, T)
-    same = C._check_frame(f"stress {case}", frag, img, ref, max_flips=max(3, H * W // 300))
-    g_img = rng.normal(size=ref["image"].shape) * same[..., None]          # flipped pixels carry no loss
-    (img * C.t(g_img)).sum().backward()
-    want = C._oracle_grads(sc, ref, g_img)
-    got = (colors.grad, gm.verts.grad, gm.sigmas.grad)
-    errs = C._check_grads(f"stress {case} N={N} {H}x{W} K={K} {'aniso' if aniso else 'iso'} [{type(img.grad_fn).__name__}]", got, want, 5)
-    worst["image"] = max(worst["image"], float(np.abs(C.n(img)[same] - ref["image"][same]).max(initial=0.0)))
-    for k, v in errs.items():
-        worst[k] = max(worst[k], v)
-print("all", n_cases, "cases ok; worst errors / scale:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+def run(n_cases=24, seed=0, verbose=True):
+    rng = np.random.default_rng(seed)
+    worst = {"image": 0.0, "colors": 0.0, "verts": 0.0, "sigmas": 0.0}
+    for case in range(n_cases):
+        N = int(rng.integers(50, 2500)); H = int(rng.integers(8, 80)); W = int(rng.integers(8, 80))
+        K = int(rng.choice([2, 4, 6, 8, 12, 16, 20, 26, 40, 64, 128, 7, 25, 1, 33, 130, 200]))
+        form = ("scalar", "scalar", "full", "diag")[int(rng.integers(0, 4))]
+        pattern = ("white_background", "attr_and_silhouette")[int(rng.integers(0, 2))]
+        verts, sig, cols = random_scene(N, seed=int(rng.integers(1 << 30)), aniso=(form == "full"), lo=0.05, hi=0.2)
+        if form == "full":
+            sig = (0.5 * (sig + sig.transpose(0, 2, 1))).astype(np.float32)
+        elif form == "diag":
+            sig = (sig[:, None] * rng.uniform(0.6, 1.6, (N, 3))).astype(np.float32)
+        sc = dict(verts=verts, sigmas=sig, colors=cols, focal=float(rng.uniform(0.7, 1.4)) * max(H, W), principal=(W / 2.0, H / 2.0),
+                  image_size=(H, W), dist=float(rng.uniform(2.6, 4.0)), elev=float(rng.uniform(-40, 40)), azim=float(rng.uniform(0, 360)), K=K)
+        frag, img, gm, colors, (R, T) = C._render(sc)
+        ref = C._oracle_frame(sc, R, T)
+        same = C._check_frame(f"stress {case}", frag, img, ref, max_flips=max(3, H * W // 300))
+        tag = f"stress {case} N={N} {H}x{W} K={K} {form} {pattern}"
+        if pattern == "white_background":
+            g_img = rng.normal(size=ref["image"].shape) * same[..., None]          # flipped pixels carry no loss
+            (img * C.t(g_img)).sum().backward()
+            want = C._oracle_grads(sc, ref, g_img)
+            tag += f" [{type(img.grad_fn).__name__}]"
+        else:
+            from voge_amd.Renderer import get_silhouette, interpolate_attr
+            rgb, sil = interpolate_attr(frag, colors), get_silhouette(frag)
+            g_rgb = rng.normal(size=ref["rgb"].shape) * same[..., None]
+            g_silh = rng.normal(size=ref["silhouette"].shape) * same
+            ((rgb * C.t(g_rgb)).sum() + (sil * C.t(g_silh)).sum()).backward()
+            wsum = ref["weight"].sum(-1)
+            g_attr, g_w = oracle.merge_bwd(ref["colsB"], ref["idx"], ref["weight"], ref["valid_num"], g_rgb)
+            live = np.arange(K)[None, None, None] < ref["valid_num"][..., None]
+            g_act, g_len, g_dsd = oracle.composite_bwd(ref["act"], ref["len"], ref["dsd"], g_w + (g_silh * (wsum < 1))[..., None] * live, 1.0)
+            _, g_mu, g_A = oracle.trace_bwd(ref["mus"], ref["isg"], ref["rays"], ref["idx"], g_len, g_act, g_dsd)
+            g_A = g_A.reshape(-1, 3, 3)
+            g_sig = {1: 2 * np.einsum("nii->n", g_A), 2: 2 * np.einsum("nii->ni", g_A), 3: 2 * g_A}[np.asarray(sig).ndim]
+            want = (g_attr, g_mu, g_sig)
+        got = (colors.grad, gm.verts.grad, gm.sigmas.grad)
+        errs = C._check_grads(tag, got, want, 1)
+        worst["image"] = max(worst["image"], float(np.abs(C.n(img)[same] - ref["image"][same]).max(initial=0.0)))
+        for k, v in errs.items():
+            worst[k] = max(worst[k], v)
+    if verbose:
+        print("all", n_cases, "cases ok; worst errors / scale:", {k: f"{v:.1e}" for k, v in worst.items()})
+    return worst
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -97,7 +97,8 @@ def _oracle_grads(sc, ref, g_img):
     g_attr = g_attr.reshape(B, N, -1).sum(0)
     g_mu = g_mu.reshape(B, N, 3).sum(0)
     g_A = g_A.reshape(B, N, 3, 3).sum(0)
-    g_sig = 2 * np.einsum("nii->n", g_A) if np.asarray(sc["sigmas"]).ndim == 1 else 2 * g_A
+    nd = np.asarray(sc["sigmas"]).ndim      # [N]: A = 2 s I; [N,3]: A = 2 diag(s); [N,3,3]: A = 2 S
+    g_sig = {1: 2 * np.einsum("nii->n", g_A), 2: 2 * np.einsum("nii->ni", g_A), 3: 2 * g_A}[nd]
     return g_attr, g_mu, g_sig
 
 
@@ -125,7 +126,13 @@ def _check_grads(label, got, want, mult):
         err = np.abs(g - w).max()
         out[name] = err / scale
         assert err <= mult * TOL * scale, f"{label} {name}: {err:.3e} vs scale {scale:.3e} (allowed {mult} x {TOL})"
-    print(f"[parity] {label} gradient errors / scale: " + ", ".join(f"{k} {v:.2e}" for k, v in out.items()))
+    line = f"[parity] {label} gradient errors / scale: " + ", ".join(f"{k} {v:.2e}" for k, v in out.items()) + f" (allowed {mult * TOL:.1e})"
+    print(line)
+    import os
+    log = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(log):
+        with open(os.path.join(log, "parity_flips.txt"), "a") as f:
+            f.write(line + "\n")
     return out
 
 
@@ -143,7 +150,7 @@ def test_config2_bunny_fwd_bwd(hip_lib):
     g_img = np.random.default_rng(2).normal(size=ref["image"].shape) * same[..., None]
     (img * t(g_img)).sum().backward()
     want = _oracle_grads(sc, ref, g_img)
-    _check_grads("cfg2", (colors.grad, gm.verts.grad, gm.sigmas.grad), want, mult=5)
+    _check_grads("cfg2", (colors.grad, gm.verts.grad, gm.sigmas.grad), want, mult=4)      # measured 1.9e-4 (verts): 2x
 
 
 # ----------------------------------------------------------------------------------------------- cfg3
@@ -157,7 +164,7 @@ def test_config3_band_gradients(hip_lib):
     same = _check_frame("cfg3 rows 252..259", frag, img, ref, max_flips=4)
     g_img = np.random.default_rng(3).normal(size=ref["image"].shape) * same[..., None]
     (img * t(g_img)).sum().backward()
-    _check_grads("cfg3 band", (colors.grad, gm.verts.grad, gm.sigmas.grad), _oracle_grads(sc, ref, g_img), mult=5)
+    _check_grads("cfg3 band", (colors.grad, gm.verts.grad, gm.sigmas.grad), _oracle_grads(sc, ref, g_img), mult=0.6)      # measured 2.6e-5
 
 
 # ----------------------------------------------------------------------------------------------- cfg4
@@ -205,7 +212,7 @@ def test_config4_full_size(hip_lib):
     same = _check_frame("cfg4 rows 510..513", frag2, img2, ref, max_flips=4)
     g_img = np.random.default_rng(4).normal(size=ref["image"].shape) * same[..., None]
     (img2 * t(g_img)).sum().backward()
-    _check_grads("cfg4 band", (colors2.grad, gm2.verts.grad, gm2.sigmas.grad), _oracle_grads(sc, ref, g_img), mult=5)
+    _check_grads("cfg4 band", (colors2.grad, gm2.verts.grad, gm2.sigmas.grad), _oracle_grads(sc, ref, g_img), mult=0.3)      # measured 1.5e-5
 
 
 # ----------------------------------------------------------------------------------------------- cfg5

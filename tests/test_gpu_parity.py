@@ -849,9 +849,12 @@ def test_renderer_against_the_running_reference_host_logic(hip_lib, case):
     _report_flips(f"host logic {case}", (~same).sum(), same.size)
     assert (~same).sum() <= 0.004 * same.size            # the reference's kernel stand-in computes in fp32: boundary flips
     assert (n(frag.valid_num)[same] == g[c + "_valid_num"][same]).all()
-    assert np.abs(n(frag.vert_weight)[same] - g[c + "_weight"][same]).max() < 3e-4
+    e_w = np.abs(n(frag.vert_weight)[same] - g[c + "_weight"][same]).max()
     hit = (g[c + "_index"] >= 0) & same[..., None]
-    assert np.abs(n(frag.vert_hit_length)[hit] - g[c + "_hit_length"][hit]).max() < 4e-4
+    e_l = np.abs(n(frag.vert_hit_length)[hit] - g[c + "_hit_length"][hit]).max()
+    from util import log_line
+    log_line(f"[parity] host logic {case}: max weight error {e_w:.2e}, max hit length error {e_l:.2e} (fixture: the fp32 stand-in)")
+    assert e_w < 3e-4 and e_l < 4e-4
 
 
 @pytest.mark.parametrize("K,B,inverse,aniso", [(40, 1, False, False), (12, 2, True, False), (26, 1, False, False),

@@ -1,0 +1,51 @@
+"""The randomised sweeps as part of the driver's suite: fixed seeds, a dozen cases each, every case
+against the fp64 oracle.  stress_parity: random shapes through the public ops (trace / composite / shade, forward and
+backward incl. the gradient of the rays).  stress_render: random scenes through GaussianRenderer with either
+to_white_background or the training pattern interpolate_attr + get_silhouette (odd K, K > 128, (N,3) and [N,3,3]
+sigmas).  aniso: needles and pancakes at the cfg3 size against oracle crops (the ellipsoid culling)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import camera_np
+from util import compare_trace
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_randomised_sweep_through_the_ops(hip_lib, seed):
+    import stress_parity
+    worst = stress_parity.run(12, seed, verbose=True)
+    assert worst, "no case reached the value checks"
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_randomised_sweep_through_the_renderer(hip_lib, seed):
+    import stress_render
+    worst = stress_render.run(10, seed, verbose=True)
+    assert max(worst.values()) > 0
+
+
+def test_strongly_anisotropic_scene_at_cfg3_size(hip_lib):
+    """random_gaussians(anisotropic=True) -- needles and pancakes -- 50k Gaussians, 512^2, K = 40: the full-frame trace
+    against the brute-force oracle on four 24x24 crops (ellipsoid culling and its depth bound at full size)."""
+    from voge_amd import ops, scenes
+    N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS["cfg3_50k_512"]
+    verts, sig, _ = scenes.random_gaussians(N, seed=0, anisotropic=True)
+    R, T = camera_np.look_at_view_transform([dd], [el], [az])
+    rays, origin = camera_np.pixel_rays(R, T, focal, pp, (H, W))
+    mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = (2 * sig).astype(np.float32)[None]
+    thr_act = oracle.thr_act_of(0.01)
+    t = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device="cuda")
+    sel = ops.ray_trace_fine(t(mus.reshape(-1, 3)), t(isg.reshape(-1, 3, 3)), t(rays), None, thr_act, 10, K)
+    got = [x.cpu().numpy() for x in sel]
+    assert (got[0] >= 0).sum(-1).mean() > 10
+    rng = np.random.default_rng(0)
+    S = 24
+    for c in range(4):
+        y0, x0 = int(rng.integers(0, H - S)), int(rng.integers(0, W - S))
+        ref = oracle.trace_fwd(mus, isg, np.ascontiguousarray(rays[:, y0:y0 + S, x0:x0 + S]), K, thr_act)
+        compare_trace([g[:, y0:y0 + S, x0:x0 + S] for g in got], ref, thr_act, min_match=0.97, label=f"aniso cfg3 crop ({y0},{x0})")

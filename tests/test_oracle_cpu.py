@@ -247,3 +247,22 @@ def test_coarse_stage_restatement():
     assert np.allclose(p[0, 0], [(35 - 35) * 2 / 50, (25 - 25) * 2 / 50, 4.0])
     assert np.allclose(p[0, 1, 0], (35 - 100 * 0.4 / 4 - 35) * 2 / 50)              # +X is left: the column decreases
     assert np.allclose(r[0, 0], np.sqrt(-np.log(0.01) / 50.0) * 100 * 2 / 50 / 4.0, rtol=1e-5)
+
+
+def test_ray_convention_against_the_reference_get_ray_camera_space():
+    """VoGE/Aggregation.py:11-27 (`get_ray_camera_space`), run by make_golden.py: the reference's own statement of the
+    view-space ray directions -- x = -(col - px) / fx, y = -(row - py) / fy, z = 1, normalised, sampled at pixel
+    CORNERS, `principle` ordered (row, col).  oracle/camera_np.pixel_rays (PyTorch3D's convention: pixel CENTRES)
+    must give the same directions when the principal point is moved by half a pixel; with R = I, T = 0 world space is
+    view space."""
+    g = np.load(os.path.join(GOLDEN, "ray_camera_space.npz"))
+    for name in "abc":
+        H, W = (int(v) for v in g[name + "_size"])
+        py, px = g[name + "_principle_row_col"]
+        fy, fx = g[name + "_focal_row_col"]
+        rays, origin = camera_np.pixel_rays(np.eye(3)[None], np.zeros((1, 3)), (fx, fy), (px + 0.5, py + 0.5), (H, W))
+        assert np.abs(origin).max() == 0
+        assert np.abs(rays[0] - g[name + "_dirs"]).max() < 2e-7, name
+        # and WITHOUT the shift the two differ by exactly the half-pixel offset (so the test above is not vacuous)
+        raw, _ = camera_np.pixel_rays(np.eye(3)[None], np.zeros((1, 3)), (fx, fy), (px, py), (H, W))
+        assert np.abs(raw[0] - g[name + "_dirs"]).max() > 0.2 / max(fx, fy) / 2

@@ -42,6 +42,18 @@ def _report_flips(label, n_flip, n_pix):
             pass
 
 
+def log_line(line):
+    """Print a measured quantity and keep it in gpurun_out/parity_flips.txt (when that directory exists)."""
+    print(line)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        try:
+            with open(os.path.join(out, "parity_flips.txt"), "a") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
+
+
 def grad_close(label, got, want, tol):
     """|got - want| <= tol * max(1, |want|_max); the measured ratio goes to the same log as the flip counts, so the
     tolerances in the tests can be seen against what the kernels actually deliver."""
