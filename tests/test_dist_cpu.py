@@ -119,3 +119,70 @@ def test_measured_rebalancing_converges():
         assert bounds[0] == 0 and bounds[-1] == H and all(b1 - b0 >= 8 for b0, b1 in zip(bounds, bounds[1:]))
     t = measure(bounds)
     assert max(t) < 0.9 * max(t0) and max(t) / (sum(t) / n) < 1.05
+
+
+# ------------------------------------------------------------------------------- stacked (view, row) sharding of a batch
+def test_stacked_bounds_and_segments():
+    from voge_amd.distributed import rebalance_bounds, stacked_bounds, stacked_segments
+    assert stacked_bounds(8, 512, 8) == [i * 512 for i in range(9)]                  # whole views
+    assert stacked_bounds(8, 512, 4) == [i * 1024 for i in range(5)]
+    b = stacked_bounds(5, 128, 2)                                                        # 5 views on 2 ranks: 320 rows each
+    assert b == [0, 320, 640]
+    assert stacked_segments(0, 320, 128) == [(0, 2, 0, 128), (2, 3, 0, 64)]
+    assert stacked_segments(320, 640, 128) == [(2, 3, 64, 128), (3, 5, 0, 128)]
+    assert stacked_segments(10, 20, 128) == [(0, 1, 10, 20)] and stacked_segments(7, 7, 128) == []
+    assert stacked_segments(100, 300, 128) == [(0, 1, 100, 128), (1, 2, 0, 128), (2, 3, 0, 44)]
+    for B, H, world in ((3, 7, 2), (5, 16, 8), (1, 64, 8), (8, 4, 3)):
+        bd = stacked_bounds(B, H, world)
+        rows = sum((b1 - b0) * (r1 - r0) for r in range(world) for b0, b1, r0, r1 in stacked_segments(bd[r], bd[r + 1], H))
+        assert bd[0] == 0 and bd[-1] == B * H and rows == B * H
+    # min_rows larger than H / n must not produce crossing bands
+    out = rebalance_bounds([0, 2, 4, 6, 9], [5.0, 1.0, 1.0, 9.0], min_rows=8)
+    assert out[0] == 0 and out[-1] == 9 and all(b1 > b0 for b0, b1 in zip(out, out[1:]))
+
+
+def _stacked_worker(rank, world, port, B, H, W, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from voge_amd.distributed import gather_stacked, render_stacked, stacked_bounds
+    sc = cuboid_scene()
+    R, T = camera_np.look_at_view_transform([sc["dist"]] * B, [10.0 + 15 * b for b in range(B)], [70.0 + 40 * b for b in range(B)])
+    colors = torch.tensor(sc["colors"], dtype=torch.float64, requires_grad=True)
+    isg = (2 * camera_np.expand_sigma(sc["sigmas"])).astype(np.float32)
+
+    def render_views(b0, b1, r0, r1):      # the oracle stands in for the renderer (product kernels need a GPU)
+        rays, origin = camera_np.pixel_rays(R[b0:b1], T[b0:b1], 60.0, (W / 2, H / 2), (H, W))
+        mus = (sc["verts"][None] - origin[:, None].astype(np.float32)).astype(np.float32)
+        idx, ln, act, dsd = oracle.trace_fwd(mus, np.broadcast_to(isg[None], (b1 - b0,) + isg.shape), rays[:, r0:r1], 8, oracle.thr_act_of(0.01))
+        w, vn = oracle.composite_fwd(idx, act, ln, dsd, 1.0)
+        valid = torch.tensor(np.arange(8)[None, None, None] < vn[..., None])
+        n_g = sc["verts"].shape[0]
+        return (colors[torch.tensor(np.maximum(idx, 0) % n_g).long()] * (torch.tensor(w) * valid)[..., None]).sum(-2)
+    bounds = stacked_bounds(B, H, world)
+    rows = render_stacked(render_views, bounds[rank], bounds[rank + 1], H)
+    assert rows.shape == (bounds[rank + 1] - bounds[rank], W, 3)
+    img = gather_stacked(rows, B, H)
+    assert img.shape == (B, H, W, 3)
+    img.reshape(B * H, W, 3)[bounds[rank]:bounds[rank + 1]].sum().backward()      # each rank owns the loss of its range
+    from voge_amd.distributed import allreduce_grads
+    allreduce_grads([colors])
+    if rank == 0:
+        torch.save({"img": img.detach(), "g": colors.grad.clone()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stacked_view_row_sharding_equals_single_rank(tmp_path):
+    """A 3-view batch over 2 ranks on the stacked (view, row) axis: rank 0 renders view 0 and the top of view 1, rank 1
+    the rest; the gathered batch and the all-reduced gradient equal the single-process render."""
+    B, H, W, world = 3, 7, 12, 2
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_stacked_worker, args=(world, _free_port(), B, H, W, out), nprocs=world, join=True)
+    got = torch.load(out)
+    sc = cuboid_scene()
+    R, T = camera_np.look_at_view_transform([sc["dist"]] * B, [10.0 + 15 * b for b in range(B)], [70.0 + 40 * b for b in range(B)])
+    ref = oracle.render(sc["verts"], sc["sigmas"], sc["colors"], R, T, 60.0, (W / 2, H / 2), (H, W), K=8)
+    assert np.abs(got["img"].numpy() - ref["rgb"]).max() < 1e-12
+    n_g = sc["verts"].shape[0]
+    g_attr, _ = oracle.merge_bwd(np.tile(sc["colors"], (B, 1)), ref["idx"], ref["weight"], ref["valid_num"], np.ones_like(ref["rgb"]))
+    assert np.abs(got["g"].numpy() - g_attr.reshape(B, n_g, 3).sum(0)).max() < 1e-10

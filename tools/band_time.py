@@ -1,20 +1,23 @@
 """Per-rank compute of the pixel-row sharding, measured on ONE GPU: forward+backward of a band of H/n
 rows (HIP graph replay, no collectives) for n = 1, 2, 4, 8 -- the part of strong scaling that does
-not depend on xGMI.  usage: python tools/band_time.py [config]"""
+not depend on xGMI.  With VIEWS=B a batch of B views is sharded on the stacked (view, row) axis instead
+(distributed.stacked_bounds: whole views per rank when B % n == 0).
+usage: [VIEWS=8] python tools/band_time.py [config]"""
 import os, sys, time, torch
 sys.path.insert(0, ".")
 from voge_amd import scenes
 from voge_amd.Meshes import GaussianMeshes
 from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
 from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
-from voge_amd.distributed import balanced_row_bounds, projected_row_weight, row_band
+from voge_amd.distributed import balanced_row_bounds, projected_row_weight, render_stacked, row_band, stacked_bounds
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_50k_512"
 dev = torch.device("cuda", 0)
 N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[name]
 verts, sig, cols = scenes.random_gaussians(N, seed=0)
 gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
 colors = torch.from_numpy(cols).to(dev).requires_grad_(True)
-R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
+VIEWS = int(os.environ.get("VIEWS", "1"))
+R, T = look_at_view_transform(dist=[dd] * VIEWS, elev=[el] * VIEWS, azim=[az + 360.0 / VIEWS * b for b in range(VIEWS)], device=dev)
 cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), device=dev)
 renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1, max_point_per_bin=-1)).to(dev)
 params = [gm.verts, gm.sigmas, colors]
@@ -31,7 +34,12 @@ for n in (1, 2, 4, 8):
             rows = (b[r], b[r + 1])
         def step():
             for p in params: p.grad = None
-            to_white_background(renderer(gm, R=R, T=T, rows=rows), colors).sum().backward()
+            if VIEWS == 1:
+                to_white_background(renderer(gm, R=R, T=T, rows=rows), colors).sum().backward()
+            else:
+                sb = stacked_bounds(VIEWS, H, n)
+                render_stacked(lambda b0, b1, r0, r1: to_white_background(renderer(gm, R=R[b0:b1], T=T[b0:b1], rows=(r0, r1)),
+                                                                          colors.repeat(b1 - b0, 1)), sb[r], sb[r + 1], H).sum().backward()
         side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3): step()

@@ -1,4 +1,4 @@
-"""Pixel-row sharding of one frame across the GPUs of a node.
+"""Pixel-row sharding of one frame -- or of a batch of views -- across the GPUs of a node.
 
 Pixels are independent in every stage of the path, so rank r renders the contiguous row band
 `row_band(H, r, world)` with the SAME kernels (the band is just a shorter ray tensor).  The
@@ -6,6 +6,11 @@ only exchanges are: one all-gather of the image rows in the forward, and one all
 of the per-Gaussian gradients in the backward.  One process per GPU, `torch.distributed`
 (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).  The reference has no
 counterpart (its only multi-device code, DataParallelBatchifier, Utils.py:179-333, is unused).
+
+A BATCH of B views (a ShapeFitting iteration renders 5, demo/ShapeFitting.py:231) shards along the STACKED (view, row)
+axis of B*H rows, view first (`stacked_bounds`): with B >= world a rank renders whole views -- the per-view fixed cost
+(launch chain, per-Gaussian binning pass) is then paid once per view in total, as on one GPU, instead of once per rank
+and view -- and falls back to row bands inside a view only where a cut lands there (`stacked_segments`).
 """
 import torch
 import torch.distributed as dist
@@ -16,6 +21,63 @@ def row_band(H, rank, world):
     base, extra = divmod(int(H), int(world))
     r0 = rank * base + min(rank, extra)
     return r0, r0 + base + (1 if rank < extra else 0)
+
+
+def stacked_bounds(B, H, world):
+    """world+1 cut points on the stacked (view, row) axis [0, B*H) of a B-view batch of H-row images: range r is
+    [b[r], b[r+1]).  View first: when the views divide evenly (B % world == 0) every rank gets B/world WHOLE views (no
+    view is rendered by two ranks: no fixed cost is paid twice); otherwise the B*H rows are cut evenly (ranges differ by
+    at most one row) and a cut may fall inside a view, which stacked_segments turns into row bands of that view."""
+    B, H, world = int(B), int(H), int(world)
+    assert B >= 1 and H >= 1 and world >= 1 and B * H >= world
+    if B % world == 0:
+        return [r * (B // world) * H for r in range(world + 1)]
+    return [row_band(B * H, r, world)[0] for r in range(world)] + [B * H]
+
+
+def stacked_segments(s0, s1, H):
+    """Stacked rows [s0, s1) as at most three rectangles (b0, b1, r0, r1) = views [b0, b1) x rows [r0, r1): the tail of a
+    first partial view, a run of whole views, the head of a last partial view -- each one renderer call (`rows=`)."""
+    s0, s1, H = int(s0), int(s1), int(H)
+    assert 0 <= s0 <= s1
+    if s0 == s1:
+        return []
+    b0, r0 = divmod(s0, H)
+    b1, r1 = divmod(s1, H)
+    if b0 == b1:
+        return [(b0, b0 + 1, r0, r1)]
+    segs = []
+    if r0 > 0:
+        segs.append((b0, b0 + 1, r0, H))
+        b0 += 1
+    if b1 > b0:
+        segs.append((b0, b1, 0, H))
+    if r1 > 0:
+        segs.append((b1, b1 + 1, 0, r1))
+    return segs
+
+
+def render_stacked(render_views, s0, s1, H):
+    """The rank's part of a batch: `render_views(b0, b1, r0, r1) -> [b1-b0, r1-r0, W, C]` (e.g. the renderer on
+    R[b0:b1], T[b0:b1] with rows=(r0, r1) followed by to_white_background) for every rectangle of stacked rows
+    [s0, s1), concatenated to [s1-s0, W, C] stacked rows (only the images are concatenated, never the fragments)."""
+    parts = []
+    for b0, b1, r0, r1 in stacked_segments(s0, s1, H):
+        img = render_views(b0, b1, r0, r1)
+        assert img.shape[0] == b1 - b0 and img.shape[1] == r1 - r0
+        parts.append(img.reshape(((b1 - b0) * (r1 - r0),) + tuple(img.shape[2:])))
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+
+
+def gather_stacked(rows, B, H, group=None, bounds=None):
+    """[s1-s0, W, C] stacked rows of every rank -> the whole batch [B, H, W, C]: ONE all_gather (gather_rows on the
+    stacked axis; differentiable the same way).  bounds = stacked_bounds(B, H, world) unless given."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return rows.reshape((B, H) + tuple(rows.shape[1:]))
+    if bounds is None:
+        bounds = stacked_bounds(B, H, dist.get_world_size(group))
+    full = gather_rows(rows[None], B * H, group=group, bounds=bounds)
+    return full.reshape((B, H) + tuple(rows.shape[1:]))
 
 
 def balanced_row_bounds(row_weight, world, floor=0.1):
@@ -52,6 +114,8 @@ def rebalance_bounds(bounds, times, fixed=0.0, damping=1.0, min_rows=1):
     n = len(times)
     assert len(bounds) == n + 1 and n >= 1
     H = int(bounds[-1])
+    min_rows = max(1, min(int(min_rows), H // n))      # (n * min_rows > H could not be met: the clamps below would cross)
+    assert H >= n, "fewer rows than bands"
     cost = torch.zeros(H, dtype=torch.float64)
     for r in range(n):
         r0, r1 = int(bounds[r]), int(bounds[r + 1])
@@ -66,6 +130,7 @@ def rebalance_bounds(bounds, times, fixed=0.0, damping=1.0, min_rows=1):
         b = min(b, H - (n - r) * min_rows)
         out.append(b)
     out.append(H)
+    assert all(b1 > b0 for b0, b1 in zip(out, out[1:])), out      # strictly increasing: every band keeps rows
     return out
 
 
