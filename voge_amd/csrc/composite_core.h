@@ -233,6 +233,16 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
   for (int a = 0; a < NS; ++a) w[a] = (em[a] != 0.0f) ? FAST_EXP(-occ * S[a]) * em[a] * kInvNorm : 0.0f;
 }
 
+// -DVOGE_FB_TIMES builds: lane utilisation of the window loops (tools/fb_sections.py).  Per workgroup (= wave) row:
+// [0] row-loop iterations x 64, [1] lanes active in them, [2] column-loop iterations x 64, [3] lanes active in them.
+#ifdef VOGE_FB_TIMES
+__device__ unsigned long long g_cw_stats[1 << 16][4];
+#define CW_COUNT(i) do { const unsigned long long m_ = __ballot(true); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(m_) && blockIdx.x < (1 << 16)) { \
+      g_cw_stats[blockIdx.x][i] += 64; g_cw_stats[blockIdx.x][(i) + 1] += (unsigned long long)__popcll(m_); } } while (0)
+#else
+#define CW_COUNT(i) do {} while (0)
+#endif
+
 // Backward, wave form, with the forward's weights given (u_m = g_m w_m comes from the caller): the closed-form
 // gradients of the lane's own slots (header of composite.hip).  The pixel's padded rows len / s' / E s' are in LDS
 // (the sentinel pads' u entries are zero); this routine stores u into Lu itself.  Same conventions as compn_fwd_rows.
@@ -300,6 +310,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
     for (int e = d0 - 2;; e -= 2) {      // column pairs in front of every own row; row 0 is the nearest
       const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
       if (!(lm[0] - l2.y < rwin)) break;
+      CW_COUNT(0);
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
         const v2f xa = (splat(lm[a]) - l2) * s2;
@@ -309,6 +320,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
     for (int e = d0 + NS;; e += 2) {     // column pairs behind every own row
       const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
       if (!(l2.x - lmB < rwin)) break;
+      CW_COUNT(0);
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
         const v2f xa = (l2 - splat(lm[a])) * s2;
@@ -381,6 +393,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
 #pragma unroll
         for (int b2 = 0; b2 < NS; ++b2) need = need || (l2.x - lm[b2] < rj[b2]);
         if (!need) break;
+        CW_COUNT(2);
 #pragma unroll
         for (int b2 = 0; b2 < NS; ++b2) {
           const v2f d = l2 - splat(lm[b2]);
@@ -395,6 +408,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
 #pragma unroll
         for (int b2 = 0; b2 < NS; ++b2) need = need || (lm[b2] - l2.y < rj[b2]);
         if (!need) break;
+        CW_COUNT(2);
 #pragma unroll
         for (int b2 = 0; b2 < NS; ++b2) {
           const v2f d = splat(lm[b2]) - l2;
