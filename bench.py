@@ -85,6 +85,10 @@ def stage_bytes(P, npix, K, C=3, iso=False):
         "fragment_bwd": npix * K * (12 if iso else 20) + npix * (2 * 4 * C + 4 + 12) + P * (4 * C + g) + P * (4 * C + g),
         # scalar sigmas, trace + composite in one entry point: Gaussians and rays in; idx, len, weight, valid_num, cnt out
         "fragments_fwd": P * 16 + npix * 12 + npix * K * 12 + npix * 12,
+        # the renderer's forward with the composite deferred: Gaussians and rays in; idx, len, cnt, records out
+        "trace_lean_fwd": P * 16 + npix * 12 + npix * K * 8 + npix * 4 + P * 16,
+        # composite + shade in one pass: idx, len, cnt, rays, records, colours in; weight, valid_num, rgb, img, wsum out
+        "composite_shade_fwd": npix * K * 8 + npix * 4 + npix * 12 + P * 16 + P * 4 * C + npix * K * 4 + npix * 8 + 2 * npix * 4 * C + npix * 4,
     }
 
 
@@ -218,7 +222,7 @@ def main():
 
     from voge_amd import _lib, ops, scenes
     from voge_amd.Meshes import GaussianMeshes
-    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, get_silhouette, interpolate_attr, to_white_background
     from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
     from voge_amd.distributed import FlatGrads, gather_rows, gather_rows_async, rebalance_bounds, row_band
     _lib.load()
@@ -230,19 +234,26 @@ def main():
     bands = {"bounds": [row_band(H, r, world)[0] for r in range(world)] + [H]} if world > 1 else None
     rows = (bands["bounds"][rank], bands["bounds"][rank + 1]) if world > 1 else None
 
-    def make_frame(anisotropic, default_bins):
-        """(step function, parameters) of one forward+backward frame of the config."""
+    renderer_of = [None]      # (the renderer of the frame made last)
+
+    def make_frame(anisotropic, default_bins, pattern="white_background"):
+        """(step function, parameters) of one forward+backward frame of the config.  pattern: the metric's
+        to_white_background image, or the reference training loops' interpolate_attr + get_silhouette pair."""
         verts, sig, cols = scenes.random_gaussians(N, seed=0, anisotropic=anisotropic)
         gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
         colors = torch.from_numpy(cols).to(dev).requires_grad_(True)
         settings = GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1,
                                           max_point_per_bin=None if default_bins else -1)
         renderer = GaussianRenderer(cams, settings).to(dev)
+        renderer_of[0] = renderer
         params = [gm.verts, gm.sigmas, colors]
 
         def fwd():
             kw = {} if bands is None else {"rows": (bands["bounds"][rank], bands["bounds"][rank + 1])}
-            return to_white_background(renderer(gm, R=R, T=T, **kw), colors)
+            frag = renderer(gm, R=R, T=T, **kw)
+            if pattern == "white_background":
+                return to_white_background(frag, colors)
+            return torch.cat((interpolate_attr(frag, colors), get_silhouette(frag).unsqueeze(-1)), dim=-1)
         return fwd, params, gm, colors, (verts, sig, cols)
 
     def warm_side_stream(fn):
@@ -511,6 +522,20 @@ def main():
                     lambda s: lib.voge_fragments_fwd_iso(P_(mus), P_(isg), P_(rays), None, P_(cones), 1, N, H, W, K, thr_act, 1.0,
                                                          P_(s["ws"]), nws, P_(s["i"]), P_(s["l"]), None, None, P_(s["c"]), P_(s["w"]),
                                                          P_(s["v"]), P_(s["r"]), st))
+                # the frame as the renderer runs it since round 3: the trace alone (composite deferred) ...
+                stage_defs["trace_lean_fwd"] = (
+                    lambda: dict(ws=torch.empty(nws, dtype=torch.uint8, device=dev), i=E(idx), l=E(w),
+                                 c=torch.empty((1, H, W), dtype=torch.int32, device=dev), r=torch.empty((N, 4), device=dev)),
+                    lambda s: lib.voge_fragments_fwd_iso(P_(mus), P_(isg), P_(rays), None, P_(cones), 1, N, H, W, K, thr_act, 1.0,
+                                                         P_(s["ws"]), nws, P_(s["i"]), P_(s["l"]), None, None, P_(s["c"]), None,
+                                                         None, P_(s["r"]), st))
+                # ... and composite + shade in one pass when to_white_background asks for the image
+                if K % 4 == 0:
+                    stage_defs["composite_shade_fwd"] = (
+                        lambda: dict(i=C_(sel[0]), c=C_(cnt), l=C_(sel[1]), w=E(w), v=E(vn), rgb=E(rgb), img=E(rgb), ws=E(wsum)),
+                        lambda s: lib.voge_composite_shade_fwd_iso(P_(s["i"]), P_(s["c"]), P_(s["l"]), P_(recs), P_(rays), 1.0, P_(colors),
+                                                                   P_(bg), -1.0, npix, K, 3, N, P_(s["w"]), P_(s["v"]), P_(s["rgb"]),
+                                                                   P_(s["img"]), P_(s["ws"]), st))
             else:
                 # the general path's fused backward (voge_fragment_shade_bwd): full 3x3 forms
                 nfb = lib.voge_fragment_bwd_workspace_bytes(N)
@@ -543,12 +568,14 @@ def main():
         dom = "trace_fwd"  # the sweep BASELINE.json's metric names
         a = stages[dom]["GBps"]
         traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r2_traffic.json")
-        if os.path.exists(tfile) and not args.anisotropic:
+        tname = next((t for t in ("r3_traffic.json", "r2_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), None)
+        tcfg = {}
+        if tname is not None and not args.anisotropic:
             # HBM bytes per launch from rocprofv3 PMC passes of this same command (not collectable from inside the run)
-            traffic = json.load(open(tfile)).get(args.config, {}).get("voge_trace_topk_fwd_bytes")
+            tcfg = json.load(open(os.path.join(ROOT, "profiles", tname))).get(args.config, {})
+            traffic = tcfg.get("voge_trace_topk_fwd_bytes")
             if traffic is not None:
-                traffic_src = ("profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2: "
+                traffic_src = (f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2: "
                                "tools/refresh_profiles.sh)")
         result["roofline"] = {"kernel": TRACE_KERNELS, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -556,21 +583,57 @@ def main():
         result["stages"] = stages
         result["stages_note"] = ("ms / GBps: the call cycling over `buffer_sets` independent sets of operands (> 3 x the 256 MB "
                                  "Infinity Cache in total), i.e. served from HBM; ms_same_buffers: replayed on one set (L3-assisted)")
-        on_frame = (("fragments_fwd", "shade_fwd", "fragment_bwd") if "fragments_fwd" in stages
+        on_frame = (("trace_lean_fwd", "composite_shade_fwd", "fragment_bwd") if "composite_shade_fwd" in stages
+                    else ("fragments_fwd", "shade_fwd", "fragment_bwd") if "fragments_fwd" in stages
                     else ("trace_fwd", "composite_fwd", "shade_fwd", "fragment_bwd"))
         result["stages_on_frame"] = list(on_frame)      # (the stand-alone entry points are timed for reference, not launched)
         result["frame_kernel_ms_sum"] = round(sum(stages[k]["ms"] for k in on_frame), 4)
         result["hits_per_pixel"] = round(hits / npix, 2)
+        # the whole frame against the same roofline: algorithmic bytes of the entry points it launches, and the HBM bytes
+        # the PMC counters saw for one frame of this config (committed passes), both over the measured ms_per_step
+        f_algo = sum(nbytes[k] for k in on_frame) + npix * 12
+        f_traffic = tcfg.get("frame_hbm_bytes")
+        result["frame_roofline"] = {
+            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes": f_algo,
+            "achieved": round(f_algo / 1e9 / (ms / 1e3), 1), "frac": round(f_algo / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
+            "traffic": f_traffic,
+            "traffic_GBps": None if f_traffic is None else round(f_traffic / 1e9 / (ms / 1e3), 1),
+            "traffic_frac": None if f_traffic is None else round(f_traffic / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
+            "note": "entry points of stages_on_frame + the rays; divided by ms_per_step (graph replay: includes the loss' reduction)"}
         if not args.no_variants and not args.anisotropic and not args.default_bins:
             # the same step on the metric's stated variants: full 3x3 forms; the demos' default bins
             variants = {}
-            for vname, (an, db) in (("anisotropic_3x3", (True, False)), ("max_point_per_bin_None", (False, True))):
+            for vname, (an, db, pat) in (("anisotropic_3x3", (True, False, "white_background")),
+                                         ("max_point_per_bin_None", (False, True, "white_background")),
+                                         # what the reference's training loops differentiate (ShapeFitting.py:217,295)
+                                         ("interpolate_attr_and_silhouette", (False, False, "attr_and_silhouette"))):
                 del fwd, params, gm, colors
                 torch.cuda.empty_cache()
-                fwd, params, gm, colors, _ = make_frame(an, db)
+                fwd, params, gm, colors, _ = make_frame(an, db, pat)
                 vrun, vlaunch = graphed_step(fwd, params)
                 vdt = timed(vrun, max(10, args.steps // 2), 3)
                 variants[vname] = {"value": round(max(10, args.steps // 2) / vdt, 1), "unit": "frames/s", "launch": vlaunch}
+            # the honest companion of the graph-replay headline: launched eagerly, and the camera MOVES every step (a new
+            # R, T on the device each frame -- nothing about a frame can be reused from the last one)
+            del fwd, params, gm, colors
+            torch.cuda.empty_cache()
+            fwd, params, gm, colors, _ = make_frame(False, False)
+            nview = 64
+            Rm, Tm = look_at_view_transform(dist=[dd] * nview, elev=[el] * nview, azim=[az + 0.5 * i for i in range(nview)], device=dev)
+            state = {"i": 0}
+
+            def moving():
+                i = state["i"] = (state["i"] + 1) % nview
+                for p_ in params:
+                    p_.grad = None
+                kw = {} if bands is None else {"rows": (bands["bounds"][rank], bands["bounds"][rank + 1])}
+                to_white_background(renderer_of[0](gm, R=Rm[i:i + 1], T=Tm[i:i + 1], **kw), colors).sum().backward()
+            for _ in range(60):
+                moving()
+            torch.cuda.synchronize()
+            nm = max(20, args.steps)
+            vdt = timed(moving, nm, 5)
+            variants["eager_moving_camera"] = {"value": round(nm / vdt, 1), "unit": "frames/s", "launch": "eager, a different camera every step"}
             result["variants"] = variants
         if not args.no_cpu_baseline:
             verts, sig, cols = host_scene

@@ -192,7 +192,12 @@ int voge_bin_gaussians(const float *points, const int64_t *cloud_to_packed_first
  * (no per-slot gather in its epilogue), the composite derives act / dsd from the (mean, a) records with the same
  * operations (voge_composite_fwd_iso), and so does voge_fragment_shade_bwd_iso when handed NULL for them: 168 MB per
  * frame at 50k Gaussians / 512^2 / K = 40 that are neither written nor read.  Weights are bit-identical either way.
- * voge_fragment_act_dsd_iso materialises them afterwards for consumers that want the arrays. */
+ * voge_fragment_act_dsd_iso materialises them afterwards for consumers that want the arrays.
+ * TRACE ONLY (scalar-sigma forms): weight = valid_num = act = dsd = NULL with records given -- the call stops behind the
+ * sweep (idx, len, cnt, records are written) and the caller composites when it knows what it wants: voge_composite_fwd_iso
+ * for the weights alone, or voge_composite_shade_fwd_iso for the weights AND the image of to_colored_background in one
+ * pass (GaussianRenderer returns its Fragments before the colours are known: the Python side defers the composite
+ * until the fragments' weights are first asked for, voge_amd/Renderer.py). */
 int voge_fragments_fwd(const float *mus, const float *isigmas, const float *rays, const float *cam_fwd,
                        const float *cones, int B, int N, int H, int W, int K, float thr_act, float occ,
                        void *workspace, size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
@@ -232,6 +237,15 @@ int voge_fragment_act_dsd_iso(const float *records, const float *rays, const int
 int voge_composite_fwd_iso(const int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                            const float *rays, float occ, long npix, int K, float *weight, int64_t *valid_num,
                            voge_stream_t stream);
+/* Composite forward (as voge_composite_fwd_iso) with the SHADE stage in the same pass: merge_final + get_silhouette +
+ * to_colored_background (VoGE/Aggregation.py:111-141, VoGE/Renderer.py:157-171) -- what voge_composite_fwd_iso followed
+ * by voge_shade_fwd computes, without reading idx / weight back (8 bytes per slot) and without the second launch.
+ * colors [Nattr,C], C = 3 | 4; bg [C]; thr as voge_shade_fwd.  Writes weight [npix,K], valid_num [npix], rgb / img [npix,C],
+ * wsum [npix], and rewrites the empty slots of idx in place (-1 -> 0, Aggregation.py:131).  K % 4 == 0; cnt required. */
+int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                                 const float *rays, float occ, const float *colors, const float *bg, float thr,
+                                 long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num, float *rgb,
+                                 float *img, float *wsum, voge_stream_t stream);
 /* The same for full 3x3 forms (mus [P,3], isigmas [P,3,3] as given to voge_fragments_fwd; P = B*N): writes g_mus
  * [P,3], g_isigmas [P,3,3] (the raw, unsymmetrised outer-product sums of ray_trace_voge.cu:324-326, as voge_trace_bwd)
  * -- both or neither -- and g_colors [Nattr,C].  Same constraints and workspace as the isotropic form. */

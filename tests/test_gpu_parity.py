@@ -938,20 +938,24 @@ def test_fused_fragment_backward_equals_the_three_kernels(hip_lib, K, B, inverse
     g_sil = torch.randn(B, H, W, device=DEV, generator=gen)
     out = {}
     for fused in (True, False):
+        # (fused: the renderer's default -- deferred composite, one-pass shade forward, one-kernel backward;
+        #  not fused: the eager chain with every stage a kernel of its own)
+        monkeypatch.setattr(ops, "LAZY_COMPOSITE", fused)
         gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(DEV)
         colors = t(np.tile(cols, (B, 1)), rg=True)
         frag = renderer(gm, R=R, T=T)
-        assert hasattr(frag.vert_weight, "voge_through")
+        if not fused:
+            assert hasattr(frag.vert_weight, "voge_through")
         if not fused:
             del frag.vert_weight.voge_through
         # the comparison chain: voge_shade_bwd -> voge_composite_bwd -> voge_trace_bwd*, act / dsd materialised
         monkeypatch.setattr(ops, "THREE_KERNEL_BACKWARD", not fused)
         img = to_colored_background(frag, colors, background_color=(0.9, 0.8, 1.0))
-        assert (type(img.grad_fn).__name__ == "_ShadeThroughBackward") == fused
+        assert (type(img.grad_fn).__name__ in ("_ShadeThroughBackward", "_CompositeShadeBackward")) == fused
         hl = torch.where(frag.vert_index >= 0, frag.vert_hit_length, torch.zeros_like(frag.vert_hit_length))
         ((img * g_img).sum() + (get_silhouette(frag) * g_sil).sum() + 0.01 * hl.sum()).backward()
         out[fused] = [n(x) for x in (img, gm.verts.grad, gm.sigmas.grad, colors.grad)]
-    assert np.array_equal(out[True][0], out[False][0])
+    assert np.abs(out[True][0] - out[False][0]).max() <= 1e-6      # (one pass sums per lane group, the shade kernel per DPP row)
     for name, x, y in zip(("verts", "sigmas", "colors"), out[True][1:], out[False][1:]):
         scale = max(1.0, float(np.abs(y).max()))
         assert np.abs(x - y).max() <= 3e-5 * scale, (name, float(np.abs(x - y).max()), scale)
@@ -974,7 +978,7 @@ def test_fused_fragment_backward_reads_a_broadcast_gradient_in_place(hip_lib):
         gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(DEV)
         colors = t(cols, rg=True)
         img = to_white_background(renderer(gm, R=R, T=T), colors)
-        assert type(img.grad_fn).__name__ == "_ShadeThroughBackward"
+        assert type(img.grad_fn).__name__ in ("_ShadeThroughBackward", "_CompositeShadeBackward")
         if broadcast:
             (0.5 * img.mean()).backward()
         else:
@@ -1047,7 +1051,7 @@ def test_renderer_edge_shapes(hip_lib, N, H, W, K, B, aniso, fused):
     renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=(H, W), max_assign=K, max_point_per_bin=-1)).to(DEV)
     frag = renderer(gm, R=R, T=T)
     img = to_white_background(frag, colors)
-    assert (type(img.grad_fn).__name__ == "_ShadeThroughBackward") == fused
+    assert (type(img.grad_fn).__name__ in ("_ShadeThroughBackward", "_CompositeShadeBackward")) == fused
     (img.sum() + get_silhouette(frag).sum()).backward()
     torch.cuda.synchronize()
     assert img.shape == (B, H, W, 3) and torch.isfinite(img).all() and torch.isfinite(colors.grad).all()

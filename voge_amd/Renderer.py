@@ -23,15 +23,51 @@ FUSED_PREAMBLE = os.environ.get("VOGE_FUSED_PREAMBLE", "1") != "0"
 
 
 class Fragments(object):
-    """vert_weight [.., K] f32, vert_index [.., K] i32, valid_num [..] i64, vert_hit_length [.., K] f32."""
+    """vert_weight [.., K] f32, vert_index [.., K] i32, valid_num [..] i64, vert_hit_length [.., K] f32.
+
+    Same fields and methods as VoGE/Renderer.py:13-50.  Fragments made by this renderer from scalar sigmas may arrive
+    with their composite DEFERRED (`_lazy`): vert_index and vert_hit_length are there, vert_weight / valid_num are
+    computed the first time anybody reads them -- or never, when to_colored_background gets the fragments first and
+    produces weights and image in one pass (ops._CompositeShade).  Reading the attributes is all it takes; nothing about
+    the values depends on when that happens."""
 
     _fields = ("vert_weight", "vert_index", "valid_num", "vert_hit_length")
 
-    def __init__(self, vert_weight, vert_index, valid_num, vert_hit_length):
-        self.vert_weight = vert_weight
+    def __init__(self, vert_weight, vert_index, valid_num, vert_hit_length, _lazy=None):
+        self._vert_weight = vert_weight
         self.vert_index = vert_index
-        self.valid_num = valid_num
+        self._valid_num = valid_num
         self.vert_hit_length = vert_hit_length
+        self._lazy = _lazy if vert_weight is None else None
+
+    def _composite(self):
+        lz, self._lazy = self._lazy, None
+        self._vert_weight, self._valid_num = ops.composite_lean(lz)
+
+    def _set_composite(self, weight, valid_num):
+        self._lazy = None
+        self._vert_weight, self._valid_num = weight, valid_num
+
+    @property
+    def vert_weight(self):
+        if self._lazy is not None:
+            self._composite()
+        return self._vert_weight
+
+    @vert_weight.setter
+    def vert_weight(self, value):
+        self._lazy = None
+        self._vert_weight = value
+
+    @property
+    def valid_num(self):
+        if self._valid_num is None and self._lazy is not None:
+            self._valid_num = self._lazy.cnt.to(torch.int64)      # (= the trace's hit count; the composite writes the same)
+        return self._valid_num
+
+    @valid_num.setter
+    def valid_num(self, value):
+        self._valid_num = value
 
     def _map(self, fn):
         # (views of the same memory keep the trace's bookkeeping -- ops.carry_tags -- so frag.copy(), frag.squeeze()
@@ -39,28 +75,30 @@ class Fragments(object):
         return Fragments(**{k: ops.carry_tags(getattr(self, k), fn(getattr(self, k))) for k in self._fields})
 
     def __getitem__(self, item):
-        assert len(self.valid_num.shape) == 3, 'Index access is only available when batched.'
+        assert self.vert_index.dim() == 4, 'Index access is only available when batched.'
         return self._map(lambda t: t[item])
 
     def __len__(self):
-        return self.valid_num.shape[0]
+        return self.vert_index.shape[0]
 
     @property
     def shape(self):
         return tuple(getattr(self, k).shape for k in self._fields)
 
     def squeeze(self):
-        assert self.valid_num.shape[0] == 1
+        assert self.vert_index.shape[0] == 1
         return self[0]
 
     def unsqueeze(self):
-        assert len(self.valid_num.shape) == 2
+        assert self.vert_index.dim() == 3
         return self._map(lambda t: t.unsqueeze(0))
 
     def to_dict(self):
         return {k: getattr(self, k) for k in self._fields}
 
     def copy(self):
+        if self._lazy is not None:      # nothing to copy yet: the same deferred composite (tensors are shared either way,
+            return Fragments(None, self.vert_index, self._valid_num, self.vert_hit_length, _lazy=self._lazy)   # .contiguous() is a no-op)
         return self._map(lambda t: t.contiguous())
 
 
@@ -144,8 +182,13 @@ class GaussianRenderer(nn.Module):
             # Renderer.py:130 and the 2*sigma / 2/sigma of :133-137 happen inside the trace's per-Gaussian
             # pass (and their chain rule inside its backward's) -- same values, no elementwise launches.
             cam_fwd = _view_axis(cams, origin[:, None]) if behind else None
-            weight, index, valid_num, hit_len = ops.fragments(2, verts2d, sigmas, origin, rays, cam_fwd, thr_act, K,
-                                                              2 if st['inverse_sigma'] else 1, occ)
+            smode = 2 if st['inverse_sigma'] else 1
+            if ops.lazy_eligible(2, verts2d, sigmas, origin, rays, K):
+                # stop behind the sweep: the composite runs when the weights are first read -- or inside
+                # to_colored_background's own pass (Fragments._lazy)
+                index, hit_len, lz = ops.trace_lean(2, verts2d, sigmas, origin, rays, cam_fwd, thr_act, K, smode, occ)
+                return Fragments(None, index, None, hit_len, _lazy=lz)
+            weight, index, valid_num, hit_len = ops.fragments(2, verts2d, sigmas, origin, rays, cam_fwd, thr_act, K, smode, occ)
             return Fragments(vert_weight=weight, vert_index=index, valid_num=valid_num, vert_hit_length=hit_len)
         centred = verts - origin[:, None]                                         # Renderer.py:130
         cam_fwd = _view_axis(cams, centred) if behind else None
@@ -156,8 +199,11 @@ class GaussianRenderer(nn.Module):
             # isotropic form whose backward produces d/d(scalar) directly.
             a = 2.0 / sigmas if st['inverse_sigma'] else 2.0 * sigmas
             a = a.unsqueeze(0).expand(B, -1)
-            weight, index, valid_num, hit_len = ops.fragments(1, centred.reshape(-1, 3), a.reshape(-1), None, rays, cam_fwd,
-                                                              thr_act, K, 0, occ)
+            mus1, a1 = centred.reshape(-1, 3), a.reshape(-1)
+            if ops.lazy_eligible(1, mus1, a1, None, rays, K):
+                index, hit_len, lz = ops.trace_lean(1, mus1, a1, None, rays, cam_fwd, thr_act, K, 0, occ)
+                return Fragments(None, index, None, hit_len, _lazy=lz)
+            weight, index, valid_num, hit_len = ops.fragments(1, mus1, a1, None, rays, cam_fwd, thr_act, K, 0, occ)
         else:
             sigmas = expend_sigma(sigmas)
             if sigmas.dim() == 3:
@@ -198,6 +244,13 @@ def to_colored_background(fragments: Fragments, colors: torch.Tensor,
     if not torch.is_tensor(background_color):
         background_color = _background_tensor(background_color, colors.device)
     background_color = background_color.to(colors.device)
+    lz = getattr(fragments, "_lazy", None)
+    if lz is not None:
+        # fragments whose composite is still pending: weights AND image in one pass (ops._CompositeShade)
+        out = ops.composite_shade(lz, colors, background_color, thr)
+        if out is not None:
+            fragments._set_composite(out[1], out[2])
+            return out[0]
     if colors.dim() == 2 and colors.shape[1] <= 4:
         # merge + silhouette + blend fused in one kernel; on fragments of this renderer the backward of the whole
         # pipeline (this blend, the composite, the trace) is one kernel as well (ops._ShadeThrough)

@@ -42,6 +42,8 @@ SIGNATURES = {
                                     + [_c_float, _c_float, _c_void_p, _c_size_t] + [_c_void_p] * 9),
     "voge_fragment_bwd_workspace_bytes": (_c_size_t, [_c_int]),
     "voge_fragment_act_dsd_iso": (_c_int, [_c_void_p] * 5 + [_c_long, _c_int, _c_int] + [_c_void_p] * 3),
+    "voge_composite_shade_fwd_iso": (_c_int, [_c_void_p] * 5 + [_c_float, _c_void_p, _c_void_p, _c_float, _c_long, _c_int, _c_int, _c_long]
+                                     + [_c_void_p] * 6),
     "voge_composite_fwd_iso": (_c_int, [_c_void_p] * 5 + [_c_float, _c_long, _c_int] + [_c_void_p] * 3),
     "voge_fragment_shade_bwd": (_c_int, [_c_void_p] * 13 + [_c_float, _c_void_p, _c_long, _c_long, _c_float]
                                 + [_c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),

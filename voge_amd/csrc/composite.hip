@@ -341,7 +341,19 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
 // WAVE: every pixel's lanes sit inside ONE wave (64 / LP pixels per wave, the remaining lanes idle), so the
 // per-pixel scans, flags and reductions are wave shuffles / ballots and the kernel has no workgroup barrier at
 // all: each wave runs from its loads to its stores on its own.  (Needs LP <= 64.)
-template <int MODE, int NS, bool WAVE, typename OffT>   // MODE 0: forward, 2: backward with weights; OffT: composite_core.h at_bytes
+// SC > 0 (forward from the records, wave form): the SHADE stage rides in the same pass -- merge_final + get_silhouette +
+// to_colored_background (VoGE/Aggregation.py:111-141, VoGE/Renderer.py:157-171) for SC colour channels: the lane gathers
+// the colours of its own slots (their indices are in registers), the pixel's lanes sum w * colour and w, lane 0 writes
+// rgb / wsum / img, and empty slots of the index list are rewritten -1 -> 0 as merge_final does (:131).  What a separate
+// shade kernel would read again (idx and weight: 8 bytes per slot) is never read.
+struct CompShade {
+  const float *colors, *bg;
+  float thr;
+  long Nattr;
+  float *rgb, *img, *wsum;
+  int32_t *idx_fix;
+};
+template <int MODE, int NS, bool WAVE, typename OffT, int SC = 0>   // MODE 0: forward, 2: backward with weights; OffT: composite_core.h at_bytes
 __global__ void __launch_bounds__(kCompThreads) __attribute__((amdgpu_waves_per_eu(VOGE_COMP_WPE)))
 compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
                   const float *__restrict__ len, const float *__restrict__ dsd,
@@ -349,7 +361,9 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
                   const int32_t *__restrict__ cnt_in, const float occ, const long npix, const int K, const int ppw,
                   float *__restrict__ out0 /* weight | g_act */, float *__restrict__ out1 /* g_len */,
                   float *__restrict__ out2 /* g_dsd */, int64_t *__restrict__ valid_num,
-                  const float4 *__restrict__ rec /* forward with act == NULL: [P] (mu, a) */, const float *__restrict__ rays) {
+                  const float4 *__restrict__ rec /* forward with act == NULL: [P] (mu, a) */, const float *__restrict__ rays,
+                  const CompShade sh = CompShade{}) {
+  static_assert(SC == 0 || (MODE == 0 && WAVE && SC <= 4), "the shade stage rides in the wave-form forward only");
   constexpr bool BWD = MODE != 0;
   constexpr int NP = NS / 2;       // own aligned pairs
   extern __shared__ __attribute__((aligned(16))) unsigned char comp_smem[];
@@ -396,8 +410,16 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
       if (active) {
 #pragma unroll
         for (int a = 0; a < NS; ++a)
-          if (has[a]) { out0[f + a] = 0.0f; if (BWD) { out1[f + a] = 0.0f; out2[f + a] = 0.0f; } }
+          if (has[a]) { out0[f + a] = 0.0f; if (BWD) { out1[f + a] = 0.0f; out2[f + a] = 0.0f; } if (SC > 0) sh.idx_fix[f + a] = 0; }
         if (!BWD && q == 0) valid_num[pix] = 0;
+        if (SC > 0 && q == 0) {      // nothing was hit: the background
+          sh.wsum[pix] = 0.0f;
+#pragma unroll
+          for (int c = 0; c < SC; ++c) {
+            sh.rgb[pix * SC + c] = 0.0f;
+            sh.img[pix * SC + c] = fminf(sh.bg[c], 1.0f);
+          }
+        }
       }
       return;
     }
@@ -406,8 +428,9 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   // what a sentinel slot evaluates to: E = 0, len = 1e10, s = 1e-5
   float lm[NS], sm[NS], em[NS], gw[NS], wg[NS];
   int id[NS];
+  int ivk[NS];      // (SC > 0) the lane's indices, kept for the colour gathers
 #pragma unroll
-  for (int a = 0; a < NS; ++a) { lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.0f; gw[a] = 0.0f; wg[a] = 0.0f; id[a] = -1; }
+  for (int a = 0; a < NS; ++a) { lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.0f; gw[a] = 0.0f; wg[a] = 0.0f; id[a] = -1; ivk[a] = -1; }
   if (!BWD && act == nullptr) {
     // Fragments without act / dsd in memory (voge_fragments_fwd_iso*): the sweep wrote index and len only; act and dsd
     // of A = a I are re-derived here from the SAME records with the SAME operations its epilogue would have used
@@ -436,6 +459,10 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
       float4 rc[NS];
 #pragma unroll
       for (int a = 0; a < NS; ++a) rc[a] = (k0 + a < lead) ? at_bytes<float4>(rec, (uint32_t)iv[a] * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (SC > 0) {
+#pragma unroll
+        for (int a = 0; a < NS; ++a) ivk[a] = (k0 + a < lead) ? iv[a] : -1;
+      }
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
         if (k0 + a < lead) {
@@ -560,6 +587,59 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
         for (int a = 0; a < NS; ++a) if (has[a]) out0[f + a] = w[a];
       }
       if (q == 0) valid_num[pix] = (cnt_in != nullptr) ? (int64_t)cnt_in[pix] : (int64_t)wave_cnt;
+    }
+    if (SC > 0) {
+      // ---- shade: sum_k w_k colour[idx_k] and sum_k w_k over the pixel's lanes; blend over the background ----
+      float part[SC + 1];
+#pragma unroll
+      for (int c = 0; c <= SC; ++c) part[c] = 0.0f;
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const int p2 = ivk[a];
+        if (p2 >= 0 && p2 < sh.Nattr && w[a] != 0.0f) {
+          const uint32_t o = (uint32_t)p2 * (uint32_t)(4 * SC);      // (bytes; Nattr * SC < 2^30: host)
+          if (SC == 3) {
+            const float3 v = at_bytes<float3>(sh.colors, o);
+            part[0] = fmaf(w[a], v.x, part[0]); part[1] = fmaf(w[a], v.y, part[1]); part[2] = fmaf(w[a], v.z, part[2]);
+          } else if (SC == 4) {
+            const float4 v = at_bytes<float4>(sh.colors, o);
+            part[0] = fmaf(w[a], v.x, part[0]); part[1] = fmaf(w[a], v.y, part[1]); part[2] = fmaf(w[a], v.z, part[2]);
+            part[SC - 1] = fmaf(w[a], v.w, part[SC - 1]);
+          } else {
+#pragma unroll
+            for (int c = 0; c < SC; ++c) part[c] = fmaf(w[a], at_bytes<float>(sh.colors, o + 4u * c), part[c]);
+          }
+        }
+        part[SC] += w[a];
+      }
+      // the pixel's lanes are consecutive in the wave: sum towards its first lane (a fixed association per pixel)
+#pragma unroll
+      for (int c = 0; c <= SC; ++c) {
+        float x = part[c];
+        for (int o = 1; o < LP; o <<= 1) {
+          const float y = __shfl_down(x, o, 64);
+          if (q + o < LP && in_wg) x += y;
+        }
+        part[c] = x;
+      }
+      if (active) {
+        // merge_final rewrites empty slots of the index list in place, -1 -> 0 (Aggregation.py:131)
+        if (k0 + NS > lead) {
+#pragma unroll
+          for (int a = 0; a < NS; ++a) if (has[a] && k0 + a >= lead) sh.idx_fix[f + a] = 0;
+        }
+        if (q == 0) {
+          const float ws = part[SC];
+          float sil = fminf(ws, 1.0f);
+          if (sh.thr > 0.0f) sil = sil > sh.thr ? 1.0f : 0.0f;
+          sh.wsum[pix] = ws;
+#pragma unroll
+          for (int c = 0; c < SC; ++c) {
+            sh.rgb[pix * SC + c] = part[c];
+            sh.img[pix * SC + c] = fminf(fmaf(1.0f - sil, sh.bg[c], part[c]), 1.0f);
+          }
+        }
+      }
     }
     return;
   }
@@ -946,6 +1026,35 @@ extern "C" int voge_composite_fwd_iso(const int32_t *idx, const int32_t *cnt, co
   if (!idx || !cnt || !len || !records || !rays || !weight || !valid_num) return VOGE_ERR_BAD_ARG;
   return launch_composite(0, idx, nullptr, len, nullptr, nullptr, nullptr, cnt, occ, npix, K, weight, nullptr, nullptr, valid_num,
                           stream, records, rays);
+}
+
+// Composite forward (from the records) with the shade stage in the same pass: weights, valid_num AND the image.
+extern "C" int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                                            const float *rays, float occ, const float *colors, const float *bg, float thr,
+                                            long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
+                                            float *rgb, float *img, float *wsum, voge_stream_t stream) {
+  if (npix < 0 || K <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
+  if ((K & 3) != 0 || K > VOGE_MAX_K || (C != 3 && C != 4)) return VOGE_ERR_K_TOO_LARGE;      // four slots per lane; RGB / RGBA
+  if (npix == 0) return 0;
+  if (!idx || !cnt || !len || !records || !rays || !weight || !valid_num || !rgb || !img || !wsum || !bg || (Nattr > 0 && !colors))
+    return VOGE_ERR_BAD_ARG;
+  if (Nattr * C >= (1l << 30)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the colour gathers
+  constexpr int NS = 4;
+  const int tn = VOGE_COMP_WAVE_T;
+  const int ppwn = compn_pixels(K, NS, tn, true);
+  const dim3 gridn((unsigned)((npix + ppwn - 1) / ppwn)), blockn(tn);
+  const size_t ldsn = compn_lds_bytes(K, NS, false, tn, true);
+  const bool small = (double)npix * K < (double)(1l << 30);
+  const CompShade sh{colors, bg, thr, Nattr, rgb, img, wsum, idx};
+  hipStream_t st = (hipStream_t)stream;
+  const float4 *rec = reinterpret_cast<const float4 *>(records);
+#define VOGE_LAUNCH_CS(OT, CC)                                                                                               \
+  hipLaunchKernelGGL((compositen_kernel<0, NS, true, OT, CC>), gridn, blockn, ldsn, st, idx, nullptr, len, nullptr, nullptr, nullptr, \
+                     cnt, occ, npix, K, ppwn, weight, nullptr, nullptr, valid_num, rec, rays, sh)
+  if (C == 3) { if (small) VOGE_LAUNCH_CS(uint32_t, 3); else VOGE_LAUNCH_CS(size_t, 3); }
+  else { if (small) VOGE_LAUNCH_CS(uint32_t, 4); else VOGE_LAUNCH_CS(size_t, 4); }
+#undef VOGE_LAUNCH_CS
+  return launch_status();
 }
 
 extern "C" int voge_composite_bwd(const float *act, const float *len, const float *dsd, const float *weight,

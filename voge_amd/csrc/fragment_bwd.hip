@@ -68,12 +68,6 @@ struct FragBwdLds {
 #ifndef VOGE_FB_LDS_RMAX
 #define VOGE_FB_LDS_RMAX 1
 #endif
-#ifndef VOGE_FB_PREFETCH
-#define VOGE_FB_PREFETCH 0      // 1: the next round's streams are requested before the current round is computed (measured: no gain, the kernel is issue-bound)
-#endif
-#ifndef VOGE_FB_TABLE_N
-#define VOGE_FB_TABLE_N 0       // 1: a lane's slots go through the table together (interleaved probe / election chains; measured: no gain)
-#endif
 #ifndef VOGE_FB_WPE
 #define VOGE_FB_WPE 4      // capping the registers for 5 / 6 waves per SIMD spills and is slower
 #endif
@@ -122,87 +116,14 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
   const int incl = wave_incl_scan(need, lane);
   if (__builtin_amdgcn_readlane(incl, 63) == 0) return;     // nothing was hit in these pixels
   wt_clear(L.tab, lane);
-  // A round = the longest run of consecutive pixels whose lanes fit the wave (pack_round).  The streams of the NEXT
-  // round (idx / weight / len [/ act / dsd / g_weight] of every lane's group) are requested before the current round
-  // is computed (VOGE_FB_PREFETCH): the record and colour gathers depend on idx, so a round would otherwise pay two
-  // dependent memory round trips before its first arithmetic.
-  struct Streams {
-    int id[NS];
-    float wv[NS], lm[NS], av[NS], dv[NS], gw[NS];
-  };
   int pc = 0, off = 0;
-  auto next_round = [&](PackLane &pk, int &npm) -> bool {      // (uniform) the next non-empty round, if any
-    while (pc < kFbG) {
-      const int pe = pack_round(need, incl, kFbG, lane, pc, off, pk, npm);
-      off = __builtin_amdgcn_readlane(incl, pe - 1);
-      pc = pe;
-      if (npm != 0) return true;
-    }
-    return false;
-  };
-  auto issue = [&](const PackLane &pk, Streams &st) {
-    const bool on = pk.p >= 0;
-    const int q = on ? lane - pk.s0 : 0;
-    const int lead = __shfl(lead_g, on ? pk.p : 0, 64);
-    const int k0 = NS * q;
-    const OffT pix = on ? (OffT)((y0 + pk.p / kFbGW) * W + x0 + (pk.p & (kFbGW - 1))) : (OffT)0;
-    const OffT fb = (pix * (OffT)K + (OffT)k0) * (OffT)4;
-    bool live[NS];
-#pragma unroll
-    for (int a = 0; a < NS; ++a) {
-      st.id[a] = -1; st.wv[a] = 0.f; st.lm[a] = VOGE_SENT_LEN; st.av[a] = 0.f; st.dv[a] = 0.f; st.gw[a] = 0.f;
-      live[a] = on && (k0 + a < lead);
-    }
-    if (live[0]) {
-      if (vec) {                // wide accesses: the group is aligned and inside the pixel's row
-#pragma unroll
-        for (int h2 = 0; h2 < NS / 2; ++h2) {
-          const OffT fo = fb + (OffT)(8 * h2);
-          if (h2 > 0 && !live[2 * h2]) break;
-          const int2 i2 = at_bytes<int2>(idx, fo);
-          const v2f w2 = at_bytes<v2f>(weight, fo), l2 = at_bytes<v2f>(len, fo);
-          st.id[2 * h2] = i2.x; st.wv[2 * h2] = w2.x; st.lm[2 * h2] = l2.x;
-          if (live[2 * h2 + 1]) { st.id[2 * h2 + 1] = i2.y; st.wv[2 * h2 + 1] = w2.y; st.lm[2 * h2 + 1] = l2.y; }
-          if (!NOAD) {
-            const v2f a2 = at_bytes<v2f>(act, fo), d2 = at_bytes<v2f>(dsd, fo);
-            st.av[2 * h2] = a2.x; st.av[2 * h2 + 1] = a2.y; st.dv[2 * h2] = d2.x; st.dv[2 * h2 + 1] = d2.y;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int a = 0; a < NS; ++a) {
-          if (!live[a]) break;
-          const OffT fo = fb + (OffT)(4 * a);
-          st.id[a] = at_bytes<int>(idx, fo); st.wv[a] = at_bytes<float>(weight, fo); st.lm[a] = at_bytes<float>(len, fo);
-          if (!NOAD) { st.av[a] = at_bytes<float>(act, fo); st.dv[a] = at_bytes<float>(dsd, fo); }
-        }
-      }
-      if (SRC == 1 && g_img != nullptr) {      // the consumers' gradient of the weights
-        if (vec && gs_c == 1 && gs_pix == (long)K) {
-#pragma unroll
-          for (int h2 = 0; h2 < NS / 2; ++h2) {
-            if (h2 > 0 && !live[2 * h2]) break;
-            const v2f g2 = at_bytes<v2f>(g_img, fb + (OffT)(8 * h2));
-            st.gw[2 * h2] = g2.x; st.gw[2 * h2 + 1] = g2.y;
-          }
-        } else {
-#pragma unroll
-          for (int a = 0; a < NS; ++a)
-            if (live[a]) st.gw[a] = g_img[(long)pix * gs_pix + (long)(k0 + a) * gs_c];
-        }
-      }
-    }
-  };
-  PackLane pk, pk_n;
-  int npm, npm_n = 0;
-  Streams st, st_n;
-  bool have = next_round(pk, npm);
-  if (have) issue(pk, st);
-  while (have) {
-#if VOGE_FB_PREFETCH
-    const bool have_n = next_round(pk_n, npm_n);
-    if (have_n) issue(pk_n, st_n);
-#endif
+  while (pc < kFbG) {
+    PackLane pk;
+    int npm;
+    const int pe = pack_round(need, incl, kFbG, lane, pc, off, pk, npm);
+    off = __builtin_amdgcn_readlane(incl, pe - 1);
+    pc = pe;
+    if (npm == 0) continue;       // (uniform) a run of empty pixels
     FB_TICK(0);
     const bool on = pk.p >= 0;
     const int q = on ? lane - pk.s0 : 0, LP = on ? pk.np : 1;
@@ -218,7 +139,7 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     bool live[NS];
 #pragma unroll
     for (int a = 0; a < NS; ++a) {
-      id[a] = st.id[a]; wv[a] = st.wv[a]; lm[a] = st.lm[a]; gwv[a] = st.gw[a]; sm[a] = 1e-5f; em[a] = 0.f;
+      id[a] = -1; wv[a] = 0.f; lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.f; gwv[a] = 0.f;
       live[a] = on && (k0 + a < lead);
     }
     float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -227,10 +148,52 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
       dx = dv.x; dy = dv.y; dz = dv.z;
     }
     float4 rc[NS][ISO ? 1 : 3];
-    if (!NOAD) {
+    float av[NS], dv2[NS];
 #pragma unroll
-      for (int a = 0; a < NS; ++a)
-        if (live[a]) { em[a] = FAST_EXP(-st.av[a]); sm[a] = FAST_SQRT(st.dv[a] + 1e-10f); }
+    for (int a = 0; a < NS; ++a) { av[a] = 0.f; dv2[a] = 0.f; }
+    if (live[0]) {
+      if (vec) {                // wide accesses: the group is aligned and inside the pixel's row
+#pragma unroll
+        for (int h2 = 0; h2 < NS / 2; ++h2) {
+          const OffT fo = fb + (OffT)(8 * h2);
+          if (h2 > 0 && !live[2 * h2]) break;
+          const int2 i2 = at_bytes<int2>(idx, fo);
+          const v2f w2 = at_bytes<v2f>(weight, fo), l2 = at_bytes<v2f>(len, fo);
+          id[2 * h2] = i2.x; wv[2 * h2] = w2.x; lm[2 * h2] = l2.x;
+          if (live[2 * h2 + 1]) { id[2 * h2 + 1] = i2.y; wv[2 * h2 + 1] = w2.y; lm[2 * h2 + 1] = l2.y; }
+          if (!NOAD) {
+            const v2f a2 = at_bytes<v2f>(act, fo), d2 = at_bytes<v2f>(dsd, fo);
+            av[2 * h2] = a2.x; av[2 * h2 + 1] = a2.y; dv2[2 * h2] = d2.x; dv2[2 * h2 + 1] = d2.y;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < NS; ++a) {
+          if (!live[a]) break;
+          const OffT fo = fb + (OffT)(4 * a);
+          id[a] = at_bytes<int>(idx, fo); wv[a] = at_bytes<float>(weight, fo); lm[a] = at_bytes<float>(len, fo);
+          if (!NOAD) { av[a] = at_bytes<float>(act, fo); dv2[a] = at_bytes<float>(dsd, fo); }
+        }
+      }
+      if (!NOAD) {
+#pragma unroll
+        for (int a = 0; a < NS; ++a)
+          if (live[a]) { em[a] = FAST_EXP(-av[a]); sm[a] = FAST_SQRT(dv2[a] + 1e-10f); }
+      }
+      if (SRC == 1 && g_img != nullptr) {      // the consumers' gradient of the weights
+        if (vec && gs_c == 1 && gs_pix == (long)K) {
+#pragma unroll
+          for (int h2 = 0; h2 < NS / 2; ++h2) {
+            if (h2 > 0 && !live[2 * h2]) break;
+            const v2f g2 = at_bytes<v2f>(g_img, fb + (OffT)(8 * h2));
+            gwv[2 * h2] = g2.x; gwv[2 * h2 + 1] = g2.y;
+          }
+        } else {
+#pragma unroll
+          for (int a = 0; a < NS; ++a)
+            if (live[a]) gwv[a] = g_img[(long)pix * gs_pix + (long)(k0 + a) * gs_c];
+        }
+      }
     }
     if (NOAD) {                 // act / dsd from the records (gathered here once, used again by the trace terms below)
       const float dn2f = (dx * dx + dy * dy) + dz * dz;      // the forward's association
@@ -335,11 +298,9 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
                                                      : make_float4(0.f, 0.f, 0.f, 0.f);   // (P < 2^26: host)
     const float dn2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float idn = __builtin_amdgcn_rcpf(dn2);
-    float4 vals[NS][NV4];
-    bool gos[NS];
 #pragma unroll
     for (int a = 0; a < NS; ++a) {
-      float4 (&val)[NV4] = vals[a];
+      float4 val[NV4];
 #pragma unroll
       for (int r = 0; r < NV4; ++r) val[r] = make_float4(0.f, 0.f, 0.f, 0.f);
       bool go = live[a];
@@ -388,40 +349,8 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
 #pragma unroll
         for (int r = 0; r < NV4; ++r) go = go || (val[r].x != 0.f || val[r].y != 0.f || val[r].z != 0.f || val[r].w != 0.f);
       }
-      gos[a] = go;
-    }
-    FB_TICK(3);
-#if VOGE_FB_TABLE_N      // the slots' probe chains and election rounds interleaved (wt_find_n / wt_add_n)
-    {
-      bool any_go = false;
-#pragma unroll
-      for (int a = 0; a < NS; ++a) any_go = any_go || gos[a];
-      if (__any(any_go)) {
-        int slots[NS];
-        wt_find_n(L.tab, id, gos, slots);
-        bool ons[NS];
-#pragma unroll
-        for (int a = 0; a < NS; ++a) ons[a] = gos[a] && slots[a] >= 0;
-        wt_add_n(L.tab, slots, vals, ons, lane);
-#pragma unroll
-        for (int a = 0; a < NS; ++a) {
-          if (gos[a] && slots[a] < 0) {         // table full: rare, straight to memory
-#pragma unroll
-            for (int r = 0; r < NV4; ++r) {
-              const float o[4] = {vals[a][r].x, vals[a][r].y, vals[a][r].z, vals[a][r].w};
-#pragma unroll
-              for (int c = 0; c < 4; ++c) unsafeAtomicAdd(acc + NACC * (size_t)id[a] + 4 * r + c, o[c]);
-            }
-          }
-        }
-      }
-    }
-#else
-#pragma unroll
-    for (int a = 0; a < NS; ++a) {
-      const bool go = gos[a];
-      float4 (&val)[NV4] = vals[a];
       if (!__any(go)) continue;     // uniform
+      FB_TICK(3);
 #if VOGE_FB_ABL & 1       // (timing experiment: no table, nothing accumulated)
       if (go && val[0].x == 1.2345f && val[NV4 - 1].y == 3.21f) acc[id[a]] = val[0].w + val[NV4 - 1].x;
       continue;
@@ -436,15 +365,8 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
           for (int c = 0; c < 4; ++c) unsafeAtomicAdd(acc + NACC * (size_t)id[a] + 4 * r + c, o[c]);
         }
       }
+      FB_TICK(4);
     }
-#endif
-    FB_TICK(4);
-#if VOGE_FB_PREFETCH
-    pk = pk_n; npm = npm_n; st = st_n; have = have_n;
-#else
-    have = next_round(pk, npm);
-    if (have) issue(pk, st);
-#endif
   }
   FB_TICK(0);
   {   // flush: NACC (4 | 8 | 12 | 16) adjacent lanes per entry -> the bytes of acc[p]: lane-coalesced atomics
@@ -474,19 +396,18 @@ fragment_bwd_finish_kernel(const float *__restrict__ acc, const int S, const flo
     for (int c = 0; c < C; ++c) g_colors[(size_t)g * C + c] = (g < P) ? acc[S * (size_t)g + 4 + c] : 0.0f;
   }
   const int n_out = view.shared ? N : P;
-  if (g < n_out && g_mus != nullptr) {
-    float4 v = *reinterpret_cast<const float4 *>(acc + S * (size_t)g);
-    if (view.shared)
-      for (int b = 1; b < B; ++b) {
-        const float4 w = *reinterpret_cast<const float4 *>(acc + S * ((size_t)b * N + g));
-        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-      }
-    g_mus[3 * (size_t)g] = v.x; g_mus[3 * (size_t)g + 1] = v.y; g_mus[3 * (size_t)g + 2] = v.z;
-    float ga = v.w;
-    if (view.mode == 1) ga = 2.0f * ga;
-    else if (view.mode == 2) { const float s = a_in[g]; ga = -2.0f * ga / (s * s); }
-    g_a[g] = ga;
-  }
+  if (g >= n_out || g_mus == nullptr) return;
+  float4 v = *reinterpret_cast<const float4 *>(acc + S * (size_t)g);
+  if (view.shared)
+    for (int b = 1; b < B; ++b) {
+      const float4 w = *reinterpret_cast<const float4 *>(acc + S * ((size_t)b * N + g));
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+  g_mus[3 * (size_t)g] = v.x; g_mus[3 * (size_t)g + 1] = v.y; g_mus[3 * (size_t)g + 2] = v.z;
+  float ga = v.w;
+  if (view.mode == 1) ga = 2.0f * ga;
+  else if (view.mode == 2) { const float s = a_in[g]; ga = -2.0f * ga / (s * s); }
+  g_a[g] = ga;
 }
 
 // General 3x3 forms: mus [P,3] + isigmas [P,9] -> 3 x float4 per Gaussian (one gather stream), acc [P][16] zeroed

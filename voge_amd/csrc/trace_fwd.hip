@@ -1144,7 +1144,8 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   if ((size_t)B * H * W == 0) return 0;  // numel == 0 early return (ray_trace_voge.cu:248-251)
   if (!rays || !idx || !len || !workspace || (act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;
   // act / dsd may be omitted by the scalar-sigma fragment entry points only (they are re-derived where needed)
-  if (act == nullptr && !(iso_in && weight != nullptr && cnt != nullptr && (long)B * N < (1l << 26)))
+  // (with weights: composited behind the sweep; without: records kept, the caller composites later)
+  if (act == nullptr && !(iso_in && (weight != nullptr || records != nullptr) && cnt != nullptr && (long)B * N < (1l << 26)))
     return VOGE_ERR_BAD_ARG;
   if (N > 0 && (!mus || !isigmas)) return VOGE_ERR_BAD_ARG;
   if (workspace_bytes < voge_trace_workspace_bytes(B, N, H, W)) return VOGE_ERR_WORKSPACE;
@@ -1268,7 +1269,7 @@ extern "C" int voge_fragments_fwd_iso(const float *mus, const float *a, const fl
                                       void *workspace, size_t workspace_bytes, int32_t *idx, float *len, float *act,
                                       float *dsd, int32_t *cnt, float *weight, int64_t *valid_num, float *records,
                                       voge_stream_t stream) {
-  if (!weight || !valid_num || !cnt) return VOGE_ERR_BAD_ARG;
+  if (!cnt || (weight == nullptr) != (valid_num == nullptr) || (!weight && (!records || act || dsd))) return VOGE_ERR_BAD_ARG;
   return trace_topk_fwd_impl(1, IsoView{nullptr, 0, 0}, mus, a, rays, cam_fwd, cones, B, N, H, W, K, thr_act, workspace,
                              workspace_bytes, idx, len, act, dsd, cnt, stream, occ, weight, valid_num, records);
 }
@@ -1279,7 +1280,9 @@ extern "C" int voge_fragments_fwd_iso_view(const float *verts, const float *sigm
                                            size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
                                            int32_t *cnt, float *weight, int64_t *valid_num, float *records,
                                            voge_stream_t stream) {
-  if (sigma_mode < 0 || sigma_mode > 2 || !weight || !valid_num || !cnt) return VOGE_ERR_BAD_ARG;
+  if (sigma_mode < 0 || sigma_mode > 2 || !cnt || (weight == nullptr) != (valid_num == nullptr) ||
+      (!weight && (!records || act || dsd)))
+    return VOGE_ERR_BAD_ARG;
   return trace_topk_fwd_impl(1, IsoView{origin, shared ? 1 : 0, sigma_mode}, verts, sigmas, rays, cam_fwd, cones, B, N, H, W, K,
                              thr_act, workspace, workspace_bytes, idx, len, act, dsd, cnt, stream, occ, weight, valid_num, records);
 }

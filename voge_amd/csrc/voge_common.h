@@ -520,72 +520,6 @@ __device__ __forceinline__ void wt_add(WaveTable<NE, NV4> &t, const int slot, co
   }
 }
 
-// The same two steps for the NS slots of a lane at once: the probe chains (and the election rounds) of the slots are
-// independent, so interleaving them halves the number of dependent LDS round trips a wave sits through.  A lane's own
-// slots carry different keys (one pixel never lists a Gaussian twice); lanes of different slots may still meet in one
-// table entry, which the election (owner tag = lane + 64 * slot) resolves like any other duplicate.
-template <int NE, int NV4, int NS>
-__device__ __forceinline__ void wt_find_n(WaveTable<NE, NV4> &t, const int (&key)[NS], const bool (&want)[NS], int (&slot)[NS]) {
-  unsigned h[NS];
-  bool pending[NS];
-  bool any = false;
-#pragma unroll
-  for (int a = 0; a < NS; ++a) {
-    h[a] = ((unsigned)key[a] * 2654435761u) >> (32 - __builtin_ctz(NE));
-    slot[a] = -1;
-    pending[a] = want[a];
-    any = any || want[a];
-  }
-#pragma unroll 1
-  for (int pr = 0; pr < kWtProbe && __any(any); ++pr) {
-    any = false;
-#pragma unroll
-    for (int a = 0; a < NS; ++a) {
-      if (pending[a]) {
-        const int old = atomicCAS(&t.keys[h[a]], -1, key[a]);
-        if (old == -1 || old == key[a]) {
-          slot[a] = (int)h[a];
-          pending[a] = false;
-        } else {
-          h[a] = (h[a] + 1) & (NE - 1);
-        }
-      }
-      any = any || pending[a];
-    }
-  }
-}
-
-template <int NE, int NV4, int NS>
-__device__ __forceinline__ void wt_add_n(WaveTable<NE, NV4> &t, const int (&slot)[NS], const float4 (&v)[NS][NV4],
-                                         const bool (&on)[NS], const int lane) {
-  volatile int *owner = t.owner;
-  bool pending[NS];
-  bool any = false;
-#pragma unroll
-  for (int a = 0; a < NS; ++a) { pending[a] = on[a]; any = any || on[a]; }
-#pragma unroll 1
-  while (__any(any)) {
-#pragma unroll
-    for (int a = 0; a < NS; ++a)
-      if (pending[a]) owner[slot[a]] = lane + 64 * a;
-    any = false;
-#pragma unroll
-    for (int a = 0; a < NS; ++a) {
-      if (pending[a] && owner[slot[a]] == lane + 64 * a) {
-        float4 *dst = t.vals + slot[a] * NV4;
-#pragma unroll
-        for (int q = 0; q < NV4; ++q) {
-          float4 x = dst[q];
-          x.x += v[a][q].x; x.y += v[a][q].y; x.z += v[a][q].z; x.w += v[a][q].w;
-          dst[q] = x;
-        }
-        pending[a] = false;
-      }
-      any = any || pending[a];
-    }
-  }
-}
-
 // Compact the occupied slots into t.owner[0..n) (the election array is free once accumulation
 // is over) and return n, so the flush issues full-width atomics instead of walking empty slots.
 // Must be called by the whole wave.

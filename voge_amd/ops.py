@@ -574,6 +574,269 @@ def fragments(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode
     return weight, sel_idx, valid, sel_len
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Deferred composite (scalar sigmas).  GaussianRenderer hands its Fragments back before anybody knows what they will be
+# used for; the sweep's outputs (index, len, hit count, records) are all the later stages need.  With VOGE_LAZY_COMPOSITE
+# (default on) the renderer therefore stops behind the sweep (_TraceLean) and the composite runs when the fragments'
+# weights are first asked for:
+#   * to_colored_background on untouched fragments -> _CompositeShade: weights AND image in ONE pass (the composite kernel
+#     gathers the colours of the slots it holds anyway; nothing is read back);
+#   * any other access (frag.vert_weight, interpolate_attr, get_silhouette, ...) -> _CompositeLean: the composite kernel alone.
+# Results are the same bits as the eager chain's weights; the image's sums are associated per lane group instead of per
+# DPP row (within 1e-7 of the separate kernel).  Both nodes take the Gaussians as inputs and hand them the gradient of
+# everything below (composite + trace backward in one pass), like _ShadeThrough.
+LAZY_COMPOSITE = os.environ.get("VOGE_LAZY_COMPOSITE", "1") != "0"
+
+
+class _TraceLean(torch.autograd.Function):
+    """The fine trace alone, without act / dsd (voge_fragments_fwd_iso* in trace-only form):
+    forward(mode 1 | 2, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode) -> sel_idx, sel_len, cnt, records.
+    backward: only vert_hit_length can carry a gradient here (voge_fragment_bwd_iso with g_weight = NULL)."""
+
+    @staticmethod
+    def forward(ctx, mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode):
+        lib = _lib.load()
+        p0_c, p1_c = _dev(p0, torch.float32, "means"), _dev(p1, torch.float32, "sigmas")
+        rays_c = _dev(rays, torch.float32, "rays")
+        assert rays_c.dim() == 4 and rays_c.shape[3] == 3 and mode in (1, 2)
+        B, H, W, _ = rays_c.shape
+        K, dev = int(n_assign), rays_c.device
+        o_c, shared = None, False
+        if mode == 2:
+            o_c = _dev(origin, torch.float32, "origin")
+            shared = p0_c.dim() == 2
+            assert p0_c.shape[-1] == 3 and (shared or p0_c.shape[0] == B) and p1_c.shape == p0_c.shape[:-1]
+            assert o_c.shape == (B, 3)
+            N = p0_c.shape[-2]
+        else:
+            assert p0_c.dim() == 2 and p0_c.shape[1] == 3 and p0_c.shape[0] % max(B, 1) == 0
+            assert p1_c.shape[0] == p0_c.shape[0] and p1_c.dim() == 1
+            N = p0_c.shape[0] // B
+        sel_idx = torch.empty((B, H, W, K), dtype=torch.int32, device=dev)
+        sel_len = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
+        cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+        records = torch.empty((B * N, 4), dtype=torch.float32, device=dev)
+        fwd = None if cam_fwd is None else _dev(cam_fwd, torch.float32, "cam_fwd")
+        with _on(dev):
+            nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
+            ws = _workspace(dev, nbytes)
+            tail = (B, N, H, W, K, float(thr_act), 1.0, _p(ws), nbytes, _p(sel_idx), _p(sel_len), None, None, _p(cnt), None, None)
+            cones = _p(cones_of(rays_c, B, H, W))
+            if mode == 2:
+                rc = lib.voge_fragments_fwd_iso_view(_p(p0_c), _p(p1_c), _p(o_c), int(shared), int(sigma_mode), _p(rays_c),
+                                                     _p(fwd), cones, *tail, _p(records), _stream())
+            else:
+                rc = lib.voge_fragments_fwd_iso(_p(p0_c), _p(p1_c), _p(rays_c), _p(fwd), cones, *tail, _p(records), _stream())
+        _lib.check(rc, "voge_fragments_fwd (trace only)")
+        ctx.save_for_backward(p0_c, p1_c, rays_c, sel_len)
+        ctx.sel_idx, ctx.cnt, ctx.records = sel_idx, cnt, records
+        ctx.meta = (int(mode), int(sigma_mode), bool(shared), B, N)
+        _tag_index(sel_idx, cnt, B * N)
+        ctx.mark_non_differentiable(sel_idx, cnt, records)
+        ctx.set_materialize_grads(False)
+        return sel_idx, sel_len, cnt, records
+
+    @staticmethod
+    def backward(ctx, _g_idx, g_len, _g_cnt, _g_rec):
+        if g_len is None:
+            return (None,) * 9
+        lib = _lib.load()
+        p0, p1, rays, ln = ctx.saved_tensors
+        mode, sigma_mode, shared, B, N = ctx.meta
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[3]:
+            raise _lib.VogeHipError("deferred-composite fragments carry no gradient for the rays / the camera centre; "
+                                    "VOGE_LAZY_COMPOSITE=0 (or rays that require grad at render time) selects the eager chain")
+        sel_idx, cnt = ctx.sel_idx, ctx.cnt
+        _, H, W, K = sel_idx.shape
+        gh = _dev(g_len, torch.float32, "grad_hit_length")
+        g0, g1 = torch.empty_like(p0), torch.empty_like(p1)
+        with _on(rays.device):
+            nbytes = lib.voge_fragment_bwd_workspace_bytes(B * N)
+            ws = _workspace(rays.device, nbytes)
+            # (g_weight = NULL: u = 0 everywhere, the `weight` operand is read but multiplies zero -- len stands in)
+            rc = lib.voge_fragment_bwd_iso(_p(ctx.records), _p(p1), int(shared), sigma_mode, _p(rays), _p(sel_idx), _p(cnt), _p(ln),
+                                           None, _p(ln), None, None, 0, 0, _p(gh), 1.0, B, N, B * H, W, K, _p(ws), nbytes, _p(g0),
+                                           _p(g1), _stream())
+        _lib.check(rc, "voge_fragment_bwd_iso")
+        return None, g0, g1, None, None, None, None, None, None
+
+
+class LazyComposite:
+    """What the deferred composite needs from a _TraceLean call (nothing in it has a grad_fn except sel_len, which the
+    composite nodes take as an input)."""
+    __slots__ = ("mode", "sigma_mode", "shared", "occ", "B", "N", "K", "p0", "p1", "sel_idx", "sel_len", "cnt", "records", "rays",
+                 "rays_version")
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def usable(self):
+        """The sweep's outputs must still be what it wrote (nobody edited them through torch in between)."""
+        return (self.sel_len._version == 0 and self.rays._version == self.rays_version
+                and hit_count_of(self.sel_idx) is not None)
+
+    def through(self, weight):
+        """Tag freshly composited weights the way fragments() does (a later to_colored_background takes _ShadeThrough)."""
+        if (self.p0.requires_grad or self.p1.requires_grad) and torch.is_grad_enabled():
+            len_d = self.sel_len.detach()
+            weight.voge_through = dict(
+                mode=self.mode, sigma_mode=self.sigma_mode, shared=self.shared, occ=self.occ, B=self.B, N=self.N,
+                records=self.records, rays=self.rays, act=None, dsd=None, len=len_d, cnt=self.cnt, idx=self.sel_idx,
+                sigmas=self.p1.detach(), means=self.p0.detach(), p0=self.p0, p1=self.p1, rays_requires_grad=False,
+                versions=(weight._version, len_d._version, self.rays._version, self.sel_idx._version))
+        return weight
+
+
+def _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K):
+    """composite + trace backward in one pass for a deferred composite: -> (g_p0, g_p1)."""
+    gw, gs_pix, gs_k = _grad_weight_layout(g_weight, K)
+    g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=ln.device)
+    g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=ln.device)
+    B, H, W = lz.cnt.shape
+    with _on(ln.device):
+        nbytes = lib.voge_fragment_bwd_workspace_bytes(lz.B * lz.N)
+        ws = _workspace(ln.device, nbytes)
+        rc = lib.voge_fragment_bwd_iso(_p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(lz.sel_idx), _p(lz.cnt),
+                                       _p(weight), None, _p(ln), None, _p(gw), gs_pix, gs_k, None, lz.occ, lz.B, lz.N, B * H, W, K,
+                                       _p(ws), nbytes, _p(g0), _p(g1), _stream())
+    _lib.check(rc, "voge_fragment_bwd_iso")
+    return g0, g1
+
+
+class _CompositeLean(torch.autograd.Function):
+    """aggregation (VoGE/Aggregation.py:82-107) of a _TraceLean call, when the weights are first asked for:
+    forward(p0, p1, sel_len, lz) -> weight, valid_num.  The Gaussians are inputs so that the backward (composite + trace,
+    one pass: voge_fragment_bwd_iso) can hand them the gradient directly; sel_len gets none from here."""
+
+    @staticmethod
+    def forward(ctx, p0, p1, sel_len, lz):
+        lib = _lib.load()
+        idx, K = lz.sel_idx, lz.K
+        weight = torch.empty_like(sel_len)
+        valid = torch.empty(idx.shape[:-1], dtype=torch.int64, device=idx.device)
+        with _on(idx.device):
+            rc = lib.voge_composite_fwd_iso(_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, idx.numel() // K, K,
+                                            _p(weight), _p(valid), _stream())
+        _lib.check(rc, "voge_composite_fwd_iso")
+        ctx.save_for_backward(_dev(p1, torch.float32, "sigmas"), sel_len, weight)
+        ctx.lz = lz
+        ctx.mark_non_differentiable(valid)
+        ctx.set_materialize_grads(False)
+        return weight, valid
+
+    @staticmethod
+    def backward(ctx, g_weight, _g_valid):
+        if g_weight is None:
+            return None, None, None, None
+        p1, ln, weight = ctx.saved_tensors
+        g0, g1 = _lazy_fragment_bwd(_lib.load(), ctx.lz, p1, weight, ln, g_weight, ctx.lz.K)
+        return g0, g1, None, None
+
+
+class _CompositeShade(torch.autograd.Function):
+    """aggregation + merge_final + get_silhouette + to_colored_background in ONE forward pass
+    (voge_composite_shade_fwd_iso): forward(attr, p0, p1, sel_len, lz, bg, thr) -> image, weight, valid_num.
+    backward: the image's gradient through voge_fragment_shade_bwd_iso (shade + composite + trace, one kernel); a gradient
+    that reaches the weights from elsewhere (a silhouette loss on the same fragments) through voge_fragment_bwd_iso."""
+
+    @staticmethod
+    def forward(ctx, attr, p0, p1, sel_len, lz, bg, thr):
+        lib = _lib.load()
+        attr_c = _dev(attr, torch.float32, "colors")
+        bg_c = _dev(bg, torch.float32, "background_color")
+        idx, K = lz.sel_idx, lz.K
+        Nattr, C = attr_c.shape
+        assert bg_c.numel() == C
+        check_index_range(idx, Nattr)
+        weight = torch.empty_like(sel_len)
+        valid = torch.empty(idx.shape[:-1], dtype=torch.int64, device=idx.device)
+        rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
+        img = torch.empty_like(rgb)
+        wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
+        with _on(idx.device):
+            rc = lib.voge_composite_shade_fwd_iso(_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c),
+                                                  _p(bg_c), float(thr), idx.numel() // K, K, C, Nattr, _p(weight), _p(valid),
+                                                  _p(rgb), _p(img), _p(wsum), _stream())
+        _lib.check(rc, "voge_composite_shade_fwd_iso")
+        ctx.save_for_backward(attr_c, _dev(p1, torch.float32, "sigmas"), sel_len, weight, rgb, bg_c, wsum)
+        ctx.lz, ctx.thr = lz, float(thr)
+        ctx.mark_non_differentiable(valid)
+        ctx.set_materialize_grads(False)
+        return img, weight, valid
+
+    @staticmethod
+    def backward(ctx, g_img, g_weight, _g_valid):
+        lib = _lib.load()
+        attr, p1, ln, weight, rgb, bg, wsum = ctx.saved_tensors
+        lz = ctx.lz
+        idx = lz.sel_idx
+        B, H, W, K = idx.shape
+        Nattr, C = attr.shape
+        g_attr = g0 = g1 = None
+        if g_img is not None:
+            if g_img.dtype == torch.float32 and g_img.is_cuda and all(s == 0 for s in g_img.stride()):
+                go, gs_pix, gs_c = g_img, 0, 0      # autograd's broadcast scalar (sum / mean losses), read in place
+            else:
+                go, gs_pix, gs_c = _dev(g_img, torch.float32, "grad_image"), C, 1
+            g_attr = torch.empty_like(attr)
+            g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=idx.device)
+            g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=idx.device)
+            with _on(idx.device):
+                nbytes = lib.voge_fragment_bwd_workspace_bytes(lz.B * lz.N)
+                ws = _workspace(idx.device, nbytes)
+                rc = lib.voge_fragment_shade_bwd_iso(
+                    _p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(attr), _p(idx), _p(lz.cnt), _p(weight), None,
+                    _p(ln), None, _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go), gs_pix, gs_c, lz.occ, lz.B, lz.N, B * H, W, K, C, Nattr,
+                    _p(ws), nbytes, _p(g0), _p(g1), _p(g_attr), _stream())
+            _lib.check(rc, "voge_fragment_shade_bwd_iso")
+        if g_weight is not None:
+            h0, h1 = _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K)
+            g0, g1 = (h0, h1) if g0 is None else (g0 + h0, g1 + h1)
+        need = ctx.needs_input_grad
+        return (g_attr if need[0] else None), (g0 if need[1] else None), (g1 if need[2] else None), None, None, None, None
+
+
+def trace_lean(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode=0, occ=1.0):
+    """-> (sel_idx, sel_len, LazyComposite): the renderer's forward up to the sweep; the composite is deferred."""
+    sel_idx, sel_len, cnt, records = _TraceLean.apply(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode)
+    B = rays.shape[0]
+    N = p0.shape[-2] if mode == 2 else p0.shape[0] // max(B, 1)
+    rays_d = rays.detach()
+    lz = LazyComposite(mode=int(mode), sigma_mode=int(sigma_mode), shared=bool(mode == 2 and p0.dim() == 2), occ=float(occ), B=B, N=N,
+                       K=int(n_assign), p0=p0, p1=p1, sel_idx=sel_idx, sel_len=sel_len, cnt=cnt, records=records, rays=rays_d,
+                       rays_version=rays_d._version)
+    return sel_idx, sel_len, lz
+
+
+def lazy_eligible(mode, p0, p1, origin, rays, n_assign):
+    """Deferred composite: scalar sigmas, record gathers in 32-bit offsets, nobody differentiating the rays."""
+    if not LAZY_COMPOSITE or mode == 0 or os.environ.get("VOGE_FRAGMENTS_KEEP_ACT_DSD", "0") == "1":
+        return False
+    B = rays.shape[0]
+    P = p0.shape[-2] * B if mode == 2 else p0.shape[0]
+    if P >= (1 << 26) or P == 0 or rays.numel() == 0 or rays.requires_grad or (origin is not None and origin.requires_grad):
+        return False
+    return p0.is_cuda and rays.is_cuda
+
+
+def composite_lean(lz):
+    """-> weight, valid_num of a deferred composite (the weights carry `voge_through` like fragments()' do)."""
+    weight, valid = _CompositeLean.apply(lz.p0, lz.p1, lz.sel_len, lz)
+    return lz.through(weight), valid
+
+
+def composite_shade(lz, attr, bg, thr):
+    """-> image, weight, valid_num, or None when the one-pass form does not apply (K % 4, channel count, offsets)."""
+    K = lz.K
+    if (K & 3) or K > 128 or attr.dim() != 2 or attr.shape[1] not in (3, 4) or attr.numel() >= (1 << 30) or not lz.usable():
+        return None      # (K <= 128: the image's backward is voge_fragment_shade_bwd_iso)
+    if os.environ.get("VOGE_SHADE_THROUGH", "1") == "0":
+        return None
+    img, weight, valid = _CompositeShade.apply(attr, lz.p0, lz.p1, lz.sel_len, lz, bg, thr)
+    return img, lz.through(weight), valid
+
+
 class _ShadeThrough(torch.autograd.Function):
     """to_colored_background on fragments this renderer made: the forward is _Shade's, the
     backward runs shade -> composite -> trace as ONE kernel (voge_fragment_shade_bwd_iso for scalar sigmas,
