@@ -185,14 +185,18 @@ def fit(iters=2000, level=4, size=128, num_views=20, views_per_iter=5, max_assig
                                                   views_per_iter, graph=graph)
     trace = torch.zeros((iters, 2), device=device)                     # losses stay on the device: no per-iteration sync
 
+    # the views of every iteration, drawn up front and kept on the device: an iteration then needs nothing from the host
+    # (no host-to-device copy, no synchronisation) and consecutive iterations queue back to back
+    schedule = np.stack([rng.permutation(num_views)[:views_per_iter] for _ in range(max(iters, 1))])
+    schedule_dev = torch.from_numpy(schedule).to(device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for i in range(iters):
         if i == rgb_on:
             weights["rgb"] = 1.0
-        views = rng.permutation(num_views).tolist()[:views_per_iter]
+        views = schedule[i].tolist()
         if step is not None:
-            trace[i].copy_(step(views, weights["rgb"]))
+            trace[i].copy_(step(schedule_dev[i], weights["rgb"]))
         else:
             optimizer.zero_grad()
             loss = {k: torch.zeros((), device=device) for k in weights}
