@@ -535,7 +535,7 @@ def main():
                                                          P_(s["ws"]), nws, P_(s["i"]), P_(s["l"]), None, None, P_(s["c"]), None,
                                                          None, P_(s["r"]), st))
                 # ... and composite + shade in one pass when to_white_background asks for the image
-                if K % 4 == 0:
+                if True:
                     stage_defs["composite_shade_fwd"] = (
                         lambda: dict(i=C_(sel[0]), c=C_(cnt), l=C_(sel[1]), w=E(w), v=E(vn), rgb=E(rgb), img=E(rgb), ws=E(wsum)),
                         lambda s: lib.voge_composite_shade_fwd_iso(P_(s["i"]), P_(s["c"]), P_(s["l"]), P_(recs), P_(rays), 1.0, P_(colors),

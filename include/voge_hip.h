@@ -241,7 +241,8 @@ int voge_composite_fwd_iso(const int32_t *idx, const int32_t *cnt, const float *
  * to_colored_background (VoGE/Aggregation.py:111-141, VoGE/Renderer.py:157-171) -- what voge_composite_fwd_iso followed
  * by voge_shade_fwd computes, without reading idx / weight back (8 bytes per slot) and without the second launch.
  * colors [Nattr,C], C = 3 | 4; bg [C]; thr as voge_shade_fwd.  Writes weight [npix,K], valid_num [npix], rgb / img [npix,C],
- * wsum [npix], and rewrites the empty slots of idx in place (-1 -> 0, Aggregation.py:131).  K % 4 == 0; cnt required. */
+ * wsum [npix], and rewrites the empty slots of idx in place (-1 -> 0, Aggregation.py:131).  Any K <= VOGE_MAX_K; cnt required.
+ * img = NULL (bg unused): merge_final and the weight sum only -- interpolate_attr / get_silhouette, no background. */
 int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                                  const float *rays, float occ, const float *colors, const float *bg, float thr,
                                  long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num, float *rgb,
@@ -262,6 +263,19 @@ int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int s
                                 const float *g_img, long g_stride_pix, long g_stride_c, float occ, int B, int N,
                                 long nrows, int W, int K, int C, long Nattr, void *workspace, size_t workspace_bytes, float *g_verts,
                                 float *g_sigmas, float *g_colors, voge_stream_t stream);
+
+/* interpolate_attr (+ get_silhouette) on fragments of this renderer, backward: merge_final's own backward
+ * (VoGE/Aggregation.py:111-141; g_rgb = the gradient of the merged attributes [nrows*W,C], strides as g_img above), plus
+ * g_wsum [nrows*W] or NULL = the gradient of the per-pixel weight sum (get_silhouette = min(sum, 1) of the same fragments),
+ * then composite and trace as above -- the reference's training pattern (demo/ShapeFitting.py:217,295) as ONE kernel.
+ * attr [Nattr,C], C <= 4, K <= 128.  Writes g_verts / g_sigmas (both or neither) and g_attr [Nattr,C]. */
+int voge_fragment_merge_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
+                                const float *rays, const float *attr, const int32_t *idx, const int32_t *cnt,
+                                const float *weight, const float *act, const float *len, const float *dsd,
+                                const float *g_rgb, long g_stride_pix, long g_stride_c, const float *g_wsum,
+                                float occ, int B, int N, long nrows, int W, int K, int C, long Nattr,
+                                void *workspace, size_t workspace_bytes, float *g_verts, float *g_sigmas,
+                                float *g_attr, voge_stream_t stream);
 
 /*
  * The same single pass driven by the gradient of the WEIGHTS, whoever produced it: the backward of

@@ -450,9 +450,15 @@ def test_deferred_composite_materialises_on_first_read(hip_lib):
     assert frag._lazy is not None and vn.dtype == torch.int64
     cp = frag.copy()
     assert cp._lazy is frag._lazy
-    rgb = interpolate_attr(frag, colors)                            # reads vert_weight -> composite now
-    assert frag._lazy is None and type(frag.vert_weight.grad_fn).__name__ == "_CompositeLeanBackward"
+    rgb = interpolate_attr(frag, colors)                            # composite + merge (+ weight sum) in one pass, now
+    assert frag._lazy is None and type(frag.vert_weight.grad_fn).__name__ == "_CompositeMergeBackward"
     assert torch.equal(frag.valid_num, vn)
+    f3 = renderer(gm, R=t(R), T=t(T))
+    w3 = f3.vert_weight                                             # a plain read: the composite kernel alone
+    assert f3._lazy is None and type(w3.grad_fn).__name__ == "_CompositeLeanBackward" and torch.equal(w3, frag.vert_weight)
+    assert (interpolate_attr(f3, colors) - rgb).abs().max().item() <= 1e-6
+    from voge_amd.Renderer import get_silhouette
+    assert (get_silhouette(frag) - get_silhouette(f3)).abs().max().item() <= 1e-6      # cached weight sum vs the kernel
     img = to_white_background(frag, colors)
     assert type(img.grad_fn).__name__ == "_ShadeThroughBackward"
     img2 = to_white_background(cp, colors)                          # the copy is still deferred: one-pass form
@@ -464,3 +470,48 @@ def test_deferred_composite_materialises_on_first_read(hip_lib):
         assert (to_white_background(f2, colors) - img).abs().max().item() <= 1e-6
     (rgb.sum() + img.sum()).backward()
     assert torch.isfinite(gm.verts.grad).all() and gm.verts.grad.abs().max() > 0
+
+
+@pytest.mark.parametrize("K,B,C", [(25, 2, 3), (40, 1, 4), (7, 1, 3)])
+def test_training_pattern_one_pass_vs_oracle(hip_lib, monkeypatch, K, B, C):
+    """interpolate_attr + get_silhouette on deferred-composite fragments: ONE forward kernel behind the sweep
+    (voge_composite_shade_fwd_iso without a background: weights, merged attributes, weight sum) and ONE backward kernel
+    (voge_fragment_merge_bwd_iso) -- any K, ShapeFitting's 25 included.  Forward and gradients against the oracle chain;
+    the stand-alone merge / silhouette / composite / trace kernels are made unreachable."""
+    from voge_amd import _lib
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import get_silhouette, interpolate_attr
+    forbid_three_kernel_chain(monkeypatch)
+    lib = _lib.load()
+
+    def boom(*a):
+        raise AssertionError("a stand-alone stage kernel was launched")
+    for name in ("voge_merge_fwd", "voge_merge_bwd", "voge_silhouette_fwd", "voge_silhouette_bwd", "voge_composite_fwd_iso", "voge_fragment_bwd_iso"):
+        monkeypatch.setattr(lib, name, boom, raising=True)
+    N, H, W = 2200, 52, 68
+    verts, sig, cols = random_scene(N, seed=900 + K, lo=0.05, hi=0.12)
+    cols = np.concatenate([cols, cols[:, :1]], axis=1)[:, :C]
+    R, T = camera_np.look_at_view_transform([3.0, 3.3][:B], [10.0, -20.0][:B], [30.0, 200.0][:B])
+    renderer = renderer_for(H, W, K, 85.0)
+    gm = GaussianMeshes(t(verts), t(sig)).to(DEV)
+    colors = t(cols, rg=True)
+    frag = renderer(gm, R=t(R), T=t(T))
+    rgb = interpolate_attr(frag, colors.repeat(B, 1))
+    sil = get_silhouette(frag)
+    assert type(rgb.grad_fn).__name__ == "_CompositeMergeBackward"
+    ref = oracle_frame(verts, sig, R, T, 85.0, (W / 2.0, H / 2.0), (H, W), K)
+    same = same_lists(frag, ref, f"training pattern, one pass K={K} B={B} C={C}", max_flips=10)
+    colsB = np.tile(cols, (B, 1))
+    rgb_ref = oracle.merge_fwd(colsB, ref["idx"], ref["weight"], ref["valid_num"])
+    wsum = ref["weight"].sum(-1)
+    assert np.abs(n(rgb) - rgb_ref)[same].max() < TOL and np.abs(n(sil) - np.minimum(wsum, 1))[same].max() < TOL
+    rng = np.random.default_rng(K)
+    g_rgb = rng.normal(size=rgb_ref.shape) * same[..., None]
+    g_silh = rng.normal(size=wsum.shape) * same
+    ((rgb * t(g_rgb)).sum() + (sil * t(g_silh)).sum()).backward()
+    g_attr, g_w = oracle.merge_bwd(colsB, ref["idx"], ref["weight"], ref["valid_num"], g_rgb)
+    live = np.arange(K)[None, None, None] < ref["valid_num"][..., None]
+    g_mu, g_sig = oracle_param_grads(ref, sig, g_w + (g_silh * (wsum < 1))[..., None] * live)
+    grad_close(f"one-pass training pattern K={K} colors", n(colors.grad), g_attr.reshape(B, N, C).sum(0), 0.25 * TOL)
+    grad_close(f"one-pass training pattern K={K} verts", n(gm.verts.grad), g_mu, 0.25 * TOL)
+    grad_close(f"one-pass training pattern K={K} sigmas", n(gm.sigmas.grad), g_sig, 0.25 * TOL)

@@ -14,7 +14,7 @@ from collections import defaultdict
 TRACE_FWD = ("cones_kernel", "prep_kernel", "binA_kernel", "binB_kernel", "trace_fwd_kernel")
 
 
-def collect(d, counter):
+def collect(d, counter, frame_only=False):
     acc = defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -23,11 +23,16 @@ def collect(d, counter):
                 continue
             k = k.split("(")[0].replace("void ", "").replace("voge::", "")
             acc[k].append(float(r["Counter_Value"]))
+    if frame_only and acc:
+        # the frame's kernels run once per step; what bench.py's set-up launched once or twice (the stand-alone composite /
+        # shade kernels behind its reference tensors) is not part of the frame
+        most = max(len(v) for v in acc.values())
+        acc = {k: v for k, v in acc.items() if 2 * len(v) >= most}
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
 def main(fetch_dir, write_dir, out, config, what="trace"):
-    fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    fe, wr = collect(fetch_dir, "FETCH_SIZE", what == "frame"), collect(write_dir, "WRITE_SIZE", what == "frame")
     kernels = {}
     for k in sorted(set(fe) | set(wr)):
         f, w = fe.get(k, 0.0), wr.get(k, 0.0)

@@ -39,6 +39,7 @@ class Fragments(object):
         self._valid_num = valid_num
         self.vert_hit_length = vert_hit_length
         self._lazy = _lazy if vert_weight is None else None
+        self._wsum = None      # (per-pixel weight sum left by a one-pass composite + merge: see get_silhouette)
 
     def _composite(self):
         lz, self._lazy = self._lazy, None
@@ -57,6 +58,7 @@ class Fragments(object):
     @vert_weight.setter
     def vert_weight(self, value):
         self._lazy = None
+        self._wsum = None
         self._vert_weight = value
 
     @property
@@ -218,11 +220,26 @@ class GaussianRenderer(nn.Module):
 
 
 def interpolate_attr(fragments: Fragments, vert_attr: torch.Tensor):
+    lz = getattr(fragments, "_lazy", None)
+    if lz is not None:
+        # fragments whose composite is still pending: weights, merged attributes and the per-pixel weight sum in one
+        # pass (ops._CompositeMerge); a get_silhouette on the same fragments then costs nothing but a clamp
+        assert vert_attr.dim() == 2
+        out = ops.composite_merge(lz, vert_attr)
+        if out is not None:
+            fragments._set_composite(out[2], out[3])
+            fragments._wsum = (out[1], out[2], out[2]._version)
+            return out[0]
     return merge_final(vert_attr=vert_attr, weight=fragments.vert_weight, valid_num=fragments.valid_num,
                        vert_assign=fragments.vert_index)
 
 
 def get_silhouette(fragments: Fragments):
+    ws = getattr(fragments, "_wsum", None)
+    if ws is not None and ws[1] is fragments._vert_weight and ws[1]._version == ws[2]:
+        # the weight sum the one-pass composite + merge left behind: min(sum_k w_k, 1) exactly as Renderer.py:157-159
+        # (torch.minimum splits the gradient at a tie like torch.min(a, b))
+        return torch.minimum(ws[0], torch.ones_like(ws[0]))
     return ops.silhouette(fragments.vert_weight)
 
 

@@ -49,6 +49,8 @@ SIGNATURES = {
                                 + [_c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),
     "voge_fragment_shade_bwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 11 + [_c_float, _c_void_p, _c_long, _c_long, _c_float]
                                     + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),
+    "voge_fragment_merge_bwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 9 + [_c_long, _c_long, _c_void_p, _c_float]
+                                    + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),
     "voge_fragment_bwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 8 + [_c_long, _c_long, _c_void_p, _c_float]
                               + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_void_p, _c_size_t] + [_c_void_p] * 3),
     "voge_fragment_bwd": (_c_int, [_c_void_p] * 10 + [_c_long, _c_long, _c_void_p, _c_float]

@@ -417,7 +417,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
 #pragma unroll
           for (int c = 0; c < SC; ++c) {
             sh.rgb[pix * SC + c] = 0.0f;
-            sh.img[pix * SC + c] = fminf(sh.bg[c], 1.0f);
+            if (sh.img != nullptr) sh.img[pix * SC + c] = fminf(sh.bg[c], 1.0f);
           }
         }
       }
@@ -636,7 +636,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
 #pragma unroll
           for (int c = 0; c < SC; ++c) {
             sh.rgb[pix * SC + c] = part[c];
-            sh.img[pix * SC + c] = fminf(fmaf(1.0f - sil, sh.bg[c], part[c]), 1.0f);
+            if (sh.img != nullptr) sh.img[pix * SC + c] = fminf(fmaf(1.0f - sil, sh.bg[c], part[c]), 1.0f);
           }
         }
       }
@@ -1034,9 +1034,10 @@ extern "C" int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, co
                                             long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
                                             float *rgb, float *img, float *wsum, voge_stream_t stream) {
   if (npix < 0 || K <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
-  if ((K & 3) != 0 || K > VOGE_MAX_K || (C != 3 && C != 4)) return VOGE_ERR_K_TOO_LARGE;      // four slots per lane; RGB / RGBA
+  if (K > VOGE_MAX_K || (C != 3 && C != 4)) return VOGE_ERR_K_TOO_LARGE;      // four slots per lane (any K: a last group may be short); RGB / RGBA
   if (npix == 0) return 0;
-  if (!idx || !cnt || !len || !records || !rays || !weight || !valid_num || !rgb || !img || !wsum || !bg || (Nattr > 0 && !colors))
+  // (img == NULL: merge_final + the weight sum only -- interpolate_attr and get_silhouette, no background; bg unused)
+  if (!idx || !cnt || !len || !records || !rays || !weight || !valid_num || !rgb || !wsum || (img && !bg) || (Nattr > 0 && !colors))
     return VOGE_ERR_BAD_ARG;
   if (Nattr * C >= (1l << 30)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the colour gathers
   constexpr int NS = 4;

@@ -229,7 +229,13 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
       }
     }
     float gr[4] = {0.f, 0.f, 0.f, 0.f}, g_sum_w = 0.0f;
-    if (SRC == 0 && on) {
+    if (SRC == 0 && on && bg == nullptr) {
+      // merge_final alone (interpolate_attr): the image's gradient is the merged attributes' own, and `wsum` carries the
+      // gradient of the per-pixel weight sum (what a get_silhouette on the same fragments hands back), or is NULL
+#pragma unroll
+      for (int c = 0; c < C; ++c) gr[c] = g_img[(long)pix * gs_pix + c * gs_c];
+      if (wsum != nullptr) g_sum_w = at_bytes<float>(wsum, pix * (OffT)4);
+    } else if (SRC == 0 && on) {
       const OffT pb = pix * (OffT)4;
       const float ws = at_bytes<float>(wsum, pb);
       float sil = fminf(ws, 1.0f);
@@ -600,6 +606,42 @@ extern "C" int voge_fragment_shade_bwd(const float *mus, const float *isigmas, c
   const long n_fin = (Nattr > P) ? Nattr : P;
   hipLaunchKernelGGL(fragment_bwd_finish_general_kernel, dim3((unsigned)((n_fin * 16 + 255) / 256)), dim3(256), 0, st, acc, 16, P, C,
                      Nattr, g_mus, g_isigmas, g_colors);
+  return launch_status();
+}
+
+// ---- interpolate_attr (+ get_silhouette) on deferred-composite fragments: merge_final's backward, the weight sum's
+// gradient, the composite and the trace backward in the one pass (the shade kernel with no background stage) ----
+extern "C" int voge_fragment_merge_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
+                                           const float *rays, const float *attr, const int32_t *idx, const int32_t *cnt,
+                                           const float *weight, const float *act, const float *len, const float *dsd,
+                                           const float *g_rgb, long g_stride_pix, long g_stride_c, const float *g_wsum,
+                                           float occ, int B, int N, long nrows, int W, int K, int C, long Nattr,
+                                           void *workspace, size_t workspace_bytes, float *g_verts, float *g_sigmas,
+                                           float *g_attr, voge_stream_t stream) {
+  if (B < 0 || N < 0 || nrows < 0 || W < 0 || K <= 0 || C <= 0 || C > 4 || Nattr < 0 || sigma_mode < 0 || sigma_mode > 2)
+    return VOGE_ERR_BAD_ARG;
+  if (K > 128) return VOGE_ERR_K_TOO_LARGE;
+  const int P = B * N;
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 0 || nrows * W == 0) {
+    if (g_attr && Nattr > 0) return (int)hipMemsetAsync(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
+    return 0;
+  }
+  if (!records || !rays || !attr || !idx || !cnt || !weight || !len || !g_rgb || !workspace) return VOGE_ERR_BAD_ARG;
+  if ((act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;
+  if ((g_verts == nullptr) != (g_sigmas == nullptr) || (sigma_mode == 2 && g_sigmas && !sigmas)) return VOGE_ERR_BAD_ARG;
+  if (workspace_bytes < (size_t)P * 32) return VOGE_ERR_WORKSPACE;
+  if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;
+  float *acc = reinterpret_cast<float *>(workspace);
+  hipError_t e = hipMemsetAsync(acc, 0, (size_t)P * 32, st);
+  if (e != hipSuccess) return (int)e;
+  // (bg = NULL selects the merge form inside the kernel; its `wsum` operand carries g_wsum)
+  const FbArgs a{reinterpret_cast<const float4 *>(records), rays, attr, idx, cnt, weight, act, len, dsd, nullptr, g_wsum, nullptr, -1.0f,
+                 g_rgb, g_stride_pix, g_stride_c, nullptr, occ, P, nrows, W, K, Nattr, acc};
+  fb_launch_shade<true>(a, C, st);
+  const long n_fin = (Nattr > P) ? Nattr : P;
+  hipLaunchKernelGGL(fragment_bwd_finish_kernel, dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, st, acc, 8, sigmas, P, N, B,
+                     IsoView{nullptr, shared ? 1 : 0, sigma_mode}, C, Nattr, g_verts, g_sigmas, g_attr);
   return launch_status();
 }
 

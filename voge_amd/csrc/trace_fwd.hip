@@ -878,20 +878,49 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       }
     }
   }
-  for (int r = 0; r < TH && !vec4 && out_weight == nullptr; ++r) {
-    const int gy = ty * TH + r;
-    if (gy >= H) break;
-    const size_t pix0 = ((size_t)b * H + gy) * W + (size_t)tx * TW;
-    {
-      for (int j = tid; j < row_items; j += T) {
-        const int x = j / K, s = j - x * K;
-        int32_t oi;
-        float ol, oa, od;
-        slot_value(r, x, s, pix0 + x, oi, ol, oa, od);
-        const size_t o = pix0 * K + j;
-        out_idx[o] = oi;
-        out_len[o] = ol;
-        if (out_act != nullptr) { out_act[o] = oa; out_dsd[o] = od; }
+  if (!vec4 && out_weight == nullptr && out_act == nullptr) {
+    // K not a multiple of four, fragments without act / dsd (ShapeFitting's max_assign = 25): index and len are the keys
+    // themselves -- every slot of the tile is one independent LDS read and two 4-byte stores, no gather, no arithmetic
+    const int th = min(TH, H - ty * TH);
+    const float inv_ri = 1.0f / (float)row_items;
+    for (int it = tid; it < th * row_items; it += T) {
+      const int r = __float2int_rz(((float)it + 0.5f) * inv_ri);
+      const int j = it - r * row_items;
+      const int x = j / K, sl = j - x * K;
+      const int owner = ((x >> 3) + (TW / 8) * (r >> 3)) * 64 + (x & 7) + 8 * (r & 7);
+      const bool in = sl < L.id[owner];
+      const uint64_t key = in ? keys[(size_t)sl * TP + owner] : 0ull;
+      const size_t o = (((size_t)b * H + ty * TH + r) * W + (size_t)tx * TW) * K + j;
+      out_idx[o] = in ? (int32_t)(uint32_t)key : -1;
+      out_len[o] = in ? ord2f((uint32_t)(key >> 32)) : VOGE_SENT_LEN;
+    }
+  }
+  if (!vec4 && out_weight == nullptr && out_act != nullptr) {
+    // K not a multiple of four, act / dsd wanted: one slot per lane and trip over the whole tile (rows x pixels x slots
+    // flattened, so a wave makes th * tw * K / 64 trips instead of th * ceil(tw * K / 64)), four trips in flight
+    const int th = min(TH, H - ty * TH);
+    const float inv_ri = 1.0f / (float)row_items;
+    const int nit = th * row_items;
+    for (int it0 = tid; it0 < nit; it0 += 4 * T) {
+      int32_t oi[4];
+      float ol[4], oa[4], od[4];
+      size_t oo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int it = it0 + u * T;
+        oo[u] = 0; oi[u] = -1; ol[u] = VOGE_SENT_LEN; oa[u] = VOGE_SENT_ACT; od[u] = 0.0f;
+        if (it < nit) {
+          const int r = __float2int_rz(((float)it + 0.5f) * inv_ri);
+          const int j = it - r * row_items;
+          const int x = j / K, sl = j - x * K;
+          const size_t pix = ((size_t)b * H + ty * TH + r) * W + (size_t)tx * TW + x;
+          slot_value(r, x, sl, pix, oi[u], ol[u], oa[u], od[u]);
+          oo[u] = pix * K + sl;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (it0 + u * T < nit) { out_idx[oo[u]] = oi[u]; out_len[oo[u]] = ol[u]; out_act[oo[u]] = oa[u]; out_dsd[oo[u]] = od[u]; }
       }
     }
   }

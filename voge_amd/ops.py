@@ -797,6 +797,81 @@ class _CompositeShade(torch.autograd.Function):
         return (g_attr if need[0] else None), (g0 if need[1] else None), (g1 if need[2] else None), None, None, None, None
 
 
+class _CompositeMerge(torch.autograd.Function):
+    """aggregation + merge_final (interpolate_attr) + the per-pixel weight sum in ONE forward pass
+    (voge_composite_shade_fwd_iso without a background): forward(attr, p0, p1, sel_len, lz) -> merged attributes,
+    weight sum, weight, valid_num.  get_silhouette on the same fragments is min(weight sum, 1), so the reference's training
+    pattern -- interpolate_attr + get_silhouette (demo/ShapeFitting.py:217-222) -- is this one kernel forward and ONE
+    kernel backward (voge_fragment_merge_bwd_iso: merge backward + the sum's gradient + composite + trace)."""
+
+    @staticmethod
+    def forward(ctx, attr, p0, p1, sel_len, lz):
+        lib = _lib.load()
+        attr_c = _dev(attr, torch.float32, "vert_attr")
+        idx, K = lz.sel_idx, lz.K
+        Nattr, C = attr_c.shape
+        check_index_range(idx, Nattr)
+        weight = torch.empty_like(sel_len)
+        valid = torch.empty(idx.shape[:-1], dtype=torch.int64, device=idx.device)
+        rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
+        wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
+        with _on(idx.device):
+            rc = lib.voge_composite_shade_fwd_iso(_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c),
+                                                  None, -1.0, idx.numel() // K, K, C, Nattr, _p(weight), _p(valid), _p(rgb), None,
+                                                  _p(wsum), _stream())
+        _lib.check(rc, "voge_composite_shade_fwd_iso")
+        ctx.save_for_backward(attr_c, _dev(p1, torch.float32, "sigmas"), sel_len, weight)
+        ctx.lz = lz
+        ctx.mark_non_differentiable(valid)
+        ctx.set_materialize_grads(False)
+        return rgb, wsum, weight, valid
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_wsum, g_weight, _g_valid):
+        lib = _lib.load()
+        attr, p1, ln, weight = ctx.saved_tensors
+        lz = ctx.lz
+        idx = lz.sel_idx
+        B, H, W, K = idx.shape
+        Nattr, C = attr.shape
+        g_attr = g0 = g1 = None
+        if g_rgb is not None or g_wsum is not None:
+            if g_rgb is None:
+                g_rgb = torch.zeros(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
+            if g_rgb.dtype == torch.float32 and g_rgb.is_cuda and all(s == 0 for s in g_rgb.stride()):
+                go, gs_pix, gs_c = g_rgb, 0, 0
+            else:
+                go, gs_pix, gs_c = _dev(g_rgb, torch.float32, "grad_out"), C, 1
+            gws = None if g_wsum is None else _dev(g_wsum, torch.float32, "grad_weight_sum")
+            g_attr = torch.empty_like(attr)
+            g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=idx.device)
+            g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=idx.device)
+            with _on(idx.device):
+                nbytes = lib.voge_fragment_bwd_workspace_bytes(lz.B * lz.N)
+                ws = _workspace(idx.device, nbytes)
+                rc = lib.voge_fragment_merge_bwd_iso(
+                    _p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(attr), _p(idx), _p(lz.cnt), _p(weight), None,
+                    _p(ln), None, _p(go), gs_pix, gs_c, _p(gws), lz.occ, lz.B, lz.N, B * H, W, K, C, Nattr, _p(ws), nbytes, _p(g0),
+                    _p(g1), _p(g_attr), _stream())
+            _lib.check(rc, "voge_fragment_merge_bwd_iso")
+        if g_weight is not None:
+            h0, h1 = _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K)
+            g0, g1 = (h0, h1) if g0 is None else (g0 + h0, g1 + h1)
+        need = ctx.needs_input_grad
+        return (g_attr if need[0] else None), (g0 if need[1] else None), (g1 if need[2] else None), None, None
+
+
+def composite_merge(lz, attr):
+    """-> merged attributes, weight sum, weight, valid_num; or None when the one-pass form does not apply."""
+    K = lz.K
+    if K > 128 or attr.dim() != 2 or attr.shape[1] not in (3, 4) or attr.numel() >= (1 << 30) or not lz.usable():
+        return None
+    if os.environ.get("VOGE_SHADE_THROUGH", "1") == "0":
+        return None
+    rgb, wsum, weight, valid = _CompositeMerge.apply(attr, lz.p0, lz.p1, lz.sel_len, lz)
+    return rgb, wsum, lz.through(weight), valid
+
+
 def trace_lean(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode=0, occ=1.0):
     """-> (sel_idx, sel_len, LazyComposite): the renderer's forward up to the sweep; the composite is deferred."""
     sel_idx, sel_len, cnt, records = _TraceLean.apply(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode)
@@ -829,7 +904,7 @@ def composite_lean(lz):
 def composite_shade(lz, attr, bg, thr):
     """-> image, weight, valid_num, or None when the one-pass form does not apply (K % 4, channel count, offsets)."""
     K = lz.K
-    if (K & 3) or K > 128 or attr.dim() != 2 or attr.shape[1] not in (3, 4) or attr.numel() >= (1 << 30) or not lz.usable():
+    if K > 128 or attr.dim() != 2 or attr.shape[1] not in (3, 4) or attr.numel() >= (1 << 30) or not lz.usable():
         return None      # (K <= 128: the image's backward is voge_fragment_shade_bwd_iso)
     if os.environ.get("VOGE_SHADE_THROUGH", "1") == "0":
         return None
