@@ -114,10 +114,14 @@ def loop_bench(args):
     for name, kw in (("graph", dict(graph=True)), ("eager", dict()), ("per_view_eager", dict(per_view=True))):
         if name == "graph" and args.no_graph:
             continue
-        demo.fit(iters=max(warm + 20, 400), quiet=True, rgb_on=0, **kw)           # settle: pools, code objects, clocks
+        demo.fit(iters=max(warm + 20, 400), quiet=True, rgb_on=0, **kw)           # settle: pools, code objects
         reps = []
-        for _ in range(3):                                                        # (every fit builds its own graph / optimizer state)
-            h = demo.fit(iters=steps, quiet=True, rgb_on=0, **kw)
+        # every fit builds its own graph / optimizer state; inside it the first iterations run untimed until ~0.5 s of
+        # load has passed (a replayed iteration is a quarter of a millisecond: `steps` of them alone would be timed on
+        # whatever clock state the box happened to be in)
+        settle = max(warm, 2000 if name == "graph" else 500)
+        for _ in range(3):
+            h = demo.fit(iters=settle + steps, timed_from=settle, quiet=True, rgb_on=0, **kw)
             reps.append(h["sec_per_iter"] * 1e3)
             sil = np.asarray(h["silhouette"])
             assert np.isfinite(sil).all() and sil[-1] < sil[0], "the loop must run and descend"

@@ -90,6 +90,39 @@ def simulate(order):
                     tot_lane += (COL * (cb[p][:n] + cf[p][:n]).sum() + ROW * (rb[p][:n] + rf[p][:n]).sum()) / 64.0
     return tot_wave, tot_lane
 
+def simulate_tail(T, c_tail=100.0):
+    """Cut every window loop after T iterations; what is left (lane-iterations beyond T, 4 pairs each) is evaluated one pair
+    per lane in a cooperative second phase: ceil(pairs / 64) steps of c_tail VALU (LDS reads, unpacked evaluation, segmented
+    reduction of the three column sums by key, write-back)."""
+    tot = 0.0
+    for y0 in range(0, H, GH):
+        for x0 in range(0, W, GW):
+            pix = [(y, x) for y in range(y0, min(y0 + GH, H)) for x in range(x0, min(x0 + GW, W))]
+            c = np.array([cnt[p] for p in pix])
+            if c.sum() == 0:
+                continue
+            lanes, cur, rounds = 0, [], []
+            for i in range(len(pix)):
+                need = (c[i] + 1) // 2
+                if need == 0:
+                    continue
+                if lanes + need > 64:
+                    rounds.append(cur); cur = []; lanes = 0
+                cur.append(pix[i]); lanes += need
+            if cur:
+                rounds.append(cur)
+            for rnd in rounds:
+                for arr, cost in ((cb, COL), (cf, COL), (rb, ROW), (rf, ROW)):
+                    t = np.concatenate([arr[p][: (cnt[p] + 1) // 2] for p in rnd])
+                    tot += cost * min(int(t.max()), T)
+                    left = int(np.maximum(t - T, 0).sum()) * 4
+                    if left:
+                        tot += c_tail * (cost / COL) * -(-left // 64)
+    return tot
+
+
+for T in (1, 2, 3, 4, 6, 99):
+    print(f"cut after {T:2d} iterations + cooperative tail: {simulate_tail(T) / 1e6:7.2f} M window-loop VALU wave-instructions")
 for order in ("stored", "count", "window"):
     w, l = simulate(order)
     print(f"{order:8s}: window-loop VALU wave-instructions {w / 1e6:7.2f} M, at full lane utilisation {l / 1e6:7.2f} M "

@@ -676,6 +676,12 @@ class LazyComposite:
         return (self.sel_len._version == 0 and self.rays._version == self.rays_version
                 and hit_count_of(self.sel_idx) is not None)
 
+    def check(self):
+        """Backward-time guard: what the kernels read outside save_for_backward must be what the forward saw."""
+        if self.rays._version != self.rays_version:
+            raise RuntimeError("the rays were modified in place after the fragments were traced: the backward would read the "
+                               "changed values (as autograd's own check for saved tensors)")
+
     def through(self, weight):
         """Tag freshly composited weights the way fragments() does (a later to_colored_background takes _ShadeThrough)."""
         if (self.p0.requires_grad or self.p1.requires_grad) and torch.is_grad_enabled():
@@ -690,6 +696,7 @@ class LazyComposite:
 
 def _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K):
     """composite + trace backward in one pass for a deferred composite: -> (g_p0, g_p1)."""
+    lz.check()
     gw, gs_pix, gs_k = _grad_weight_layout(g_weight, K)
     g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=ln.device)
     g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=ln.device)
@@ -770,6 +777,7 @@ class _CompositeShade(torch.autograd.Function):
         lib = _lib.load()
         attr, p1, ln, weight, rgb, bg, wsum = ctx.saved_tensors
         lz = ctx.lz
+        lz.check()
         idx = lz.sel_idx
         B, H, W, K = idx.shape
         Nattr, C = attr.shape
@@ -831,6 +839,7 @@ class _CompositeMerge(torch.autograd.Function):
         lib = _lib.load()
         attr, p1, ln, weight = ctx.saved_tensors
         lz = ctx.lz
+        lz.check()
         idx = lz.sel_idx
         B, H, W, K = idx.shape
         Nattr, C = attr.shape
