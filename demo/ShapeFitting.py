@@ -218,6 +218,9 @@ def fit(iters=2000, level=4, size=128, num_views=20, views_per_iter=5, max_assig
     history["sec_per_iter"] = (time.perf_counter() - t0) / max(iters - max(timed_from, 0), 1)
     tr = trace.cpu().numpy()
     history["silhouette"], history["rgb"] = tr[:, 0].tolist(), tr[:, 1].tolist()
+    history["final_verts"] = gsrc.verts.detach().cpu().numpy()
+    history["final_colors"] = vert_color.detach().cpu().numpy()
+    history["sigmas"] = gsrc.sigmas.detach().cpu().numpy()
     if save:
         os.makedirs(save, exist_ok=True)
         with torch.no_grad():

@@ -318,3 +318,35 @@ def test_bin_and_tile_list_overflow_fallbacks(hip_lib, N, H, W, K, what):
     compare_trace(got_gen, ref, thr_act, min_match=0.995, label=f"overflow {what} general N={N}")
     for x, y in zip(got_iso, got_gen):
         assert np.array_equal(x, y)                                       # the two entry points agree bit for bit
+
+
+@pytest.mark.parametrize("N,extent,what", [
+    (9000, 0.22, "interleaved dealing (N < 16384): 563 Gaussians per slice, all inside one super-tile"),
+    (40000, 0.30, "chunked dealing: 2-3 chunks of 1024 per slice, most of them inside four super-tiles"),
+    (2562, 0.5, "ShapeFitting's size: no segment may overflow at all (160 Gaussians per slice)")])
+def test_small_object_segment_overflow_is_handled_per_slice(hip_lib, N, extent, what):
+    """A small object far away puts more than kSegCap = 512 of a slice's Gaussians into ONE super-tile.  Round 2 sent
+    every tile of such a super-tile to the stream-everything fallback (the fitted ShapeFitting sphere: sweep 80 -> 780 us);
+    now small sets are dealt Gaussian by Gaussian over the slices (trace_bin.h: deal_interleaved), and a segment that still
+    overflows is re-tested from the per-Gaussian records inside binB.  Results must equal the brute-force oracle
+    (scalar-sigma and general entry points, which share binB)."""
+    from voge_amd import ops
+    rng = np.random.default_rng(N)
+    verts = rng.uniform(-extent, extent, (N, 3)).astype(np.float32)
+    r = rng.uniform(0.006, 0.012, N)
+    sig = (1.0 / (r * r / (2 * np.log(1 / 0.6)))).astype(np.float32)
+    H = W = 96
+    K = 12
+    R, T = camera_np.look_at_view_transform(3.0, 10.0, 20.0)
+    rays, origin = camera_np.pixel_rays(R, T, 110.0, (W / 2.0, H / 2.0), (H, W))
+    mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = (2 * camera_np.expand_sigma(sig)).astype(np.float32)[None]
+    thr_act = oracle.thr_act_of(0.01)
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    assert (ref[0][..., 0] >= 0).mean() > 0.02 and (ref[0] >= 0).sum() > 2000, what      # the object is hit
+    a = np.ascontiguousarray(isg[..., 0, 0])
+    got_iso = [n(x) for x in ops._RayTraceVoGEIso.apply(t(mus.reshape(-1, 3)), t(a.reshape(-1)), t(rays), None, thr_act, K)]
+    compare_trace(got_iso, ref, thr_act, min_match=0.998, label=f"small object N={N} iso")
+    got_gen = [n(x) for x in ops.ray_trace_fine(t(mus).reshape(-1, 3), t(isg).reshape(-1, 3, 3), t(rays), None, thr_act, 10, K)]
+    for x, y in zip(got_iso, got_gen):
+        assert np.array_equal(x, y)

@@ -265,11 +265,11 @@ extern "C" int voge_ray_dense_bwd(const float *mus, const float *isigmas, const 
   if (M < 0 || N < 0) return VOGE_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
-  if (N > 0) { if (!g_ray) return VOGE_ERR_BAD_ARG; e = hipMemsetAsync(g_ray, 0, sizeof(float) * 3 * (size_t)N, st); if (e != hipSuccess) return (int)e; }
+  if (N > 0) { if (!g_ray) return VOGE_ERR_BAD_ARG; e = voge_fill_async(g_ray, 0, sizeof(float) * 3 * (size_t)N, st); if (e != hipSuccess) return (int)e; }
   if (M > 0) {
     if (!g_mus || !g_isg) return VOGE_ERR_BAD_ARG;
-    e = hipMemsetAsync(g_mus, 0, sizeof(float) * 3 * (size_t)M, st); if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(g_isg, 0, sizeof(float) * 9 * (size_t)M, st); if (e != hipSuccess) return (int)e;
+    e = voge_fill_async(g_mus, 0, sizeof(float) * 3 * (size_t)M, st); if (e != hipSuccess) return (int)e;
+    e = voge_fill_async(g_isg, 0, sizeof(float) * 9 * (size_t)M, st); if (e != hipSuccess) return (int)e;
   }
   if ((long)M * N == 0) return 0;
   if (!mus || !isigmas || !rays || !g_len || !g_act || !g_dsd) return VOGE_ERR_BAD_ARG;
@@ -303,9 +303,9 @@ extern "C" int voge_find_nearest_k_bwd(const int32_t *idx, const float *g_len, c
   const size_t bytes = sizeof(float) * (size_t)N * M;
   if (bytes > 0) {
     if (!gi_len || !gi_act || !gi_dsd) return VOGE_ERR_BAD_ARG;
-    hipError_t e = hipMemsetAsync(gi_len, 0, bytes, st); if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(gi_act, 0, bytes, st); if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(gi_dsd, 0, bytes, st); if (e != hipSuccess) return (int)e;
+    hipError_t e = voge_fill_async(gi_len, 0, bytes, st); if (e != hipSuccess) return (int)e;
+    e = voge_fill_async(gi_act, 0, bytes, st); if (e != hipSuccess) return (int)e;
+    e = voge_fill_async(gi_dsd, 0, bytes, st); if (e != hipSuccess) return (int)e;
   }
   if (N * K == 0 || M == 0) return 0;
   if (!idx || !g_len || !g_act || !g_dsd) return VOGE_ERR_BAD_ARG;
@@ -320,7 +320,7 @@ extern "C" int voge_scatter_max(const float *weight, const int32_t *idx, long n,
   hipStream_t st = (hipStream_t)stream;
   if (Nv > 0) {
     if (!out) return VOGE_ERR_BAD_ARG;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)Nv, st);
+    hipError_t e = voge_fill_async(out, 0, sizeof(float) * (size_t)Nv, st);
     if (e != hipSuccess) return (int)e;
   }
   if (n == 0 || Nv == 0) return 0;
@@ -339,7 +339,7 @@ extern "C" int voge_bin_gaussians(const float *points, const int64_t *cloud_to_p
   if (n == 0) return 0;
   if (!bin_elems || !cloud_to_packed_first_idx || !num_points_per_cloud || (P > 0 && (!points || !radius))) return VOGE_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const hipError_t e = hipMemsetAsync(bin_elems, 0xff, n * sizeof(int32_t), st);      // at::full(-1), :222
+  const hipError_t e = voge_fill_async(bin_elems, 0xff, n * sizeof(int32_t), st);      // at::full(-1), :222
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(coarse_bin_kernel, dim3(nbx * nby, B), dim3(256), 0, st, points, radius, cloud_to_packed_first_idx,
                      num_points_per_cloud, P, H, W, bin_size, max_points_per_bin, bin_elems);

@@ -555,7 +555,7 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
   const int P = B * N;
   hipStream_t st = (hipStream_t)stream;
   if (P == 0 || nrows * W == 0) {
-    if (g_colors && Nattr > 0) return (int)hipMemsetAsync(g_colors, 0, sizeof(float) * (size_t)Nattr * C, st);
+    if (g_colors && Nattr > 0) return (int)voge_fill_async(g_colors, 0, sizeof(float) * (size_t)Nattr * C, st);
     return 0;
   }
   if (!records || !rays || !colors || !idx || !cnt || !weight || !len || !rgb || !wsum || !bg || !g_img || !workspace)
@@ -565,8 +565,7 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
   if (workspace_bytes < (size_t)P * 32) return VOGE_ERR_WORKSPACE;
   if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
   float *acc = reinterpret_cast<float *>(workspace);
-  hipError_t e = hipMemsetAsync(acc, 0, (size_t)P * 32, st);
-  if (e != hipSuccess) return (int)e;
+  { const hipError_t e = voge_fill_async(acc, 0, (size_t)P * 32, st); if (e != hipSuccess) return (int)e; }
   const FbArgs a{reinterpret_cast<const float4 *>(records), rays, colors, idx, cnt, weight, act, len, dsd, rgb, wsum, bg, thr, g_img,
                  g_stride_pix, g_stride_c, nullptr, occ, P, nrows, W, K, Nattr, acc};
   fb_launch_shade<true>(a, C, st);
@@ -587,7 +586,7 @@ extern "C" int voge_fragment_shade_bwd(const float *mus, const float *isigmas, c
   if (K > 128) return VOGE_ERR_K_TOO_LARGE;
   hipStream_t st = (hipStream_t)stream;
   if (P == 0 || nrows * W == 0) {
-    if (g_colors && Nattr > 0) return (int)hipMemsetAsync(g_colors, 0, sizeof(float) * (size_t)Nattr * C, st);
+    if (g_colors && Nattr > 0) return (int)voge_fill_async(g_colors, 0, sizeof(float) * (size_t)Nattr * C, st);
     return 0;
   }
   if (!mus || !isigmas || !rays || !colors || !idx || !cnt || !weight || !act || !len || !dsd || !rgb || !wsum || !bg || !g_img ||
@@ -624,7 +623,7 @@ extern "C" int voge_fragment_merge_bwd_iso(const float *records, const float *si
   const int P = B * N;
   hipStream_t st = (hipStream_t)stream;
   if (P == 0 || nrows * W == 0) {
-    if (g_attr && Nattr > 0) return (int)hipMemsetAsync(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
+    if (g_attr && Nattr > 0) return (int)voge_fill_async(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
     return 0;
   }
   if (!records || !rays || !attr || !idx || !cnt || !weight || !len || !g_rgb || !workspace) return VOGE_ERR_BAD_ARG;
@@ -633,8 +632,7 @@ extern "C" int voge_fragment_merge_bwd_iso(const float *records, const float *si
   if (workspace_bytes < (size_t)P * 32) return VOGE_ERR_WORKSPACE;
   if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;
   float *acc = reinterpret_cast<float *>(workspace);
-  hipError_t e = hipMemsetAsync(acc, 0, (size_t)P * 32, st);
-  if (e != hipSuccess) return (int)e;
+  { const hipError_t e = voge_fill_async(acc, 0, (size_t)P * 32, st); if (e != hipSuccess) return (int)e; }
   // (bg = NULL selects the merge form inside the kernel; its `wsum` operand carries g_wsum)
   const FbArgs a{reinterpret_cast<const float4 *>(records), rays, attr, idx, cnt, weight, act, len, dsd, nullptr, g_wsum, nullptr, -1.0f,
                  g_rgb, g_stride_pix, g_stride_c, nullptr, occ, P, nrows, W, K, Nattr, acc};
@@ -660,8 +658,8 @@ extern "C" int voge_fragment_bwd_iso(const float *records, const float *sigmas, 
   if (n_out == 0) return 0;      // no Gaussians: nothing to write
   if (!g_verts || !g_sigmas) return VOGE_ERR_BAD_ARG;
   if (P == 0 || nrows * W == 0) {
-    hipError_t e0 = hipMemsetAsync(g_verts, 0, sizeof(float) * 3 * (size_t)n_out, st);
-    if (e0 == hipSuccess) e0 = hipMemsetAsync(g_sigmas, 0, sizeof(float) * (size_t)n_out, st);
+    hipError_t e0 = voge_fill_async(g_verts, 0, sizeof(float) * 3 * (size_t)n_out, st);
+    if (e0 == hipSuccess) e0 = voge_fill_async(g_sigmas, 0, sizeof(float) * (size_t)n_out, st);
     return (int)e0;
   }
   if (!records || !rays || !idx || !cnt || !weight || !len || !workspace) return VOGE_ERR_BAD_ARG;
@@ -669,8 +667,7 @@ extern "C" int voge_fragment_bwd_iso(const float *records, const float *sigmas, 
   if (workspace_bytes < (size_t)P * 16) return VOGE_ERR_WORKSPACE;
   if (P >= (1 << 26)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the record gathers
   float *acc = reinterpret_cast<float *>(workspace);
-  hipError_t e = hipMemsetAsync(acc, 0, (size_t)P * 16, st);
-  if (e != hipSuccess) return (int)e;
+  { const hipError_t e = voge_fill_async(acc, 0, (size_t)P * 16, st); if (e != hipSuccess) return (int)e; }
   const FbArgs a{reinterpret_cast<const float4 *>(records), rays, nullptr, idx, cnt, weight, act, len, dsd, nullptr, nullptr, nullptr,
                  -1.0f, g_weight, gw_stride_pix, gw_stride_k, g_hitlen, occ, P, nrows, W, K, 0, acc};
   fb_launch_gw<true>(a, st);
@@ -690,8 +687,8 @@ extern "C" int voge_fragment_bwd(const float *mus, const float *isigmas, const f
   if (P == 0) return 0;      // no Gaussians: nothing to write
   if (!g_mus || !g_isigmas) return VOGE_ERR_BAD_ARG;
   if (nrows * W == 0) {
-    hipError_t e0 = hipMemsetAsync(g_mus, 0, sizeof(float) * 3 * (size_t)P, st);
-    if (e0 == hipSuccess) e0 = hipMemsetAsync(g_isigmas, 0, sizeof(float) * 9 * (size_t)P, st);
+    hipError_t e0 = voge_fill_async(g_mus, 0, sizeof(float) * 3 * (size_t)P, st);
+    if (e0 == hipSuccess) e0 = voge_fill_async(g_isigmas, 0, sizeof(float) * 9 * (size_t)P, st);
     return (int)e0;
   }
   if (!mus || !isigmas || !rays || !idx || !cnt || !weight || !act || !len || !dsd || !workspace) return VOGE_ERR_BAD_ARG;

@@ -527,7 +527,7 @@ extern "C" int voge_shade_bwd(const float *attr, const int32_t *idx, const float
   if (nrows < 0 || W < 0 || K <= 0 || C <= 0 || C > 4 || Nattr < 0) return VOGE_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (g_attr != nullptr && Nattr > 0) {
-    hipError_t e = hipMemsetAsync(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
+    hipError_t e = voge_fill_async(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
     if (e != hipSuccess) return (int)e;
   }
   if (nrows * W == 0) return 0;
@@ -555,7 +555,7 @@ extern "C" int voge_merge_bwd(const float *attr, const int32_t *idx, const float
                                     g_attr, g_weight, stream);
   hipStream_t st = (hipStream_t)stream;
   if (g_attr != nullptr && Nattr > 0) {
-    hipError_t e = hipMemsetAsync(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
+    hipError_t e = voge_fill_async(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
     if (e != hipSuccess) return (int)e;
   }
   const long npix = nrows * W;

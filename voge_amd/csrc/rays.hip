@@ -251,7 +251,7 @@ extern "C" int voge_rays_bwd(const float *R, const float *T, const float *focal,
   if (B == 0) return 0;
   if (!R || !T || !focal || !pp || !scratch) return VOGE_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float) * 16 * (size_t)B, st);
+  hipError_t e = voge_fill_async(scratch, 0, sizeof(float) * 16 * (size_t)B, st);
   if (e != hipSuccess) return (int)e;
   const int n = h * W;
   if (n > 0 && g_rays != nullptr) {

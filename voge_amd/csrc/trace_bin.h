@@ -122,6 +122,21 @@ __device__ __forceinline__ float4 binA_record(const int g, const int b, const in
   return c;
 }
 
+// How binA deals the N Gaussians of a batch element to its kParts slices (see binA_kernel), for binB, which re-derives a
+// slice's members when that slice's segment of a super-tile overflowed kSegCap.
+__host__ __device__ inline bool deal_interleaved(const int N) { return N < kParts * kBinThreads; }
+__device__ __forceinline__ int slice_len(const int p, const int N) {
+  if (deal_interleaved(N)) return (N - p + kParts - 1) / kParts;                   // g = k * kParts + p
+  const int nchunks = (N + kBinThreads - 1) / kBinThreads;
+  int n = 0;
+  for (int j = p; j < nchunks; j += kParts) n += min(kBinThreads, N - j * kBinThreads);
+  return n;
+}
+__device__ __forceinline__ int slice_gauss(const int p, const int k, const int N) {
+  if (deal_interleaved(N)) return k * kParts + p;
+  return (p + kParts * (k / kBinThreads)) * kBinThreads + (k % kBinThreads);      // chunks p, p + kParts, ...
+}
+
 template <bool ISO_PREP>
 __global__ void __launch_bounds__(kBinThreads)
 binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, const int nsty, const int nst0x,
@@ -136,7 +151,15 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
   const int nst = nstx * nsty;
   if (tid < kCh * kCh) L.base[tid] = 0;
   BIN_TS(0, 0);
-  const int nchunks = (N + kBinThreads - 1) / kBinThreads;
+  // How the N Gaussians are dealt to the kParts slices.  Large sets: whole 1024-Gaussian chunks round-robin (coalesced
+  // loads; a spatially ordered input still spreads over the slices).  Small sets (fewer than kParts chunks) would leave
+  // most slices empty and put 1024 candidates into a 512-entry segment as soon as half of them fall into one
+  // super-tile -- the fitted ShapeFitting sphere (2562 Gaussians on a 50-pixel object) did exactly that and sent every tile
+  // of the image to the stream-everything fallback (sweep 80 -> 780 us).  They are dealt Gaussian by Gaussian instead
+  // (g = slot * kParts + part): every slice gets N / kParts of them.
+  const bool interleaved = deal_interleaved(N);
+  const int nchunks = interleaved ? kParts * ((N + kParts * kBinThreads - 1) / (kParts * kBinThreads))
+                                  : (N + kBinThreads - 1) / kBinThreads;
   const bool writes_records = ISO_PREP && region == 0;   // region 0's slices cover every Gaussian exactly once
   // the first round's candidates do not depend on the cones: their loads go out first
   float4 c[kRoundChunks];
@@ -145,8 +168,9 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
   auto load_round = [&](const int j0) {
 #pragma unroll
     for (int q = 0; q < kRoundChunks; ++q) {
-      const int g = (j0 + q * kParts) * kBinThreads + tid;
-      gq[q] = (j0 + q * kParts < nchunks && g < N) ? g : -1;
+      const int j = j0 + q * kParts;      // (j % kParts == part)
+      const int g = interleaved ? ((j / kParts) * kBinThreads + tid) * kParts + part : j * kBinThreads + tid;
+      gq[q] = (j < nchunks && g < N) ? g : -1;
       av[q] = 0.f;
       c[q] = (gq[q] >= 0) ? binA_record<ISO_PREP>(g, b, N, cull, mus, isg, cam_fwd, thr_act, view, av[q])
                           : make_float4(0.f, 0.f, 0.f, -1.f);
@@ -306,7 +330,8 @@ struct BinLds {
   int hist[kBuckets];
   uint32_t bmin[kBuckets];   // per bucket: smallest own len bound of the entries with an ellipsoid record (ord)
   int wsum[8];
-  int segn[kParts + 1];      // exclusive prefix of the segment counts
+  int segn[kParts + 1];      // exclusive prefix of the segment counts (an overflowed segment counts its whole slice)
+  unsigned ovf;              // bit p: slice p's segment overflowed kSegCap -- its Gaussians are re-tested from their records
   int count;
   int nflag;      // entries with an ellipsoid record
   int spill;      // a tile list overflowed kTileCap: the quad's ordered list goes to memory as its fallback
@@ -363,13 +388,20 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
     if (lane == 0) { L.red[wave * 8 + 0] = wsx; L.red[wave * 8 + 1] = wsy; L.red[wave * 8 + 2] = wsz; L.red[wave * 8 + 3] = wok ? 1.f : 0.f; }
     if (tid == 0) { L.count = 0; L.nflag = 0; L.spill = 0; }
     if (tid == 0) {
-      int run = 0, bad = 0;
+      // A segment that overflowed its kSegCap entries (more than 512 of a slice's Gaussians in one super-tile: a small
+      // object far away, a zoomed-out view) does not send the quad to the stream-everything fallback any more: the
+      // slice's Gaussians -- N / kParts of them -- are tested against the quad's cone right here, from the records
+      // binA / prep left per Gaussian.  Only a quad list beyond kQCap still falls back.
+      int run = 0;
+      unsigned ovf = 0u;
       for (int p = 0; p < kParts; ++p) {
-        const int c = seg_count[(size_t)bin * kParts + p];
+        int c = seg_count[(size_t)bin * kParts + p];
         L.segn[p] = run;
-        if (c < 0) bad = 1; else run += c;
+        if (c < 0) { ovf |= 1u << p; c = slice_len(p, N); }
+        run += c;
       }
-      L.segn[kParts] = bad ? -1 : run;
+      L.segn[kParts] = run;
+      L.ovf = ovf;
     }
     __syncthreads();
     const float gx = L.red[0] + L.red[8] + L.red[16] + L.red[24], gy = L.red[1] + L.red[9] + L.red[17] + L.red[25],
@@ -415,6 +447,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   }
   int2 *my_order = order + (size_t)rank * kTilesPerBin + qq * kTilesPerQuad;     // this quad's four launch slots
   const int n_src = L.segn[kParts];
+  const unsigned ovf = L.ovf;
   // ---- the super-tile's segments against the quad's cone; survivors' keys are compacted in LDS.  Anisotropic
   // candidates are tested with their ellipsoid as well (binA tested bounding spheres only). ----
   const float4 *cullb = cull + (size_t)b * N;
@@ -437,9 +470,15 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
         int p = 0;
 #pragma unroll
         for (int q = 1; q < kParts; ++q) p += (i >= L.segn[q]) ? 1 : 0;
-        const int o = p * kSegCap + (i - L.segn[p]);
-        gid[j] = segs[o];
-        c[j] = segr[o];
+        const int k = i - L.segn[p];
+        if ((ovf >> p) & 1u) {      // (rare) the slice itself, record by record
+          const int g = slice_gauss(p, k, N);
+          if (g < N) { gid[j] = g; c[j] = cullb[g]; }
+        } else {
+          const int o = p * kSegCap + k;
+          gid[j] = segs[o];
+          c[j] = segr[o];
+        }
       }
     }
 #pragma unroll

@@ -468,7 +468,7 @@ extern "C" int voge_trace_bwd(const float *mus, const float *isigmas, const floa
   if (P < 0 || nrows < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (P == 0) {
-    if (g_ray && nrows * W > 0) return (int)hipMemsetAsync(g_ray, 0, sizeof(float) * 3 * (size_t)(nrows * W), st);
+    if (g_ray && nrows * W > 0) return (int)voge_fill_async(g_ray, 0, sizeof(float) * 3 * (size_t)(nrows * W), st);
     return 0;
   }
   if (!g_mus || !g_isg || !mus || !isigmas || !workspace) return VOGE_ERR_BAD_ARG;
@@ -498,7 +498,7 @@ static int trace_bwd_iso_impl(const IsoView view, const float *mus, const float 
   if (P < 0 || nrows < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (P == 0) {
-    if (g_ray && nrows * W > 0) return (int)hipMemsetAsync(g_ray, 0, sizeof(float) * 3 * (size_t)(nrows * W), st);
+    if (g_ray && nrows * W > 0) return (int)voge_fill_async(g_ray, 0, sizeof(float) * 3 * (size_t)(nrows * W), st);
     return 0;
   }
   if (!g_mus || !g_a || !mus || !a || !workspace) return VOGE_ERR_BAD_ARG;

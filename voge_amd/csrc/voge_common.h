@@ -572,6 +572,27 @@ __device__ __forceinline__ float seg_sum_key(float x, const int key, const int l
 
 inline int launch_status() { return (int)hipGetLastError(); }
 
+// Fill `bytes` (a multiple of 4) at p with one 32-bit pattern -- by a kernel of this library, never hipMemsetAsync.
+// A memset captured into a HIP graph (torch.cuda.graph around a training iteration) did NOT reliably take effect on
+// replay on ROCm 7.2 / gfx950: the fused backward's accumulators kept the previous contents and one replayed SGD step sent
+// every vertex to 1e20 (tools/loop_graph_check.py, round 3).  A kernel node has no such problem, and it is one launch where
+// the runtime turns a memset into two fill kernels.
+static __global__ void __launch_bounds__(256) voge_fill32_kernel(uint32_t *__restrict__ p, const size_t n, const uint32_t value) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n && (reinterpret_cast<uintptr_t>(p + i) & 15) == 0) {
+    *reinterpret_cast<uint4 *>(p + i) = make_uint4(value, value, value, value);
+  } else {
+    for (size_t j = i; j < n && j < i + 4; ++j) p[j] = value;
+  }
+}
+inline hipError_t voge_fill_async(void *p, const int byte_value, const size_t bytes, hipStream_t st) {
+  if (bytes == 0 || p == nullptr) return hipSuccess;
+  const uint32_t b = (uint32_t)(byte_value & 0xff), v = b | (b << 8) | (b << 16) | (b << 24);
+  const size_t n = bytes / 4;      // (every caller fills float / int32 arrays)
+  hipLaunchKernelGGL(voge_fill32_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, reinterpret_cast<uint32_t *>(p), n, v);
+  return hipGetLastError();
+}
+
 // The opt-in for more than 64 KB of dynamic LDS is a per-function, per-device attribute.  Set it when the request
 // grows -- not on every call, and not again inside a stream capture once a frame of this size has run.
 struct DynLdsCache {
