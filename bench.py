@@ -279,6 +279,8 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
+    graph_checked = []      # (one entry per captured frame whose replayed gradients were compared with the eager step's)
+
     def graphed_step(fwd, params):
         """One frame as a HIP graph replay (every replay runs exactly the kernels of an eager step on the same static
         tensors); eager on capture failure or --no-graph.  Returns (callable, launch description)."""
@@ -293,11 +295,18 @@ def main():
             return step, "eager"
         try:
             warm_side_stream(step)
+            torch.cuda.synchronize()
+            want = [p.grad.detach().clone() for p in params]      # (the eager step's gradients: what a replay must reproduce)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 step()
-            graph.replay()
+            for _ in range(3):                                     # back-to-back replays, no host synchronisation between them
+                graph.replay()
             torch.cuda.synchronize()
+            for p, w in zip(params, want):
+                err = float((p.grad - w).abs().max()) / max(float(w.abs().max()), 1e-30)
+                assert err < 1e-3, f"HIP graph replay does not reproduce the eager step's gradients (rel. error {err:.2e})"
+            graph_checked.append(True)
             return graph.replay, "hip graph replay"
         except Exception as e:  # pragma: no cover - depends on the runtime
             print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -434,7 +443,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {N} random Gaussians ({sig_kind}), {H}x{W}, K={K}, max_point_per_bin={bins_kind}, "
                                f"fwd+bwd (grads to verts, sigmas, colors)",
-                   "launch": launch,
+                   "launch": launch, "graph_replay_gradients_checked_against_eager": bool(graph_checked),
                    "parallelism": "1 gpu" if world == 1 else f"pixel-row bands x{world}, all_gather(image)+all_reduce(grads)"},
     }
 
