@@ -1,0 +1,28 @@
+"""One case of tools/cliff_scan.py, stage by stage.  usage: python tools/cliff_one.py N size K dist rlo rhi"""
+import sys, torch
+sys.path.insert(0, ".")
+from voge_amd import scenes
+from voge_amd.Meshes import GaussianMeshes
+from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
+from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
+N, size, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+dist, rlo, rhi = float(sys.argv[4]), float(sys.argv[5]), float(sys.argv[6])
+dev = torch.device("cuda", 0)
+verts, sig, cols = scenes.random_gaussians(N, seed=0, r_lo=rlo, r_hi=rhi)
+gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
+colors = torch.from_numpy(cols).to(dev).requires_grad_(True)
+R, T = look_at_view_transform(dist=dist, elev=10.0, azim=70.0, device=dev)
+cams = PerspectiveCameras(focal_length=1.17 * size, principal_point=((size / 2.0, size / 2.0),), image_size=((size, size),), device=dev)
+renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=(size, size), max_assign=K, max_point_per_bin=-1)).to(dev)
+def ev():
+    e = torch.cuda.Event(enable_timing=True); e.record(); return e
+for rep in range(6):
+    for p in (gm.verts, gm.sigmas, colors):
+        p.grad = None
+    t = [ev()]
+    frag = renderer(gm, R=R, T=T); idx = frag.vert_index; t.append(ev())
+    img = to_white_background(frag, colors); t.append(ev())
+    loss = img.sum(); t.append(ev())
+    loss.backward(); t.append(ev())
+    torch.cuda.synchronize()
+    print(rep, [round(t[i].elapsed_time(t[i + 1]) * 1e3, 1) for i in range(4)], "us (trace, composite+shade, loss, backward)")
