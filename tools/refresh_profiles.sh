@@ -42,5 +42,5 @@ python bench.py | tail -1 > $OUT/${TAG}_bench_line.json
 python bench.py --no-graph --no-cpu-baseline --no-variants | tail -1 > $OUT/${TAG}_bench_line_eager.json
 python bench.py --config cfg4_200k_1024 --no-cpu-baseline --no-variants --steps 20 | tail -1 > $OUT/${TAG}_bench_line_cfg4.json
 python bench.py --config cfg5_shapefit_128 --no-variants --steps 50 | tail -1 > $OUT/${TAG}_bench_line_cfg5.json
-python bench.py --loop --steps 300 | tail -1 > $OUT/${TAG}_bench_line_cfg5_loop.json
+python bench.py --loop | tail -1 > $OUT/${TAG}_bench_line_cfg5_loop.json
 head -c 700 $OUT/${TAG}_bench_line.json; echo; grep -E "voge" $OUT/${TAG}_kernel_trace_summary.txt | cut -c1-60,90-150

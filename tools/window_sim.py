@@ -121,6 +121,27 @@ def simulate_tail(T, c_tail=100.0):
     return tot
 
 
+def simulate_sorted_columns(col1=29.0, row1=10.0):
+    """One column per lane (no own pair), the columns of a whole 4x3 group sorted by their trip counts before they are cut
+    into rounds of 64 lanes: a round then holds columns of similar windows.  Trips at one column x two rows per iteration
+    (col1 VALU) / one row x two columns (row1 VALU)."""
+    tot = 0.0
+    f1 = (front + 1) // 2; b1 = (behind + 1) // 2; rf1 = (rfront + 1) // 2; rb1 = (rbehind + 1) // 2
+    for y0 in range(0, H, GH):
+        for x0 in range(0, W, GW):
+            pix = [(y, x) for y in range(y0, min(y0 + GH, H)) for x in range(x0, min(x0 + GW, W))]
+            if sum(cnt[p] for p in pix) == 0:
+                continue
+            for fa, ba, cost in ((f1, b1, col1), (rf1, rb1, row1)):
+                f = np.concatenate([fa[p][: cnt[p]] for p in pix]); b = np.concatenate([ba[p][: cnt[p]] for p in pix])
+                o = np.argsort(-(f + b), kind="stable")
+                f, b = f[o], b[o]
+                for i in range(0, len(f), 64):
+                    tot += cost * (int(f[i:i + 64].max()) + int(b[i:i + 64].max()))
+    return tot
+
+
+print(f"columns of a group sorted by window, one per lane: {simulate_sorted_columns() / 1e6:7.2f} M window-loop VALU wave-instructions")
 for T in (1, 2, 3, 4, 6, 99):
     print(f"cut after {T:2d} iterations + cooperative tail: {simulate_tail(T) / 1e6:7.2f} M window-loop VALU wave-instructions")
 for order in ("stored", "count", "window"):
