@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--split-graph", action="store_true",
                     help="single GPU: use the multi-GPU launch scheme (forward graph / eager exchange / backward graph)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU oracle work for cpu_baseline")
+    ap.add_argument("--row-bands", action="store_true",
+                    help="multi-GPU: STRONG scaling -- ONE frame split into pixel-row bands over the ranks (rounds 1-2's scheme).  "
+                         "Default for --gpus N > 1: WEAK scaling -- a batch of N views of the same Gaussians (a multi-view training "
+                         "iteration), sharded view first on the stacked (view, row) axis: one whole view per rank")
     ap.add_argument("--loop", action="store_true",
                     help="BASELINE config 5 as a loop: a step = ONE ShapeFitting iteration (5 views batched, interpolate_attr + "
                          "get_silhouette MSE losses, backward, SGD step); implies --config cfg5_shapefit_128")
@@ -242,11 +246,25 @@ def main():
     _lib.load()
 
     N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[args.config]
-    R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
-    cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), device=dev)
+    # Multi-GPU, default: a batch of `world` views of the SAME Gaussians -- what a multi-view training iteration renders
+    # (ShapeFitting: 5 per step) -- sharded on the stacked (view, row) axis, view first (distributed.stacked_bounds): rank r
+    # renders whole view r with no per-band fixed cost paid twice; ONE all_gather assembles the batch of images, ONE
+    # all_reduce sums the Gaussians' gradients.  Per-GPU work is fixed as N grows: "scaling": "weak", value = all ranks' frames/s.
+    # --row-bands: ONE frame split into pixel-row bands (total work fixed: "strong").
+    by_views = world > 1 and not args.row_bands
+    if by_views:
+        Rv, Tv = look_at_view_transform(dist=[dd] * world, elev=[el] * world, azim=[az + 360.0 / world * r for r in range(world)], device=dev)
+        R, T = Rv[rank:rank + 1].contiguous(), Tv[rank:rank + 1].contiguous()
+    else:
+        R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
+    # (the cameras carry the view too: the stand-alone stage timings below build their rays from `cams` alone)
+    cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), R=R, T=T, device=dev)
     # row bands of the ranks: band r = rows [bounds[r], bounds[r + 1]); equal heights to start with
-    bands = {"bounds": [row_band(H, r, world)[0] for r in range(world)] + [H]} if world > 1 else None
-    rows = (bands["bounds"][rank], bands["bounds"][rank + 1]) if world > 1 else None
+    bands = {"bounds": [row_band(H, r, world)[0] for r in range(world)] + [H]} if (world > 1 and not by_views) else None
+    rows = (bands["bounds"][rank], bands["bounds"][rank + 1]) if bands is not None else None
+    # what the gather sees: the rank's rows of the stacked image (views mode: view r = rows [r H, (r + 1) H) of world x H)
+    H_all = world * H if by_views else H
+    stack_bounds = [r * H for r in range(world + 1)] if by_views else None
 
     renderer_of = [None]      # (the renderer of the frame made last)
 
@@ -381,7 +399,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             rows = (bands["bounds"][rank], bands["bounds"][rank + 1])
-        gb = None if bands is None else bands["bounds"]
+        gb = stack_bounds if by_views else (None if bands is None else bands["bounds"])
         run, launch = None, "eager"
         if not args.no_graph:
             try:
@@ -397,7 +415,7 @@ def main():
 
                 def run_split():
                     g_fwd.replay()
-                    finish = gather_rows_async(band_static.detach(), H, bounds=gb)   # all_gather starts (no-op on one GPU) ...
+                    finish = gather_rows_async(band_static.detach(), H_all, bounds=gb)   # all_gather starts (no-op on one GPU) ...
                     g_bwd.replay()                                          # ... and overlaps the band's backward
                     flat.allreduce()                                        # one eager all_reduce, in place
                     return finish().sum()                                   # the full-image loss every rank holds
@@ -412,9 +430,9 @@ def main():
             def run():
                 flat.zero()
                 band = fwd()
-                img = gather_rows(band, H, bounds=gb)
-                r0, r1 = rows if rows is not None else (0, H)
-                img[:, r0:r1].sum().backward()      # each rank owns the loss of its band; grads are summed below
+                img = gather_rows(band, H_all, bounds=gb)
+                r0, r1 = (rank * H, (rank + 1) * H) if by_views else (rows if rows is not None else (0, H))
+                img[:, r0:r1].sum().backward()      # each rank owns the loss of its band / view; grads are summed below
                 flat.allreduce()
                 return img
 
@@ -432,22 +450,25 @@ def main():
         torch.cuda.synchronize()
     dt = timed(run, args.steps, args.warmup)
     ms = dt / args.steps * 1e3
-    fps = args.steps / dt
+    fps = (world if by_views else 1) * args.steps / dt      # (views mode: every step renders `world` frames, one per rank)
 
     sig_kind = "[N,3,3] L L^T sigmas" if args.anisotropic else "scalar sigmas"
     bins_kind = "None (default)" if args.default_bins else "-1"
     result = {
         "metric": "forward+backward frames/sec at 512^2, 50k Gaussians; ray-trace HBM GB/s vs peak",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak" if by_views else "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: {N} random Gaussians ({sig_kind}), {H}x{W}, K={K}, max_point_per_bin={bins_kind}, "
                                f"fwd+bwd (grads to verts, sigmas, colors)",
                    "launch": launch, "graph_replay_gradients_checked_against_eager": bool(graph_checked),
-                   "parallelism": "1 gpu" if world == 1 else f"pixel-row bands x{world}, all_gather(image)+all_reduce(grads)"},
+                   "parallelism": ("1 gpu" if world == 1 else
+                                   f"a batch of {world} views on the stacked (view, row) axis, view first: one whole view per rank; "
+                                   f"all_gather(images) + all_reduce(gradients); a step = {world} frames" if by_views else
+                                   f"pixel-row bands x{world}, all_gather(image)+all_reduce(grads)")},
     }
 
-    if world > 1:
+    if world > 1 and bands is not None:
         result["config"]["bands"] = list(bands["bounds"])      # rows [b[r], b[r+1]) of rank r, after the measured balancing
         result["band_balance"] = balance_log                      # (setup, untimed) what every round measured
     lib = _lib.load()
@@ -665,7 +686,7 @@ def main():
         # the dominant kernel on rank 0's band of rows (same entry point, shorter image), timed live
         with torch.no_grad():
             from voge_amd.cameras import pixel_rays
-            r0, r1 = rows
+            r0, r1 = rows if rows is not None else (0, H)       # (views mode: rank 0's whole view)
             rays_b, origin = pixel_rays(cams, (H, W), rows=rows)
             cones = ops.cones_of(rays_b, 1, r1 - r0, W)
             h = r1 - r0
@@ -687,7 +708,7 @@ def main():
             nb = stage_bytes(N, h * W, K, iso=iso)["trace_fwd"]
             t_ms, _ = rotating(mk, call, nb)
             a = round(nb / 1e9 / (t_ms / 1e3), 1)
-            result["roofline"] = {"kernel": TRACE_KERNELS + f" on rank 0's band of rows [{r0}, {r1})",
+            result["roofline"] = {"kernel": TRACE_KERNELS + (" on rank 0's view" if by_views else f" on rank 0's band of rows [{r0}, {r1})"),
                                   "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                                   "algorithmic_bytes": nb, "avg_launch_ms": round(t_ms, 4)}

@@ -1059,3 +1059,29 @@ def test_renderer_edge_shapes(hip_lib, N, H, W, K, B, aniso, fused):
         assert torch.isfinite(gm.verts.grad).all() and torch.isfinite(gm.sigmas.grad).all()
     else:
         assert (img == 1).all() and (frag.valid_num == 0).all()
+
+
+@pytest.mark.parametrize("mode", ["views", "row_bands"])
+def test_bench_two_ranks_on_one_gpu(hip_lib, mode):
+    """bench.py's N > 1 path end to end (its own rank spawning, split HIP graphs, overlapped all_gather, flat all_reduce)
+    with both ranks on this one GPU through gloo: the line it prints carries the contract's fields for the mode."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VOGE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--balance-rounds", "1"]
+    if mode == "row_bands":
+        cmd.append("--row-bands")
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0 and line["unit"] == "frames/s"
+    assert line["scaling"] == ("weak" if mode == "views" else "strong")
+    # a step is 2 frames (one view per rank) or 1 frame (two row bands)
+    frames = 2 if mode == "views" else 1
+    assert abs(line["value"] - frames * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    assert ("bands" in line["config"]) == (mode == "row_bands")
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
