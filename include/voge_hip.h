@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOGE_ABI_VERSION 3
+#define VOGE_ABI_VERSION 4
 
 #define VOGE_ERR_BAD_ARG (-1)        /* null pointer / non-positive size */
 #define VOGE_ERR_WORKSPACE (-2)      /* workspace smaller than voge_trace_workspace_bytes() */
@@ -53,6 +53,15 @@ const char *voge_error_string(int code);
  * aligned (any torch allocation is).
  */
 size_t voge_trace_workspace_bytes(int B, int N, int H, int W);
+
+/*
+ * Diagnostic: how much of the workspace's candidate-list POOL the last forward trace that ran on `workspace` (same
+ * B, N, H, W) used.  The pool holds the lists of image quads (16x16 px) with more candidates than the in-LDS sort
+ * takes (a small object behind a few dozen pixels); *used > *capacity means it ran out and those quads' tiles fell
+ * back to streaming every Gaussian (slow, still exact).  Synchronous (copies one int from the device).  No reference
+ * counterpart: the reference's coarse stage drops points when a bin overflows (rasterize_coarse.cu).
+ */
+int voge_trace_pool_usage(const void *workspace, int B, int N, int H, int W, int *used, int *capacity);
 
 /*
  * Fine ray trace forward, "all Gaussians are candidates" form.

@@ -350,3 +350,36 @@ def test_small_object_segment_overflow_is_handled_per_slice(hip_lib, N, extent, 
     got_gen = [n(x) for x in ops.ray_trace_fine(t(mus).reshape(-1, 3), t(isg).reshape(-1, 3, 3), t(rays), None, thr_act, 10, K)]
     for x, y in zip(got_iso, got_gen):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("N,extent,r_lo,r_hi,K,expect", [
+    (40000, 0.30, 0.006, 0.012, 12, "pooled"),      # 40 000 Gaussians behind ~22 pixels: every quad of the object is long
+    (60000, 0.25, 0.004, 0.008, 40, "pooled"),      # denser still, K = 40 (full lists in the middle, short ones at the rim)
+    (32000, 0.5, 0.6, 0.7, 8, "exhausted")])        # huge footprints: every Gaussian in every quad -> the pool runs out
+def test_quads_with_more_candidates_than_the_lds_sort_use_pooled_lists(hip_lib, N, extent, r_lo, r_hi, K, expect):
+    """A quad (16x16 pixels) with more than kQCap = 3008 candidates used to send its four tiles to the stream-everything
+    fallback (trace 0.1 -> 3 ms at 50k Gaussians seen from 4x farther than cfg3).  binB now counts and
+    scatters such a quad's candidates bucket by bucket into per-tile lists taken from a pool (trace_bin.h: long path);
+    only an exhausted pool still falls back.  Either way the result equals the brute-force oracle."""
+    from voge_amd import ops
+    rng = np.random.default_rng(N)
+    verts = rng.uniform(-extent, extent, (N, 3)).astype(np.float32)
+    r = rng.uniform(r_lo, r_hi, N)
+    sig = (1.0 / (r * r / (2 * np.log(1 / 0.6)))).astype(np.float32)
+    H = W = 96
+    R, T = camera_np.look_at_view_transform(3.0, 10.0, 20.0)
+    rays, origin = camera_np.pixel_rays(R, T, 110.0, (W / 2.0, H / 2.0), (H, W))
+    mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = (2 * camera_np.expand_sigma(sig)).astype(np.float32)[None]
+    thr_act = oracle.thr_act_of(0.01)
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    assert (ref[0][..., 0] >= 0).mean() > 0.02
+    a = np.ascontiguousarray(isg[..., 0, 0])
+    got_iso = [n(x) for x in ops._RayTraceVoGEIso.apply(t(mus.reshape(-1, 3)), t(a.reshape(-1)), t(rays), None, thr_act, K)]
+    used, cap = ops.trace_pool_usage("cuda:0", 1, N, H, W)
+    assert used > 0, "no quad took the long path: the scene does not test it"
+    assert (used <= cap) == (expect == "pooled"), (used, cap)
+    compare_trace(got_iso, ref, thr_act, min_match=0.998, label=f"long quads N={N} iso")
+    got_gen = [n(x) for x in ops.ray_trace_fine(t(mus).reshape(-1, 3), t(isg).reshape(-1, 3, 3), t(rays), None, thr_act, 10, K)]
+    for x, y in zip(got_iso, got_gen):
+        assert np.array_equal(x, y)

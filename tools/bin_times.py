@@ -11,6 +11,8 @@ from voge_amd.Meshes import GaussianMeshes
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_50k_512"
 N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[name]
 verts, sig, colors = scenes.random_gaussians(N, seed=0)
+import os
+dd = float(os.environ.get("DIST", dd))      # (DIST=16: the small-object case of tools/cliff_scan.py -- binB's long path)
 dev = torch.device("cuda", 0)
 gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
 R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)

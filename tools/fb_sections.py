@@ -17,7 +17,8 @@ from voge_amd.Meshes import GaussianMeshes  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_50k_512"
 pattern = sys.argv[2] if len(sys.argv) > 2 else "white"
 N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[name]
-verts, sig, colors = scenes.random_gaussians(N, seed=0)
+import os
+verts, sig, colors = scenes.random_gaussians(N, seed=0, anisotropic=bool(os.environ.get("ANISO")))      # ANISO=1: [N,3,3] sigmas
 dev = torch.device("cuda", 0)
 gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
 cols = torch.from_numpy(colors).to(dev).requires_grad_(True)

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VOGE_HIP_LIB points at another build of the same ABI (kernel tuning variants)
 LIB_PATH = os.environ.get("VOGE_HIP_LIB") or os.path.join(_HERE, "libvoge_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_void_p = ctypes.c_void_p
 _c_int = ctypes.c_int
@@ -22,6 +22,7 @@ SIGNATURES = {
     "voge_abi_version": (_c_int, []),
     "voge_error_string": (ctypes.c_char_p, [_c_int]),
     "voge_trace_workspace_bytes": (_c_size_t, [_c_int] * 4),
+    "voge_trace_pool_usage": (_c_int, [_c_void_p] + [_c_int] * 4 + [_c_void_p] * 2),
     "voge_trace_topk_fwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_float, _c_void_p, _c_size_t]
                             + [_c_void_p] * 6),
     "voge_trace_topk_list_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 9 + [_c_float] + [_c_void_p] * 6),

@@ -143,10 +143,12 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
             const float *__restrict__ mus, const float *__restrict__ isg, const float *__restrict__ cam_fwd, const int N,
             const float thr_act, const IsoView view, float4 *__restrict__ cull, float4 *__restrict__ ms,
             int *__restrict__ seg_count /* [B*nst][kParts] */, int32_t *__restrict__ seg_id /* [B*nst][kParts][kSegCap] */,
-            float4 *__restrict__ seg_rec /* the same shape: the entries' cull records */) {
+            float4 *__restrict__ seg_rec /* the same shape: the entries' cull records */,
+            int *__restrict__ pool_top /* binB's list pool: reset here, one launch ahead of its first use */) {
   __shared__ BinALds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int region = blockIdx.x / kParts, part = blockIdx.x - region * kParts, b = blockIdx.y;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *pool_top = 0;
   const int rx = region % nst0x, ry = region / nst0x;
   const int nst = nstx * nsty;
   if (tid < kCh * kCh) L.base[tid] = 0;
@@ -320,10 +322,14 @@ constexpr int kQCap = 3008;         // entries of a quad's ordered list (LDS sor
 constexpr int kQRec = kQCap / 2;       // ... whose cull records are kept in LDS for the tile filters (the rest: gathered)
 constexpr int kBuckets = 512;       // depth buckets of the counting sort
 constexpr int kTilesPerQuad = 4;
+// order[].x of a tile whose list lives in the POOL (a quad with more than kQCap candidates: binB's long path) carries this
+// flag; the list then starts at pool entry tl_off[tile] and may be longer than kTileCap.
+constexpr int kPoolFlag = 1 << 30;
 struct BinLds {
   union {
     uint64_t keys[kQCap];     // (ord(depth key) << 32 | flag << 31 | id) of the quad's candidates, unordered
     float4 rec[kQRec];        // after the sort: cull records of the ordered list's first kQRec entries
+    int hist4[kTilesPerQuad][kBuckets];      // long path: per-tile bucket counters / cursors
   };
   uint32_t sorted[kQCap];     // (flag << 31 | id), front to back (an entry's depth key is recomputed from its record)
   float red[4 * 8];
@@ -335,6 +341,8 @@ struct BinLds {
   int count;
   int nflag;      // entries with an ellipsoid record
   int spill;      // a tile list overflowed kTileCap: the quad's ordered list goes to memory as its fallback
+  float tc[kTilesPerQuad][8];      // long path: the four tile cones (ax, ay, az, cs, sn, ok)
+  int toff[kTilesPerQuad];         // long path: where each tile's list starts in the pool (-1: the pool is exhausted)
 };
 
 #ifndef VOGE_ELL_KEY
@@ -349,6 +357,8 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
             int *__restrict__ q_count, int32_t *__restrict__ q_id, float *__restrict__ q_lb,
             int *__restrict__ tl_count, int32_t *__restrict__ tl_id, float *__restrict__ tl_lb,
             int2 *__restrict__ order /* [nbin_total][16]: (tile, list length) by launch rank */,
+            int *__restrict__ pool_top, const int pool_cap, int32_t *__restrict__ pool_id, float *__restrict__ pool_lb,
+            int *__restrict__ tl_off,
             const int K, int32_t *__restrict__ out_idx, float *__restrict__ out_len, float *__restrict__ out_act,
             float *__restrict__ out_dsd, int32_t *__restrict__ out_cnt, float *__restrict__ out_weight,
             int64_t *__restrict__ out_valid) {
@@ -458,65 +468,91 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   float klo = INFINITY, khi = -INFINITY;   // extrema of the finite order keys of this thread's entries
   bool any_el = false;
   constexpr int kGU = 8;      // gathers in flight per thread
-  for (int base = 0; base < n_src; base += kQT * kGU) {
-    int gid[kGU];
-    float4 c[kGU];
+  // One pass over the quad's sources -- the super-tile's segments, or whole slices where a segment overflowed -- with the
+  // quad-cone test, kGU entries per thread at a time; `sink(ids, records, kept, has ellipsoid, ellipsoid key)` sees every
+  // batch, wave-uniformly.
+  auto stream_sources = [&](auto &&sink) {
+    for (int base = 0; base < n_src; base += kQT * kGU) {
+      int gid[kGU];
+      float4 c[kGU];
 #pragma unroll
-    for (int j = 0; j < kGU; ++j) {     // ids and records are two streams: one round trip, nothing dependent
-      const int i = base + j * kQT + tid;
-      gid[j] = -1;
-      c[j] = make_float4(0.f, 0.f, 0.f, -1.f);
-      if (i < n_src) {
+      for (int j = 0; j < kGU; ++j) {     // ids and records are two streams: one round trip, nothing dependent
+        // (branch-free: exactly one id load and one record load per entry, whatever its source)
+        const int i = base + j * kQT + tid;
+        const bool in = i < n_src;
         int p = 0;
 #pragma unroll
-        for (int q = 1; q < kParts; ++q) p += (i >= L.segn[q]) ? 1 : 0;
-        const int k = i - L.segn[p];
-        if ((ovf >> p) & 1u) {      // (rare) the slice itself, record by record
-          const int g = slice_gauss(p, k, N);
-          if (g < N) { gid[j] = g; c[j] = cullb[g]; }
-        } else {
-          const int o = p * kSegCap + k;
-          gid[j] = segs[o];
-          c[j] = segr[o];
+        for (int q = 1; q < kParts; ++q) p += (in && i >= L.segn[q]) ? 1 : 0;
+        const int k = in ? i - L.segn[p] : 0;
+        const bool whole = ((ovf >> p) & 1u) != 0u;      // (rare) the slice itself, record by record
+        const int g = whole ? slice_gauss(p, k, N) : -1;
+        const bool gok = in && (!whole || g < N);
+        const int o = p * kSegCap + (whole ? 0 : k);
+        const int sid = segs[o];
+        const float4 *src = (whole && gok) ? cullb + g : segr + o;
+        const float4 rec = *src;
+        gid[j] = gok ? (whole ? g : sid) : -1;
+        c[j] = gok ? rec : make_float4(0.f, 0.f, 0.f, -1.f);
+      }
+      bool kp[kGU], el[kGU];
+      float gkey[kGU];
+#pragma unroll
+      for (int j = 0; j < kGU; ++j) {
+        kp[j] = cone_keep(c[j], qcone);         // (padding: reach -1, never kept)
+        el[j] = kp[j] && cull_has_ell(c[j]);
+        gkey[j] = 0.0f;
+        if (__any(el[j])) {
+          if (el[j]) {
+            const float4 e0 = ellb[2 * (size_t)gid[j]], e1 = ellb[2 * (size_t)gid[j] + 1];
+            kp[j] = cone_keep_ell(c[j], e0, e1, qcone);
+            el[j] = kp[j];
+            // order key: VOGE_ELL_KEY 0 = the centre's depth along the axis, 1 = the entry's own lower bound of len
+            const float pa = fmaf(c[j].z, qcone.az, fmaf(c[j].y, qcone.ay, c[j].x * qcone.ax));
+#if VOGE_ELL_KEY == 1
+            gkey[j] = pa - ell_support(e0, e1, qcone.ax, qcone.ay, qcone.az) + 0.0f;
+#else
+            gkey[j] = pa + 0.0f;
+#endif
+          }
         }
       }
+      sink(gid, c, kp, el, gkey);
+    }
+  };
+  // Slots of a batch's survivors in the workgroup's compacted order: ONE LDS atomic per wave and batch (round 3: one per
+  // wave and ENTRY -- eight dependent atomic + broadcast chains per batch were most of this loop's time).
+  auto batch_slots = [&](const bool (&kp)[kGU], int (&slot)[kGU]) {
+    unsigned long long m[kGU];
+    int cw = 0;
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) { m[j] = __ballot(kp[j]); cw += __popcll(m[j]); }
+    int start = 0;
+    if (cw > 0) {      // uniform
+      if (lane == 0) start = atomicAdd(&L.count, cw);
+      start = __builtin_amdgcn_readfirstlane(start);
     }
 #pragma unroll
     for (int j = 0; j < kGU; ++j) {
-      if (base + j * kQT >= n_src) break;     // uniform
-      bool kp = cone_keep(c[j], qcone);         // (padding: reach -1, never kept)
-      bool el = kp && cull_has_ell(c[j]);
-      float gkey = 0.0f;
-      if (__any(el)) {
-        if (el) {
-          const float4 e0 = ellb[2 * (size_t)gid[j]], e1 = ellb[2 * (size_t)gid[j] + 1];
-          kp = cone_keep_ell(c[j], e0, e1, qcone);
-          el = kp;
-          // order key: VOGE_ELL_KEY 0 = the centre's depth along the axis, 1 = the entry's own lower bound of len
-          const float pa = fmaf(c[j].z, qcone.az, fmaf(c[j].y, qcone.ay, c[j].x * qcone.ax));
-#if VOGE_ELL_KEY == 1
-          gkey = pa - ell_support(e0, e1, qcone.ax, qcone.ay, qcone.az) + 0.0f;
-#else
-          gkey = pa + 0.0f;
-#endif
-        }
-      }
-      const unsigned long long m = __ballot(kp);
-      if (m == 0ull) continue;     // uniform
-      int start = 0;
-      if (lane == 0) start = atomicAdd(&L.count, __popcll(m));
-      start = __shfl(start, 0, 64);
-      if (kp) {
-        const int slot = start + __popcll(m & ((1ull << lane) - 1ull));
-        if (!el && c[j].w < 3e38f) rmax = fmaxf(rmax, c[j].w);
+      slot[j] = start + __popcll(m[j] & ((1ull << lane) - 1ull));
+      start += __popcll(m[j]);
+    }
+  };
+  stream_sources([&](const int (&g)[kGU], const float4 (&cj)[kGU], const bool (&kp)[kGU], const bool (&el)[kGU],
+                     const float (&gkey)[kGU]) {
+    int slot[kGU];
+    batch_slots(kp, slot);
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      if (kp[j]) {
+        if (!el[j] && cj[j].w < 3e38f) rmax = fmaxf(rmax, cj[j].w);
         // bit 31 of the id word: the entry has an ellipsoid record (its len bound is its own)
-        const float kv = el ? gkey : depth_key(c[j], qcone);
+        const float kv = el[j] ? gkey[j] : depth_key(cj[j], qcone);
         if (kv > -INFINITY) { klo = fminf(klo, kv); khi = fmaxf(khi, kv); }
-        if (slot < kQCap) L.keys[slot] = ((uint64_t)f2ord(kv) << 32) | (uint32_t)gid[j] | (el ? 0x80000000u : 0u);
-        any_el = any_el || el;
+        if (slot[j] < kQCap) L.keys[slot[j]] = ((uint64_t)f2ord(kv) << 32) | (uint32_t)g[j] | (el[j] ? 0x80000000u : 0u);
+        any_el = any_el || el[j];
       }
     }
-  }
+  });
   BIN_TS(1, 1);
   if (__any(any_el) && lane == 0) L.nflag = 1;
   // ---- order the survivors front to back: counting sort on the depth key.  Exact order is not needed for
@@ -527,44 +563,218 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   for (int i = tid; i < kBuckets; i += kQT) { L.hist[i] = 0; L.bmin[i] = f2ord(INFINITY); }
   __syncthreads();
   const int total = L.count;
-  if (n_src < 0 || total > kQCap) {
-    // a segment or the quad's list overflowed: the sweep walks every Gaussian of the batch element for these tiles
-    if (tid == 0) q_count[quad] = -1;
-    if (lane == 0) {
-      if (tile_ok) tl_count[tile] = -1;
-      my_order[wave] = make_int2(tile_ok ? tile : -1, -1);
-    }
-    return;
-  }
   hi = fmaxf(fmaxf(L.red[0], L.red[8]), fmaxf(L.red[16], L.red[24]));
   lo = fminf(fminf(L.red[1], L.red[9]), fminf(L.red[17], L.red[25]));
   rm = fmaxf(fmaxf(L.red[2], L.red[10]), fmaxf(L.red[18], L.red[26]));
   const float span = fmaxf(hi - lo, 1e-20f);
   const float scale = (float)(kBuckets - 2) / span;
   const bool flagged = L.nflag != 0;     // any entry with an ellipsoid record (workgroup-uniform)
-  auto bucket_of = [&](const uint64_t k) {
-    const float v = ord2f((uint32_t)(k >> 32));
+  auto bucket_of_key = [&](const float v) {
     return (v > -INFINITY) ? 1 + min(kBuckets - 2, max(0, (int)((v - lo) * scale))) : 0;
   };
+  auto bucket_of = [&](const uint64_t k) { return bucket_of_key(ord2f((uint32_t)(k >> 32))); };
+  // own lower bound of len of an entry with an ellipsoid record: the peak point x = len d of a hit lies in the
+  // ellipsoid, so len (d.a) = x.a >= t = mu.a - h(a), and d.a is in [cs, 1]
+  auto own_bound = [&](const size_t g) {
+    const float4 cj = cullb[g], e0 = ellb[2 * g], e1 = ellb[2 * g + 1];
+    float bnd = -INFINITY;
+    if (qcone.ok) {
+      const float pa = fmaf(cj.z, qcone.az, fmaf(cj.y, qcone.ay, cj.x * qcone.ax));
+      const float nm1 = fabsf(cj.x) + fabsf(cj.y) + fabsf(cj.z);
+      const float t = pa - ell_support(e0, e1, qcone.ax, qcone.ay, qcone.az) - 4e-6f * nm1;
+      bnd = (t >= 0.0f) ? t : t / qcone.cs;
+      bnd = bnd - 1e-5f * fabsf(bnd) - 1e-30f;
+    }
+    return bnd;
+  };
+  // Suffix minimum over the buckets of the flagged entries' own bounds (thread <-> two buckets).  (barriers inside)
+  auto bmin_suffix = [&]() {
+    uint32_t m4[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) m4[q] = L.bmin[2 * tid + q];
+    m4[0] = min(m4[0], m4[1]);
+    uint32_t x = m4[0];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_down(x, o, 64);
+      if (lane + o < 64) x = min(x, y);
+    }
+    if (lane == 0) L.wsum[4 + wave] = (int)x;
+    __syncthreads();
+    // x = minimum from this thread's first bucket to the end of the wave; beyond: the later waves' minima
+    uint32_t later = 0xffffffffu;      // minimum over the lanes / waves behind this thread
+    {
+      const uint32_t nxt = __shfl_down(x, 1, 64);
+      later = (lane < 63) ? nxt : 0xffffffffu;
+      for (int w = wave + 1; w < 4; ++w) later = min(later, (uint32_t)L.wsum[4 + w]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) L.bmin[2 * tid + q] = min(m4[q], later);
+  };
+  // the len bound of an entry from its depth key (its bucket's lower edge, see below)
+  const float slack = 1.13f * rm * (1.0f + 1e-5f);
+  const float inv_scale = span / (float)(kBuckets - 2);
+  auto len_bound_key = [&](const float v) {
+    float edge = -INFINITY;
+    int qb = 0;
+    if (v > -INFINITY) {
+      const int q = min(kBuckets - 2, max(0, (int)((v - lo) * scale)));
+      edge = fminf(v, lo + (float)q * inv_scale - 4e-6f * span);
+      qb = 1 + q;
+    }
+    // sphere-only entries: bucket edge minus the largest sphere reach; entries with an ellipsoid record: the
+    // smallest own bound from this bucket on.  Both are monotone along the list.
+    const float lb_sphere = (edge > -INFINITY) ? edge - slack - 1e-5f * fabsf(edge) - 1e-30f : -INFINITY;
+    return flagged ? fminf(lb_sphere, ord2f(L.bmin[qb])) : lb_sphere;
+  };
+  if (total > kQCap) {
+    // ---- LONG PATH: more candidates than the LDS sort holds (tens of thousands of Gaussians behind a few dozen pixels:
+    // a small object, a zoomed-out view).  Rounds 1-3 sent such a quad's tiles to the stream-everything fallback (trace
+    // 0.1 -> 3 ms).  Now the sources are streamed once more to put the quad's survivors into a POOL
+    // (their number is known from pass one); two walks over the survivors then count, per tile and depth bucket, the
+    // candidates that pass the tile's cone (and collect the flagged entries' bounds), and scatter them -- bucket by
+    // bucket, i.e. front to back -- into per-tile lists of exactly the needed length, also from the pool.  Inside a
+    // bucket the order is arbitrary, as in the LDS sort; every entry carries its bucket's bound.  Only an exhausted
+    // pool still falls back.
+    __syncthreads();                                   // (everyone is done with L.red / L.count of pass one)
+    for (int i = tid; i < kTilesPerQuad * kBuckets; i += kQT) (&L.hist4[0][0])[i] = 0;
+    if (lane == 0) {
+      L.tc[wave][0] = tcone.ax; L.tc[wave][1] = tcone.ay; L.tc[wave][2] = tcone.az; L.tc[wave][3] = tcone.cs;
+      L.tc[wave][4] = tcone.sn; L.tc[wave][5] = (tcone.ok || !tile_ok) ? 1.0f : 0.0f;      // (a tile outside the image keeps nothing)
+      L.tc[wave][6] = tile_ok ? 1.0f : 0.0f;
+    }
+    if (tid == 0) {
+      // the quad's survivors -- (id | flag, depth key) -- go to the pool first: the sources (up to N entries where
+      // segments overflowed) are streamed ONCE more, everything after that walks the `total` survivors only
+      int at = atomicAdd(pool_top, total);
+      if (total > pool_cap || at > pool_cap - total) at = -1;      // exhausted (the counter may run on: only compared)
+      L.toff[0] = at;
+      L.count = 0;
+    }
+    __syncthreads();
+    const int surv_at = L.toff[0];
+    bool pooled = surv_at >= 0;
+    int tile_n[kTilesPerQuad] = {0, 0, 0, 0};
+    if (pooled) {
+      int32_t *sv_id = pool_id + surv_at;
+      float *sv_key = pool_lb + surv_at;
+      stream_sources([&](const int (&g)[kGU], const float4 (&cj)[kGU], const bool (&kp)[kGU], const bool (&el)[kGU],
+                         const float (&gkey)[kGU]) {
+        int slot[kGU];
+        batch_slots(kp, slot);
+#pragma unroll
+        for (int j = 0; j < kGU; ++j) {
+          if (kp[j]) {      // (the same tests on the same data as pass one: slot < total)
+            sv_id[slot[j]] = (int32_t)((uint32_t)g[j] | (el[j] ? 0x80000000u : 0u));
+            sv_key[slot[j]] = el[j] ? gkey[j] : depth_key(cj[j], qcone);
+          }
+        }
+      });
+      __threadfence_block();
+      __syncthreads();
+      BIN_TS(1, 2);
+      // (the cones stay in LDS -- broadcast reads -- so that this rare path does not raise the kernel's register count)
+      auto tile_mask = [&](const size_t g, const float4 cj, const bool el) {
+        unsigned mk = 0u;
+#pragma unroll 1
+        for (int t = 0; t < kTilesPerQuad; ++t) {
+          Cone tk;
+          tk.ax = L.tc[t][0]; tk.ay = L.tc[t][1]; tk.az = L.tc[t][2]; tk.cs = L.tc[t][3]; tk.sn = L.tc[t][4];
+          tk.ok = L.tc[t][5] != 0.0f;
+          bool k2 = (L.tc[t][6] != 0.0f) && cone_keep(cj, tk);
+          if (k2 && el) k2 = cone_keep_ell(cj, ellb[2 * g], ellb[2 * g + 1], tk);
+          mk |= k2 ? (1u << t) : 0u;
+        }
+        return mk;
+      };
+      // count, per tile and depth bucket, the survivors of the tile's cone; the flagged entries' own bounds
+      for (int i = tid; i < total; i += kQT) {
+        const uint32_t word = (uint32_t)sv_id[i];
+        const size_t g = word & 0x7fffffffu;
+        const bool el = (word & 0x80000000u) != 0u;
+        const int q = bucket_of_key(sv_key[i]);
+        const unsigned mk = tile_mask(g, cullb[g], el);
+#pragma unroll
+        for (int t = 0; t < kTilesPerQuad; ++t)
+          if ((mk >> t) & 1u) atomicAdd(&L.hist4[t][q], 1);
+        if (el) atomicMin(&L.bmin[q], f2ord(own_bound(g)));
+      }
+      __syncthreads();
+      // exclusive scans of the four tiles' bucket counters (two buckets per thread, as below); totals -> tile_n
+      for (int t = 0; t < kTilesPerQuad; ++t) {
+        const int2 v = *reinterpret_cast<const int2 *>(&L.hist4[t][2 * tid]);
+        const int s4 = v.x + v.y;
+        int x = s4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int y = __shfl_up(x, o, 64);
+          if (lane >= o) x += y;
+        }
+        if (lane == 63) L.wsum[wave] = x;
+        __syncthreads();
+        int off = x - s4;
+        for (int w = 0; w < wave; ++w) off += L.wsum[w];
+        tile_n[t] = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+        *reinterpret_cast<int2 *>(&L.hist4[t][2 * tid]) = make_int2(off, off + v.x);
+        __syncthreads();
+      }
+      if (flagged) { bmin_suffix(); }
+      if (tid == 0) {
+        const int need = tile_n[0] + tile_n[1] + tile_n[2] + tile_n[3];
+        int at = (need > 0) ? atomicAdd(pool_top, need) : 0;
+        if (need > pool_cap || at > pool_cap - need) at = -1;
+#pragma unroll
+        for (int t = 0; t < kTilesPerQuad; ++t) { L.toff[t] = at; if (at >= 0) at += tile_n[t]; }
+      }
+      __syncthreads();
+      pooled = L.toff[0] >= 0;
+      BIN_TS(1, 3);
+      if (pooled) {      // scatter: bucket by bucket, i.e. front to back; inside a bucket in whatever order the atomics give
+        for (int i = tid; i < total; i += kQT) {
+          const uint32_t word = (uint32_t)sv_id[i];
+          const size_t g = word & 0x7fffffffu;
+          const bool el = (word & 0x80000000u) != 0u;
+          const float kv = sv_key[i];
+          const int q = bucket_of_key(kv);
+          const unsigned mk = tile_mask(g, cullb[g], el);
+          if (mk == 0u) continue;
+          const float lbv = len_bound_key(kv);
+#pragma unroll
+          for (int t = 0; t < kTilesPerQuad; ++t) {
+            if ((mk >> t) & 1u) {
+              const size_t pos = (size_t)L.toff[t] + (size_t)atomicAdd(&L.hist4[t][q], 1);
+              pool_id[pos] = (int32_t)g;
+              pool_lb[pos] = lbv;
+            }
+          }
+        }
+      }
+    }
+    if (lane == 0 && tile_ok) {
+      tl_count[tile] = pooled ? tile_n[wave] : -1;
+      tl_off[tile] = pooled ? L.toff[wave] : -1;
+    }
+    __syncthreads();
+    // launch slots: longest list first (an overflowed one counts as longest), tiles outside the image last
+    if (lane == 0) L.wsum[wave] = tile_ok ? (pooled ? tile_n[wave] : 0x7fffffff) : -1;
+    __syncthreads();
+    if (lane == 0) {
+      const int mine = L.wsum[wave];
+      int slot = 0;
+      for (int w = 0; w < kTilesPerQuad; ++w) {
+        const int o = L.wsum[w];
+        slot += (o > mine || (o == mine && w < wave)) ? 1 : 0;
+      }
+      my_order[slot] = make_int2(tile_ok ? (pooled ? (tile | kPoolFlag) : tile) : -1, pooled ? mine : -1);
+    }
+    if (tid == 0) q_count[quad] = pooled ? -2 : -1;
+    BIN_TS(1, 4);
+  } else {
   for (int i = tid; i < total; i += kQT) {
     const uint64_t kk = L.keys[i];
     const int q = bucket_of(kk);
     atomicAdd(&L.hist[q], 1);
-    if ((uint32_t)kk & 0x80000000u) {
-      // own lower bound of len: the peak point x = len d of a hit lies in the ellipsoid, so
-      // len (d.a) = x.a >= t = mu.a - h(a), and d.a is in [cs, 1]
-      const size_t g = (uint32_t)kk & 0x7fffffffu;
-      const float4 cj = cullb[g], e0 = ellb[2 * g], e1 = ellb[2 * g + 1];
-      float bnd = -INFINITY;
-      if (qcone.ok) {
-        const float pa = fmaf(cj.z, qcone.az, fmaf(cj.y, qcone.ay, cj.x * qcone.ax));
-        const float nm1 = fabsf(cj.x) + fabsf(cj.y) + fabsf(cj.z);
-        const float t = pa - ell_support(e0, e1, qcone.ax, qcone.ay, qcone.az) - 4e-6f * nm1;
-        bnd = (t >= 0.0f) ? t : t / qcone.cs;
-        bnd = bnd - 1e-5f * fabsf(bnd) - 1e-30f;
-      }
-      atomicMin(&L.bmin[q], f2ord(bnd));
-    }
+    if ((uint32_t)kk & 0x80000000u) atomicMin(&L.bmin[q], f2ord(own_bound((size_t)((uint32_t)kk & 0x7fffffffu))));
   }
   __syncthreads();
   // exclusive scan of the kBuckets counters: two consecutive buckets per thread, wave scan, wave offsets
@@ -597,27 +807,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   // Suffix minimum over the buckets of the flagged entries' own bounds (thread <-> two buckets).
   if (flagged) {
     __syncthreads();
-    uint32_t m4[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) m4[q] = L.bmin[2 * tid + q];
-    m4[0] = min(m4[0], m4[1]);
-    uint32_t x = m4[0];
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t y = __shfl_down(x, o, 64);
-      if (lane + o < 64) x = min(x, y);
-    }
-    if (lane == 0) L.wsum[4 + wave] = (int)x;
-    __syncthreads();
-    // x = minimum from this thread's first bucket to the end of the wave; beyond: the later waves' minima
-    uint32_t later = 0xffffffffu;      // minimum over the lanes / waves behind this thread
-    {
-      const uint32_t nxt = __shfl_down(x, 1, 64);
-      later = (lane < 63) ? nxt : 0xffffffffu;
-      for (int w = wave + 1; w < 4; ++w) later = min(later, (uint32_t)L.wsum[4 + w]);
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) L.bmin[2 * tid + q] = min(m4[q], later);
+    bmin_suffix();
   }
   __syncthreads();
   // the cull records of the list's first kQRec entries, in list order, over the (now dead) unordered keys
@@ -637,23 +827,11 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   __syncthreads();
   BIN_TS(1, 3);
   // the len bound of list entry `k` (its bucket's lower edge, see above)
-  const float slack = 1.13f * rm * (1.0f + 1e-5f);
-  const float inv_scale = span / (float)(kBuckets - 2);
   auto len_bound = [&](const uint32_t word, const float4 cr) {
     // the entry's depth key, as the gather computed it (same record, same cone: the same bits)
     const float v = (word & 0x80000000u) ? fmaf(cr.z, qcone.az, fmaf(cr.y, qcone.ay, cr.x * qcone.ax)) + 0.0f
                                          : depth_key(cr, qcone);
-    float edge = -INFINITY;
-    int qb = 0;
-    if (v > -INFINITY) {
-      const int q = min(kBuckets - 2, max(0, (int)((v - lo) * scale)));
-      edge = fminf(v, lo + (float)q * inv_scale - 4e-6f * span);
-      qb = 1 + q;
-    }
-    // sphere-only entries: bucket edge minus the largest sphere reach; entries with an ellipsoid record: the
-    // smallest own bound from this bucket on.  Both are monotone along the list.
-    const float lb_sphere = (edge > -INFINITY) ? edge - slack - 1e-5f * fabsf(edge) - 1e-30f : -INFINITY;
-    return flagged ? fminf(lb_sphere, ord2f(L.bmin[qb])) : lb_sphere;
+    return len_bound_key(v);
   };
 
   // ---- the four sweep tiles: wave w filters the ordered list (in LDS, records included) with the bounding cone of
@@ -727,6 +905,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
     }
   }
   if (tid == 0) q_count[quad] = L.spill ? total : -2;     // (-2: never read -- every tile of this quad has its own list)
+  }      // (short path)
   // Tiles nothing can hit get their all-sentinel outputs (ray_trace_voge.cu:244-247) here, written by the whole
   // workgroup: 40 KB per tile at K = 40, 62 MB per frame at cfg3 -- HBM-write-bound wherever it happens.  The
   // quads with empty tiles are the ones with short lists, i.e. the workgroups that would otherwise finish long

@@ -183,7 +183,8 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
                  const float4 *__restrict__ ms, const float *__restrict__ rays, const int *__restrict__ bin_count,
                  const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb,
                  const int *__restrict__ tl_count, const int32_t *__restrict__ tl_id,
-                 const float *__restrict__ tl_lb, const int2 *__restrict__ order, const int tiles_per_img,
+                 const float *__restrict__ tl_lb, const int32_t *__restrict__ pool_id, const float *__restrict__ pool_lb,
+                 const int *__restrict__ tl_off, const int2 *__restrict__ order, const int tiles_per_img,
                  const int nstx, const int nst,
                  const int N, const int H,
                  const int W, const int K, const float thr_act, int32_t *__restrict__ out_idx,
@@ -208,9 +209,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   // Heavy tiles first: workgroup i takes slot i % 16 of the super-tile with launch rank i / 16 (binB: super-tiles by
   // descending candidate count, inside them quad by quad, a quad's tiles by descending list length).  The sweep lasts as long as its longest
   // tile, so that one must not start late; everything shorter fills in behind it.
-  const int2 slot = order[blockIdx.x];               // (tile, length of its list | -1 = overflowed)
-  const int lin = slot.x;
-  if (lin < 0 || slot.y == 0) return;                // outside the image | nothing can hit it: binB wrote its outputs
+  const int2 slot = order[blockIdx.x];               // (tile [| kPoolFlag], length of its list | -1 = overflowed)
+  if (slot.x < 0 || slot.y == 0) return;             // outside the image | nothing can hit it: binB wrote its outputs
+  const bool pooled = (slot.x & kPoolFlag) != 0;     // a long list (binB's long path): it lives in the pool
+  const int lin = slot.x & ~kPoolFlag;
   const int b = lin / tiles_per_img, bx = lin - b * tiles_per_img;
   const int tx = bx % tiles_x, ty = bx / tiles_x;
   const int px = tx * TW + (wave & 1) * 8 * (TW == 16) + (lane & 7);
@@ -272,8 +274,9 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
   const int bc = (tc >= 0) ? tc : ((bin_count != nullptr) ? bin_count[bin] : -1);
   const bool binned = bc >= 0;
   const int src_n = binned ? bc : N;
-  const int32_t *src_id = (tc >= 0) ? tl_id + (size_t)tile * kTileCap : (binned ? bin_id + (size_t)bin * kQCap : nullptr);
-  const float *src_lb = (tc >= 0) ? tl_lb + (size_t)tile * kTileCap : (binned ? bin_lb + (size_t)bin * kQCap : nullptr);
+  const size_t list_at = pooled ? (size_t)tl_off[tile] : (size_t)tile * kTileCap;
+  const int32_t *src_id = (tc >= 0) ? (pooled ? pool_id : tl_id) + list_at : (binned ? bin_id + (size_t)bin * kQCap : nullptr);
+  const float *src_lb = (tc >= 0) ? (pooled ? pool_lb : tl_lb) + list_at : (binned ? bin_lb + (size_t)bin * kQCap : nullptr);
   const float4 *cullb = cull + (size_t)b * N;
   const float4 *evrb = evr + (size_t)b * N * 3;
   const float4 cull_none = make_float4(0.f, 0.f, 0.f, -1.f);
@@ -1015,8 +1018,20 @@ struct TraceWs {
   float *tl_lb;
   float4 *seg_rec;
   int2 *order;                        // launch order of the sweep: (tile, list length) by super-tile rank and slot
+  int *pool_top;                      // binB's long path: lists of quads with more than kQCap candidates
+  int32_t *pool_id;
+  float *pool_lb;
+  int *tl_off;                        // per sweep tile: start of its pooled list
+  int pool_cap;
   int nstx, nsty, nst0x, nst0y, nbin;
 };
+
+// Entries of the list pool: a Gaussian sits in the list of every tile its (conservative) footprint touches -- a handful
+// for the small footprints that make a quad overflow in the first place.
+static size_t trace_pool_entries(const size_t P) {
+  const size_t want = 32 * P;
+  return want < ((size_t)1 << 20) ? ((size_t)1 << 20) : (want > ((size_t)1 << 30) ? ((size_t)1 << 30) : want);
+}
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -1033,7 +1048,12 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
        *bi = take(nbin * 4 * kQCap * 4), *bl = take(nbin * 4 * kQCap * 4), *tc = take(ntile * 4),
        *ti = take(ntile * kTileCap * 4), *tl = take(ntile * kTileCap * 4), *sr = take(nbin * kParts * (size_t)kSegCap * 16),
        *cq = take(nbin * kTilesPerBin * 8 * 2);      // (second half: the exactly sorted copy of VOGE_EXACT_ORDER builds)
+  const size_t npool = trace_pool_entries(P);
+  char *pt = take(4), *pi = take(npool * 4), *pl = take(npool * 4), *to = take(ntile * 4);
   if (ws) {
+    ws->pool_top = reinterpret_cast<int *>(pt); ws->pool_id = reinterpret_cast<int32_t *>(pi);
+    ws->pool_lb = reinterpret_cast<float *>(pl); ws->tl_off = reinterpret_cast<int *>(to);
+    ws->pool_cap = (int)npool;
     ws->cull = reinterpret_cast<float4 *>(c); ws->evr = reinterpret_cast<float4 *>(e);
     ws->ms = reinterpret_cast<float4 *>(m4); ws->ell = reinterpret_cast<float4 *>(el);
     ws->cones = reinterpret_cast<ConeRec *>(cn);
@@ -1106,7 +1126,8 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
   }
   hipLaunchKernelGGL(binB_kernel, dim3(ws.nstx * ws.nsty * 4, B), dim3(kQT), 0, st, ws.cull, ws.ell, ws.seg_count, ws.seg_id, ws.seg_rec,
                      rays, N, H, W, ws.nstx, ws.nsty, ws.nbin, ws.q_count, ws.q_id, ws.q_lb, ws.tl_count, ws.tl_id, ws.tl_lb,
-                     ws.order, K, idx, len, act, dsd, cnt, weight, valid_num);
+                     ws.order, ws.pool_top, ws.pool_cap, ws.pool_id, ws.pool_lb, ws.tl_off, K, idx, len, act, dsd, cnt, weight,
+                     valid_num);
   {
     int rc = launch_status();
     if (rc) return rc;
@@ -1118,7 +1139,7 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
 #endif
   dim3 grid(ws.nbin * kTilesPerBin);     // one workgroup per tile slot of every super-tile (slots outside the image exit)
   hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, ws.ms, rays, ws.q_count, ws.q_id, ws.q_lb,
-                     ws.tl_count, ws.tl_id, ws.tl_lb, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx,
+                     ws.tl_count, ws.tl_id, ws.tl_lb, ws.pool_id, ws.pool_lb, ws.tl_off, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx,
                      ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, weight, valid_num);
   return launch_status();
 }
@@ -1155,6 +1176,14 @@ extern "C" int voge_debug_bin_times(unsigned long long *out, int which, int n_wg
 extern "C" size_t voge_trace_workspace_bytes(int B, int N, int H, int W) {
   if (B <= 0 || N < 0 || H <= 0 || W <= 0) return 0;
   return trace_ws_layout(B, N, H, W, nullptr, nullptr);
+}
+
+extern "C" int voge_trace_pool_usage(const void *workspace, int B, int N, int H, int W, int *used, int *capacity) {
+  if (!workspace || !used || !capacity || B <= 0 || N < 0 || H <= 0 || W <= 0) return VOGE_ERR_BAD_ARG;
+  TraceWs ws;
+  trace_ws_layout(B, N, H, W, const_cast<void *>(workspace), &ws);
+  *capacity = ws.pool_cap;
+  return (int)hipMemcpy(used, ws.pool_top, sizeof(int), hipMemcpyDeviceToHost);
 }
 
 extern "C" int voge_ray_cones(const float *rays, int B, int H, int W, float *cones, voge_stream_t stream);   // rays.hip
@@ -1196,13 +1225,13 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   if (iso_in) {
     // scalar sigmas: binA derives the per-Gaussian records itself -- two launches in front of the sweep
     hipLaunchKernelGGL(binA_kernel<true>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
-                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec);
+                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top);
   } else {
     if (P > 0)
       hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P, thr_act, ws.cull,
                          ws.evr, ws.ms, ws.ell);
     hipLaunchKernelGGL(binA_kernel<false>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
-                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec);
+                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top);
   }
   {
     int rc = launch_status();

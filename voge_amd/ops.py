@@ -82,6 +82,23 @@ def _workspace(dev, nbytes):
     return ws
 
 
+def trace_pool_usage(dev, B, N, H, W):
+    """(used, capacity) of the candidate-list pool after the last forward trace of this shape on the current stream of
+    `dev` (include/voge_hip.h: voge_trace_pool_usage) -- diagnostics: used > 0 means some 16x16-pixel quads held more
+    candidates than the in-LDS sort takes (a small, dense object); used > capacity means the pool ran out and those
+    quads fell back to streaming every Gaussian.  Synchronises."""
+    import ctypes
+    lib = _lib.load()
+    dev = torch.device(dev)
+    with _on(dev):
+        nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
+        ws = _workspace(dev, nbytes)
+        used, cap = ctypes.c_int(0), ctypes.c_int(0)
+        torch.cuda.current_stream(dev).synchronize()
+        _lib.check(lib.voge_trace_pool_usage(_p(ws), B, N, H, W, ctypes.byref(used), ctypes.byref(cap)), "voge_trace_pool_usage")
+    return used.value, cap.value
+
+
 def _tag_index(sel_idx, cnt, n_index):
     """Bookkeeping the trace leaves on the index tensor it returns:
     voge_hit_count  (cnt [B,H,W] int32, torch version of sel_idx when it was written): lets aggregation() skip its
