@@ -122,19 +122,11 @@ __device__ __forceinline__ float4 binA_record(const int g, const int b, const in
   return c;
 }
 
-// How binA deals the N Gaussians of a batch element to its kParts slices (see binA_kernel), for binB, which re-derives a
-// slice's members when that slice's segment of a super-tile overflowed kSegCap.
+// How binA deals the N Gaussians of a batch element to its kParts slices (see binA_kernel), for binB, which re-tests a
+// slice's members from their records when that slice's segment of a super-tile overflowed kSegCap.
 __host__ __device__ inline bool deal_interleaved(const int N) { return N < kParts * kBinThreads; }
-__device__ __forceinline__ int slice_len(const int p, const int N) {
-  if (deal_interleaved(N)) return (N - p + kParts - 1) / kParts;                   // g = k * kParts + p
-  const int nchunks = (N + kBinThreads - 1) / kBinThreads;
-  int n = 0;
-  for (int j = p; j < nchunks; j += kParts) n += min(kBinThreads, N - j * kBinThreads);
-  return n;
-}
-__device__ __forceinline__ int slice_gauss(const int p, const int k, const int N) {
-  if (deal_interleaved(N)) return k * kParts + p;
-  return (p + kParts * (k / kBinThreads)) * kBinThreads + (k % kBinThreads);      // chunks p, p + kParts, ...
+__device__ __forceinline__ int slice_of(const int g, const int N) {
+  return deal_interleaved(N) ? g % kParts : (g / kBinThreads) % kParts;
 }
 
 template <bool ISO_PREP>
@@ -336,7 +328,7 @@ struct BinLds {
   int hist[kBuckets];
   uint32_t bmin[kBuckets];   // per bucket: smallest own len bound of the entries with an ellipsoid record (ord)
   int wsum[8];
-  int segn[kParts + 1];      // exclusive prefix of the segment counts (an overflowed segment counts its whole slice)
+  int segn[kParts + 1];      // exclusive prefix of the segment counts (an overflowed segment counts as empty here)
   unsigned ovf;              // bit p: slice p's segment overflowed kSegCap -- its Gaussians are re-tested from their records
   int count;
   int nflag;      // entries with an ellipsoid record
@@ -407,7 +399,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
       for (int p = 0; p < kParts; ++p) {
         int c = seg_count[(size_t)bin * kParts + p];
         L.segn[p] = run;
-        if (c < 0) { ovf |= 1u << p; c = slice_len(p, N); }
+        if (c < 0) { ovf |= 1u << p; c = 0; }      // (its Gaussians come from the records, second loop of stream_sources)
         run += c;
       }
       L.segn[kParts] = run;
@@ -471,52 +463,64 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   // One pass over the quad's sources -- the super-tile's segments, or whole slices where a segment overflowed -- with the
   // quad-cone test, kGU entries per thread at a time; `sink(ids, records, kept, has ellipsoid, ellipsoid key)` sees every
   // batch, wave-uniformly.
+  auto test_batch = [&](const int (&gid)[kGU], const float4 (&c)[kGU], auto &&sink) {
+    bool kp[kGU], el[kGU];
+    float gkey[kGU];
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {
+      kp[j] = cone_keep(c[j], qcone);         // (padding: reach -1, never kept)
+      el[j] = kp[j] && cull_has_ell(c[j]);
+      gkey[j] = 0.0f;
+      if (__any(el[j])) {
+        if (el[j]) {
+          const float4 e0 = ellb[2 * (size_t)gid[j]], e1 = ellb[2 * (size_t)gid[j] + 1];
+          kp[j] = cone_keep_ell(c[j], e0, e1, qcone);
+          el[j] = kp[j];
+          // order key: VOGE_ELL_KEY 0 = the centre's depth along the axis, 1 = the entry's own lower bound of len
+          const float pa = fmaf(c[j].z, qcone.az, fmaf(c[j].y, qcone.ay, c[j].x * qcone.ax));
+#if VOGE_ELL_KEY == 1
+          gkey[j] = pa - ell_support(e0, e1, qcone.ax, qcone.ay, qcone.az) + 0.0f;
+#else
+          gkey[j] = pa + 0.0f;
+#endif
+        }
+      }
+    }
+    sink(gid, c, kp, el, gkey);
+  };
   auto stream_sources = [&](auto &&sink) {
-    for (int base = 0; base < n_src; base += kQT * kGU) {
+    for (int base = 0; base < n_src; base += kQT * kGU) {      // the segments binA filled
       int gid[kGU];
       float4 c[kGU];
 #pragma unroll
       for (int j = 0; j < kGU; ++j) {     // ids and records are two streams: one round trip, nothing dependent
-        // (branch-free: exactly one id load and one record load per entry, whatever its source)
         const int i = base + j * kQT + tid;
-        const bool in = i < n_src;
-        int p = 0;
+        gid[j] = -1;
+        c[j] = make_float4(0.f, 0.f, 0.f, -1.f);
+        if (i < n_src) {
+          int p = 0;
 #pragma unroll
-        for (int q = 1; q < kParts; ++q) p += (in && i >= L.segn[q]) ? 1 : 0;
-        const int k = in ? i - L.segn[p] : 0;
-        const bool whole = ((ovf >> p) & 1u) != 0u;      // (rare) the slice itself, record by record
-        const int g = whole ? slice_gauss(p, k, N) : -1;
-        const bool gok = in && (!whole || g < N);
-        const int o = p * kSegCap + (whole ? 0 : k);
-        const int sid = segs[o];
-        const float4 *src = (whole && gok) ? cullb + g : segr + o;
-        const float4 rec = *src;
-        gid[j] = gok ? (whole ? g : sid) : -1;
-        c[j] = gok ? rec : make_float4(0.f, 0.f, 0.f, -1.f);
-      }
-      bool kp[kGU], el[kGU];
-      float gkey[kGU];
-#pragma unroll
-      for (int j = 0; j < kGU; ++j) {
-        kp[j] = cone_keep(c[j], qcone);         // (padding: reach -1, never kept)
-        el[j] = kp[j] && cull_has_ell(c[j]);
-        gkey[j] = 0.0f;
-        if (__any(el[j])) {
-          if (el[j]) {
-            const float4 e0 = ellb[2 * (size_t)gid[j]], e1 = ellb[2 * (size_t)gid[j] + 1];
-            kp[j] = cone_keep_ell(c[j], e0, e1, qcone);
-            el[j] = kp[j];
-            // order key: VOGE_ELL_KEY 0 = the centre's depth along the axis, 1 = the entry's own lower bound of len
-            const float pa = fmaf(c[j].z, qcone.az, fmaf(c[j].y, qcone.ay, c[j].x * qcone.ax));
-#if VOGE_ELL_KEY == 1
-            gkey[j] = pa - ell_support(e0, e1, qcone.ax, qcone.ay, qcone.az) + 0.0f;
-#else
-            gkey[j] = pa + 0.0f;
-#endif
-          }
+          for (int q = 1; q < kParts; ++q) p += (i >= L.segn[q]) ? 1 : 0;
+          const int o = p * kSegCap + (i - L.segn[p]);
+          gid[j] = segs[o];
+          c[j] = segr[o];
         }
       }
-      sink(gid, c, kp, el, gkey);
+      test_batch(gid, c, sink);
+    }
+    if (ovf != 0u) {      // (rare) slices whose segment overflowed: their Gaussians straight from the per-Gaussian records
+      for (int base = 0; base < N; base += kQT * kGU) {
+        int gid[kGU];
+        float4 c[kGU];
+#pragma unroll
+        for (int j = 0; j < kGU; ++j) {
+          const int g = base + j * kQT + tid;
+          const bool ok = g < N && ((ovf >> slice_of(g, N)) & 1u) != 0u;
+          gid[j] = ok ? g : -1;
+          c[j] = ok ? cullb[g] : make_float4(0.f, 0.f, 0.f, -1.f);
+        }
+        test_batch(gid, c, sink);
+      }
     }
   };
   // Slots of a batch's survivors in the workgroup's compacted order: ONE LDS atomic per wave and batch (round 3: one per
