@@ -341,7 +341,325 @@ struct BinLds {
 #define VOGE_ELL_KEY 0
 #endif
 
-__global__ void __launch_bounds__(kQT)
+constexpr int kGU = 8;      // gathers in flight per thread of binB's source passes
+
+// What one pass over a quad's sources needs: the super-tile's segments (as binA filled them), the per-Gaussian records
+// for the slices whose segment overflowed, and the quad's cone.
+struct BinStream {
+  const float4 *cullb, *ellb, *segr;
+  const int32_t *segs;
+  int n_src, N;
+  unsigned ovf;
+  Cone qcone;
+};
+// The quad-cone test of one batch (kGU entries per thread), then `sink(ids, records, kept, has ellipsoid, ellipsoid key)`.
+template <class Sink>
+__device__ __forceinline__ void bin_test_batch(const BinStream &S, const int (&gid)[kGU], const float4 (&c)[kGU], Sink &&sink) {
+  bool kp[kGU], el[kGU];
+  float gkey[kGU];
+#pragma unroll
+  for (int j = 0; j < kGU; ++j) {
+    kp[j] = cone_keep(c[j], S.qcone);         // (padding: reach -1, never kept)
+    el[j] = kp[j] && cull_has_ell(c[j]);
+    gkey[j] = 0.0f;
+    if (__any(el[j])) {
+      if (el[j]) {
+        const float4 e0 = S.ellb[2 * (size_t)gid[j]], e1 = S.ellb[2 * (size_t)gid[j] + 1];
+        kp[j] = cone_keep_ell(c[j], e0, e1, S.qcone);
+        el[j] = kp[j];
+        // order key: VOGE_ELL_KEY 0 = the centre's depth along the axis, 1 = the entry's own lower bound of len
+        const float pa = fmaf(c[j].z, S.qcone.az, fmaf(c[j].y, S.qcone.ay, c[j].x * S.qcone.ax));
+#if VOGE_ELL_KEY == 1
+        gkey[j] = pa - ell_support(e0, e1, S.qcone.ax, S.qcone.ay, S.qcone.az) + 0.0f;
+#else
+        gkey[j] = pa + 0.0f;
+#endif
+      }
+    }
+  }
+  sink(gid, c, kp, el, gkey);
+}
+// One pass over the quad's sources, kGU entries per thread at a time; the sink sees every batch, wave-uniformly.
+template <class Sink>
+__device__ __forceinline__ void bin_stream_sources(const BinStream &S, const int *segn /* LDS: exclusive prefix of the segment counts */,
+                                                   const int tid, Sink &&sink) {
+  for (int base = 0; base < S.n_src; base += kQT * kGU) {      // the segments binA filled
+    int gid[kGU];
+    float4 c[kGU];
+#pragma unroll
+    for (int j = 0; j < kGU; ++j) {     // ids and records are two streams: one round trip, nothing dependent
+      const int i = base + j * kQT + tid;
+      gid[j] = -1;
+      c[j] = make_float4(0.f, 0.f, 0.f, -1.f);
+      if (i < S.n_src) {
+        int p = 0;
+#pragma unroll
+        for (int q = 1; q < kParts; ++q) p += (i >= segn[q]) ? 1 : 0;
+        const int o = p * kSegCap + (i - segn[p]);
+        gid[j] = S.segs[o];
+        c[j] = S.segr[o];
+      }
+    }
+    bin_test_batch(S, gid, c, sink);
+  }
+  if (S.ovf != 0u) {      // (rare) slices whose segment overflowed: their Gaussians straight from the per-Gaussian records
+    for (int base = 0; base < S.N; base += kQT * kGU) {
+      int gid[kGU];
+      float4 c[kGU];
+#pragma unroll
+      for (int j = 0; j < kGU; ++j) {
+        const int g = base + j * kQT + tid;
+        const bool ok = g < S.N && ((S.ovf >> slice_of(g, S.N)) & 1u) != 0u;
+        gid[j] = ok ? g : -1;
+        c[j] = ok ? S.cullb[g] : make_float4(0.f, 0.f, 0.f, -1.f);
+      }
+      bin_test_batch(S, gid, c, sink);
+    }
+  }
+}
+// Slots of a batch's survivors in the workgroup's compacted order: ONE LDS atomic per wave and batch (rounds 1-2: one per
+// wave and ENTRY -- eight dependent atomic + broadcast chains per batch).
+__device__ __forceinline__ void bin_batch_slots(int *count /* LDS */, const int lane, const bool (&kp)[kGU], int (&slot)[kGU]) {
+  unsigned long long m[kGU];
+  int cw = 0;
+#pragma unroll
+  for (int j = 0; j < kGU; ++j) { m[j] = __ballot(kp[j]); cw += __popcll(m[j]); }
+  int start = 0;
+  if (cw > 0) {      // uniform
+    if (lane == 0) start = atomicAdd(count, cw);
+    start = __builtin_amdgcn_readfirstlane(start);
+  }
+#pragma unroll
+  for (int j = 0; j < kGU; ++j) {
+    slot[j] = start + __popcll(m[j] & ((1ull << lane) - 1ull));
+    start += __popcll(m[j]);
+  }
+}
+// The depth buckets of a quad's candidates and the len bounds they stand for.
+struct BinKeys {
+  float lo, scale, span, slack;      // bucket b covers keys [lo + (b - 1) / scale, ...); slack: 1.13 x the largest sphere reach
+  bool flagged;                      // some entry has an ellipsoid record: L.bmin holds suffix minima of their own bounds
+};
+__device__ __forceinline__ int bin_bucket_of(const BinKeys &Kk, const float v) {
+  return (v > -INFINITY) ? 1 + min(kBuckets - 2, max(0, (int)((v - Kk.lo) * Kk.scale))) : 0;
+}
+// own lower bound of len of an entry with an ellipsoid record: the peak point x = len d of a hit lies in the
+// ellipsoid, so len (d.a) = x.a >= t = mu.a - h(a), and d.a is in [cs, 1]
+__device__ __forceinline__ float bin_own_bound(const BinStream &S, const size_t g) {
+  const float4 cj = S.cullb[g], e0 = S.ellb[2 * g], e1 = S.ellb[2 * g + 1];
+  float bnd = -INFINITY;
+  if (S.qcone.ok) {
+    const float pa = fmaf(cj.z, S.qcone.az, fmaf(cj.y, S.qcone.ay, cj.x * S.qcone.ax));
+    const float nm1 = fabsf(cj.x) + fabsf(cj.y) + fabsf(cj.z);
+    const float t = pa - ell_support(e0, e1, S.qcone.ax, S.qcone.ay, S.qcone.az) - 4e-6f * nm1;
+    bnd = (t >= 0.0f) ? t : t / S.qcone.cs;
+    bnd = bnd - 1e-5f * fabsf(bnd) - 1e-30f;
+  }
+  return bnd;
+}
+// Suffix minimum over the buckets of the flagged entries' own bounds (thread <-> two buckets).  (one barrier inside)
+__device__ __forceinline__ void bin_bmin_suffix(uint32_t *bmin, int *wsum, const int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  uint32_t m4[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) m4[q] = bmin[2 * tid + q];
+  m4[0] = min(m4[0], m4[1]);
+  uint32_t x = m4[0];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_down(x, o, 64);
+    if (lane + o < 64) x = min(x, y);
+  }
+  if (lane == 0) wsum[4 + wave] = (int)x;
+  __syncthreads();
+  // x = minimum from this thread's first bucket to the end of the wave; beyond: the later waves' minima
+  uint32_t later = 0xffffffffu;      // minimum over the lanes / waves behind this thread
+  {
+    const uint32_t nxt = __shfl_down(x, 1, 64);
+    later = (lane < 63) ? nxt : 0xffffffffu;
+    for (int w = wave + 1; w < 4; ++w) later = min(later, (uint32_t)wsum[4 + w]);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) bmin[2 * tid + q] = min(m4[q], later);
+}
+// the len bound of an entry from its depth key: its bucket's lower edge (see binB_kernel)
+__device__ __forceinline__ float bin_len_bound(const BinKeys &Kk, const uint32_t *bmin, const float v) {
+  float edge = -INFINITY;
+  int qb = 0;
+  if (v > -INFINITY) {
+    const int q = min(kBuckets - 2, max(0, (int)((v - Kk.lo) * Kk.scale)));
+    edge = fminf(v, Kk.lo + (float)q * (Kk.span / (float)(kBuckets - 2)) - 4e-6f * Kk.span);
+    qb = 1 + q;
+  }
+  // sphere-only entries: bucket edge minus the largest sphere reach; entries with an ellipsoid record: the
+  // smallest own bound from this bucket on.  Both are monotone along the list.
+  const float lb_sphere = (edge > -INFINITY) ? edge - Kk.slack - 1e-5f * fabsf(edge) - 1e-30f : -INFINITY;
+  return Kk.flagged ? fminf(lb_sphere, ord2f(bmin[qb])) : lb_sphere;
+}
+
+// ---- binB's LONG PATH: a quad with more candidates than the LDS sort holds (tens of thousands of Gaussians behind a few
+// dozen pixels: a small object, a zoomed-out view).  Rounds 1-3 sent such a quad's tiles to the stream-everything fallback
+// (trace 0.1 -> 3 ms).  Here the sources are streamed once more to put the quad's survivors into a POOL
+// (their number is known from the kernel's first pass); two walks over the survivors then count, per tile and depth
+// bucket, the candidates that pass the tile's cone (and collect the flagged entries' bounds), and scatter them -- bucket
+// by bucket, i.e. front to back -- into per-tile lists of exactly the needed length, also from the pool.  Inside a bucket
+// the order is arbitrary, as in the LDS sort; every entry carries its bucket's bound.  Only an exhausted pool still falls
+// back.  
+struct BinLong {
+  BinStream S;
+  BinKeys Kk;
+  Cone tcone;
+  bool tile_ok;
+  int tile, quad, total;
+  int *pool_top, *tl_off, *tl_count, *q_count;
+  int pool_cap;
+  int32_t *pool_id;
+  float *pool_lb;
+  int2 *my_order;
+};
+__device__ __forceinline__ void binB_long_path(const BinLong A, BinLds &L) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const BinStream &S = A.S;
+  const int total = A.total;
+  __syncthreads();                                   // (everyone is done with L.red / L.count of pass one)
+  for (int i = tid; i < kTilesPerQuad * kBuckets; i += kQT) (&L.hist4[0][0])[i] = 0;
+  if (lane == 0) {
+    L.tc[wave][0] = A.tcone.ax; L.tc[wave][1] = A.tcone.ay; L.tc[wave][2] = A.tcone.az; L.tc[wave][3] = A.tcone.cs;
+    L.tc[wave][4] = A.tcone.sn; L.tc[wave][5] = (A.tcone.ok || !A.tile_ok) ? 1.0f : 0.0f;      // (a tile outside the image keeps nothing)
+    L.tc[wave][6] = A.tile_ok ? 1.0f : 0.0f;
+  }
+  if (tid == 0) {
+    // the quad's survivors -- (id | flag, depth key) -- go to the pool first: the sources (up to N entries where
+    // segments overflowed) are streamed ONCE more, everything after that walks the `total` survivors only
+    int at = atomicAdd(A.pool_top, total);
+    if (total > A.pool_cap || at > A.pool_cap - total) at = -1;      // exhausted (the counter may run on: only compared)
+    L.toff[0] = at;
+    L.count = 0;
+  }
+  __syncthreads();
+  const int surv_at = L.toff[0];
+  bool pooled = surv_at >= 0;
+  int tile_n[kTilesPerQuad] = {0, 0, 0, 0};
+  if (pooled) {
+    int32_t *sv_id = A.pool_id + surv_at;
+    float *sv_key = A.pool_lb + surv_at;
+    bin_stream_sources(S, L.segn, tid, [&](const int (&g)[kGU], const float4 (&cj)[kGU], const bool (&kp)[kGU],
+                                            const bool (&el)[kGU], const float (&gkey)[kGU]) {
+      int slot[kGU];
+      bin_batch_slots(&L.count, lane, kp, slot);
+#pragma unroll
+      for (int j = 0; j < kGU; ++j) {
+        if (kp[j]) {      // (the same tests on the same data as pass one: slot < total)
+          sv_id[slot[j]] = (int32_t)((uint32_t)g[j] | (el[j] ? 0x80000000u : 0u));
+          sv_key[slot[j]] = el[j] ? gkey[j] : depth_key(cj[j], S.qcone);
+        }
+      }
+    });
+    __threadfence_block();
+    __syncthreads();
+    BIN_TS(1, 2);
+    auto tile_mask = [&](const size_t g, const float4 cj, const bool el) {
+      unsigned mk = 0u;
+#pragma unroll 1
+      for (int t = 0; t < kTilesPerQuad; ++t) {
+        Cone tk;
+        tk.ax = L.tc[t][0]; tk.ay = L.tc[t][1]; tk.az = L.tc[t][2]; tk.cs = L.tc[t][3]; tk.sn = L.tc[t][4];
+        tk.ok = L.tc[t][5] != 0.0f;
+        bool k2 = (L.tc[t][6] != 0.0f) && cone_keep(cj, tk);
+        if (k2 && el) k2 = cone_keep_ell(cj, S.ellb[2 * g], S.ellb[2 * g + 1], tk);
+        mk |= k2 ? (1u << t) : 0u;
+      }
+      return mk;
+    };
+    // count, per tile and depth bucket, the survivors of the tile's cone; the flagged entries' own bounds
+    for (int i = tid; i < total; i += kQT) {
+      const uint32_t word = (uint32_t)sv_id[i];
+      const size_t g = word & 0x7fffffffu;
+      const bool el = (word & 0x80000000u) != 0u;
+      const int q = bin_bucket_of(A.Kk, sv_key[i]);
+      const unsigned mk = tile_mask(g, S.cullb[g], el);
+#pragma unroll
+      for (int t = 0; t < kTilesPerQuad; ++t)
+        if ((mk >> t) & 1u) atomicAdd(&L.hist4[t][q], 1);
+      if (el) atomicMin(&L.bmin[q], f2ord(bin_own_bound(S, g)));
+    }
+    __syncthreads();
+    // exclusive scans of the four tiles' bucket counters (two buckets per thread); totals -> tile_n
+    for (int t = 0; t < kTilesPerQuad; ++t) {
+      const int2 v = *reinterpret_cast<const int2 *>(&L.hist4[t][2 * tid]);
+      const int s4 = v.x + v.y;
+      int x = s4;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+      }
+      if (lane == 63) L.wsum[wave] = x;
+      __syncthreads();
+      int off = x - s4;
+      for (int w = 0; w < wave; ++w) off += L.wsum[w];
+      tile_n[t] = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+      *reinterpret_cast<int2 *>(&L.hist4[t][2 * tid]) = make_int2(off, off + v.x);
+      __syncthreads();
+    }
+    if (A.Kk.flagged) bin_bmin_suffix(L.bmin, L.wsum, tid);
+    if (tid == 0) {
+      const int need = tile_n[0] + tile_n[1] + tile_n[2] + tile_n[3];
+      int at = (need > 0) ? atomicAdd(A.pool_top, need) : 0;
+      if (need > A.pool_cap || at > A.pool_cap - need) at = -1;
+#pragma unroll
+      for (int t = 0; t < kTilesPerQuad; ++t) { L.toff[t] = at; if (at >= 0) at += tile_n[t]; }
+    }
+    __syncthreads();
+    pooled = L.toff[0] >= 0;
+    BIN_TS(1, 3);
+    if (pooled) {      // scatter: bucket by bucket, i.e. front to back; inside a bucket in whatever order the atomics give
+      for (int i = tid; i < total; i += kQT) {
+        const uint32_t word = (uint32_t)sv_id[i];
+        const size_t g = word & 0x7fffffffu;
+        const bool el = (word & 0x80000000u) != 0u;
+        const float kv = sv_key[i];
+        const int q = bin_bucket_of(A.Kk, kv);
+        const unsigned mk = tile_mask(g, S.cullb[g], el);
+        if (mk == 0u) continue;
+        const float lbv = bin_len_bound(A.Kk, L.bmin, kv);
+#pragma unroll
+        for (int t = 0; t < kTilesPerQuad; ++t) {
+          if ((mk >> t) & 1u) {
+            const size_t pos = (size_t)L.toff[t] + (size_t)atomicAdd(&L.hist4[t][q], 1);
+            A.pool_id[pos] = (int32_t)g;
+            A.pool_lb[pos] = lbv;
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0 && A.tile_ok) {
+    A.tl_count[A.tile] = pooled ? tile_n[wave] : -1;
+    A.tl_off[A.tile] = pooled ? L.toff[wave] : -1;
+  }
+  __syncthreads();
+  // launch slots: longest list first (an overflowed one counts as longest), tiles outside the image last
+  if (lane == 0) L.wsum[wave] = A.tile_ok ? (pooled ? tile_n[wave] : 0x7fffffff) : -1;
+  __syncthreads();
+  if (lane == 0) {
+    const int mine = L.wsum[wave];
+    int slot = 0;
+    for (int w = 0; w < kTilesPerQuad; ++w) {
+      const int o = L.wsum[w];
+      slot += (o > mine || (o == mine && w < wave)) ? 1 : 0;
+    }
+    A.my_order[slot] = make_int2(A.tile_ok ? (pooled ? (A.tile | kPoolFlag) : A.tile) : -1, pooled ? mine : -1);
+  }
+  if (tid == 0) A.q_count[A.quad] = pooled ? -2 : -1;
+  BIN_TS(1, 4);
+}
+
+
+#ifndef VOGE_BINB_WPE
+#define VOGE_BINB_WPE 4
+#endif
+__global__ void __launch_bounds__(kQT) __attribute__((amdgpu_waves_per_eu(VOGE_BINB_WPE, VOGE_BINB_WPE)))
 binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, const int *__restrict__ seg_count,
             const int32_t *__restrict__ seg_id, const float4 *__restrict__ seg_rec, const float *__restrict__ rays,
             const int N, const int H, const int W,
@@ -459,92 +777,13 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   float rmax = 0.0f;   // largest finite reach among this thread's survivors WITHOUT an ellipsoid record
   float klo = INFINITY, khi = -INFINITY;   // extrema of the finite order keys of this thread's entries
   bool any_el = false;
-  constexpr int kGU = 8;      // gathers in flight per thread
-  // One pass over the quad's sources -- the super-tile's segments, or whole slices where a segment overflowed -- with the
-  // quad-cone test, kGU entries per thread at a time; `sink(ids, records, kept, has ellipsoid, ellipsoid key)` sees every
-  // batch, wave-uniformly.
-  auto test_batch = [&](const int (&gid)[kGU], const float4 (&c)[kGU], auto &&sink) {
-    bool kp[kGU], el[kGU];
-    float gkey[kGU];
-#pragma unroll
-    for (int j = 0; j < kGU; ++j) {
-      kp[j] = cone_keep(c[j], qcone);         // (padding: reach -1, never kept)
-      el[j] = kp[j] && cull_has_ell(c[j]);
-      gkey[j] = 0.0f;
-      if (__any(el[j])) {
-        if (el[j]) {
-          const float4 e0 = ellb[2 * (size_t)gid[j]], e1 = ellb[2 * (size_t)gid[j] + 1];
-          kp[j] = cone_keep_ell(c[j], e0, e1, qcone);
-          el[j] = kp[j];
-          // order key: VOGE_ELL_KEY 0 = the centre's depth along the axis, 1 = the entry's own lower bound of len
-          const float pa = fmaf(c[j].z, qcone.az, fmaf(c[j].y, qcone.ay, c[j].x * qcone.ax));
-#if VOGE_ELL_KEY == 1
-          gkey[j] = pa - ell_support(e0, e1, qcone.ax, qcone.ay, qcone.az) + 0.0f;
-#else
-          gkey[j] = pa + 0.0f;
-#endif
-        }
-      }
-    }
-    sink(gid, c, kp, el, gkey);
-  };
-  auto stream_sources = [&](auto &&sink) {
-    for (int base = 0; base < n_src; base += kQT * kGU) {      // the segments binA filled
-      int gid[kGU];
-      float4 c[kGU];
-#pragma unroll
-      for (int j = 0; j < kGU; ++j) {     // ids and records are two streams: one round trip, nothing dependent
-        const int i = base + j * kQT + tid;
-        gid[j] = -1;
-        c[j] = make_float4(0.f, 0.f, 0.f, -1.f);
-        if (i < n_src) {
-          int p = 0;
-#pragma unroll
-          for (int q = 1; q < kParts; ++q) p += (i >= L.segn[q]) ? 1 : 0;
-          const int o = p * kSegCap + (i - L.segn[p]);
-          gid[j] = segs[o];
-          c[j] = segr[o];
-        }
-      }
-      test_batch(gid, c, sink);
-    }
-    if (ovf != 0u) {      // (rare) slices whose segment overflowed: their Gaussians straight from the per-Gaussian records
-      for (int base = 0; base < N; base += kQT * kGU) {
-        int gid[kGU];
-        float4 c[kGU];
-#pragma unroll
-        for (int j = 0; j < kGU; ++j) {
-          const int g = base + j * kQT + tid;
-          const bool ok = g < N && ((ovf >> slice_of(g, N)) & 1u) != 0u;
-          gid[j] = ok ? g : -1;
-          c[j] = ok ? cullb[g] : make_float4(0.f, 0.f, 0.f, -1.f);
-        }
-        test_batch(gid, c, sink);
-      }
-    }
-  };
-  // Slots of a batch's survivors in the workgroup's compacted order: ONE LDS atomic per wave and batch (round 3: one per
-  // wave and ENTRY -- eight dependent atomic + broadcast chains per batch were most of this loop's time).
-  auto batch_slots = [&](const bool (&kp)[kGU], int (&slot)[kGU]) {
-    unsigned long long m[kGU];
-    int cw = 0;
-#pragma unroll
-    for (int j = 0; j < kGU; ++j) { m[j] = __ballot(kp[j]); cw += __popcll(m[j]); }
-    int start = 0;
-    if (cw > 0) {      // uniform
-      if (lane == 0) start = atomicAdd(&L.count, cw);
-      start = __builtin_amdgcn_readfirstlane(start);
-    }
-#pragma unroll
-    for (int j = 0; j < kGU; ++j) {
-      slot[j] = start + __popcll(m[j] & ((1ull << lane) - 1ull));
-      start += __popcll(m[j]);
-    }
-  };
-  stream_sources([&](const int (&g)[kGU], const float4 (&cj)[kGU], const bool (&kp)[kGU], const bool (&el)[kGU],
-                     const float (&gkey)[kGU]) {
+  BinStream S;
+  S.cullb = cullb; S.ellb = ellb; S.segr = segr; S.segs = segs; S.n_src = n_src; S.N = N; S.ovf = ovf; S.qcone = qcone;
+  // pass one: the quad's survivors -- keys compacted in LDS (the first kQCap of them), extrema, the largest sphere reach
+  bin_stream_sources(S, L.segn, tid, [&](const int (&g)[kGU], const float4 (&cj)[kGU], const bool (&kp)[kGU],
+                                          const bool (&el)[kGU], const float (&gkey)[kGU]) {
     int slot[kGU];
-    batch_slots(kp, slot);
+    bin_batch_slots(&L.count, lane, kp, slot);
 #pragma unroll
     for (int j = 0; j < kGU; ++j) {
       if (kp[j]) {
@@ -573,212 +812,33 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   const float span = fmaxf(hi - lo, 1e-20f);
   const float scale = (float)(kBuckets - 2) / span;
   const bool flagged = L.nflag != 0;     // any entry with an ellipsoid record (workgroup-uniform)
-  auto bucket_of_key = [&](const float v) {
-    return (v > -INFINITY) ? 1 + min(kBuckets - 2, max(0, (int)((v - lo) * scale))) : 0;
-  };
-  auto bucket_of = [&](const uint64_t k) { return bucket_of_key(ord2f((uint32_t)(k >> 32))); };
-  // own lower bound of len of an entry with an ellipsoid record: the peak point x = len d of a hit lies in the
-  // ellipsoid, so len (d.a) = x.a >= t = mu.a - h(a), and d.a is in [cs, 1]
-  auto own_bound = [&](const size_t g) {
-    const float4 cj = cullb[g], e0 = ellb[2 * g], e1 = ellb[2 * g + 1];
-    float bnd = -INFINITY;
-    if (qcone.ok) {
-      const float pa = fmaf(cj.z, qcone.az, fmaf(cj.y, qcone.ay, cj.x * qcone.ax));
-      const float nm1 = fabsf(cj.x) + fabsf(cj.y) + fabsf(cj.z);
-      const float t = pa - ell_support(e0, e1, qcone.ax, qcone.ay, qcone.az) - 4e-6f * nm1;
-      bnd = (t >= 0.0f) ? t : t / qcone.cs;
-      bnd = bnd - 1e-5f * fabsf(bnd) - 1e-30f;
-    }
-    return bnd;
-  };
-  // Suffix minimum over the buckets of the flagged entries' own bounds (thread <-> two buckets).  (barriers inside)
-  auto bmin_suffix = [&]() {
-    uint32_t m4[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) m4[q] = L.bmin[2 * tid + q];
-    m4[0] = min(m4[0], m4[1]);
-    uint32_t x = m4[0];
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t y = __shfl_down(x, o, 64);
-      if (lane + o < 64) x = min(x, y);
-    }
-    if (lane == 0) L.wsum[4 + wave] = (int)x;
-    __syncthreads();
-    // x = minimum from this thread's first bucket to the end of the wave; beyond: the later waves' minima
-    uint32_t later = 0xffffffffu;      // minimum over the lanes / waves behind this thread
-    {
-      const uint32_t nxt = __shfl_down(x, 1, 64);
-      later = (lane < 63) ? nxt : 0xffffffffu;
-      for (int w = wave + 1; w < 4; ++w) later = min(later, (uint32_t)L.wsum[4 + w]);
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) L.bmin[2 * tid + q] = min(m4[q], later);
-  };
-  // the len bound of an entry from its depth key (its bucket's lower edge, see below)
-  const float slack = 1.13f * rm * (1.0f + 1e-5f);
-  const float inv_scale = span / (float)(kBuckets - 2);
-  auto len_bound_key = [&](const float v) {
-    float edge = -INFINITY;
-    int qb = 0;
-    if (v > -INFINITY) {
-      const int q = min(kBuckets - 2, max(0, (int)((v - lo) * scale)));
-      edge = fminf(v, lo + (float)q * inv_scale - 4e-6f * span);
-      qb = 1 + q;
-    }
-    // sphere-only entries: bucket edge minus the largest sphere reach; entries with an ellipsoid record: the
-    // smallest own bound from this bucket on.  Both are monotone along the list.
-    const float lb_sphere = (edge > -INFINITY) ? edge - slack - 1e-5f * fabsf(edge) - 1e-30f : -INFINITY;
-    return flagged ? fminf(lb_sphere, ord2f(L.bmin[qb])) : lb_sphere;
-  };
+  BinKeys Kk;
+  Kk.lo = lo; Kk.scale = scale; Kk.span = span; Kk.slack = 1.13f * rm * (1.0f + 1e-5f); Kk.flagged = flagged;
+  auto bucket_of = [&](const uint64_t k) { return bin_bucket_of(Kk, ord2f((uint32_t)(k >> 32))); };
+#ifdef VOGE_NO_LONG      // (A/B builds: the pre-pool behaviour -- such quads stream every Gaussian in the sweep)
   if (total > kQCap) {
-    // ---- LONG PATH: more candidates than the LDS sort holds (tens of thousands of Gaussians behind a few dozen pixels:
-    // a small object, a zoomed-out view).  Rounds 1-3 sent such a quad's tiles to the stream-everything fallback (trace
-    // 0.1 -> 3 ms).  Now the sources are streamed once more to put the quad's survivors into a POOL
-    // (their number is known from pass one); two walks over the survivors then count, per tile and depth bucket, the
-    // candidates that pass the tile's cone (and collect the flagged entries' bounds), and scatter them -- bucket by
-    // bucket, i.e. front to back -- into per-tile lists of exactly the needed length, also from the pool.  Inside a
-    // bucket the order is arbitrary, as in the LDS sort; every entry carries its bucket's bound.  Only an exhausted
-    // pool still falls back.
-    __syncthreads();                                   // (everyone is done with L.red / L.count of pass one)
-    for (int i = tid; i < kTilesPerQuad * kBuckets; i += kQT) (&L.hist4[0][0])[i] = 0;
+    if (tid == 0) q_count[quad] = -1;
     if (lane == 0) {
-      L.tc[wave][0] = tcone.ax; L.tc[wave][1] = tcone.ay; L.tc[wave][2] = tcone.az; L.tc[wave][3] = tcone.cs;
-      L.tc[wave][4] = tcone.sn; L.tc[wave][5] = (tcone.ok || !tile_ok) ? 1.0f : 0.0f;      // (a tile outside the image keeps nothing)
-      L.tc[wave][6] = tile_ok ? 1.0f : 0.0f;
+      if (tile_ok) tl_count[tile] = -1;
+      my_order[wave] = make_int2(tile_ok ? tile : -1, -1);
     }
-    if (tid == 0) {
-      // the quad's survivors -- (id | flag, depth key) -- go to the pool first: the sources (up to N entries where
-      // segments overflowed) are streamed ONCE more, everything after that walks the `total` survivors only
-      int at = atomicAdd(pool_top, total);
-      if (total > pool_cap || at > pool_cap - total) at = -1;      // exhausted (the counter may run on: only compared)
-      L.toff[0] = at;
-      L.count = 0;
-    }
-    __syncthreads();
-    const int surv_at = L.toff[0];
-    bool pooled = surv_at >= 0;
-    int tile_n[kTilesPerQuad] = {0, 0, 0, 0};
-    if (pooled) {
-      int32_t *sv_id = pool_id + surv_at;
-      float *sv_key = pool_lb + surv_at;
-      stream_sources([&](const int (&g)[kGU], const float4 (&cj)[kGU], const bool (&kp)[kGU], const bool (&el)[kGU],
-                         const float (&gkey)[kGU]) {
-        int slot[kGU];
-        batch_slots(kp, slot);
-#pragma unroll
-        for (int j = 0; j < kGU; ++j) {
-          if (kp[j]) {      // (the same tests on the same data as pass one: slot < total)
-            sv_id[slot[j]] = (int32_t)((uint32_t)g[j] | (el[j] ? 0x80000000u : 0u));
-            sv_key[slot[j]] = el[j] ? gkey[j] : depth_key(cj[j], qcone);
-          }
-        }
-      });
-      __threadfence_block();
-      __syncthreads();
-      BIN_TS(1, 2);
-      // (the cones stay in LDS -- broadcast reads -- so that this rare path does not raise the kernel's register count)
-      auto tile_mask = [&](const size_t g, const float4 cj, const bool el) {
-        unsigned mk = 0u;
-#pragma unroll 1
-        for (int t = 0; t < kTilesPerQuad; ++t) {
-          Cone tk;
-          tk.ax = L.tc[t][0]; tk.ay = L.tc[t][1]; tk.az = L.tc[t][2]; tk.cs = L.tc[t][3]; tk.sn = L.tc[t][4];
-          tk.ok = L.tc[t][5] != 0.0f;
-          bool k2 = (L.tc[t][6] != 0.0f) && cone_keep(cj, tk);
-          if (k2 && el) k2 = cone_keep_ell(cj, ellb[2 * g], ellb[2 * g + 1], tk);
-          mk |= k2 ? (1u << t) : 0u;
-        }
-        return mk;
-      };
-      // count, per tile and depth bucket, the survivors of the tile's cone; the flagged entries' own bounds
-      for (int i = tid; i < total; i += kQT) {
-        const uint32_t word = (uint32_t)sv_id[i];
-        const size_t g = word & 0x7fffffffu;
-        const bool el = (word & 0x80000000u) != 0u;
-        const int q = bucket_of_key(sv_key[i]);
-        const unsigned mk = tile_mask(g, cullb[g], el);
-#pragma unroll
-        for (int t = 0; t < kTilesPerQuad; ++t)
-          if ((mk >> t) & 1u) atomicAdd(&L.hist4[t][q], 1);
-        if (el) atomicMin(&L.bmin[q], f2ord(own_bound(g)));
-      }
-      __syncthreads();
-      // exclusive scans of the four tiles' bucket counters (two buckets per thread, as below); totals -> tile_n
-      for (int t = 0; t < kTilesPerQuad; ++t) {
-        const int2 v = *reinterpret_cast<const int2 *>(&L.hist4[t][2 * tid]);
-        const int s4 = v.x + v.y;
-        int x = s4;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int y = __shfl_up(x, o, 64);
-          if (lane >= o) x += y;
-        }
-        if (lane == 63) L.wsum[wave] = x;
-        __syncthreads();
-        int off = x - s4;
-        for (int w = 0; w < wave; ++w) off += L.wsum[w];
-        tile_n[t] = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
-        *reinterpret_cast<int2 *>(&L.hist4[t][2 * tid]) = make_int2(off, off + v.x);
-        __syncthreads();
-      }
-      if (flagged) { bmin_suffix(); }
-      if (tid == 0) {
-        const int need = tile_n[0] + tile_n[1] + tile_n[2] + tile_n[3];
-        int at = (need > 0) ? atomicAdd(pool_top, need) : 0;
-        if (need > pool_cap || at > pool_cap - need) at = -1;
-#pragma unroll
-        for (int t = 0; t < kTilesPerQuad; ++t) { L.toff[t] = at; if (at >= 0) at += tile_n[t]; }
-      }
-      __syncthreads();
-      pooled = L.toff[0] >= 0;
-      BIN_TS(1, 3);
-      if (pooled) {      // scatter: bucket by bucket, i.e. front to back; inside a bucket in whatever order the atomics give
-        for (int i = tid; i < total; i += kQT) {
-          const uint32_t word = (uint32_t)sv_id[i];
-          const size_t g = word & 0x7fffffffu;
-          const bool el = (word & 0x80000000u) != 0u;
-          const float kv = sv_key[i];
-          const int q = bucket_of_key(kv);
-          const unsigned mk = tile_mask(g, cullb[g], el);
-          if (mk == 0u) continue;
-          const float lbv = len_bound_key(kv);
-#pragma unroll
-          for (int t = 0; t < kTilesPerQuad; ++t) {
-            if ((mk >> t) & 1u) {
-              const size_t pos = (size_t)L.toff[t] + (size_t)atomicAdd(&L.hist4[t][q], 1);
-              pool_id[pos] = (int32_t)g;
-              pool_lb[pos] = lbv;
-            }
-          }
-        }
-      }
-    }
-    if (lane == 0 && tile_ok) {
-      tl_count[tile] = pooled ? tile_n[wave] : -1;
-      tl_off[tile] = pooled ? L.toff[wave] : -1;
-    }
-    __syncthreads();
-    // launch slots: longest list first (an overflowed one counts as longest), tiles outside the image last
-    if (lane == 0) L.wsum[wave] = tile_ok ? (pooled ? tile_n[wave] : 0x7fffffff) : -1;
-    __syncthreads();
-    if (lane == 0) {
-      const int mine = L.wsum[wave];
-      int slot = 0;
-      for (int w = 0; w < kTilesPerQuad; ++w) {
-        const int o = L.wsum[w];
-        slot += (o > mine || (o == mine && w < wave)) ? 1 : 0;
-      }
-      my_order[slot] = make_int2(tile_ok ? (pooled ? (tile | kPoolFlag) : tile) : -1, pooled ? mine : -1);
-    }
-    if (tid == 0) q_count[quad] = pooled ? -2 : -1;
-    BIN_TS(1, 4);
+    return;
+  }
+  {
+#else
+  if (__builtin_expect(total > kQCap, 0)) {
+    BinLong A;
+    A.S = S; A.Kk = Kk; A.tcone = tcone; A.tile_ok = tile_ok; A.tile = tile; A.quad = quad; A.total = total;
+    A.pool_top = pool_top; A.tl_off = tl_off; A.tl_count = tl_count; A.q_count = q_count; A.pool_cap = pool_cap;
+    A.pool_id = pool_id; A.pool_lb = pool_lb; A.my_order = my_order;
+    binB_long_path(A, L);
   } else {
+#endif
   for (int i = tid; i < total; i += kQT) {
     const uint64_t kk = L.keys[i];
     const int q = bucket_of(kk);
     atomicAdd(&L.hist[q], 1);
-    if ((uint32_t)kk & 0x80000000u) atomicMin(&L.bmin[q], f2ord(own_bound((size_t)((uint32_t)kk & 0x7fffffffu))));
+    if ((uint32_t)kk & 0x80000000u) atomicMin(&L.bmin[q], f2ord(bin_own_bound(S, (size_t)((uint32_t)kk & 0x7fffffffu))));
   }
   __syncthreads();
   // exclusive scan of the kBuckets counters: two consecutive buckets per thread, wave scan, wave offsets
@@ -811,7 +871,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   // Suffix minimum over the buckets of the flagged entries' own bounds (thread <-> two buckets).
   if (flagged) {
     __syncthreads();
-    bmin_suffix();
+    bin_bmin_suffix(L.bmin, L.wsum, tid);
   }
   __syncthreads();
   // the cull records of the list's first kQRec entries, in list order, over the (now dead) unordered keys
@@ -835,7 +895,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
     // the entry's depth key, as the gather computed it (same record, same cone: the same bits)
     const float v = (word & 0x80000000u) ? fmaf(cr.z, qcone.az, fmaf(cr.y, qcone.ay, cr.x * qcone.ax)) + 0.0f
                                          : depth_key(cr, qcone);
-    return len_bound_key(v);
+    return bin_len_bound(Kk, L.bmin, v);
   };
 
   // ---- the four sweep tiles: wave w filters the ordered list (in LDS, records included) with the bounding cone of

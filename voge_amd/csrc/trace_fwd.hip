@@ -401,7 +401,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             }
           }
 #endif
-          topk_commit(mykeys, TP, K, cnt, worst, tail, key, take);
+#ifndef VOGE_ISO_ROWS4
+#define VOGE_ISO_ROWS4 0
+#endif
+          topk_commit<(!ISO) || (VOGE_ISO_ROWS4 != 0)>(mykeys, TP, K, cnt, worst, tail, key, take);
         };
 #ifdef VOGE_SWEEP_STATS
         st_eval += __popcll(m); ++st_batches;
