@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--anisotropic", action="store_true", help="full [N,3,3] Sigma^-1 (L L^T) instead of scalar sigmas")
     ap.add_argument("--default-bins", action="store_true", help="max_point_per_bin=None (the demos' default) instead of -1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--diagonal", action="store_true", help="(N,3) per-axis Sigma^-1 instead of scalar sigmas")
     ap.add_argument("--no-variants", action="store_true", help="skip the anisotropic / default-bins variant frames")
     ap.add_argument("--balance-rounds", type=int, default=4,
                     help="multi-GPU: measure -> rebalance rounds of the row bands before the timed region (0: equal-height bands)")
@@ -351,7 +352,7 @@ def main():
             dt = float(tt.item())
         return dt
 
-    fwd, params, gm, colors, host_scene = make_frame(args.anisotropic, args.default_bins)
+    fwd, params, gm, colors, host_scene = make_frame("diag" if args.diagonal else args.anisotropic, args.default_bins)
     balance_log = []
     if args.only_stage and args.only_stage != "frame":      # ("frame": the frame alone, no stand-alone stage calls)
         run, launch = (lambda: None), "none (--only-stage)"
@@ -452,7 +453,7 @@ def main():
     ms = dt / args.steps * 1e3
     fps = (world if by_views else 1) * args.steps / dt      # (views mode: every step renders `world` frames, one per rank)
 
-    sig_kind = "[N,3,3] L L^T sigmas" if args.anisotropic else "scalar sigmas"
+    sig_kind = "(N,3) per-axis sigmas" if args.diagonal else ("[N,3,3] L L^T sigmas" if args.anisotropic else "scalar sigmas")
     bins_kind = "None (default)" if args.default_bins else "-1"
     result = {
         "metric": "forward+backward frames/sec at 512^2, 50k Gaussians; ray-trace HBM GB/s vs peak",
@@ -648,6 +649,7 @@ def main():
             # the same step on the metric's stated variants: full 3x3 forms; the demos' default bins
             variants = {}
             for vname, (an, db, pat) in (("anisotropic_3x3", (True, False, "white_background")),
+                                         ("diagonal_Nx3", ("diag", False, "white_background")),      # (EfficientCuboidViaOptimization's form)
                                          ("max_point_per_bin_None", (False, True, "white_background")),
                                          # what the reference's training loops differentiate (ShapeFitting.py:217,295)
                                          ("interpolate_attr_and_silhouette", (False, False, "attr_and_silhouette"))):

@@ -207,6 +207,14 @@ int voge_bin_gaussians(const float *points, const int64_t *cloud_to_packed_first
  * for the weights alone, or voge_composite_shade_fwd_iso for the weights AND the image of to_colored_background in one
  * pass (GaussianRenderer returns its Fragments before the colours are known: the Python side defers the composite
  * until the fragments' weights are first asked for, voge_amd/Renderer.py). */
+/* TRACE ONLY for the general forms (mus [P,3], isigmas [P,3,3]): idx, len, cnt and `records` -- the packed (mu, A),
+ * [B*N][12] floats -- are written; voge_composite_fwd_rec / voge_composite_shade_fwd_rec composite later from them, and
+ * voge_fragment_shade_bwd / voge_fragment_bwd / voge_fragment_merge_bwd take act = dsd = NULL for such fragments.
+ * Replaces the same reference code as voge_fragments_fwd (RayTracing.py:17-59 + ray_trace_voge.cu:219-280), deferred. */
+int voge_trace_lean_fwd(const float *mus, const float *isigmas, const float *rays, const float *cam_fwd,
+                        const float *cones, int B, int N, int H, int W, int K, float thr_act, void *workspace,
+                        size_t workspace_bytes, int32_t *idx, float *len, int32_t *cnt, float *records,
+                        voge_stream_t stream);
 int voge_fragments_fwd(const float *mus, const float *isigmas, const float *rays, const float *cam_fwd,
                        const float *cones, int B, int N, int H, int W, int K, float thr_act, float occ,
                        void *workspace, size_t workspace_bytes, int32_t *idx, float *len, float *act, float *dsd,
@@ -256,6 +264,17 @@ int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *
                                  const float *rays, float occ, const float *colors, const float *bg, float thr,
                                  long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num, float *rgb,
                                  float *img, float *wsum, voge_stream_t stream);
+/* The two composite entry points above for the GENERAL path: records = the packed (mu, A) [B*N][12] of voge_trace_lean_fwd
+ * (act / dsd re-derived with make_eval + pair_eval, the operations of the sweep's own epilogue: bit-identical weights).
+ * act / dsd [npix,K] (both or NULL): written for the live slots when given -- the fused backward reads 8 bytes per slot
+ * rather than gathering 48 and evaluating again. */
+int voge_composite_fwd_rec(int32_t *idx, const int32_t *cnt, const float *len, const float *records, const float *rays,
+                           float occ, long npix, int K, float *weight, int64_t *valid_num, float *act, float *dsd,
+                           voge_stream_t stream);
+int voge_composite_shade_fwd_rec(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                                 const float *rays, float occ, const float *colors, const float *bg, float thr,
+                                 long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num, float *rgb,
+                                 float *img, float *wsum, float *act, float *dsd, voge_stream_t stream);
 /* The same for full 3x3 forms (mus [P,3], isigmas [P,3,3] as given to voge_fragments_fwd; P = B*N): writes g_mus
  * [P,3], g_isigmas [P,3,3] (the raw, unsymmetrised outer-product sums of ray_trace_voge.cu:324-326, as voge_trace_bwd)
  * -- both or neither -- and g_colors [Nattr,C].  Same constraints and workspace as the isotropic form. */
@@ -278,6 +297,12 @@ int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int s
  * g_wsum [nrows*W] or NULL = the gradient of the per-pixel weight sum (get_silhouette = min(sum, 1) of the same fragments),
  * then composite and trace as above -- the reference's training pattern (demo/ShapeFitting.py:217,295) as ONE kernel.
  * attr [Nattr,C], C <= 4, K <= 128.  Writes g_verts / g_sigmas (both or neither) and g_attr [Nattr,C]. */
+int voge_fragment_merge_bwd(const float *mus, const float *isigmas, const float *rays, const float *attr,
+                            const int32_t *idx, const int32_t *cnt, const float *weight, const float *act,
+                            const float *len, const float *dsd, const float *g_rgb, long g_stride_pix,
+                            long g_stride_c, const float *g_wsum, float occ, int P, long nrows, int W, int K, int C,
+                            long Nattr, void *workspace, size_t workspace_bytes, float *g_mus, float *g_isigmas,
+                            float *g_attr, voge_stream_t stream);      /* (the general 3x3 form of the entry point below) */
 int voge_fragment_merge_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
                                 const float *rays, const float *attr, const int32_t *idx, const int32_t *cnt,
                                 const float *weight, const float *act, const float *len, const float *dsd,

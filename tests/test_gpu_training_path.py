@@ -333,10 +333,16 @@ def test_fragment_views_keep_the_fast_paths(hip_lib, monkeypatch):
 
 
 # ----------------------------------------------------------------------------------------------- closing self-comparisons
-@pytest.mark.parametrize("form,K", [("full", 20), ("full", 33), ("diag", 12)])
-def test_shade_through_general_forms_vs_oracle(hip_lib, form, K):
+@pytest.mark.parametrize("form,K,lazy", [("full", 20, True), ("full", 33, True), ("diag", 12, True), ("full", 20, False),
+                                         ("diag", 12, False), ("full", 20, "noad"), ("diag", 12, "noad")])
+def test_shade_through_general_forms_vs_oracle(hip_lib, monkeypatch, form, K, lazy):
     """voge_fragment_shade_bwd (full 3x3 forms: to_colored_background on this renderer's fragments, ONE backward kernel)
-    directly against the oracle chain -- round 2 compared it with this repo's own three kernels only."""
+    directly against the oracle chain -- round 2 compared it with this repo's own three kernels only.  lazy: the composite
+    is deferred (voge_trace_lean_fwd keeps the packed (mu, A) records, voge_composite_shade_fwd_rec composites and shades in
+    one pass, the backward re-derives act / dsd); otherwise the eager chain with act / dsd in memory (VOGE_LAZY_GENERAL=0)."""
+    monkeypatch.setenv("VOGE_LAZY_GENERAL", "1" if lazy else "0")
+    # ("noad": the deferred composite keeps no act / dsd either; the backward re-derives them from the packed (mu, A))
+    monkeypatch.setenv("VOGE_GENERAL_KEEP_ACT_DSD", "0" if lazy == "noad" else "1")
     from voge_amd.Meshes import GaussianMeshes
     from voge_amd.Renderer import to_colored_background
     N, H, W = 2000, 56, 72
@@ -350,7 +356,7 @@ def test_shade_through_general_forms_vs_oracle(hip_lib, form, K):
     colors = t(cols, rg=True)
     frag = renderer(gm, R=t(R), T=t(T))
     img = to_colored_background(frag, colors, background_color=bg)
-    assert type(img.grad_fn).__name__ == "_ShadeThroughBackward"      # (full forms: the composite is not deferred)
+    assert type(img.grad_fn).__name__ == ("_CompositeShadeBackward" if lazy else "_ShadeThroughBackward")
     ref = oracle_frame(verts, sig, R, T, 80.0, (W / 2.0, H / 2.0), (H, W), K)
     same = same_lists(frag, ref, f"shade-through {form} K={K}", max_flips=8)
     rgb = oracle.merge_fwd(cols, ref["idx"], ref["weight"], ref["valid_num"])

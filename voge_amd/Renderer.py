@@ -211,8 +211,12 @@ class GaussianRenderer(nn.Module):
             if sigmas.dim() == 3:
                 sigmas = sigmas.unsqueeze(0).expand(B, -1, -1, -1)
             isigma = 2 * torch.inverse(sigmas) if st['inverse_sigma'] else 2 * sigmas
-            weight, index, valid_num, hit_len = ops.fragments(0, centred.reshape(-1, 3), isigma.reshape(-1, 3, 3), None, rays,
-                                                              cam_fwd, thr_act, K, 0, occ)
+            mus0, isg0 = centred.reshape(-1, 3), isigma.reshape(-1, 3, 3)
+            if ops.lazy_eligible(0, mus0, isg0, None, rays, K):
+                # (full 3x3 forms defer their composite too: the sweep keeps the packed (mu, A) records instead of act / dsd)
+                index, hit_len, lz = ops.trace_lean(0, mus0, isg0, None, rays, cam_fwd, thr_act, K, 0, occ)
+                return Fragments(None, index, None, hit_len, _lazy=lz)
+            weight, index, valid_num, hit_len = ops.fragments(0, mus0, isg0, None, rays, cam_fwd, thr_act, K, 0, occ)
         # merge_final later rewrites -1 -> 0 inside the fragments' index tensor.  The reference clones
         # it here (Renderer.py:145) because its backward finds empty slots by idx == -1; this trace
         # backward uses the per-pixel hit count instead, so no copy is needed.

@@ -45,6 +45,12 @@ SIGNATURES = {
     "voge_fragment_act_dsd_iso": (_c_int, [_c_void_p] * 5 + [_c_long, _c_int, _c_int] + [_c_void_p] * 3),
     "voge_composite_shade_fwd_iso": (_c_int, [_c_void_p] * 5 + [_c_float, _c_void_p, _c_void_p, _c_float, _c_long, _c_int, _c_int, _c_long]
                                      + [_c_void_p] * 6),
+    "voge_composite_shade_fwd_rec": (_c_int, [_c_void_p] * 5 + [_c_float, _c_void_p, _c_void_p, _c_float, _c_long, _c_int, _c_int, _c_long]
+                                     + [_c_void_p] * 8),
+    "voge_composite_fwd_rec": (_c_int, [_c_void_p] * 5 + [_c_float, _c_long, _c_int] + [_c_void_p] * 5),
+    "voge_trace_lean_fwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_float, _c_void_p, _c_size_t] + [_c_void_p] * 5),
+    "voge_fragment_merge_bwd": (_c_int, [_c_void_p] * 11 + [_c_long, _c_long, _c_void_p, _c_float, _c_int, _c_long, _c_int, _c_int, _c_int,
+                                                             _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),
     "voge_composite_fwd_iso": (_c_int, [_c_void_p] * 5 + [_c_float, _c_long, _c_int] + [_c_void_p] * 3),
     "voge_fragment_shade_bwd": (_c_int, [_c_void_p] * 13 + [_c_float, _c_void_p, _c_long, _c_long, _c_float]
                                 + [_c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),

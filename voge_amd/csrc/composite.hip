@@ -353,7 +353,9 @@ struct CompShade {
   float *rgb, *img, *wsum;
   int32_t *idx_fix;
 };
-template <int MODE, int NS, bool WAVE, typename OffT, int SC = 0>   // MODE 0: forward, 2: backward with weights; OffT: composite_core.h at_bytes
+// GEN (forward from the records): the records are the general path's packed (mu, A), three float4 per Gaussian
+// (voge_trace_lean_fwd); act / dsd come from make_eval + pair_eval, the operations of the sweep's own epilogue.
+template <int MODE, int NS, bool WAVE, typename OffT, int SC = 0, bool GEN = false>   // MODE 0: forward, 2: backward with weights; OffT: composite_core.h at_bytes
 __global__ void __launch_bounds__(kCompThreads) __attribute__((amdgpu_waves_per_eu(VOGE_COMP_WPE)))
 compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
                   const float *__restrict__ len, const float *__restrict__ dsd,
@@ -456,9 +458,12 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
         const v2f l2 = at_bytes<v2f>(len, fb);
         iv[0] = i2.x; iv[1] = i2.y; lv[0] = l2.x; lv[1] = l2.y;
       }
-      float4 rc[NS];
+      float4 rc[NS][GEN ? 3 : 1];
 #pragma unroll
-      for (int a = 0; a < NS; ++a) rc[a] = (k0 + a < lead) ? at_bytes<float4>(rec, (uint32_t)iv[a] * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int a = 0; a < NS; ++a)
+#pragma unroll
+        for (int r = 0; r < (GEN ? 3 : 1); ++r)
+          rc[a][r] = (k0 + a < lead) ? at_bytes<float4>(rec, (uint32_t)iv[a] * (GEN ? 48u : 16u) + 16u * r) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (SC > 0) {
 #pragma unroll
         for (int a = 0; a < NS; ++a) ivk[a] = (k0 + a < lead) ? iv[a] : -1;
@@ -466,7 +471,18 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
         if (k0 + a < lead) {
-          const PairOut o = pair_eval_iso_at(rc[a].x, rc[a].y, rc[a].z, rc[a].w, lv[a], d.x, d.y, d.z, dn2);
+          PairOut o;
+          if (GEN) {
+            const float4 r0 = rc[a][0], r1 = rc[a][GEN ? 1 : 0], r2 = rc[a][GEN ? 2 : 0];
+            const float A[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+            o = pair_eval(r0.x, r0.y, r0.z, make_eval(r0.x, r0.y, r0.z, A), d.x, d.y, d.z, d.x * d.x, d.y * d.y, d.z * d.z,
+                          d.x * d.y, d.x * d.z, d.y * d.z);
+            // (optional: act / dsd kept for the fused backward, which is VALU-bound and would rather read 8 bytes per slot
+            // than gather 48 and evaluate again: out1 / out2 are free in the forward)
+            if (out1 != nullptr) { out1[f + a] = o.act; out2[f + a] = o.dsd; }
+          } else {
+            o = pair_eval_iso_at(rc[a][0].x, rc[a][0].y, rc[a][0].z, rc[a][0].w, lv[a], d.x, d.y, d.z, dn2);
+          }
           em[a] = FAST_EXP(-o.act); lm[a] = lv[a]; sm[a] = FAST_SQRT(o.dsd + 1e-10f);
         }
       }
@@ -1029,17 +1045,20 @@ extern "C" int voge_composite_fwd_iso(const int32_t *idx, const int32_t *cnt, co
 }
 
 // Composite forward (from the records) with the shade stage in the same pass: weights, valid_num AND the image.
-extern "C" int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
-                                            const float *rays, float occ, const float *colors, const float *bg, float thr,
-                                            long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
-                                            float *rgb, float *img, float *wsum, voge_stream_t stream) {
+// gen: the records are the general path's packed (mu, A) (voge_trace_lean_fwd) instead of (mu, a).  C = 0: no shade stage.
+static int composite_shade_fwd_impl(const bool gen, int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                                    const float *rays, float occ, const float *colors, const float *bg, float thr,
+                                    long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
+                                    float *rgb, float *img, float *wsum, voge_stream_t stream, float *act_out = nullptr,
+                                    float *dsd_out = nullptr) {
+  if ((act_out == nullptr) != (dsd_out == nullptr)) return VOGE_ERR_BAD_ARG;
   if (npix < 0 || K <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
-  if (K > VOGE_MAX_K || (C != 3 && C != 4)) return VOGE_ERR_K_TOO_LARGE;      // four slots per lane (any K: a last group may be short); RGB / RGBA
+  if (K > VOGE_MAX_K || (C != 0 && C != 3 && C != 4)) return VOGE_ERR_K_TOO_LARGE;      // four slots per lane (any K: a last group may be short); RGB / RGBA
   if (npix == 0) return 0;
   // (img == NULL: merge_final + the weight sum only -- interpolate_attr and get_silhouette, no background; bg unused)
-  if (!idx || !cnt || !len || !records || !rays || !weight || !valid_num || !rgb || !wsum || (img && !bg) || (Nattr > 0 && !colors))
-    return VOGE_ERR_BAD_ARG;
-  if (Nattr * C >= (1l << 30)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the colour gathers
+  if (!idx || !cnt || !len || !records || !rays || !weight || !valid_num) return VOGE_ERR_BAD_ARG;
+  if (C > 0 && (!rgb || !wsum || (img && !bg) || (Nattr > 0 && !colors))) return VOGE_ERR_BAD_ARG;
+  if (Nattr * (C > 0 ? C : 1) >= (1l << 30)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the colour gathers
   constexpr int NS = 4;
   const int tn = VOGE_COMP_WAVE_T;
   const int ppwn = compn_pixels(K, NS, tn, true);
@@ -1049,13 +1068,43 @@ extern "C" int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, co
   const CompShade sh{colors, bg, thr, Nattr, rgb, img, wsum, idx};
   hipStream_t st = (hipStream_t)stream;
   const float4 *rec = reinterpret_cast<const float4 *>(records);
-#define VOGE_LAUNCH_CS(OT, CC)                                                                                               \
-  hipLaunchKernelGGL((compositen_kernel<0, NS, true, OT, CC>), gridn, blockn, ldsn, st, idx, nullptr, len, nullptr, nullptr, nullptr, \
-                     cnt, occ, npix, K, ppwn, weight, nullptr, nullptr, valid_num, rec, rays, sh)
-  if (C == 3) { if (small) VOGE_LAUNCH_CS(uint32_t, 3); else VOGE_LAUNCH_CS(size_t, 3); }
-  else { if (small) VOGE_LAUNCH_CS(uint32_t, 4); else VOGE_LAUNCH_CS(size_t, 4); }
+#define VOGE_LAUNCH_CS(OT, CC, GG)                                                                                           \
+  hipLaunchKernelGGL((compositen_kernel<0, NS, true, OT, CC, GG>), gridn, blockn, ldsn, st, idx, nullptr, len, nullptr, nullptr, nullptr, \
+                     cnt, occ, npix, K, ppwn, weight, act_out, dsd_out, valid_num, rec, rays, sh)
+#define VOGE_LAUNCH_CS2(CC, GG) do { if (small) VOGE_LAUNCH_CS(uint32_t, CC, GG); else VOGE_LAUNCH_CS(size_t, CC, GG); } while (0)
+  if (gen) {
+    if (C == 3) VOGE_LAUNCH_CS2(3, true); else if (C == 4) VOGE_LAUNCH_CS2(4, true); else VOGE_LAUNCH_CS2(0, true);
+  } else {
+    if (C == 3) VOGE_LAUNCH_CS2(3, false); else if (C == 4) VOGE_LAUNCH_CS2(4, false); else VOGE_LAUNCH_CS2(0, false);
+  }
+#undef VOGE_LAUNCH_CS2
 #undef VOGE_LAUNCH_CS
   return launch_status();
+}
+
+extern "C" int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                                            const float *rays, float occ, const float *colors, const float *bg, float thr,
+                                            long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
+                                            float *rgb, float *img, float *wsum, voge_stream_t stream) {
+  if (C != 3 && C != 4) return VOGE_ERR_K_TOO_LARGE;
+  return composite_shade_fwd_impl(false, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
+                                  rgb, img, wsum, stream);
+}
+
+// The same two for the general path: records = the packed (mu, A) [B*N][12] of voge_trace_lean_fwd.
+extern "C" int voge_composite_shade_fwd_rec(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                                            const float *rays, float occ, const float *colors, const float *bg, float thr,
+                                            long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
+                                            float *rgb, float *img, float *wsum, float *act, float *dsd, voge_stream_t stream) {
+  if (C != 3 && C != 4) return VOGE_ERR_K_TOO_LARGE;
+  return composite_shade_fwd_impl(true, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
+                                  rgb, img, wsum, stream, act, dsd);
+}
+extern "C" int voge_composite_fwd_rec(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                                      const float *rays, float occ, long npix, int K, float *weight, int64_t *valid_num,
+                                      float *act, float *dsd, voge_stream_t stream) {
+  return composite_shade_fwd_impl(true, idx, cnt, len, records, rays, occ, nullptr, nullptr, -1.0f, npix, K, 0, 0, weight,
+                                  valid_num, nullptr, nullptr, nullptr, stream, act, dsd);
 }
 
 extern "C" int voge_composite_bwd(const float *act, const float *len, const float *dsd, const float *weight,

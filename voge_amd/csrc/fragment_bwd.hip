@@ -82,8 +82,8 @@ struct FragBwdLds {
 // OffT: uint32_t when every BYTE offset into the [pix][K] arrays fits 32 bits (the loads
 // then take scalar base + 32-bit lane offset and the address arithmetic leaves the vector unit), else size_t.
 // ISO: every Gaussian is A = a I (rec = [P] (mu, a)); otherwise rec = [P][3] packed (mu, A) as in trace_bwd.hip.
-// NOAD (ISO only): the forward kept no act / dsd (voge_fragments_fwd_iso* with act = dsd = NULL); they are re-derived
-// from the records, the ray and len with the forward's own operations (pair_eval_iso_at): 8 bytes per slot less to read.
+// NOAD: the forward kept no act / dsd (voge_fragments_fwd_iso* with act = dsd = NULL, voge_trace_lean_fwd); they are re-derived
+// from the records, the ray and len with the forward's own operations (pair_eval_iso_at / pair_eval): 8 bytes per slot less to read.
 // K need not be a multiple of NS: `vec` (uniform) says whether a lane's group is aligned and inside its pixel's row
 // (wide loads) or is read slot by slot.
 template <int SRC, int C, int NS, typename OffT, bool ISO, bool NOAD>
@@ -195,7 +195,7 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
         }
       }
     }
-    if (NOAD) {                 // act / dsd from the records (gathered here once, used again by the trace terms below)
+    if (NOAD && ISO) {          // act / dsd from the records (gathered here once, used again by the trace terms below)
       const float dn2f = (dx * dx + dy * dy) + dz * dz;      // the forward's association
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
@@ -203,6 +203,22 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
         rc[a][0] = ok ? at_bytes<float4>(rec, (uint32_t)id[a] * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
           const PairOut o = pair_eval_iso_at(rc[a][0].x, rc[a][0].y, rc[a][0].z, rc[a][0].w, lm[a], dx, dy, dz, dn2f);
+          em[a] = FAST_EXP(-o.act); sm[a] = FAST_SQRT(o.dsd + 1e-10f);
+        }
+      }
+    }
+    if (NOAD && !ISO) {         // general forms: the same from the packed (mu, A) records, with the forward's operations
+      // (make_eval + pair_eval, as the deferred composite; the 48-byte records are gathered AGAIN for the trace terms below
+      // rather than held across the composite: 24 registers)
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const bool ok = live[a] && id[a] >= 0 && id[a] < P;
+        if (ok) {
+          const uint32_t ro = (uint32_t)id[a] * 48u;
+          const float4 r0 = at_bytes<float4>(rec, ro), r1 = at_bytes<float4>(rec, ro + 16u), r2 = at_bytes<float4>(rec, ro + 32u);
+          const float A[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+          const PairOut o = pair_eval(r0.x, r0.y, r0.z, make_eval(r0.x, r0.y, r0.z, A), dx, dy, dz, dx * dx, dy * dy, dz * dz,
+                                      dx * dy, dx * dz, dy * dz);
           em[a] = FAST_EXP(-o.act); sm[a] = FAST_SQRT(o.dsd + 1e-10f);
         }
       }
@@ -295,7 +311,7 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     }
     // ---- trace backward terms (isotropic: trace_bwd.hip) + the colour term, one table entry per Gaussian.  (The
     // (mu, a) records are gathered only now: held across the composite they cost the kernel a wave per SIMD.) ----
-    if (!NOAD)
+    if (!NOAD || !ISO)
 #pragma unroll
     for (int a = 0; a < NS; ++a)
 #pragma unroll
@@ -524,7 +540,7 @@ void fb_launch(const FbArgs &a, hipStream_t st) {
 template <int SRC, int C, int NS, bool ISO>
 void fb_launch_off(const FbArgs &a, hipStream_t st) {
   const bool small = (double)a.nrows * a.W * a.K < (double)(1l << 30);      // every byte offset fits 32 bits
-  if (ISO && a.act == nullptr) { if (small) fb_launch<SRC, C, NS, uint32_t, ISO, ISO>(a, st); else fb_launch<SRC, C, NS, size_t, ISO, ISO>(a, st); }
+  if (a.act == nullptr) { if (small) fb_launch<SRC, C, NS, uint32_t, ISO, true>(a, st); else fb_launch<SRC, C, NS, size_t, ISO, true>(a, st); }
   else { if (small) fb_launch<SRC, C, NS, uint32_t, ISO, false>(a, st); else fb_launch<SRC, C, NS, size_t, ISO, false>(a, st); }
 }
 template <bool ISO>
@@ -589,9 +605,9 @@ extern "C" int voge_fragment_shade_bwd(const float *mus, const float *isigmas, c
     if (g_colors && Nattr > 0) return (int)voge_fill_async(g_colors, 0, sizeof(float) * (size_t)Nattr * C, st);
     return 0;
   }
-  if (!mus || !isigmas || !rays || !colors || !idx || !cnt || !weight || !act || !len || !dsd || !rgb || !wsum || !bg || !g_img ||
-      !workspace)
+  if (!mus || !isigmas || !rays || !colors || !idx || !cnt || !weight || !len || !rgb || !wsum || !bg || !g_img || !workspace)
     return VOGE_ERR_BAD_ARG;
+  if ((act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;      // both or neither (neither: re-derived from (mu, A))
   if ((g_mus == nullptr) != (g_isigmas == nullptr)) return VOGE_ERR_BAD_ARG;
   if (workspace_bytes < voge_fragment_bwd_workspace_bytes(P)) return VOGE_ERR_WORKSPACE;
   if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
@@ -605,6 +621,38 @@ extern "C" int voge_fragment_shade_bwd(const float *mus, const float *isigmas, c
   const long n_fin = (Nattr > P) ? Nattr : P;
   hipLaunchKernelGGL(fragment_bwd_finish_general_kernel, dim3((unsigned)((n_fin * 16 + 255) / 256)), dim3(256), 0, st, acc, 16, P, C,
                      Nattr, g_mus, g_isigmas, g_colors);
+  return launch_status();
+}
+
+// The merge form (below) for general 3x3 forms: interpolate_attr (+ get_silhouette) on the fragments of voge_trace_lean_fwd.
+extern "C" int voge_fragment_merge_bwd(const float *mus, const float *isigmas, const float *rays, const float *attr,
+                                       const int32_t *idx, const int32_t *cnt, const float *weight, const float *act,
+                                       const float *len, const float *dsd, const float *g_rgb, long g_stride_pix,
+                                       long g_stride_c, const float *g_wsum, float occ, int P, long nrows, int W, int K, int C,
+                                       long Nattr, void *workspace, size_t workspace_bytes, float *g_mus, float *g_isigmas,
+                                       float *g_attr, voge_stream_t stream) {
+  if (P < 0 || nrows < 0 || W < 0 || K <= 0 || C <= 0 || C > 4 || Nattr < 0) return VOGE_ERR_BAD_ARG;
+  if (K > 128) return VOGE_ERR_K_TOO_LARGE;
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 0 || nrows * W == 0) {
+    if (g_attr && Nattr > 0) return (int)voge_fill_async(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
+    return 0;
+  }
+  if (!mus || !isigmas || !rays || !attr || !idx || !cnt || !weight || !len || !g_rgb || !workspace) return VOGE_ERR_BAD_ARG;
+  if ((act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;
+  if ((g_mus == nullptr) != (g_isigmas == nullptr)) return VOGE_ERR_BAD_ARG;
+  if (workspace_bytes < voge_fragment_bwd_workspace_bytes(P)) return VOGE_ERR_WORKSPACE;
+  if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;
+  float4 *rec = reinterpret_cast<float4 *>(workspace);
+  float *acc = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (size_t)P * 48);
+  hipLaunchKernelGGL(fragment_bwd_pack_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, mus, isigmas, P, rec,
+                     reinterpret_cast<float4 *>(acc), 4);
+  const FbArgs a{rec, rays, attr, idx, cnt, weight, act, len, dsd, nullptr, g_wsum, nullptr, -1.0f, g_rgb, g_stride_pix, g_stride_c,
+                 nullptr, occ, P, nrows, W, K, Nattr, acc};
+  fb_launch_shade<false>(a, C, st);
+  const long n_fin = (Nattr > P) ? Nattr : P;
+  hipLaunchKernelGGL(fragment_bwd_finish_general_kernel, dim3((unsigned)((n_fin * 16 + 255) / 256)), dim3(256), 0, st, acc, 16, P, C,
+                     Nattr, g_mus, g_isigmas, g_attr);
   return launch_status();
 }
 
@@ -691,7 +739,8 @@ extern "C" int voge_fragment_bwd(const float *mus, const float *isigmas, const f
     if (e0 == hipSuccess) e0 = voge_fill_async(g_isigmas, 0, sizeof(float) * 9 * (size_t)P, st);
     return (int)e0;
   }
-  if (!mus || !isigmas || !rays || !idx || !cnt || !weight || !act || !len || !dsd || !workspace) return VOGE_ERR_BAD_ARG;
+  if (!mus || !isigmas || !rays || !idx || !cnt || !weight || !len || !workspace) return VOGE_ERR_BAD_ARG;
+  if ((act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;      // both or neither (neither: re-derived from (mu, A))
   if (workspace_bytes < voge_fragment_bwd_workspace_bytes(P)) return VOGE_ERR_WORKSPACE;
   if (P >= (1 << 26)) return VOGE_ERR_BAD_ARG;
   float4 *rec = reinterpret_cast<float4 *>(workspace);

@@ -33,7 +33,8 @@ __device__ inline double lambda_min_sym3(double a00, double a11, double a22, dou
 __device__ __forceinline__ void prep_one(const int g, const float *__restrict__ mus, const float *__restrict__ isg,
                                          const float *__restrict__ cam_fwd, const int N, const float thr_act,
                                          const int iso_in, float4 *__restrict__ cull, float4 *__restrict__ evr,
-                                         float4 *__restrict__ ms, float4 *__restrict__ ell, const IsoView view) {
+                                         float4 *__restrict__ ms, float4 *__restrict__ ell, const IsoView view,
+                                         float4 *__restrict__ pk = nullptr /* [P][3] packed (mu, A): kept by the caller */) {
   float mx, my, mz;
   const int src = view.shared ? g % N : g;
   if (view.origin != nullptr) {   // centring of Renderer.py:130 done here: the same single fp32 subtraction
@@ -52,6 +53,11 @@ __device__ __forceinline__ void prep_one(const int g, const float *__restrict__ 
     for (int i = 0; i < 9; ++i) A[i] = isg[9 * (size_t)g + i];
   }
   const EvalRec e = make_eval(mx, my, mz, A);
+  if (pk != nullptr) {      // what the deferred composite and the fused backward gather (fragment_bwd.hip's record layout)
+    pk[3 * (size_t)g + 0] = make_float4(mx, my, mz, A[0]);
+    pk[3 * (size_t)g + 1] = make_float4(A[1], A[2], A[3], A[4]);
+    pk[3 * (size_t)g + 2] = make_float4(A[5], A[6], A[7], A[8]);
+  }
 
   const double lmin = lambda_min_sym3(A[0], A[4], A[8], 0.5 * ((double)A[1] + A[3]),
                                       0.5 * ((double)A[2] + A[6]), 0.5 * ((double)A[5] + A[7]));
@@ -122,9 +128,9 @@ __device__ __forceinline__ EvalRec unpack_eval(const float4 a, const float4 b, c
 __global__ void __launch_bounds__(256)
 prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const float *__restrict__ cam_fwd, const int N,
             const int P, const float thr_act, float4 *__restrict__ cull, float4 *__restrict__ evr,
-            float4 *__restrict__ ms, float4 *__restrict__ ell) {
+            float4 *__restrict__ ms, float4 *__restrict__ ell, float4 *__restrict__ pk) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < P) prep_one(g, mus, isg, cam_fwd, N, thr_act, 0, cull, evr, ms, ell, IsoView{nullptr, 0, 0});
+  if (g < P) prep_one(g, mus, isg, cam_fwd, N, thr_act, 0, cull, evr, ms, ell, IsoView{nullptr, 0, 0}, pk);
 }
 
 }  // namespace voge
@@ -713,7 +719,8 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     // together for kEpiG items -- one round trip per round instead of "centre, then 3 more per slot".
     // (pair_eval dispatches on the record, so an isotropic entry in such a tile is still exact.)
     constexpr int kEpiG = 2;
-    for (int it0 = tid; tile_gen && it0 < nitem; it0 += T * kEpiG) {
+    const bool want_ad = out_act != nullptr;
+    for (int it0 = tid; tile_gen && want_ad && it0 < nitem; it0 += T * kEpiG) {
       uint64_t key[kEpiG][4];
       float4 rc[kEpiG][4], g0[kEpiG][4], g1[kEpiG][4], g2[kEpiG][4];
       float ex[kEpiG], ey[kEpiG], ez[kEpiG];
@@ -777,8 +784,7 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
     // Fragment mode without act / dsd (out_act == NULL; voge_fragments_fwd_iso*): index and len are the key itself --
     // no gather, no ray, no arithmetic; the composite kernel behind the sweep derives act / dsd from the same
     // records with the same operations (composite.hip), at its own, much higher residency.
-    const bool want_ad = out_act != nullptr;
-    for (int it0 = tid; !tile_gen && !want_ad && it0 < nitem; it0 += T * kEpiU) {
+    for (int it0 = tid; !want_ad && it0 < nitem; it0 += T * kEpiU) {
 #pragma unroll
       for (int u = 0; u < kEpiU; ++u) {
         const int it = it0 + u * T;
@@ -1206,7 +1212,9 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   if (!rays || !idx || !len || !workspace || (act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;
   // act / dsd may be omitted by the scalar-sigma fragment entry points only (they are re-derived where needed)
   // (with weights: composited behind the sweep; without: records kept, the caller composites later)
-  if (act == nullptr && !(iso_in && (weight != nullptr || records != nullptr) && cnt != nullptr && (long)B * N < (1l << 26)))
+  // (general forms: trace only, with the packed (mu, A) records kept for the deferred composite -- voge_trace_lean_fwd)
+  if (act == nullptr && !((iso_in ? (weight != nullptr || records != nullptr) : (weight == nullptr && records != nullptr)) &&
+                          cnt != nullptr && (long)B * N < (1l << 26)))
     return VOGE_ERR_BAD_ARG;
   if (N > 0 && (!mus || !isigmas)) return VOGE_ERR_BAD_ARG;
   if (workspace_bytes < voge_trace_workspace_bytes(B, N, H, W)) return VOGE_ERR_WORKSPACE;
@@ -1216,7 +1224,7 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   const int P = B * N;
   TraceWs ws;
   trace_ws_layout(B, N, H, W, workspace, &ws);
-  if (records != nullptr) ws.ms = reinterpret_cast<float4 *>(records);      // the caller keeps the (centre, a) records (backward)
+  if (records != nullptr && iso_in) ws.ms = reinterpret_cast<float4 *>(records);      // the caller keeps the (centre, a) records (backward)
   // super-tile cones: the caller's (voge_rays_fwd makes them while it makes the rays), or one more launch here
   const ConeRec *cones = reinterpret_cast<const ConeRec *>(cones_in);
   if (cones == nullptr) {
@@ -1232,7 +1240,7 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   } else {
     if (P > 0)
       hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P, thr_act, ws.cull,
-                         ws.evr, ws.ms, ws.ell);
+                         ws.evr, ws.ms, ws.ell, reinterpret_cast<float4 *>(records));
     hipLaunchKernelGGL(binA_kernel<false>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
                        cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top);
   }
@@ -1313,6 +1321,17 @@ extern "C" int voge_trace_topk_fwd_iso_view(const float *verts, const float *sig
   if (sigma_mode < 0 || sigma_mode > 2) return VOGE_ERR_BAD_ARG;
   return trace_topk_fwd_impl(1, IsoView{origin, shared ? 1 : 0, sigma_mode}, verts, sigmas, rays, cam_fwd, cones, B, N, H, W, K,
                              thr_act, workspace, workspace_bytes, idx, len, act, dsd, cnt, stream);
+}
+
+// ---- the general trace alone (no act / dsd, no composite): index, len, hit counts, and the packed (mu, A) records
+// [B*N][12] the deferred composite (voge_composite_fwd_rec / voge_composite_shade_fwd_rec) and the fused backward read ----
+extern "C" int voge_trace_lean_fwd(const float *mus, const float *isigmas, const float *rays, const float *cam_fwd,
+                                   const float *cones, int B, int N, int H, int W, int K, float thr_act, void *workspace,
+                                   size_t workspace_bytes, int32_t *idx, float *len, int32_t *cnt, float *records,
+                                   voge_stream_t stream) {
+  if (!cnt || !records) return VOGE_ERR_BAD_ARG;
+  return trace_topk_fwd_impl(0, IsoView{nullptr, 0, 0}, mus, isigmas, rays, cam_fwd, cones, B, N, H, W, K, thr_act, workspace,
+                             workspace_bytes, idx, len, nullptr, nullptr, cnt, stream, 1.0f, nullptr, nullptr, records);
 }
 
 // ---- trace + composite in one call: fragments (weight, idx, valid_num, len) plus act / dsd / cnt for the backward ----

@@ -615,11 +615,15 @@ class _TraceLean(torch.autograd.Function):
         lib = _lib.load()
         p0_c, p1_c = _dev(p0, torch.float32, "means"), _dev(p1, torch.float32, "sigmas")
         rays_c = _dev(rays, torch.float32, "rays")
-        assert rays_c.dim() == 4 and rays_c.shape[3] == 3 and mode in (1, 2)
+        assert rays_c.dim() == 4 and rays_c.shape[3] == 3 and mode in (0, 1, 2)
         B, H, W, _ = rays_c.shape
         K, dev = int(n_assign), rays_c.device
         o_c, shared = None, False
-        if mode == 2:
+        if mode == 0:      # full 3x3 forms: (mus [P,3], isigmas [P,3,3]); records = the packed (mu, A)
+            assert p0_c.dim() == 2 and p0_c.shape[1] == 3 and p0_c.shape[0] % max(B, 1) == 0
+            assert p1_c.shape == (p0_c.shape[0], 3, 3)
+            N = p0_c.shape[0] // B
+        elif mode == 2:
             o_c = _dev(origin, torch.float32, "origin")
             shared = p0_c.dim() == 2
             assert p0_c.shape[-1] == 3 and (shared or p0_c.shape[0] == B) and p1_c.shape == p0_c.shape[:-1]
@@ -632,14 +636,17 @@ class _TraceLean(torch.autograd.Function):
         sel_idx = torch.empty((B, H, W, K), dtype=torch.int32, device=dev)
         sel_len = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
         cnt = torch.empty((B, H, W), dtype=torch.int32, device=dev)
-        records = torch.empty((B * N, 4), dtype=torch.float32, device=dev)
+        records = torch.empty((B * N, 12 if mode == 0 else 4), dtype=torch.float32, device=dev)
         fwd = None if cam_fwd is None else _dev(cam_fwd, torch.float32, "cam_fwd")
         with _on(dev):
             nbytes = lib.voge_trace_workspace_bytes(B, N, H, W)
             ws = _workspace(dev, nbytes)
             tail = (B, N, H, W, K, float(thr_act), 1.0, _p(ws), nbytes, _p(sel_idx), _p(sel_len), None, None, _p(cnt), None, None)
             cones = _p(cones_of(rays_c, B, H, W))
-            if mode == 2:
+            if mode == 0:
+                rc = lib.voge_trace_lean_fwd(_p(p0_c), _p(p1_c), _p(rays_c), _p(fwd), cones, B, N, H, W, K, float(thr_act), _p(ws),
+                                             nbytes, _p(sel_idx), _p(sel_len), _p(cnt), _p(records), _stream())
+            elif mode == 2:
                 rc = lib.voge_fragments_fwd_iso_view(_p(p0_c), _p(p1_c), _p(o_c), int(shared), int(sigma_mode), _p(rays_c),
                                                      _p(fwd), cones, *tail, _p(records), _stream())
             else:
@@ -671,10 +678,14 @@ class _TraceLean(torch.autograd.Function):
             nbytes = lib.voge_fragment_bwd_workspace_bytes(B * N)
             ws = _workspace(rays.device, nbytes)
             # (g_weight = NULL: u = 0 everywhere, the `weight` operand is read but multiplies zero -- len stands in)
-            rc = lib.voge_fragment_bwd_iso(_p(ctx.records), _p(p1), int(shared), sigma_mode, _p(rays), _p(sel_idx), _p(cnt), _p(ln),
-                                           None, _p(ln), None, None, 0, 0, _p(gh), 1.0, B, N, B * H, W, K, _p(ws), nbytes, _p(g0),
-                                           _p(g1), _stream())
-        _lib.check(rc, "voge_fragment_bwd_iso")
+            if mode == 0:
+                rc = lib.voge_fragment_bwd(_p(p0), _p(p1), _p(rays), _p(sel_idx), _p(cnt), _p(ln), None, _p(ln), None, None, 0, 0,
+                                           _p(gh), 1.0, B * N, B * H, W, K, _p(ws), nbytes, _p(g0), _p(g1), _stream())
+            else:
+                rc = lib.voge_fragment_bwd_iso(_p(ctx.records), _p(p1), int(shared), sigma_mode, _p(rays), _p(sel_idx), _p(cnt), _p(ln),
+                                               None, _p(ln), None, None, 0, 0, _p(gh), 1.0, B, N, B * H, W, K, _p(ws), nbytes, _p(g0),
+                                               _p(g1), _stream())
+        _lib.check(rc, "voge_fragment_bwd")
         return None, g0, g1, None, None, None, None, None, None
 
 
@@ -687,6 +698,10 @@ class LazyComposite:
     def __init__(self, **kw):
         for k, v in kw.items():
             setattr(self, k, v)
+
+    def means(self):
+        """(general forms) the centres as the trace saw them: contiguous fp32, no grad_fn."""
+        return _dev(self.p0.detach(), torch.float32, "means")
 
     def usable(self):
         """The sweep's outputs must still be what it wrote (nobody edited them through torch in between)."""
@@ -703,15 +718,24 @@ class LazyComposite:
         """Tag freshly composited weights the way fragments() does (a later to_colored_background takes _ShadeThrough)."""
         if (self.p0.requires_grad or self.p1.requires_grad) and torch.is_grad_enabled():
             len_d = self.sel_len.detach()
+            act, dsd = getattr(weight, "voge_act_dsd", (None, None))      # (general forms: what the composite kept)
             weight.voge_through = dict(
                 mode=self.mode, sigma_mode=self.sigma_mode, shared=self.shared, occ=self.occ, B=self.B, N=self.N,
-                records=self.records, rays=self.rays, act=None, dsd=None, len=len_d, cnt=self.cnt, idx=self.sel_idx,
+                records=self.records, rays=self.rays, act=act, dsd=dsd, len=len_d, cnt=self.cnt, idx=self.sel_idx,
                 sigmas=self.p1.detach(), means=self.p0.detach(), p0=self.p0, p1=self.p1, rays_requires_grad=False,
                 versions=(weight._version, len_d._version, self.rays._version, self.sel_idx._version))
         return weight
 
 
-def _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K):
+def _general_act_dsd(lz, sel_len, need):
+    """(act, dsd) buffers the general composite fills for its backward (VOGE_GENERAL_KEEP_ACT_DSD=0: none -- the backward
+    re-derives them from the packed records, 19 us slower at the cfg3 size); scalar-sigma fragments never keep them."""
+    if lz.mode != 0 or os.environ.get("VOGE_GENERAL_KEEP_ACT_DSD", "1") == "0" or not need:
+        return (None, None)
+    return (torch.empty_like(sel_len), torch.empty_like(sel_len))
+
+
+def _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K, ad=(None, None)):
     """composite + trace backward in one pass for a deferred composite: -> (g_p0, g_p1)."""
     lz.check()
     gw, gs_pix, gs_k = _grad_weight_layout(g_weight, K)
@@ -721,10 +745,15 @@ def _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K):
     with _on(ln.device):
         nbytes = lib.voge_fragment_bwd_workspace_bytes(lz.B * lz.N)
         ws = _workspace(ln.device, nbytes)
-        rc = lib.voge_fragment_bwd_iso(_p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(lz.sel_idx), _p(lz.cnt),
-                                       _p(weight), None, _p(ln), None, _p(gw), gs_pix, gs_k, None, lz.occ, lz.B, lz.N, B * H, W, K,
-                                       _p(ws), nbytes, _p(g0), _p(g1), _stream())
-    _lib.check(rc, "voge_fragment_bwd_iso")
+        if lz.mode == 0:
+            rc = lib.voge_fragment_bwd(_p(lz.means()), _p(p1), _p(lz.rays), _p(lz.sel_idx), _p(lz.cnt), _p(weight), _p(ad[0]), _p(ln),
+                                       _p(ad[1]), _p(gw), gs_pix, gs_k, None, lz.occ, lz.B * lz.N, B * H, W, K, _p(ws), nbytes, _p(g0),
+                                       _p(g1), _stream())
+        else:
+            rc = lib.voge_fragment_bwd_iso(_p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(lz.sel_idx), _p(lz.cnt),
+                                           _p(weight), None, _p(ln), None, _p(gw), gs_pix, gs_k, None, lz.occ, lz.B, lz.N, B * H, W, K,
+                                           _p(ws), nbytes, _p(g0), _p(g1), _stream())
+    _lib.check(rc, "voge_fragment_bwd")
     return g0, g1
 
 
@@ -740,9 +769,15 @@ class _CompositeLean(torch.autograd.Function):
         weight = torch.empty_like(sel_len)
         valid = torch.empty(idx.shape[:-1], dtype=torch.int64, device=idx.device)
         with _on(idx.device):
-            rc = lib.voge_composite_fwd_iso(_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, idx.numel() // K, K,
-                                            _p(weight), _p(valid), _stream())
-        _lib.check(rc, "voge_composite_fwd_iso")
+            ctx.ad = _general_act_dsd(lz, sel_len, any(ctx.needs_input_grad))
+            if lz.mode == 0:
+                rc = lib.voge_composite_fwd_rec(_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, idx.numel() // K,
+                                                K, _p(weight), _p(valid), _p(ctx.ad[0]), _p(ctx.ad[1]), _stream())
+            else:
+                rc = lib.voge_composite_fwd_iso(_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, idx.numel() // K,
+                                                K, _p(weight), _p(valid), _stream())
+        _lib.check(rc, "voge_composite_fwd (from the records)")
+        weight.voge_act_dsd = ctx.ad
         ctx.save_for_backward(_dev(p1, torch.float32, "sigmas"), sel_len, weight)
         ctx.lz = lz
         ctx.mark_non_differentiable(valid)
@@ -754,7 +789,7 @@ class _CompositeLean(torch.autograd.Function):
         if g_weight is None:
             return None, None, None, None
         p1, ln, weight = ctx.saved_tensors
-        g0, g1 = _lazy_fragment_bwd(_lib.load(), ctx.lz, p1, weight, ln, g_weight, ctx.lz.K)
+        g0, g1 = _lazy_fragment_bwd(_lib.load(), ctx.lz, p1, weight, ln, g_weight, ctx.lz.K, ctx.ad)
         return g0, g1, None, None
 
 
@@ -779,10 +814,15 @@ class _CompositeShade(torch.autograd.Function):
         img = torch.empty_like(rgb)
         wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
         with _on(idx.device):
-            rc = lib.voge_composite_shade_fwd_iso(_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c),
-                                                  _p(bg_c), float(thr), idx.numel() // K, K, C, Nattr, _p(weight), _p(valid),
-                                                  _p(rgb), _p(img), _p(wsum), _stream())
-        _lib.check(rc, "voge_composite_shade_fwd_iso")
+            ctx.ad = _general_act_dsd(lz, sel_len, any(ctx.needs_input_grad))
+            args = (_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c), _p(bg_c), float(thr),
+                    idx.numel() // K, K, C, Nattr, _p(weight), _p(valid), _p(rgb), _p(img), _p(wsum))
+            if lz.mode == 0:
+                rc = lib.voge_composite_shade_fwd_rec(*args, _p(ctx.ad[0]), _p(ctx.ad[1]), _stream())
+            else:
+                rc = lib.voge_composite_shade_fwd_iso(*args, _stream())
+        _lib.check(rc, "voge_composite_shade_fwd")
+        weight.voge_act_dsd = ctx.ad
         ctx.save_for_backward(attr_c, _dev(p1, torch.float32, "sigmas"), sel_len, weight, rgb, bg_c, wsum)
         ctx.lz, ctx.thr = lz, float(thr)
         ctx.mark_non_differentiable(valid)
@@ -810,13 +850,19 @@ class _CompositeShade(torch.autograd.Function):
             with _on(idx.device):
                 nbytes = lib.voge_fragment_bwd_workspace_bytes(lz.B * lz.N)
                 ws = _workspace(idx.device, nbytes)
-                rc = lib.voge_fragment_shade_bwd_iso(
-                    _p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(attr), _p(idx), _p(lz.cnt), _p(weight), None,
-                    _p(ln), None, _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go), gs_pix, gs_c, lz.occ, lz.B, lz.N, B * H, W, K, C, Nattr,
-                    _p(ws), nbytes, _p(g0), _p(g1), _p(g_attr), _stream())
-            _lib.check(rc, "voge_fragment_shade_bwd_iso")
+                if lz.mode == 0:
+                    rc = lib.voge_fragment_shade_bwd(
+                        _p(lz.means()), _p(p1), _p(lz.rays), _p(attr), _p(idx), _p(lz.cnt), _p(weight), _p(ctx.ad[0]), _p(ln),
+                        _p(ctx.ad[1]), _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go), gs_pix, gs_c, lz.occ, lz.B * lz.N, B * H, W, K, C, Nattr,
+                        _p(ws), nbytes, _p(g0), _p(g1), _p(g_attr), _stream())
+                else:
+                    rc = lib.voge_fragment_shade_bwd_iso(
+                        _p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(attr), _p(idx), _p(lz.cnt), _p(weight), None,
+                        _p(ln), None, _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go), gs_pix, gs_c, lz.occ, lz.B, lz.N, B * H, W, K, C, Nattr,
+                        _p(ws), nbytes, _p(g0), _p(g1), _p(g_attr), _stream())
+            _lib.check(rc, "voge_fragment_shade_bwd")
         if g_weight is not None:
-            h0, h1 = _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K)
+            h0, h1 = _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K, ctx.ad)
             g0, g1 = (h0, h1) if g0 is None else (g0 + h0, g1 + h1)
         need = ctx.needs_input_grad
         return (g_attr if need[0] else None), (g0 if need[1] else None), (g1 if need[2] else None), None, None, None, None
@@ -841,10 +887,15 @@ class _CompositeMerge(torch.autograd.Function):
         rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
         wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
         with _on(idx.device):
-            rc = lib.voge_composite_shade_fwd_iso(_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c),
-                                                  None, -1.0, idx.numel() // K, K, C, Nattr, _p(weight), _p(valid), _p(rgb), None,
-                                                  _p(wsum), _stream())
-        _lib.check(rc, "voge_composite_shade_fwd_iso")
+            ctx.ad = _general_act_dsd(lz, sel_len, any(ctx.needs_input_grad))
+            args = (_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c), None, -1.0, idx.numel() // K, K,
+                    C, Nattr, _p(weight), _p(valid), _p(rgb), None, _p(wsum))
+            if lz.mode == 0:
+                rc = lib.voge_composite_shade_fwd_rec(*args, _p(ctx.ad[0]), _p(ctx.ad[1]), _stream())
+            else:
+                rc = lib.voge_composite_shade_fwd_iso(*args, _stream())
+        _lib.check(rc, "voge_composite_shade_fwd")
+        weight.voge_act_dsd = ctx.ad
         ctx.save_for_backward(attr_c, _dev(p1, torch.float32, "sigmas"), sel_len, weight)
         ctx.lz = lz
         ctx.mark_non_differentiable(valid)
@@ -875,13 +926,19 @@ class _CompositeMerge(torch.autograd.Function):
             with _on(idx.device):
                 nbytes = lib.voge_fragment_bwd_workspace_bytes(lz.B * lz.N)
                 ws = _workspace(idx.device, nbytes)
-                rc = lib.voge_fragment_merge_bwd_iso(
-                    _p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(attr), _p(idx), _p(lz.cnt), _p(weight), None,
-                    _p(ln), None, _p(go), gs_pix, gs_c, _p(gws), lz.occ, lz.B, lz.N, B * H, W, K, C, Nattr, _p(ws), nbytes, _p(g0),
-                    _p(g1), _p(g_attr), _stream())
-            _lib.check(rc, "voge_fragment_merge_bwd_iso")
+                if lz.mode == 0:
+                    rc = lib.voge_fragment_merge_bwd(
+                        _p(lz.means()), _p(p1), _p(lz.rays), _p(attr), _p(idx), _p(lz.cnt), _p(weight), _p(ctx.ad[0]), _p(ln),
+                        _p(ctx.ad[1]), _p(go), gs_pix, gs_c, _p(gws), lz.occ, lz.B * lz.N, B * H, W, K, C, Nattr, _p(ws), nbytes, _p(g0),
+                        _p(g1), _p(g_attr), _stream())
+                else:
+                    rc = lib.voge_fragment_merge_bwd_iso(
+                        _p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(attr), _p(idx), _p(lz.cnt), _p(weight), None,
+                        _p(ln), None, _p(go), gs_pix, gs_c, _p(gws), lz.occ, lz.B, lz.N, B * H, W, K, C, Nattr, _p(ws), nbytes, _p(g0),
+                        _p(g1), _p(g_attr), _stream())
+            _lib.check(rc, "voge_fragment_merge_bwd")
         if g_weight is not None:
-            h0, h1 = _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K)
+            h0, h1 = _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K, ctx.ad)
             g0, g1 = (h0, h1) if g0 is None else (g0 + h0, g1 + h1)
         need = ctx.needs_input_grad
         return (g_attr if need[0] else None), (g0 if need[1] else None), (g1 if need[2] else None), None, None
@@ -911,8 +968,11 @@ def trace_lean(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mod
 
 
 def lazy_eligible(mode, p0, p1, origin, rays, n_assign):
-    """Deferred composite: scalar sigmas, record gathers in 32-bit offsets, nobody differentiating the rays."""
-    if not LAZY_COMPOSITE or mode == 0 or os.environ.get("VOGE_FRAGMENTS_KEEP_ACT_DSD", "0") == "1":
+    """Deferred composite: record gathers in 32-bit offsets, nobody differentiating the rays.  (mode 0 = full 3x3 forms,
+    VOGE_LAZY_GENERAL=0 keeps those on the eager chain with act / dsd.)"""
+    if not LAZY_COMPOSITE or os.environ.get("VOGE_FRAGMENTS_KEEP_ACT_DSD", "0") == "1":
+        return False
+    if mode == 0 and os.environ.get("VOGE_LAZY_GENERAL", "1") == "0":
         return False
     B = rays.shape[0]
     P = p0.shape[-2] * B if mode == 2 else p0.shape[0]
