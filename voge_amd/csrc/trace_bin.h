@@ -88,7 +88,21 @@ __device__ unsigned long long g_bin_wave[1024 * 16 * 4];   // binB: per (workgro
 constexpr int kRoundChunks = 4;                           // 1024-Gaussian chunks a workgroup tests per round
 constexpr int kRoundCap = kRoundChunks * kBinThreads;     // candidates (hence at most survivors) of a round
 
+// A segment that outgrows its kSegCap inline entries continues in an EXTENSION: ids only, in chunks of kExtChunk taken
+// on demand from an arena of kExtMul * slice_cap(N) ids that belongs to the (region, slice) workgroup (an LDS counter: no
+// global one, nothing to reset); up to kExtChunks chunks per segment, their offsets in seg_ext.  A Gaussian falls into one
+// or two of a region's super-tiles, so the arena holds whatever the slice produces; only a segment beyond
+// kSegCap + kExtChunks * kExtChunk entries (or a used-up arena) still counts as overflowed (binB then re-tests its slice).
+constexpr int kExtMul = 3;
+constexpr int kExtChunk = 1024;
+constexpr int kExtChunks = 16;
+__host__ __device__ inline int slice_cap(const int N) {
+  return ((N + kParts * kBinThreads - 1) / (kParts * kBinThreads)) * kBinThreads;      // the most Gaussians a slice can hold
+}
 struct BinALds {
+  int arena_top;               // ids of the workgroup's extension arena handed out so far
+  int extc[kCh * kCh][kExtChunks];      // per child: where its extension chunks start in the arena
+  int extn[kCh * kCh];         // per child: chunks it holds (-1: one could not be had -- the segment counts as overflowed)
   float4 srec[kRoundCap];      // survivors of the region test, this round: record ...
   int sid[kRoundCap];          // ... and Gaussian id, in (chunk, wave, lane) order
   ConeRec child[kCh * kCh];
@@ -136,14 +150,19 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
             const float thr_act, const IsoView view, float4 *__restrict__ cull, float4 *__restrict__ ms,
             int *__restrict__ seg_count /* [B*nst][kParts] */, int32_t *__restrict__ seg_id /* [B*nst][kParts][kSegCap] */,
             float4 *__restrict__ seg_rec /* the same shape: the entries' cull records */,
-            int *__restrict__ pool_top /* binB's list pool: reset here, one launch ahead of its first use */) {
+            int *__restrict__ pool_top /* binB's list pool: reset here, one launch ahead of its first use */,
+            int *__restrict__ seg_ext /* [B*nst][kParts][kExtChunks]: starts of the segment's extension chunks in ext_id */,
+            int32_t *__restrict__ ext_id /* [B][regions][kParts][ext_arena] */, const int ext_arena) {
   __shared__ BinALds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int region = blockIdx.x / kParts, part = blockIdx.x - region * kParts, b = blockIdx.y;
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *pool_top = 0;
   const int rx = region % nst0x, ry = region / nst0x;
   const int nst = nstx * nsty;
-  if (tid < kCh * kCh) L.base[tid] = 0;
+  if (tid < kCh * kCh) { L.base[tid] = 0; L.extn[tid] = 0; }
+  if (tid == 0) L.arena_top = 0;
+  int32_t *const arena = ext_id + ((size_t)(b * (int)(gridDim.x / kParts) + region) * kParts + part) * (size_t)ext_arena;
+  int ext_have = 0;      // (wave cc <-> child cc for the whole kernel) extension chunks held; -1: one could not be had
   BIN_TS(0, 0);
   // How the N Gaussians are dealt to the kParts slices.  Large sets: whole 1024-Gaussian chunks round-robin (coalesced
   // loads; a spatially ordered input still spreads over the slices).  Small sets (fewer than kParts chunks) would leave
@@ -275,6 +294,7 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
           bool kp[kU];
 #pragma unroll
           for (int q = 0; q < kU; ++q) kp[q] = cone_keep(r[q], ck);      // (padding: reach -1, never kept)
+          const int fill0 = fill;
 #pragma unroll
           for (int q = 0; q < kU; ++q) {
             const unsigned long long m = __ballot(kp[q]);
@@ -284,8 +304,35 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
             }
             fill += __popcll(m);
           }
+#ifndef VOGE_NO_SEG_EXT      // (A/B builds: no extensions -- a segment beyond kSegCap counts as overflowed)
+          if (__builtin_expect(fill > kSegCap, 0)) {      // (uniform, rare) this trip's entries beyond the inline part
+            const int need = (fill - kSegCap + kExtChunk - 1) / kExtChunk;
+            while (ext_have >= 0 && ext_have < need) {      // (uniform) one more chunk from the workgroup's arena
+              int at = 0;
+              if (lane == 0) at = atomicAdd(&L.arena_top, kExtChunk);
+              at = __builtin_amdgcn_readfirstlane(at);
+              if (ext_have < kExtChunks && at + kExtChunk <= ext_arena) {
+                if (lane == 0) L.extc[cc][ext_have] = at;
+                ++ext_have;
+              } else {
+                ext_have = -1;
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (ext_have >= 0) {
+              int f = fill0;
+#pragma unroll
+              for (int q = 0; q < kU; ++q) {
+                const unsigned long long m = __ballot(kp[q]);
+                const int e = f + __popcll(m & ((1ull << lane) - 1ull)) - kSegCap;
+                if (kp[q] && e >= 0) arena[*reinterpret_cast<volatile int *>(&L.extc[cc][e / kExtChunk]) + (e % kExtChunk)] = id[q];
+                f += __popcll(m);
+              }
+            }
+          }
+#endif
         }
-        if (lane == 0) L.base[cc] = fill;
+        if (lane == 0) { L.base[cc] = fill; L.extn[cc] = ext_have; }
       }
     }
     BIN_TS(0, 3);
@@ -295,8 +342,13 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
   BIN_TS(0, 5);
   if (tid < kCh * kCh) {
     const int ccx = rx * kCh + (tid & (kCh - 1)), ccy = ry * kCh + tid / kCh;
-    if (ccx < nstx && ccy < nsty)
-      seg_count[((size_t)b * nst + ccy * nstx + ccx) * kParts + part] = (L.base[tid] > kSegCap) ? -1 : L.base[tid];
+    if (ccx < nstx && ccy < nsty) {
+      const size_t so = ((size_t)b * nst + ccy * nstx + ccx) * kParts + part;
+      const bool over = L.base[tid] > kSegCap;
+      seg_count[so] = (over && L.extn[tid] < 0) ? -1 : L.base[tid];      // (> kSegCap: the rest is in the extension chunks)
+      if (over && L.extn[tid] > 0)
+        for (int q = 0; q < L.extn[tid]; ++q) seg_ext[so * kExtChunks + q] = (int)(arena - ext_id) + L.extc[tid][q];
+    }
   }
 }
 
@@ -325,10 +377,14 @@ struct BinLds {
   };
   uint32_t sorted[kQCap];     // (flag << 31 | id), front to back (an entry's depth key is recomputed from its record)
   float red[4 * 8];
-  int hist[kBuckets];
+  union {
+    int hist[kBuckets];
+    int exto[kParts][kExtChunks];      // (while the sources are streamed) where each segment's extension chunks start in ext_id
+  };
   uint32_t bmin[kBuckets];   // per bucket: smallest own len bound of the entries with an ellipsoid record (ord)
   int wsum[8];
-  int segn[kParts + 1];      // exclusive prefix of the segment counts (an overflowed segment counts as empty here)
+  int segn[kParts + 1];      // exclusive prefix of the segments' INLINE counts (an overflowed segment counts as empty here)
+  int extn[kParts + 1];      // exclusive prefix of the segments' extension counts (entries beyond kSegCap, ids only)
   unsigned ovf;              // bit p: slice p's segment overflowed kSegCap -- its Gaussians are re-tested from their records
   int count;
   int nflag;      // entries with an ellipsoid record
@@ -347,8 +403,9 @@ constexpr int kGU = 8;      // gathers in flight per thread of binB's source pas
 // for the slices whose segment overflowed, and the quad's cone.
 struct BinStream {
   const float4 *cullb, *ellb, *segr;
-  const int32_t *segs;
-  int n_src, N;
+  const int32_t *segs, *ext_id;
+  const int *exto;      // LDS: [kParts][kExtChunks] starts of the extension chunks
+  int n_src, n_ext, N;
   unsigned ovf;
   Cone qcone;
 };
@@ -381,8 +438,8 @@ __device__ __forceinline__ void bin_test_batch(const BinStream &S, const int (&g
 }
 // One pass over the quad's sources, kGU entries per thread at a time; the sink sees every batch, wave-uniformly.
 template <class Sink>
-__device__ __forceinline__ void bin_stream_sources(const BinStream &S, const int *segn /* LDS: exclusive prefix of the segment counts */,
-                                                   const int tid, Sink &&sink) {
+__device__ __forceinline__ void bin_stream_sources(const BinStream &S, const int *segn /* LDS: exclusive prefix of the segment counts;
+                                                   behind it (BinLds): extn[kParts + 1] */, const int tid, Sink &&sink) {
   for (int base = 0; base < S.n_src; base += kQT * kGU) {      // the segments binA filled
     int gid[kGU];
     float4 c[kGU];
@@ -402,7 +459,29 @@ __device__ __forceinline__ void bin_stream_sources(const BinStream &S, const int
     }
     bin_test_batch(S, gid, c, sink);
   }
-  if (S.ovf != 0u) {      // (rare) slices whose segment overflowed: their Gaussians straight from the per-Gaussian records
+  if (S.n_ext > 0) {      // (rare) the part of long segments that binA put into their extensions: ids, records by gather
+    const int *extn = segn + (kParts + 1), *exto = S.exto;
+    for (int base = 0; base < S.n_ext; base += kQT * kGU) {
+      int gid[kGU];
+      float4 c[kGU];
+#pragma unroll
+      for (int j = 0; j < kGU; ++j) {
+        const int i = base + j * kQT + tid;
+        gid[j] = -1;
+        if (i < S.n_ext) {
+          int p = 0;
+#pragma unroll
+          for (int q = 1; q < kParts; ++q) p += (i >= extn[q]) ? 1 : 0;
+          const int e = i - extn[p];
+          gid[j] = S.ext_id[(size_t)exto[p * kExtChunks + e / kExtChunk] + (size_t)(e % kExtChunk)];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kGU; ++j) c[j] = (gid[j] >= 0) ? S.cullb[gid[j]] : make_float4(0.f, 0.f, 0.f, -1.f);
+      bin_test_batch(S, gid, c, sink);
+    }
+  }
+  if (S.ovf != 0u) {      // (rarer) slices whose segment overflowed: their Gaussians straight from the per-Gaussian records
     for (int base = 0; base < S.N; base += kQT * kGU) {
       int gid[kGU];
       float4 c[kGU];
@@ -512,6 +591,8 @@ struct BinLong {
   bool tile_ok;
   int tile, quad, total;
   int *pool_top, *tl_off, *tl_count, *q_count;
+  const int *seg_ext;
+  int bin;
   int pool_cap;
   int32_t *pool_id;
   float *pool_lb;
@@ -523,6 +604,11 @@ __device__ __forceinline__ void binB_long_path(const BinLong A, BinLds &L) {
   const int total = A.total;
   __syncthreads();                                   // (everyone is done with L.red / L.count of pass one)
   for (int i = tid; i < kTilesPerQuad * kBuckets; i += kQT) (&L.hist4[0][0])[i] = 0;
+  if (S.n_ext > 0) {      // the extension chunk tables again (they share their LDS with the histogram the kernel just cleared)
+    const int p = tid / kExtChunks, q = tid % kExtChunks;
+    const int ne = L.extn[p + 1] - L.extn[p];
+    L.exto[p][q] = (q * kExtChunk < ne) ? A.seg_ext[((size_t)A.bin * kParts + p) * kExtChunks + q] : 0;
+  }
   if (lane == 0) {
     L.tc[wave][0] = A.tcone.ax; L.tc[wave][1] = A.tcone.ay; L.tc[wave][2] = A.tcone.az; L.tc[wave][3] = A.tcone.cs;
     L.tc[wave][4] = A.tcone.sn; L.tc[wave][5] = (A.tcone.ok || !A.tile_ok) ? 1.0f : 0.0f;      // (a tile outside the image keeps nothing)
@@ -668,7 +754,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
             int *__restrict__ tl_count, int32_t *__restrict__ tl_id, float *__restrict__ tl_lb,
             int2 *__restrict__ order /* [nbin_total][16]: (tile, list length) by launch rank */,
             int *__restrict__ pool_top, const int pool_cap, int32_t *__restrict__ pool_id, float *__restrict__ pool_lb,
-            int *__restrict__ tl_off,
+            int *__restrict__ tl_off, const int *__restrict__ seg_ext, const int32_t *__restrict__ ext_id,
             const int K, int32_t *__restrict__ out_idx, float *__restrict__ out_len, float *__restrict__ out_act,
             float *__restrict__ out_dsd, int32_t *__restrict__ out_cnt, float *__restrict__ out_weight,
             int64_t *__restrict__ out_valid) {
@@ -712,18 +798,28 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
       // object far away, a zoomed-out view) does not send the quad to the stream-everything fallback any more: the
       // slice's Gaussians -- N / kParts of them -- are tested against the quad's cone right here, from the records
       // binA / prep left per Gaussian.  Only a quad list beyond kQCap still falls back.
-      int run = 0;
+      int run = 0, erun = 0;
       unsigned ovf = 0u;
       for (int p = 0; p < kParts; ++p) {
         int c = seg_count[(size_t)bin * kParts + p];
         L.segn[p] = run;
-        if (c < 0) { ovf |= 1u << p; c = 0; }      // (its Gaussians come from the records, second loop of stream_sources)
+        L.extn[p] = erun;
+        if (c < 0) { ovf |= 1u << p; c = 0; }      // (its Gaussians come from the records, last loop of bin_stream_sources)
+        if (c > kSegCap) { erun += c - kSegCap; c = kSegCap; }
         run += c;
       }
       L.segn[kParts] = run;
+      L.extn[kParts] = erun;
       L.ovf = ovf;
     }
     __syncthreads();
+    auto load_ext_tables = [&]() {      // the chunk tables of the segments with an extension: thread <-> (slice, chunk)
+      static_assert(kParts * kExtChunks == kQT, "one thread per (slice, chunk)");
+      const int p = tid / kExtChunks, q = tid % kExtChunks;
+      const int ne = L.extn[p + 1] - L.extn[p];
+      L.exto[p][q] = (q * kExtChunk < ne) ? seg_ext[((size_t)bin * kParts + p) * kExtChunks + q] : 0;
+    };
+    if (L.extn[kParts] > 0) load_ext_tables();      // (uniform, rare; the tables share their LDS with the sort's histogram)
     const float gx = L.red[0] + L.red[8] + L.red[16] + L.red[24], gy = L.red[1] + L.red[9] + L.red[17] + L.red[25],
                 gz = L.red[2] + L.red[10] + L.red[18] + L.red[26];
     const bool gok = (L.red[3] != 0.f) && (L.red[11] != 0.f) && (L.red[19] != 0.f) && (L.red[27] != 0.f);
@@ -779,6 +875,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   bool any_el = false;
   BinStream S;
   S.cullb = cullb; S.ellb = ellb; S.segr = segr; S.segs = segs; S.n_src = n_src; S.N = N; S.ovf = ovf; S.qcone = qcone;
+  S.ext_id = ext_id; S.n_ext = L.extn[kParts]; S.exto = &L.exto[0][0];
   // pass one: the quad's survivors -- keys compacted in LDS (the first kQCap of them), extrema, the largest sphere reach
   bin_stream_sources(S, L.segn, tid, [&](const int (&g)[kGU], const float4 (&cj)[kGU], const bool (&kp)[kGU],
                                           const bool (&el)[kGU], const float (&gkey)[kGU]) {
@@ -830,7 +927,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
     BinLong A;
     A.S = S; A.Kk = Kk; A.tcone = tcone; A.tile_ok = tile_ok; A.tile = tile; A.quad = quad; A.total = total;
     A.pool_top = pool_top; A.tl_off = tl_off; A.tl_count = tl_count; A.q_count = q_count; A.pool_cap = pool_cap;
-    A.pool_id = pool_id; A.pool_lb = pool_lb; A.my_order = my_order;
+    A.pool_id = pool_id; A.pool_lb = pool_lb; A.my_order = my_order; A.seg_ext = seg_ext; A.bin = bin;
     binB_long_path(A, L);
   } else {
 #endif

@@ -1032,6 +1032,9 @@ struct TraceWs {
   float *pool_lb;
   int *tl_off;                        // per sweep tile: start of its pooled list
   int pool_cap;
+  int *seg_ext;                       // binA -> binB: extensions of segments with more than kSegCap entries
+  int32_t *ext_id;
+  int ext_arena;                      // ids per (region, slice) workgroup of binA
   int nstx, nsty, nst0x, nst0y, nbin;
 };
 
@@ -1059,7 +1062,11 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
        *cq = take(nbin * kTilesPerBin * 8 * 2);      // (second half: the exactly sorted copy of VOGE_EXACT_ORDER builds)
   const size_t npool = trace_pool_entries(P);
   char *pt = take(4), *pi = take(npool * 4), *pl = take(npool * 4), *to = take(ntile * 4);
+  const int nst0x = (W + kST0 - 1) / kST0, nst0y = (H + kST0 - 1) / kST0;
+  const size_t arena = (size_t)kExtMul * slice_cap(N);
+  char *se = take(nbin * kParts * kExtChunks * 4), *ei = take((size_t)B * nst0x * nst0y * kParts * arena * 4);
   if (ws) {
+    ws->seg_ext = reinterpret_cast<int *>(se); ws->ext_id = reinterpret_cast<int32_t *>(ei); ws->ext_arena = (int)arena;
     ws->pool_top = reinterpret_cast<int *>(pt); ws->pool_id = reinterpret_cast<int32_t *>(pi);
     ws->pool_lb = reinterpret_cast<float *>(pl); ws->tl_off = reinterpret_cast<int *>(to);
     ws->pool_cap = (int)npool;
@@ -1135,8 +1142,8 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
   }
   hipLaunchKernelGGL(binB_kernel, dim3(ws.nstx * ws.nsty * 4, B), dim3(kQT), 0, st, ws.cull, ws.ell, ws.seg_count, ws.seg_id, ws.seg_rec,
                      rays, N, H, W, ws.nstx, ws.nsty, ws.nbin, ws.q_count, ws.q_id, ws.q_lb, ws.tl_count, ws.tl_id, ws.tl_lb,
-                     ws.order, ws.pool_top, ws.pool_cap, ws.pool_id, ws.pool_lb, ws.tl_off, K, idx, len, act, dsd, cnt, weight,
-                     valid_num);
+                     ws.order, ws.pool_top, ws.pool_cap, ws.pool_id, ws.pool_lb, ws.tl_off, ws.seg_ext, ws.ext_id, K, idx, len, act, dsd,
+                     cnt, weight, valid_num);
   {
     int rc = launch_status();
     if (rc) return rc;
@@ -1236,13 +1243,13 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   if (iso_in) {
     // scalar sigmas: binA derives the per-Gaussian records itself -- two launches in front of the sweep
     hipLaunchKernelGGL(binA_kernel<true>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
-                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top);
+                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top, ws.seg_ext, ws.ext_id, ws.ext_arena);
   } else {
     if (P > 0)
       hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P, thr_act, ws.cull,
                          ws.evr, ws.ms, ws.ell, reinterpret_cast<float4 *>(records));
     hipLaunchKernelGGL(binA_kernel<false>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
-                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top);
+                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top, ws.seg_ext, ws.ext_id, ws.ext_arena);
   }
   {
     int rc = launch_status();
