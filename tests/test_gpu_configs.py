@@ -383,3 +383,26 @@ def test_quads_with_more_candidates_than_the_lds_sort_use_pooled_lists(hip_lib, 
     got_gen = [n(x) for x in ops.ray_trace_fine(t(mus).reshape(-1, 3), t(isg).reshape(-1, 3, 3), t(rays), None, thr_act, 10, K)]
     for x, y in zip(got_iso, got_gen):
         assert np.array_equal(x, y)
+
+
+def test_long_quads_and_segment_extensions_in_a_batch_of_views(hip_lib):
+    """The pooled lists and binA's segment extensions with B = 2: two views of the same small dense object (their arenas
+    and pool entries are per batch element / shared), against the brute-force oracle."""
+    from voge_amd import ops
+    N, K, H, W = 24000, 16, 96, 96
+    rng = np.random.default_rng(7)
+    verts = rng.uniform(-0.28, 0.28, (N, 3)).astype(np.float32)
+    r = rng.uniform(0.006, 0.012, N)
+    sig = (1.0 / (r * r / (2 * np.log(1 / 0.6)))).astype(np.float32)
+    R, T = camera_np.look_at_view_transform([3.0, 3.4], [10.0, -20.0], [20.0, 140.0])
+    rays, origin = camera_np.pixel_rays(R, T, 110.0, (W / 2.0, H / 2.0), (H, W))
+    assert rays.shape[0] == 2
+    mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = np.ascontiguousarray(np.broadcast_to((2 * camera_np.expand_sigma(sig)).astype(np.float32)[None], (2, N, 3, 3)))
+    thr_act = oracle.thr_act_of(0.01)
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    a = np.ascontiguousarray(isg[..., 0, 0])
+    got = [n(x) for x in ops._RayTraceVoGEIso.apply(t(mus.reshape(-1, 3)), t(a.reshape(-1)), t(rays), None, thr_act, K)]
+    used, cap = ops.trace_pool_usage("cuda:0", 2, N, H, W)
+    assert 0 < used <= cap, (used, cap)
+    compare_trace(got, ref, thr_act, min_match=0.998, label="long quads, two views")
