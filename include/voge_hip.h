@@ -461,6 +461,20 @@ size_t voge_cones_floats(int B, int H, int W);
 int voge_ray_cones(const float *rays, int B, int H, int W, float *cones, voge_stream_t stream);
 
 /*
+ * The renderer's elementwise preamble for (N,3) / (N,3,3) sigmas in one launch each way.
+ * Replaces: VoGE/Renderer.py:130-137 with VoGE/Aggregation.py:144-175 (centred = verts - origin[b];
+ * isigma = 2 * expend_sigma(sigmas)) and their autograd.  kind 1: sigmas [.., N, 3] (A = 2 diag(s)); kind 2: [.., N, 3, 3]
+ * (A = 2 S).  shared_verts / shared_sigmas: one [N, ...] set for every view, or [B, N, ...].  Writes mus [B*N,3],
+ * isigmas [B*N,3,3]; the backward writes g_verts / g_sigmas in the parameters' own shapes (either may be NULL), a shared
+ * set summing its views in a fixed order.
+ */
+int voge_general_preamble_fwd(const float *verts, const float *sigmas, const float *origin, int B, int N,
+                              int shared_verts, int shared_sigmas, int kind, float *mus, float *isigmas,
+                              voge_stream_t stream);
+int voge_general_preamble_bwd(const float *g_mus, const float *g_isigmas, int B, int N, int shared_verts,
+                              int shared_sigmas, int kind, float *g_verts, float *g_sigmas, voge_stream_t stream);
+
+/*
  * Backward of voge_rays_fwd: g_rays [B,h,W,3] (may be NULL) and g_origin [B,3] (may be NULL) ->
  * g_R [B,3,3], g_T [B,3], g_focal [B,2], g_pp [B,2] (each may be NULL).  scratch: B*16 floats.
  */

@@ -543,3 +543,34 @@ def test_replayed_training_iteration_equals_eager(hip_lib):
         assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max()), (key, a[:6], b[:6])
     assert np.abs(runs[True]["final_verts"] - runs[False]["final_verts"]).max() < 1e-3
     assert np.asarray(runs[True]["silhouette"])[-1] < 0.8 * np.asarray(runs[True]["silhouette"])[0]
+
+
+@pytest.mark.parametrize("kind,shared", [("diag", True), ("full", True), ("diag", False), ("full", False)])
+def test_general_preamble_equals_the_torch_chain(hip_lib, kind, shared):
+    """voge_general_preamble_fwd / _bwd against the reference's own operations (Renderer.py:130-137: centred = verts -
+    origin[b], isigma = 2 * expend_sigma(sigmas)) and their autograd: identical values (the same fp32 operations),
+    gradients to rounding of the sum over views."""
+    from voge_amd import ops
+    from voge_amd.Aggregation import expend_sigma
+    B, N = 3, 257
+    g = torch.Generator().manual_seed(5)
+    vshape = (N, 3) if shared else (B, N, 3)
+    sshape = ((N, 3) if kind == "diag" else (N, 3, 3)) if shared else ((B, N, 3) if kind == "diag" else (B, N, 3, 3))
+    verts = torch.randn(vshape, generator=g).to(DEV).requires_grad_(True)
+    sigmas = (torch.rand(sshape, generator=g) + 0.5).to(DEV).requires_grad_(True)
+    origin = torch.randn((B, 3), generator=g).to(DEV)
+    mus, isg = ops.general_preamble(verts, sigmas, origin)
+    v2, s2 = verts.detach().clone().requires_grad_(True), sigmas.detach().clone().requires_grad_(True)
+    vb = v2[None].expand(B, -1, -1) if shared else v2
+    centred = (vb - origin[:, None]).reshape(-1, 3)
+    if shared:
+        sig3 = expend_sigma(s2).unsqueeze(0).expand(B, -1, -1, -1)
+    else:
+        sig3 = torch.stack([expend_sigma(s2[b]) for b in range(B)])
+    isg_ref = (2 * sig3).reshape(-1, 3, 3)
+    assert torch.equal(mus, centred) and torch.equal(isg, isg_ref)
+    gm, ga = torch.randn(mus.shape, generator=g).to(DEV), torch.randn(isg.shape, generator=g).to(DEV)
+    ((mus * gm).sum() + (isg * ga).sum()).backward()
+    ((centred * gm).sum() + (isg_ref * ga).sum()).backward()
+    assert (verts.grad - v2.grad).abs().max().item() <= 1e-5 * max(1.0, v2.grad.abs().max().item())
+    assert (sigmas.grad - s2.grad).abs().max().item() <= 1e-5 * max(1.0, s2.grad.abs().max().item())

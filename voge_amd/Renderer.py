@@ -192,6 +192,16 @@ class GaussianRenderer(nn.Module):
                 return Fragments(None, index, None, hit_len, _lazy=lz)
             weight, index, valid_num, hit_len = ops.fragments(2, verts2d, sigmas, origin, rays, cam_fwd, thr_act, K, smode, occ)
             return Fragments(vert_weight=weight, vert_index=index, valid_num=valid_num, vert_hit_length=hit_len)
+        if (sigmas.dim() >= 2 and not st['inverse_sigma'] and not origin.requires_grad and FUSED_PREAMBLE
+                and verts.is_cuda and sigmas.shape[-1] == 3):
+            # (N,3) / (N,3,3) sigmas: the centring and 2 * expend_sigma of Renderer.py:130-137 as ONE launch each way
+            cam_fwd = _view_axis(cams, origin[:, None]) if behind else None
+            mus0, isg0 = ops.general_preamble(verts2d if shared_verts else verts, sigmas, origin)
+            if ops.lazy_eligible(0, mus0, isg0, None, rays, K):
+                index, hit_len, lz = ops.trace_lean(0, mus0, isg0, None, rays, cam_fwd, thr_act, K, 0, occ)
+                return Fragments(None, index, None, hit_len, _lazy=lz)
+            weight, index, valid_num, hit_len = ops.fragments(0, mus0, isg0, None, rays, cam_fwd, thr_act, K, 0, occ)
+            return Fragments(vert_weight=weight, vert_index=index, valid_num=valid_num, vert_hit_length=hit_len)
         centred = verts - origin[:, None]                                         # Renderer.py:130
         cam_fwd = _view_axis(cams, centred) if behind else None
         B = centred.shape[0]

@@ -72,6 +72,8 @@ SIGNATURES = {
     "voge_rays_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p] * 4),
     "voge_cones_floats": (_c_size_t, [_c_int] * 3),
     "voge_ray_cones": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "voge_general_preamble_fwd": (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p] * 3),
+    "voge_general_preamble_bwd": (_c_int, [_c_void_p] * 2 + [_c_int] * 5 + [_c_void_p] * 3),
     "voge_rays_bwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_void_p] * 6),
     "voge_ray_dense_fwd": (_c_int, [_c_void_p] * 3 + [_c_int, _c_long] + [_c_void_p] * 4),
     "voge_ray_dense_bwd": (_c_int, [_c_void_p] * 6 + [_c_int, _c_long] + [_c_void_p] * 4),

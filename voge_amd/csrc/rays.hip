@@ -264,3 +264,93 @@ extern "C" int voge_rays_bwd(const float *R, const float *T, const float *focal,
                      g_T, g_focal, g_pp);
   return launch_status();
 }
+
+// ------------------------------------------------------------------------------------------
+// The renderer's elementwise preamble for (N,3) and (N,3,3) sigmas (VoGE/Renderer.py:130-137 with
+// VoGE/Aggregation.py:144-175: centred = verts - origin[b]; isigma = 2 * expend_sigma(sigmas)) as ONE launch each way
+// instead of four to five torch kernels: the general path's frames are short enough for those launches to show
+// (8 % of the (N,3) frame at the cfg3 size).  Same fp32 operations, so the values are the torch chain's.
+//   kind 1: sigmas [.., N, 3] (per-axis values: A = 2 diag(s)), kind 2: [.., N, 3, 3] (A = 2 S).
+//   shared_verts / shared_sigmas: one [N, ...] set seen by every view, or [B, N, ...].
+// ------------------------------------------------------------------------------------------
+namespace voge {
+__global__ void __launch_bounds__(256)
+general_preamble_fwd_kernel(const float *__restrict__ verts, const float *__restrict__ sigmas, const float *__restrict__ origin,
+                            const int B, const int N, const int shared_verts, const int shared_sigmas, const int kind,
+                            float *__restrict__ mus, float *__restrict__ isg) {
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long)B * N) return;
+  const int b = (int)(g / N), n = (int)(g - (long)b * N);
+  const float *v = verts + 3 * (shared_verts ? (long)n : g), *o = origin + 3 * b;
+  mus[3 * g + 0] = v[0] - o[0]; mus[3 * g + 1] = v[1] - o[1]; mus[3 * g + 2] = v[2] - o[2];
+  float *A = isg + 9 * g;
+  if (kind == 1) {
+    const float *s = sigmas + 3 * (shared_sigmas ? (long)n : g);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = (i % 4 == 0) ? 2.0f * s[i / 4] : 0.0f;
+  } else {
+    const float *s = sigmas + 9 * (shared_sigmas ? (long)n : g);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = 2.0f * s[i];
+  }
+}
+// thread <-> one Gaussian of the parameter set; a shared set sums its views in a fixed order (deterministic)
+__global__ void __launch_bounds__(256)
+general_preamble_bwd_kernel(const float *__restrict__ g_mus, const float *__restrict__ g_isg, const int B, const int N,
+                            const int shared_verts, const int shared_sigmas, const int kind, float *__restrict__ g_verts,
+                            float *__restrict__ g_sigmas) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g_verts != nullptr && g_mus != nullptr) {
+    const long nv = shared_verts ? (long)N : (long)B * N;
+    if (t < nv) {
+      float x = 0.f, y = 0.f, z = 0.f;
+      for (int b = 0; b < (shared_verts ? B : 1); ++b) {
+        const float *gm = g_mus + 3 * (shared_verts ? (long)b * N + t : t);
+        x += gm[0]; y += gm[1]; z += gm[2];
+      }
+      g_verts[3 * t + 0] = x; g_verts[3 * t + 1] = y; g_verts[3 * t + 2] = z;
+    }
+  }
+  if (g_sigmas != nullptr && g_isg != nullptr) {
+    const long ns = shared_sigmas ? (long)N : (long)B * N;
+    if (t < ns) {
+      float a[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) a[i] = 0.f;
+      for (int b = 0; b < (shared_sigmas ? B : 1); ++b) {
+        const float *ga = g_isg + 9 * (shared_sigmas ? (long)b * N + t : t);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a[i] += ga[i];
+      }
+      if (kind == 1) {
+        g_sigmas[3 * t + 0] = 2.0f * a[0]; g_sigmas[3 * t + 1] = 2.0f * a[4]; g_sigmas[3 * t + 2] = 2.0f * a[8];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g_sigmas[9 * t + i] = 2.0f * a[i];
+      }
+    }
+  }
+}
+}  // namespace voge
+
+extern "C" int voge_general_preamble_fwd(const float *verts, const float *sigmas, const float *origin, int B, int N,
+                                         int shared_verts, int shared_sigmas, int kind, float *mus, float *isigmas,
+                                         voge_stream_t stream) {
+  if (B < 0 || N < 0 || (kind != 1 && kind != 2)) return VOGE_ERR_BAD_ARG;
+  if ((long)B * N == 0) return 0;
+  if (!verts || !sigmas || !origin || !mus || !isigmas) return VOGE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(general_preamble_fwd_kernel, dim3((unsigned)(((long)B * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     verts, sigmas, origin, B, N, shared_verts, shared_sigmas, kind, mus, isigmas);
+  return launch_status();
+}
+
+extern "C" int voge_general_preamble_bwd(const float *g_mus, const float *g_isigmas, int B, int N, int shared_verts,
+                                         int shared_sigmas, int kind, float *g_verts, float *g_sigmas,
+                                         voge_stream_t stream) {
+  if (B < 0 || N < 0 || (kind != 1 && kind != 2)) return VOGE_ERR_BAD_ARG;
+  if ((long)B * N == 0) return 0;
+  if ((g_verts && !g_mus) || (g_sigmas && !g_isigmas)) return VOGE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(general_preamble_bwd_kernel, dim3((unsigned)(((long)B * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     g_mus, g_isigmas, B, N, shared_verts, shared_sigmas, kind, g_verts, g_sigmas);
+  return launch_status();
+}

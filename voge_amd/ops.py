@@ -82,6 +82,62 @@ def _workspace(dev, nbytes):
     return ws
 
 
+class _GeneralPreamble(torch.autograd.Function):
+    """Renderer.py:130-137 for (N,3) / (N,3,3) sigmas as one launch each way (voge_general_preamble_fwd / _bwd):
+    forward(verts [N,3] | [B,N,3], sigmas [N,3] | [N,3,3] | [B,N,...], origin [B,3]) -> mus [B*N,3], isigmas [B*N,3,3]
+    (= verts - origin[b], 2 * expend_sigma(sigmas)).  No gradient for origin (camera optimisation takes the torch chain)."""
+
+    @staticmethod
+    def forward(ctx, verts, sigmas, origin):
+        lib = _lib.load()
+        v_c, s_c, o_c = _dev(verts, torch.float32, "verts"), _dev(sigmas, torch.float32, "sigmas"), _dev(origin, torch.float32, "origin")
+        B = o_c.shape[0]
+        shared_v = v_c.dim() == 2
+        N = v_c.shape[-2]
+        kind = 2 if tuple(s_c.shape[-2:]) == (3, 3) and s_c.dim() >= 3 else 1
+        shared_s = s_c.dim() == (3 if kind == 2 else 2)
+        assert v_c.shape[-1] == 3 and (shared_v or v_c.shape[0] == B) and o_c.shape == (B, 3)
+        assert s_c.shape[-1] == 3 and s_c.shape[-(kind + 1)] == N and (shared_s or s_c.shape[0] == B)
+        mus = torch.empty((B * N, 3), dtype=torch.float32, device=v_c.device)
+        isg = torch.empty((B * N, 3, 3), dtype=torch.float32, device=v_c.device)
+        with _on(v_c.device):
+            rc = lib.voge_general_preamble_fwd(_p(v_c), _p(s_c), _p(o_c), B, N, int(shared_v), int(shared_s), kind, _p(mus), _p(isg),
+                                               _stream())
+        _lib.check(rc, "voge_general_preamble_fwd")
+        ctx.meta = (B, N, shared_v, shared_s, kind, tuple(v_c.shape), tuple(s_c.shape))
+        ctx.set_materialize_grads(False)
+        return mus, isg
+
+    @staticmethod
+    def backward(ctx, g_mus, g_isg):
+        lib = _lib.load()
+        B, N, shared_v, shared_s, kind, vshape, sshape = ctx.meta
+        if ctx.needs_input_grad[2]:
+            raise _lib.VogeHipError("the fused preamble carries no gradient for the camera centre")
+        g_v = g_s = None
+        gm = None if g_mus is None else _dev(g_mus, torch.float32, "grad_mus")
+        ga = None if g_isg is None else _dev(g_isg, torch.float32, "grad_isigmas")
+        dev = (gm if gm is not None else ga)
+        if dev is None:
+            return None, None, None
+        dev = dev.device
+        if ctx.needs_input_grad[0] and gm is not None:
+            g_v = torch.empty(vshape, dtype=torch.float32, device=dev)
+        if ctx.needs_input_grad[1] and ga is not None:
+            g_s = torch.empty(sshape, dtype=torch.float32, device=dev)
+        if g_v is not None or g_s is not None:
+            with _on(dev):
+                rc = lib.voge_general_preamble_bwd(_p(gm if g_v is not None else None), _p(ga if g_s is not None else None), B, N,
+                                                   int(shared_v), int(shared_s), kind, _p(g_v), _p(g_s), _stream())
+            _lib.check(rc, "voge_general_preamble_bwd")
+        return g_v, g_s, None
+
+
+def general_preamble(verts, sigmas, origin):
+    """-> (mus [B*N,3], isigmas [B*N,3,3]) of the general path, one launch (see _GeneralPreamble)."""
+    return _GeneralPreamble.apply(verts, sigmas, origin)
+
+
 def trace_pool_usage(dev, B, N, H, W):
     """(used, capacity) of the candidate-list pool after the last forward trace of this shape on the current stream of
     `dev` (include/voge_hip.h: voge_trace_pool_usage) -- diagnostics: used > 0 means some 16x16-pixel quads held more
