@@ -114,7 +114,11 @@ def _check_frame(label, frag, img, ref, max_flips, img_tol=TOL):
     err = np.abs(n(frag.vert_hit_length)[hit] - ref["len"][hit]) / np.maximum(1.0, np.abs(ref["len"][hit]))
     assert err.max(initial=0.0) < TOL
     assert np.abs(n(img)[same] - ref["image"][same]).max(initial=0.0) < img_tol
-    assert np.abs(n(img) - ref["image"]).max() < 0.05      # a flipped member moves a weight by <= thr e^0.5
+    # a flipped member moves a weight by <= thr e^0.5 -- unless the list is full: then the flip also swaps the LAST member for
+    # another Gaussian of any weight (tools/soak.py, seed 201 case 77: K = 8, a member at the activation threshold with
+    # weight 0.014 missing, a far one with weight 0.50 in its place), so only lists with room are held to the bound
+    roomy = same | (ref["valid_num"] < idx.shape[-1])
+    assert np.abs(n(img) - ref["image"])[roomy].max(initial=0.0) < 0.05
     return same
 
 
