@@ -101,3 +101,40 @@ def run(n_cases=40, seed=0, verbose=True):
 
 if __name__ == "__main__":
     run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+
+def run_dense(n_cases=6, seed=0, verbose=True):
+    """Small DENSE objects: thousands to tens of thousands of Gaussians behind a few dozen pixels, so that quads exceed the
+    in-LDS sort (binB's pooled long path), binA's segments outgrow their inline part (extension chunks) or even their
+    extensions (slice re-test), with random N, image shape, K, batch size and entry point.  Forward trace against the
+    brute-force oracle.  -> number of cases whose quads took the long path."""
+    rng = np.random.default_rng(seed)
+    pooled = 0
+    for case in range(n_cases):
+        N = int(rng.choice([3000, 9000, 20000, 45000])); H = int(rng.integers(24, 80)); W = int(rng.integers(24, 80))
+        K = int(rng.choice([1, 5, 12, 25, 40, 64])); B = int(rng.integers(1, 3))
+        extent = float(rng.uniform(0.12, 0.5)); r_hi = float(rng.uniform(0.006, 0.03))
+        iso_api = bool(rng.integers(0, 2))
+        g = np.random.default_rng(int(rng.integers(1 << 30)))
+        verts = g.uniform(-extent, extent, (N, 3)).astype(np.float32)
+        r = g.uniform(0.5 * r_hi, r_hi, N)
+        sig = (1.0 / (r * r / (2 * np.log(1 / 0.6)))).astype(np.float32)
+        R, T = camera_np.look_at_view_transform([float(rng.uniform(2.5, 4.0))] * B, [float(rng.uniform(-30, 30))] * B,
+                                                [float(rng.uniform(0, 360)) + 47 * b for b in range(B)])
+        rays, origin = camera_np.pixel_rays(R, T, float(rng.uniform(0.8, 1.4)) * max(H, W), (W / 2.0, H / 2.0), (H, W))
+        mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+        isg = (2 * camera_np.expand_sigma(sig)).astype(np.float32)
+        isg = np.ascontiguousarray(np.broadcast_to(isg[None], (B,) + isg.shape))
+        thr_act = oracle.thr_act_of(0.01)
+        if iso_api:
+            sel = ops._RayTraceVoGEIso.apply(t(mus.reshape(-1, 3)), t(np.ascontiguousarray(isg[..., 0, 0]).reshape(-1)), t(rays), None, thr_act, K)
+        else:
+            sel = ops.ray_trace_fine(t(mus.reshape(-1, 3)), t(isg.reshape(-1, 3, 3)), t(rays), None, thr_act, 10, K)
+        used, cap = ops.trace_pool_usage("cuda:0", B, N, H, W)
+        pooled += used > 0
+        ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+        tag = f"dense case {case}: N={N} {H}x{W} K={K} B={B} extent={extent:.2f} r<={r_hi:.3f} {'iso-api' if iso_api else 'general-api'} pool {used}/{cap}"
+        if verbose:
+            print(tag, flush=True)
+        compare_trace([n(x) for x in sel], ref, thr_act, min_match=0.99, label=tag)
+    return pooled

@@ -34,6 +34,11 @@ def run(n_cases=24, seed=0, verbose=True):
         frag, img, gm, colors, (R, T) = C._render(sc)
         ref = C._oracle_frame(sc, R, T)
         same = C._check_frame(f"stress {case}", frag, img, ref, max_flips=max(3, H * W // 300))
+        # pixels AT a clamp -- min(rgb + (1 - silhouette) bg, 1) or min(sum of weights, 1) within 1e-5 of 1 -- carry no loss
+        # either: fp32 and fp64 may sit on different sides, and the gradient jumps there (tools/soak.py seed 302, case 42: a
+        # blue channel of 0.9999999 passed the oracle's gradient and half of it on the GPU, torch.min's tie rule)
+        x_white = ref["rgb"] + (1 - ref["silhouette"])[..., None]
+        same = same & ~((np.abs(x_white - 1) < 1e-5).any(-1) | (np.abs(ref["weight"].sum(-1) - 1) < 1e-5))
         tag = f"stress {case} N={N} {H}x{W} K={K} {form} {pattern}"
         if pattern == "white_background":
             g_img = rng.normal(size=ref["image"].shape) * same[..., None]          # flipped pixels carry no loss

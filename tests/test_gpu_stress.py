@@ -21,6 +21,14 @@ def test_randomised_sweep_through_the_ops(hip_lib, seed):
     assert worst, "no case reached the value checks"
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_randomised_dense_small_objects(hip_lib, seed):
+    """Random small dense objects (stress_parity.run_dense): the pooled long lists, the segment extensions and the slice
+    re-test of the binning, against the brute-force oracle."""
+    import stress_parity
+    assert stress_parity.run_dense(5, seed, verbose=True) > 0, "no case reached the long path"
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_randomised_sweep_through_the_renderer(hip_lib, seed):
     import stress_render

@@ -10,4 +10,6 @@ for seed in range(s0, s0 + 4):
     print("parity seed", seed, {k: f"{v:.2e}" for k, v in w.items()}, flush=True)
     w = stress_render.run(max(10, n // 2), seed, verbose=False)
     print("render seed", seed, {k: f"{v:.2e}" for k, v in w.items()}, flush=True)
+for seed in range(s0, s0 + 4):
+    print("dense seed", seed, "long-path cases:", stress_parity.run_dense(max(4, n // 10), seed, verbose=False), flush=True)
 print("soak ok in", round(time.time() - t0), "s")
