@@ -574,3 +574,54 @@ def test_general_preamble_equals_the_torch_chain(hip_lib, kind, shared):
     ((centred * gm).sum() + (isg_ref * ga).sum()).backward()
     assert (verts.grad - v2.grad).abs().max().item() <= 1e-5 * max(1.0, v2.grad.abs().max().item())
     assert (sigmas.grad - s2.grad).abs().max().item() <= 1e-5 * max(1.0, s2.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("form", ["scalar", "full"])
+def test_graph_replay_of_a_small_dense_object(hip_lib, form):
+    """A frame whose quads take binB's pooled long path (and whose segments use binA's extensions), captured into a HIP
+    graph: the pool counter is reset by binA on every replay and the extension arenas by an LDS counter, so back-to-back
+    replays must reproduce the eager frame's image and gradients.  Scalar and full 3x3 forms (deferred composite)."""
+    from voge_amd import ops
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import to_white_background
+    N, H, W, K = 30000, 96, 96, 16
+    rng = np.random.default_rng(11)
+    verts = rng.uniform(-0.3, 0.3, (N, 3)).astype(np.float32)
+    r = rng.uniform(0.006, 0.012, N)
+    s = (1.0 / (r * r / (2 * np.log(1 / 0.6)))).astype(np.float32)
+    sig = s if form == "scalar" else (s[:, None, None] * np.eye(3, dtype=np.float32)[None] * rng.uniform(0.7, 1.4, (N, 3, 1))).astype(np.float32)
+    cols = rng.uniform(0, 1, (N, 3)).astype(np.float32)
+    R, T = camera_np.look_at_view_transform(3.0, 10.0, 20.0)
+    renderer = renderer_for(H, W, K, 110.0)
+    gm = GaussianMeshes(t(verts), t(sig)).to(DEV)
+    colors = t(cols, rg=True)
+    Rt, Tt = t(R), t(T)
+    params = [gm.verts, gm.sigmas, colors]
+
+    def step():
+        for p in params:
+            p.grad = None
+        img = to_white_background(renderer(gm, R=Rt, T=Tt), colors)
+        img.sum().backward()
+        return img
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            img_e = step()
+        used, cap = ops.trace_pool_usage(side.device, 1, N, H, W)      # (the workspace of THIS stream)
+    assert 0 < used <= cap, (used, cap)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    want_img = img_e.detach().clone()
+    want = [p.grad.detach().clone() for p in params]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        img_g = step()
+    for _ in range(4):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert (img_g - want_img).abs().max().item() < 1e-6
+    for p, w in zip(params, want):
+        assert (p.grad - w).abs().max().item() <= 2e-4 * max(1.0, w.abs().max().item())      # (atomics: order of the sums)
+    assert float(want_img.min()) < 0.9      # the object is there
