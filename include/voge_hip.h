@@ -48,9 +48,13 @@ const char *voge_error_string(int code);
 
 /*
  * Bytes of scratch the forward trace needs for B batch elements of N Gaussians and an HxW
- * image: per-Gaussian derived records (cull sphere + quadratic-form coefficients, 64 B each)
- * and the per-super-tile (64x64 px) depth-sorted candidate lists.  Caller allocates, 256-byte
- * aligned (any torch allocation is).
+ * image: per-Gaussian derived records (cull sphere + quadratic-form coefficients, 112 B each),
+ * the binning's segments (per 32x32-px super-tile and Gaussian slice) with their extension arenas,
+ * the per-tile (8x8 px) depth-ordered candidate lists, and a pool of list entries (32 per Gaussian,
+ * at least 2^20) for image quads with more candidates than the in-LDS sort takes.  165 MB at
+ * 50k Gaussians / 512^2, 774 MB at 200k / 1024^2.  Caller allocates, 256-byte aligned (any torch
+ * allocation is); the contents need no initialisation and nothing in it outlives the call except
+ * what voge_trace_pool_usage reads.
  */
 size_t voge_trace_workspace_bytes(int B, int N, int H, int W);
 
