@@ -10,7 +10,7 @@ from voge_amd.Renderer import GaussianRenderSettings, GaussianRenderer
 from voge_amd.Meshes import GaussianMeshes
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_50k_512"
 N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[name]
-verts, sig, colors = scenes.random_gaussians(N, seed=0)
+verts, sig, colors = scenes.random_gaussians(N, seed=0, anisotropic=bool(__import__("os").environ.get("ANISO")))      # ANISO=1: [N,3,3] sigmas
 import os
 dd = float(os.environ.get("DIST", dd))      # (DIST=16: the small-object case of tools/cliff_scan.py -- binB's long path)
 dev = torch.device("cuda", 0)

@@ -410,16 +410,18 @@ struct BinStream {
   Cone qcone;
 };
 // The quad-cone test of one batch (kGU entries per thread), then `sink(ids, records, kept, has ellipsoid, ellipsoid key)`.
-template <class Sink>
+// ELL (here and below): Gaussians with an ellipsoid record can occur (the general entry points); the scalar-sigma ones
+// instantiate everything without that code.
+template <bool ELL, class Sink>
 __device__ __forceinline__ void bin_test_batch(const BinStream &S, const int (&gid)[kGU], const float4 (&c)[kGU], Sink &&sink) {
   bool kp[kGU], el[kGU];
   float gkey[kGU];
 #pragma unroll
   for (int j = 0; j < kGU; ++j) {
     kp[j] = cone_keep(c[j], S.qcone);         // (padding: reach -1, never kept)
-    el[j] = kp[j] && cull_has_ell(c[j]);
+    el[j] = ELL && kp[j] && cull_has_ell(c[j]);
     gkey[j] = 0.0f;
-    if (__any(el[j])) {
+    if (ELL && __any(el[j])) {
       if (el[j]) {
         const float4 e0 = S.ellb[2 * (size_t)gid[j]], e1 = S.ellb[2 * (size_t)gid[j] + 1];
         kp[j] = cone_keep_ell(c[j], e0, e1, S.qcone);
@@ -437,7 +439,7 @@ __device__ __forceinline__ void bin_test_batch(const BinStream &S, const int (&g
   sink(gid, c, kp, el, gkey);
 }
 // One pass over the quad's sources, kGU entries per thread at a time; the sink sees every batch, wave-uniformly.
-template <class Sink>
+template <bool ELL, class Sink>
 __device__ __forceinline__ void bin_stream_sources(const BinStream &S, const int *segn /* LDS: exclusive prefix of the segment counts;
                                                    behind it (BinLds): extn[kParts + 1] */, const int tid, Sink &&sink) {
   for (int base = 0; base < S.n_src; base += kQT * kGU) {      // the segments binA filled
@@ -457,7 +459,7 @@ __device__ __forceinline__ void bin_stream_sources(const BinStream &S, const int
         c[j] = S.segr[o];
       }
     }
-    bin_test_batch(S, gid, c, sink);
+    bin_test_batch<ELL>(S, gid, c, sink);
   }
   if (S.n_ext > 0) {      // (rare) the part of long segments that binA put into their extensions: ids, records by gather
     const int *extn = segn + (kParts + 1), *exto = S.exto;
@@ -478,7 +480,7 @@ __device__ __forceinline__ void bin_stream_sources(const BinStream &S, const int
       }
 #pragma unroll
       for (int j = 0; j < kGU; ++j) c[j] = (gid[j] >= 0) ? S.cullb[gid[j]] : make_float4(0.f, 0.f, 0.f, -1.f);
-      bin_test_batch(S, gid, c, sink);
+      bin_test_batch<ELL>(S, gid, c, sink);
     }
   }
   if (S.ovf != 0u) {      // (rarer) slices whose segment overflowed: their Gaussians straight from the per-Gaussian records
@@ -492,7 +494,7 @@ __device__ __forceinline__ void bin_stream_sources(const BinStream &S, const int
         gid[j] = ok ? g : -1;
         c[j] = ok ? S.cullb[g] : make_float4(0.f, 0.f, 0.f, -1.f);
       }
-      bin_test_batch(S, gid, c, sink);
+      bin_test_batch<ELL>(S, gid, c, sink);
     }
   }
 }
@@ -598,6 +600,7 @@ struct BinLong {
   float *pool_lb;
   int2 *my_order;
 };
+template <bool ELL>
 __device__ __forceinline__ void binB_long_path(const BinLong A, BinLds &L) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const BinStream &S = A.S;
@@ -629,7 +632,7 @@ __device__ __forceinline__ void binB_long_path(const BinLong A, BinLds &L) {
   if (pooled) {
     int32_t *sv_id = A.pool_id + surv_at;
     float *sv_key = A.pool_lb + surv_at;
-    bin_stream_sources(S, L.segn, tid, [&](const int (&g)[kGU], const float4 (&cj)[kGU], const bool (&kp)[kGU],
+    bin_stream_sources<ELL>(S, L.segn, tid, [&](const int (&g)[kGU], const float4 (&cj)[kGU], const bool (&kp)[kGU],
                                             const bool (&el)[kGU], const float (&gkey)[kGU]) {
       int slot[kGU];
       bin_batch_slots(&L.count, lane, kp, slot);
@@ -661,7 +664,7 @@ __device__ __forceinline__ void binB_long_path(const BinLong A, BinLds &L) {
     for (int i = tid; i < total; i += kQT) {
       const uint32_t word = (uint32_t)sv_id[i];
       const size_t g = word & 0x7fffffffu;
-      const bool el = (word & 0x80000000u) != 0u;
+      const bool el = ELL && (word & 0x80000000u) != 0u;
       const int q = bin_bucket_of(A.Kk, sv_key[i]);
       const unsigned mk = tile_mask(g, S.cullb[g], el);
 #pragma unroll
@@ -688,7 +691,7 @@ __device__ __forceinline__ void binB_long_path(const BinLong A, BinLds &L) {
       *reinterpret_cast<int2 *>(&L.hist4[t][2 * tid]) = make_int2(off, off + v.x);
       __syncthreads();
     }
-    if (A.Kk.flagged) bin_bmin_suffix(L.bmin, L.wsum, tid);
+    if (ELL && A.Kk.flagged) bin_bmin_suffix(L.bmin, L.wsum, tid);
     if (tid == 0) {
       const int need = tile_n[0] + tile_n[1] + tile_n[2] + tile_n[3];
       int at = (need > 0) ? atomicAdd(A.pool_top, need) : 0;
@@ -703,7 +706,7 @@ __device__ __forceinline__ void binB_long_path(const BinLong A, BinLds &L) {
       for (int i = tid; i < total; i += kQT) {
         const uint32_t word = (uint32_t)sv_id[i];
         const size_t g = word & 0x7fffffffu;
-        const bool el = (word & 0x80000000u) != 0u;
+        const bool el = ELL && (word & 0x80000000u) != 0u;
         const float kv = sv_key[i];
         const int q = bin_bucket_of(A.Kk, kv);
         const unsigned mk = tile_mask(g, S.cullb[g], el);
@@ -745,6 +748,7 @@ __device__ __forceinline__ void binB_long_path(const BinLong A, BinLds &L) {
 #ifndef VOGE_BINB_WPE
 #define VOGE_BINB_WPE 4
 #endif
+template <bool ELL>
 __global__ void __launch_bounds__(kQT) __attribute__((amdgpu_waves_per_eu(VOGE_BINB_WPE, VOGE_BINB_WPE)))
 binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, const int *__restrict__ seg_count,
             const int32_t *__restrict__ seg_id, const float4 *__restrict__ seg_rec, const float *__restrict__ rays,
@@ -877,7 +881,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   S.cullb = cullb; S.ellb = ellb; S.segr = segr; S.segs = segs; S.n_src = n_src; S.N = N; S.ovf = ovf; S.qcone = qcone;
   S.ext_id = ext_id; S.n_ext = L.extn[kParts]; S.exto = &L.exto[0][0];
   // pass one: the quad's survivors -- keys compacted in LDS (the first kQCap of them), extrema, the largest sphere reach
-  bin_stream_sources(S, L.segn, tid, [&](const int (&g)[kGU], const float4 (&cj)[kGU], const bool (&kp)[kGU],
+  bin_stream_sources<ELL>(S, L.segn, tid, [&](const int (&g)[kGU], const float4 (&cj)[kGU], const bool (&kp)[kGU],
                                           const bool (&el)[kGU], const float (&gkey)[kGU]) {
     int slot[kGU];
     bin_batch_slots(&L.count, lane, kp, slot);
@@ -908,7 +912,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   rm = fmaxf(fmaxf(L.red[2], L.red[10]), fmaxf(L.red[18], L.red[26]));
   const float span = fmaxf(hi - lo, 1e-20f);
   const float scale = (float)(kBuckets - 2) / span;
-  const bool flagged = L.nflag != 0;     // any entry with an ellipsoid record (workgroup-uniform)
+  const bool flagged = ELL && L.nflag != 0;     // any entry with an ellipsoid record (workgroup-uniform)
   BinKeys Kk;
   Kk.lo = lo; Kk.scale = scale; Kk.span = span; Kk.slack = 1.13f * rm * (1.0f + 1e-5f); Kk.flagged = flagged;
   auto bucket_of = [&](const uint64_t k) { return bin_bucket_of(Kk, ord2f((uint32_t)(k >> 32))); };
@@ -928,14 +932,14 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
     A.S = S; A.Kk = Kk; A.tcone = tcone; A.tile_ok = tile_ok; A.tile = tile; A.quad = quad; A.total = total;
     A.pool_top = pool_top; A.tl_off = tl_off; A.tl_count = tl_count; A.q_count = q_count; A.pool_cap = pool_cap;
     A.pool_id = pool_id; A.pool_lb = pool_lb; A.my_order = my_order; A.seg_ext = seg_ext; A.bin = bin;
-    binB_long_path(A, L);
+    binB_long_path<ELL>(A, L);
   } else {
 #endif
   for (int i = tid; i < total; i += kQT) {
     const uint64_t kk = L.keys[i];
     const int q = bucket_of(kk);
     atomicAdd(&L.hist[q], 1);
-    if ((uint32_t)kk & 0x80000000u) atomicMin(&L.bmin[q], f2ord(bin_own_bound(S, (size_t)((uint32_t)kk & 0x7fffffffu))));
+    if (ELL && ((uint32_t)kk & 0x80000000u)) atomicMin(&L.bmin[q], f2ord(bin_own_bound(S, (size_t)((uint32_t)kk & 0x7fffffffu))));
   }
   __syncthreads();
   // exclusive scan of the kBuckets counters: two consecutive buckets per thread, wave scan, wave offsets
@@ -990,7 +994,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   // the len bound of list entry `k` (its bucket's lower edge, see above)
   auto len_bound = [&](const uint32_t word, const float4 cr) {
     // the entry's depth key, as the gather computed it (same record, same cone: the same bits)
-    const float v = (word & 0x80000000u) ? fmaf(cr.z, qcone.az, fmaf(cr.y, qcone.ay, cr.x * qcone.ax)) + 0.0f
+    const float v = (ELL && (word & 0x80000000u)) ? fmaf(cr.z, qcone.az, fmaf(cr.y, qcone.ay, cr.x * qcone.ax)) + 0.0f
                                          : depth_key(cr, qcone);
     return bin_len_bound(Kk, L.bmin, v);
   };
@@ -1020,7 +1024,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
       for (int q = 0; q < kFU; ++q) {
         if (base + q * 64 >= total) break;      // uniform
         const uint32_t word = k[q];
-        const bool el = kp[q] && (word & 0x80000000u);      // sphere survivors with an ellipsoid record: that test too
+        const bool el = ELL && kp[q] && (word & 0x80000000u);      // sphere survivors with an ellipsoid record: that test too
         if (__any(el)) {
           if (el) {
             const size_t g = word & 0x7fffffffu;

@@ -1140,7 +1140,7 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
     const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, cache);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(binB_kernel, dim3(ws.nstx * ws.nsty * 4, B), dim3(kQT), 0, st, ws.cull, ws.ell, ws.seg_count, ws.seg_id, ws.seg_rec,
+  hipLaunchKernelGGL(binB_kernel<!ISO>, dim3(ws.nstx * ws.nsty * 4, B), dim3(kQT), 0, st, ws.cull, ws.ell, ws.seg_count, ws.seg_id, ws.seg_rec,
                      rays, N, H, W, ws.nstx, ws.nsty, ws.nbin, ws.q_count, ws.q_id, ws.q_lb, ws.tl_count, ws.tl_id, ws.tl_lb,
                      ws.order, ws.pool_top, ws.pool_cap, ws.pool_id, ws.pool_lb, ws.tl_off, ws.seg_ext, ws.ext_id, K, idx, len, act, dsd,
                      cnt, weight, valid_num);
