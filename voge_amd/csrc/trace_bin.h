@@ -150,13 +150,13 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
             const float thr_act, const IsoView view, float4 *__restrict__ cull, float4 *__restrict__ ms,
             int *__restrict__ seg_count /* [B*nst][kParts] */, int32_t *__restrict__ seg_id /* [B*nst][kParts][kSegCap] */,
             float4 *__restrict__ seg_rec /* the same shape: the entries' cull records */,
-            int *__restrict__ pool_top /* binB's list pool: reset here, one launch ahead of its first use */,
+            unsigned long long *__restrict__ pool_top /* binB's list pool: reset here, one launch ahead of its first use */,
             int *__restrict__ seg_ext /* [B*nst][kParts][kExtChunks]: starts of the segment's extension chunks in ext_id */,
             int32_t *__restrict__ ext_id /* [B][regions][kParts][ext_arena] */, const int ext_arena) {
   __shared__ BinALds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int region = blockIdx.x / kParts, part = blockIdx.x - region * kParts, b = blockIdx.y;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *pool_top = 0;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *pool_top = 0ull;
   const int rx = region % nst0x, ry = region / nst0x;
   const int nst = nstx * nsty;
   if (tid < kCh * kCh) { L.base[tid] = 0; L.extn[tid] = 0; }
@@ -592,7 +592,8 @@ struct BinLong {
   Cone tcone;
   bool tile_ok;
   int tile, quad, total;
-  int *pool_top, *tl_off, *tl_count, *q_count;
+  unsigned long long *pool_top;      // (64 bits: the counter runs on past an exhausted pool and must not wrap)
+  int *tl_off, *tl_count, *q_count;
   const int *seg_ext;
   int bin;
   int pool_cap;
@@ -620,8 +621,8 @@ __device__ __forceinline__ void binB_long_path(const BinLong A, BinLds &L) {
   if (tid == 0) {
     // the quad's survivors -- (id | flag, depth key) -- go to the pool first: the sources (up to N entries where
     // segments overflowed) are streamed ONCE more, everything after that walks the `total` survivors only
-    int at = atomicAdd(A.pool_top, total);
-    if (total > A.pool_cap || at > A.pool_cap - total) at = -1;      // exhausted (the counter may run on: only compared)
+    const unsigned long long at64 = atomicAdd(A.pool_top, (unsigned long long)total);
+    int at = (at64 + (unsigned long long)total <= (unsigned long long)A.pool_cap) ? (int)at64 : -1;      // -1: exhausted (the counter runs on)
     L.toff[0] = at;
     L.count = 0;
   }
@@ -694,8 +695,8 @@ __device__ __forceinline__ void binB_long_path(const BinLong A, BinLds &L) {
     if (ELL && A.Kk.flagged) bin_bmin_suffix(L.bmin, L.wsum, tid);
     if (tid == 0) {
       const int need = tile_n[0] + tile_n[1] + tile_n[2] + tile_n[3];
-      int at = (need > 0) ? atomicAdd(A.pool_top, need) : 0;
-      if (need > A.pool_cap || at > A.pool_cap - need) at = -1;
+      const unsigned long long at64 = (need > 0) ? atomicAdd(A.pool_top, (unsigned long long)need) : 0ull;
+      int at = (at64 + (unsigned long long)need <= (unsigned long long)A.pool_cap) ? (int)at64 : -1;
 #pragma unroll
       for (int t = 0; t < kTilesPerQuad; ++t) { L.toff[t] = at; if (at >= 0) at += tile_n[t]; }
     }
@@ -757,7 +758,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
             int *__restrict__ q_count, int32_t *__restrict__ q_id, float *__restrict__ q_lb,
             int *__restrict__ tl_count, int32_t *__restrict__ tl_id, float *__restrict__ tl_lb,
             int2 *__restrict__ order /* [nbin_total][16]: (tile, list length) by launch rank */,
-            int *__restrict__ pool_top, const int pool_cap, int32_t *__restrict__ pool_id, float *__restrict__ pool_lb,
+            unsigned long long *__restrict__ pool_top, const int pool_cap, int32_t *__restrict__ pool_id, float *__restrict__ pool_lb,
             int *__restrict__ tl_off, const int *__restrict__ seg_ext, const int32_t *__restrict__ ext_id,
             const int K, int32_t *__restrict__ out_idx, float *__restrict__ out_len, float *__restrict__ out_act,
             float *__restrict__ out_dsd, int32_t *__restrict__ out_cnt, float *__restrict__ out_weight,

@@ -1027,7 +1027,7 @@ struct TraceWs {
   float *tl_lb;
   float4 *seg_rec;
   int2 *order;                        // launch order of the sweep: (tile, list length) by super-tile rank and slot
-  int *pool_top;                      // binB's long path: lists of quads with more than kQCap candidates
+  unsigned long long *pool_top;       // binB's long path: lists of quads with more than kQCap candidates
   int32_t *pool_id;
   float *pool_lb;
   int *tl_off;                        // per sweep tile: start of its pooled list
@@ -1061,13 +1061,13 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
        *ti = take(ntile * kTileCap * 4), *tl = take(ntile * kTileCap * 4), *sr = take(nbin * kParts * (size_t)kSegCap * 16),
        *cq = take(nbin * kTilesPerBin * 8 * 2);      // (second half: the exactly sorted copy of VOGE_EXACT_ORDER builds)
   const size_t npool = trace_pool_entries(P);
-  char *pt = take(4), *pi = take(npool * 4), *pl = take(npool * 4), *to = take(ntile * 4);
+  char *pt = take(8), *pi = take(npool * 4), *pl = take(npool * 4), *to = take(ntile * 4);
   const int nst0x = (W + kST0 - 1) / kST0, nst0y = (H + kST0 - 1) / kST0;
   const size_t arena = (size_t)kExtMul * slice_cap(N);
   char *se = take(nbin * kParts * kExtChunks * 4), *ei = take((size_t)B * nst0x * nst0y * kParts * arena * 4);
   if (ws) {
     ws->seg_ext = reinterpret_cast<int *>(se); ws->ext_id = reinterpret_cast<int32_t *>(ei); ws->ext_arena = (int)arena;
-    ws->pool_top = reinterpret_cast<int *>(pt); ws->pool_id = reinterpret_cast<int32_t *>(pi);
+    ws->pool_top = reinterpret_cast<unsigned long long *>(pt); ws->pool_id = reinterpret_cast<int32_t *>(pi);
     ws->pool_lb = reinterpret_cast<float *>(pl); ws->tl_off = reinterpret_cast<int *>(to);
     ws->pool_cap = (int)npool;
     ws->cull = reinterpret_cast<float4 *>(c); ws->evr = reinterpret_cast<float4 *>(e);
@@ -1199,7 +1199,10 @@ extern "C" int voge_trace_pool_usage(const void *workspace, int B, int N, int H,
   TraceWs ws;
   trace_ws_layout(B, N, H, W, const_cast<void *>(workspace), &ws);
   *capacity = ws.pool_cap;
-  return (int)hipMemcpy(used, ws.pool_top, sizeof(int), hipMemcpyDeviceToHost);
+  unsigned long long top = 0ull;
+  const hipError_t e = hipMemcpy(&top, ws.pool_top, sizeof(top), hipMemcpyDeviceToHost);
+  *used = top > 0x7fffffffull ? 0x7fffffff : (int)top;
+  return (int)e;
 }
 
 extern "C" int voge_ray_cones(const float *rays, int B, int H, int W, float *cones, voge_stream_t stream);   // rays.hip
