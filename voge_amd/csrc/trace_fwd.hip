@@ -1063,7 +1063,10 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
   const size_t npool = trace_pool_entries(P);
   char *pt = take(8), *pi = take(npool * 4), *pl = take(npool * 4), *to = take(ntile * 4);
   const int nst0x = (W + kST0 - 1) / kST0, nst0y = (H + kST0 - 1) / kST0;
-  const size_t arena = (size_t)kExtMul * slice_cap(N);
+  size_t arena = (size_t)kExtMul * slice_cap(N);
+  // (seg_ext holds 32-bit offsets into ext_id: a batch so large that the extensions would pass 2^31 ids goes without them
+  // -- such segments then count as overflowed and binB re-tests their slice, as before round 3)
+  if ((size_t)B * nst0x * nst0y * kParts * arena > (size_t)0x7fffffff) arena = 0;
   char *se = take(nbin * kParts * kExtChunks * 4), *ei = take((size_t)B * nst0x * nst0y * kParts * arena * 4);
   if (ws) {
     ws->seg_ext = reinterpret_cast<int *>(se); ws->ext_id = reinterpret_cast<int32_t *>(ei); ws->ext_arena = (int)arena;
