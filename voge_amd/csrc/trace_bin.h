@@ -905,6 +905,10 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   // append.  Bucket 0 collects the -inf keys (unbounded reach).
   float hi = wave_max(khi), lo = wave_min(klo), rm = wave_max(rmax);
   if (lane == 0) { L.red[wave * 8 + 0] = hi; L.red[wave * 8 + 1] = lo; L.red[wave * 8 + 2] = rm; }
+  // (the histogram shares its LDS with the extension chunk tables: every wave must be through with its source pass
+  // before the first one clears it -- without this barrier a fast wave zeroed table entries a slow one still read, and a
+  // candidate went missing once in a few hundred dense scenes: tools/soak.py, seed 502)
+  if (S.n_ext > 0) __syncthreads();      // (uniform, rare)
   for (int i = tid; i < kBuckets; i += kQT) { L.hist[i] = 0; L.bmin[i] = f2ord(INFINITY); }
   __syncthreads();
   const int total = L.count;
