@@ -29,6 +29,15 @@ def test_randomised_dense_small_objects(hip_lib, seed):
     assert stress_parity.run_dense(5, seed, verbose=True) > 0, "no case reached the long path"
 
 
+def test_dense_scenes_that_once_lost_a_candidate(hip_lib):
+    """Regression: seed 502 of the dense sweep holds a scene (45 000 Gaussians, two views) in which binB's extension chunk
+    tables were cleared by a fast wave while a slow one still read them -- one wrong candidate in about one run of twelve.
+    Five passes over its fifteen cases."""
+    import stress_parity
+    for _ in range(5):
+        stress_parity.run_dense(15, 502, verbose=False)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_randomised_sweep_through_the_renderer(hip_lib, seed):
     import stress_render
