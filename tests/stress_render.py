@@ -12,6 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import oracle
+from oracle import camera_np
 import test_gpu_configs as C
 from util import TOL, random_scene
 
@@ -31,7 +32,12 @@ def run(n_cases=24, seed=0, verbose=True):
             sig = (sig[:, None] * rng.uniform(0.6, 1.6, (N, 3))).astype(np.float32)
         sc = dict(verts=verts, sigmas=sig, colors=cols, focal=float(rng.uniform(0.7, 1.4)) * max(H, W), principal=(W / 2.0, H / 2.0),
                   image_size=(H, W), dist=float(rng.uniform(2.6, 4.0)), elev=float(rng.uniform(-40, 40)), azim=float(rng.uniform(0, 360)), K=K)
-        frag, img, gm, colors, (R, T) = C._render(sc)
+        views = None
+        if rng.random() < 0.35:      # a batch of 2-3 views of the same Gaussians (shared verts / sigmas: the fused preambles)
+            nv = int(rng.integers(2, 4))
+            views = camera_np.look_at_view_transform([sc["dist"] + 0.3 * v for v in range(nv)], [sc["elev"] - 15.0 * v for v in range(nv)],
+                                                     [sc["azim"] + 70.0 * v for v in range(nv)])
+        frag, img, gm, colors, (R, T) = C._render(sc, views=views)
         ref = C._oracle_frame(sc, R, T)
         same = C._check_frame(f"stress {case}", frag, img, ref, max_flips=max(3, H * W // 300))
         # pixels AT a clamp -- min(rgb + (1 - silhouette) bg, 1) or min(sum of weights, 1) within 1e-5 of 1 -- carry no loss
@@ -39,7 +45,7 @@ def run(n_cases=24, seed=0, verbose=True):
         # blue channel of 0.9999999 passed the oracle's gradient and half of it on the GPU, torch.min's tie rule)
         x_white = ref["rgb"] + (1 - ref["silhouette"])[..., None]
         same = same & ~((np.abs(x_white - 1) < 1e-5).any(-1) | (np.abs(ref["weight"].sum(-1) - 1) < 1e-5))
-        tag = f"stress {case} N={N} {H}x{W} K={K} {form} {pattern}"
+        tag = f"stress {case} N={N} {H}x{W} K={K} {form} {pattern}" + ("" if views is None else f" B={len(views[0])}")
         if pattern == "white_background":
             g_img = rng.normal(size=ref["image"].shape) * same[..., None]          # flipped pixels carry no loss
             (img * C.t(g_img)).sum().backward()
@@ -47,7 +53,8 @@ def run(n_cases=24, seed=0, verbose=True):
             tag += f" [{type(img.grad_fn).__name__}]"
         else:
             from voge_amd.Renderer import get_silhouette, interpolate_attr
-            rgb, sil = interpolate_attr(frag, colors), get_silhouette(frag)
+            nB = 1 if views is None else len(views[0])
+            rgb, sil = interpolate_attr(frag, colors.repeat(nB, 1) if nB > 1 else colors), get_silhouette(frag)
             g_rgb = rng.normal(size=ref["rgb"].shape) * same[..., None]
             g_silh = rng.normal(size=ref["silhouette"].shape) * same
             ((rgb * C.t(g_rgb)).sum() + (sil * C.t(g_silh)).sum()).backward()
@@ -56,7 +63,8 @@ def run(n_cases=24, seed=0, verbose=True):
             live = np.arange(K)[None, None, None] < ref["valid_num"][..., None]
             g_act, g_len, g_dsd = oracle.composite_bwd(ref["act"], ref["len"], ref["dsd"], g_w + (g_silh * (wsum < 1))[..., None] * live, 1.0)
             _, g_mu, g_A = oracle.trace_bwd(ref["mus"], ref["isg"], ref["rays"], ref["idx"], g_len, g_act, g_dsd)
-            g_A = g_A.reshape(-1, 3, 3)
+            g_attr, g_mu = g_attr.reshape(nB, N, -1).sum(0), g_mu.reshape(nB, N, 3).sum(0)      # (one shared set: sum over the views)
+            g_A = g_A.reshape(nB, N, 3, 3).sum(0)
             g_sig = {1: 2 * np.einsum("nii->n", g_A), 2: 2 * np.einsum("nii->ni", g_A), 3: 2 * g_A}[np.asarray(sig).ndim]
             want = (g_attr, g_mu, g_sig)
         got = (colors.grad, gm.verts.grad, gm.sigmas.grad)

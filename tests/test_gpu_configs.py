@@ -55,7 +55,9 @@ def _render(sc, rows=None, grad=True, max_point_per_bin=-1, views=None):
     colors = t(sc["colors"], rg=grad)
     kw = {} if rows is None else dict(rows=rows)
     frag = renderer(gm, R=t(R), T=t(T), **kw)
-    img = to_white_background(frag, colors)
+    B = np.asarray(R).reshape(-1, 3, 3).shape[0]
+    # (a batch of B views addresses attribute rows b * N + n: the attributes are tiled over the batch, Aggregation.py:120)
+    img = to_white_background(frag, colors.repeat(B, 1) if B > 1 else colors)
     return frag, img, gm, colors, (R, T)
 
 
