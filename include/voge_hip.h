@@ -68,6 +68,15 @@ size_t voge_trace_workspace_bytes(int B, int N, int H, int W);
 int voge_trace_pool_usage(const void *workspace, int B, int N, int H, int W, int *used, int *capacity);
 
 /*
+ * Diagnostic / A-B switch (process-wide): which kernel the scalar-sigma forward entry points (voge_trace_topk_fwd_iso*,
+ * voge_fragments_fwd_iso*) sweep with.  0 (default): round 4's sweep_iso_kernel (fp32 len + 16-bit stream position per
+ * list entry, float-compare commits); 1: round 3's trace_fwd_kernel (64-bit (ord(len), id) keys).  Both produce the same
+ * bits (tests/test_gpu_parity.py); the switch exists so that a test can say so and a profile can time both.  No reference
+ * counterpart.
+ */
+int voge_debug_sweep_variant(int variant);
+
+/*
  * Fine ray trace forward, "all Gaussians are candidates" form.
  * Replaces: VoGE._C.ray_trace_voge_fine (ray_trace_voge.h:7-15, ray_trace_voge.cu:219-280)
  * called with the bin list RayTracing.py:22-26 builds for max_points_per_bin == -1

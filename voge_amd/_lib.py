@@ -23,6 +23,7 @@ SIGNATURES = {
     "voge_error_string": (ctypes.c_char_p, [_c_int]),
     "voge_trace_workspace_bytes": (_c_size_t, [_c_int] * 4),
     "voge_trace_pool_usage": (_c_int, [_c_void_p] + [_c_int] * 4 + [_c_void_p] * 2),
+    "voge_debug_sweep_variant": (_c_int, [_c_int]),
     "voge_trace_topk_fwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_float, _c_void_p, _c_size_t]
                             + [_c_void_p] * 6),
     "voge_trace_topk_list_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 9 + [_c_float] + [_c_void_p] * 6),

@@ -1,0 +1,462 @@
+// Round 4: the scalar-sigma sweep, rebuilt around what round 3's per-tile timers and a VALU / LDS issue micro-benchmark
+// (tools/valu_bench.hip, profiles/r4_valu_bench.txt) said about the old kernel (trace_fwd_kernel<1, true>):
+//   * a tile spends two thirds of its life in the consume loop, ~160 ns per candidate at 1.75 waves per SIMD: ~27 VALU +
+//     ~14 SALU + 3 LDS instructions, of which the 64-bit (ord(len) << 32 | id) keys cost the most (key building, two 64-bit
+//     compares at ~2x the price of a float compare, register pairs through every select);
+//   * the 8-byte keys are also what holds the kernel at 7 waves per CU.
+// Here a list entry is the fp32 len itself plus a 16-bit POSITION in the tile's candidate stream (6 bytes: 9 workgroups per
+// CU at K = 40).  Order and admission are decided by plain float compares; the Gaussian's id is looked up only when two
+// lens tie exactly (the slow path) and in the epilogue, so the result is still "the K lexicographically smallest
+// (len, id)" of ray_trace_voge.cu:197-212.  The staged chunk is kept as SoA (x[], y[], z[], a[]): one ds_read_b128 per
+// array serves four candidates, addresses are immediates, and no id is read in the loop at all.
+// Streams longer than 65536 entries (a pooled list or the stream-everything fallback of a large scene) take the same
+// code with 32-bit positions over HALF the rays at a time (two passes: the same LDS bytes hold 32 columns of u32).
+#pragma once
+#include <type_traits>
+
+#include "voge_common.h"
+
+namespace voge {
+
+#ifndef VOGE_SWEEP_V2
+#define VOGE_SWEEP_V2 1
+#endif
+
+constexpr int kS2TP = 65;      // floats per row of the len array (odd: the epilogue's transposed reads stay conflict-light)
+constexpr int kS2TQ = 66;      // u16 per row of the position array (= 33 u32 in the wide form)
+constexpr int kS2Pad = 4;      // never-hit records behind the staged chunk: a trip of four needs no bounds
+
+struct Sweep2Stage {
+  float x[64 + kS2Pad], y[64 + kS2Pad], z[64 + kS2Pad], a[64 + kS2Pad];      // the staged chunk's (mu, a), SoA
+  union {
+    float lb[64];      // its len bounds (the exit test)
+    int cnt[64];       // epilogue: hits per ray
+  };
+  int pos[64 + kS2Pad];      // the staged entries' handles: Gaussian id, or position in the tile's stream (see h_is_id)
+};
+__host__ __device__ inline size_t sweep2_len_bytes(const int K) { return (sizeof(float) * (size_t)(K + 1) * kS2TP + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t sweep2_pos_bytes(const int K) { return (sizeof(uint16_t) * (size_t)(K + 1) * kS2TQ + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t sweep2_lds_bytes(const int K) { return sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage); }
+
+#ifndef VOGE_S2_EPI_B
+#define VOGE_S2_EPI_B 5      // epilogue: items (4 slots each) per thread and batch
+#endif
+#ifndef VOGE_S2_EPI_R
+#define VOGE_S2_EPI_R 3      // ... and how many of them have their (mu, a) gathers in flight together (act / dsd wanted)
+#endif
+#ifndef VOGE_S2_PRIO_LEN
+#define VOGE_S2_PRIO_LEN 0   // (experiment) tiles with at least this many candidates run at raised wave priority; 0: off
+#endif
+
+__global__ void __launch_bounds__(64)
+sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms, const float *__restrict__ rays,
+                 const int *__restrict__ bin_count, const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb,
+                 const int32_t *__restrict__ tl_id, const float *__restrict__ tl_lb, const int32_t *__restrict__ pool_id,
+                 const float *__restrict__ pool_lb, const int *__restrict__ tl_off, const int2 *__restrict__ order,
+                 const int tiles_per_img, const int nstx, const int nst, const int N, const int H, const int W, const int K,
+                 const float thr_act, int32_t *__restrict__ out_idx, float *__restrict__ out_len, float *__restrict__ out_act,
+                 float *__restrict__ out_dsd, int32_t *__restrict__ out_cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float *const Llen = reinterpret_cast<float *>(smem_raw);
+  unsigned char *const Lpos_raw = smem_raw + sweep2_len_bytes(K);
+  Sweep2Stage &S = *reinterpret_cast<Sweep2Stage *>(smem_raw + sweep2_len_bytes(K) + sweep2_pos_bytes(K));
+
+  const int lane = threadIdx.x;
+  const int tiles_x = (W + 7) >> 3;
+#ifdef VOGE_SWEEP_TIMES
+  const unsigned long long ts0 = wall_clock64();
+  unsigned long long ts_fill = 0, ts_cons = 0, ts1 = 0, ts2 = 0;
+  unsigned st_eval = 0;
+#endif
+  const int2 slot = order[blockIdx.x];               // (tile [| kPoolFlag], length of its list | -1 = overflowed)
+  if (slot.x < 0 || slot.y == 0) return;             // outside the image | nothing can hit it: binB wrote its outputs
+  const bool pooled = (slot.x & kPoolFlag) != 0;
+  const int lin = slot.x & ~kPoolFlag;
+  const int b = lin / tiles_per_img, bx = lin - b * tiles_per_img;
+  const int tx = bx % tiles_x, ty = bx / tiles_x;
+  // ---- the tile's candidate stream: its own list (binB) -> its quad's ordered list -> every Gaussian of the element
+  const int bin = (b * nst + ((ty * 8) / kST) * nstx + (tx * 8) / kST) * 4 + (((ty * 8) / kQuad) & 1) * 2 + (((tx * 8) / kQuad) & 1);
+  const int tc = slot.y;
+  const int bc = (tc >= 0) ? tc : ((bin_count != nullptr) ? bin_count[bin] : -1);
+  const bool binned = bc >= 0;
+  const int src_n = binned ? bc : N;
+  const size_t list_at = pooled ? (size_t)tl_off[lin] : (size_t)lin * kTileCap;
+  const int32_t *src_id = (tc >= 0) ? (pooled ? pool_id : tl_id) + list_at : (binned ? bin_id + (size_t)bin * kQCap : nullptr);
+  const float *src_lb = (tc >= 0) ? (pooled ? pool_lb : tl_lb) + list_at : (binned ? bin_lb + (size_t)bin * kQCap : nullptr);
+  const bool pref = tc >= 0;      // the tile's own list is already filtered with this tile's cone
+#if VOGE_S2_PRIO_LEN > 0
+  if (src_n >= VOGE_S2_PRIO_LEN) __builtin_amdgcn_s_setprio(3);
+#endif
+  const float4 *cullb = cull + (size_t)b * N;
+  const float4 *msb = ms + (size_t)b * N;
+  const float4 rec_none = make_float4(0.f, 0.f, 0.f, INFINITY);      // act = inf * 0 = NaN: never below the threshold
+  const float4 cull_none = make_float4(0.f, 0.f, 0.f, -1.f);
+  // What a list entry carries in its 16 (32) bits: the Gaussian's id itself where every id of the batch element fits 16
+  // bits -- no look-up anywhere --, else the entry's POSITION in the tile's stream, resolved through the stream's id list
+  // on an exact len tie and in the epilogue.
+  const bool h_is_id = (N <= 65536) || !binned;
+  auto id_of = [&](const unsigned h) -> int { return h_is_id ? (int)h : src_id[h]; };
+  const float not_full = __uint_as_float(__float_as_uint(VOGE_SENT_LEN) - 1u);      // len <= this  <=>  len < the sentinel
+  if (lane < kS2Pad) { S.x[64 + lane] = 0.f; S.y[64 + lane] = 0.f; S.z[64 + lane] = 0.f; S.a[64 + lane] = INFINITY; }
+
+  // ---- the wave's bounding cone over all 64 rays of the tile (only a cone-filtered stream needs it), unit-ray flag ----
+  Cone wcone;
+  bool unit_rays;
+  {
+    const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+    const size_t rid = ((size_t)b * H + min(py, H - 1)) * W + min(px, W - 1);
+    const RayDir u = ray_dir(rays[3 * rid + 0], rays[3 * rid + 1], rays[3 * rid + 2]);
+    unit_rays = __all(!u.ok || u.unit);
+    wcone.ok = false;
+    if (!pref) {      // (uniform)
+      const bool dirs_ok = __all(u.ok);
+      const float wsx = wave_sum_dpp(u.ok ? u.ux : 0.f), wsy = wave_sum_dpp(u.ok ? u.uy : 0.f), wsz = wave_sum_dpp(u.ok ? u.uz : 0.f);
+      const float n = sqrtf(fmaf(wsz, wsz, fmaf(wsy, wsy, wsx * wsx)));
+      const float ax = wsx / n, ay = wsy / n, az = wsz / n;
+      float smax = 0.f, cmin = 1.f;
+      cone_partial(u, ax, ay, az, smax, cmin);
+      wcone = cone_finish(ax, ay, az, n, wave_max(smax), wave_min(cmin), dirs_ok);
+    }
+  }
+
+  // One pass = the whole trace of the rays it covers: all 64 (16-bit positions) or rows [4 pass, 4 pass + 4) of the tile
+  // on lanes 0..31 (32-bit positions; lanes 32..63 evaluate along and never commit).
+  auto run = [&](auto wide_tag, const int pass) {
+    constexpr bool WIDE = decltype(wide_tag)::value;
+    const int r = WIDE ? pass * 32 + (lane & 31) : lane;      // the lane's ray inside the tile
+    const int col = WIDE ? (lane & 31) : lane;                 // ... and its column of the lists
+    const int px = tx * 8 + (r & 7), py = ty * 8 + (r >> 3);
+    const bool valid = (px < W) && (py < H) && (!WIDE || lane < 32);
+    const size_t ray_id = ((size_t)b * H + min(py, H - 1)) * W + min(px, W - 1);
+    const float dx = rays[3 * ray_id + 0], dy = rays[3 * ray_id + 1], dz = rays[3 * ray_id + 2];
+    const float rdn2 = __builtin_amdgcn_rcpf((dx * dx + dy * dy) + dz * dz);      // (pair_eval_iso: md * rcp(qxx + qyy + qzz))
+    // (24-bit multiplies of 32-bit offsets: a plain `row * stride` index becomes a quarter-rate 64-bit multiply-add)
+    float *const mylen = Llen + col;
+    uint16_t *const mypos16 = reinterpret_cast<uint16_t *>(Lpos_raw) + col;
+    uint32_t *const mypos32 = reinterpret_cast<uint32_t *>(Lpos_raw) + col;
+    auto put = [&](const int row, const float len, const unsigned p) {
+      mylen[__umul24((unsigned)row, (unsigned)kS2TP)] = len;
+      if (WIDE) mypos32[__umul24((unsigned)row, (unsigned)(kS2TQ / 2))] = p; else mypos16[__umul24((unsigned)row, (unsigned)kS2TQ)] = (uint16_t)p;
+    };
+    auto len_at = [&](const int row) -> float { return mylen[__umul24((unsigned)row, (unsigned)kS2TP)]; };
+    auto pos_at = [&](const int row) -> unsigned {
+      return WIDE ? mypos32[__umul24((unsigned)row, (unsigned)(kS2TQ / 2))] : (unsigned)mypos16[__umul24((unsigned)row, (unsigned)kS2TQ)];
+    };
+
+    int cnt = 0;
+    float worstf = valid ? not_full : __uint_as_float(0x7fc00000u);      // (NaN: a ray outside the image takes nothing)
+    float tailf = -INFINITY;
+    bool wdone = false;
+
+    // a candidate that passed `act < thr && len <= worst` but is not a plain append: exact (len, id) insertion
+    auto slow_insert = [&](const float len, const unsigned p) {
+      const bool full = (cnt == K);
+      int my_id = -1;
+      auto key_le = [&](const float pl, const int row) {      // list entry (pl, id(row)) <= (len, my id)
+        if (pl != len) return pl < len;
+        if (my_id < 0) my_id = id_of(p);
+        return id_of(pos_at(row)) <= my_id;
+      };
+      if (full && len == worstf && key_le(worstf, K - 1)) return;      // not below the K-th entry after all
+      int pos = full ? K - 1 : cnt;
+      float new_tail = len;      // (full lists) what ends up in row K - 1
+      bool first = true;
+      while (pos > 0) {
+        const float pl = len_at(pos - 1);
+        if (key_le(pl, pos - 1)) break;
+        if (first) new_tail = pl;
+        put(pos, pl, pos_at(pos - 1));
+        first = false;
+        --pos;
+      }
+      put(pos, len, p);
+      if (full) {
+        tailf = new_tail;
+        worstf = new_tail;
+      } else {
+        if (pos == cnt) tailf = len;      // (a tie with the tail and the larger id: still the last entry)
+        if (++cnt == K) worstf = tailf;
+      }
+    };
+    auto commit = [&](const float len, const float act, const unsigned p) {
+      const bool take = (act < thr_act) & (len <= worstf);
+      const bool app = take & (len > tailf);      // (a full list has tail == worst: it never appends)
+      put(app ? cnt : K, len, p);                  // (the others store into the spare row K, which is never read)
+      cnt += app ? 1 : 0;
+      tailf = app ? len : tailf;
+      worstf = (app & (cnt == K)) ? len : worstf;      // the append that fills the list: its len is the admission bound now
+      // Everything that is not an append (4 % of the candidates of a tile, any lane) sits OUT of line behind a uniform,
+      // predicted-not-taken branch: a divergent `if` is a taken skip-branch for every candidate nobody needs it for.
+      const bool slow = take & !app;
+      if (__builtin_expect(__ballot(slow) != 0ull, 0)) {
+        if (slow) slow_insert(len, p);
+      }
+    };
+
+    auto load_id = [&](const int g) { return (g < src_n) ? (binned ? src_id[g] : g) : -1; };
+    auto load_lb = [&](const int g) { return (binned && g < src_n) ? src_lb[g] : -INFINITY; };
+    auto load_ms = [&](const int id) { return (id >= 0) ? msb[id] : rec_none; };
+    auto load_cull = [&](const int id) { return (id >= 0) ? cullb[id] : cull_none; };
+
+#ifdef VOGE_SWEEP_TIMES
+    ts1 = wall_clock64();
+#endif
+    // two-deep software pipeline: ids two chunks ahead, records one chunk ahead
+    int id0 = load_id(lane);
+    float lb0 = load_lb(lane);
+    float4 m0 = load_ms(id0);
+    float4 c0 = pref ? cull_none : load_cull(id0);
+    int id1 = load_id(64 + lane);
+    float lb1 = load_lb(64 + lane);
+    for (int base = 0; base < src_n && !wdone; base += 64) {
+      const int id = id0;
+      const float lbv = lb0;
+      const float4 mrec = m0, crec = c0;
+      id0 = id1; lb0 = lb1;
+      m0 = load_ms(id0);
+      c0 = pref ? cull_none : load_cull(id0);
+      id1 = load_id(base + 128 + lane);
+      lb1 = load_lb(base + 128 + lane);
+      // ---- stage ----
+#ifdef VOGE_SWEEP_TIMES
+      const unsigned long long tsa = wall_clock64();
+#endif
+      int nbuf;
+      __syncthreads();      // (the previous chunk's readers are done)
+      if (pref) {
+        S.x[lane] = mrec.x; S.y[lane] = mrec.y; S.z[lane] = mrec.z; S.a[lane] = mrec.w;      // (behind the list: never-hit records)
+        S.lb[lane] = lbv;
+        S.pos[lane] = h_is_id ? id : base + lane;
+        nbuf = min(64, src_n - base);
+      } else {
+        const bool keep = cone_keep(crec, wcone);      // (padding: reach -1, never kept)
+        const unsigned long long m = __ballot(keep);
+        nbuf = __popcll(m);
+        if (keep) {
+          const int sl = __popcll(m & ((1ull << lane) - 1ull));
+          S.x[sl] = mrec.x; S.y[sl] = mrec.y; S.z[sl] = mrec.z; S.a[sl] = mrec.w;
+          S.lb[sl] = lbv;
+          S.pos[sl] = h_is_id ? id : base + lane;
+        }
+        if (lane < kS2Pad) { S.x[nbuf + lane] = 0.f; S.y[nbuf + lane] = 0.f; S.z[nbuf + lane] = 0.f; S.a[nbuf + lane] = INFINITY; }
+      }
+      __syncthreads();
+      // ---- exit test, once per chunk: the bounds are monotone along the stream, so the first staged entry whose bound
+      // lies above every ray's K-th len ends the tile (unit rays only: the bound is a depth along a unit direction) ----
+#ifdef VOGE_SWEEP_TIMES
+      const unsigned long long tsb = wall_clock64();
+      ts_fill += tsb - tsa;
+#endif
+      int n = nbuf;
+      if (binned && unit_rays && __all(!valid || cnt == K)) {
+        const float wmax = wave_max(valid ? worstf : -INFINITY);
+        const unsigned long long ex = __ballot(lane < nbuf && S.lb[lane] > wmax);
+        if (ex) { n = __builtin_ctzll(ex); wdone = true; }
+      }
+      // ---- consume: four candidates per trip, evaluated as one straight-line block, committed in order.  Entries behind
+      // n inside the last trip are either real candidates the exit test just proved too deep (len > worst: rejected by
+      // the same compare) or never-hit padding. ----
+      for (int s0 = 0; s0 < n; s0 += 4) {
+        const float4 X = *reinterpret_cast<const float4 *>(&S.x[s0]), Y = *reinterpret_cast<const float4 *>(&S.y[s0]),
+                     Z = *reinterpret_cast<const float4 *>(&S.z[s0]), A = *reinterpret_cast<const float4 *>(&S.a[s0]);
+        const int4 P = *reinterpret_cast<const int4 *>(&S.pos[s0]);      // the entries' handles (id or stream position)
+        const float mx[4] = {X.x, X.y, X.z, X.w}, my[4] = {Y.x, Y.y, Y.z, Y.w}, mz[4] = {Z.x, Z.y, Z.z, Z.w}, av[4] = {A.x, A.y, A.z, A.w};
+        const int pv[4] = {P.x, P.y, P.z, P.w};
+        float len[4], act[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {      // pair_eval_iso's operations, bit for bit
+          const float md = fmaf(mz[q], dz, fmaf(my[q], dy, mx[q] * dx));
+          const float t = md * rdn2 + 0.0f;
+          const float vx = fmaf(-t, dx, mx[q]), vy = fmaf(-t, dy, my[q]), vz = fmaf(-t, dz, mz[q]);
+          len[q] = t;
+          act[q] = av[q] * fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(len[q]), "+v"(act[q]));      // four interleaved chains, then the commits
+#pragma unroll
+        for (int q = 0; q < 4; ++q) commit(len[q], act[q], (unsigned)pv[q]);
+      }
+#ifdef VOGE_SWEEP_TIMES
+      ts_cons += wall_clock64() - tsb;
+      st_eval += n;
+#endif
+    }
+#ifdef VOGE_SWEEP_TIMES
+    ts2 = wall_clock64();
+#endif
+
+    // ---- epilogue: lanes re-mapped to (pixel, 4 slots); ids looked up from the stream, act / dsd re-derived ----
+    __syncthreads();
+    S.cnt[lane] = valid ? cnt : 0;
+    if (out_cnt != nullptr && valid) out_cnt[((size_t)b * H + py) * W + px] = cnt;
+    __syncthreads();
+    const int row0 = WIDE ? pass * 4 : 0;
+    const int th = max(0, min(WIDE ? 4 : 8, H - ty * 8 - row0)), tw = min(8, W - tx * 8);
+    const int row_items = tw * K;
+    const uint16_t *const P16 = reinterpret_cast<const uint16_t *>(Lpos_raw);
+    const uint32_t *const P32 = reinterpret_cast<const uint32_t *>(Lpos_raw);
+    auto entry_pos = [&](const int s, const int owner) -> unsigned {
+      return WIDE ? P32[s * (kS2TQ / 2) + owner] : (unsigned)P16[s * kS2TQ + owner];
+    };
+    const bool want_ad = out_act != nullptr;
+    const int gofs = b * N;
+    if ((K & 3) == 0) {
+      // An item = four consecutive slots of one pixel (16-byte stores).  A thread takes kEpiB items per batch -- at K = 40
+      // all ten of its items: every len / position comes out of LDS first, then ALL id look-ups of the batch are in flight
+      // together (one memory round trip; the 2.5 dependent rounds of a 16-slot batch cost 5.6 us per tile), then the
+      // stores; with act / dsd the (mu, a) gathers follow in sub-batches of kEpiR items.
+      constexpr int kEpiB = VOGE_S2_EPI_B, kEpiR = VOGE_S2_EPI_R;
+      const int ipr = row_items >> 2, nitem = th * ipr;
+      const float inv_ipr = 1.0f / (float)max(ipr, 1), invK = 1.0f / (float)K;
+      const size_t tile_pix = ((size_t)b * H + ty * 8 + row0) * W + (size_t)tx * 8;      // the pass's first pixel
+      int32_t *const t_idx = out_idx + tile_pix * K;
+      float *const t_len = out_len + tile_pix * K;
+      for (int it0 = lane; it0 < nitem; it0 += 64 * kEpiB) {
+        int32_t oi[kEpiB][4];
+        float ol[kEpiB][4];
+        unsigned rel[kEpiB];      // element offset of the item's first slot from the pass's first pixel (8 W K < 2^31)
+        int nv[kEpiB];
+#pragma unroll
+        for (int u = 0; u < kEpiB; ++u) {
+          const int it = it0 + u * 64;
+          nv[u] = -1; rel[u] = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { oi[u][q] = -1; ol[u][q] = VOGE_SENT_LEN; }
+          if (it < nitem) {
+            const int rr = __float2int_rz(((float)it + 0.5f) * inv_ipr);
+            const int j = (it - rr * ipr) * 4;
+            const int x = __float2int_rz(((float)j + 0.5f) * invK);
+            const int sl = j - x * K;
+            const int owner = rr * 8 + x;
+            rel[u] = (unsigned)(rr * W + x) * (unsigned)K + (unsigned)sl;
+            nv[u] = max(0, min(4, S.cnt[owner] - sl));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (q < nv[u]) {
+                ol[u][q] = Llen[(sl + q) * kS2TP + owner];
+                oi[u][q] = (int)entry_pos(sl + q, owner);      // (the position; the id follows)
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kEpiB; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < nv[u]) oi[u][q] = id_of((unsigned)oi[u][q]) + gofs;
+        if (!want_ad) {
+#pragma unroll
+          for (int u = 0; u < kEpiB; ++u) {
+            if (nv[u] < 0) continue;
+            *reinterpret_cast<int4 *>(t_idx + rel[u]) = make_int4(oi[u][0], oi[u][1], oi[u][2], oi[u][3]);
+            *reinterpret_cast<float4 *>(t_len + rel[u]) = make_float4(ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
+          }
+        } else {
+          float *const t_act = out_act + tile_pix * K, *const t_dsd = out_dsd + tile_pix * K;
+#pragma unroll
+          for (int u0 = 0; u0 < kEpiB; u0 += kEpiR) {
+            float4 rec[kEpiR][4];
+            float ex[kEpiR], ey[kEpiR], ez[kEpiR];
+#pragma unroll
+            for (int v = 0; v < kEpiR; ++v) {
+              const int u = u0 + v;
+              ex[v] = ey[v] = ez[v] = 0.f;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) rec[v][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (u < kEpiB && nv[u] > 0) {
+                const unsigned pr = rel[u] / (unsigned)K;      // pixel offset (rr W + x)
+                const float *ry = rays + (tile_pix + pr) * 3;
+                ex[v] = ry[0]; ey[v] = ry[1]; ez[v] = ry[2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  if (q < nv[u]) rec[v][q] = ms[oi[u][q]];
+              }
+            }
+#pragma unroll
+            for (int v = 0; v < kEpiR; ++v) {
+              const int u = u0 + v;
+              if (u >= kEpiB || nv[u] < 0) continue;
+              float oa[4], od[4];
+              const float dn2 = (ex[v] * ex[v] + ey[v] * ey[v]) + ez[v] * ez[v];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                oa[q] = VOGE_SENT_ACT; od[q] = 0.0f;
+                if (q < nv[u]) {
+                  const PairOut o = pair_eval_iso_at(rec[v][q].x, rec[v][q].y, rec[v][q].z, rec[v][q].w, ol[u][q], ex[v], ey[v], ez[v], dn2);
+                  oa[q] = o.act; od[q] = o.dsd;
+                }
+              }
+              *reinterpret_cast<int4 *>(t_idx + rel[u]) = make_int4(oi[u][0], oi[u][1], oi[u][2], oi[u][3]);
+              *reinterpret_cast<float4 *>(t_len + rel[u]) = make_float4(ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
+              *reinterpret_cast<float4 *>(t_act + rel[u]) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+              *reinterpret_cast<float4 *>(t_dsd + rel[u]) = make_float4(od[0], od[1], od[2], od[3]);
+            }
+          }
+        }
+      }
+    } else {
+      // K not a multiple of four: one slot per lane and trip over the pass's rows (rows x pixels x slots flattened), four
+      // trips in flight
+      const float inv_ri = 1.0f / (float)max(row_items, 1);
+      const int nit = th * row_items;
+      for (int it0 = lane; it0 < nit; it0 += 4 * 64) {
+        int32_t oi[4];
+        float ol[4];
+        size_t oo[4], pixs[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int it = it0 + u * 64;
+          oo[u] = 0; pixs[u] = 0; oi[u] = -1; ol[u] = VOGE_SENT_LEN; in[u] = false;
+          if (it < nit) {
+            const int rr = __float2int_rz(((float)it + 0.5f) * inv_ri);
+            const int j = it - rr * row_items;
+            const int x = j / K, sl = j - x * K;
+            const int owner = rr * 8 + x;
+            pixs[u] = ((size_t)b * H + ty * 8 + row0 + rr) * W + (size_t)tx * 8 + x;
+            oo[u] = pixs[u] * K + sl;
+            in[u] = sl < S.cnt[owner];
+            if (in[u]) { ol[u] = Llen[sl * kS2TP + owner]; oi[u] = (int)entry_pos(sl, owner); }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (in[u]) oi[u] = id_of((unsigned)oi[u]) + gofs;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (it0 + u * 64 >= nit) continue;
+          out_idx[oo[u]] = oi[u];
+          out_len[oo[u]] = ol[u];
+          if (want_ad) {
+            float oa = VOGE_SENT_ACT, od = 0.0f;
+            if (in[u]) {
+              const float *ry = rays + pixs[u] * 3;
+              const float ex = ry[0], ey = ry[1], ez = ry[2];
+              const float4 cc = ms[oi[u]];
+              const PairOut o = pair_eval_iso_at(cc.x, cc.y, cc.z, cc.w, ol[u], ex, ey, ez, (ex * ex + ey * ey) + ez * ez);
+              oa = o.act; od = o.dsd;
+            }
+            out_act[oo[u]] = oa;
+            out_dsd[oo[u]] = od;
+          }
+        }
+      }
+    }
+  };
+
+  if ((h_is_id ? N : src_n) <= 65536) {      // (every handle fits 16 bits)
+    run(std::false_type{}, 0);
+  } else {
+    run(std::true_type{}, 0);
+    run(std::true_type{}, 1);
+  }
+#ifdef VOGE_SWEEP_TIMES
+  if (lane == 0 && b == 0 && bx < 8192) {
+    unsigned long long *o = g_sweep_times + 8 * (size_t)bx;
+    o[0] = ts0; o[1] = ts1; o[2] = ts_fill; o[3] = ts_cons; o[4] = ts2; o[5] = wall_clock64(); o[6] = st_eval;
+    o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+  }
+#endif
+}
+
+}  // namespace voge

@@ -168,6 +168,10 @@ __device__ unsigned long long g_sweep_times[8192 * 8];   // per WG: start, after
 #endif
 constexpr int kTrip = VOGE_TRIP;   // candidates evaluated per trip of the sweep's inner loop
 
+}  // namespace voge
+#include "sweep_iso.h"      // round 4's scalar-sigma sweep (sweep_iso_kernel)
+namespace voge {
+
 template <int T, bool ISO>
 struct TraceLds {
   // layout inside dynamic LDS, after the [K][T+1] key array.  ISO (the scalar-sigma entry point: every
@@ -1127,6 +1131,9 @@ __global__ void __launch_bounds__(1024) order_sort_kernel(const int2 *__restrict
 #ifndef VOGE_SWEEP_LDS_PAD
 #define VOGE_SWEEP_LDS_PAD 0      // (occupancy experiments: extra dynamic LDS per workgroup)
 #endif
+// 0: default kernels; 1: round 3's scalar-sigma sweep (trace_fwd_kernel<1, true>) instead of sweep_iso_kernel -- for A/B
+// timing and the bit-for-bit comparison in tests/ (voge_debug_sweep_variant)
+static std::atomic<int> g_sweep_variant{0};
 // binB + the sweep (one wave = one 8x8-pixel tile per workgroup)
 template <bool ISO>
 static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *rays, int B, int N, int H, int W, int K,
@@ -1138,9 +1145,13 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
   const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + ((sizeof(TraceLds<T, ISO>) + 15) & ~(size_t)15) +
                      comp + VOGE_SWEEP_LDS_PAD;
   auto kern = trace_fwd_kernel<1, ISO>;
+  // scalar sigmas, no composite inside the epilogue: round 4's kernel (sweep_iso.h: float-compare commits, 6-byte list entries)
+  const bool v2 = ISO && VOGE_SWEEP_V2 && weight == nullptr && g_sweep_variant.load(std::memory_order_relaxed) != 1;
+  const size_t lds2 = sweep2_lds_bytes(K) + VOGE_SWEEP_LDS_PAD;
   {
-    static DynLdsCache cache;
-    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, cache);
+    static DynLdsCache cache, cache2;
+    const int rc = v2 ? ensure_dynamic_lds(reinterpret_cast<const void *>(sweep_iso_kernel), lds2, cache2)
+                      : ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, cache);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(binB_kernel<!ISO>, dim3(ws.nstx * ws.nsty * 4, B), dim3(kQT), 0, st, ws.cull, ws.ell, ws.seg_count, ws.seg_id, ws.seg_rec,
@@ -1157,6 +1168,12 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
   order = ws.order + (size_t)ws.nbin * kTilesPerBin;
 #endif
   dim3 grid(ws.nbin * kTilesPerBin);     // one workgroup per tile slot of every super-tile (slots outside the image exit)
+  if (v2) {
+    hipLaunchKernelGGL(sweep_iso_kernel, grid, dim3(T), lds2, st, ws.cull, ws.ms, rays, ws.q_count, ws.q_id, ws.q_lb, ws.tl_id, ws.tl_lb,
+                       ws.pool_id, ws.pool_lb, ws.tl_off, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx, ws.nstx * ws.nsty, N, H, W, K,
+                       thr_act, idx, len, act, dsd, cnt);
+    return launch_status();
+  }
   hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, ws.ms, rays, ws.q_count, ws.q_id, ws.q_lb,
                      ws.tl_count, ws.tl_id, ws.tl_lb, ws.pool_id, ws.pool_lb, ws.tl_off, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx,
                      ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, weight, valid_num);
@@ -1191,6 +1208,12 @@ extern "C" int voge_debug_bin_times(unsigned long long *out, int which, int n_wg
                                   sizeof(unsigned long long) * 8 * 1024 * (size_t)which);
 }
 #endif
+
+extern "C" int voge_debug_sweep_variant(int variant) {
+  if (variant < 0 || variant > 1) return VOGE_ERR_BAD_ARG;
+  voge::g_sweep_variant.store(variant, std::memory_order_relaxed);
+  return 0;
+}
 
 extern "C" size_t voge_trace_workspace_bytes(int B, int N, int H, int W) {
   if (B <= 0 || N < 0 || H <= 0 || W <= 0) return 0;
