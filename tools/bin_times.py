@@ -38,5 +38,7 @@ for which, n, names in ((0, min(nreg, 1024), ["first loads + region cone", "regi
     tot = t[:, k - 1] - t[:, 0]
     print(f"  {'total':42s} {tot.mean():6.2f} {tot.max():6.2f}   start spread {t[:, 0].max() - t[:, 0].min():.2f}; first stamp after kernel start")
     if which == 1:
+        print(f"  entry -> cones done {(t[:, 6] - t[:, 7]).mean():6.2f} {(t[:, 6] - t[:, 7]).max():6.2f};  cones -> rank done {(t[:, 0] - t[:, 6]).mean():6.2f} {(t[:, 0] - t[:, 6]).max():6.2f}"
+              f";  first entry -> last end {t[:, k - 1].max() - t[:, 7].min():.1f};  entry spread {t[:, 7].max() - t[:, 7].min():.2f}")
         o = np.argsort(-tot)[:5]
         print("  slowest workgroups:", [(int(i), [round(float(x), 1) for x in d[i]]) for i in o])

@@ -44,6 +44,16 @@ __host__ __device__ inline size_t sweep2_lds_bytes(const int K) { return sweep2_
 #ifndef VOGE_S2_EPI_R
 #define VOGE_S2_EPI_R 3      // ... and how many of them have their (mu, a) gathers in flight together (act / dsd wanted)
 #endif
+#ifndef VOGE_S2_READLANE
+#define VOGE_S2_READLANE 0      // the tile's own list: records out of the lanes' registers (v_readlane) instead of LDS staging
+#endif
+#ifndef VOGE_S2_PACKED
+#define VOGE_S2_PACKED 1        // two candidates per packed-fp32 instruction in the evaluation
+#endif
+#ifndef VOGE_S2_EXIT_GROUP
+#define VOGE_S2_EXIT_GROUP 16   // candidates between two exit tests (a power of two, >= 4)
+#endif
+constexpr int kExitGroup = VOGE_S2_EXIT_GROUP;
 #ifndef VOGE_S2_PRIO_LEN
 #define VOGE_S2_PRIO_LEN 0   // (experiment) tiles with at least this many candidates run at raised wave priority; 0: off
 #endif
@@ -178,10 +188,12 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
         if (++cnt == K) worstf = tailf;
       }
     };
+    int Kv = K;
+    asm volatile("" : "+v"(Kv));      // (K in a VGPR for good: the compiler re-materialised it from its SGPR in front of every select)
     auto commit = [&](const float len, const float act, const unsigned p) {
       const bool take = (act < thr_act) & (len <= worstf);
       const bool app = take & (len > tailf);      // (a full list has tail == worst: it never appends)
-      put(app ? cnt : K, len, p);                  // (the others store into the spare row K, which is never read)
+      put(app ? cnt : Kv, len, p);                 // (the others store into the spare row K, which is never read)
       cnt += app ? 1 : 0;
       tailf = app ? len : tailf;
       worstf = (app & (cnt == K)) ? len : worstf;      // the append that fills the list: its len is the admission bound now
@@ -217,10 +229,62 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       c0 = pref ? cull_none : load_cull(id0);
       id1 = load_id(base + 128 + lane);
       lb1 = load_lb(base + 128 + lane);
-      // ---- stage ----
 #ifdef VOGE_SWEEP_TIMES
       const unsigned long long tsa = wall_clock64();
 #endif
+#if VOGE_S2_READLANE
+      if (pref) {
+        // ---- the tile's own list: nothing is staged.  Lane i holds entry base + i's record in registers; the wave reads
+        // candidate s out of lane s with v_readlane (the values land in SGPRs and feed the evaluation as scalar operands).
+        // The old form broadcast every record to all 64 lanes through LDS: a ds_read_b128 per candidate, 1 KB through the
+        // LDS crossbar each -- with nine waves per CU the LDS pipe was as busy as the VALUs (tools/valu_bench.hip prices a
+        // broadcast ds_read_b64 at ~6 LDS clocks). ----
+        const int nb = min(64, src_n - base);
+        const int hnd = h_is_id ? id : base + lane;
+        int n = nb;
+#ifdef VOGE_SWEEP_TIMES
+        const unsigned long long tsb = wall_clock64();
+        ts_fill += tsb - tsa;
+#endif
+        for (int s0 = 0; s0 < n; s0 += 4) {
+          if ((s0 & (kExitGroup - 1)) == 0 && binned && unit_rays && __all(!valid || cnt == K)) {
+            const float wmax = wave_max(valid ? worstf : -INFINITY);
+            const unsigned long long ex = __ballot(lane < nb && lbv > wmax);
+            if (ex) {
+              n = __builtin_ctzll(ex);
+              wdone = true;
+              if (n <= s0) break;
+            }
+          }
+          float len[4], act[4];
+          int pv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {      // (lanes behind the list hold the never-hit record)
+            const int l = s0 + q;
+            const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mrec.x), l));
+            const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mrec.y), l));
+            const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mrec.z), l));
+            const float sa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mrec.w), l));
+            pv[q] = __builtin_amdgcn_readlane(hnd, l);
+            const float md = fmaf(sz, dz, fmaf(sy, dy, sx * dx));      // pair_eval_iso's operations, bit for bit
+            const float t = md * rdn2;
+            const float vx = fmaf(-t, dx, sx), vy = fmaf(-t, dy, sy), vz = fmaf(-t, dz, sz);
+            len[q] = t;
+            act[q] = sa * fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(len[q]), "+v"(act[q]));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) commit(len[q], act[q], (unsigned)pv[q]);
+        }
+#ifdef VOGE_SWEEP_TIMES
+        ts_cons += wall_clock64() - tsb;
+        st_eval += min(n, nb);
+#endif
+        continue;
+      }
+#endif
+      // ---- stage ----
       int nbuf;
       __syncthreads();      // (the previous chunk's readers are done)
       if (pref) {
@@ -241,36 +305,61 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
         if (lane < kS2Pad) { S.x[nbuf + lane] = 0.f; S.y[nbuf + lane] = 0.f; S.z[nbuf + lane] = 0.f; S.a[nbuf + lane] = INFINITY; }
       }
       __syncthreads();
-      // ---- exit test, once per chunk: the bounds are monotone along the stream, so the first staged entry whose bound
-      // lies above every ray's K-th len ends the tile (unit rays only: the bound is a depth along a unit direction) ----
 #ifdef VOGE_SWEEP_TIMES
       const unsigned long long tsb = wall_clock64();
       ts_fill += tsb - tsa;
 #endif
-      int n = nbuf;
-      if (binned && unit_rays && __all(!valid || cnt == K)) {
-        const float wmax = wave_max(valid ? worstf : -INFINITY);
-        const unsigned long long ex = __ballot(lane < nbuf && S.lb[lane] > wmax);
-        if (ex) { n = __builtin_ctzll(ex); wdone = true; }
-      }
-      // ---- consume: four candidates per trip, evaluated as one straight-line block, committed in order.  Entries behind
-      // n inside the last trip are either real candidates the exit test just proved too deep (len > worst: rejected by
+      // ---- consume: four candidates per trip, evaluated as one straight-line block, committed in order.  The exit test
+      // runs in front of every group of kExitGroup candidates: the bounds are monotone along the stream, so the first
+      // staged entry whose bound lies above every ray's K-th len ends the tile (unit rays only: the bound is a depth along
+      // a unit direction).  (Round 3's kernel tested once per 64-candidate chunk: a tile whose last ray filled early in a
+      // chunk evaluated the rest of it for nothing -- tools/sweep_hwmap.py showed counts of exactly 128 / 192.)  Entries
+      // behind n inside the last trip are either real candidates the test just proved too deep (len > worst: rejected by
       // the same compare) or never-hit padding. ----
+      const float lbl = S.lb[lane];      // (the bound of staged entry `lane`)
+      int n = nbuf;
       for (int s0 = 0; s0 < n; s0 += 4) {
+        if ((s0 & (kExitGroup - 1)) == 0 && binned && unit_rays && __all(!valid || cnt == K)) {
+          const float wmax = wave_max(valid ? worstf : -INFINITY);
+          const unsigned long long ex = __ballot(lane < nbuf && lbl > wmax);
+          if (ex) {
+            n = __builtin_ctzll(ex);
+            wdone = true;
+            if (n <= s0) break;
+          }
+        }
         const float4 X = *reinterpret_cast<const float4 *>(&S.x[s0]), Y = *reinterpret_cast<const float4 *>(&S.y[s0]),
                      Z = *reinterpret_cast<const float4 *>(&S.z[s0]), A = *reinterpret_cast<const float4 *>(&S.a[s0]);
         const int4 P = *reinterpret_cast<const int4 *>(&S.pos[s0]);      // the entries' handles (id or stream position)
-        const float mx[4] = {X.x, X.y, X.z, X.w}, my[4] = {Y.x, Y.y, Y.z, Y.w}, mz[4] = {Z.x, Z.y, Z.z, Z.w}, av[4] = {A.x, A.y, A.z, A.w};
         const int pv[4] = {P.x, P.y, P.z, P.w};
         float len[4], act[4];
+#if VOGE_S2_PACKED
+        // pair_eval_iso's operations, bit for bit, two candidates per instruction (v_pk_mul / v_pk_fma_f32: the halves of a
+        // ds_read_b128 are aligned register pairs already).  A packed FMA costs 1.7x a plain one on a SIMD that is shared
+        // by several waves and the same as one when the wave runs alone (tools/valu_bench.hip) -- the heavy tiles at the
+        // end of the launch, which decide its duration.
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const v2f x2 = h ? (v2f){X.z, X.w} : (v2f){X.x, X.y}, y2 = h ? (v2f){Y.z, Y.w} : (v2f){Y.x, Y.y},
+                    z2 = h ? (v2f){Z.z, Z.w} : (v2f){Z.x, Z.y}, a2 = h ? (v2f){A.z, A.w} : (v2f){A.x, A.y};
+          const v2f md = pk_fma(z2, splat(dz), pk_fma(y2, splat(dy), x2 * splat(dx)));
+          const v2f t = md * splat(rdn2);      // (no +0: a len of -0 orders, ties and re-evaluates exactly like +0 under float compares)
+          const v2f vx = pk_fma(-t, splat(dx), x2), vy = pk_fma(-t, splat(dy), y2), vz = pk_fma(-t, splat(dz), z2);
+          const v2f a = a2 * pk_fma(vz, vz, pk_fma(vy, vy, vx * vx));
+          len[2 * h] = t.x; len[2 * h + 1] = t.y;
+          act[2 * h] = a.x; act[2 * h + 1] = a.y;
+        }
+#else
+        const float mx[4] = {X.x, X.y, X.z, X.w}, my[4] = {Y.x, Y.y, Y.z, Y.w}, mz[4] = {Z.x, Z.y, Z.z, Z.w}, av[4] = {A.x, A.y, A.z, A.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {      // pair_eval_iso's operations, bit for bit
           const float md = fmaf(mz[q], dz, fmaf(my[q], dy, mx[q] * dx));
-          const float t = md * rdn2 + 0.0f;
+          const float t = md * rdn2;      // (no +0: a len of -0 orders, ties and re-evaluates exactly like +0 under float compares)
           const float vx = fmaf(-t, dx, mx[q]), vy = fmaf(-t, dy, my[q]), vz = fmaf(-t, dz, mz[q]);
           len[q] = t;
           act[q] = av[q] * fmaf(vz, vz, fmaf(vy, vy, vx * vx));
         }
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(len[q]), "+v"(act[q]));      // four interleaved chains, then the commits
 #pragma unroll
@@ -278,7 +367,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       }
 #ifdef VOGE_SWEEP_TIMES
       ts_cons += wall_clock64() - tsb;
-      st_eval += n;
+      st_eval += min(n, nbuf);
 #endif
     }
 #ifdef VOGE_SWEEP_TIMES
@@ -453,7 +542,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 #ifdef VOGE_SWEEP_TIMES
   if (lane == 0 && b == 0 && bx < 8192) {
     unsigned long long *o = g_sweep_times + 8 * (size_t)bx;
-    o[0] = ts0; o[1] = ts1; o[2] = ts_fill; o[3] = ts_cons; o[4] = ts2; o[5] = wall_clock64(); o[6] = st_eval;
+    o[0] = ts0; o[1] = ts1; o[2] = ts_fill; o[3] = ts_cons; o[4] = ts2; o[5] = wall_clock64(); o[6] = ((unsigned long long)blockIdx.x << 32) | st_eval;
     o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
   }
 #endif

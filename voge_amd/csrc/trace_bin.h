@@ -442,6 +442,10 @@ __device__ __forceinline__ void bin_test_batch(const BinStream &S, const int (&g
 template <bool ELL, class Sink>
 __device__ __forceinline__ void bin_stream_sources(const BinStream &S, const int *segn /* LDS: exclusive prefix of the segment counts;
                                                    behind it (BinLds): extn[kParts + 1] */, const int tid, Sink &&sink) {
+  // (A thread's stream indices only ever grow, so the segment an index falls into is carried along: one LDS read and a
+  // compare per entry.  Round 3 searched all 15 boundaries for every entry -- 15 LDS reads and 30 VALU instructions of the
+  // ~80 a streamed entry cost: the source pass of a central quad, 7.3 us of its 16, was bound by exactly that.)
+  int seg_p = 0, seg_lo = 0, seg_hi = segn[1];
   for (int base = 0; base < S.n_src; base += kQT * kGU) {      // the segments binA filled
     int gid[kGU];
     float4 c[kGU];
@@ -451,10 +455,8 @@ __device__ __forceinline__ void bin_stream_sources(const BinStream &S, const int
       gid[j] = -1;
       c[j] = make_float4(0.f, 0.f, 0.f, -1.f);
       if (i < S.n_src) {
-        int p = 0;
-#pragma unroll
-        for (int q = 1; q < kParts; ++q) p += (i >= segn[q]) ? 1 : 0;
-        const int o = p * kSegCap + (i - segn[p]);
+        while (i >= seg_hi) { seg_lo = seg_hi; ++seg_p; seg_hi = segn[seg_p + 1]; }      // (i < n_src = segn[kParts]: ends)
+        const int o = seg_p * kSegCap + (i - seg_lo);
         gid[j] = S.segs[o];
         c[j] = S.segr[o];
       }
@@ -765,6 +767,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
             int64_t *__restrict__ out_valid) {
   __shared__ BinLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  BIN_TS(1, 7);      // (kernel entry)
   const int b = blockIdx.y;
   const int binl = blockIdx.x >> 2, qq = blockIdx.x & 3;            // super-tile of this batch element, quad inside it
   const int stx = binl % nstx, sty = binl / nstx;
@@ -845,6 +848,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   // four segments of every super-tile (a quarter of the Gaussians, dealt round-robin: proportional to the total).
   // Every workgroup derives the rank from the same numbers, so the ranks are a permutation: no exchange.  The sweep's
   // workgroup number lin then finds its tile (and the length of its list) in order[lin]: one load. ----
+  BIN_TS(1, 6);      // (cones done)
   int rank = bin;
   {
     auto estimate = [&](const int q) {
