@@ -17,7 +17,7 @@ import torch
 
 import oracle
 from oracle import camera_np
-from util import TOL, bunny_scene, compare_trace, random_scene, _report_flips
+from util import TOL, bunny_scene, compare_trace, log_line, random_scene, _report_flips
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -412,3 +412,75 @@ def test_long_quads_and_segment_extensions_in_a_batch_of_views(hip_lib):
     used, cap = ops.trace_pool_usage("cuda:0", 2, N, H, W)
     assert 0 < used <= cap, (used, cap)
     compare_trace(got, ref, thr_act, min_match=0.998, label="long quads, two views")
+
+
+# ------------------------------------------------------------------ round 4: the rebuilt scalar-sigma sweep (sweep_iso.h)
+def _sweep_variant(v):
+    from voge_amd import _lib
+    assert _lib.load().voge_debug_sweep_variant(v) == 0
+
+
+@pytest.mark.parametrize("N,H,W,K,B,r_lo,r_hi,extent", [
+    (3000, 72, 88, 40, 1, 0.03, 0.08, 1.0),      # K = 40, ragged image
+    (1500, 40, 56, 25, 2, 0.05, 0.12, 1.0),      # odd K (the slot-by-slot epilogue), two views
+    (70000, 96, 96, 12, 1, 0.01, 0.03, 1.0),     # more than 65536 Gaussians: list entries carry stream positions
+    (20000, 64, 64, 7, 1, 0.004, 0.009, 0.2),    # a small dense object: pooled lists, segment extensions
+])
+def test_rebuilt_sweep_equals_round_3_sweep_bit_for_bit(hip_lib, N, H, W, K, B, r_lo, r_hi, extent):
+    """sweep_iso_kernel (fp32 len + 16-bit handle per list entry, float-compare commits) against trace_fwd_kernel<1, true>
+    (64-bit (ord(len), id) keys): the same "K lexicographically smallest (len, id)" (ray_trace_voge.cu:197-212), hence the
+    same index lists, hit counts and -- the evaluation being the same operations -- the same len / act / dsd bits, with and
+    without act / dsd (voge_debug_sweep_variant switches the kernel)."""
+    from voge_amd import ops
+    rng = np.random.default_rng(N + K)
+    verts = rng.uniform(-extent, extent, (N, 3)).astype(np.float32)
+    r = rng.uniform(r_lo, r_hi, N)
+    sig = (1.0 / (r * r / (2 * np.log(1 / 0.6)))).astype(np.float32)
+    R, T = camera_np.look_at_view_transform([3.0, 3.3][:B], [10.0, -25.0][:B], [20.0, 160.0][:B])
+    rays, origin = camera_np.pixel_rays(R, T, 1.1 * W, (W / 2.0, H / 2.0), (H, W))
+    mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    a = np.ascontiguousarray(np.broadcast_to((2 * sig)[None], (B, N))).astype(np.float32)
+    thr_act = oracle.thr_act_of(0.01)
+    out = {}
+    try:
+        for v in (1, 0):
+            _sweep_variant(v)
+            full = [n(x) for x in ops._RayTraceVoGEIso.apply(t(mus.reshape(-1, 3)), t(a.reshape(-1)), t(rays), None, thr_act, K)]
+            li, ll, lz = ops.trace_lean(1, t(mus.reshape(-1, 3)), t(a.reshape(-1)), None, t(rays), None, thr_act, K)      # (no act / dsd)
+            out[v] = (full, [n(li), n(ll), n(lz.cnt)])
+    finally:
+        _sweep_variant(0)
+    assert (out[0][0][0] >= 0).sum() > 500
+    for x, y in zip(out[0][0], out[1][0]):
+        assert np.array_equal(x, y)
+    if out[0][1] is not None:
+        for x, y in zip(out[0][1], out[1][1]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(out[0][1][0], out[0][0][0]) and np.array_equal(out[0][1][1], out[0][0][1])
+
+
+@pytest.mark.parametrize("N,extent,r_lo,r_hi,K,what", [
+    (70000, 0.5, 0.6, 0.7, 6, "stream-everything fallback with more than 65536 Gaussians: 32-bit handles, two half-tile passes"),
+    (90000, 0.05, 0.002, 0.004, 9, "pooled tile lists longer than 65536 entries"),
+])
+def test_streams_longer_than_16_bit_handles(hip_lib, N, extent, r_lo, r_hi, K, what):
+    """The rebuilt sweep keeps a 16-bit handle per list entry; a stream of more than 65536 entries in a scene of more than
+    65536 Gaussians takes its wide form (32-bit handles over half the rays at a time).  Against the brute-force oracle."""
+    from voge_amd import ops
+    rng = np.random.default_rng(N)
+    verts = rng.uniform(-extent, extent, (N, 3)).astype(np.float32)
+    r = rng.uniform(r_lo, r_hi, N)
+    sig = (1.0 / (r * r / (2 * np.log(1 / 0.6)))).astype(np.float32)
+    H, W = 40, 48
+    R, T = camera_np.look_at_view_transform(3.0, 10.0, 20.0)
+    rays, origin = camera_np.pixel_rays(R, T, 110.0, (W / 2.0, H / 2.0), (H, W))
+    mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = (2 * camera_np.expand_sigma(sig)).astype(np.float32)[None]
+    thr_act = oracle.thr_act_of(0.01)
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    assert (ref[0][..., 0] >= 0).sum() > 10, what
+    a = np.ascontiguousarray(isg[..., 0, 0])
+    got = [n(x) for x in ops._RayTraceVoGEIso.apply(t(mus.reshape(-1, 3)), t(a.reshape(-1)), t(rays), None, thr_act, K)]
+    used, cap = ops.trace_pool_usage("cuda:0", 1, N, H, W)
+    log_line(f"[sweep] {what}: pool used {used} of {cap}")
+    compare_trace(got, ref, thr_act, min_match=0.995, label=f"wide handles N={N}")
