@@ -625,3 +625,52 @@ def test_graph_replay_of_a_small_dense_object(hip_lib, form):
     for p, w in zip(params, want):
         assert (p.grad - w).abs().max().item() <= 2e-4 * max(1.0, w.abs().max().item())      # (atomics: order of the sums)
     assert float(want_img.min()) < 0.9      # the object is there
+
+
+# ------------------------------------------------------------------ the deferred composite and the autograd mode
+@pytest.mark.parametrize("sig_kind", ["scalar", "full3x3"])
+def test_deferred_composite_keeps_the_render_calls_autograd_mode(sig_kind):
+    """The reference composites inside the renderer call (Renderer.py:139-143), so WHEN somebody first reads the weights
+    cannot matter.  Here the composite is deferred: it must run under the autograd mode of the render call, not of the
+    first reader.  (a) render with grad, read vert_weight / valid_num under no_grad (a feature-bank update, logging), then
+    differentiate a loss through interpolate_attr: the Gaussians still get their gradient, and it equals the one of the
+    same frame whose weights were never touched under no_grad.  (b) fragments rendered under no_grad stay graph-free when
+    they are composited outside it.  (c) assigning vert_weight before anything was read leaves valid_num in place."""
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import interpolate_attr, to_white_background
+    verts, sig, cols = random_scene(500, seed=11, lo=0.07, hi=0.16)
+    if sig_kind == "full3x3":
+        sig = camera_np.expand_sigma(sig).astype(np.float32)
+    H, W, K = 48, 64, 12
+    R, T = camera_np.look_at_view_transform(3.2, 15.0, 35.0)
+    renderer = renderer_for(H, W, K, 60.0)
+
+    def frame(read_first):
+        gm = GaussianMeshes(t(verts, rg=True), t(sig, rg=True))
+        colors = t(cols, rg=True)
+        frag = renderer(gm, R=t(R), T=t(T))
+        if read_first:
+            with torch.no_grad():
+                w = frag.vert_weight
+                assert frag.valid_num is not None and w.shape[-1] == K
+                _ = frag.shape, frag[0]
+        img = interpolate_attr(frag, colors)
+        (img * t(np.linspace(0.5, 1.5, 3))).sum().backward()
+        return n(gm.verts.grad), n(gm.sigmas.grad), n(colors.grad)
+
+    plain, touched = frame(False), frame(True)
+    for name, a, b in zip(("verts", "sigmas", "colors"), plain, touched):
+        assert np.abs(a).max() > 0, name
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), name      # (atomics order: not bit-equal)
+
+    gm = GaussianMeshes(t(verts, rg=True), t(sig, rg=True))
+    with torch.no_grad():
+        frag = renderer(gm, R=t(R), T=t(T))
+    w = frag.vert_weight                      # composited outside no_grad: still no graph, nothing kept for a backward
+    assert not w.requires_grad and w.grad_fn is None
+    img = to_white_background(frag, t(cols))
+    assert not img.requires_grad
+
+    frag = renderer(gm, R=t(R), T=t(T))
+    frag.vert_weight = torch.zeros_like(frag.vert_hit_length)
+    assert frag.valid_num is not None and frag.valid_num.shape == frag.vert_index.shape[:-1]

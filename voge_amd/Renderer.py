@@ -57,6 +57,8 @@ class Fragments(object):
 
     @vert_weight.setter
     def vert_weight(self, value):
+        if self._lazy is not None and self._valid_num is None:      # (the reference's Fragments always has valid_num)
+            self._valid_num = self._lazy.cnt.to(torch.int64)
         self._lazy = None
         self._wsum = None
         self._vert_weight = value

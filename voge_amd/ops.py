@@ -749,7 +749,7 @@ class LazyComposite:
     """What the deferred composite needs from a _TraceLean call (nothing in it has a grad_fn except sel_len, which the
     composite nodes take as an input)."""
     __slots__ = ("mode", "sigma_mode", "shared", "occ", "B", "N", "K", "p0", "p1", "sel_idx", "sel_len", "cnt", "records", "rays",
-                 "rays_version")
+                 "rays_version", "grad_mode", "idx_version", "p0_version")
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -769,10 +769,22 @@ class LazyComposite:
         if self.rays._version != self.rays_version:
             raise RuntimeError("the rays were modified in place after the fragments were traced: the backward would read the "
                                "changed values (as autograd's own check for saved tensors)")
+        if self.sel_idx._version != self.idx_version:
+            raise RuntimeError("vert_index was modified in place after the fragments were traced: the backward would read the "
+                               "changed values (as autograd's own check for saved tensors)")
+        if self.mode == 0 and self.p0._version != self.p0_version:
+            raise RuntimeError("the Gaussians' centres were modified in place after the fragments were traced (an optimizer "
+                               "step between forward and backward?): the backward would read the changed values")
+
+    def grad(self):
+        """The autograd mode the RENDER ran under, for whoever composites these fragments later: the reference computes the
+        weights inside the renderer call, so reading them first under torch.no_grad() (a feature-bank update, logging) must
+        neither drop the graph of a later loss nor build one for fragments rendered without."""
+        return torch.set_grad_enabled(self.grad_mode)
 
     def through(self, weight):
         """Tag freshly composited weights the way fragments() does (a later to_colored_background takes _ShadeThrough)."""
-        if (self.p0.requires_grad or self.p1.requires_grad) and torch.is_grad_enabled():
+        if (self.p0.requires_grad or self.p1.requires_grad) and self.grad_mode:
             len_d = self.sel_len.detach()
             act, dsd = getattr(weight, "voge_act_dsd", (None, None))      # (general forms: what the composite kept)
             weight.voge_through = dict(
@@ -1007,7 +1019,8 @@ def composite_merge(lz, attr):
         return None
     if os.environ.get("VOGE_SHADE_THROUGH", "1") == "0":
         return None
-    rgb, wsum, weight, valid = _CompositeMerge.apply(attr, lz.p0, lz.p1, lz.sel_len, lz)
+    with lz.grad():
+        rgb, wsum, weight, valid = _CompositeMerge.apply(attr, lz.p0, lz.p1, lz.sel_len, lz)
     return rgb, wsum, lz.through(weight), valid
 
 
@@ -1019,7 +1032,8 @@ def trace_lean(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mod
     rays_d = rays.detach()
     lz = LazyComposite(mode=int(mode), sigma_mode=int(sigma_mode), shared=bool(mode == 2 and p0.dim() == 2), occ=float(occ), B=B, N=N,
                        K=int(n_assign), p0=p0, p1=p1, sel_idx=sel_idx, sel_len=sel_len, cnt=cnt, records=records, rays=rays_d,
-                       rays_version=rays_d._version)
+                       rays_version=rays_d._version, grad_mode=torch.is_grad_enabled(), idx_version=sel_idx._version,
+                       p0_version=p0._version)
     return sel_idx, sel_len, lz
 
 
@@ -1039,7 +1053,8 @@ def lazy_eligible(mode, p0, p1, origin, rays, n_assign):
 
 def composite_lean(lz):
     """-> weight, valid_num of a deferred composite (the weights carry `voge_through` like fragments()' do)."""
-    weight, valid = _CompositeLean.apply(lz.p0, lz.p1, lz.sel_len, lz)
+    with lz.grad():
+        weight, valid = _CompositeLean.apply(lz.p0, lz.p1, lz.sel_len, lz)
     return lz.through(weight), valid
 
 
@@ -1050,7 +1065,8 @@ def composite_shade(lz, attr, bg, thr):
         return None      # (K <= 128: the image's backward is voge_fragment_shade_bwd_iso)
     if os.environ.get("VOGE_SHADE_THROUGH", "1") == "0":
         return None
-    img, weight, valid = _CompositeShade.apply(attr, lz.p0, lz.p1, lz.sel_len, lz, bg, thr)
+    with lz.grad():
+        img, weight, valid = _CompositeShade.apply(attr, lz.p0, lz.p1, lz.sel_len, lz, bg, thr)
     return img, lz.through(weight), valid
 
 
