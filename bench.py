@@ -6,8 +6,11 @@ synthetic Gaussians, 512x512, K=40, max_point_per_bin=-1):
     frag = renderer(gaussians, R=R, T=T); img = to_white_background(frag, colors); img.sum().backward()
 with gradients to verts [N,3], sigmas [N] and colours [N,3].  Inputs are resident in HBM before
 the timed region.  With --gpus N > 1 (one process per GPU) the frame's pixel rows are sharded over the
-ranks: each rank traces / composites its own row band, the image is assembled by ONE all-gather (RCCL) and
-the per-Gaussian gradients by ONE all-reduce -> total work is fixed, "scaling": "strong".
+ranks -- dealt in interleaved 32-row stripes (voge_amd.distributed.Stripes), so that every rank gets a sample of
+the whole image; --row-bands: one contiguous band per rank with measured rebalancing, rounds 1-2's scheme --: each
+rank traces / composites its own rows, the image is assembled by ONE all-gather (RCCL) and the per-Gaussian
+gradients by ONE all-reduce -> total work is fixed, "scaling": "strong".  --views runs the weak-scaling batch of
+N views instead (one whole view per rank); both alternatives and config 4 are also reported under `variants`.
 `python bench.py --gpus N` from a bare shell starts its own N ranks (torch.distributed.run as a child
 process, before this process touches a GPU); under torchrun it is one of the ranks.
 
@@ -49,9 +52,12 @@ def parse():
                     help="single GPU: use the multi-GPU launch scheme (forward graph / eager exchange / backward graph)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU oracle work for cpu_baseline")
     ap.add_argument("--row-bands", action="store_true",
-                    help="multi-GPU: STRONG scaling -- ONE frame split into pixel-row bands over the ranks (rounds 1-2's scheme).  "
-                         "Default for --gpus N > 1: WEAK scaling -- a batch of N views of the same Gaussians (a multi-view training "
-                         "iteration), sharded view first on the stacked (view, row) axis: one whole view per rank")
+                    help="multi-GPU: ONE frame as one CONTIGUOUS pixel-row band per rank with measured rebalancing (rounds 1-2's "
+                         "scheme) instead of the default interleaved stripes; strong scaling either way")
+    ap.add_argument("--views", action="store_true",
+                    help="multi-GPU: WEAK scaling -- a batch of N views of the same Gaussians (a multi-view training iteration), "
+                         "one whole view per rank.  Default for --gpus N > 1: STRONG scaling -- ONE frame of the metric config, "
+                         "its pixel rows dealt to the ranks in interleaved stripes")
     ap.add_argument("--loop", action="store_true",
                     help="BASELINE config 5 as a loop: a step = ONE ShapeFitting iteration (5 views batched, interpolate_attr + "
                          "get_silhouette MSE losses, backward, SGD step); implies --config cfg5_shapefit_128")
@@ -243,215 +249,247 @@ def main():
     from voge_amd.Meshes import GaussianMeshes
     from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, get_silhouette, interpolate_attr, to_white_background
     from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
-    from voge_amd.distributed import FlatGrads, gather_rows, gather_rows_async, rebalance_bounds, row_band
+    from types import SimpleNamespace
+    from voge_amd.distributed import (FlatGrads, Stripes, gather_rows, gather_rows_async, gather_stripes, gather_stripes_async,
+                                      rebalance_bounds, row_band, stripe_height)
     _lib.load()
 
     N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[args.config]
-    # Multi-GPU, default: a batch of `world` views of the SAME Gaussians -- what a multi-view training iteration renders
-    # (ShapeFitting: 5 per step) -- sharded on the stacked (view, row) axis, view first (distributed.stacked_bounds): rank r
-    # renders whole view r with no per-band fixed cost paid twice; ONE all_gather assembles the batch of images, ONE
-    # all_reduce sums the Gaussians' gradients.  Per-GPU work is fixed as N grows: "scaling": "weak", value = all ranks' frames/s.
-    # --row-bands: ONE frame split into pixel-row bands (total work fixed: "strong").
-    by_views = world > 1 and not args.row_bands
-    if by_views:
-        Rv, Tv = look_at_view_transform(dist=[dd] * world, elev=[el] * world, azim=[az + 360.0 / world * r for r in range(world)], device=dev)
-        R, T = Rv[rank:rank + 1].contiguous(), Tv[rank:rank + 1].contiguous()
-    else:
-        R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
-    # (the cameras carry the view too: the stand-alone stage timings below build their rays from `cams` alone)
-    cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), R=R, T=T, device=dev)
-    # row bands of the ranks: band r = rows [bounds[r], bounds[r + 1]); equal heights to start with
-    bands = {"bounds": [row_band(H, r, world)[0] for r in range(world)] + [H]} if (world > 1 and not by_views) else None
-    rows = (bands["bounds"][rank], bands["bounds"][rank + 1]) if bands is not None else None
-    # what the gather sees: the rank's rows of the stacked image (views mode: view r = rows [r H, (r + 1) H) of world x H)
-    H_all = world * H if by_views else H
-    stack_bounds = [r * H for r in range(world + 1)] if by_views else None
+    def measure(mode, primary=True, cfg=None):
+        """Set up `mode` (see below) on config `cfg` (default: --config), build the step (HIP graph(s)), settle, and time
+        args.steps steps.  Returns every local (the frame factory, the cameras, the partition, the timings) as a namespace."""
+        N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[cfg or args.config]
+        # Multi-GPU modes (`mode`):
+        #  "stripes" (default): north_star's split -- ONE frame of the metric config, its pixel rows dealt to the ranks in
+        #     interleaved 32-row stripes (distributed.Stripes: balanced by construction), ONE all_gather for the image, ONE
+        #     all_reduce for the gradients; total work fixed: "scaling": "strong".
+        #  "row_bands": the same frame as one contiguous band per rank with measured rebalancing (rounds 1-2's scheme).
+        #  "views": a batch of `world` views of the SAME Gaussians -- what a multi-view training iteration renders -- one whole
+        #     view per rank (distributed.stacked_bounds); per-GPU work fixed: "scaling": "weak", value = all ranks' frames/s.
+        by_views = world > 1 and mode == "views"
+        striped = world > 1 and mode == "stripes"
+        stripe_h = stripe_height(H, world) if striped else None
+        if by_views:
+            Rv, Tv = look_at_view_transform(dist=[dd] * world, elev=[el] * world, azim=[az + 360.0 / world * r for r in range(world)], device=dev)
+            R, T = Rv[rank:rank + 1].contiguous(), Tv[rank:rank + 1].contiguous()
+        else:
+            R, T = look_at_view_transform(dist=dd, elev=el, azim=az, device=dev)
+        # (the cameras carry the view too: the stand-alone stage timings below build their rays from `cams` alone)
+        cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), R=R, T=T, device=dev)
+        # row bands of the ranks: band r = rows [bounds[r], bounds[r + 1]); equal heights to start with
+        bands = {"bounds": [row_band(H, r, world)[0] for r in range(world)] + [H]} if (world > 1 and mode == "row_bands") else None
+        rows = (bands["bounds"][rank], bands["bounds"][rank + 1]) if bands is not None else None
+        my_stripes = Stripes(H, rank, world, stripe_h) if striped else None
 
-    renderer_of = [None]      # (the renderer of the frame made last)
+        def rows_kw():
+            if striped:
+                return {"rows": my_stripes}
+            return {} if bands is None else {"rows": (bands["bounds"][rank], bands["bounds"][rank + 1])}
+        # what the gather sees: the rank's rows of the stacked image (views mode: view r = rows [r H, (r + 1) H) of world x H)
+        H_all = world * H if by_views else H
+        stack_bounds = [r * H for r in range(world + 1)] if by_views else None
 
-    def make_frame(anisotropic, default_bins, pattern="white_background"):
-        """(step function, parameters) of one forward+backward frame of the config.  pattern: the metric's
-        to_white_background image, or the reference training loops' interpolate_attr + get_silhouette pair."""
-        verts, sig, cols = scenes.random_gaussians(N, seed=0, anisotropic=anisotropic)
-        gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
-        colors = torch.from_numpy(cols).to(dev).requires_grad_(True)
-        settings = GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1,
-                                          max_point_per_bin=None if default_bins else -1)
-        renderer = GaussianRenderer(cams, settings).to(dev)
-        renderer_of[0] = renderer
-        params = [gm.verts, gm.sigmas, colors]
+        renderer_of = [None]      # (the renderer of the frame made last)
 
-        def fwd():
-            kw = {} if bands is None else {"rows": (bands["bounds"][rank], bands["bounds"][rank + 1])}
-            frag = renderer(gm, R=R, T=T, **kw)
-            if pattern == "white_background":
-                return to_white_background(frag, colors)
-            return torch.cat((interpolate_attr(frag, colors), get_silhouette(frag).unsqueeze(-1)), dim=-1)
-        return fwd, params, gm, colors, (verts, sig, cols)
+        def make_frame(anisotropic, default_bins, pattern="white_background"):
+            """(step function, parameters) of one forward+backward frame of the config.  pattern: the metric's
+            to_white_background image, or the reference training loops' interpolate_attr + get_silhouette pair."""
+            verts, sig, cols = scenes.random_gaussians(N, seed=0, anisotropic=anisotropic)
+            gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
+            colors = torch.from_numpy(cols).to(dev).requires_grad_(True)
+            settings = GaussianRenderSettings(image_size=(H, W), max_assign=K, thr_activation=0.01, absorptivity=1,
+                                              max_point_per_bin=None if default_bins else -1)
+            renderer = GaussianRenderer(cams, settings).to(dev)
+            renderer_of[0] = renderer
+            params = [gm.verts, gm.sigmas, colors]
 
-    def warm_side_stream(fn):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+            def fwd():
+                frag = renderer(gm, R=R, T=T, **rows_kw())
+                if pattern == "white_background":
+                    return to_white_background(frag, colors)
+                return torch.cat((interpolate_attr(frag, colors), get_silhouette(frag).unsqueeze(-1)), dim=-1)
+            return fwd, params, gm, colors, (verts, sig, cols)
 
-    graph_checked = []      # (one entry per captured frame whose replayed gradients were compared with the eager step's)
-
-    def graphed_step(fwd, params):
-        """One frame as a HIP graph replay (every replay runs exactly the kernels of an eager step on the same static
-        tensors); eager on capture failure or --no-graph.  Returns (callable, launch description)."""
-        def step():
-            for p in params:
-                p.grad = None
-            fwd().sum().backward()
-        if args.no_graph:
-            for _ in range(60):      # allocator pools, lazily loaded code objects, clocks: what graph capture warms on the way
-                step()
-            torch.cuda.synchronize()
-            return step, "eager"
-        try:
-            warm_side_stream(step)
-            torch.cuda.synchronize()
-            want = [p.grad.detach().clone() for p in params]      # (the eager step's gradients: what a replay must reproduce)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
-            for _ in range(3):                                     # back-to-back replays, no host synchronisation between them
-                graph.replay()
-            torch.cuda.synchronize()
-            for p, w in zip(params, want):
-                err = float((p.grad - w).abs().max()) / max(float(w.abs().max()), 1e-30)
-                assert err < 1e-3, f"HIP graph replay does not reproduce the eager step's gradients (rel. error {err:.2e})"
-            graph_checked.append(True)
-            return graph.replay, "hip graph replay"
-        except Exception as e:  # pragma: no cover - depends on the runtime
-            print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            torch.cuda.synchronize()
-            return step, "eager"
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(run, steps, warmup):
-        for _ in range(warmup):
-            run()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            run()
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt
-
-    fwd, params, gm, colors, host_scene = make_frame("diag" if args.diagonal else args.anisotropic, args.default_bins)
-    balance_log = []
-    if args.only_stage and args.only_stage != "frame":      # ("frame": the frame alone, no stand-alone stage calls)
-        run, launch = (lambda: None), "none (--only-stage)"
-    elif world == 1 and not args.split_graph:
-        run, launch = graphed_step(fwd, params)
-    else:
-        # Multi-GPU: the local compute is two HIP graphs -- band forward, band backward -- and the two exchanges
-        # (all_gather of image rows, asynchronous, overlapping the backward graph; all_reduce of the gradients) run
-        # eagerly, so no collective is ever captured.  The loss is sum(image): every rank owns the loss of its band,
-        # whose upstream gradient is a constant tensor of ones.  The gradients live in ONE persistent flat buffer
-        # (FlatGrads): the backward graph accumulates into views of it, the all_reduce runs on it in place.
-        flat = FlatGrads(params)
-
-        def eager_once():
-            flat.zero()
-            b = fwd()
-            torch.autograd.backward(b, torch.ones_like(b))
-        # Measured load balancing (stationary scene): every rank times its band's local compute, the times are exchanged
-        # once per round and every rank moves the boundaries the same way (distributed.rebalance_bounds).  Setup, untimed.
-        if world > 1 and bands is not None and args.balance_rounds > 0:
-            fixed = None
-            side = torch.cuda.Stream()      # (like every eager run in front of a capture: never on the default stream)
+        def warm_side_stream(fn):
+            side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for it in range(args.balance_rounds + 1):
-                    for _w in range(3):
-                        eager_once()
-                    side.synchronize()
-                    t0 = time.perf_counter()
-                    for _w in range(8):
-                        eager_once()
-                    side.synchronize()
-                    mine = (time.perf_counter() - t0) / 8 * 1e6
-                    times = [None] * world
-                    dist.all_gather_object(times, float(mine))
-                    balance_log.append({"bounds": list(bands["bounds"]), "band_us": [round(t) for t in times]})
-                    if it == args.balance_rounds:
-                        break
-                    if fixed is None:
-                        fixed = 0.5 * min(times)      # what a nearly empty band still costs: latency, not work
-                    bands["bounds"] = rebalance_bounds(bands["bounds"], times, fixed=fixed, damping=0.8, min_rows=8)
-            # the best partition actually measured (the equal-height start included): noise cannot make things worse
-            best = min(balance_log, key=lambda e: max(e["band_us"]))
-            bands["bounds"] = list(best["bounds"])
+                for _ in range(3):
+                    fn()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            rows = (bands["bounds"][rank], bands["bounds"][rank + 1])
-        gb = stack_bounds if by_views else (None if bands is None else bands["bounds"])
-        run, launch = None, "eager"
-        if not args.no_graph:
+
+        graph_checked = []      # (one entry per captured frame whose replayed gradients were compared with the eager step's)
+
+        def graphed_step(fwd, params):
+            """One frame as a HIP graph replay (every replay runs exactly the kernels of an eager step on the same static
+            tensors); eager on capture failure or --no-graph.  Returns (callable, launch description)."""
+            def step():
+                for p in params:
+                    p.grad = None
+                fwd().sum().backward()
+            if args.no_graph:
+                for _ in range(60):      # allocator pools, lazily loaded code objects, clocks: what graph capture warms on the way
+                    step()
+                torch.cuda.synchronize()
+                return step, "eager"
             try:
-                warm_side_stream(eager_once)
-                g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                # thread_local: RCCL's watchdog thread polls events while we capture
-                with torch.cuda.graph(g_fwd, capture_error_mode="thread_local"):
-                    band_static = fwd()
-                ones_static = torch.ones_like(band_static)
-                with torch.cuda.graph(g_bwd, pool=g_fwd.pool(), capture_error_mode="thread_local"):
-                    flat.zero()
-                    torch.autograd.backward(band_static, ones_static)
-
-                def run_split():
-                    g_fwd.replay()
-                    finish = gather_rows_async(band_static.detach(), H_all, bounds=gb)   # all_gather starts (no-op on one GPU) ...
-                    g_bwd.replay()                                          # ... and overlaps the band's backward
-                    flat.allreduce()                                        # one eager all_reduce, in place
-                    return finish().sum()                                   # the full-image loss every rank holds
-                run_split()
+                warm_side_stream(step)
                 torch.cuda.synchronize()
-                run = run_split
-                launch = "hip graphs (band forward, band backward) + eager all_gather_into_tensor / all_reduce (flat buffer)"
+                want = [p.grad.detach().clone() for p in params]      # (the eager step's gradients: what a replay must reproduce)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    step()
+                for _ in range(3):                                     # back-to-back replays, no host synchronisation between them
+                    graph.replay()
+                torch.cuda.synchronize()
+                for p, w in zip(params, want):
+                    err = float((p.grad - w).abs().max()) / max(float(w.abs().max()), 1e-30)
+                    assert err < 1e-3, f"HIP graph replay does not reproduce the eager step's gradients (rel. error {err:.2e})"
+                graph_checked.append(True)
+                return graph.replay, "hip graph replay"
             except Exception as e:  # pragma: no cover - depends on the runtime
-                print(f"[bench] split HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 torch.cuda.synchronize()
-        if run is None:
-            def run():
-                flat.zero()
-                band = fwd()
-                img = gather_rows(band, H_all, bounds=gb)
-                r0, r1 = (rank * H, (rank + 1) * H) if by_views else (rows if rows is not None else (0, H))
-                img[:, r0:r1].sum().backward()      # each rank owns the loss of its band / view; grads are summed below
-                flat.allreduce()
-                return img
+                return step, "eager"
 
-    # settle (untimed, before the contract's W warmup steps): a fresh box ramps its clocks and pools over the first
-    # tenths of a second of load; K steps of a 0.4 ms frame would otherwise be timed on the ramp
-    if world == 1:
-        t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < 0.3:
-            for _ in range(20):
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        def timed(run, steps, warmup):
+            for _ in range(warmup):
+                run()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run()
+            barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            return dt
+
+        fwd, params, gm, colors, host_scene = make_frame("diag" if args.diagonal else args.anisotropic, args.default_bins)
+        if not primary:
+            del host_scene
+            host_scene = None
+        balance_log = []
+        if primary and args.only_stage and args.only_stage != "frame":      # ("frame": the frame alone, no stand-alone stage calls)
+            run, launch = (lambda: None), "none (--only-stage)"
+        elif world == 1 and not args.split_graph:
+            run, launch = graphed_step(fwd, params)
+        else:
+            # Multi-GPU: the local compute is two HIP graphs -- band forward, band backward -- and the two exchanges
+            # (all_gather of image rows, asynchronous, overlapping the backward graph; all_reduce of the gradients) run
+            # eagerly, so no collective is ever captured.  The loss is sum(image): every rank owns the loss of its band,
+            # whose upstream gradient is a constant tensor of ones.  The gradients live in ONE persistent flat buffer
+            # (FlatGrads): the backward graph accumulates into views of it, the all_reduce runs on it in place.
+            flat = FlatGrads(params)
+
+            def eager_once():
+                flat.zero()
+                b = fwd()
+                torch.autograd.backward(b, torch.ones_like(b))
+            # Measured load balancing (stationary scene): every rank times its band's local compute, the times are exchanged
+            # once per round and every rank moves the boundaries the same way (distributed.rebalance_bounds).  Setup, untimed.
+            if world > 1 and bands is not None and args.balance_rounds > 0:
+                fixed = None
+                side = torch.cuda.Stream()      # (like every eager run in front of a capture: never on the default stream)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for it in range(args.balance_rounds + 1):
+                        for _w in range(3):
+                            eager_once()
+                        side.synchronize()
+                        t0 = time.perf_counter()
+                        for _w in range(8):
+                            eager_once()
+                        side.synchronize()
+                        mine = (time.perf_counter() - t0) / 8 * 1e6
+                        times = [None] * world
+                        dist.all_gather_object(times, float(mine))
+                        balance_log.append({"bounds": list(bands["bounds"]), "band_us": [round(t) for t in times]})
+                        if it == args.balance_rounds:
+                            break
+                        if fixed is None:
+                            fixed = 0.5 * min(times)      # what a nearly empty band still costs: latency, not work
+                        bands["bounds"] = rebalance_bounds(bands["bounds"], times, fixed=fixed, damping=0.8, min_rows=8)
+                # the best partition actually measured (the equal-height start included): noise cannot make things worse
+                best = min(balance_log, key=lambda e: max(e["band_us"]))
+                bands["bounds"] = list(best["bounds"])
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                rows = (bands["bounds"][rank], bands["bounds"][rank + 1])
+            gb = stack_bounds if by_views else (None if bands is None else bands["bounds"])
+            run, launch = None, "eager"
+            if not args.no_graph:
+                try:
+                    warm_side_stream(eager_once)
+                    g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    # thread_local: RCCL's watchdog thread polls events while we capture
+                    with torch.cuda.graph(g_fwd, capture_error_mode="thread_local"):
+                        band_static = fwd()
+                    ones_static = torch.ones_like(band_static)
+                    with torch.cuda.graph(g_bwd, pool=g_fwd.pool(), capture_error_mode="thread_local"):
+                        flat.zero()
+                        torch.autograd.backward(band_static, ones_static)
+
+                    def run_split():
+                        g_fwd.replay()
+                        finish = (gather_stripes_async(band_static.detach(), H, stripe_h) if striped else      # all_gather starts (no-op on one GPU) ...
+                                  gather_rows_async(band_static.detach(), H_all, bounds=gb))
+                        g_bwd.replay()                                          # ... and overlaps the band's backward
+                        flat.allreduce()                                        # one eager all_reduce, in place
+                        return finish().sum()                                   # the full-image loss every rank holds
+                    run_split()
+                    torch.cuda.synchronize()
+                    run = run_split
+                    launch = "hip graphs (band forward, band backward) + eager all_gather_into_tensor / all_reduce (flat buffer)"
+                except Exception as e:  # pragma: no cover - depends on the runtime
+                    print(f"[bench] split HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                    torch.cuda.synchronize()
+            if run is None:
+                def run():
+                    flat.zero()
+                    band = fwd()
+                    if striped:
+                        img = gather_stripes(band, H, stripe_h)
+                        img.index_select(1, my_stripes.image_rows(dev)).sum().backward()
+                    else:
+                        img = gather_rows(band, H_all, bounds=gb)
+                        r0, r1 = (rank * H, (rank + 1) * H) if by_views else (rows if rows is not None else (0, H))
+                        img[:, r0:r1].sum().backward()      # each rank owns the loss of its band / view; grads are summed below
+                    flat.allreduce()
+                    return img
+
+        # settle (untimed, before the contract's W warmup steps): a fresh box ramps its clocks and pools over the first
+        # tenths of a second of load; K steps of a 0.4 ms frame would otherwise be timed on the ramp
+        if world == 1:
+            t_settle = time.perf_counter()
+            while time.perf_counter() - t_settle < 0.3:
+                for _ in range(20):
+                    run()
+                torch.cuda.synchronize()
+        else:                                  # (collectives inside: every rank must run the SAME number of steps)
+            for _ in range(300):
                 run()
             torch.cuda.synchronize()
-    else:                                  # (collectives inside: every rank must run the SAME number of steps)
-        for _ in range(300):
-            run()
-        torch.cuda.synchronize()
-    dt = timed(run, args.steps, args.warmup)
-    ms = dt / args.steps * 1e3
-    fps = (world if by_views else 1) * args.steps / dt      # (views mode: every step renders `world` frames, one per rank)
+        dt = timed(run, args.steps, args.warmup)
+        ms = dt / args.steps * 1e3
+        fps = (world if by_views else 1) * args.steps / dt      # (views mode: every step renders `world` frames, one per rank)
+        return SimpleNamespace(**{k: v for k, v in locals().items() if k != "mode"})
+
+
+    mode = "views" if args.views else ("row_bands" if args.row_bands else "stripes")
+    M = measure(mode if world > 1 else "single")
+    (by_views, striped, stripe_h, bands, rows, my_stripes, cams, R, T, make_frame, graphed_step, timed, barrier, renderer_of, fwd, params, gm,
+     colors, host_scene, balance_log, launch, dt, ms, fps, rows_kw, graph_checked) = (
+        M.by_views, M.striped, M.stripe_h, M.bands, M.rows, M.my_stripes, M.cams, M.R, M.T, M.make_frame, M.graphed_step, M.timed, M.barrier,
+        M.renderer_of, M.fwd, M.params, M.gm, M.colors, M.host_scene, M.balance_log, M.launch, M.dt, M.ms, M.fps, M.rows_kw, M.graph_checked)
 
     sig_kind = "(N,3) per-axis sigmas" if args.diagonal else ("[N,3,3] L L^T sigmas" if args.anisotropic else "scalar sigmas")
     bins_kind = "None (default)" if args.default_bins else "-1"
@@ -466,8 +504,13 @@ def main():
                    "parallelism": ("1 gpu" if world == 1 else
                                    f"a batch of {world} views on the stacked (view, row) axis, view first: one whole view per rank; "
                                    f"all_gather(images) + all_reduce(gradients); a step = {world} frames" if by_views else
-                                   f"pixel-row bands x{world}, all_gather(image)+all_reduce(grads)")},
+                                   f"ONE frame, pixel rows dealt to {world} ranks in interleaved stripes of {stripe_h} rows (each rank renders "
+                                   f"its stripes stacked into one image); all_gather(image) + all_reduce(grads)" if striped else
+                                   f"ONE frame, one contiguous pixel-row band per rank x{world} (measured rebalancing), "
+                                   f"all_gather(image)+all_reduce(grads)")},
     }
+    if world > 1 and rank == 0:
+        result["config"]["multi_gpu_mode"] = mode
 
     if world > 1 and bands is not None:
         result["config"]["bands"] = list(bands["bounds"])      # rows [b[r], b[r+1]) of rank r, after the measured balancing
@@ -672,8 +715,7 @@ def main():
                 i = state["i"] = (state["i"] + 1) % nview
                 for p_ in params:
                     p_.grad = None
-                kw = {} if bands is None else {"rows": (bands["bounds"][rank], bands["bounds"][rank + 1])}
-                to_white_background(renderer_of[0](gm, R=Rm[i:i + 1], T=Tm[i:i + 1], **kw), colors).sum().backward()
+                to_white_background(renderer_of[0](gm, R=Rm[i:i + 1], T=Tm[i:i + 1], **rows_kw()), colors).sum().backward()
             for _ in range(60):
                 moving()
             torch.cuda.synchronize()
@@ -684,14 +726,28 @@ def main():
         if not args.no_cpu_baseline:
             verts, sig, cols = host_scene
             result["cpu_baseline"] = cpu_baseline(verts, sig, cols, H, W, K, focal, pp, (dd, el, az), args.cpu_seconds)
+    if world > 1 and not args.no_variants:
+        # the other ways to use the same N GPUs, same scene (every rank takes part): the contiguous bands of rounds 1-2, the
+        # weak-scaling batch of views, and north_star's config 4 (200k Gaussians, 1024^2) in the default mode
+        variants = {}
+        for vname, vmode, vcfg in (("row_bands_contiguous", "row_bands", None), ("views_weak_scaling", "views", None),
+                                   ("stripes", "stripes", None), ("cfg4_200k_1024_" + mode, mode, "cfg4_200k_1024")):
+            if (vmode == mode and vcfg is None) or (vcfg is not None and vcfg == args.config):
+                continue
+            V = measure(vmode, primary=False, cfg=vcfg)
+            variants[vname] = {"value": round(V.fps, 1), "unit": "frames/s", "ms_per_step": round(V.ms, 4),
+                               "scaling": "weak" if vmode == "views" else "strong", "launch": V.launch}
+            del V
+            torch.cuda.empty_cache()
+        result["variants"] = variants
     if rank == 0 and world > 1:
-        # the dominant kernel on rank 0's band of rows (same entry point, shorter image), timed live
+        # the dominant kernel on rank 0's rows (same entry point, shorter image), timed live
         with torch.no_grad():
             from voge_amd.cameras import pixel_rays
             r0, r1 = rows if rows is not None else (0, H)       # (views mode: rank 0's whole view)
-            rays_b, origin = pixel_rays(cams, (H, W), rows=rows)
-            cones = ops.cones_of(rays_b, 1, r1 - r0, W)
-            h = r1 - r0
+            rays_b, origin = pixel_rays(cams, (H, W), rows=my_stripes if striped else rows)
+            h = my_stripes.h if striped else r1 - r0
+            cones = ops.cones_of(rays_b, 1, h, W)
             iso = gm.sigmas.dim() == 1
             st = torch.cuda.current_stream().cuda_stream
             nws = lib.voge_trace_workspace_bytes(1, N, h, W)
@@ -710,7 +766,8 @@ def main():
             nb = stage_bytes(N, h * W, K, iso=iso)["trace_fwd"]
             t_ms, _ = rotating(mk, call, nb)
             a = round(nb / 1e9 / (t_ms / 1e3), 1)
-            result["roofline"] = {"kernel": TRACE_KERNELS + (" on rank 0's view" if by_views else f" on rank 0's band of rows [{r0}, {r1})"),
+            result["roofline"] = {"kernel": TRACE_KERNELS + (" on rank 0's view" if by_views else f" on rank 0's {h} rows (interleaved stripes)" if striped
+                                                             else f" on rank 0's band of rows [{r0}, {r1})"),
                                   "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                                   "algorithmic_bytes": nb, "avg_launch_ms": round(t_ms, 4)}

@@ -469,6 +469,23 @@ int voge_shade_bwd(const float *attr, const int32_t *idx, const float *weight,
 int voge_rays_fwd(const float *R, const float *T, const float *focal, const float *pp, int B,
                   int row0, int h, int W, float *rays, float *origin, float *cones, voge_stream_t stream);
 
+/*
+ * The same for a STRIPED row set: output row i is image row row0 + (i / stripe_h) * pitch + i % stripe_h -- every
+ * pitch-th stripe of stripe_h rows from row0 on, h rows in total (only the last stripe may be cut short by h).  What a
+ * rank renders when one frame is dealt to the ranks of a node in interleaved stripes (voge_amd/distributed.py: a
+ * contiguous band per rank leaves the centre band 4x as expensive as the rim bands).  The stacked rows are an image like
+ * any other to every later stage (pixels are independent; the cones bound the rays actually present).  stripe_h >= h is
+ * voge_rays_fwd.  voge_rays_striped_bwd is its backward (voge_rays_bwd's arguments plus the stripe geometry).
+ * No counterpart in the reference (single device).
+ */
+int voge_rays_striped_fwd(const float *R, const float *T, const float *focal, const float *pp, int B,
+                          int row0, int h, int stripe_h, int pitch, int W, float *rays, float *origin, float *cones,
+                          voge_stream_t stream);
+int voge_rays_striped_bwd(const float *R, const float *T, const float *focal, const float *pp,
+                          const float *g_rays, const float *g_origin, int B, int row0, int h, int stripe_h, int pitch, int W,
+                          float *scratch, float *g_R, float *g_T, float *g_focal, float *g_pp,
+                          voge_stream_t stream);
+
 /* The same cones from any rays [B,H,W,3] tensor (no counterpart in the reference: culling aid). */
 size_t voge_cones_floats(int B, int H, int W);
 int voge_ray_cones(const float *rays, int B, int H, int W, float *cones, voge_stream_t stream);

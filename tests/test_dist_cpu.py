@@ -186,3 +186,64 @@ def test_stacked_view_row_sharding_equals_single_rank(tmp_path):
     n_g = sc["verts"].shape[0]
     g_attr, _ = oracle.merge_bwd(np.tile(sc["colors"], (B, 1)), ref["idx"], ref["weight"], ref["valid_num"], np.ones_like(ref["rgb"]))
     assert np.abs(got["g"].numpy() - g_attr.reshape(B, n_g, 3).sum(0)).max() < 1e-10
+
+
+# ------------------------------------------------------------------ round 4: one frame dealt in interleaved stripes
+def _stripe_worker(rank, world, port, H, W, stripe_h, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from voge_amd.distributed import FlatGrads, Stripes, gather_stripes, gather_stripes_async
+    sc = cuboid_scene()
+    R, T = camera_np.look_at_view_transform(sc["dist"], sc["elev"], sc["azim"])
+    mine = Stripes(H, rank, world, stripe_h)
+    rows = mine.image_rows().numpy()
+    rays, origin = camera_np.pixel_rays(R, T, 60.0, (W / 2, H / 2), (H, W))
+    mus = (sc["verts"][None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = (2 * camera_np.expand_sigma(sc["sigmas"])).astype(np.float32)[None]
+    stacked = np.ascontiguousarray(rays[:, rows])                              # the rank's stripes as ONE image of mine.h rows
+    idx, ln, act, dsd = oracle.trace_fwd(mus, isg, stacked, 8, oracle.thr_act_of(0.01))
+    w, vn = oracle.composite_fwd(idx, act, ln, dsd, 1.0)
+    colors = torch.tensor(sc["colors"], dtype=torch.float64, requires_grad=True)
+    fg = FlatGrads([colors])
+    wt = torch.tensor(w)
+    valid = torch.tensor(np.arange(8)[None, None, None] < vn[..., None])
+    band = (colors[torch.tensor(np.maximum(idx, 0)).long()] * (wt * valid)[..., None]).sum(-2)      # [1, h, W, 3]
+    assert band.shape[1] == mine.h
+    img = gather_stripes(band, H, stripe_h)                                    # ONE all_gather + a local row permutation
+    assert img.shape == (1, H, W, 3)
+    assert torch.equal(gather_stripes_async(band.detach(), H, stripe_h)(), img.detach())
+    (img * torch.linspace(0.5, 1.5, H, dtype=torch.float64)[None, :, None, None]).sum().backward()   # a loss on the WHOLE frame
+    fg.allreduce()                                                             # ONE all_reduce
+    if rank == 0:
+        torch.save({"img": img.detach(), "g": colors.grad.clone()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stripe_dealt_frame_equals_single_rank(tmp_path):
+    """Stripes(H, rank, world, stripe_h): every rank renders its interleaved stripes stacked into one image; the gathered,
+    re-ordered frame and the all-reduced gradient of a full-frame loss equal the single-process render.  (H = 21 with
+    stripes of 4 rows over 2 ranks: rank 0 gets rows 0-3, 8-11, 16-19, rank 1 rows 4-7, 12-15, 20 -- a cut last stripe and
+    unequal stacked heights.)"""
+    from voge_amd.distributed import Stripes, stripe_height
+    H, W, world, stripe_h = 21, 16, 2, 4
+    s0, s1 = Stripes(H, 0, world, stripe_h), Stripes(H, 1, world, stripe_h)
+    assert s0.image_rows().tolist() == [0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19] and s1.image_rows().tolist() == [4, 5, 6, 7, 12, 13, 14, 15, 20]
+    assert sorted(s0.image_rows().tolist() + s1.image_rows().tolist()) == list(range(H))
+    assert stripe_height(1024, 8) == 32 and stripe_height(64, 8) == 8 and stripe_height(21, 2, 4) == 4 and stripe_height(5, 8) == 1
+    out = str(tmp_path / "s0.pt")
+    mp.spawn(_stripe_worker, args=(world, _free_port(), H, W, stripe_h, out), nprocs=world, join=True)
+    got = torch.load(out)
+    sc = cuboid_scene()
+    R, T = camera_np.look_at_view_transform(sc["dist"], sc["elev"], sc["azim"])
+    rays, origin = camera_np.pixel_rays(R, T, 60.0, (W / 2, H / 2), (H, W))
+    mus = (sc["verts"][None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = (2 * camera_np.expand_sigma(sc["sigmas"])).astype(np.float32)[None]
+    idx, ln, act, dsd = oracle.trace_fwd(mus, isg, rays, 8, oracle.thr_act_of(0.01))
+    w, vn = oracle.composite_fwd(idx, act, ln, dsd, 1.0)
+    colors = torch.tensor(sc["colors"], dtype=torch.float64, requires_grad=True)
+    valid = torch.tensor(np.arange(8)[None, None, None] < vn[..., None])
+    img = (colors[torch.tensor(np.maximum(idx, 0)).long()] * (torch.tensor(w) * valid)[..., None]).sum(-2)
+    (img * torch.linspace(0.5, 1.5, H, dtype=torch.float64)[None, :, None, None]).sum().backward()
+    assert torch.equal(got["img"], img.detach())                               # pixels are independent: the same bits
+    assert torch.allclose(got["g"], colors.grad, rtol=1e-12, atol=1e-14)

@@ -471,6 +471,30 @@ def test_row_bands_equal_whole_frame_and_default_bins(hip_lib):
     assert torch.equal(img2, img) and torch.equal(frag2.vert_index, frag.vert_index)
 
 
+def test_interleaved_stripes_equal_whole_frame(hip_lib):
+    """One frame dealt to the ranks in interleaved stripes (distributed.Stripes, voge_rays_striped_fwd): every rank's
+    stripes, stacked into one image and rendered by ONE renderer call, reproduce their rows of the whole frame bit for bit
+    (pixels are independent; the binning's cones bound whatever rays are present), for stripe heights that are and are not
+    multiples of the 32-row super-tiles, with a cut last stripe, B = 2."""
+    from voge_amd.distributed import Stripes
+    sc = cuboid_scene()
+    size = (100, 80)
+    sc = dict(sc, focal=100.0, principal=(40.0, 50.0))
+    frag, img, *_ = _render(sc, size, B=2)
+    for world, stripe_h in ((3, 32), (2, 8), (4, 5)):
+        seen = []
+        for rank in range(world):
+            st = Stripes(size[0], rank, world, stripe_h)
+            rows = st.image_rows(DEV)
+            seen += rows.tolist()
+            f, im, *_ = _render(sc, size, B=2, rows=st)
+            assert im.shape[1] == st.h
+            for name in ("vert_weight", "vert_index", "valid_num", "vert_hit_length"):
+                assert torch.equal(getattr(f, name), getattr(frag, name).index_select(1, rows)), (name, world, stripe_h, rank)
+            assert torch.equal(im, img.index_select(1, rows))
+        assert sorted(seen) == list(range(size[0]))
+
+
 def test_full_size_properties_config3(hip_lib):
     """BASELINE config 3 (50k Gaussians, 512x512, K=40): too large for the oracle in seconds, so
     check size-independent properties + an oracle spot check on a row band."""
@@ -1061,10 +1085,11 @@ def test_renderer_edge_shapes(hip_lib, N, H, W, K, B, aniso, fused):
         assert (img == 1).all() and (frag.valid_num == 0).all()
 
 
-@pytest.mark.parametrize("mode", ["views", "row_bands"])
+@pytest.mark.parametrize("mode", ["stripes", "views", "row_bands"])
 def test_bench_two_ranks_on_one_gpu(hip_lib, mode):
     """bench.py's N > 1 path end to end (its own rank spawning, split HIP graphs, overlapped all_gather, flat all_reduce)
-    with both ranks on this one GPU through gloo: the line it prints carries the contract's fields for the mode."""
+    with both ranks on this one GPU through gloo: the line it prints carries the contract's fields for the mode.  The
+    default is north_star's split: ONE frame, strong scaling (interleaved stripes)."""
     import json
     import subprocess
     import sys
@@ -1073,15 +1098,19 @@ def test_bench_two_ranks_on_one_gpu(hip_lib, mode):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--balance-rounds", "1"]
-    if mode == "row_bands":
-        cmd.append("--row-bands")
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    if mode != "stripes":
+        cmd += ["--no-variants", "--row-bands" if mode == "row_bands" else "--views"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0 and line["unit"] == "frames/s"
-    assert line["scaling"] == ("weak" if mode == "views" else "strong")
-    # a step is 2 frames (one view per rank) or 1 frame (two row bands)
+    assert line["scaling"] == ("weak" if mode == "views" else "strong") and line["config"]["multi_gpu_mode"] == mode
+    # a step is 2 frames (one view per rank) or 1 frame (two ranks' rows)
     frames = 2 if mode == "views" else 1
     assert abs(line["value"] - frames * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
     assert ("bands" in line["config"]) == (mode == "row_bands")
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    if mode == "stripes":      # the default line also carries the alternatives and config 4
+        v = line["variants"]
+        assert set(v) == {"row_bands_contiguous", "views_weak_scaling", "cfg4_200k_1024_stripes"}
+        assert v["views_weak_scaling"]["scaling"] == "weak" and all(x["value"] > 0 for x in v.values())

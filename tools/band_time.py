@@ -2,14 +2,15 @@
 rows (HIP graph replay, no collectives) for n = 1, 2, 4, 8 -- the part of strong scaling that does
 not depend on xGMI.  With VIEWS=B a batch of B views is sharded on the stacked (view, row) axis instead
 (distributed.stacked_bounds: whole views per rank when B % n == 0).
-usage: [VIEWS=8] python tools/band_time.py [config]"""
+STRIPE=h deals the frame in interleaved stripes of h rows instead of contiguous bands (distributed.Stripes; round 4).
+usage: [VIEWS=8 | STRIPE=32] python tools/band_time.py [config]"""
 import os, sys, time, torch
 sys.path.insert(0, ".")
 from voge_amd import scenes
 from voge_amd.Meshes import GaussianMeshes
 from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
 from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
-from voge_amd.distributed import balanced_row_bounds, projected_row_weight, render_stacked, row_band, stacked_bounds
+from voge_amd.distributed import Stripes, balanced_row_bounds, projected_row_weight, render_stacked, row_band, stacked_bounds, stripe_height
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_50k_512"
 dev = torch.device("cuda", 0)
 N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS[name]
@@ -23,6 +24,7 @@ renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=(H, W), max_
 params = [gm.verts, gm.sigmas, colors]
 base = None
 FLOOR = float(os.environ.get("FLOOR", "-1"))       # >= 0: work-balanced bands (balanced_row_bounds) with this floor
+STRIPE = int(os.environ.get("STRIPE", "0"))        # > 0: interleaved stripes of (at most) this many rows
 weight = projected_row_weight(verts, R[0], T[0], focal, pp[1], H)
 for n in (1, 2, 4, 8):
     worst = 0.0
@@ -32,6 +34,8 @@ for n in (1, 2, 4, 8):
         if FLOOR >= 0:
             b = balanced_row_bounds(weight, n, floor=FLOOR)
             rows = (b[r], b[r + 1])
+        if STRIPE > 0 and n > 1:
+            rows = Stripes(H, r, n, stripe_height(H, n, STRIPE))
         def step():
             for p in params: p.grad = None
             if VIEWS == 1:

@@ -71,6 +71,8 @@ SIGNATURES = {
     "voge_shade_fwd": (_c_int, [_c_void_p] * 5 + [_c_float, _c_long, _c_int, _c_int, _c_long, _c_int] + [_c_void_p] * 5),
     "voge_shade_bwd": (_c_int, [_c_void_p] * 7 + [_c_float, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_long] + [_c_void_p] * 3),
     "voge_rays_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p] * 4),
+    "voge_rays_striped_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p] * 4),
+    "voge_rays_striped_bwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 6 + [_c_void_p] * 6),
     "voge_cones_floats": (_c_size_t, [_c_int] * 3),
     "voge_ray_cones": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "voge_general_preamble_fwd": (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p] * 3),

@@ -76,6 +76,7 @@ class PerspectiveCameras:
 def pixel_rays(cameras, image_size, rows=None):
     """Unit world-space ray directions [B,h,W,3] for pixel rows `rows=(r0,r1)` (default: all H
     rows) and the camera centres [B,3]: what Renderer.py:124-128 reads from the ray bundle.
+    `rows` may also be a distributed.Stripes (a rank's interleaved stripes of the frame, stacked into one image).
     One HIP kernel (voge_rays_fwd); differentiable w.r.t. R, T, focal_length, principal_point."""
     from . import ops
     H, W = int(image_size[0]), int(image_size[1])
@@ -88,6 +89,8 @@ def pixel_rays(cameras, image_size, rows=None):
     T = T.expand(B, 3)
     f = _as_b2(cameras.focal_length, B, device)
     pp = _as_b2(cameras.principal_point, B, device)
+    if hasattr(rows, "stripe_h"):      # distributed.Stripes
+        return ops.pixel_rays(R, T, f, pp, rows.row0, rows.h, W, rows.stripe_h, rows.pitch)
     r0, r1 = (0, H) if rows is None else (int(rows[0]), int(rows[1]))
     return ops.pixel_rays(R, T, f, pp, r0, r1 - r0, W)
 

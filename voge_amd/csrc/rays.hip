@@ -33,9 +33,12 @@ __device__ __forceinline__ Mat3 inv3(const float *R) {
 
 __global__ void __launch_bounds__(256)
 rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const float *__restrict__ focal,
-                const float *__restrict__ pp, const int row0, const int h, const int W,
+                const float *__restrict__ pp, const int row0, const int h, const int W, const int stripe_h, const int pitch,
                 float *__restrict__ rays, float *__restrict__ origin, const int ray_blocks,
                 ConeRec *__restrict__ cones /* NULL | [B][nsty][nstx] */) {
+  // row i of the output is image row irow(i): a contiguous band (stripe_h >= h), or every `pitch`-th stripe of
+  // `stripe_h` rows starting at row0 (a rank's share of a frame dealt in stripes: voge_amd/distributed.py)
+  auto irow = [&](const int i) { const int k = i / stripe_h; return row0 + k * pitch + (i - k * stripe_h); };
   const int b = blockIdx.y;
   const Mat3 Ri = inv3(R + 9 * b);
   const float fx = focal[2 * b], fy = focal[2 * b + 1], px = pp[2 * b], py = pp[2 * b + 1];
@@ -56,7 +59,7 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
       const int j = x0 + lx0 + u, i = y0 + ly;
       has |= (j < W && i < h) ? (1u << u) : 0u;
       const float vx = (px - ((float)j + 0.5f)) * ifx;
-      const float vy = (py - ((float)(row0 + i) + 0.5f)) * ify;
+      const float vy = (py - ((float)irow(min(i, max(h - 1, 0))) + 0.5f)) * ify;
       const float wx = vx * Ri.m[0] + vy * Ri.m[3] + Ri.m[6];
       const float wy = vx * Ri.m[1] + vy * Ri.m[4] + Ri.m[7];
       const float wz = vx * Ri.m[2] + vy * Ri.m[5] + Ri.m[8];
@@ -89,7 +92,7 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
       int j = p - i * W;
       if (j < 0) { --i; j += W; } else if (j >= W) { ++i; j -= W; }
       const float vx = (px - ((float)j + 0.5f)) * ifx;
-      const float vy = (py - ((float)(row0 + i) + 0.5f)) * ify;
+      const float vy = (py - ((float)irow(i) + 0.5f)) * ify;
       const float wx = vx * Ri.m[0] + vy * Ri.m[3] + Ri.m[6];
       const float wy = vx * Ri.m[1] + vy * Ri.m[4] + Ri.m[7];
       const float wz = vx * Ri.m[2] + vy * Ri.m[5] + Ri.m[8];
@@ -132,7 +135,7 @@ cones_kernel(const float *__restrict__ rays, const int H, const int W, ConeRec *
 __global__ void __launch_bounds__(256)
 rays_bwd_reduce_kernel(const float *__restrict__ R, const float *__restrict__ focal,
                        const float *__restrict__ pp, const float *__restrict__ g_rays, const int row0,
-                       const int h, const int W, float *__restrict__ part /* [B][16], zeroed */) {
+                       const int h, const int W, const int stripe_h, const int pitch, float *__restrict__ part /* [B][16], zeroed */) {
   __shared__ float red[4][13];
   const int b = blockIdx.y;
   const Mat3 Ri = inv3(R + 9 * b);
@@ -143,7 +146,8 @@ rays_bwd_reduce_kernel(const float *__restrict__ R, const float *__restrict__ fo
   const int n = h * W;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
     const int i = p / W, j = p - i * W;
-    const float ax = px - ((float)j + 0.5f), ay = py - ((float)(row0 + i) + 0.5f);
+    const int sk = i / stripe_h;
+    const float ax = px - ((float)j + 0.5f), ay = py - ((float)(row0 + sk * pitch + (i - sk * stripe_h)) + 0.5f);
     const float vx = ax / fx, vy = ay / fy;
     const float wx = vx * Ri.m[0] + vy * Ri.m[3] + Ri.m[6];
     const float wy = vx * Ri.m[1] + vy * Ri.m[4] + Ri.m[7];
@@ -214,9 +218,22 @@ __global__ void rays_bwd_finish_kernel(const float *__restrict__ R, const float 
 
 using namespace voge;
 
+extern "C" int voge_rays_striped_fwd(const float *R, const float *T, const float *focal, const float *pp, int B,
+                                     int row0, int h, int stripe_h, int pitch, int W, float *rays, float *origin, float *cones,
+                                     voge_stream_t stream);
+extern "C" int voge_rays_striped_bwd(const float *R, const float *T, const float *focal, const float *pp,
+                                     const float *g_rays, const float *g_origin, int B, int row0, int h, int stripe_h, int pitch,
+                                     int W, float *scratch, float *g_R, float *g_T, float *g_focal, float *g_pp, voge_stream_t stream);
+
 extern "C" int voge_rays_fwd(const float *R, const float *T, const float *focal, const float *pp, int B,
                              int row0, int h, int W, float *rays, float *origin, float *cones, voge_stream_t stream) {
-  if (B < 0 || h < 0 || W < 0) return VOGE_ERR_BAD_ARG;
+  return voge_rays_striped_fwd(R, T, focal, pp, B, row0, h, h > 0 ? h : 1, 0, W, rays, origin, cones, stream);
+}
+
+extern "C" int voge_rays_striped_fwd(const float *R, const float *T, const float *focal, const float *pp, int B,
+                                     int row0, int h, int stripe_h, int pitch, int W, float *rays, float *origin, float *cones,
+                                     voge_stream_t stream) {
+  if (B < 0 || h < 0 || W < 0 || stripe_h <= 0 || pitch < 0) return VOGE_ERR_BAD_ARG;
   if (B == 0) return 0;
   if (!R || !T || !focal || !pp || !origin || ((size_t)h * W > 0 && !rays)) return VOGE_ERR_BAD_ARG;
   const int n = h * W;
@@ -225,7 +242,7 @@ extern "C" int voge_rays_fwd(const float *R, const float *T, const float *focal,
   if (blocks > 2048) blocks = 2048;
   const int nst = (cones != nullptr && n > 0) ? ((W + kST - 1) / kST) * ((h + kST - 1) / kST) : 0;
   hipLaunchKernelGGL(rays_fwd_kernel, dim3(blocks + nst, B), dim3(256), 0, (hipStream_t)stream, R, T, focal, pp, row0, h, W,
-                     rays, origin, blocks, reinterpret_cast<ConeRec *>(cones));
+                     stripe_h, pitch, rays, origin, blocks, reinterpret_cast<ConeRec *>(cones));
   return launch_status();
 }
 
@@ -247,7 +264,14 @@ extern "C" int voge_rays_bwd(const float *R, const float *T, const float *focal,
                              const float *g_rays, const float *g_origin, int B, int row0, int h, int W,
                              float *scratch /* [B][16] floats */, float *g_R, float *g_T, float *g_focal,
                              float *g_pp, voge_stream_t stream) {
-  if (B < 0 || h < 0 || W < 0) return VOGE_ERR_BAD_ARG;
+  return voge_rays_striped_bwd(R, T, focal, pp, g_rays, g_origin, B, row0, h, h > 0 ? h : 1, 0, W, scratch, g_R, g_T, g_focal, g_pp, stream);
+}
+
+extern "C" int voge_rays_striped_bwd(const float *R, const float *T, const float *focal, const float *pp,
+                                     const float *g_rays, const float *g_origin, int B, int row0, int h, int stripe_h, int pitch,
+                                     int W, float *scratch /* [B][16] floats */, float *g_R, float *g_T, float *g_focal,
+                                     float *g_pp, voge_stream_t stream) {
+  if (B < 0 || h < 0 || W < 0 || stripe_h <= 0 || pitch < 0) return VOGE_ERR_BAD_ARG;
   if (B == 0) return 0;
   if (!R || !T || !focal || !pp || !scratch) return VOGE_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -258,7 +282,7 @@ extern "C" int voge_rays_bwd(const float *R, const float *T, const float *focal,
     int blocks = (n + 255) / 256;
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(rays_bwd_reduce_kernel, dim3(blocks, B), dim3(256), 0, st, R, focal, pp, g_rays, row0, h, W,
-                       scratch);
+                       stripe_h, pitch, scratch);
   }
   hipLaunchKernelGGL(rays_bwd_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, st, R, T, scratch, g_origin, B, g_R,
                      g_T, g_focal, g_pp);

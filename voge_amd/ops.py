@@ -1397,8 +1397,9 @@ class _PixelRays(torch.autograd.Function):
     unit world-space directions [B,h,W,3] of image rows row0..row0+h-1 and the camera centres [B,3]."""
 
     @staticmethod
-    def forward(ctx, R, T, focal, pp, row0, h, W):
+    def forward(ctx, R, T, focal, pp, row0, h, W, stripe_h=None, pitch=0):
         lib = _lib.load()
+        stripe_h = max(int(h), 1) if stripe_h is None else int(stripe_h)      # (None: one contiguous band)
         R_c, T_c = _dev(R, torch.float32, "R"), _dev(T, torch.float32, "T")
         f_c, p_c = _dev(focal, torch.float32, "focal_length"), _dev(pp, torch.float32, "principal_point")
         B = R_c.shape[0]
@@ -1408,11 +1409,11 @@ class _PixelRays(torch.autograd.Function):
         # bounding cones of the band's 32x32-pixel super-tiles: the trace's culling aid, made here for free
         cones = torch.empty((max(int(lib.voge_cones_floats(B, int(h), int(W))), 1),), dtype=torch.float32, device=R_c.device)
         with _on(R_c.device):
-            rc = lib.voge_rays_fwd(_p(R_c), _p(T_c), _p(f_c), _p(p_c), B, int(row0), int(h), int(W), _p(rays),
-                                   _p(origin), _p(cones), _stream())
-        _lib.check(rc, "voge_rays_fwd")
+            rc = lib.voge_rays_striped_fwd(_p(R_c), _p(T_c), _p(f_c), _p(p_c), B, int(row0), int(h), stripe_h, int(pitch), int(W),
+                                           _p(rays), _p(origin), _p(cones), _stream())
+        _lib.check(rc, "voge_rays_striped_fwd")
         ctx.save_for_backward(R_c, T_c, f_c, p_c)
-        ctx.geom = (int(row0), int(h), int(W))
+        ctx.geom = (int(row0), int(h), int(W), stripe_h, int(pitch))
         ctx.mark_non_differentiable(cones)
         return rays, origin, cones
 
@@ -1420,7 +1421,7 @@ class _PixelRays(torch.autograd.Function):
     def backward(ctx, g_rays, g_origin, _g_cones):
         lib = _lib.load()
         R, T, f, pp = ctx.saved_tensors
-        row0, h, W = ctx.geom
+        row0, h, W, stripe_h, pitch = ctx.geom
         B = R.shape[0]
         gr = None if g_rays is None else _dev(g_rays, torch.float32, "grad_rays")
         go = None if g_origin is None else _dev(g_origin, torch.float32, "grad_origin")
@@ -1431,10 +1432,10 @@ class _PixelRays(torch.autograd.Function):
         g_p = torch.empty_like(pp) if need[3] else None
         scratch = torch.empty((B, 16), dtype=torch.float32, device=R.device)
         with _on(R.device):
-            rc = lib.voge_rays_bwd(_p(R), _p(T), _p(f), _p(pp), _p(gr), _p(go), B, row0, h, W, _p(scratch), _p(g_R),
-                                   _p(g_T), _p(g_f), _p(g_p), _stream())
-        _lib.check(rc, "voge_rays_bwd")
-        return g_R, g_T, g_f, g_p, None, None, None
+            rc = lib.voge_rays_striped_bwd(_p(R), _p(T), _p(f), _p(pp), _p(gr), _p(go), B, row0, h, stripe_h, pitch, W, _p(scratch),
+                                           _p(g_R), _p(g_T), _p(g_f), _p(g_p), _stream())
+        _lib.check(rc, "voge_rays_striped_bwd")
+        return g_R, g_T, g_f, g_p, None, None, None, None, None
 
 
 class _RayTraceVoGERay(torch.autograd.Function):
@@ -1586,8 +1587,10 @@ def scatter_max(weight, idx, n_vert):
     return out
 
 
-def pixel_rays(R, T, focal, pp, row0, h, W):
-    rays, origin, cones = _PixelRays.apply(R, T, focal, pp, row0, h, W)
+def pixel_rays(R, T, focal, pp, row0, h, W, stripe_h=None, pitch=0):
+    """rays [B,h,W,3] of image rows row0 .. row0+h-1, or (stripe_h, pitch given) of every pitch-th stripe of stripe_h rows
+    from row0 on, h rows in total; origin [B,3]."""
+    rays, origin, cones = _PixelRays.apply(R, T, focal, pp, row0, h, W, stripe_h, pitch)
     rays.voge_cones = (cones, rays._version)      # see cones_of()
     return rays, origin
 
