@@ -726,6 +726,8 @@ def main():
         if not args.no_cpu_baseline:
             verts, sig, cols = host_scene
             result["cpu_baseline"] = cpu_baseline(verts, sig, cols, H, W, K, focal, pp, (dd, el, az), args.cpu_seconds)
+            # ... and the reference's own CPU-capable tensor program beside the C port
+            result["cpu_baseline_torch"] = cpu_baseline_torch(verts, sig, cols, H, W, K, focal, pp, (dd, el, az), args.cpu_seconds)
     if world > 1 and not args.no_variants:
         # the other ways to use the same N GPUs, same scene (every rank takes part): the contiguous bands of rounds 1-2, the
         # weak-scaling batch of views, and north_star's config 4 (200k Gaussians, 1024^2) in the default mode
@@ -816,6 +818,47 @@ def cpu_baseline(verts, sig, cols, H, W, K, focal, pp, view, target_s):
             "sample": f"{nrows} of {H} pixel rows (rows {r0}..{r0 + nrows - 1}) of the same frame, fwd+bwd, "
                       f"oracle/voge_oracle.c fp64, OpenMP over pixels in every stage ({os.cpu_count()} threads; the two backward "
                       f"scatters use atomic adds); {t_all:.2f} s measured (fwd {t_fwd:.2f} s), scaled x{scale:.1f}"}
+
+
+def cpu_baseline_torch(verts, sig, cols, H, W, K, focal, pp, view, target_s):
+    """BASELINE.md section 3's "reference's pure-PyTorch CPU path", timed on this host: the reference's dense tensor program
+    for aggregation / merge / blend (VoGE/Aggregation.py:30-141, VoGE/Renderer.py:157-176: [pix, K, K] erf / exp tensors,
+    autograd backward) behind a dense einsum + topk statement of the fine trace (ray_trace_voge.cu:135-217) -- the
+    restatement in oracle/torch_ref.py, fp32, torch.set_num_threads(all cores) -- on a bounded sample: `nrows` pixel rows
+    around the image centre, forward and forward+backward, scaled to a whole frame by H / nrows."""
+    import numpy as np
+    import torch
+    from oracle import camera_np, torch_ref
+    ncore = os.cpu_count()
+    torch.set_num_threads(ncore)
+    R, T = camera_np.look_at_view_transform(*view)
+    rays_all, origin = camera_np.pixel_rays(R, T, focal, pp, (H, W))
+    origin_t = torch.tensor(origin[0], dtype=torch.float32)
+
+    def run(nrows):
+        r0 = H // 2 - nrows // 2
+        rays = torch.tensor(np.ascontiguousarray(rays_all[0, r0:r0 + nrows]).reshape(-1, 3), dtype=torch.float32)
+        v = torch.tensor(verts, dtype=torch.float32, requires_grad=True)
+        s = torch.tensor(sig, dtype=torch.float32, requires_grad=True)
+        c = torch.tensor(cols, dtype=torch.float32, requires_grad=True)
+        t0 = time.perf_counter()
+        img = torch_ref.frame(v, s, c, rays, origin_t, K)
+        t_fwd = time.perf_counter() - t0
+        img.sum().backward()
+        assert torch.isfinite(v.grad).all() and float(v.grad.abs().max()) > 0
+        return time.perf_counter() - t0, t_fwd, r0
+
+    run(1)                                  # (first call: thread pool, allocator)
+    t_probe, _, _ = run(2)
+    nrows = int(max(2, min(H, round(2 * target_s / max(t_probe, 1e-3)))))
+    t_all, t_fwd, r0 = run(nrows)
+    scale = H / nrows
+    return {"value": 1.0 / (t_all * scale), "unit": "frames/s", "cores": ncore, "kind": "port",
+            "forward_only_frames_per_s": 1.0 / (t_fwd * scale),
+            "sample": f"{nrows} of {H} pixel rows (rows {r0}..{r0 + nrows - 1}) of the same frame, fwd+bwd in torch {torch.__version__} CPU fp32 "
+                      f"({ncore} threads): dense einsum + topk trace over all {len(verts)} Gaussians, then the reference's [pix,K,K] "
+                      f"aggregation / merge_final / to_white_background tensor program with autograd (oracle/torch_ref.py, pinned to the "
+                      f"imported reference by tests/test_oracle_cpu.py); {t_all:.2f} s measured (fwd {t_fwd:.2f} s), scaled x{scale:.1f}"}
 
 
 if __name__ == "__main__":

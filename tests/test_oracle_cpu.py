@@ -266,3 +266,49 @@ def test_ray_convention_against_the_reference_get_ray_camera_space():
         # and WITHOUT the shift the two differ by exactly the half-pixel offset (so the test above is not vacuous)
         raw, _ = camera_np.pixel_rays(np.eye(3)[None], np.zeros((1, 3)), (fx, fy), (px, py), (H, W))
         assert np.abs(raw[0] - g[name + "_dirs"]).max() > 0.2 / max(fx, fy) / 2
+
+
+# ------------------------------------------------------------------ the torch tensor program of bench.py's cpu_baseline_torch
+@pytest.mark.parametrize("name", ["k5", "k25", "k40"])
+def test_torch_tensor_program_matches_the_reference_outputs(name):
+    """oracle/torch_ref.py restates the reference's dense tensor program (Aggregation.py:30-141, Renderer.py:157-171) for
+    the CPU baseline BASELINE.md section 3 defines; its weights and autograd gradients equal what the imported reference
+    produced on the same inputs (the golden fixtures of tests/golden/make_golden.py)."""
+    import torch
+    from oracle import torch_ref
+    g = np.load(os.path.join(GOLDEN, f"composite_{name}.npz"))
+    td = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, requires_grad=True)
+    act, ln, dsd = td(g["act"]), td(g["len"]), td(g["dsd"])
+    w, vn = torch_ref.aggregation(torch.tensor(g["idx"]), act, ln, dsd, float(g["occ"]))
+    assert np.abs(w.detach().numpy() - g["weight"]).max() < 1e-13 and (vn.numpy() == g["valid_num"]).all()
+    (w * torch.tensor(g["g_weight"])).sum().backward()
+    for got, key in ((act.grad, "g_act"), (ln.grad, "g_len"), (dsd.grad, "g_dsd")):
+        assert np.abs(got.numpy() - g[key]).max() <= 1e-11 * max(1.0, np.abs(g[key]).max()), key
+
+
+def test_torch_tensor_program_merge_blend_and_dense_trace():
+    import torch
+    from oracle import torch_ref
+    m = np.load(os.path.join(GOLDEN, "merge_blend.npz"))
+    td = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    rgb = torch_ref.merge_final(td(m["colors"]), td(m["weight"]), torch.tensor(m["valid_num"]), torch.tensor(m["idx"]))
+    assert np.abs(rgb.numpy() - m["rgb"]).max() < 1e-14
+    img = torch_ref.to_colored_background(rgb, td(m["weight"]), torch.ones(3, dtype=torch.float64))
+    assert np.abs(img.numpy() - m["img_white"]).max() < 1e-14
+    img2 = torch_ref.to_colored_background(rgb, td(m["weight"]), td(m["bg"]), float(m["thr"]))
+    assert np.abs(img2.numpy() - m["img_colored_thr"]).max() < 1e-6
+    # the dense trace against the C oracle's (same selection rule: K smallest len among act < thr_act)
+    from util import random_scene
+    verts, sig, _ = random_scene(300, seed=3, lo=0.08, hi=0.2)
+    R, T = camera_np.look_at_view_transform(3.0, 10.0, 25.0)
+    H, W, K = 12, 16, 9
+    rays, origin = camera_np.pixel_rays(R, T, 20.0, (W / 2.0, H / 2.0), (H, W))
+    mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = (2 * camera_np.expand_sigma(sig)).astype(np.float32)[None]
+    thr_act = oracle.thr_act_of(0.01)
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    idx, ln, act, dsd = torch_ref.trace_dense(td(mus[0]), td(isg[0]), td(rays.reshape(-1, 3)), K, thr_act, chunk=50)
+    same = (idx.numpy().reshape(ref[0].shape) == ref[0]).all(-1)
+    assert same.mean() > 0.99
+    for got, want in ((ln, ref[1]), (act, ref[2]), (dsd, ref[3])):
+        assert np.abs(got.numpy().reshape(want.shape)[same] - want[same]).max() < 1e-6 * max(1.0, np.abs(want[same]).max())
