@@ -155,6 +155,18 @@ def gen_misc(Agg, Ren, Cub, Conv, IO):
     print("bunny:", cv.shape, float(cs.mean()), float(cs.max()))
 
 
+def gen_car(Conv, IO):
+    """demo/ExtractTexture.py:40-42's input at its real size: data/car.off through the reference's own loader,
+    pre_process_pascal and naive_vertices_converter(percentage=0.5, max_sig_rate=2) -- 25 662 Gaussians -- plus the pose of
+    data/car_annotation.npz (theta, azimuth, elevation) the demo renders it with."""
+    cv, cs, _ = Conv.naive_vertices_converter(*IO.pre_process_pascal(*IO.load_off(os.path.join(REF, "demo/data/car.off"))),
+                                              percentage=0.5, max_sig_rate=2)
+    an = np.load(os.path.join(REF, "demo/data/car_annotation.npz"))
+    np.savez_compressed(os.path.join(OUT, "car_gaussians.npz"), verts=np.asarray(cv, np.float32), isigma=np.asarray(cs, np.float32),
+                        theta=float(an["theta"]), azimuth=float(an["azimuth"]), elevation=float(an["elevation"]))
+    print("car:", np.asarray(cv).shape, float(np.asarray(cs).mean()), float(np.asarray(cs).max()))
+
+
 def gen_trace_known_answer():
     """The reference's embedded backward proof (ray_trace_voge.cu:381-448): same inputs, the
     same three forms, loss = len + act, gradients by torch autograd."""
@@ -324,3 +336,4 @@ if __name__ == "__main__":
     gen_converters_more(mods[2], mods[3])
     gen_host_logic(mods[1])
     gen_ray_camera_space(mods[0])
+    gen_car(mods[3], mods[4])
