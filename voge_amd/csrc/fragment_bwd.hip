@@ -330,7 +330,11 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
         if (ISO) {
           const float mx = rc[a][0].x, my = rc[a][0].y, mz = rc[a][0].z, aa = rc[a][0].w;
           const float t = fmaf(mz, dz, fmaf(my, dy, mx * dx)) * idn;
-          const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
+          float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
+          {   // (trace_bwd.hip: the component of v along d is t's rounding error; project it out before 2 a g_act scales it)
+            const float rr = fmaf(vz, dz, fmaf(vy, dy, vx * dx)) * idn;
+            vx = fmaf(-rr, dx, vx); vy = fmaf(-rr, dy, vy); vz = fmaf(-rr, dz, vz);
+          }
           const float c1 = gl[a] * idn, c2 = 2.0f * aa * ga[a];
           val[0] = make_float4(fmaf(c1, dx, c2 * vx), fmaf(c1, dy, c2 * vy), fmaf(c1, dz, c2 * vz),
                                fmaf(ga[a], fmaf(vz, vz, fmaf(vy, vy, vx * vx)), gd[a] * dn2));
@@ -346,7 +350,11 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
           const float ksk = fmaf(dz, adz, fmaf(dy, ady, dx * adx)), msk = fmaf(mz, adz, fmaf(my, ady, mx * adx));
           const float ik = __builtin_amdgcn_rcpf(ksk);
           const float t = msk * ik;
-          const float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
+          float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
+          {   // (v^T A d = 0 by construction: what is left of it is t's rounding error; one projection along d removes it)
+            const float rr = fmaf(vz, adz, fmaf(vy, ady, vx * adx)) * ik;
+            vx = fmaf(-rr, dx, vx); vy = fmaf(-rr, dy, vy); vz = fmaf(-rr, dz, vz);
+          }
           const float avx = fmaf(A[2], vz, fmaf(A[1], vy, A[0] * vx)), avy = fmaf(A[5], vz, fmaf(A[4], vy, A[3] * vx)),
                       avz = fmaf(A[8], vz, fmaf(A[7], vy, A[6] * vx));
           const float tvx = fmaf(A[6], vz, fmaf(A[3], vy, A[0] * vx)), tvy = fmaf(A[7], vz, fmaf(A[4], vy, A[1] * vx)),
