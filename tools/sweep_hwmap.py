@@ -30,14 +30,20 @@ blk = (t[:, 6] >> np.uint64(32)).astype(np.int64)
 ev = (t[:, 6] & np.uint64(0xffffffff)).astype(np.int64)
 hw = t[:, 7].astype(np.int64)
 wave, simd, cu, sh, se = hw & 15, (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
-xcc = (hw >> 16) & 15     # (XCC_ID lives in another register on gfx94x; printed for what it is worth)
+xcc = (t[:, 7].astype(np.uint64) >> np.uint64(32)).astype(np.int64) & 15     # XCC_ID register (gfx94x+)
 start = (t[:, 0] - t[:, 0].min()).astype(np.float64) * 0.01
 dur = (t[:, 5] - t[:, 0]).astype(np.float64) * 0.01
 o = np.argsort(blk)
-print("first 40 workgroups by launch index: (blk, se, sh, cu, simd, wave, start us, dur us, evals)")
-for i in o[:40]:
-    print(int(blk[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[i]), int(wave[i]), round(start[i], 1), round(dur[i], 1), int(ev[i]))
-key = ((se * 2 + sh) * 16 + cu) * 4 + simd
+key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+print("first 24 workgroups by launch index: (blk, xcc, se, sh, cu, simd, wave, start us, dur us, evals)")
+for i in o[:24]:
+    print(int(blk[i]), int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[i]), int(wave[i]), round(start[i], 1), round(dur[i], 1), int(ev[i]))
+pos = {int(b): i for i, b in enumerate(blk)}
+for step in (256, 512, 1024, 2048):
+    pairs = [(b, b + step) for b in range(0, 256) if b in pos and b + step in pos]
+    same_simd = sum(1 for a, c in pairs if key[pos[a]] == key[pos[c]])
+    same_cu = sum(1 for a, c in pairs if key[pos[a]] // 4 == key[pos[c]] // 4)
+    print(f"blocks b and b+{step}: same SIMD {same_simd} / {len(pairs)}, same CU {same_cu} / {len(pairs)}")
 first = start < 1.0
 print("distinct (se, sh, cu, simd) seen:", len(np.unique(key)), " workgroups resident at t < 1 us:", int(first.sum()))
 cnt = np.bincount(key[first])

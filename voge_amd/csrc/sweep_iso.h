@@ -543,7 +543,8 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   if (lane == 0 && b == 0 && bx < 8192) {
     unsigned long long *o = g_sweep_times + 8 * (size_t)bx;
     o[0] = ts0; o[1] = ts1; o[2] = ts_fill; o[3] = ts_cons; o[4] = ts2; o[5] = wall_clock64(); o[6] = ((unsigned long long)blockIdx.x << 32) | st_eval;
-    o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+    o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |      // HW_ID
+           ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);      // XCC_ID
   }
 #endif
 }
