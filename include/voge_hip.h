@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOGE_ABI_VERSION 4
+#define VOGE_ABI_VERSION 5
 
 #define VOGE_ERR_BAD_ARG (-1)        /* null pointer / non-positive size */
 #define VOGE_ERR_WORKSPACE (-2)      /* workspace smaller than voge_trace_workspace_bytes() */

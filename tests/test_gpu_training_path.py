@@ -674,3 +674,43 @@ def test_deferred_composite_keeps_the_render_calls_autograd_mode(sig_kind):
     frag = renderer(gm, R=t(R), T=t(T))
     frag.vert_weight = torch.zeros_like(frag.vert_hit_length)
     assert frag.valid_num is not None and frag.valid_num.shape == frag.vert_index.shape[:-1]
+
+
+def test_every_public_fragments_transformation_is_classified(hip_lib):
+    """the fast paths hang on Python attributes of the fragment tensors (ops.carry_tags), so every public way
+    to get Fragments out of Fragments must either KEEP them or be LISTED as dropping them -- a new method that is neither
+    fails here.  KEEP: the result still takes the one-pass backward / needs no synchronising range check, with the
+    composite deferred or done.  DROP (documented): a true slice of a multi-view batch is other
+    memory -- it takes the checked, three-kernel paths with the same values."""
+    from voge_amd import ops
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import Fragments
+    KEEP = {"copy": lambda f: f.copy(), "squeeze": lambda f: f.squeeze(), "unsqueeze": lambda f: f.squeeze().unsqueeze(),
+            "__getitem__": lambda f: f[0]}
+    DROP = {"__getitem__ of a multi-view batch": None}
+    NOT_A_TRANSFORMATION = {"to_dict", "shape", "vert_weight", "valid_num", "__len__", "__init__"}
+    public = {k for k, v in vars(Fragments).items() if not k.startswith("_") or k in ("__getitem__", "__len__", "__init__")}
+    public -= {"_fields"}
+    assert public == set(KEEP) | NOT_A_TRANSFORMATION, public ^ (set(KEEP) | NOT_A_TRANSFORMATION)
+    verts, sig, cols = random_scene(600, seed=9, lo=0.06, hi=0.12)
+    R1, T1 = camera_np.look_at_view_transform(3.0, 10.0, 30.0)
+    renderer = renderer_for(32, 40, 10, 50.0)
+    for deferred in (True, False):
+        gm = GaussianMeshes(t(verts, rg=True), t(sig, rg=True))
+        for name, fn in KEEP.items():
+            frag = renderer(gm, R=t(R1), T=t(T1))
+            if not deferred:
+                _ = frag.vert_weight                      # composite now: the tags live on the weight tensor
+            g = fn(frag)
+            assert isinstance(g, Fragments), name
+            assert ops.hit_count_of(g.vert_index) is not None, (name, deferred)
+            assert getattr(g.vert_index, "voge_index_bound", None) is not None, (name, deferred)
+            w = g.vert_weight
+            assert ops.through_of(w, g.vert_index) is not None, (name, deferred)      # -> the one-pass backward
+    # the documented drop: one view of a two-view batch
+    R2, T2 = camera_np.look_at_view_transform([3.0, 3.2], [10.0, -5.0], [30.0, 100.0])
+    gm = GaussianMeshes(t(verts, rg=True), t(sig, rg=True))
+    frag = renderer(gm, R=t(R2), T=t(T2))
+    one = frag[1]
+    assert ops.hit_count_of(one.vert_index) is None and ops.through_of(one.vert_weight, one.vert_index) is None
+    assert torch.equal(one.vert_weight, frag.vert_weight[1]) and list(DROP)

@@ -11,7 +11,7 @@ import os
 import sys
 from collections import defaultdict
 
-TRACE_FWD = ("cones_kernel", "prep_kernel", "binA_kernel", "binB_kernel", "trace_fwd_kernel")
+TRACE_FWD = ("cones_kernel", "prep_kernel", "binA_kernel", "binB_kernel", "trace_fwd_kernel", "sweep_iso_kernel")
 
 
 def collect(d, counter, frame_only=False):

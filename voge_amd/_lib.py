@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VOGE_HIP_LIB points at another build of the same ABI (kernel tuning variants)
 LIB_PATH = os.environ.get("VOGE_HIP_LIB") or os.path.join(_HERE, "libvoge_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_void_p = ctypes.c_void_p
 _c_int = ctypes.c_int

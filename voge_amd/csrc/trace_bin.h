@@ -782,11 +782,15 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   // ---- this thread's ray -> the wave's tile cone, and the quad's cone over all four waves ----
   const int px = min(tx * 8 + (lane & 7), W - 1), py = min(ty * 8 + (lane >> 3), H - 1);
   const bool has = tile_ok && (tx * 8 + (lane & 7) < W) && (ty * 8 + (lane >> 3) < H);
-  RayDir u;
-  {
-    const float *r = rays + (((size_t)b * H + min(py, H - 1)) * W + min(px, W - 1)) * 3;
-    u = ray_dir(r[0], r[1], r[2]);
-  }
+  // (everything the prologue needs from memory is requested here, before the first use: the ray, this super-tile's 16
+  // segment counts, and the counts the launch rank is estimated from)
+  const float *rp = rays + (((size_t)b * H + min(py, H - 1)) * W + min(px, W - 1)) * 3;
+  const float ray_x = rp[0], ray_y = rp[1], ray_z = rp[2];
+  const int my_cnt = (tid < kParts) ? seg_count[(size_t)bin * kParts + tid] : 0;
+  const bool ranked = nbin_total <= kRankMaxBins;
+  const int4 est0 = (ranked && tid < nbin_total) ? *reinterpret_cast<const int4 *>(seg_count + (size_t)tid * kParts) : make_int4(0, 0, 0, 0);
+  const int4 est_mine = ranked ? *reinterpret_cast<const int4 *>(seg_count + (size_t)bin * kParts) : make_int4(0, 0, 0, 0);
+  const RayDir u = ray_dir(ray_x, ray_y, ray_z);
   Cone tcone, qcone;
   {
     const float wsx = wave_sum_dpp((has && u.ok) ? u.ux : 0.f), wsy = wave_sum_dpp((has && u.ok) ? u.uy : 0.f),
@@ -801,24 +805,28 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
     }
     if (lane == 0) { L.red[wave * 8 + 0] = wsx; L.red[wave * 8 + 1] = wsy; L.red[wave * 8 + 2] = wsz; L.red[wave * 8 + 3] = wok ? 1.f : 0.f; }
     if (tid == 0) { L.count = 0; L.nflag = 0; L.spill = 0; }
-    if (tid == 0) {
-      // A segment that overflowed its kSegCap entries (more than 512 of a slice's Gaussians in one super-tile: a small
-      // object far away, a zoomed-out view) does not send the quad to the stream-everything fallback any more: the
-      // slice's Gaussians -- N / kParts of them -- are tested against the quad's cone right here, from the records
-      // binA / prep left per Gaussian.  Only a quad list beyond kQCap still falls back.
-      int run = 0, erun = 0;
-      unsigned ovf = 0u;
-      for (int p = 0; p < kParts; ++p) {
-        int c = seg_count[(size_t)bin * kParts + p];
-        L.segn[p] = run;
-        L.extn[p] = erun;
-        if (c < 0) { ovf |= 1u << p; c = 0; }      // (its Gaussians come from the records, last loop of bin_stream_sources)
-        if (c > kSegCap) { erun += c - kSegCap; c = kSegCap; }
-        run += c;
+    // A segment that overflowed its kSegCap entries (more than 512 of a slice's Gaussians in one super-tile: a small
+    // object far away, a zoomed-out view) does not send the quad to the stream-everything fallback any more: the
+    // slice's Gaussians -- N / kParts of them -- are tested against the quad's cone right here, from the records
+    // binA / prep left per Gaussian.  Only a quad list beyond kQCap still falls back.
+    // (The 16 counts were requested at the kernel's entry, one per lane, together with the rays and the ranking's counts:
+    // one memory round trip in front of the source pass instead of three dependent ones -- thread 0 used to load them in a
+    // loop AFTER the cones.  Their prefix sums are a 16-lane scan.)
+    if (wave == 0) {
+      int c = (lane < kParts) ? my_cnt : 0;
+      const unsigned long long ofm = __ballot(lane < kParts && c < 0);      // (its Gaussians come from the records, last loop of bin_stream_sources)
+      if (c < 0) c = 0;
+      int e = 0;
+      if (c > kSegCap) { e = c - kSegCap; c = kSegCap; }
+      int xc = c, xe = e;
+#pragma unroll
+      for (int o = 1; o < kParts; o <<= 1) {
+        const int yc = __shfl_up(xc, o, 64), ye = __shfl_up(xe, o, 64);
+        if (lane >= o) { xc += yc; xe += ye; }
       }
-      L.segn[kParts] = run;
-      L.extn[kParts] = erun;
-      L.ovf = ovf;
+      if (lane < kParts) { L.segn[lane] = xc - c; L.extn[lane] = xe - e; }
+      if (lane == kParts - 1) { L.segn[kParts] = xc; L.extn[kParts] = xe; }
+      if (lane == 0) L.ovf = (unsigned)ofm;
     }
     __syncthreads();
     auto load_ext_tables = [&]() {      // the chunk tables of the segments with an extension: thread <-> (slice, chunk)
@@ -851,16 +859,15 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   BIN_TS(1, 6);      // (cones done)
   int rank = bin;
   {
-    auto estimate = [&](const int q) {
-      const int4 v = *reinterpret_cast<const int4 *>(seg_count + (size_t)q * kParts);
-      // (an overflowed segment counts as full: such super-tiles go first)
+    auto est_of = [](const int4 v) {      // (an overflowed segment counts as full: such super-tiles go first)
       return (v.x < 0 ? kSegCap : v.x) + (v.y < 0 ? kSegCap : v.y) + (v.z < 0 ? kSegCap : v.z) + (v.w < 0 ? kSegCap : v.w);
     };
-    if (nbin_total <= kRankMaxBins) {
-      const int mine = estimate(bin);
+    auto estimate = [&](const int q) { return est_of(*reinterpret_cast<const int4 *>(seg_count + (size_t)q * kParts)); };
+    if (ranked) {
+      const int mine = est_of(est_mine);
       int ahead = 0;
       for (int q = tid; q < nbin_total; q += kQT) {
-        const int e = estimate(q);
+        const int e = (q == tid) ? est_of(est0) : estimate(q);      // (the first one was requested at the kernel's entry)
         ahead += (e > mine || (e == mine && q < bin)) ? 1 : 0;
       }
       ahead = (int)wave_sum_dpp((float)ahead);      // (< 2^24: exact in fp32)

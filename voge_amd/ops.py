@@ -82,6 +82,15 @@ def _workspace(dev, nbytes):
     return ws
 
 
+def release_workspaces(device=None):
+    """Drop the cached scratch buffers (all, or those of one device): the trace's lists are 165 MB per 512^2 view and
+    774 MB at 1024^2, held per (device, stream) from the first call on -- a long-lived process that is done rendering big
+    frames, or that warmed a side stream for graph capture, gives the memory back here.  The next call re-allocates."""
+    idx = None if device is None else (torch.device(device).index if torch.device(device).index is not None else _get_dev())
+    for key in [k for k in _WS if idx is None or k[0] == idx]:
+        del _WS[key]
+
+
 class _GeneralPreamble(torch.autograd.Function):
     """Renderer.py:130-137 for (N,3) / (N,3,3) sigmas as one launch each way (voge_general_preamble_fwd / _bwd):
     forward(verts [N,3] | [B,N,3], sigmas [N,3] | [N,3,3] | [B,N,...], origin [B,3]) -> mus [B*N,3], isigmas [B*N,3,3]
