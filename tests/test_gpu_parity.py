@@ -471,6 +471,35 @@ def test_row_bands_equal_whole_frame_and_default_bins(hip_lib):
     assert torch.equal(img2, img) and torch.equal(frag2.vert_index, frag.vert_index)
 
 
+def test_striped_rays_fwd_bwd(hip_lib):
+    """voge_rays_striped_fwd / _bwd: a rank's interleaved stripes are the same rays as the whole frame's rows (bit for bit),
+    and the camera gradients of a loss on them equal the whole-frame kernel's for the same rows."""
+    from voge_amd import ops
+    from voge_amd.distributed import Stripes
+    rng = np.random.default_rng(1)
+    R, T = camera_np.look_at_view_transform([3.0, 4.0], [10.0, -20.0], [30.0, 100.0])
+    f = np.float32([[300.0, 310.0], [150.0, 140.0]])
+    pp = np.float32([[26.0, 18.0], [30.0, 20.5]])
+    H, W = 41, 53
+    for world, rank, sh in ((3, 1, 4), (2, 0, 8), (4, 3, 5)):
+        st = Stripes(H, rank, world, sh)
+        rows = st.image_rows(DEV)
+        G = t(rng.normal(size=(2, st.h, W, 3)))
+        grads = []
+        for striped in (True, False):
+            tR, tT, tf, tp = t(R, rg=True), t(T, rg=True), t(f, rg=True), t(pp, rg=True)
+            if striped:
+                rays, origin = ops.pixel_rays(tR, tT, tf, tp, st.row0, st.h, W, st.stripe_h, st.pitch)
+            else:
+                full, origin = ops.pixel_rays(tR, tT, tf, tp, 0, H, W)
+                rays = full.index_select(1, rows)
+            ((rays * G).sum() + origin.sum()).backward()
+            grads.append((n(rays), [n(x.grad) for x in (tR, tT, tf, tp)]))
+        assert np.array_equal(grads[0][0], grads[1][0])
+        for a, b in zip(grads[0][1], grads[1][1]):
+            assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
+
+
 def test_interleaved_stripes_equal_whole_frame(hip_lib):
     """One frame dealt to the ranks in interleaved stripes (distributed.Stripes, voge_rays_striped_fwd): every rank's
     stripes, stacked into one image and rendered by ONE renderer call, reproduce their rows of the whole frame bit for bit
