@@ -111,7 +111,9 @@ def run_dense(n_cases=6, seed=0, verbose=True):
     rng = np.random.default_rng(seed)
     pooled = 0
     for case in range(n_cases):
-        N = int(rng.choice([3000, 9000, 20000, 45000])); H = int(rng.integers(24, 80)); W = int(rng.integers(24, 80))
+        # (70 000 / 90 000: more than 65 536 Gaussians -- the rebuilt sweep's list entries then carry stream positions, and a
+        # tile with more than 65 536 candidates takes its wide form)
+        N = int(rng.choice([3000, 9000, 20000, 45000, 70000, 90000])); H = int(rng.integers(24, 80)); W = int(rng.integers(24, 80))
         K = int(rng.choice([1, 5, 12, 25, 40, 64])); B = int(rng.integers(1, 3))
         extent = float(rng.uniform(0.12, 0.5)); r_hi = float(rng.uniform(0.006, 0.03))
         iso_api = bool(rng.integers(0, 2))
