@@ -36,6 +36,26 @@ def _as_b2(v, B, device, dtype=torch.float32):
     return v
 
 
+_INTR = {}      # (one entry per device: the last (focal_length, principal_point) pair prepared and what it became)
+
+
+def _intrinsics(focal, pp, B, device):
+    """focal_length / principal_point as contiguous fp32 [B,2] tensors.  The same two objects come in on every frame of a loop
+    (only R / T move), so the last pair is remembered per device -- by identity and version of the tensors, held weakly --
+    instead of being re-expanded and re-copied by two tiny kernels per frame."""
+    import weakref
+    key = str(device)
+    hit = _INTR.get(key)
+    if (hit is not None and torch.is_tensor(focal) and torch.is_tensor(pp) and hit[0]() is focal and hit[1]() is pp
+            and hit[2] == (focal._version, pp._version, B) and not focal.requires_grad and not pp.requires_grad):
+        return hit[3], hit[4]
+    f_c, p_c = _as_b2(focal, B, device), _as_b2(pp, B, device)
+    if torch.is_tensor(focal) and torch.is_tensor(pp) and not focal.requires_grad and not pp.requires_grad:
+        f_c, p_c = f_c.contiguous(), p_c.contiguous()
+        _INTR[key] = (weakref.ref(focal), weakref.ref(pp), (focal._version, pp._version, B), f_c, p_c)
+    return f_c, p_c
+
+
 class PerspectiveCameras:
     """Screen-space pinhole cameras: the subset of pytorch3d.renderer.PerspectiveCameras the
     renderer and the demos touch (attributes R, T, focal_length, principal_point, image_size,
@@ -87,8 +107,7 @@ def pixel_rays(cameras, image_size, rows=None):
     B = max(R.shape[0], T.shape[0])
     R = R.expand(B, 3, 3)
     T = T.expand(B, 3)
-    f = _as_b2(cameras.focal_length, B, device)
-    pp = _as_b2(cameras.principal_point, B, device)
+    f, pp = _intrinsics(cameras.focal_length, cameras.principal_point, B, device)
     if hasattr(rows, "stripe_h"):      # distributed.Stripes
         return ops.pixel_rays(R, T, f, pp, rows.row0, rows.h, W, rows.stripe_h, rows.pitch)
     r0, r1 = (0, H) if rows is None else (int(rows[0]), int(rows[1]))
