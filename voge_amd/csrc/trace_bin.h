@@ -19,6 +19,8 @@
 // Both tests are conservative (cone_keep / cone_keep_ell, voge_common.h), so the sweep's result equals the
 // brute-force "-1" candidate list of VoGE/RayTracing.py:22-26.
 #pragma once
+#include <type_traits>
+
 #include "voge_common.h"
 
 namespace voge {
@@ -107,6 +109,8 @@ struct BinALds {
   int sid[kRoundCap];          // ... and Gaussian id, in (chunk, wave, lane) order
   ConeRec child[kCh * kCh];
   ConeRec region;
+  ConeRec rowc[kCh];           // cones of the region's kCh rows of super-tiles (the stacked-stripes case, see binA_kernel)
+  int use_rows;                // the region's own cone is much wider than its rows': test the rows instead
   int cnt0[kRoundChunks][16];  // [chunk][wave] survivors of the region test -> exclusive prefix
   int base[kCh * kCh];         // entries written so far per child
   int nS;
@@ -205,140 +209,198 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
     bool ok = __all(!present || r.ok > 0.f);
     const float n = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
     const float ax = sx / n, ay = sy / n, az = sz / n;
-    float smax = 0.f, cmin = 1.f;
-    if (present) {
-      const float ca = fmaf(r.az, az, fmaf(r.ay, ay, r.ax * ax));
-      const float qx = fmaf(-ca, ax, r.ax), qy = fmaf(-ca, ay, r.ay), qz = fmaf(-ca, az, r.az);
-      const float sa = sqrtf(fmaf(qz, qz, fmaf(qy, qy, qx * qx))) * (1.0f + 1e-6f) + 1e-7f;
-      const float cl = fminf(ca, 1.0f) - 1e-7f;
-      if (!(cl > 0.0f)) ok = false;
-      cmin = fmaf(cl, r.cs, -sa * r.sn);
-      smax = fmaf(fminf(ca + 1e-7f, 1.0f), r.sn, sa);
-    }
+    // a child's extrema with respect to an axis (ax, ay, az): cos >= cos(alpha) cs - sin(alpha) sn, sin <= sin(alpha) + cos(alpha) sn
+    auto child_extrema = [&](const float ax_, const float ay_, const float az_, float &smax_, float &cmin_, bool &ok_) {
+      smax_ = 0.f; cmin_ = 1.f;
+      if (present) {
+        const float ca = fmaf(r.az, az_, fmaf(r.ay, ay_, r.ax * ax_));
+        const float qx = fmaf(-ca, ax_, r.ax), qy = fmaf(-ca, ay_, r.ay), qz = fmaf(-ca, az_, r.az);
+        const float sa = sqrtf(fmaf(qz, qz, fmaf(qy, qy, qx * qx))) * (1.0f + 1e-6f) + 1e-7f;
+        const float cl = fminf(ca, 1.0f) - 1e-7f;
+        if (!(cl > 0.0f)) ok_ = false;
+        cmin_ = fmaf(cl, r.cs, -sa * r.sn);
+        smax_ = fmaf(fminf(ca + 1e-7f, 1.0f), r.sn, sa);
+      }
+    };
+    float smax, cmin;
+    child_extrema(ax, ay, az, smax, cmin, ok);
     ok = __all(ok);
     smax = wave_max(smax); cmin = wave_min(cmin);
     const Cone cn = cone_finish(ax, ay, az, n / fmaxf(npres, 1.f), smax, cmin, ok);
     if (lane == 0) L.region = ConeRec{cn.ax, cn.ay, cn.az, cn.cs, cn.sn, cn.ok ? 1.f : 0.f, 0.f, 0.f};
+    // ---- the same union per ROW of super-tiles (lanes 4g .. 4g+3 = a DPP quad).  A frame's region is compact and its
+    // own cone is what culls; but the rows of a STACKED image (a rank's interleaved stripes of a frame dealt over several
+    // GPUs: voge_rays_striped_fwd) come from distant parts of the frame: the region's cone then spans all of them and
+    // keeps nearly every Gaussian (binA 31 -> 75 us per rank at 200k / 1024^2 / 8 ranks), while each row's cone is tight.
+    // (computed only when the region's cone is far wider than a compact 4x4 block of its children would make it --
+    // uniform: a frame's regions never take this branch)
+    const float widest_child = wave_max(present ? (r.ok > 0.f ? r.sn : 2.0f) : 0.f);
+    if (lane == 0) L.use_rows = 0;
+    if (__builtin_expect((!cn.ok || cn.sn > 8.0f * widest_child) && N < (1 << 27), 0)) {      // (the row mask rides in the id's top bits)
+      auto quad_sum = [](float v) { v += VOGE_DPP(v, 0xB1); v += VOGE_DPP(v, 0x4E); return v; };
+      auto quad_max = [](float v) { v = fmaxf(v, VOGE_DPP(v, 0xB1)); v = fmaxf(v, VOGE_DPP(v, 0x4E)); return v; };
+      auto quad_min = [](float v) { v = fminf(v, VOGE_DPP(v, 0xB1)); v = fminf(v, VOGE_DPP(v, 0x4E)); return v; };
+      static_assert(kCh == 4, "a row of super-tiles is a DPP quad");
+      const float qsx = quad_sum(present ? r.ax : 0.f), qsy = quad_sum(present ? r.ay : 0.f), qsz = quad_sum(present ? r.az : 0.f);
+      const float qn = quad_sum(present ? 1.f : 0.f);
+      const float nn = sqrtf(fmaf(qsz, qsz, fmaf(qsy, qsy, qsx * qsx)));
+      const float rax = qsx / nn, ray = qsy / nn, raz = qsz / nn;
+      float rs, rc;
+      bool rok = !present || r.ok > 0.f;
+      child_extrema(rax, ray, raz, rs, rc, rok);
+      rs = quad_max(rs); rc = quad_min(rc);
+      const float okf = quad_min(rok ? 1.f : 0.f);
+      const Cone rcn = cone_finish(rax, ray, raz, nn / fmaxf(qn, 1.f), rs, rc, okf != 0.f);
+      // (a row without super-tiles: ok = -1, nothing is kept for it)
+      if (lane < kCh * kCh && (lane & 3) == 0) L.rowc[lane >> 2] = ConeRec{rcn.ax, rcn.ay, rcn.az, rcn.cs, rcn.sn, qn > 0.f ? (rcn.ok ? 1.f : 0.f) : -1.f, 0.f, 0.f};
+      const float widest_row = wave_max((lane < kCh * kCh && qn > 0.f) ? (rcn.ok ? rcn.sn : 2.0f) : 0.f);
+      if (lane == 0) L.use_rows = (!cn.ok || cn.sn > 1.6f * widest_row) ? 1 : 0;
+    }
   }
   __syncthreads();
   const Cone rcone = load_cone(L.region);
+  const bool use_rows = L.use_rows != 0;      // (uniform)
   BIN_TS(0, 1);
 
   // ---- the slice's Gaussians: chunks of 1024 dealt round-robin to the kParts slices (so a spatially ordered
   // input, e.g. mesh vertices, still spreads evenly over the segments), kRoundChunks chunks per round ----
-  for (int j0 = part; j0 < nchunks; j0 += kParts * kRoundChunks) {
-    // (1) every candidate of the round against the region's cone; the survivors' records go to LDS in a fixed order
-    if (j0 != part) load_round(j0);
-    bool k0[kRoundChunks];
-#pragma unroll
-    for (int q = 0; q < kRoundChunks; ++q) {
-      if (writes_records && gq[q] >= 0) {
-        cull[(size_t)b * N + gq[q]] = c[q];
-        ms[(size_t)b * N + gq[q]] = make_float4(c[q].x, c[q].y, c[q].z, av[q]);
-      }
-      k0[q] = cone_keep(c[q], rcone);     // (a padding record has reach -1: never kept)
-    }
-    unsigned long long m0[kRoundChunks];
-#pragma unroll
-    for (int q = 0; q < kRoundChunks; ++q) {
-      m0[q] = __ballot(k0[q]);
-      if (lane == 0) L.cnt0[q][wave] = __popcll(m0[q]);
-    }
-    __syncthreads();
-    if (wave == 0) {     // lane <-> (chunk, wave): exclusive prefix of the 64 counts
-      static_assert(kRoundChunks * 16 == 64, "one lane per (chunk, wave)");
-      const int v = (&L.cnt0[0][0])[lane];
-      int x = v;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(x, o, 64);
-        if (lane >= o) x += y;
-      }
-      (&L.cnt0[0][0])[lane] = x - v;
-      if (lane == 63) L.nS = x;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kRoundChunks; ++q)
-      if (k0[q]) {
-        const int pos = L.cnt0[q][wave] + __popcll(m0[q] & ((1ull << lane) - 1ull));
-        L.srec[pos] = c[q];
-        L.sid[pos] = gq[q];
-      }
-    __syncthreads();
-    BIN_TS(0, 2);
-    // (2) survivors x children: wave cc walks ALL survivors against child cc's cone (in registers), four 64-survivor
-    // batches per trip.  It is the only writer of that child's segment, so its running count IS the fill position:
-    // one pass, no counters in LDS, no barrier, and the order is a pure function of the inputs.
-    const int nS = L.nS;
-    {
-      const int cc = wave;
-      const ConeRec cr = L.child[cc];
-      if (cr.ok >= 0.f) {                // (uniform) the super-tile exists
-        const Cone ck = load_cone(cr);
-        const int ccx = rx * kCh + (cc & (kCh - 1)), ccy = ry * kCh + cc / kCh;
-        const size_t seg0 = (((size_t)b * nst + ccy * nstx + ccx) * kParts + part) * kSegCap;
-        int32_t *seg = seg_id + seg0;
-        float4 *segr = seg_rec + seg0;      // (the record rides along: binB then streams it instead of gathering by id)
-        int fill = L.base[cc];
-        constexpr int kU = 4;
-        for (int s0 = 0; s0 < nS; s0 += 64 * kU) {
-          float4 r[kU];
-          int id[kU];
-#pragma unroll
-          for (int q = 0; q < kU; ++q) {
-            const int si = s0 + q * 64 + lane;
-            r[q] = (si < nS) ? L.srec[si] : make_float4(0.f, 0.f, 0.f, -1.f);
-            id[q] = (si < nS) ? L.sid[si] : -1;
-          }
-          bool kp[kU];
-#pragma unroll
-          for (int q = 0; q < kU; ++q) kp[q] = cone_keep(r[q], ck);      // (padding: reach -1, never kept)
-          const int fill0 = fill;
-#pragma unroll
-          for (int q = 0; q < kU; ++q) {
-            const unsigned long long m = __ballot(kp[q]);
-            if (kp[q]) {
-              const int pos = fill + __popcll(m & ((1ull << lane) - 1ull));
-              if (pos < kSegCap) { seg[pos] = id[q]; segr[pos] = r[q]; }
-            }
-            fill += __popcll(m);
-          }
-#ifndef VOGE_NO_SEG_EXT      // (A/B builds: no extensions -- a segment beyond kSegCap counts as overflowed)
-          if (__builtin_expect(fill > kSegCap, 0)) {      // (uniform, rare) this trip's entries beyond the inline part
-            const int need = (fill - kSegCap + kExtChunk - 1) / kExtChunk;
-            while (ext_have >= 0 && ext_have < need) {      // (uniform) one more chunk from the workgroup's arena
-              int at = 0;
-              if (lane == 0) at = atomicAdd(&L.arena_top, kExtChunk);
-              at = __builtin_amdgcn_readfirstlane(at);
-              if (ext_have < kExtChunks && at + kExtChunk <= ext_arena) {
-                if (lane == 0) L.extc[cc][ext_have] = at;
-                ++ext_have;
-              } else {
-                ext_have = -1;
-              }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (ext_have >= 0) {
-              int f = fill0;
-#pragma unroll
-              for (int q = 0; q < kU; ++q) {
-                const unsigned long long m = __ballot(kp[q]);
-                const int e = f + __popcll(m & ((1ull << lane) - 1ull)) - kSegCap;
-                if (kp[q] && e >= 0) arena[*reinterpret_cast<volatile int *>(&L.extc[cc][e / kExtChunk]) + (e % kExtChunk)] = id[q];
-                f += __popcll(m);
-              }
-            }
-          }
-#endif
+  // (two copies of the round loop, chosen once per workgroup: the stacked-rows form carries a row mask with every
+  // survivor; a frame's regions run the original code, instruction for instruction)
+  auto rounds = [&](auto rows_tag) {
+    constexpr bool ROWS = decltype(rows_tag)::value;
+    for (int j0 = part; j0 < nchunks; j0 += kParts * kRoundChunks) {
+      // (1) every candidate of the round against the region's cone; the survivors' records go to LDS in a fixed order
+      if (j0 != part) load_round(j0);
+      bool k0[kRoundChunks];
+      unsigned rowm[kRoundChunks];
+  #pragma unroll
+      for (int q = 0; q < kRoundChunks; ++q) {
+        if (writes_records && gq[q] >= 0) {
+          cull[(size_t)b * N + gq[q]] = c[q];
+          ms[(size_t)b * N + gq[q]] = make_float4(c[q].x, c[q].y, c[q].z, av[q]);
         }
-        if (lane == 0) { L.base[cc] = fill; L.extn[cc] = ext_have; }
+        k0[q] = cone_keep(c[q], rcone);     // (a padding record has reach -1: never kept)
+        rowm[q] = 0xFu;
+        if (ROWS) {      // the rows' cones instead (see above): bit g of the mask = row g can be hit
+          rowm[q] = 0u;
+  #pragma unroll
+          for (int g = 0; g < kCh; ++g) {
+            const ConeRec rr = L.rowc[g];
+            if (rr.ok >= 0.f && cone_keep(c[q], load_cone(rr))) rowm[q] |= 1u << g;
+          }
+          k0[q] = rowm[q] != 0u;
+        }
       }
+      unsigned long long m0[kRoundChunks];
+  #pragma unroll
+      for (int q = 0; q < kRoundChunks; ++q) {
+        m0[q] = __ballot(k0[q]);
+        if (lane == 0) L.cnt0[q][wave] = __popcll(m0[q]);
+      }
+      __syncthreads();
+      if (wave == 0) {     // lane <-> (chunk, wave): exclusive prefix of the 64 counts
+        static_assert(kRoundChunks * 16 == 64, "one lane per (chunk, wave)");
+        const int v = (&L.cnt0[0][0])[lane];
+        int x = v;
+  #pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int y = __shfl_up(x, o, 64);
+          if (lane >= o) x += y;
+        }
+        (&L.cnt0[0][0])[lane] = x - v;
+        if (lane == 63) L.nS = x;
+      }
+      __syncthreads();
+  #pragma unroll
+      for (int q = 0; q < kRoundChunks; ++q)
+        if (k0[q]) {
+          const int pos = L.cnt0[q][wave] + __popcll(m0[q] & ((1ull << lane) - 1ull));
+          L.srec[pos] = c[q];
+          L.sid[pos] = ROWS ? (gq[q] | (int)(rowm[q] << 27)) : gq[q];      // (ids stay below 2^27: the row mask rides in bits 27..30)
+        }
+      __syncthreads();
+      BIN_TS(0, 2);
+      // (2) survivors x children: wave cc walks ALL survivors against child cc's cone (in registers), four 64-survivor
+      // batches per trip.  It is the only writer of that child's segment, so its running count IS the fill position:
+      // one pass, no counters in LDS, no barrier, and the order is a pure function of the inputs.
+      const int nS = L.nS;
+      {
+        const int cc = wave;
+        const ConeRec cr = L.child[cc];
+        if (cr.ok >= 0.f) {                // (uniform) the super-tile exists
+          const Cone ck = load_cone(cr);
+          const int ccx = rx * kCh + (cc & (kCh - 1)), ccy = ry * kCh + cc / kCh;
+          const size_t seg0 = (((size_t)b * nst + ccy * nstx + ccx) * kParts + part) * kSegCap;
+          int32_t *seg = seg_id + seg0;
+          float4 *segr = seg_rec + seg0;      // (the record rides along: binB then streams it instead of gathering by id)
+          int fill = L.base[cc];
+          constexpr int kU = 4;
+          for (int s0 = 0; s0 < nS; s0 += 64 * kU) {
+            float4 r[kU];
+            int id[kU];
+  #pragma unroll
+            for (int q = 0; q < kU; ++q) {
+              const int si = s0 + q * 64 + lane;
+              r[q] = (si < nS) ? L.srec[si] : make_float4(0.f, 0.f, 0.f, -1.f);
+              id[q] = (si < nS) ? L.sid[si] : -1;
+            }
+            bool kp[kU];
+  #pragma unroll
+            for (int q = 0; q < kU; ++q) {
+              bool in_row = true;
+              if (ROWS) {      // (a frame's regions never carry a mask)
+                in_row = id[q] >= 0 && (((unsigned)id[q] >> (27 + (cc >> 2))) & 1u) != 0u;      // its row of super-tiles can be hit
+                id[q] = (id[q] >= 0) ? (id[q] & 0x07ffffff) : -1;
+              }
+              kp[q] = in_row && cone_keep(r[q], ck);      // (padding: reach -1, never kept)
+            }
+            const int fill0 = fill;
+  #pragma unroll
+            for (int q = 0; q < kU; ++q) {
+              const unsigned long long m = __ballot(kp[q]);
+              if (kp[q]) {
+                const int pos = fill + __popcll(m & ((1ull << lane) - 1ull));
+                if (pos < kSegCap) { seg[pos] = id[q]; segr[pos] = r[q]; }
+              }
+              fill += __popcll(m);
+            }
+  #ifndef VOGE_NO_SEG_EXT      // (A/B builds: no extensions -- a segment beyond kSegCap counts as overflowed)
+            if (__builtin_expect(fill > kSegCap, 0)) {      // (uniform, rare) this trip's entries beyond the inline part
+              const int need = (fill - kSegCap + kExtChunk - 1) / kExtChunk;
+              while (ext_have >= 0 && ext_have < need) {      // (uniform) one more chunk from the workgroup's arena
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&L.arena_top, kExtChunk);
+                at = __builtin_amdgcn_readfirstlane(at);
+                if (ext_have < kExtChunks && at + kExtChunk <= ext_arena) {
+                  if (lane == 0) L.extc[cc][ext_have] = at;
+                  ++ext_have;
+                } else {
+                  ext_have = -1;
+                }
+              }
+              __builtin_amdgcn_wave_barrier();
+              if (ext_have >= 0) {
+                int f = fill0;
+  #pragma unroll
+                for (int q = 0; q < kU; ++q) {
+                  const unsigned long long m = __ballot(kp[q]);
+                  const int e = f + __popcll(m & ((1ull << lane) - 1ull)) - kSegCap;
+                  if (kp[q] && e >= 0) arena[*reinterpret_cast<volatile int *>(&L.extc[cc][e / kExtChunk]) + (e % kExtChunk)] = id[q];
+                  f += __popcll(m);
+                }
+              }
+            }
+  #endif
+          }
+          if (lane == 0) { L.base[cc] = fill; L.extn[cc] = ext_have; }
+        }
+      }
+      BIN_TS(0, 3);
+      __syncthreads();     // srec / sid / cnt are rewritten by the next round
+      BIN_TS(0, 4);
     }
-    BIN_TS(0, 3);
-    __syncthreads();     // srec / sid / cnt are rewritten by the next round
-    BIN_TS(0, 4);
-  }
+  };
+  if (__builtin_expect(!use_rows, 1)) rounds(std::false_type{}); else rounds(std::true_type{});
   BIN_TS(0, 5);
   if (tid < kCh * kCh) {
     const int ccx = rx * kCh + (tid & (kCh - 1)), ccy = ry * kCh + tid / kCh;
