@@ -42,9 +42,10 @@ static_assert(kFbG <= 64 && (kFbGW & (kFbGW - 1)) == 0, "a group's pixels are th
 #ifdef VOGE_FB_TIMES
 constexpr int kFbTimesWaves = 1 << 16;
 __device__ unsigned long long g_fb_times[kFbTimesWaves][8];      // one row per workgroup (plain stores: no same-address atomics)
-#define FB_T0() unsigned long long fb_t_ = __builtin_readcyclecounter(), fb_acc_[6] = {0, 0, 0, 0, 0, 0}
+__device__ unsigned long long g_fb_wall[kFbTimesWaves][2];       // its first and last stamp (s_memrealtime, 100 MHz): tools/fb_wall.py
+#define FB_T0() const unsigned long long fb_w0_ = __builtin_amdgcn_s_memrealtime(); unsigned long long fb_t_ = __builtin_readcyclecounter(), fb_acc_[6] = {0, 0, 0, 0, 0, 0}
 #define FB_TICK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); fb_acc_[i] += n_ - fb_t_; fb_t_ = n_; } while (0)
-#define FB_TOUT() do { if (threadIdx.x == 0 && blockIdx.x < kFbTimesWaves) { for (int i_ = 0; i_ < 6; ++i_) g_fb_times[blockIdx.x][i_] = fb_acc_[i_]; g_fb_times[blockIdx.x][6] = 1ull; } } while (0)
+#define FB_TOUT() do { if (threadIdx.x == 0 && blockIdx.x < kFbTimesWaves) { for (int i_ = 0; i_ < 6; ++i_) g_fb_times[blockIdx.x][i_] = fb_acc_[i_]; g_fb_times[blockIdx.x][6] = 1ull; g_fb_wall[blockIdx.x][0] = fb_w0_; g_fb_wall[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define FB_T0() do {} while (0)
 #define FB_TICK(i) do {} while (0)
@@ -502,6 +503,16 @@ extern "C" int voge_debug_fb_times(unsigned long long *out, int reset) {      //
   for (int i = 0; i < 8; ++i) out[i] = 0;
   for (int w = 0; w < voge::kFbTimesWaves; ++w)
     for (int i = 0; i < 8; ++i) out[i] += host[w][i];
+  return rc;
+}
+extern "C" int voge_debug_fb_wall(unsigned long long *out /* [n][2] */, int n, int reset) {
+  static unsigned long long host[voge::kFbTimesWaves][2];
+  if (reset) {
+    for (auto &row : host) for (auto &v : row) v = 0;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(voge::g_fb_wall), host, sizeof(host));
+  }
+  const int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(voge::g_fb_wall), sizeof(host));
+  for (int w = 0; w < n && w < voge::kFbTimesWaves; ++w) { out[2 * w] = host[w][0]; out[2 * w + 1] = host[w][1]; }
   return rc;
 }
 extern "C" int voge_debug_cw_stats(unsigned long long *out, int reset) {      // out: [4] sums (composite_core.h: CW_COUNT)

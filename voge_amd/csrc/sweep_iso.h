@@ -79,7 +79,40 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   unsigned st_eval = 0;
 #endif
   const int2 slot = order[blockIdx.x];               // (tile [| kPoolFlag], length of its list | -1 = overflowed)
-  if (slot.x < 0 || slot.y == 0) return;             // outside the image | nothing can hit it: binB wrote its outputs
+  if (slot.x < 0) return;                            // outside the image
+  if (slot.y == 0) {
+    // Nothing can hit this tile: its all-sentinel outputs (ray_trace_voge.cu:244-247), 20 KB per array pair at K = 40.
+    // The renderer's form (no act / dsd kept: 31 MB per frame at cfg3) writes them HERE: these slots sit behind the loaded
+    // ones in the launch order, and their stores go out while the heavy tiles compute (binB 21.1 -> 18.6 us, this kernel
+    // + 0.3).  With act / dsd (62 MB) the sweep's own epilogues already keep HBM busy -- the same move costs this kernel
+    // 4.7 us for 4.4 saved -- and binB keeps writing them.
+    if (out_act != nullptr) return;
+    const int lin0 = slot.x & ~kPoolFlag;      // (an empty tile of a pooled quad carries the flag too)
+    const int b = lin0 / tiles_per_img, bx = lin0 - b * tiles_per_img;
+    const int ftx = bx % tiles_x, fty = bx / tiles_x;
+    const int tw = min(8, W - ftx * 8), th = min(8, H - fty * 8);
+    const int row_items = tw * K;
+    if ((K & 3) == 0) {
+      const int ipr = row_items >> 2;
+      for (int it = lane; it < th * ipr; it += 64) {
+        const int rr = it / ipr, j4 = it - rr * ipr;
+        const size_t o = (((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8) * K + (size_t)j4 * 4;
+        *reinterpret_cast<int4 *>(out_idx + o) = make_int4(-1, -1, -1, -1);
+        *reinterpret_cast<float4 *>(out_len + o) = make_float4(VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN);
+      }
+    } else {
+      for (int it = lane; it < th * row_items; it += 64) {
+        const int rr = it / row_items, j = it - rr * row_items;
+        const size_t o = (((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8) * K + j;
+        out_idx[o] = -1; out_len[o] = VOGE_SENT_LEN;
+      }
+    }
+    if (out_cnt != nullptr) {
+      const int rr = lane >> 3, x = lane & 7;
+      if (rr < th && x < tw) out_cnt[((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8 + x] = 0;
+    }
+    return;
+  }
   const bool pooled = (slot.x & kPoolFlag) != 0;
   const int lin = slot.x & ~kPoolFlag;
   const int b = lin / tiles_per_img, bx = lin - b * tiles_per_img;

@@ -1153,7 +1153,8 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   // workgroup: 40 KB per tile at K = 40, 62 MB per frame at cfg3 -- HBM-write-bound wherever it happens.  The
   // quads with empty tiles are the ones with short lists, i.e. the workgroups that would otherwise finish long
   // before the kernel does; the sweep (a few waves per CU, latency-bound) never sees these tiles.
-  for (int w = 0; w < kTilesPerQuad; ++w) {
+  // (out_idx == NULL: the sweep that follows writes them itself -- sweep_iso_kernel without act / dsd, see there)
+  for (int w = 0; w < kTilesPerQuad && out_idx != nullptr; ++w) {
     if (L.wsum[w] != 0) continue;      // uniform
     const int ftx = stx * (kST / 8) + (qq & 1) * 2 + (w & 1), fty = sty * (kST / 8) + (qq >> 1) * 2 + (w >> 1);
     const int tw = min(8, W - ftx * 8), th = min(8, H - fty * 8);

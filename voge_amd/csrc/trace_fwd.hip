@@ -1156,8 +1156,9 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
   }
   hipLaunchKernelGGL(binB_kernel<!ISO>, dim3(ws.nstx * ws.nsty * 4, B), dim3(kQT), 0, st, ws.cull, ws.ell, ws.seg_count, ws.seg_id, ws.seg_rec,
                      rays, N, H, W, ws.nstx, ws.nsty, ws.nbin, ws.q_count, ws.q_id, ws.q_lb, ws.tl_count, ws.tl_id, ws.tl_lb,
-                     ws.order, ws.pool_top, ws.pool_cap, ws.pool_id, ws.pool_lb, ws.tl_off, ws.seg_ext, ws.ext_id, K, idx, len, act, dsd,
-                     cnt, weight, valid_num);
+                     ws.order, ws.pool_top, ws.pool_cap, ws.pool_id, ws.pool_lb, ws.tl_off, ws.seg_ext, ws.ext_id, K,
+                     (v2 && act == nullptr) ? nullptr : idx /* (sweep_iso_kernel writes the empty tiles itself) */, len, act, dsd, cnt,
+                     weight, valid_num);
   {
     int rc = launch_status();
     if (rc) return rc;
