@@ -25,14 +25,28 @@ renderer = GaussianRenderer(cams, settings).to(dev)
 lib = _lib.load()
 out = (ctypes.c_ulonglong * 16)()
 ctypes.CDLL(_lib.LIB_PATH).voge_debug_sweep_stats(out)
+FULL = bool(os.environ.get("FULL"))      # FULL=1: the stand-alone trace entry point (idx, len, act, dsd) instead of the renderer's
+if FULL:
+    import math
+    from voge_amd import ops
+    from oracle import camera_np
+    Rn, Tn = camera_np.look_at_view_transform([dd], [el], [az])
+    rays_np, origin = camera_np.pixel_rays(Rn, Tn, focal, pp, (H, W))
+    mus_t = torch.from_numpy((verts - origin[0].astype("float32")).astype("float32")).to(dev)
+    a_t = torch.from_numpy((2 * sig).astype("float32")).to(dev)
+    rays_t = torch.from_numpy(rays_np.astype("float32")).to(dev)
+    thr_act = -math.log(0.01 + 1e-10)
+    run = lambda: ops._RayTraceVoGEIso.apply(mus_t, a_t, rays_t, None, thr_act, K)
+else:
+    run = lambda: renderer(gm, R=R, T=T)
 with torch.no_grad():
     for _ in range(3):
-        frag = renderer(gm, R=R, T=T)
+        frag = run()
     torch.cuda.synchronize()
     ctypes.CDLL(_lib.LIB_PATH).voge_debug_sweep_stats(out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    frag = renderer(gm, R=R, T=T)
+    frag = run()
     e1.record()
 torch.cuda.synchronize()
 print('renderer forward (events) us', e0.elapsed_time(e1) * 1000)
