@@ -32,6 +32,11 @@ loss.backward()
 torch.cuda.synchronize()
 raw.voge_debug_fb_wall(buf, nw, 0)
 t = np.array(list(buf), dtype=np.float64).reshape(nw, 2) * 0.01      # us
+import os
+if os.environ.get("DUMP"):      # per-group stamps + the hit counts: the input of tools/fb_order_sim.py
+    with torch.no_grad():
+        cnt = renderer(gm, R=R, T=T).valid_num.reshape(H, W).to(torch.int16).cpu().numpy()
+    np.savez_compressed(os.environ["DUMP"], t=np.where(t > 0, t - t[t[:, 0] > 0, 0].min(), -1.0).astype(np.float32), cnt=cnt, H=H, W=W, K=K)
 ran = t[:, 0] > 0
 t = t[ran]
 t0 = t[:, 0].min()
