@@ -85,3 +85,23 @@ h, edges = np.histogram((end[ran] - t0) * tick, bins=10)
 print("end-time histogram (us):", [(round(float(a), 1), int(b)) for a, b in zip(edges[:-1], h)])
 h, edges = np.histogram(tot, bins=10)
 print("tile-duration histogram (us):", [(round(float(a), 1), int(b)) for a, b in zip(edges[:-1], h)])
+# candidates evaluated per tile (the low word of stamp 6) against its duration and the hits its rays kept
+evs = (ev.astype(np.uint64) & np.uint64(0xffffffff)).astype(np.float64)
+vn = (frag.valid_num if not FULL else (frag[0] >= 0).sum(-1)).reshape(H, W).float().cpu().numpy()
+ty, tx = (H + 7) // 8, (W + 7) // 8
+padv = np.zeros((ty * 8, tx * 8)); padv[:H, :W] = vn
+kept = padv.reshape(ty, 8, tx, 8).transpose(0, 2, 1, 3).reshape(ty * tx, 64).sum(1)[:nwg]
+e, k = evs[ran], kept[ran]
+cons_us = cons[ran] * tick
+print(f"evaluated candidates per swept tile: mean {e.mean():.0f}, max {e.max():.0f}; kept hits per tile: mean {k.mean():.0f} (64 K = {64 * K})")
+print(f"consume time per evaluated candidate: mean {1e3 * cons_us.sum() / e.sum():.0f} ns; correlation duration~evaluated {np.corrcoef(tot, e)[0, 1]:.3f}")
+print(f"kept hits / (64 x evaluated): {k.sum() / (64 * e.sum()):.2f} overall; the 200 longest tiles {k[np.argsort(-tot)[:200]].sum() / (64 * e[np.argsort(-tot)[:200]].sum()):.2f}")
+for i in np.argsort(-tot)[:6]:
+    print(f"   tile total {tot[i]:.1f} us: evaluated {e[i]:.0f}, kept {k[i]:.0f}, consume {cons_us[i]:.1f} us = {1e3 * cons_us[i] / max(e[i], 1):.0f} ns per candidate")
+if os.environ.get("SLOW"):      # build with -DVOGE_SWEEP_SLOW: stamp 7 = ticks inside the list insertions << 32 | candidates that needed one
+    s7 = t[:, 7].astype(np.uint64)
+    nslow = (s7 & np.uint64(0xffffffff)).astype(np.float64)[ran]
+    tslow = (s7 >> np.uint64(32)).astype(np.float64)[ran] * tick
+    print(f"candidates with an insertion (any lane): {nslow.sum() / e.sum():.2f} of the evaluated; time inside: {tslow.sum() / cons_us.sum():.2f} of the consume phase")
+    for i in np.argsort(-tot)[:6]:
+        print(f"   tile total {tot[i]:.1f} us: evaluated {e[i]:.0f}, with an insertion {nslow[i]:.0f}, inside them {tslow[i]:.1f} us of {cons_us[i]:.1f}")

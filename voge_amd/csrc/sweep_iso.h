@@ -77,6 +77,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   const unsigned long long ts0 = wall_clock64();
   unsigned long long ts_fill = 0, ts_cons = 0, ts1 = 0, ts2 = 0;
   unsigned st_eval = 0;
+  unsigned long long ts_slow = 0; unsigned st_slow = 0;
 #endif
   const int2 slot = order[blockIdx.x];               // (tile [| kPoolFlag], length of its list | -1 = overflowed)
   if (slot.x < 0) return;                            // outside the image
@@ -204,8 +205,8 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       int pos = full ? K - 1 : cnt;
       float new_tail = len;      // (full lists) what ends up in row K - 1
       bool first = true;
-      while (pos > 0) {
-        const float pl = len_at(pos - 1);
+      while (pos > 0) {      // (four rows per trip with their eight LDS reads in flight together: 0.66 instead of 0.5 us per
+        const float pl = len_at(pos - 1);      //  insertion -- the walks are short, the cost is this block's fixed overhead)
         if (key_le(pl, pos - 1)) break;
         if (first) new_tail = pl;
         put(pos, pl, pos_at(pos - 1));
@@ -234,7 +235,13 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       // predicted-not-taken branch: a divergent `if` is a taken skip-branch for every candidate nobody needs it for.
       const bool slow = take & !app;
       if (__builtin_expect(__ballot(slow) != 0ull, 0)) {
+#ifdef VOGE_SWEEP_SLOW      // (-DVOGE_SWEEP_TIMES -DVOGE_SWEEP_SLOW: stamp 7 = time in the insertions << 32 | their number)
+        const unsigned long long tss = wall_clock64();
+#endif
         if (slow) slow_insert(len, p);
+#ifdef VOGE_SWEEP_SLOW
+        ts_slow += wall_clock64() - tss; ++st_slow;
+#endif
       }
     };
 
@@ -576,8 +583,12 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   if (lane == 0 && b == 0 && bx < 8192) {
     unsigned long long *o = g_sweep_times + 8 * (size_t)bx;
     o[0] = ts0; o[1] = ts1; o[2] = ts_fill; o[3] = ts_cons; o[4] = ts2; o[5] = wall_clock64(); o[6] = ((unsigned long long)blockIdx.x << 32) | st_eval;
+#ifdef VOGE_SWEEP_SLOW
+    o[7] = (ts_slow << 32) | st_slow;
+#else
     o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |      // HW_ID
            ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);      // XCC_ID
+#endif
   }
 #endif
 }
