@@ -5,7 +5,10 @@ from voge_amd.Meshes import GaussianMeshes
 from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, to_white_background
 from voge_amd.cameras import PerspectiveCameras, look_at_view_transform
 dev = torch.device("cuda", 0)
+import os
 N, (H, W), K, focal, pp, (dd, el, az) = scenes.CONFIGS["cfg3_50k_512"]
+if os.environ.get("TINY"):      # TINY=1: 64 Gaussians on 16x16 pixels -- the GPU work vanishes, what is left is the host's cost per frame
+    N, (H, W), focal, pp = 64, (16, 16), 20.0, (8.0, 8.0)
 verts, sig, cols = scenes.random_gaussians(N, seed=0)
 gm = GaussianMeshes(torch.from_numpy(verts), torch.from_numpy(sig)).to(dev)
 colors = torch.from_numpy(cols).to(dev).requires_grad_(True)
@@ -25,4 +28,5 @@ print("host per step %.3f ms, total %.3f ms"%((t1-t0)/50*1e3,(t2-t0)/50*1e3))
 pr=cProfile.Profile(); pr.enable()
 for _ in range(50): step()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(25)
