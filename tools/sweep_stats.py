@@ -105,3 +105,9 @@ if os.environ.get("SLOW"):      # build with -DVOGE_SWEEP_SLOW: stamp 7 = ticks 
     print(f"candidates with an insertion (any lane): {nslow.sum() / e.sum():.2f} of the evaluated; time inside: {tslow.sum() / cons_us.sum():.2f} of the consume phase")
     for i in np.argsort(-tot)[:6]:
         print(f"   tile total {tot[i]:.1f} us: evaluated {e[i]:.0f}, with an insertion {nslow[i]:.0f}, inside them {tslow[i]:.1f} us of {cons_us[i]:.1f}")
+    s2 = t[:, 2].astype(np.uint64)[ran]
+    lanes, moved, far = (s2 & np.uint64(0xffffffff)).astype(float), ((s2 >> np.uint64(32)) & np.uint64(0xffff)).astype(float), (s2 >> np.uint64(48)).astype(float)
+    print(f"per insertion event: {lanes.sum() / max(nslow.sum(), 1):.1f} lanes insert, the longest walk among them {moved.sum() / max(nslow.sum(), 1):.1f} rows on average; "
+          f"events with a walk of 4+ rows: {far.sum() / max(nslow.sum(), 1):.2f}")
+    for i in np.argsort(-tot)[:6]:
+        print(f"   tile total {tot[i]:.1f} us: events {nslow[i]:.0f}, lanes per event {lanes[i] / max(nslow[i], 1):.1f}, longest walk per event {moved[i] / max(nslow[i], 1):.1f}, far events {far[i]:.0f}")

@@ -77,7 +77,8 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   const unsigned long long ts0 = wall_clock64();
   unsigned long long ts_fill = 0, ts_cons = 0, ts1 = 0, ts2 = 0;
   unsigned st_eval = 0;
-  unsigned long long ts_slow = 0; unsigned st_slow = 0;
+  unsigned long long ts_slow = 0; unsigned st_slow = 0, st_lanes = 0, st_moved = 0, st_far = 0;
+  int dbg_moved = 0;
 #endif
   const int2 slot = order[blockIdx.x];               // (tile [| kPoolFlag], length of its list | -1 = overflowed)
   if (slot.x < 0) return;                            // outside the image
@@ -214,6 +215,9 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
         --pos;
       }
       put(pos, len, p);
+#ifdef VOGE_SWEEP_SLOW
+      dbg_moved = (full ? K - 1 : cnt) - pos;
+#endif
       if (full) {
         tailf = new_tail;
         worstf = new_tail;
@@ -221,6 +225,31 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
         if (pos == cnt) tailf = len;      // (a tie with the tail and the larger id: still the last entry)
         if (++cnt == K) worstf = tailf;
       }
+    };
+    // The insertion as it nearly always is (tools/sweep_stats.py SLOW=1: 14 lanes per event, the longest walk among them one
+    // row on average, never four): the new entry lands zero, one or two rows below the top, every comparison that places it
+    // strict.  Straight-line: five LDS reads in flight together, at most three row writes.  Anything else -- a len tie (the
+    // id rule), a longer walk -- returns false and takes slow_insert.  (slow_insert alone cost 0.5 us per event in fixed
+    // overhead: 8-14 events and 5-7 of the 27 us of a heavy tile's candidate loop at cfg3.)
+    auto lean_insert = [&](const float len, const unsigned p, const bool slow, const int Kv) -> bool {
+      // (branch-free: every lane of the wave runs it, `slow` selects who really writes -- the others hit the spare row)
+      const bool full = (cnt == K);
+      const int top = full ? Kv - 1 : cnt;      // the row the entry takes if nothing moves (a full list drops its row K - 1)
+      const int r1 = max(top - 1, 0), r2 = max(top - 2, 0), r3 = max(top - 3, 0);
+      float l1 = len_at(r1), l2 = len_at(r2), l3 = len_at(r3);
+      const unsigned h1 = pos_at(r1), h2 = pos_at(r2);
+      l1 = (top >= 1) ? l1 : -INFINITY; l2 = (top >= 2) ? l2 : -INFINITY; l3 = (top >= 3) ? l3 : -INFINITY;
+      const bool g1 = l1 > len, g2 = g1 & (l2 > len);
+      const float below = g2 ? l3 : (g1 ? l2 : l1);      // the entry the new one comes to rest on
+      const bool ok = slow & (below < len) & !(full & (len == worstf));
+      const int n = (g1 ? 1 : 0) + (g2 ? 1 : 0);      // rows that move up
+      put((ok & g1) ? top : Kv, l1, h1);
+      put((ok & g2) ? top - 1 : Kv, l2, h2);
+      put(ok ? top - n : Kv, len, p);
+      tailf = ok ? (g1 ? l1 : len) : tailf;              // (a list that is not full: n >= 1 and l1 is its tail already)
+      cnt += (ok & !full) ? 1 : 0;
+      worstf = (ok & (cnt == K)) ? tailf : worstf;      // (full before, or filled by this entry)
+      return slow & !ok;
     };
     int Kv = K;
     asm volatile("" : "+v"(Kv));      // (K in a VGPR for good: the compiler re-materialised it from its SGPR in front of every select)
@@ -238,9 +267,21 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 #ifdef VOGE_SWEEP_SLOW      // (-DVOGE_SWEEP_TIMES -DVOGE_SWEEP_SLOW: stamp 7 = time in the insertions << 32 | their number)
         const unsigned long long tss = wall_clock64();
 #endif
-        if (slow) slow_insert(len, p);
+#ifdef VOGE_SWEEP_SLOW
+        dbg_moved = 0;
+#endif
+        const bool hard = lean_insert(len, p, slow, Kv);
+        if (__builtin_expect(__ballot(hard) != 0ull, 0)) {
+          if (hard) slow_insert(len, p);
+        }
 #ifdef VOGE_SWEEP_SLOW
         ts_slow += wall_clock64() - tss; ++st_slow;
+        {      // (per event: lanes inserting, the longest walk among them)
+          const int nl = __popcll(__ballot(slow));
+          int mx = slow ? dbg_moved : 0;
+          for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+          st_lanes += nl; st_moved += mx; st_far += (mx >= 4) ? 1 : 0;
+        }
 #endif
       }
     };
@@ -585,6 +626,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
     o[0] = ts0; o[1] = ts1; o[2] = ts_fill; o[3] = ts_cons; o[4] = ts2; o[5] = wall_clock64(); o[6] = ((unsigned long long)blockIdx.x << 32) | st_eval;
 #ifdef VOGE_SWEEP_SLOW
     o[7] = (ts_slow << 32) | st_slow;
+    o[2] = ((unsigned long long)st_far << 48) | ((unsigned long long)(st_moved & 0xffffu) << 32) | st_lanes;      // (instead of the fill time)
 #else
     o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |      // HW_ID
            ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);      // XCC_ID
