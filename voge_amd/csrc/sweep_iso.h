@@ -481,6 +481,11 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       const size_t tile_pix = ((size_t)b * H + ty * 8 + row0) * W + (size_t)tx * 8;      // the pass's first pixel
       int32_t *const t_idx = out_idx + tile_pix * K;
       float *const t_len = out_len + tile_pix * K;
+      // Branch-free inside a batch: every load is unconditional (an item beyond the pass re-reads item 0, a slot beyond the
+      // pixel's count reads its stale LDS row and a valid dummy record) and selects keep what counts.  The `if (q < count)`
+      // form compiled into one exec-mask region per slot and load: hundreds of scalar instructions and branches per batch,
+      // 4.7 us of a heavy tile (10-13 us with act / dsd).
+      const unsigned h_last = (unsigned)max(src_n - 1, 0);
       for (int it0 = lane; it0 < nitem; it0 += 64 * kEpiB) {
         int32_t oi[kEpiB][4];
         float ol[kEpiB][4];
@@ -489,31 +494,39 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 #pragma unroll
         for (int u = 0; u < kEpiB; ++u) {
           const int it = it0 + u * 64;
-          nv[u] = -1; rel[u] = 0;
+          const bool in = it < nitem;
+          const int itc = in ? it : 0;
+          const int rr = __float2int_rz(((float)itc + 0.5f) * inv_ipr);
+          const int j = (itc - rr * ipr) * 4;
+          const int x = __float2int_rz(((float)j + 0.5f) * invK);
+          const int sl = j - x * K;
+          const int owner = rr * 8 + x;
+          rel[u] = (unsigned)(rr * W + x) * (unsigned)K + (unsigned)sl;
+          nv[u] = in ? max(0, min(4, S.cnt[owner] - sl)) : -1;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { oi[u][q] = -1; ol[u][q] = VOGE_SENT_LEN; }
-          if (it < nitem) {
-            const int rr = __float2int_rz(((float)it + 0.5f) * inv_ipr);
-            const int j = (it - rr * ipr) * 4;
-            const int x = __float2int_rz(((float)j + 0.5f) * invK);
-            const int sl = j - x * K;
-            const int owner = rr * 8 + x;
-            rel[u] = (unsigned)(rr * W + x) * (unsigned)K + (unsigned)sl;
-            nv[u] = max(0, min(4, S.cnt[owner] - sl));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              if (q < nv[u]) {
-                ol[u][q] = Llen[(sl + q) * kS2TP + owner];
-                oi[u][q] = (int)entry_pos(sl + q, owner);      // (the position; the id follows)
-              }
-            }
+          for (int q = 0; q < 4; ++q) {
+            const float l = Llen[(sl + q) * kS2TP + owner];
+            const unsigned h = entry_pos(sl + q, owner);      // (the position; the id follows)
+            ol[u][q] = (q < nv[u]) ? l : VOGE_SENT_LEN;
+            oi[u][q] = (int)h;
           }
         }
+        if (h_is_id) {      // (uniform)
 #pragma unroll
-        for (int u = 0; u < kEpiB; ++u)
+          for (int u = 0; u < kEpiB; ++u)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q < nv[u]) oi[u][q] = id_of((unsigned)oi[u][q]) + gofs;
+            for (int q = 0; q < 4; ++q) oi[u][q] = (q < nv[u]) ? oi[u][q] + gofs : -1;
+        } else {
+          int idv[kEpiB][4];
+#pragma unroll
+          for (int u = 0; u < kEpiB; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) idv[u][q] = src_id[min((unsigned)oi[u][q], h_last)];
+#pragma unroll
+          for (int u = 0; u < kEpiB; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) oi[u][q] = (q < nv[u]) ? idv[u][q] + gofs : -1;
+        }
         if (!want_ad) {
 #pragma unroll
           for (int u = 0; u < kEpiB; ++u) {
@@ -530,32 +543,26 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 #pragma unroll
             for (int v = 0; v < kEpiR; ++v) {
               const int u = u0 + v;
-              ex[v] = ey[v] = ez[v] = 0.f;
+              if (u >= kEpiB) continue;      // (compile time)
+              const unsigned pr = rel[u] / (unsigned)K;      // pixel offset (rr W + x)
+              const float *ry = rays + (tile_pix + pr) * 3;
+              ex[v] = ry[0]; ey[v] = ry[1]; ez[v] = ry[2];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) rec[v][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (u < kEpiB && nv[u] > 0) {
-                const unsigned pr = rel[u] / (unsigned)K;      // pixel offset (rr W + x)
-                const float *ry = rays + (tile_pix + pr) * 3;
-                ex[v] = ry[0]; ey[v] = ry[1]; ez[v] = ry[2];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                  if (q < nv[u]) rec[v][q] = ms[oi[u][q]];
-              }
+              for (int q = 0; q < 4; ++q) rec[v][q] = ms[(q < nv[u]) ? oi[u][q] : gofs];
             }
 #pragma unroll
             for (int v = 0; v < kEpiR; ++v) {
               const int u = u0 + v;
-              if (u >= kEpiB || nv[u] < 0) continue;
+              if (u >= kEpiB) continue;      // (compile time)
               float oa[4], od[4];
               const float dn2 = (ex[v] * ex[v] + ey[v] * ey[v]) + ez[v] * ez[v];
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                oa[q] = VOGE_SENT_ACT; od[q] = 0.0f;
-                if (q < nv[u]) {
-                  const PairOut o = pair_eval_iso_at(rec[v][q].x, rec[v][q].y, rec[v][q].z, rec[v][q].w, ol[u][q], ex[v], ey[v], ez[v], dn2);
-                  oa[q] = o.act; od[q] = o.dsd;
-                }
+                const PairOut o = pair_eval_iso_at(rec[v][q].x, rec[v][q].y, rec[v][q].z, rec[v][q].w, ol[u][q], ex[v], ey[v], ez[v], dn2);
+                oa[q] = (q < nv[u]) ? o.act : VOGE_SENT_ACT;
+                od[q] = (q < nv[u]) ? o.dsd : 0.0f;
               }
+              if (nv[u] < 0) continue;
               *reinterpret_cast<int4 *>(t_idx + rel[u]) = make_int4(oi[u][0], oi[u][1], oi[u][2], oi[u][3]);
               *reinterpret_cast<float4 *>(t_len + rel[u]) = make_float4(ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
               *reinterpret_cast<float4 *>(t_act + rel[u]) = make_float4(oa[0], oa[1], oa[2], oa[3]);
