@@ -43,6 +43,8 @@ torch.cuda.synchronize()
 raw.voge_debug_fb_times(out, 1)
 cw = (ctypes.c_ulonglong * 4)()
 raw.voge_debug_cw_stats(cw, 1)
+tab = (ctypes.c_ulonglong * 4)()
+raw.voge_debug_fb_tab(tab, 1)
 loss = frame()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -61,3 +63,6 @@ for i, nm in enumerate(names):
 raw.voge_debug_cw_stats(cw, 0)
 print(f"  window loops: row loops {cw[0] // 64} wave-iterations, {100.0 * cw[1] / max(cw[0], 1):.1f} % of lanes active; "
       f"column loops {cw[2] // 64} wave-iterations, {100.0 * cw[3] / max(cw[2], 1):.1f} % of lanes active")
+raw.voge_debug_fb_tab(tab, 0)
+print(f"  table: {tab[0]} wave-wide accumulations, {tab[1] / max(tab[0], 1):.2f} election rounds each, {tab[2] / max(tab[0], 1):.1f} lanes taking part "
+      f"({tab[2] / max(tab[1], 1):.1f} lanes served per round)")

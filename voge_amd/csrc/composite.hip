@@ -463,14 +463,15 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
       for (int a = 0; a < NS; ++a)
 #pragma unroll
         for (int r = 0; r < (GEN ? 3 : 1); ++r)
-          rc[a][r] = (k0 + a < lead) ? at_bytes<float4>(rec, (uint32_t)iv[a] * (GEN ? 48u : 16u) + 16u * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+          rc[a][r] = at_bytes<float4>(rec, (uint32_t)max(iv[a], 0) * (GEN ? 48u : 16u) + 16u * r);      // (a slot beyond the count: record 0, selected out below -- no exec-mask region per slot)
       if (SC > 0) {
 #pragma unroll
         for (int a = 0; a < NS; ++a) ivk[a] = (k0 + a < lead) ? iv[a] : -1;
       }
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
-        if (k0 + a < lead) {
+        if (GEN && !(k0 + a < lead)) continue;
+        {
           PairOut o;
           if (GEN) {
             const float4 r0 = rc[a][0], r1 = rc[a][GEN ? 1 : 0], r2 = rc[a][GEN ? 2 : 0];
@@ -483,7 +484,8 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
           } else {
             o = pair_eval_iso_at(rc[a][0].x, rc[a][0].y, rc[a][0].z, rc[a][0].w, lv[a], d.x, d.y, d.z, dn2);
           }
-          em[a] = FAST_EXP(-o.act); lm[a] = lv[a]; sm[a] = FAST_SQRT(o.dsd + 1e-10f);
+          const bool lv_on = GEN || (k0 + a < lead);      // (scalar sigmas: evaluated for every slot, kept for the live ones)
+          em[a] = lv_on ? FAST_EXP(-o.act) : 0.0f; lm[a] = lv_on ? lv[a] : VOGE_SENT_LEN; sm[a] = lv_on ? FAST_SQRT(o.dsd + 1e-10f) : 1e-5f;
         }
       }
     }
@@ -612,16 +614,23 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
         const int p2 = ivk[a];
-        if (p2 >= 0 && p2 < sh.Nattr && w[a] != 0.0f) {
-          const uint32_t o = (uint32_t)p2 * (uint32_t)(4 * SC);      // (bytes; Nattr * SC < 2^30: host)
+        if (SC == 3 || SC == 4) {
+          // (no exec-mask region per slot: a slot that contributes nothing reads colour row 0 and multiplies a zero; the
+          //  row is selected to zero first, so a non-finite colour there cannot leak)
+          const bool on = p2 >= 0 && p2 < sh.Nattr && w[a] != 0.0f;
+          const uint32_t o = (uint32_t)(on ? p2 : 0) * (uint32_t)(4 * SC);      // (bytes; Nattr * SC < 2^30: host)
           if (SC == 3) {
             const float3 v = at_bytes<float3>(sh.colors, o);
-            part[0] = fmaf(w[a], v.x, part[0]); part[1] = fmaf(w[a], v.y, part[1]); part[2] = fmaf(w[a], v.z, part[2]);
-          } else if (SC == 4) {
-            const float4 v = at_bytes<float4>(sh.colors, o);
-            part[0] = fmaf(w[a], v.x, part[0]); part[1] = fmaf(w[a], v.y, part[1]); part[2] = fmaf(w[a], v.z, part[2]);
-            part[SC - 1] = fmaf(w[a], v.w, part[SC - 1]);
+            part[0] = fmaf(w[a], on ? v.x : 0.0f, part[0]); part[1] = fmaf(w[a], on ? v.y : 0.0f, part[1]);
+            part[2] = fmaf(w[a], on ? v.z : 0.0f, part[2]);
           } else {
+            const float4 v = at_bytes<float4>(sh.colors, o);
+            part[0] = fmaf(w[a], on ? v.x : 0.0f, part[0]); part[1] = fmaf(w[a], on ? v.y : 0.0f, part[1]);
+            part[2] = fmaf(w[a], on ? v.z : 0.0f, part[2]); part[SC - 1] = fmaf(w[a], on ? v.w : 0.0f, part[SC - 1]);
+          }
+        } else if (p2 >= 0 && p2 < sh.Nattr && w[a] != 0.0f) {
+          const uint32_t o = (uint32_t)p2 * (uint32_t)(4 * SC);
+          {
 #pragma unroll
             for (int c = 0; c < SC; ++c) part[c] = fmaf(w[a], at_bytes<float>(sh.colors, o + 4u * c), part[c]);
           }

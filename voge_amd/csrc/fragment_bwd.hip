@@ -42,6 +42,7 @@ static_assert(kFbG <= 64 && (kFbGW & (kFbGW - 1)) == 0, "a group's pixels are th
 #ifdef VOGE_FB_TIMES
 constexpr int kFbTimesWaves = 1 << 16;
 __device__ unsigned long long g_fb_times[kFbTimesWaves][8];      // one row per workgroup (plain stores: no same-address atomics)
+__device__ unsigned long long g_fb_tab[kFbTimesWaves][4];       // accumulations (wave-wide calls), their election rounds, lanes taking part
 __device__ unsigned long long g_fb_wall[kFbTimesWaves][2];       // its first and last stamp (s_memrealtime, 100 MHz): tools/fb_wall.py
 #define FB_T0() const unsigned long long fb_w0_ = __builtin_amdgcn_s_memrealtime(); unsigned long long fb_t_ = __builtin_readcyclecounter(), fb_acc_[6] = {0, 0, 0, 0, 0, 0}
 #define FB_TICK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); fb_acc_[i] += n_ - fb_t_; fb_t_ = n_; } while (0)
@@ -387,6 +388,22 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
       continue;
 #endif
       const int slot = wt_find(L.tab, id[a], go);
+#ifdef VOGE_FB_TIMES      // (election rounds per accumulation: tools/fb_sections.py)
+      {
+        volatile int *owner = L.tab.owner;
+        bool pending = go && slot >= 0;
+        const unsigned long long m0 = __ballot(pending);
+        unsigned rounds = 0;
+        while (__any(pending)) {
+          if (pending) owner[slot] = lane;
+          if (pending && owner[slot] == lane) pending = false;
+          ++rounds;
+        }
+        if (lane == 0 && blockIdx.x < kFbTimesWaves) {
+          g_fb_tab[blockIdx.x][0] += 1; g_fb_tab[blockIdx.x][1] += rounds; g_fb_tab[blockIdx.x][2] += (unsigned)__popcll(m0);
+        }
+      }
+#endif
       wt_add(L.tab, slot, val, go && slot >= 0, lane);
       if (go && slot < 0) {         // table full: rare, straight to memory
 #pragma unroll
@@ -503,6 +520,18 @@ extern "C" int voge_debug_fb_times(unsigned long long *out, int reset) {      //
   for (int i = 0; i < 8; ++i) out[i] = 0;
   for (int w = 0; w < voge::kFbTimesWaves; ++w)
     for (int i = 0; i < 8; ++i) out[i] += host[w][i];
+  return rc;
+}
+extern "C" int voge_debug_fb_tab(unsigned long long *out /* [4] sums */, int reset) {
+  static unsigned long long host[voge::kFbTimesWaves][4];
+  if (reset) {
+    for (auto &row : host) for (auto &v : row) v = 0;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(voge::g_fb_tab), host, sizeof(host));
+  }
+  const int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(voge::g_fb_tab), sizeof(host));
+  for (int i = 0; i < 4; ++i) out[i] = 0;
+  for (int w = 0; w < voge::kFbTimesWaves; ++w)
+    for (int i = 0; i < 4; ++i) out[i] += host[w][i];
   return rc;
 }
 extern "C" int voge_debug_fb_wall(unsigned long long *out /* [n][2] */, int n, int reset) {
