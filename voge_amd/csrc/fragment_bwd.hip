@@ -70,6 +70,9 @@ struct FragBwdLds {
 #ifndef VOGE_FB_LDS_RMAX
 #define VOGE_FB_LDS_RMAX 1
 #endif
+#ifndef VOGE_FB_PAIR_TABLE
+#define VOGE_FB_PAIR_TABLE 1      // scalar sigmas: a lane's two table accumulations share one election loop (wt_add2)
+#endif
 #ifndef VOGE_FB_WPE
 #define VOGE_FB_WPE 4      // capping the registers for 5 / 6 waves per SIMD spills and is slower
 #endif
@@ -322,6 +325,10 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
                                                      : make_float4(0.f, 0.f, 0.f, 0.f);   // (P < 2^26: host)
     const float dn2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float idn = __builtin_amdgcn_rcpf(dn2);
+    // (scalar sigmas, two slots per lane: both slots' terms first, then ONE election loop for both -- wt_add2)
+    constexpr bool PAIR = ISO && NS == 2 && VOGE_FB_PAIR_TABLE;
+    float4 valp[PAIR ? 2 : 1][NV4];
+    bool gop[2] = {false, false};
 #pragma unroll
     for (int a = 0; a < NS; ++a) {
       float4 val[NV4];
@@ -381,6 +388,12 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
 #pragma unroll
         for (int r = 0; r < NV4; ++r) go = go || (val[r].x != 0.f || val[r].y != 0.f || val[r].z != 0.f || val[r].w != 0.f);
       }
+      if (PAIR) {
+#pragma unroll
+        for (int r = 0; r < NV4; ++r) valp[PAIR ? a : 0][r] = val[r];
+        gop[a] = go;
+        continue;
+      }
       if (!__any(go)) continue;     // uniform
       FB_TICK(3);
 #if VOGE_FB_ABL & 1       // (timing experiment: no table, nothing accumulated)
@@ -411,6 +424,25 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
           const float o[4] = {val[r].x, val[r].y, val[r].z, val[r].w};
 #pragma unroll
           for (int c = 0; c < 4; ++c) unsafeAtomicAdd(acc + NACC * (size_t)id[a] + 4 * r + c, o[c]);
+        }
+      }
+      FB_TICK(4);
+    }
+    if (PAIR && __any(gop[0] | gop[1])) {
+      FB_TICK(3);
+      const int slot0 = wt_find(L.tab, id[0], gop[0]);
+      const int slot1 = wt_find(L.tab, id[NS - 1], gop[1]);
+      wt_add2(L.tab, slot0, valp[0], gop[0] && slot0 >= 0, slot1, valp[PAIR ? 1 : 0], gop[1] && slot1 >= 0, lane);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int sl = a == 0 ? slot0 : slot1;
+        if (gop[a] && sl < 0) {         // table full: rare, straight to memory
+#pragma unroll
+          for (int r = 0; r < NV4; ++r) {
+            const float o[4] = {valp[PAIR ? a : 0][r].x, valp[PAIR ? a : 0][r].y, valp[PAIR ? a : 0][r].z, valp[PAIR ? a : 0][r].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) unsafeAtomicAdd(acc + NACC * (size_t)id[a == 0 ? 0 : NS - 1] + 4 * r + c, o[c]);
+          }
         }
       }
       FB_TICK(4);

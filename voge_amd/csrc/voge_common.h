@@ -557,6 +557,34 @@ __device__ __forceinline__ void wt_add(WaveTable<NE, NV4> &t, const int slot, co
   }
 }
 
+// Two accumulations per lane in ONE election loop: a lane contends for its first slot until it wins it, then for its
+// second -- lanes that are through with one key move on while others still queue for theirs.  (Two wt_add calls in a row
+// cost the sum of their election rounds: 3.4 + 3.4 at cfg3; tools/fb_sections.py.)  Must be called by the whole wave.
+template <int NE, int NV4>
+__device__ __forceinline__ void wt_add2(WaveTable<NE, NV4> &t, const int slot0, const float4 (&v0)[NV4], const bool on0,
+                                        const int slot1, const float4 (&v1)[NV4], const bool on1, const int lane) {
+  volatile int *owner = t.owner;
+  bool p0 = on0, p1 = on1;
+#pragma unroll 1
+  while (__any(p0 | p1)) {
+    const bool use0 = p0, pend = p0 | p1;
+    const int s = use0 ? slot0 : slot1;
+    if (pend) owner[s] = lane;
+    if (pend && owner[s] == lane) {
+      float4 *dst = t.vals + s * NV4;
+#pragma unroll
+      for (int q = 0; q < NV4; ++q) {
+        float4 x = dst[q];
+        x.x += use0 ? v0[q].x : v1[q].x; x.y += use0 ? v0[q].y : v1[q].y;
+        x.z += use0 ? v0[q].z : v1[q].z; x.w += use0 ? v0[q].w : v1[q].w;
+        dst[q] = x;
+      }
+      p1 = use0 ? p1 : false;
+      p0 = false;
+    }
+  }
+}
+
 // Compact the occupied slots into t.owner[0..n) (the election array is free once accumulation
 // is over) and return n, so the flush issues full-width atomics instead of walking empty slots.
 // Must be called by the whole wave.
