@@ -99,8 +99,8 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       for (int it = lane; it < th * ipr; it += 64) {
         const int rr = it / ipr, j4 = it - rr * ipr;
         const size_t o = (((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8) * K + (size_t)j4 * 4;
-        *reinterpret_cast<int4 *>(out_idx + o) = make_int4(-1, -1, -1, -1);
-        *reinterpret_cast<float4 *>(out_len + o) = make_float4(VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN);
+        st16i<(VOGE_NT_STORES & 1) != 0>(out_idx + o, -1, -1, -1, -1);
+        st16f<(VOGE_NT_STORES & 1) != 0>(out_len + o, VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN);
       }
     } else {
       for (int it = lane; it < th * row_items; it += 64) {
@@ -531,8 +531,8 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 #pragma unroll
           for (int u = 0; u < kEpiB; ++u) {
             if (nv[u] < 0) continue;
-            *reinterpret_cast<int4 *>(t_idx + rel[u]) = make_int4(oi[u][0], oi[u][1], oi[u][2], oi[u][3]);
-            *reinterpret_cast<float4 *>(t_len + rel[u]) = make_float4(ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
+            st16i<false>(t_idx + rel[u], oi[u][0], oi[u][1], oi[u][2], oi[u][3]);      // (read next by the composite: plain stores)
+            st16f<false>(t_len + rel[u], ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
           }
         } else {
           float *const t_act = out_act + tile_pix * K, *const t_dsd = out_dsd + tile_pix * K;
@@ -563,10 +563,10 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
                 od[q] = (q < nv[u]) ? o.dsd : 0.0f;
               }
               if (nv[u] < 0) continue;
-              *reinterpret_cast<int4 *>(t_idx + rel[u]) = make_int4(oi[u][0], oi[u][1], oi[u][2], oi[u][3]);
-              *reinterpret_cast<float4 *>(t_len + rel[u]) = make_float4(ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
-              *reinterpret_cast<float4 *>(t_act + rel[u]) = make_float4(oa[0], oa[1], oa[2], oa[3]);
-              *reinterpret_cast<float4 *>(t_dsd + rel[u]) = make_float4(od[0], od[1], od[2], od[3]);
+              st16i<(VOGE_NT_STORES & 2) != 0>(t_idx + rel[u], oi[u][0], oi[u][1], oi[u][2], oi[u][3]);
+              st16f<(VOGE_NT_STORES & 2) != 0>(t_len + rel[u], ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
+              st16f<(VOGE_NT_STORES & 2) != 0>(t_act + rel[u], oa[0], oa[1], oa[2], oa[3]);
+              st16f<(VOGE_NT_STORES & 2) != 0>(t_dsd + rel[u], od[0], od[1], od[2], od[3]);
             }
           }
         }

@@ -1164,15 +1164,15 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
       for (int it = tid; it < th * ipr; it += kQT) {
         const int rr = it / ipr, j4 = it - rr * ipr;
         const size_t o = (((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8) * K + (size_t)j4 * 4;
-        *reinterpret_cast<int4 *>(out_idx + o) = make_int4(-1, -1, -1, -1);
-        *reinterpret_cast<float4 *>(out_len + o) = make_float4(VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN);
+        st16i<(VOGE_NT_STORES & 1) != 0>(out_idx + o, -1, -1, -1, -1);
+        st16f<(VOGE_NT_STORES & 1) != 0>(out_len + o, VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN, VOGE_SENT_LEN);
         if (out_weight != nullptr) {
           // fused trace + composite: the fragments are (weight, idx, len); act / dsd only serve the backward, which
           // never reads a pixel without hits -- a quarter of the empty tiles' bytes stays unwritten
           *reinterpret_cast<float4 *>(out_weight + o) = make_float4(0.f, 0.f, 0.f, 0.f);
         } else if (out_act != nullptr) {      // (NULL: the scalar-sigma fragment entry points keep no act / dsd)
-          *reinterpret_cast<float4 *>(out_act + o) = make_float4(VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT);
-          *reinterpret_cast<float4 *>(out_dsd + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+          st16f<(VOGE_NT_STORES & 1) != 0>(out_act + o, VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT, VOGE_SENT_ACT);
+          st16f<(VOGE_NT_STORES & 1) != 0>(out_dsd + o, 0.f, 0.f, 0.f, 0.f);
         }
       }
     } else {

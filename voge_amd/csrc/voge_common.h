@@ -308,6 +308,28 @@ __device__ __forceinline__ float wave_sum(float v) {
 // cycles each) reduce every aligned row of 16 lanes, four v_readlane + three operations combine the rows.  Max and min do
 // not depend on the order (same bits as the shuffle form); the sum's association differs from wave_sum's, so
 // wave_sum_dpp is used only where the value is not part of a result (bounding-cone axes, counts).
+// 16-byte stores of the trace's outputs.  NT = non-temporal: write-once data that nothing in the same chain of launches
+// reads again -- the all-sentinel tiles (never read at all: consumers go by the hit counts) and the stand-alone entry
+// point's (idx, len, act, dsd), 168 MB at cfg3 against 32 MB of L2.  As plain stores they evict the tile lists and records
+// the sweep is reading and leave the kernel's end waiting for their write-back: trace entry 84.1 -> 76.5 us at cfg3 with
+// both, sentinels alone 81.8 (tools/ab_bench.sh, interleaved).  The renderer's form keeps plain stores in its epilogue:
+// its (idx, len) are read by the composite that follows from the Infinity Cache (NT there: trace - 2.4 us, frame - 1 %);
+// the unfused pipeline (voge_fragments_fwd: trace with act / dsd, then the composite) is unchanged either way (118 us).
+#ifndef VOGE_NT_STORES
+#define VOGE_NT_STORES 3      // bit 0: sentinel tiles, bit 1: the epilogue with act / dsd (A/B builds: 0)
+#endif
+typedef float voge_v4f __attribute__((ext_vector_type(4)));
+typedef int voge_v4i __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void st16f(float *p, const float a, const float b, const float c, const float d) {
+  const voge_v4f v = {a, b, c, d};
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<voge_v4f *>(p)); else *reinterpret_cast<voge_v4f *>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ void st16i(int32_t *p, const int a, const int b, const int c, const int d) {
+  const voge_v4i v = {a, b, c, d};
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<voge_v4i *>(p)); else *reinterpret_cast<voge_v4i *>(p) = v;
+}
 #define VOGE_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
 #define VOGE_LANE(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l))
 __device__ __forceinline__ float wave_max(float v) {
