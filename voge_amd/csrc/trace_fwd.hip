@@ -697,10 +697,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
       __builtin_amdgcn_wave_barrier();      // the rows are rewritten by the next round
       if (cur.on) {
         const size_t ob = cur.pix * K + k0;
-        *reinterpret_cast<int4 *>(out_idx + ob) = make_int4(oi[0], oi[1], oi[2], oi[3]);
-        *reinterpret_cast<float4 *>(out_len + ob) = make_float4(ol[0], ol[1], ol[2], ol[3]);
-        *reinterpret_cast<float4 *>(out_act + ob) = make_float4(oa[0], oa[1], oa[2], oa[3]);
-        *reinterpret_cast<float4 *>(out_dsd + ob) = make_float4(od[0], od[1], od[2], od[3]);
+        st16i<(VOGE_NT_STORES & 2) != 0>(out_idx + ob, oi[0], oi[1], oi[2], oi[3]);      // (write-once, 16 B per slot: non-temporal, voge_common.h)
+        st16f<(VOGE_NT_STORES & 2) != 0>(out_len + ob, ol[0], ol[1], ol[2], ol[3]);
+        st16f<(VOGE_NT_STORES & 2) != 0>(out_act + ob, oa[0], oa[1], oa[2], oa[3]);
+        st16f<(VOGE_NT_STORES & 2) != 0>(out_dsd + ob, od[0], od[1], od[2], od[3]);
         *reinterpret_cast<float4 *>(out_weight + ob) = make_float4(wgt[0], wgt[1], wgt[2], wgt[3]);
         if (q == 0 && out_valid != nullptr) out_valid[cur.pix] = (int64_t)cur.cntp;
       }
@@ -779,10 +779,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             od[q] = o.dsd;
           }
         }
-        *reinterpret_cast<int4 *>(out_idx + ob[u]) = make_int4(oi[0], oi[1], oi[2], oi[3]);
-        *reinterpret_cast<float4 *>(out_len + ob[u]) = make_float4(ol[0], ol[1], ol[2], ol[3]);
-        *reinterpret_cast<float4 *>(out_act + ob[u]) = make_float4(oa[0], oa[1], oa[2], oa[3]);
-        *reinterpret_cast<float4 *>(out_dsd + ob[u]) = make_float4(od[0], od[1], od[2], od[3]);
+        st16i<(VOGE_NT_STORES & 2) != 0>(out_idx + ob[u], oi[0], oi[1], oi[2], oi[3]);      // (write-once, 16 B per slot: non-temporal, voge_common.h)
+        st16f<(VOGE_NT_STORES & 2) != 0>(out_len + ob[u], ol[0], ol[1], ol[2], ol[3]);
+        st16f<(VOGE_NT_STORES & 2) != 0>(out_act + ob[u], oa[0], oa[1], oa[2], oa[3]);
+        st16f<(VOGE_NT_STORES & 2) != 0>(out_dsd + ob[u], od[0], od[1], od[2], od[3]);
       }
     }
     // Fragment mode without act / dsd (out_act == NULL; voge_fragments_fwd_iso*): index and len are the key itself --
@@ -887,10 +887,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
             od[q] = o.dsd;
           }
         }
-        *reinterpret_cast<int4 *>(out_idx + ob[u]) = make_int4(oi[0], oi[1], oi[2], oi[3]);
-        *reinterpret_cast<float4 *>(out_len + ob[u]) = make_float4(ol[0], ol[1], ol[2], ol[3]);
-        *reinterpret_cast<float4 *>(out_act + ob[u]) = make_float4(oa[0], oa[1], oa[2], oa[3]);
-        *reinterpret_cast<float4 *>(out_dsd + ob[u]) = make_float4(od[0], od[1], od[2], od[3]);
+        st16i<(VOGE_NT_STORES & 2) != 0>(out_idx + ob[u], oi[0], oi[1], oi[2], oi[3]);      // (write-once, 16 B per slot: non-temporal, voge_common.h)
+        st16f<(VOGE_NT_STORES & 2) != 0>(out_len + ob[u], ol[0], ol[1], ol[2], ol[3]);
+        st16f<(VOGE_NT_STORES & 2) != 0>(out_act + ob[u], oa[0], oa[1], oa[2], oa[3]);
+        st16f<(VOGE_NT_STORES & 2) != 0>(out_dsd + ob[u], od[0], od[1], od[2], od[3]);
       }
     }
   }
