@@ -486,6 +486,9 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       // form compiled into one exec-mask region per slot and load: hundreds of scalar instructions and branches per batch,
       // 4.7 us of a heavy tile (10-13 us with act / dsd).
       const unsigned h_last = (unsigned)max(src_n - 1, 0);
+      const bool wt_ok = (size_t)W * (size_t)K < ((size_t)1 << 26);      // (byte offsets of the pass's eight rows below 2^31)
+      const unsigned rs_bytes = wt_ok ? 8u * (unsigned)W * (unsigned)K * 4u : 0u;
+      const __amdgpu_buffer_rsrc_t rs_idx = out_rsrc(t_idx, rs_bytes), rs_len = out_rsrc(t_len, rs_bytes);
       for (int it0 = lane; it0 < nitem; it0 += 64 * kEpiB) {
         int32_t oi[kEpiB][4];
         float ol[kEpiB][4];
@@ -531,8 +534,13 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 #pragma unroll
           for (int u = 0; u < kEpiB; ++u) {
             if (nv[u] < 0) continue;
-            st16i<false>(t_idx + rel[u], oi[u][0], oi[u][1], oi[u][2], oi[u][3]);      // (read next by the composite: plain stores)
-            st16f<false>(t_len + rel[u], ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
+            if (wt_ok) {      // (uniform) read next by the composite: write-through stores (voge_common.h)
+              st16i_wt(rs_idx, rel[u] * 4u, oi[u][0], oi[u][1], oi[u][2], oi[u][3]);
+              st16f_wt(rs_len, rel[u] * 4u, ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
+            } else {
+              st16i<false>(t_idx + rel[u], oi[u][0], oi[u][1], oi[u][2], oi[u][3]);
+              st16f<false>(t_len + rel[u], ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
+            }
           }
         } else {
           float *const t_act = out_act + tile_pix * K, *const t_dsd = out_dsd + tile_pix * K;

@@ -325,6 +325,24 @@ __device__ __forceinline__ void st16f(float *p, const float a, const float b, co
   const voge_v4f v = {a, b, c, d};
   if (NT) __builtin_nontemporal_store(v, reinterpret_cast<voge_v4f *>(p)); else *reinterpret_cast<voge_v4f *>(p) = v;
 }
+// 16-byte stores of what the NEXT kernel reads (the renderer-form trace's (idx, len) for the composite): agent-scope
+// write-through (`sc1` on a buffer store).  The data leaves the XCD's L2 as it is written -- no write-back for the kernel's
+// end to wait for -- and, unlike a non-temporal store, still allocates in the memory-side cache the consumer reads from:
+// renderer-form trace 72.4 -> 70.9 us, frame + 0.5 % (plain stores / non-temporal: - 2.4 us but frame - 1 %).
+// base: wave-uniform; byte offsets below 2^31.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(void *base, const unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void st16f_wt(const __amdgpu_buffer_rsrc_t r, const unsigned byte_off, const float a, const float b,
+                                         const float c, const float d) {
+  const voge_v4f v = {a, b, c, d};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ void st16i_wt(const __amdgpu_buffer_rsrc_t r, const unsigned byte_off, const int a, const int b,
+                                         const int c, const int d) {
+  const voge_v4i v = {a, b, c, d};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 16 /* sc1 */);
+}
 template <bool NT>
 __device__ __forceinline__ void st16i(int32_t *p, const int a, const int b, const int c, const int d) {
   const voge_v4i v = {a, b, c, d};
