@@ -171,14 +171,6 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
   float S[NS];
 #pragma unroll
   for (int a = 0; a < NS; ++a) S[a] = 0.0f;
-#ifndef VOGE_EXP_FWD_ROWPHI
-#define VOGE_EXP_FWD_ROWPHI 0      // (timing experiment, VERDICT r3 item 2: the forward also accumulates the backward's row sums)
-#endif
-#if VOGE_EXP_FWD_ROWPHI
-  v2f accR[NS];
-#pragma unroll
-  for (int a = 0; a < NS; ++a) accR[a] = splat(0.0f);
-#endif
   if (any_e && sorted) {
     v2f accF[NS], accB[NS];
 #pragma unroll
@@ -202,31 +194,19 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
     for (int e = d0 - 2;; e -= 2) {      // column pairs in front of every own row; row 0 is the nearest
       const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
       if (!(lm[0] - l2.y < rwin)) break;
-#if VOGE_EXP_FWD_ROWPHI
-      const v2f Es2 = E2 * s2;
-#endif
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
         const v2f xa = (splat(lm[a]) - l2) * s2;
         accF[a] = pk_fma(E2, h_pair(xa), accF[a]);
-#if VOGE_EXP_FWD_ROWPHI
-        accR[a] = pk_fma(Es2, gauss_pair(xa), accR[a]);
-#endif
       }
     }
     for (int e = d0 + NS;; e += 2) {     // column pairs behind every own row
       const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
       if (!(l2.x - lmB < rwin)) break;
-#if VOGE_EXP_FWD_ROWPHI
-      const v2f Es2 = E2 * s2;
-#endif
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
         const v2f xa = (l2 - splat(lm[a])) * s2;
         accB[a] = pk_fma(E2, h_pair(xa), accB[a]);
-#if VOGE_EXP_FWD_ROWPHI
-        accR[a] = pk_fma(Es2, gauss_pair(xa), accR[a]);
-#endif
       }
     }
     float pre = ex;
@@ -251,10 +231,6 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
   }
 #pragma unroll
   for (int a = 0; a < NS; ++a) w[a] = (em[a] != 0.0f) ? FAST_EXP(-occ * S[a]) * em[a] * kInvNorm : 0.0f;
-#if VOGE_EXP_FWD_ROWPHI
-#pragma unroll
-  for (int a = 0; a < NS; ++a) w[a] = fmaf(1e-30f, accR[a].x + accR[a].y, w[a]);      // (keeps the sums alive; WRONG weights: timing only)
-#endif
 }
 
 // -DVOGE_FB_TIMES builds: lane utilisation of the window loops (tools/fb_sections.py).  Per workgroup (= wave) row:
@@ -312,10 +288,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
   float rterm[NS];
 #pragma unroll
   for (int a = 0; a < NS; ++a) rterm[a] = 0.0f;
-#ifndef VOGE_EXP_BWD_NO_ROWWALK
-#define VOGE_EXP_BWD_NO_ROWWALK 0      // (timing experiment: the row sums come from the forward -- here simply left out)
-#endif
-  if (any_e && sorted && !VOGE_EXP_BWD_NO_ROWWALK) {
+  if (any_e && sorted) {
     v2f accR[NS];
 #pragma unroll
     for (int a = 0; a < NS; ++a) accR[a] = splat(0.0f);
