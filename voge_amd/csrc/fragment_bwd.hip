@@ -71,7 +71,7 @@ struct FragBwdLds {
 #define VOGE_FB_LDS_RMAX 1
 #endif
 #ifndef VOGE_FB_PAIR_TABLE
-#define VOGE_FB_PAIR_TABLE 1      // scalar sigmas: a lane's two table accumulations share one election loop (wt_add2)
+#define VOGE_FB_PAIR_TABLE 1      // a lane's two table accumulations share one election loop (wt_add2)
 #endif
 #ifndef VOGE_FB_WPE
 #define VOGE_FB_WPE 4      // capping the registers for 5 / 6 waves per SIMD spills and is slower
@@ -325,8 +325,8 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
                                                      : make_float4(0.f, 0.f, 0.f, 0.f);   // (P < 2^26: host)
     const float dn2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float idn = __builtin_amdgcn_rcpf(dn2);
-    // (scalar sigmas, two slots per lane: both slots' terms first, then ONE election loop for both -- wt_add2)
-    constexpr bool PAIR = ISO && NS == 2 && VOGE_FB_PAIR_TABLE;
+    // (two slots per lane: both slots' terms first, then ONE election loop for both -- wt_add2)
+    constexpr bool PAIR = NS == 2 && VOGE_FB_PAIR_TABLE;
     float4 valp[PAIR ? 2 : 1][NV4];
     bool gop[2] = {false, false};
 #pragma unroll
