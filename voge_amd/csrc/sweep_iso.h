@@ -580,50 +580,67 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
         }
       }
     } else {
-      // K not a multiple of four: one slot per lane and trip over the pass's rows (rows x pixels x slots flattened), four
-      // trips in flight
-      const float inv_ri = 1.0f / (float)max(row_items, 1);
+      // K not a multiple of four: one slot per lane and trip over the pass's rows (rows x pixels x slots flattened), kOddU
+      // trips in flight; branch-free like the batches above (a trip beyond the pass re-reads item 0, a slot beyond the pixel's
+      // count its stale LDS row), 32-bit offsets from the pass's first pixel, reciprocal instead of integer division
+      constexpr int kOddU = 8;
+      const float inv_ri = 1.0f / (float)max(row_items, 1), invK = 1.0f / (float)K;
       const int nit = th * row_items;
-      for (int it0 = lane; it0 < nit; it0 += 4 * 64) {
-        int32_t oi[4];
-        float ol[4];
-        size_t oo[4], pixs[4];
-        bool in[4];
+      const size_t tile_pix = ((size_t)b * H + ty * 8 + row0) * W + (size_t)tx * 8;      // the pass's first pixel
+      int32_t *const t_idx = out_idx + tile_pix * K;
+      float *const t_len = out_len + tile_pix * K;
+      const unsigned h_last = (unsigned)max(src_n - 1, 0);
+      for (int it0 = lane; it0 < nit; it0 += kOddU * 64) {
+        int32_t oi[kOddU];
+        float ol[kOddU];
+        unsigned rel[kOddU], pr[kOddU];      // slot / pixel offset from the pass's first pixel
+        bool in[kOddU], on[kOddU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kOddU; ++u) {
           const int it = it0 + u * 64;
-          oo[u] = 0; pixs[u] = 0; oi[u] = -1; ol[u] = VOGE_SENT_LEN; in[u] = false;
-          if (it < nit) {
-            const int rr = __float2int_rz(((float)it + 0.5f) * inv_ri);
-            const int j = it - rr * row_items;
-            const int x = j / K, sl = j - x * K;
-            const int owner = rr * 8 + x;
-            pixs[u] = ((size_t)b * H + ty * 8 + row0 + rr) * W + (size_t)tx * 8 + x;
-            oo[u] = pixs[u] * K + sl;
-            in[u] = sl < S.cnt[owner];
-            if (in[u]) { ol[u] = Llen[sl * kS2TP + owner]; oi[u] = (int)entry_pos(sl, owner); }
-          }
+          on[u] = it < nit;
+          const int itc = on[u] ? it : 0;
+          const int rr = __float2int_rz(((float)itc + 0.5f) * inv_ri);
+          const int j = itc - rr * row_items;
+          const int x = __float2int_rz(((float)j + 0.5f) * invK);
+          const int sl = j - x * K;
+          const int owner = rr * 8 + x;
+          pr[u] = (unsigned)(rr * W + x);
+          rel[u] = pr[u] * (unsigned)K + (unsigned)sl;
+          in[u] = on[u] && sl < S.cnt[owner];
+          ol[u] = Llen[sl * kS2TP + owner];
+          oi[u] = (int)entry_pos(sl, owner);
+        }
+        if (h_is_id) {      // (uniform)
+#pragma unroll
+          for (int u = 0; u < kOddU; ++u) oi[u] = in[u] ? oi[u] + gofs : -1;
+        } else {
+          int idv[kOddU];
+#pragma unroll
+          for (int u = 0; u < kOddU; ++u) idv[u] = src_id[min((unsigned)oi[u], h_last)];
+#pragma unroll
+          for (int u = 0; u < kOddU; ++u) oi[u] = in[u] ? idv[u] + gofs : -1;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (in[u]) oi[u] = id_of((unsigned)oi[u]) + gofs;
+        for (int u = 0; u < kOddU; ++u) ol[u] = in[u] ? ol[u] : VOGE_SENT_LEN;
+        if (!want_ad) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (it0 + u * 64 >= nit) continue;
-          out_idx[oo[u]] = oi[u];
-          out_len[oo[u]] = ol[u];
-          if (want_ad) {
-            float oa = VOGE_SENT_ACT, od = 0.0f;
-            if (in[u]) {
-              const float *ry = rays + pixs[u] * 3;
-              const float ex = ry[0], ey = ry[1], ez = ry[2];
-              const float4 cc = ms[oi[u]];
-              const PairOut o = pair_eval_iso_at(cc.x, cc.y, cc.z, cc.w, ol[u], ex, ey, ez, (ex * ex + ey * ey) + ez * ez);
-              oa = o.act; od = o.dsd;
-            }
-            out_act[oo[u]] = oa;
-            out_dsd[oo[u]] = od;
+          for (int u = 0; u < kOddU; ++u)
+            if (on[u]) { t_idx[rel[u]] = oi[u]; t_len[rel[u]] = ol[u]; }
+        } else {
+          float *const t_act = out_act + tile_pix * K, *const t_dsd = out_dsd + tile_pix * K;
+          float oa[kOddU], od[kOddU];
+#pragma unroll
+          for (int u = 0; u < kOddU; ++u) {
+            const float *ry = rays + (tile_pix + pr[u]) * 3;
+            const float ex = ry[0], ey = ry[1], ez = ry[2];
+            const float4 cc = ms[in[u] ? oi[u] : gofs];
+            const PairOut o = pair_eval_iso_at(cc.x, cc.y, cc.z, cc.w, ol[u], ex, ey, ez, (ex * ex + ey * ey) + ez * ez);
+            oa[u] = in[u] ? o.act : VOGE_SENT_ACT; od[u] = in[u] ? o.dsd : 0.0f;
           }
+#pragma unroll
+          for (int u = 0; u < kOddU; ++u)
+            if (on[u]) { t_idx[rel[u]] = oi[u]; t_len[rel[u]] = ol[u]; t_act[rel[u]] = oa[u]; t_dsd[rel[u]] = od[u]; }
         }
       }
     }
