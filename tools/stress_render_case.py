@@ -9,6 +9,7 @@ import test_gpu_configs as C
 from util import random_scene
 from voge_amd import _lib
 
+from stress_render import _well_conditioned
 seed, want = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed)
 for case in range(want + 1):
@@ -19,6 +20,7 @@ for case in range(want + 1):
     verts, sig, cols = random_scene(N, seed=int(rng.integers(1 << 30)), aniso=(form == "full"), lo=0.05, hi=0.2)
     if form == "full":
         sig = (0.5 * (sig + sig.transpose(0, 2, 1))).astype(np.float32)
+        sig = _well_conditioned(sig)
     elif form == "diag":
         sig = (sig[:, None] * rng.uniform(0.6, 1.6, (N, 3))).astype(np.float32)
     sc = dict(verts=verts, sigmas=sig, colors=cols, focal=float(rng.uniform(0.7, 1.4)) * max(H, W), principal=(W / 2.0, H / 2.0),
