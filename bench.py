@@ -369,6 +369,7 @@ def main():
                 run()
             barrier()
             dt = time.perf_counter() - t0
+            timed.last_local_dt = dt      # (this rank's own clock; the line reports min / max over the ranks)
             if world > 1:
                 tt = torch.tensor([dt], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -480,9 +481,39 @@ def main():
             for _ in range(300):
                 run()
             torch.cuda.synchronize()
+        # Once, untimed, N > 1 only: the frame the split assembles must be the frame ONE GPU renders -- the same bits (pixels
+        # are independent in every stage; stripes / bands / views only choose who computes which rows).  Every rank takes part
+        # in the gather; rank 0 renders the whole frame (views mode: every view) alone and compares with torch.equal.
+        split_exact = None
+        if world > 1 and primary and not (args.only_stage and args.only_stage != "frame"):
+            with torch.no_grad():
+                band = fwd()
+                whole = gather_stripes(band, H, stripe_h) if striped else gather_rows(band, H_all, bounds=gb)
+                if rank == 0:
+                    rr = renderer_of[0]
+                    if by_views:
+                        alone = torch.cat([to_white_background(rr(gm, R=Rv[v:v + 1].contiguous(), T=Tv[v:v + 1].contiguous()), colors)
+                                           for v in range(world)], dim=1)
+                    else:
+                        alone = to_white_background(rr(gm, R=R, T=T), colors)
+                    split_exact = bool(torch.equal(whole, alone))
+                    assert split_exact, (f"the {mode} split over {world} ranks does not reproduce the single-GPU frame: "
+                                         f"max |diff| {float((whole - alone).abs().max()):.3e}")
+            torch.cuda.synchronize()
         dt = timed(run, args.steps, args.warmup)
         ms = dt / args.steps * 1e3
         fps = (world if by_views else 1) * args.steps / dt      # (views mode: every step renders `world` frames, one per rank)
+        # what the line says about the job it ran on: the process group's own view of the world, and every rank's local clock
+        # over the same timed region (before the max-reduction above)
+        dist_info = None
+        if world > 1:
+            mine = [None] * world
+            dist.all_gather_object(mine, float(timed.last_local_dt / args.steps * 1e3))
+            dist_info = {"world_size": int(dist.get_world_size()), "backend": str(dist.get_backend()),
+                         "rank_ms_per_step": {"min": round(min(mine), 4), "max": round(max(mine), 4),
+                                              "per_rank": [round(x, 4) for x in mine]},
+                         "devices": int(torch.cuda.device_count()),
+                         "gathered_frame_equals_single_gpu_render": split_exact}
         return SimpleNamespace(**{k: v for k, v in locals().items() if k != "mode"})
 
 
@@ -513,6 +544,7 @@ def main():
     }
     if world > 1 and rank == 0:
         result["config"]["multi_gpu_mode"] = mode
+        result["config"].update(M.dist_info)      # world_size / backend as torch.distributed reports them, per-rank ms, the exactness check
 
     if world > 1 and bands is not None:
         result["config"]["bands"] = list(bands["bounds"])      # rows [b[r], b[r+1]) of rank r, after the measured balancing

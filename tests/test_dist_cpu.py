@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -220,16 +221,20 @@ def _stripe_worker(rank, world, port, H, W, stripe_h, out):
     dist.destroy_process_group()
 
 
-def test_stripe_dealt_frame_equals_single_rank(tmp_path):
+@pytest.mark.parametrize("H,W,world,stripe_h", [(21, 16, 2, 4), (23, 12, 3, 4)])
+def test_stripe_dealt_frame_equals_single_rank(tmp_path, H, W, world, stripe_h):
     """Stripes(H, rank, world, stripe_h): every rank renders its interleaved stripes stacked into one image; the gathered,
     re-ordered frame and the all-reduced gradient of a full-frame loss equal the single-process render.  (H = 21 with
     stripes of 4 rows over 2 ranks: rank 0 gets rows 0-3, 8-11, 16-19, rank 1 rows 4-7, 12-15, 20 -- a cut last stripe and
-    unequal stacked heights.)"""
+    unequal stacked heights.  H = 23 over 3 ranks: H is not a multiple of world * stripe_h, the last rank's second stripe is
+    cut to 3 rows -- ADVICE r4.)"""
     from voge_amd.distributed import Stripes, stripe_height
-    H, W, world, stripe_h = 21, 16, 2, 4
-    s0, s1 = Stripes(H, 0, world, stripe_h), Stripes(H, 1, world, stripe_h)
-    assert s0.image_rows().tolist() == [0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19] and s1.image_rows().tolist() == [4, 5, 6, 7, 12, 13, 14, 15, 20]
-    assert sorted(s0.image_rows().tolist() + s1.image_rows().tolist()) == list(range(H))
+    if world == 2:
+        s0, s1 = Stripes(H, 0, world, stripe_h), Stripes(H, 1, world, stripe_h)
+        assert s0.image_rows().tolist() == [0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19] and s1.image_rows().tolist() == [4, 5, 6, 7, 12, 13, 14, 15, 20]
+    else:
+        assert Stripes(H, 2, world, stripe_h).image_rows().tolist() == [8, 9, 10, 11, 20, 21, 22]
+    assert sorted(sum((Stripes(H, r, world, stripe_h).image_rows().tolist() for r in range(world)), [])) == list(range(H))
     assert stripe_height(1024, 8) == 32 and stripe_height(64, 8) == 8 and stripe_height(21, 2, 4) == 4 and stripe_height(5, 8) == 1
     out = str(tmp_path / "s0.pt")
     mp.spawn(_stripe_worker, args=(world, _free_port(), H, W, stripe_h, out), nprocs=world, join=True)
@@ -247,3 +252,30 @@ def test_stripe_dealt_frame_equals_single_rank(tmp_path):
     (img * torch.linspace(0.5, 1.5, H, dtype=torch.float64)[None, :, None, None]).sum().backward()
     assert torch.equal(got["img"], img.detach())                               # pixels are independent: the same bits
     assert torch.allclose(got["g"], colors.grad, rtol=1e-12, atol=1e-14)
+
+
+def _bad_stripe_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from voge_amd.distributed import Stripes, gather_stripes
+    H, W, stripe_h = 4, 8, 4                      # one stripe in all: rank 1 owns no row
+    mine = Stripes(H, rank, world, stripe_h)
+    band = torch.zeros((1, mine.h, W, 3), dtype=torch.float64)
+    msg = ""
+    try:
+        gather_stripes(band, H, stripe_h)         # (the local check fires on every rank before any collective is entered)
+    except AssertionError as e:
+        msg = str(e)
+    if rank == 0:
+        torch.save({"msg": msg}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stripes_that_leave_a_rank_empty_are_refused(tmp_path):
+    """A stripe height that gives some rank no row at all (Stripes.h == 0) must not reach the renderer or the collective:
+    gather_stripes names distributed.stripe_height's answer instead."""
+    out = str(tmp_path / "bad.pt")
+    mp.spawn(_bad_stripe_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    msg = torch.load(out)["msg"]
+    assert "without a row" in msg and "stripe_height" in msg

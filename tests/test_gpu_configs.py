@@ -163,6 +163,23 @@ def test_config2_bunny_fwd_bwd(hip_lib):
     # oracle's fp64 backward chain fed with the fp32 forward values alone shows 1.4e-4.  Any fp32 path -- the reference's
     # included, which stores len as float -- carries it; the reference's own fp32 operation order does far worse (below).
     got = _check_grads("cfg2", (colors.grad, gm.verts.grad, gm.sigmas.grad), want, mult=2)      # measured 1.5e-4 (verts)
+    # Round 5, the FORMAT's floor: the oracle's fp64 chain -- composite, merge, blend and their backward,
+    # trace backward -- with nothing changed but len rounded to the NEAREST fp32 (<= 0.5 ulp; act / dsd left in fp64).  On
+    # this frame that alone moves the vertex gradient by 1.46e-4 of scale: above north_star's 1e-4, i.e. no path that hands
+    # len over as a float -- the reference's `float` tensors included -- can meet 1e-4 against an fp64 truth here, however the
+    # float was computed (the HIP len's 2.5 ulp cost 0.05e-4 more).  The 2 x tolerance above stands on this number; HIP is
+    # held to within 10 % of it.
+    fl = dict(ref)
+    fl["len"] = ref["len"].astype(np.float32).astype(np.float64)
+    fl["weight"], fl["valid_num"] = oracle.composite_fwd(ref["idx"], ref["act"], fl["len"], ref["dsd"], 1.0)
+    fl["rgb"] = oracle.merge_fwd(ref["colsB"], ref["idx"], fl["weight"], fl["valid_num"])
+    _, fl["silhouette"] = oracle.blend_fwd(fl["rgb"], fl["weight"])
+    floor = np.abs(_oracle_grads(sc, fl, g_img)[1] - want[1]).max() / max(1.0, np.abs(want[1]).max())
+    from util import log_line
+    log_line(f"[parity] cfg2 verts gradient: fp64 chain with len rounded to nearest fp32 (the format's floor) {floor:.3e} of scale; "
+             f"HIP {got['verts']:.3e} = {got['verts'] / floor:.3f} x the floor")
+    assert floor > TOL, "the fp32-len floor fell below north_star's tolerance: tighten _check_grads('cfg2') to mult=1"
+    assert got["verts"] <= 1.10 * floor
     # the reference's arithmetic floor on the same frame: the fp32 reference-order oracle (act = mu^T A mu - (mu^T A d)^2/dsd
     # cancels catastrophically here), same lists, same loss
     f32 = dict(ref)
@@ -176,7 +193,6 @@ def test_config2_bunny_fwd_bwd(hip_lib):
     ga, gl, gd = oracle.composite_bwd(f32["act"], f32["len"], f32["dsd"], g_w, 1.0, precision="f32")
     _, g_mu32, _ = oracle.trace_bwd(ref["mus"], ref["isg"], ref["rays"], ref["idx"], gl, ga, gd, precision="f32")
     err32 = np.abs(np.asarray(g_mu32, np.float64).reshape(want[1].shape) - want[1]).max() / max(1.0, np.abs(want[1]).max())
-    from util import log_line
     log_line(f"[parity] cfg2 verts gradient: HIP {got['verts']:.2e} of scale; the fp32 reference-order oracle chain {err32:.2e}")
     assert got["verts"] <= err32
 

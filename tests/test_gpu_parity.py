@@ -1138,6 +1138,11 @@ def test_bench_two_ranks_on_one_gpu(hip_lib, mode):
     frames = 2 if mode == "views" else 1
     assert abs(line["value"] - frames * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
     assert ("bands" in line["config"]) == (mode == "row_bands")
+    # the line describes the job it ran on: the process group's world size and backend, every rank's own
+    # clock, and the one-off check that the assembled frame is bit for bit the frame one GPU renders
+    c = line["config"]
+    assert c["world_size"] == 2 and c["backend"] == "gloo" and c["gathered_frame_equals_single_gpu_render"] is True
+    assert len(c["rank_ms_per_step"]["per_rank"]) == 2 and 0 < c["rank_ms_per_step"]["min"] <= c["rank_ms_per_step"]["max"] <= line["ms_per_step"] * 1.001
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
     if mode == "stripes":      # the default line also carries the alternatives and config 4
         v = line["variants"]

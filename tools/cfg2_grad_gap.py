@@ -78,3 +78,16 @@ ga, gl, gd = oracle.composite_bwd(np.where(s32, a32, act), np.where(s32, l32, ln
 _, g_mu_ref32, _ = oracle.trace_bwd(mus, isg, rays, idx, gl, ga, gd, precision="f32")
 print(f"fp32 REFERENCE-ORDER oracle, whole chain (its own len/act/dsd where its lists agree: {s32.mean() * 100:.2f} %): g_mu err / scale = "
       f"{rel(np.asarray(g_mu_ref32, np.float64).reshape(-1, 3), g_mu, scale):.2e};  its act: max abs err {np.abs(a32 - act)[(idx >= 0) & s32].max():.3e}")
+# ---- round 5: the FORMAT's floor -- the fp64 chain with len (alone) rounded to the nearest fp32
+def chain64(ln_, act_, dsd_):
+    w_, vn_ = oracle.composite_fwd(idx, act_, ln_, dsd_, 1.0)
+    rgb_ = oracle.merge_fwd(cols, idx, w_, vn_)
+    _, sil_ = oracle.blend_fwd(rgb_, w_)
+    g_rgb_ = g_img * (rgb_ + (1 - sil_)[..., None] < 1)
+    _, gw_ = oracle.merge_bwd(cols, idx, w_, vn_, g_rgb_)
+    gw_ = gw_ - ((g_rgb_.sum(-1)) * (w_.sum(-1) < 1))[..., None] * (np.arange(K)[None, None, None] < vn_[..., None])
+    ga_, gl_, gd_ = oracle.composite_bwd(act_, ln_, dsd_, gw_, 1.0)
+    return oracle.trace_bwd(mus, isg, rays, idx, gl_, ga_, gd_)[1].reshape(-1, 3)
+r32 = lambda x: x.astype(np.float32).astype(np.float64)
+print(f"fp64 chain, len rounded to NEAREST fp32 (act / dsd fp64): g_mu err / scale = {rel(chain64(r32(ln), act, dsd), g_mu, scale):.3e}   <- the format's floor")
+print(f"fp64 chain, act alone rounded: {rel(chain64(ln, r32(act), dsd), g_mu, scale):.2e};  dsd alone rounded: {rel(chain64(ln, act, r32(dsd)), g_mu, scale):.2e}")

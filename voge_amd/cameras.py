@@ -45,14 +45,21 @@ def _intrinsics(focal, pp, B, device):
     instead of being re-expanded and re-copied by two tiny kernels per frame."""
     import weakref
     key = str(device)
-    hit = _INTR.get(key)
+    # (while a HIP graph is being captured the cache is neither read nor written, like ops._workspace: a pair prepared inside
+    # a capture lives in the graph's private pool and is only filled when the graph replays -- an eager call that hit such an
+    # entry would read unwritten memory)
+    capturing = torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
+    hit = None if capturing else _INTR.get(key)
     if (hit is not None and torch.is_tensor(focal) and torch.is_tensor(pp) and hit[0]() is focal and hit[1]() is pp
             and hit[2] == (focal._version, pp._version, B) and not focal.requires_grad and not pp.requires_grad):
         return hit[3], hit[4]
     f_c, p_c = _as_b2(focal, B, device), _as_b2(pp, B, device)
     if torch.is_tensor(focal) and torch.is_tensor(pp) and not focal.requires_grad and not pp.requires_grad:
         f_c, p_c = f_c.contiguous(), p_c.contiguous()
-        _INTR[key] = (weakref.ref(focal), weakref.ref(pp), (focal._version, pp._version, B), f_c, p_c)
+        # (an input that already is a contiguous [B,2] fp32 tensor comes back as itself: caching it would hold a strong
+        # reference the weak ones never release -- and there is nothing to save)
+        if not capturing and f_c is not focal and p_c is not pp:
+            _INTR[key] = (weakref.ref(focal), weakref.ref(pp), (focal._version, pp._version, B), f_c, p_c)
     return f_c, p_c
 
 

@@ -1067,6 +1067,11 @@ static int composite_shade_fwd_impl(const bool gen, int32_t *idx, const int32_t 
   // (img == NULL: merge_final + the weight sum only -- interpolate_attr and get_silhouette, no background; bg unused)
   if (!idx || !cnt || !len || !records || !rays || !weight || !valid_num) return VOGE_ERR_BAD_ARG;
   if (C > 0 && (!rgb || !wsum || (img && !bg) || (Nattr > 0 && !colors))) return VOGE_ERR_BAD_ARG;
+  // (the shade stage's colour gather is branch-free: a slot that contributes nothing still LOADS colour row 0 and drops
+  //  the value.  An empty table (Nattr == 0: colors may be NULL) therefore reads its discarded row from the rgb output
+  //  instead -- C readable floats that exist whenever there is a shade stage -- so a direct C-ABI caller in that state
+  //  dereferences nothing of its own)
+  if (C > 0 && Nattr == 0) colors = rgb;
   if (Nattr * (C > 0 ? C : 1) >= (1l << 30)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the colour gathers
   constexpr int NS = 4;
   const int tn = VOGE_COMP_WAVE_T;

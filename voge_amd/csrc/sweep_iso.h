@@ -54,6 +54,9 @@ __host__ __device__ inline size_t sweep2_lds_bytes(const int K) { return sweep2_
 #define VOGE_S2_EXIT_GROUP 16   // candidates between two exit tests (a power of two, >= 4)
 #endif
 constexpr int kExitGroup = VOGE_S2_EXIT_GROUP;
+#ifndef VOGE_S2_PREFETCH
+#define VOGE_S2_PREFETCH 1      // the next trip's staged records are requested before this trip's commits
+#endif
 #ifndef VOGE_S2_PRIO_LEN
 #define VOGE_S2_PRIO_LEN 0   // (experiment) tiles with at least this many candidates run at raised wave priority; 0: off
 #endif
@@ -399,6 +402,16 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       // the same compare) or never-hit padding. ----
       const float lbl = S.lb[lane];      // (the bound of staged entry `lane`)
       int n = nbuf;
+#if VOGE_S2_PREFETCH
+      // The records of trip s0 + 4 are requested BEFORE trip s0's commits (round 5): the loop used to issue its five
+      // ds_read_b128 and wait for them at once -- behind the previous trip's eight ds_write still in the wave's LDS queue --
+      // so every trip of four candidates began with an exposed LDS round trip (SQ_WAIT_ANY: 42 % of the kernel's wave
+      // cycles at 2.2 waves per SIMD, profiles/r5_pmc_sq_counters.txt).  (The staged arrays carry kS2Pad entries of
+      // padding: the request behind the last trip reads those.)
+      float4 Xn = *reinterpret_cast<const float4 *>(&S.x[0]), Yn = *reinterpret_cast<const float4 *>(&S.y[0]),
+             Zn = *reinterpret_cast<const float4 *>(&S.z[0]), An = *reinterpret_cast<const float4 *>(&S.a[0]);
+      int4 Pn = *reinterpret_cast<const int4 *>(&S.pos[0]);
+#endif
       for (int s0 = 0; s0 < n; s0 += 4) {
         if ((s0 & (kExitGroup - 1)) == 0 && binned && unit_rays && __all(!valid || cnt == K)) {
           const float wmax = wave_max(valid ? worstf : -INFINITY);
@@ -409,9 +422,14 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
             if (n <= s0) break;
           }
         }
+#if VOGE_S2_PREFETCH
+        const float4 X = Xn, Y = Yn, Z = Zn, A = An;
+        const int4 P = Pn;
+#else
         const float4 X = *reinterpret_cast<const float4 *>(&S.x[s0]), Y = *reinterpret_cast<const float4 *>(&S.y[s0]),
                      Z = *reinterpret_cast<const float4 *>(&S.z[s0]), A = *reinterpret_cast<const float4 *>(&S.a[s0]);
         const int4 P = *reinterpret_cast<const int4 *>(&S.pos[s0]);      // the entries' handles (id or stream position)
+#endif
         const int pv[4] = {P.x, P.y, P.z, P.w};
         float len[4], act[4];
 #if VOGE_S2_PACKED
@@ -443,6 +461,11 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 #endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(len[q]), "+v"(act[q]));      // four interleaved chains, then the commits
+#if VOGE_S2_PREFETCH
+        Xn = *reinterpret_cast<const float4 *>(&S.x[s0 + 4]); Yn = *reinterpret_cast<const float4 *>(&S.y[s0 + 4]);
+        Zn = *reinterpret_cast<const float4 *>(&S.z[s0 + 4]); An = *reinterpret_cast<const float4 *>(&S.a[s0 + 4]);
+        Pn = *reinterpret_cast<const int4 *>(&S.pos[s0 + 4]);
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) commit(len[q], act[q], (unsigned)pv[q]);
       }
@@ -487,7 +510,9 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       // 4.7 us of a heavy tile (10-13 us with act / dsd).
       const unsigned h_last = (unsigned)max(src_n - 1, 0);
       const bool wt_ok = (size_t)W * (size_t)K < ((size_t)1 << 26);      // (byte offsets of the pass's eight rows below 2^31)
-      const unsigned rs_bytes = wt_ok ? 8u * (unsigned)W * (unsigned)K * 4u : 0u;
+      // (the descriptor covers the pass's rows INSIDE the image only: on the last tile row of the last batch element a
+      //  full eight rows would reach past the end of the allocation, and the hardware's range check would protect nothing)
+      const unsigned rs_bytes = wt_ok ? (unsigned)th * (unsigned)W * (unsigned)K * 4u : 0u;
       const __amdgpu_buffer_rsrc_t rs_idx = out_rsrc(t_idx, rs_bytes), rs_len = out_rsrc(t_len, rs_bytes);
       for (int it0 = lane; it0 < nitem; it0 += 64 * kEpiB) {
         int32_t oi[kEpiB][4];

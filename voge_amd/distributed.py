@@ -323,9 +323,37 @@ def _stripe_index(H, world, stripe_h, device):
     return hit
 
 
+_STRIPE_CHECKED = set()
+
+
+def _check_stripe_layout(band, H, stripe_h, group):
+    """Every rank derives the padded layout and the row permutation of the gather LOCALLY from (H, world, stripe_h): a rank
+    that disagrees on any of them -- or on the band's trailing shape -- would scramble the frame silently or hang the
+    collective.  Checked here: locally on every call (this rank's rows; every rank owns at least one stripe), and across
+    the ranks ONCE per layout with one small all_gather of (H, stripe_h, B, W, C) (VOGE_DIST_CHECK=0 turns that off)."""
+    import os
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B, h, W, C = band.shape
+    mine = Stripes(H, rank, world, stripe_h)
+    assert h == mine.h, f"rank {rank}: band has {h} rows, its stripes of an {H}-row frame hold {mine.h}"
+    last = Stripes(H, world - 1, world, stripe_h)
+    assert last.h >= 1, (f"stripes of {stripe_h} rows leave rank {world - 1} of {world} without a row of an {H}-row frame: "
+                         f"use distributed.stripe_height(H, world) = {stripe_height(H, world, stripe_h)}")
+    key = (int(H), int(stripe_h), int(B), int(W), int(C), world, id(group))
+    if key in _STRIPE_CHECKED or os.environ.get("VOGE_DIST_CHECK", "1") == "0":
+        return
+    me = torch.tensor(key[:5], dtype=torch.int64, device=band.device)
+    every = me.new_empty(world * 5)      # (the concatenated form: gloo takes no other)
+    dist.all_gather_into_tensor(every, me, group=group)
+    every = every.view(world, 5)
+    assert bool((every == me[None]).all()), f"ranks disagree on (H, stripe_h, B, W, C): {every.tolist()}"
+    _STRIPE_CHECKED.add(key)
+
+
 def _gather_stripes(band, H, stripe_h, group, async_op=False):
     world = dist.get_world_size(group)
     B, h, W, C = band.shape
+    _check_stripe_layout(band, H, stripe_h, group)
     hmax, index = _stripe_index(H, world, stripe_h, band.device)
     if h == hmax:
         src = band.contiguous()
@@ -349,7 +377,6 @@ class _GatherStripes(torch.autograd.Function):
     def forward(ctx, band, H, stripe_h, group):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         mine = Stripes(H, rank, world, stripe_h)
-        assert band.shape[1] == mine.h
         _, assemble = _gather_stripes(band, H, stripe_h, group)
         ctx.rows = mine.image_rows(band.device)
         return assemble()
