@@ -30,10 +30,10 @@
 extern "C" {
 #endif
 
-#define VOGE_ABI_VERSION 5
+#define VOGE_ABI_VERSION 6
 
 #define VOGE_ERR_BAD_ARG (-1)        /* null pointer / non-positive size */
-#define VOGE_ERR_WORKSPACE (-2)      /* workspace smaller than voge_trace_workspace_bytes() */
+#define VOGE_ERR_WORKSPACE (-2)      /* workspace smaller than one view's voge_trace_workspace_bytes(1, ...) */
 #define VOGE_ERR_K_TOO_LARGE (-3)    /* K above VOGE_MAX_K (top-K lists live in LDS) */
 
 #define VOGE_MAX_K 256
@@ -51,10 +51,14 @@ const char *voge_error_string(int code);
  * image: per-Gaussian derived records (cull sphere + quadratic-form coefficients, 112 B each),
  * the binning's segments (per 32x32-px super-tile and Gaussian slice) with their extension arenas,
  * the per-tile (8x8 px) depth-ordered candidate lists, and a pool of list entries (32 per Gaussian,
- * at least 2^20) for image quads with more candidates than the in-LDS sort takes.  165 MB at
- * 50k Gaussians / 512^2, 774 MB at 200k / 1024^2.  Caller allocates, 256-byte aligned (any torch
- * allocation is); the contents need no initialisation and nothing in it outlives the call except
- * what voge_trace_pool_usage reads.
+ * at least 2^20) for image quads with more candidates than the in-LDS sort takes.  165 MB per view at
+ * 50k Gaussians / 512^2, 774 MB at 200k / 1024^2.  Views are independent: the entry points walk a
+ * batch in CHUNKS of as many views as the scratch holds (stream-ordered launches on the same
+ * buffers), and this function asks for the largest chunk under 1 GiB -- never less than one
+ * view, never more than the batch.  Any size >= one view's (voge_trace_workspace_bytes(1, ...))
+ * is accepted and used in full; pass more to keep a big batch in one chunk.  Caller allocates,
+ * 256-byte aligned (any torch allocation is); the contents need no initialisation and nothing
+ * in it outlives the call except what voge_trace_pool_usage reads (the LAST chunk's pool).
  */
 size_t voge_trace_workspace_bytes(int B, int N, int H, int W);
 
@@ -68,13 +72,10 @@ size_t voge_trace_workspace_bytes(int B, int N, int H, int W);
 int voge_trace_pool_usage(const void *workspace, int B, int N, int H, int W, int *used, int *capacity);
 
 /*
- * Diagnostic / A-B switch (process-wide): which kernel the scalar-sigma forward entry points (voge_trace_topk_fwd_iso*,
- * voge_fragments_fwd_iso*) sweep with.  0 (default): round 4's sweep_iso_kernel (fp32 len + 16-bit stream position per
- * list entry, float-compare commits); 1: round 3's trace_fwd_kernel (64-bit (ord(len), id) keys).  Both produce the same
- * bits (tests/test_gpu_parity.py); the switch exists so that a test can say so and a profile can time both.  No reference
- * counterpart.
+ * (Not part of this ABI: `voge_debug_sweep_variant(int)` exists in -DVOGE_AB builds only -- voge_amd/libvoge_hip_ab.so, a
+ * test artefact that also carries round 3's scalar-sigma sweep for the bit-for-bit comparison in
+ * tests/test_gpu_configs.py::test_rebuilt_sweep_equals_round_3_sweep_bit_for_bit.  The product library is stateless.)
  */
-int voge_debug_sweep_variant(int variant);
 
 /*
  * Fine ray trace forward, "all Gaussians are candidates" form.
@@ -93,9 +94,10 @@ int voge_debug_sweep_variant(int variant);
  * cam_fwd: NULL, or [B,3] unit view axis in the rays' frame: Gaussians with mu.fwd < 0
  * are skipped, which is the candidate rule of the reference's coarse stage
  * (rasterize_coarse.cu:35, "skip z<0") used when max_points_per_bin != -1.
- * cones: NULL, or the bounding cones of the rays' 32x32-pixel super-tiles that voge_rays_fwd /
- * voge_ray_cones produced for exactly this `rays` tensor (voge_cones_floats(B,H,W) floats); they
- * only steer the conservative candidate culling.  NULL costs one more launch that derives them.
+ * cones: NULL, or the bounding-cone hierarchy of the rays (per 32x32-pixel super-tile: its own cone, its four
+ * 16x16 quads', its sixteen 8x8 tiles') that voge_rays_fwd / voge_ray_cones produced for exactly this
+ * `rays` tensor (voge_cones_floats(B,H,W) floats, an opaque blob); they only steer the conservative
+ * candidate culling.  NULL costs one more launch that derives them.
  */
 int voge_trace_topk_fwd(const float *mus, const float *isigmas, const float *rays,
                         const float *cam_fwd, const float *cones, int B, int N, int H, int W, int K,
@@ -462,9 +464,10 @@ int voge_shade_bwd(const float *attr, const int32_t *idx, const float *weight,
  *   origin = -T @ R^-1          (row vectors, X_view = X_world @ R + T).
  * R [B,3,3], T [B,3], focal [B,2], pp [B,2] (principal point, pixels).  Renders image rows
  * row0 .. row0+h-1 (a pixel-row band): rays [B,h,W,3], origin [B,3].
- * cones: NULL, or voge_cones_floats(B,h,W) floats receiving the bounding cone (axis, cos, sin of the
- * half angle, flags) of every 32x32-pixel super-tile of the band: what voge_trace_topk_fwd*'s
- * `cones` argument takes.  They come out of the same arithmetic as the rays, at no extra launch.
+ * cones: NULL, or voge_cones_floats(B,h,W) floats receiving the bounding cones (axis, cos, sin of the
+ * half angle, flags) of every 32x32-pixel super-tile of the band, of its quads and of its 8x8 tiles:
+ * what voge_trace_topk_fwd*'s `cones` argument takes.  They come out of the same arithmetic as the
+ * rays, at no extra launch.
  */
 int voge_rays_fwd(const float *R, const float *T, const float *focal, const float *pp, int B,
                   int row0, int h, int W, float *rays, float *origin, float *cones, voge_stream_t stream);

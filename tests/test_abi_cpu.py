@@ -54,7 +54,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_version_errors_and_sizes_without_gpu(lib):
-    assert lib.voge_abi_version() == 5
+    assert lib.voge_abi_version() == 6
     assert lib.voge_error_string(0) == b"success"
     assert b"K exceeds" in lib.voge_error_string(-3)
     assert b"workspace" in lib.voge_error_string(-2)
@@ -65,7 +65,15 @@ def test_version_errors_and_sizes_without_gpu(lib):
     # argument validation happens before any HIP call
     assert lib.voge_composite_fwd(None, None, None, None, None, 1.0, 10, 0, None, None, None) == -1
     assert lib.voge_trace_topk_fwd(None, None, None, None, None, 1, 10, 8, 8, 1000, 4.6, None, 0, None, None, None, None, None, None) == -3
-    assert lib.voge_cones_floats(2, 65, 33) == 2 * 3 * 2 * 8
+    # the cone hierarchy: 21 records of 8 floats per 32x32-pixel super-tile (its own, 4 quads', 16 tiles')
+    assert lib.voge_cones_floats(2, 65, 33) == 2 * 3 * 2 * 21 * 8
+    # the trace's scratch is sized for a CHUNK of the batch: never below one view, capped at 1 GiB beyond that
+    # (eight 1024^2 views of 200k Gaussians asked for 6.2 GB)
+    one = lib.voge_trace_workspace_bytes(1, 200000, 1024, 1024)
+    assert 700e6 < one < 900e6 and lib.voge_trace_workspace_bytes(8, 200000, 1024, 1024) == one < 1.5e9
+    v512 = lib.voge_trace_workspace_bytes(1, 50000, 512, 512)
+    assert lib.voge_trace_workspace_bytes(8, 50000, 512, 512) <= (1 << 30) < 8 * v512
+    assert lib.voge_trace_workspace_bytes(5, 2562, 128, 128) > 3 * lib.voge_trace_workspace_bytes(1, 2562, 128, 128)   # small batches: one chunk (the list pool's floor does not scale)
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -453,9 +453,15 @@ def test_long_quads_and_segment_extensions_in_a_batch_of_views(hip_lib):
 
 
 # ------------------------------------------------------------------ round 4: the rebuilt scalar-sigma sweep (sweep_iso.h)
-def _sweep_variant(v):
+def _ab_library():
+    """libvoge_hip_ab.so: the -DVOGE_AB build (round 3's scalar-sigma sweep + voge_debug_sweep_variant).  A test artefact: the
+    product library has neither (no process-wide switch in the stable ABI)."""
+    import ctypes
     from voge_amd import _lib
-    assert _lib.load().voge_debug_sweep_variant(v) == 0
+    ctx = _lib.using(_lib.AB_LIB_PATH)
+    lib = ctx.__enter__()
+    lib.voge_debug_sweep_variant.restype, lib.voge_debug_sweep_variant.argtypes = ctypes.c_int, [ctypes.c_int]
+    return ctx, lib
 
 
 @pytest.mark.parametrize("N,H,W,K,B,r_lo,r_hi,extent", [
@@ -463,12 +469,14 @@ def _sweep_variant(v):
     (1500, 40, 56, 25, 2, 0.05, 0.12, 1.0),      # odd K (the slot-by-slot epilogue), two views
     (70000, 96, 96, 12, 1, 0.01, 0.03, 1.0),     # more than 65536 Gaussians: list entries carry stream positions
     (20000, 64, 64, 7, 1, 0.004, 0.009, 0.2),    # a small dense object: pooled lists, segment extensions
+    (70000, 40, 48, 6, 1, 0.6, 0.7, 0.5),        # > 65536 Gaussians that nearly all hit: the stream-everything fallback's wide form
 ])
 def test_rebuilt_sweep_equals_round_3_sweep_bit_for_bit(hip_lib, N, H, W, K, B, r_lo, r_hi, extent):
     """sweep_iso_kernel (fp32 len + 16-bit handle per list entry, float-compare commits) against trace_fwd_kernel<1, true>
     (64-bit (ord(len), id) keys): the same "K lexicographically smallest (len, id)" (ray_trace_voge.cu:197-212), hence the
     same index lists, hit counts and -- the evaluation being the same operations -- the same len / act / dsd bits, with and
-    without act / dsd (voge_debug_sweep_variant switches the kernel)."""
+    without act / dsd (round 3's kernel runs in the -DVOGE_AB build of the library, libvoge_hip_ab.so; the last case is the wide,
+    two-pass form of a stream of more than 65536 entries -- ADVICE r4)."""
     from voge_amd import ops
     rng = np.random.default_rng(N + K)
     verts = rng.uniform(-extent, extent, (N, 3)).astype(np.float32)
@@ -480,14 +488,19 @@ def test_rebuilt_sweep_equals_round_3_sweep_bit_for_bit(hip_lib, N, H, W, K, B, 
     a = np.ascontiguousarray(np.broadcast_to((2 * sig)[None], (B, N))).astype(np.float32)
     thr_act = oracle.thr_act_of(0.01)
     out = {}
+
+    def both():
+        full = [n(x) for x in ops._RayTraceVoGEIso.apply(t(mus.reshape(-1, 3)), t(a.reshape(-1)), t(rays), None, thr_act, K)]
+        li, ll, lz = ops.trace_lean(1, t(mus.reshape(-1, 3)), t(a.reshape(-1)), None, t(rays), None, thr_act, K)      # (no act / dsd)
+        return full, [n(li), n(ll), n(lz.cnt)]
+    out[0] = both()                                   # the product library
+    ctx, ab = _ab_library()
     try:
-        for v in (1, 0):
-            _sweep_variant(v)
-            full = [n(x) for x in ops._RayTraceVoGEIso.apply(t(mus.reshape(-1, 3)), t(a.reshape(-1)), t(rays), None, thr_act, K)]
-            li, ll, lz = ops.trace_lean(1, t(mus.reshape(-1, 3)), t(a.reshape(-1)), None, t(rays), None, thr_act, K)      # (no act / dsd)
-            out[v] = (full, [n(li), n(ll), n(lz.cnt)])
+        assert ab.voge_debug_sweep_variant(1) == 0    # round 3's sweep, in the A/B build
+        out[1] = both()
     finally:
-        _sweep_variant(0)
+        ab.voge_debug_sweep_variant(0)
+        ctx.__exit__()
     assert (out[0][0][0] >= 0).sum() > 500
     for x, y in zip(out[0][0], out[1][0]):
         assert np.array_equal(x, y)

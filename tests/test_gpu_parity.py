@@ -48,7 +48,7 @@ def run_trace(mus, isg, rays, K, thr_act, bins=None, bin_size=0):
 def test_abi_loaded_is_in_tree(hip_lib):
     from voge_amd import _lib
     assert os.path.samefile(os.path.dirname(_lib.LIB_PATH), os.path.join(os.path.dirname(GOLDEN), "..", "voge_amd"))
-    assert hip_lib.voge_abi_version() == 5
+    assert hip_lib.voge_abi_version() == 6
 
 
 def test_trace_fwd_cuboid_config1(hip_lib):
@@ -1148,3 +1148,57 @@ def test_bench_two_ranks_on_one_gpu(hip_lib, mode):
         v = line["variants"]
         assert set(v) == {"row_bands_contiguous", "views_weak_scaling", "cfg4_200k_1024_stripes"}
         assert v["views_weak_scaling"]["scaling"] == "weak" and all(x["value"] > 0 for x in v.values())
+
+
+@pytest.mark.parametrize("form", ["iso", "iso_view_shared", "general", "fragments_iso_lean"])
+def test_batch_walked_in_chunks_equals_one_chunk(hip_lib, form):
+    """the trace's scratch is sized for a chunk of the batch and the entry points walk the batch in chunks
+    (include/voge_hip.h: voge_trace_workspace_bytes).  A three-view batch traced with ONE view's scratch (three chunks: every
+    caller-visible array offset per chunk, the chunk's view-local indices moved up afterwards) must equal the same batch
+    traced in one chunk, bit for bit -- per-view Gaussian sets, a set shared by all views, full 3x3 forms, and the renderer's
+    trace-only form with the records kept."""
+    lib = hip_lib
+    rng = np.random.default_rng(77)
+    B, N, H, W, K = 3, 900, 40, 72, 12
+    verts = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    sig = rng.uniform(60, 250, (B, N)).astype(np.float32)
+    R, T = camera_np.look_at_view_transform([3.2] * B, [12.0] * B, [40.0, 75.0, 130.0])
+    rays, origin = camera_np.pixel_rays(R, T, 60.0, (W / 2.0, H / 2.0), (H, W))
+    rays_t, org_t = t(rays.astype(np.float32)), t(origin.astype(np.float32))
+    cones = torch.empty(int(lib.voge_cones_floats(B, H, W)), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    P_ = lambda x: None if x is None else x.data_ptr()
+    assert lib.voge_ray_cones(P_(rays_t), B, H, W, P_(cones), st) == 0
+    thr_act = oracle.thr_act_of(0.01)
+    mus = t(verts - origin.astype(np.float32)[:, None]).reshape(-1, 3).contiguous()
+    a = t(2 * sig).reshape(-1).contiguous()
+    isg = (t(2 * sig).reshape(-1, 1, 1) * torch.eye(3, device="cuda")).contiguous()
+    isg[::3, 0, 1] = 0.3 * isg[::3, 0, 0]; isg[::3, 1, 0] = isg[::3, 0, 1]            # a third of them anisotropic
+    n_full, n_one = lib.voge_trace_workspace_bytes(B, N, H, W), lib.voge_trace_workspace_bytes(1, N, H, W)
+    assert n_one < n_full
+    outs = []
+    for nws in (n_full, n_one):
+        ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+        idx = torch.full((B, H, W, K), -7, dtype=torch.int32, device="cuda")
+        ln, act, dsd = (torch.full((B, H, W, K), -7.0, device="cuda") for _ in range(3))
+        cnt = torch.full((B, H, W), -7, dtype=torch.int32, device="cuda")
+        rec = torch.full((B * N, 12 if form == "general" else 4), -7.0, device="cuda")
+        if form == "iso":
+            rc = lib.voge_trace_topk_fwd_iso(P_(mus), P_(a), P_(rays_t), None, P_(cones), B, N, H, W, K, thr_act, P_(ws), nws,
+                                             P_(idx), P_(ln), P_(act), P_(dsd), P_(cnt), st)
+        elif form == "iso_view_shared":
+            rc = lib.voge_trace_topk_fwd_iso_view(P_(t(verts[0])), P_(t(sig[0])), P_(org_t), 1, 1, P_(rays_t), None, P_(cones), B, N, H, W, K,
+                                                  thr_act, P_(ws), nws, P_(idx), P_(ln), P_(act), P_(dsd), P_(cnt), st)
+        elif form == "general":
+            rc = lib.voge_trace_lean_fwd(P_(mus), P_(isg), P_(rays_t), None, P_(cones), B, N, H, W, K, thr_act, P_(ws), nws,
+                                         P_(idx), P_(ln), P_(cnt), P_(rec), st)
+        else:
+            rc = lib.voge_fragments_fwd_iso(P_(mus), P_(a), P_(rays_t), None, P_(cones), B, N, H, W, K, thr_act, 1.0, P_(ws), nws,
+                                            P_(idx), P_(ln), None, None, P_(cnt), None, None, P_(rec), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append([n(x) for x in (idx, ln, act, dsd, cnt, rec)])
+    one, chunked = outs
+    assert (one[0] >= 0).mean() > 0.05 and one[0][2].max() >= 2 * N          # the last view's indices address its own Gaussians
+    for name, x, y in zip(("idx", "len", "act", "dsd", "cnt", "records"), one, chunked):
+        assert np.array_equal(x, y), (form, name)

@@ -37,6 +37,9 @@ for which, n, names in ((0, min(nreg, 1024), ["first loads + region cone", "regi
         print(f"  {nm:42s} {d[:, i].mean():6.2f} {d[:, i].max():6.2f}")
     tot = t[:, k - 1] - t[:, 0]
     print(f"  {'total':42s} {tot.mean():6.2f} {tot.max():6.2f}   start spread {t[:, 0].max() - t[:, 0].min():.2f}; first stamp after kernel start")
+    if which == 0:
+        print(f"  entry -> region cone in LDS (wave 0) {(t[:, 6] - t[:, 0]).mean():6.2f} {(t[:, 6] - t[:, 0]).max():6.2f};  -> first Gaussians loaded, records derived "
+              f"{(t[:, 7] - t[:, 6]).mean():6.2f} {(t[:, 7] - t[:, 6]).max():6.2f};  -> through the barrier {(t[:, 1] - t[:, 7]).mean():6.2f} {(t[:, 1] - t[:, 7]).max():6.2f}")
     if which == 1:
         print(f"  entry -> cones done {(t[:, 6] - t[:, 7]).mean():6.2f} {(t[:, 6] - t[:, 7]).max():6.2f};  cones -> rank done {(t[:, 0] - t[:, 6]).mean():6.2f} {(t[:, 0] - t[:, 6]).max():6.2f}"
               f";  first entry -> last end {t[:, k - 1].max() - t[:, 7].min():.1f};  entry spread {t[:, 7].max() - t[:, 7].min():.2f}")

@@ -37,7 +37,10 @@ for case in range(want + 1):
             nB = 1 if views is None else len(views[0])
             rng.normal(size=(nB, H, W, 3)); rng.normal(size=(nB, H, W))
 print(f"case {want}: N={N} {H}x{W} K={K} {form} {pattern} views={None if views is None else len(views[0])}")
-lib = _lib.load()
+import ctypes
+_ctx = _lib.using(_lib.AB_LIB_PATH)      # (the -DVOGE_AB build: both sweeps and the switch between them)
+lib = _ctx.__enter__()
+lib.voge_debug_sweep_variant.restype, lib.voge_debug_sweep_variant.argtypes = ctypes.c_int, [ctypes.c_int]
 out = {}
 for v in (0, 1):
     lib.voge_debug_sweep_variant(v)

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VOGE_HIP_LIB points at another build of the same ABI (kernel tuning variants)
 LIB_PATH = os.environ.get("VOGE_HIP_LIB") or os.path.join(_HERE, "libvoge_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_void_p = ctypes.c_void_p
 _c_int = ctypes.c_int
@@ -23,7 +23,6 @@ SIGNATURES = {
     "voge_error_string": (ctypes.c_char_p, [_c_int]),
     "voge_trace_workspace_bytes": (_c_size_t, [_c_int] * 4),
     "voge_trace_pool_usage": (_c_int, [_c_void_p] + [_c_int] * 4 + [_c_void_p] * 2),
-    "voge_debug_sweep_variant": (_c_int, [_c_int]),
     "voge_trace_topk_fwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_float, _c_void_p, _c_size_t]
                             + [_c_void_p] * 6),
     "voge_trace_topk_list_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 9 + [_c_float] + [_c_void_p] * 6),
@@ -123,6 +122,34 @@ def load():
         raise VogeHipError(f"libvoge_hip.so ABI {got} != expected {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+AB_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvoge_hip_ab.so")
+
+
+class using:
+    """`with _lib.using(path) as lib:` -- every entry point resolves to another build of the library inside the block (the
+    -DVOGE_AB build with round 3's sweep and its switch, for the bit-for-bit test; tools' timing builds).  The product
+    library is untouched: it is a second dlopen with its own globals."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        if not os.path.exists(self.path):
+            raise VogeHipError(f"{self.path} not found (make -C voge_amd/csrc builds it)")
+        lib = ctypes.CDLL(self.path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        self.prev, _lib = _lib, lib
+        return lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
 
 
 def check(code, what):

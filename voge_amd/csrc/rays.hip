@@ -46,7 +46,7 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
     // The workgroups behind the ray blocks: one per 32x32-pixel super-tile, its bounding cone for the trace's
     // binning (voge_trace_topk_fwd*'s `cones`).  The directions are recomputed with the arithmetic below (no loads),
     // so the cones cost the frame nothing: the trace otherwise reads every ray once more to derive them.
-    __shared__ float red[4 * 8];
+    __shared__ ConeHierLds Lc;
     const int nstx = (W + kST - 1) / kST;
     const int st = (int)blockIdx.x - ray_blocks;
     const int x0 = (st % nstx) * kST, y0 = (st / nstx) * kST;
@@ -66,8 +66,10 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
       const float inv = __builtin_amdgcn_rsqf(wx * wx + wy * wy + wz * wz);
       cx[u] = wx * inv; cy[u] = wy * inv; cz[u] = wz * inv;
     }
-    const ConeRec rec = block_cone256<4>(cx, cy, cz, has, min(kST, W - x0) * min(kST, h - y0), red);
-    if (threadIdx.x == 0) cones[(size_t)b * (gridDim.x - ray_blocks) + st] = rec;
+    // (the super-tile's cone and, since round 5, its quads' and tiles': voge_common.h, block_cones_hier256)
+    const size_t nst = gridDim.x - ray_blocks;
+    block_cones_hier256(cx, cy, cz, has, cones + cone_super_at(b, nst, st), cones + cone_quad_at(b, nst, st, 0),
+                        cones + cone_tile_at(b, nst, st, 0), Lc);
     return;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -113,7 +115,7 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
 // The same cones from a ray tensor the caller built any other way (the trace's fallback when it is given none).
 __global__ void __launch_bounds__(256)
 cones_kernel(const float *__restrict__ rays, const int H, const int W, ConeRec *__restrict__ cones) {
-  __shared__ float red[4 * 8];
+  __shared__ ConeHierLds Lc;
   const int b = blockIdx.y, nstx = (W + kST - 1) / kST;
   const int x0 = ((int)blockIdx.x % nstx) * kST, y0 = ((int)blockIdx.x / nstx) * kST;
   const int ly = threadIdx.x >> 3, lx0 = (threadIdx.x & 7) * 4;
@@ -126,8 +128,9 @@ cones_kernel(const float *__restrict__ rays, const int H, const int W, ConeRec *
     const float *r = rays + (((size_t)b * H + min(i, H - 1)) * W + min(j, W - 1)) * 3;
     cx[u] = r[0]; cy[u] = r[1]; cz[u] = r[2];
   }
-  const ConeRec rec = block_cone256<4>(cx, cy, cz, has, min(kST, W - x0) * min(kST, H - y0), red);
-  if (threadIdx.x == 0) cones[(size_t)b * gridDim.x + blockIdx.x] = rec;
+  const size_t nst = gridDim.x;
+  block_cones_hier256(cx, cy, cz, has, cones + cone_super_at(b, nst, blockIdx.x), cones + cone_quad_at(b, nst, blockIdx.x, 0),
+                      cones + cone_tile_at(b, nst, blockIdx.x, 0), Lc);
 }
 
 // Backward, stage 1: per-batch sums over pixels.  part[b][0..8] = d_view^T g_dw (gradient of
@@ -248,7 +251,8 @@ extern "C" int voge_rays_striped_fwd(const float *R, const float *T, const float
 
 extern "C" size_t voge_cones_floats(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return (size_t)B * ((W + kST - 1) / kST) * ((H + kST - 1) / kST) * (sizeof(ConeRec) / sizeof(float));
+  // (per super-tile: its own record, four quad records, sixteen tile records -- voge_common.h, block_cones_hier256)
+  return cone_records((size_t)B, (size_t)((W + kST - 1) / kST) * ((H + kST - 1) / kST)) * (sizeof(ConeRec) / sizeof(float));
 }
 
 extern "C" int voge_ray_cones(const float *rays, int B, int H, int W, float *cones, voge_stream_t stream) {

@@ -62,8 +62,10 @@ __device__ __forceinline__ float4 iso_cull_record(const float mx, const float my
                                                   const float thr_act) {
   float reach = INFINITY;
   if (a > 0.0f && a < 3e38f) {
-    const float nm = sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx)));
-    const float r = sqrtf(fmaxf(thr_act, 0.0f) / (a * (1.0f - 4e-6f))) * (1.0f + 2e-5f) + 2e-5f * nm + 1e-30f;
+    // (hardware square root and reciprocal, ~1 ulp each, far inside the 2e-5 margins: the IEEE sequences were 40 of the
+    //  instructions every workgroup of binA spends per Gaussian before its first test, 16 times over per Gaussian)
+    const float nm = __builtin_amdgcn_sqrtf(fmaf(mz, mz, fmaf(my, my, mx * mx)));
+    const float r = __builtin_amdgcn_sqrtf(fmaxf(thr_act, 0.0f) * __builtin_amdgcn_rcpf(a * (1.0f - 4e-6f))) * (1.0f + 2e-5f) + 2e-5f * nm + 1e-30f;
     reach = r;
     if (!(reach >= 0.0f)) reach = INFINITY;  // NaN guard
     // the lowest mantissa bit of a finite reach says "has an ellipsoid record": never for A = a I (round up to even)
@@ -117,26 +119,54 @@ struct BinALds {
 };
 
 // Gaussian g of batch element b as (centre, reach) -- from the prepared records, or derived on the fly from the
-// scalar-sigma inputs (ISO_PREP), in which case `a_out` also receives a.
+// scalar-sigma inputs (ISO_PREP), in which case `a_out` also receives a.  Two steps, so that a round's loads are all in
+// flight before the first one is waited for (round 5: as one function per Gaussian the compiler had serialised the four
+// Gaussians of a thread -- load, wait, scalar loads of the view, wait, derive, next -- and a workgroup's first round took
+// 3.7 us from kernel entry to "records derived": profiles/r5_bin_times.txt):
+//   binA_fetch: the Gaussian's raw words (an index of -1 reads Gaussian 0: every load is unconditional);
+//   binA_derive: the record from them and the workgroup-uniform view terms (loaded once, BinAView).
+struct BinARaw {
+  float4 v;      // ISO_PREP: (mu as stored, sigma word); else the prepared cull record
+};
+struct BinAView {
+  float ox, oy, oz;      // the batch element's origin (centring of Renderer.py:130), or 0
+  float fx, fy, fz;      // the camera's forward axis (rasterize_coarse.cu:35), valid if has_f
+  bool has_f;
+};
 template <bool ISO_PREP>
-__device__ __forceinline__ float4 binA_record(const int g, const int b, const int N, const float4 *__restrict__ cull,
-                                              const float *__restrict__ mus, const float *__restrict__ isg,
-                                              const float *__restrict__ cam_fwd, const float thr_act, const IsoView view,
-                                              float &a_out) {
-  if (!ISO_PREP) return cull[(size_t)b * N + g];
-  const size_t src = view.shared ? (size_t)g : (size_t)b * N + g;
-  float mx = mus[3 * src + 0], my = mus[3 * src + 1], mz = mus[3 * src + 2];
-  if (view.origin != nullptr) {   // centring of Renderer.py:130: the same single fp32 subtraction
-    const float *o = view.origin + 3 * b;
-    mx -= o[0]; my -= o[1]; mz -= o[2];
+__device__ __forceinline__ BinAView binA_view(const int b, const float *__restrict__ cam_fwd, const IsoView view) {
+  BinAView V;
+  V.ox = V.oy = V.oz = 0.f; V.fx = V.fy = V.fz = 0.f; V.has_f = false;
+  if (ISO_PREP) {
+    if (view.origin != nullptr) { const float *o = view.origin + 3 * b; V.ox = o[0]; V.oy = o[1]; V.oz = o[2]; }
+    if (cam_fwd != nullptr) { const float *f = cam_fwd + 3 * b; V.fx = f[0]; V.fy = f[1]; V.fz = f[2]; V.has_f = true; }
   }
-  const float a = iso_view_a(isg[src], view.mode);
+  return V;
+}
+template <bool ISO_PREP>
+__device__ __forceinline__ BinARaw binA_fetch(const int g, const int b, const int N, const float4 *__restrict__ cull,
+                                              const float *__restrict__ mus, const float *__restrict__ isg, const IsoView view) {
+  BinARaw r;
+  r.v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (N <= 0) return r;      // (uniform: an empty batch element has nothing to read)
+  const int gc = max(g, 0);
+  if (!ISO_PREP) { r.v = cull[(size_t)b * N + gc]; return r; }
+  const size_t src = view.shared ? (size_t)gc : (size_t)b * N + gc;
+  r.v = make_float4(mus[3 * src + 0], mus[3 * src + 1], mus[3 * src + 2], isg[src]);
+  return r;
+}
+template <bool ISO_PREP>
+__device__ __forceinline__ float4 binA_derive(const BinARaw r, const bool valid, const BinAView &V, const float thr_act,
+                                              const IsoView view, float &a_out) {
+  a_out = 0.f;
+  if (!valid) return make_float4(0.f, 0.f, 0.f, -1.f);      // (a padding record: reach -1, never kept)
+  if (!ISO_PREP) return r.v;
+  float mx = r.v.x, my = r.v.y, mz = r.v.z;
+  if (view.origin != nullptr) { mx -= V.ox; my -= V.oy; mz -= V.oz; }   // centring of Renderer.py:130: the same single fp32 subtraction
+  const float a = iso_view_a(r.v.w, view.mode);
   a_out = a;
   float4 c = iso_cull_record(mx, my, mz, a, thr_act);
-  if (cam_fwd != nullptr) {
-    const float *f = cam_fwd + 3 * b;
-    if (fmaf(mz, f[2], fmaf(my, f[1], mx * f[0])) < 0.0f) c.w = -1.0f;   // rasterize_coarse.cu:35 ("skip z < 0")
-  }
+  if (V.has_f && fmaf(mz, V.fz, fmaf(my, V.fy, mx * V.fx)) < 0.0f) c.w = -1.0f;   // rasterize_coarse.cu:35 ("skip z < 0")
   return c;
 }
 
@@ -182,18 +212,23 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
   float4 c[kRoundChunks];
   float av[kRoundChunks];
   int gq[kRoundChunks];
-  auto load_round = [&](const int j0) {
+  const BinAView V = binA_view<ISO_PREP>(b, cam_fwd, view);
+  BinARaw raw[kRoundChunks];
+  auto fetch_round = [&](const int j0) {      // (all of the round's loads go out together ...)
 #pragma unroll
     for (int q = 0; q < kRoundChunks; ++q) {
       const int j = j0 + q * kParts;      // (j % kParts == part)
       const int g = interleaved ? ((j / kParts) * kBinThreads + tid) * kParts + part : j * kBinThreads + tid;
       gq[q] = (j < nchunks && g < N) ? g : -1;
-      av[q] = 0.f;
-      c[q] = (gq[q] >= 0) ? binA_record<ISO_PREP>(g, b, N, cull, mus, isg, cam_fwd, thr_act, view, av[q])
-                          : make_float4(0.f, 0.f, 0.f, -1.f);
+      raw[q] = binA_fetch<ISO_PREP>(gq[q], b, N, cull, mus, isg, view);
     }
   };
-  load_round(part);
+  auto derive_round = [&]() {                 // (... and the records are derived once they are here)
+#pragma unroll
+    for (int q = 0; q < kRoundChunks; ++q) c[q] = binA_derive<ISO_PREP>(raw[q], gq[q] >= 0, V, thr_act, view, av[q]);
+  };
+  auto load_round = [&](const int j0) { fetch_round(j0); derive_round(); };
+  fetch_round(part);
   // ---- the region's child cones, and its own cone as their conservative union (wave 0, lane <-> child): a ray of
   // child i makes at most alpha_i + theta_i with the parent axis (alpha_i = angle between the axes), so
   //   cos >= cos(alpha_i) cs_i - sin(alpha_i) sn_i ,   sin <= sin(alpha_i) + cos(alpha_i) sn_i .
@@ -201,7 +236,7 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
     const int cc = lane & (kCh * kCh - 1);
     const int cx = rx * kCh + (cc & (kCh - 1)), cy = ry * kCh + cc / kCh;
     ConeRec r = {0.f, 0.f, 1.f, 1.f, 0.f, -1.f, 0.f, 0.f};      // ok = -1: no such super-tile
-    if (cx < nstx && cy < nsty) r = cones[(size_t)b * nst + cy * nstx + cx];
+    if (cx < nstx && cy < nsty) r = cones[cone_super_at(b, nst, cy * nstx + cx)];
     if (lane < kCh * kCh) L.child[lane] = r;
     const bool present = lane < kCh * kCh && r.ok >= 0.f;
     const float sx = wave_sum_dpp(present ? r.ax : 0.f), sy = wave_sum_dpp(present ? r.ay : 0.f), sz = wave_sum_dpp(present ? r.az : 0.f);
@@ -257,6 +292,11 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
       if (lane == 0) L.use_rows = (!cn.ok || cn.sn > 1.6f * widest_row) ? 1 : 0;
     }
   }
+  BIN_TS(0, 6);      // (wave 0: the region's cone is in LDS)
+  // (the first round's records: derived behind the cone block, so that wave 0's cone loads -- requested right after its
+  // Gaussians -- and the region's cone overlap the Gaussians' way in instead of following it)
+  derive_round();
+  BIN_TS(0, 7);      // (the first round's Gaussians have arrived and their records are derived)
   __syncthreads();
   const Cone rcone = load_cone(L.region);
   const bool use_rows = L.use_rows != 0;      // (uniform)
@@ -298,23 +338,22 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
         if (lane == 0) L.cnt0[q][wave] = __popcll(m0[q]);
       }
       __syncthreads();
-      if (wave == 0) {     // lane <-> (chunk, wave): exclusive prefix of the 64 counts
-        static_assert(kRoundChunks * 16 == 64, "one lane per (chunk, wave)");
+      // lane <-> (chunk, wave): exclusive prefix of the 64 counts -- by EVERY wave for itself (round 5: wave 0 used to scan
+      // them for all and hand the offsets back through LDS behind one more barrier)
+      static_assert(kRoundChunks * 16 == 64, "one lane per (chunk, wave)");
+      int nS;
+      int my_off[kRoundChunks];
+      {
         const int v = (&L.cnt0[0][0])[lane];
-        int x = v;
+        const int x = wave_incl_scan_i32(v);
+        nS = __builtin_amdgcn_readlane(x, 63);
   #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int y = __shfl_up(x, o, 64);
-          if (lane >= o) x += y;
-        }
-        (&L.cnt0[0][0])[lane] = x - v;
-        if (lane == 63) L.nS = x;
+        for (int q = 0; q < kRoundChunks; ++q) my_off[q] = __shfl(x - v, q * 16 + wave, 64);
       }
-      __syncthreads();
   #pragma unroll
       for (int q = 0; q < kRoundChunks; ++q)
         if (k0[q]) {
-          const int pos = L.cnt0[q][wave] + __popcll(m0[q] & ((1ull << lane) - 1ull));
+          const int pos = my_off[q] + __popcll(m0[q] & ((1ull << lane) - 1ull));
           L.srec[pos] = c[q];
           L.sid[pos] = ROWS ? (gq[q] | (int)(rowm[q] << 27)) : gq[q];      // (ids stay below 2^27: the row mask rides in bits 27..30)
         }
@@ -323,7 +362,6 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
       // (2) survivors x children: wave cc walks ALL survivors against child cc's cone (in registers), four 64-survivor
       // batches per trip.  It is the only writer of that child's segment, so its running count IS the fill position:
       // one pass, no counters in LDS, no barrier, and the order is a pure function of the inputs.
-      const int nS = L.nS;
       {
         const int cc = wave;
         const ConeRec cr = L.child[cc];
@@ -816,7 +854,8 @@ __device__ __forceinline__ void binB_long_path(const BinLong A, BinLds &L) {
 template <bool ELL>
 __global__ void __launch_bounds__(kQT) __attribute__((amdgpu_waves_per_eu(VOGE_BINB_WPE, VOGE_BINB_WPE)))
 binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, const int *__restrict__ seg_count,
-            const int32_t *__restrict__ seg_id, const float4 *__restrict__ seg_rec, const float *__restrict__ rays,
+            const int32_t *__restrict__ seg_id, const float4 *__restrict__ seg_rec,
+            const ConeRec *__restrict__ cones /* the hierarchy of voge_cones_floats: super-tiles, quads, tiles */,
             const int N, const int H, const int W,
             const int nstx, const int nsty, const int nbin_total,
             int *__restrict__ q_count, int32_t *__restrict__ q_id, float *__restrict__ q_lb,
@@ -841,39 +880,27 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   const bool tile_ok = tx < tiles_x && ty < tiles_y;
   const int tile = b * tiles_x * tiles_y + ty * tiles_x + tx;
 
-  // ---- this thread's ray -> the wave's tile cone, and the quad's cone over all four waves ----
-  const int px = min(tx * 8 + (lane & 7), W - 1), py = min(ty * 8 + (lane >> 3), H - 1);
-  const bool has = tile_ok && (tx * 8 + (lane & 7) < W) && (ty * 8 + (lane >> 3) < H);
-  // (everything the prologue needs from memory is requested here, before the first use: the ray, this super-tile's 16
+  // ---- the wave's tile cone and the quad's cone: since round 5 both come with the rays (voge_common.h,
+  // block_cones_hier256: one pass over the super-tile's rays in the ray kernel makes all 21 records).  The workgroup used to
+  // derive them here from its 256 rays -- a memory round trip, four wave reductions and two barriers in front of its first
+  // useful load (entry -> cones done: 3.8 us of the 11.5 us a workgroup lasts, profiles/r5_bin_times.txt).
+  // (everything the prologue needs from memory is requested here, before the first use: the two cones, this super-tile's 16
   // segment counts, and the counts the launch rank is estimated from)
-  const float *rp = rays + (((size_t)b * H + min(py, H - 1)) * W + min(px, W - 1)) * 3;
-  const float ray_x = rp[0], ray_y = rp[1], ray_z = rp[2];
+  const ConeRec tcr = cones[cone_tile_at(b, (size_t)nstx * nsty, binl, ((qq >> 1) * 2 + (wave >> 1)) * 4 + (qq & 1) * 2 + (wave & 1))];
+  const ConeRec qcr = cones[cone_quad_at(b, (size_t)nstx * nsty, binl, qq)];
   const int my_cnt = (tid < kParts) ? seg_count[(size_t)bin * kParts + tid] : 0;
   const bool ranked = nbin_total <= kRankMaxBins;
   const int4 est0 = (ranked && tid < nbin_total) ? *reinterpret_cast<const int4 *>(seg_count + (size_t)tid * kParts) : make_int4(0, 0, 0, 0);
   const int4 est_mine = ranked ? *reinterpret_cast<const int4 *>(seg_count + (size_t)bin * kParts) : make_int4(0, 0, 0, 0);
-  const RayDir u = ray_dir(ray_x, ray_y, ray_z);
-  Cone tcone, qcone;
+  const Cone tcone = load_cone(tcr), qcone = load_cone(qcr);
   {
-    const float wsx = wave_sum_dpp((has && u.ok) ? u.ux : 0.f), wsy = wave_sum_dpp((has && u.ok) ? u.uy : 0.f),
-                wsz = wave_sum_dpp((has && u.ok) ? u.uz : 0.f);
-    const bool wok = __all(!has || u.ok);
-    {
-      const float n = sqrtf(fmaf(wsz, wsz, fmaf(wsy, wsy, wsx * wsx)));
-      const float ax = wsx / n, ay = wsy / n, az = wsz / n;
-      float smax = 0.f, cmin = 1.f;
-      if (has) cone_partial(u, ax, ay, az, smax, cmin);
-      tcone = cone_finish(ax, ay, az, n, wave_max(smax), wave_min(cmin), wok);
-    }
-    if (lane == 0) { L.red[wave * 8 + 0] = wsx; L.red[wave * 8 + 1] = wsy; L.red[wave * 8 + 2] = wsz; L.red[wave * 8 + 3] = wok ? 1.f : 0.f; }
     if (tid == 0) { L.count = 0; L.nflag = 0; L.spill = 0; }
     // A segment that overflowed its kSegCap entries (more than 512 of a slice's Gaussians in one super-tile: a small
     // object far away, a zoomed-out view) does not send the quad to the stream-everything fallback any more: the
     // slice's Gaussians -- N / kParts of them -- are tested against the quad's cone right here, from the records
     // binA / prep left per Gaussian.  Only a quad list beyond kQCap still falls back.
-    // (The 16 counts were requested at the kernel's entry, one per lane, together with the rays and the ranking's counts:
-    // one memory round trip in front of the source pass instead of three dependent ones -- thread 0 used to load them in a
-    // loop AFTER the cones.  Their prefix sums are a 16-lane scan.)
+    // (The 16 counts were requested at the kernel's entry, one per lane, together with the cones and the ranking's counts.
+    // Their prefix sums are a 16-lane scan.)
     if (wave == 0) {
       int c = (lane < kParts) ? my_cnt : 0;
       const unsigned long long ofm = __ballot(lane < kParts && c < 0);      // (its Gaussians come from the records, last loop of bin_stream_sources)
@@ -898,19 +925,6 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
       L.exto[p][q] = (q * kExtChunk < ne) ? seg_ext[((size_t)bin * kParts + p) * kExtChunks + q] : 0;
     };
     if (L.extn[kParts] > 0) load_ext_tables();      // (uniform, rare; the tables share their LDS with the sort's histogram)
-    const float gx = L.red[0] + L.red[8] + L.red[16] + L.red[24], gy = L.red[1] + L.red[9] + L.red[17] + L.red[25],
-                gz = L.red[2] + L.red[10] + L.red[18] + L.red[26];
-    const bool gok = (L.red[3] != 0.f) && (L.red[11] != 0.f) && (L.red[19] != 0.f) && (L.red[27] != 0.f);
-    const float n = sqrtf(fmaf(gz, gz, fmaf(gy, gy, gx * gx)));
-    const float ax = gx / n, ay = gy / n, az = gz / n;
-    float smax = 0.f, cmin = 1.f;
-    if (has) cone_partial(u, ax, ay, az, smax, cmin);
-    smax = wave_max(smax); cmin = wave_min(cmin);
-    if (lane == 0) { L.red[wave * 8 + 4] = smax; L.red[wave * 8 + 5] = cmin; }
-    __syncthreads();
-    smax = fmaxf(fmaxf(L.red[4], L.red[12]), fmaxf(L.red[20], L.red[28]));
-    cmin = fminf(fminf(L.red[5], L.red[13]), fminf(L.red[21], L.red[29]));
-    qcone = cone_finish(ax, ay, az, n, smax, cmin, gok);
   }
   BIN_TS(1, 0);
 

@@ -1059,7 +1059,7 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
   size_t off = 0;
   char *p = reinterpret_cast<char *>(base);
   auto take = [&](size_t bytes) { char *q = p ? p + off : nullptr; off += align256(bytes); return q; };
-  char *c = take(P * 16), *e = take(P * 48), *m4 = take(P * 16), *el = take(P * 32), *cn = take(nbin * sizeof(ConeRec)),
+  char *c = take(P * 16), *e = take(P * 48), *m4 = take(P * 16), *el = take(P * 32), *cn = take(cone_records(1, nbin) * sizeof(ConeRec)),
        *sc = take(nbin * kParts * 4), *si = take(nbin * kParts * (size_t)kSegCap * 4), *bc = take(nbin * 4 * 4),
        *bi = take(nbin * 4 * kQCap * 4), *bl = take(nbin * 4 * kQCap * 4), *tc = take(ntile * 4),
        *ti = take(ntile * kTileCap * 4), *tl = take(ntile * kTileCap * 4), *sr = take(nbin * kParts * (size_t)kSegCap * 16),
@@ -1128,12 +1128,18 @@ __global__ void __launch_bounds__(1024) order_sort_kernel(const int2 *__restrict
   }
 }
 
+#ifndef VOGE_FUSED_EPILOGUE
+#define VOGE_FUSED_EPILOGUE 0      // (experiment, see trace_chunk_fwd) composite inside the sweep's epilogue
+#endif
 #ifndef VOGE_SWEEP_LDS_PAD
 #define VOGE_SWEEP_LDS_PAD 0      // (occupancy experiments: extra dynamic LDS per workgroup)
 #endif
-// 0: default kernels; 1: round 3's scalar-sigma sweep (trace_fwd_kernel<1, true>) instead of sweep_iso_kernel -- for A/B
-// timing and the bit-for-bit comparison in tests/ (voge_debug_sweep_variant)
+// -DVOGE_AB builds only (libvoge_hip_ab.so, never the product library): a process-wide switch between sweep_iso_kernel (0)
+// and round 3's scalar-sigma sweep, trace_fwd_kernel<1, true> (1) -- for A/B timing and the bit-for-bit comparison in
+// tests/test_gpu_configs.py (voge_debug_sweep_variant).  The product library has neither the switch nor the old kernel.
+#ifdef VOGE_AB
 static std::atomic<int> g_sweep_variant{0};
+#endif
 // binB + the sweep (one wave = one 8x8-pixel tile per workgroup)
 template <bool ISO>
 static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *rays, int B, int N, int H, int W, int K,
@@ -1144,9 +1150,17 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
   const size_t comp = (weight != nullptr) ? sizeof(float) * 3 * (size_t)compn_rows(K, 4, 64, true) : 0;
   const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + ((sizeof(TraceLds<T, ISO>) + 15) & ~(size_t)15) +
                      comp + VOGE_SWEEP_LDS_PAD;
-  auto kern = trace_fwd_kernel<1, ISO>;
   // scalar sigmas, no composite inside the epilogue: round 4's kernel (sweep_iso.h: float-compare commits, 6-byte list entries)
+#ifdef VOGE_AB
   const bool v2 = ISO && VOGE_SWEEP_V2 && weight == nullptr && g_sweep_variant.load(std::memory_order_relaxed) != 1;
+  constexpr bool kOldIso = true;
+#else
+  const bool v2 = ISO && VOGE_SWEEP_V2 && weight == nullptr;
+  constexpr bool kOldIso = !VOGE_SWEEP_V2 || VOGE_FUSED_EPILOGUE;      // (the product keeps round 3's ISO kernel out of the library)
+  if (ISO && !v2 && !kOldIso) return VOGE_ERR_BAD_ARG;
+#endif
+  // (ISO && !kOldIso: the name below is the general kernel's -- never launched for scalar sigmas, see the check above)
+  auto kern = trace_fwd_kernel<1, ISO && kOldIso>;
   const size_t lds2 = sweep2_lds_bytes(K) + VOGE_SWEEP_LDS_PAD;
   {
     static DynLdsCache cache, cache2;
@@ -1155,7 +1169,7 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
     if (rc) return rc;
   }
   hipLaunchKernelGGL(binB_kernel<!ISO>, dim3(ws.nstx * ws.nsty * 4, B), dim3(kQT), 0, st, ws.cull, ws.ell, ws.seg_count, ws.seg_id, ws.seg_rec,
-                     rays, N, H, W, ws.nstx, ws.nsty, ws.nbin, ws.q_count, ws.q_id, ws.q_lb, ws.tl_count, ws.tl_id, ws.tl_lb,
+                     cones, N, H, W, ws.nstx, ws.nsty, ws.nbin, ws.q_count, ws.q_id, ws.q_lb, ws.tl_count, ws.tl_id, ws.tl_lb,
                      ws.order, ws.pool_top, ws.pool_cap, ws.pool_id, ws.pool_lb, ws.tl_off, ws.seg_ext, ws.ext_id, K,
                      (v2 && act == nullptr) ? nullptr : idx /* (sweep_iso_kernel writes the empty tiles itself) */, len, act, dsd, cnt,
                      weight, valid_num);
@@ -1210,21 +1224,35 @@ extern "C" int voge_debug_bin_times(unsigned long long *out, int which, int n_wg
 }
 #endif
 
+#ifdef VOGE_AB
 extern "C" int voge_debug_sweep_variant(int variant) {
   if (variant < 0 || variant > 1) return VOGE_ERR_BAD_ARG;
   voge::g_sweep_variant.store(variant, std::memory_order_relaxed);
   return 0;
 }
+#endif
 
+// Round 5: the scratch is sized for a CHUNK of the batch, not for all of it (it used to be B x 165 MB at 512^2, B x 774 MB at
+// 1024^2: 6.2 GB for eight 1024^2 views).  Views are independent in every stage, so the entry points walk a batch in
+// chunks of as many views as the scratch they were given holds -- stream-ordered launches on the same buffers -- and the
+// size asked for here is what the largest chunk under kTraceWsCap needs (never less than one view).  A caller that wants a
+// big batch in ONE chunk passes more: any size >= this is accepted and used.
+constexpr size_t kTraceWsCap = (size_t)1 << 30;
+static int trace_views_that_fit(const int B, const int N, const int H, const int W, const size_t bytes) {
+  int nb = 1;      // (layout is monotone in the view count: the largest nb whose layout fits)
+  for (int step = B; step >= 1; step >>= 1)
+    while (nb + step <= B && trace_ws_layout(nb + step, N, H, W, nullptr, nullptr) <= bytes) nb += step;
+  return nb;
+}
 extern "C" size_t voge_trace_workspace_bytes(int B, int N, int H, int W) {
   if (B <= 0 || N < 0 || H <= 0 || W <= 0) return 0;
-  return trace_ws_layout(B, N, H, W, nullptr, nullptr);
+  return trace_ws_layout(trace_views_that_fit(B, N, H, W, kTraceWsCap), N, H, W, nullptr, nullptr);
 }
 
 extern "C" int voge_trace_pool_usage(const void *workspace, int B, int N, int H, int W, int *used, int *capacity) {
   if (!workspace || !used || !capacity || B <= 0 || N < 0 || H <= 0 || W <= 0) return VOGE_ERR_BAD_ARG;
-  TraceWs ws;
-  trace_ws_layout(B, N, H, W, const_cast<void *>(workspace), &ws);
+  TraceWs ws;      // (the pool of the LAST chunk the entry point walked: chunks share the scratch)
+  trace_ws_layout(trace_views_that_fit(B, N, H, W, kTraceWsCap), N, H, W, const_cast<void *>(workspace), &ws);
   *capacity = ws.pool_cap;
   unsigned long long top = 0ull;
   const hipError_t e = hipMemcpy(&top, ws.pool_top, sizeof(top), hipMemcpyDeviceToHost);
@@ -1236,6 +1264,26 @@ extern "C" int voge_ray_cones(const float *rays, int B, int H, int W, float *con
 extern "C" int voge_composite_fwd_iso(const int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                                       const float *rays, float occ, long npix, int K, float *weight, int64_t *valid_num,
                                       voge_stream_t stream);                                                     // composite.hip
+
+// idx[i] += off where idx[i] >= 0 (a chunk's indices are local to its first view: see trace_topk_fwd_impl)
+__global__ void __launch_bounds__(256) idx_rebase_kernel(int32_t *__restrict__ idx, const size_t n4, const int off) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    int4 v = reinterpret_cast<int4 *>(idx)[i];
+    v.x = v.x >= 0 ? v.x + off : v.x; v.y = v.y >= 0 ? v.y + off : v.y; v.z = v.z >= 0 ? v.z + off : v.z; v.w = v.w >= 0 ? v.w + off : v.w;
+    reinterpret_cast<int4 *>(idx)[i] = v;
+  }
+}
+__global__ void __launch_bounds__(256) idx_rebase1_kernel(int32_t *__restrict__ idx, const size_t n, const int off) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = idx[i];
+    if (v >= 0) idx[i] = v + off;
+  }
+}
+
+static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mus, const float *isigmas, const float *rays,
+                           const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
+                           float thr_act, void *workspace, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
+                           voge_stream_t stream, float occ, float *weight, int64_t *valid_num, float *records);
 
 static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float *mus, const float *isigmas, const float *rays,
                                const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
@@ -1254,9 +1302,49 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
                           cnt != nullptr && (long)B * N < (1l << 26)))
     return VOGE_ERR_BAD_ARG;
   if (N > 0 && (!mus || !isigmas)) return VOGE_ERR_BAD_ARG;
-  if (workspace_bytes < voge_trace_workspace_bytes(B, N, H, W)) return VOGE_ERR_WORKSPACE;
+  // (one view's scratch is the least that works; voge_trace_workspace_bytes(B, ...) is what to allocate)
+  if (workspace_bytes < trace_ws_layout(1, N, H, W, nullptr, nullptr)) return VOGE_ERR_WORKSPACE;
   // the top-K lists of one 8x8 tile must fit the CU's LDS: validated before anything is enqueued
   if (sizeof(uint64_t) * (size_t)(K + 1) * 65 + 16 + sizeof(TraceLds<64, false>) > 160 * 1024) return VOGE_ERR_K_TOO_LARGE;
+  // ---- the batch in chunks of as many views as the scratch holds (all of them, when it was sized for that): every array the
+  // caller sees is offset to the chunk's first view, the chunk runs as a batch of its own, and the indices it wrote -- local
+  // to that first view -- are moved up by b0 N afterwards (one pass over idx, chunks behind the first only)
+  const int per = trace_views_that_fit(B, N, H, W, workspace_bytes);
+  const size_t npv = (size_t)H * W;      // pixels per view
+  const size_t nst = (size_t)((W + kST - 1) / kST) * ((H + kST - 1) / kST);
+  const size_t stride_mu = view.shared ? 0 : (size_t)N * 3, stride_sg = view.shared ? 0 : (size_t)N * (iso_in ? 1 : 9);
+  for (int b0 = 0; b0 < B; b0 += per) {
+    const int nb = (B - b0 < per) ? B - b0 : per;
+    IsoView v = view;
+    if (v.origin != nullptr) v.origin += 3 * (size_t)b0;
+    auto at = [&](auto *p, const size_t per_view) { return p ? p + (size_t)b0 * per_view : p; };
+    const int rc = trace_chunk_fwd(iso_in, v, at(mus, stride_mu), at(isigmas, stride_sg), at(rays, npv * 3), at(cam_fwd, 3),
+                                   at(cones_in, nst * kConeRecsPerST * (sizeof(ConeRec) / sizeof(float))), nb, N, H, W, K, thr_act, workspace,
+                                   at(idx, npv * K), at(len, npv * K), at(act, npv * K), at(dsd, npv * K), at(cnt, npv), stream, occ,
+                                   at(weight, npv * K), at(valid_num, npv), at(records, (size_t)N * (iso_in ? 4 : 12)));
+    if (rc) return rc;
+    if (b0 > 0 && N > 0) {
+      const size_t n = (size_t)nb * npv * K;
+      int32_t *ic = idx + (size_t)b0 * npv * K;
+      if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(ic) & 15) == 0) {
+        const size_t n4 = n >> 2;
+        hipLaunchKernelGGL(idx_rebase_kernel, dim3((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0,
+                           (hipStream_t)stream, ic, n4, b0 * N);
+      } else {
+        hipLaunchKernelGGL(idx_rebase1_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
+                           (hipStream_t)stream, ic, n, b0 * N);
+      }
+      const int rc2 = launch_status();
+      if (rc2) return rc2;
+    }
+  }
+  return 0;
+}
+
+static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mus, const float *isigmas, const float *rays,
+                           const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
+                           float thr_act, void *workspace, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
+                           voge_stream_t stream, float occ, float *weight, int64_t *valid_num, float *records) {
   hipStream_t st = (hipStream_t)stream;
   const int P = B * N;
   TraceWs ws;
@@ -1292,9 +1380,6 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   // built and measured: the sweep holds ~1.5 waves per SIMD (its top-K lists fill the LDS), so the composite's row
   // walks run latency-bound there -- sweep 64 -> 142 us at cfg3 against 52 us for the kernel it would replace, which
   // does the same instructions at eight waves per SIMD and reads its 126 MB mostly from the Infinity Cache.
-#ifndef VOGE_FUSED_EPILOGUE
-#define VOGE_FUSED_EPILOGUE 0
-#endif
   const bool fused = VOGE_FUSED_EPILOGUE && weight != nullptr && (K & 3) == 0 && K <= 256 && cnt != nullptr;
   int rc;
 #ifndef VOGE_NO_ISO_SWEEP

@@ -364,6 +364,16 @@ __device__ __forceinline__ float wave_min(float v) {
   v = fminf(v, VOGE_DPP(v, 0x140));
   return fminf(fminf(VOGE_LANE(v, 0), VOGE_LANE(v, 16)), fminf(VOGE_LANE(v, 32), VOGE_LANE(v, 48)));
 }
+// inclusive prefix sum of one int per lane over the wave (DPP row shifts, then the row totals)
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+  return v;
+}
 __device__ __forceinline__ float wave_sum_dpp(float v) {
   v += VOGE_DPP(v, 0xB1);
   v += VOGE_DPP(v, 0x4E);
@@ -485,6 +495,126 @@ __device__ __forceinline__ ConeRec block_cone256(const float (&rx)[NR], const fl
   // v_rsq is good to ~1 ulp: pad the bounds by 4e-7 relative on top of cone_finish's margins
   const Cone c = cone_finish(ax, ay, az, n / (float)max(npx, 1), sqrtf(s2max) * (1.0f + 4e-7f) + 4e-7f, cmin - 4e-7f, okf != 0.f);
   return ConeRec{c.ax, c.ay, c.az, c.cs, c.sn, c.ok ? 1.f : 0.f, 0.f, 0.f};
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 5: the whole cone hierarchy of a 32x32-pixel super-tile from ONE pass over its rays -- the super-tile's own cone
+// (what block_cone256 returns), its four 16x16-pixel QUAD cones and its sixteen 8x8-pixel TILE cones.  binB used to
+// derive the last two itself, per workgroup, from the rays (a memory round trip, two wave reductions and two barriers in
+// front of its first useful load: 3.8 us of its 11.5 us mean critical path, profiles/r5_bin_times.txt); now it loads them.
+// Layout of the `cones` buffer (voge_cones_floats), per batch element (so that a sub-batch is a pointer offset):
+// [nst] super-tile records, then [nst][4] quad records (quad qy * 2 + qx), then [nst][16] tile records (tile ty * 4 + tx,
+// local to the super-tile): kConeRecsPerST records per super-tile in all.
+// Thread t of the 256 holds the four rays (x = 4 (t & 7) .. + 3, y = t >> 3) of the super-tile: a tile is the 16 lanes of
+// wave ty whose ((lane & 7) >> 1) == tx, i.e. the lanes reached by xor 1, 8, 16, 32.
+// ------------------------------------------------------------------------------------------
+struct ConeHierLds {
+  float4 sum[16];      // per tile: (sum of the unit directions, all finite)
+  float cnt[16];       // per tile: rays inside the image
+  float ext[16][6];    // per tile: (s2max, cmin) w.r.t. the tile's, its quad's and the super-tile's axis
+};
+constexpr int kConeRecsPerST = 21;
+// record index of batch element b's super-tile st / its quad q / its tile t (nst = super-tiles per batch element)
+__host__ __device__ inline size_t cone_super_at(const size_t b, const size_t nst, const size_t st) { return b * nst * kConeRecsPerST + st; }
+__host__ __device__ inline size_t cone_quad_at(const size_t b, const size_t nst, const size_t st, const int q) { return b * nst * kConeRecsPerST + nst + st * 4 + q; }
+__host__ __device__ inline size_t cone_tile_at(const size_t b, const size_t nst, const size_t st, const int t) { return b * nst * kConeRecsPerST + nst * 5 + st * 16 + t; }
+__host__ __device__ inline size_t cone_records(const size_t B, const size_t nst) { return B * nst * kConeRecsPerST; }
+__device__ __forceinline__ float tile16_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float tile16_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+__device__ __forceinline__ float tile16_min(float v) {
+  v = fminf(v, __shfl_xor(v, 1, 64)); v = fminf(v, __shfl_xor(v, 8, 64)); v = fminf(v, __shfl_xor(v, 16, 64)); v = fminf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+__device__ __forceinline__ void block_cones_hier256(const float (&rx)[4], const float (&ry)[4], const float (&rz)[4], const unsigned has,
+                                                    ConeRec *__restrict__ c_super, ConeRec *__restrict__ c_quad /* [4] */,
+                                                    ConeRec *__restrict__ c_tile /* [16] */, ConeHierLds &L) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ltx = (lane & 7) >> 1, tile = wave * 4 + ltx;
+  float sx = 0.f, sy = 0.f, sz = 0.f, okf = 1.f, np = 0.f;
+  float inv[4];
+  bool fin[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float dn2 = fmaf(rz[k], rz[k], fmaf(ry[k], ry[k], rx[k] * rx[k]));
+    const bool on = (has >> k) & 1u;
+    fin[k] = dn2 > 1e-30f && dn2 < 1e30f;
+    inv[k] = __builtin_amdgcn_rsqf(dn2);
+    sx += (on && fin[k]) ? rx[k] : 0.f; sy += (on && fin[k]) ? ry[k] : 0.f; sz += (on && fin[k]) ? rz[k] : 0.f;
+    okf = (on && !fin[k]) ? 0.f : okf;
+    np += on ? 1.f : 0.f;
+  }
+  sx = tile16_sum(sx); sy = tile16_sum(sy); sz = tile16_sum(sz); okf = tile16_min(okf); np = tile16_sum(np);
+  if ((lane & 0x39) == 0) { L.sum[tile] = make_float4(sx, sy, sz, okf); L.cnt[tile] = np; }      // (the tile's first lane)
+  __syncthreads();
+  // the three axes this thread's rays are measured against: its tile's, its quad's, the super-tile's
+  float ax[3], ay[3], az[3];
+  {
+    float qx = 0.f, qy = 0.f, qz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    const int q0 = (wave & 2) * 4 + (ltx & 2);      // the quad's first tile
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float4 v = L.sum[i];
+      gx += v.x; gy += v.y; gz += v.z;
+      const bool inq = (i == q0) || (i == q0 + 1) || (i == q0 + 4) || (i == q0 + 5);
+      qx += inq ? v.x : 0.f; qy += inq ? v.y : 0.f; qz += inq ? v.z : 0.f;
+    }
+    const float vx[3] = {sx, qx, gx}, vy[3] = {sy, qy, gy}, vz[3] = {sz, qz, gz};
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      const float n = sqrtf(fmaf(vz[l], vz[l], fmaf(vy[l], vy[l], vx[l] * vx[l])));
+      ax[l] = vx[l] / n; ay[l] = vy[l] / n; az[l] = vz[l] / n;
+    }
+  }
+  float s2m[3] = {0.f, 0.f, 0.f}, cmn[3] = {1.f, 1.f, 1.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool on = (has >> k) & 1u;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      const float da = fmaf(rz[k], az[l], fmaf(ry[k], ay[l], rx[k] * ax[l]));
+      const float qx = fmaf(-da, ax[l], rx[k]), qy = fmaf(-da, ay[l], ry[k]), qz = fmaf(-da, az[l], rz[k]);
+      const float s2 = fmaf(qz, qz, fmaf(qy, qy, qx * qx)) * (inv[k] * inv[k]);
+      s2m[l] = on ? fmaxf(s2m[l], fin[k] ? s2 : 4.0f) : s2m[l];
+      cmn[l] = on ? fminf(cmn[l], fin[k] ? da * inv[k] : -1.0f) : cmn[l];
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < 3; ++l) { s2m[l] = tile16_max(s2m[l]); cmn[l] = tile16_min(cmn[l]); }
+  if ((lane & 0x39) == 0) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l) { L.ext[tile][2 * l] = s2m[l]; L.ext[tile][2 * l + 1] = cmn[l]; }
+  }
+  __syncthreads();
+  if (t < 21) {      // threads 0..15: the tiles; 16..19: the quads; 20: the super-tile
+    const int level = t < 16 ? 0 : (t < 20 ? 1 : 2);
+    const int q0 = (t >= 16 && t < 20) ? ((t - 16) >> 1) * 8 + ((t - 16) & 1) * 2 : 0;
+    float vx = 0.f, vy = 0.f, vz = 0.f, ok = 1.f, n_in = 0.f, s2 = 0.f, cm = 1.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bool in = level == 0 ? (i == t) : (level == 1 ? ((i == q0) || (i == q0 + 1) || (i == q0 + 4) || (i == q0 + 5)) : true);
+      const float4 v = L.sum[i];
+      const float c = L.cnt[i];
+      vx += in ? v.x : 0.f; vy += in ? v.y : 0.f; vz += in ? v.z : 0.f;
+      ok = (in && c > 0.f) ? fminf(ok, v.w) : ok;
+      n_in += in ? c : 0.f;
+      const float e_s = level == 0 ? L.ext[i][0] : (level == 1 ? L.ext[i][2] : L.ext[i][4]);
+      const float e_c = level == 0 ? L.ext[i][1] : (level == 1 ? L.ext[i][3] : L.ext[i][5]);
+      s2 = (in && c > 0.f) ? fmaxf(s2, e_s) : s2;
+      cm = (in && c > 0.f) ? fminf(cm, e_c) : cm;
+    }
+    const float n = sqrtf(fmaf(vz, vz, fmaf(vy, vy, vx * vx)));
+    // v_rsq is good to ~1 ulp: pad the bounds by 4e-7 relative on top of cone_finish's margins (as block_cone256)
+    const Cone c = cone_finish(vx / n, vy / n, vz / n, n / fmaxf(n_in, 1.f), sqrtf(s2) * (1.0f + 4e-7f) + 4e-7f, cm - 4e-7f, ok != 0.f);
+    // (a tile / quad without a pixel inside the image: ok = -1, "no such tile" -- nothing is ever tested against it)
+    const ConeRec rec = {c.ax, c.ay, c.az, c.cs, c.sn, n_in > 0.f ? (c.ok ? 1.f : 0.f) : -1.f, 0.f, 0.f};
+    if (level == 0) c_tile[t] = rec; else if (level == 1) c_quad[t - 16] = rec; else *c_super = rec;
+  }
 }
 
 // Does the cull record carry an ellipsoid record (trace_fwd.hip, prep_one)?
