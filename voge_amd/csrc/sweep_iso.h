@@ -148,12 +148,17 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   if (lane < kS2Pad) { S.x[64 + lane] = 0.f; S.y[64 + lane] = 0.f; S.z[64 + lane] = 0.f; S.a[64 + lane] = INFINITY; }
 
   // ---- the wave's bounding cone over all 64 rays of the tile (only a cone-filtered stream needs it), unit-ray flag ----
+  // (evaluated inside run(), BEHIND the first requests for the tile's list: the flag is needed at the first exit test only,
+  // and as a block in front of run() its ray load was waited for -- one memory round trip -- before the list's ids were
+  // even asked for: the prologue was order -> rays -> ids -> records, four dependent trips; now rays and ids travel together)
   Cone wcone;
-  bool unit_rays;
-  {
+  bool unit_rays = false;
+  wcone.ok = false;
+  auto ray_setup = [&](const bool mine, const float mdx, const float mdy, const float mdz) {
+    // (mine: the caller's (dx, dy, dz) IS lane's ray of the tile -- the 16-bit form; the wide form's lanes hold other rays)
     const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
     const size_t rid = ((size_t)b * H + min(py, H - 1)) * W + min(px, W - 1);
-    const RayDir u = ray_dir(rays[3 * rid + 0], rays[3 * rid + 1], rays[3 * rid + 2]);
+    const RayDir u = mine ? ray_dir(mdx, mdy, mdz) : ray_dir(rays[3 * rid + 0], rays[3 * rid + 1], rays[3 * rid + 2]);
     unit_rays = __all(!u.ok || u.unit);
     wcone.ok = false;
     if (!pref) {      // (uniform)
@@ -165,7 +170,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       cone_partial(u, ax, ay, az, smax, cmin);
       wcone = cone_finish(ax, ay, az, n, wave_max(smax), wave_min(cmin), dirs_ok);
     }
-  }
+  };
 
   // One pass = the whole trace of the rays it covers: all 64 (16-bit positions) or rows [4 pass, 4 pass + 4) of the tile
   // on lanes 0..31 (32-bit positions; lanes 32..63 evaluate along and never commit).
@@ -176,7 +181,30 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
     const int px = tx * 8 + (r & 7), py = ty * 8 + (r >> 3);
     const bool valid = (px < W) && (py < H) && (!WIDE || lane < 32);
     const size_t ray_id = ((size_t)b * H + min(py, H - 1)) * W + min(px, W - 1);
+    // (the list's first two chunks of ids and bounds are requested before anything else -- see ray_setup)
+    int id0 = (lane < src_n) ? (binned ? src_id[lane] : lane) : -1;
+    float lb0 = (binned && lane < src_n) ? src_lb[lane] : -INFINITY;
+    int id1 = (64 + lane < src_n) ? (binned ? src_id[64 + lane] : 64 + lane) : -1;
+    float lb1 = (binned && 64 + lane < src_n) ? src_lb[64 + lane] : -INFINITY;
     const float dx = rays[3 * ray_id + 0], dy = rays[3 * ray_id + 1], dz = rays[3 * ray_id + 2];
+    // (unconditional 16-byte loads at a clamped index, then a select: the `id >= 0 ? load : constant` form compiled into four
+    //  dword loads per record)
+    //  dword loads per record, each in an exec-mask region of its own -- and the compiler re-derives that from any select
+    //  around a plain load.  Buffer loads: an id of -1 is an offset beyond the range and reads zeros, .w is fixed up.)
+    const __amdgpu_buffer_rsrc_t rs_ms = out_rsrc(const_cast<float4 *>(msb), (unsigned)N * 16u),
+                                 rs_cull = out_rsrc(const_cast<float4 *>(cullb), (unsigned)N * 16u);
+    auto load_ms = [&](const int id) {
+      const voge_v4f r = __builtin_amdgcn_raw_buffer_load_b128(rs_ms, id * 16, 0, 0);
+      return make_float4(r[0], r[1], r[2], (id >= 0) ? r[3] : INFINITY);
+    };
+    auto load_cull = [&](const int id) {
+      const voge_v4f r = __builtin_amdgcn_raw_buffer_load_b128(rs_cull, id * 16, 0, 0);
+      return make_float4(r[0], r[1], r[2], (id >= 0) ? r[3] : -1.f);
+    };
+    // (the first chunk's records go out as soon as its ids are here; the rays' set-up runs while they travel)
+    float4 m0 = load_ms(id0);
+    float4 c0 = pref ? cull_none : load_cull(id0);
+    if (pass == 0) ray_setup(!WIDE, dx, dy, dz);
     const float rdn2 = __builtin_amdgcn_rcpf((dx * dx + dy * dy) + dz * dz);      // (pair_eval_iso: md * rcp(qxx + qyy + qzz))
     // (24-bit multiplies of 32-bit offsets: a plain `row * stride` index becomes a quarter-rate 64-bit multiply-add)
     float *const mylen = Llen + col;
@@ -291,19 +319,11 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 
     auto load_id = [&](const int g) { return (g < src_n) ? (binned ? src_id[g] : g) : -1; };
     auto load_lb = [&](const int g) { return (binned && g < src_n) ? src_lb[g] : -INFINITY; };
-    auto load_ms = [&](const int id) { return (id >= 0) ? msb[id] : rec_none; };
-    auto load_cull = [&](const int id) { return (id >= 0) ? cullb[id] : cull_none; };
 
 #ifdef VOGE_SWEEP_TIMES
     ts1 = wall_clock64();
 #endif
-    // two-deep software pipeline: ids two chunks ahead, records one chunk ahead
-    int id0 = load_id(lane);
-    float lb0 = load_lb(lane);
-    float4 m0 = load_ms(id0);
-    float4 c0 = pref ? cull_none : load_cull(id0);
-    int id1 = load_id(64 + lane);
-    float lb1 = load_lb(64 + lane);
+    // two-deep software pipeline: ids two chunks ahead, records one chunk ahead (the first of each: requested at the top of run())
     for (int base = 0; base < src_n && !wdone; base += 64) {
       const int id = id0;
       const float lbv = lb0;
