@@ -139,6 +139,12 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     const int r0 = NS * pk.s0 + 4 * pk.ord, RS = NS * LP + 4;
     const int d0 = on ? r0 + 2 + k0 : 2;
     // ---- the lane's slots ----
+    // Round 5: the loads of a round go out in TWO waves of requests -- everything addressed by the pixel (ray, the slots'
+    // idx / weight / len [/ act / dsd / g_weight], the pixel's forward sums and upstream gradient), then everything addressed
+    // by the slots' Gaussian ids (records, colours) -- each unconditional at a clamped address, masks applied to the VALUES
+    // afterwards.  As `if (on) load ...; if (live) load ...` the compiler had to join every exec-mask region before the next:
+    // ray -> wait -> streams -> wait -> record 0 -> wait -> record 1 -> wait -> colours -> pixel data, six dependent round trips
+    // per round (SQ_WAIT_ANY: 46 % of the kernel's wave cycles, profiles/r5_pmc_sq_counters_head.txt).
     int id[NS];
     float wv[NS], lm[NS], sm[NS], em[NS], gwv[NS];
     bool live[NS];
@@ -147,126 +153,137 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
       id[a] = -1; wv[a] = 0.f; lm[a] = VOGE_SENT_LEN; sm[a] = 1e-5f; em[a] = 0.f; gwv[a] = 0.f;
       live[a] = on && (k0 + a < lead);
     }
-    float dx = 0.f, dy = 0.f, dz = 0.f;
-    if (on) {
-      const float3 dv = at_bytes<float3>(rays, pix * (OffT)12);
-      dx = dv.x; dy = dv.y; dz = dv.z;
-    }
+    // (a lane that is off reads pixel 0, slot 0: pix = 0 and q = 0 there)
+    const float3 dv = at_bytes<float3>(rays, pix * (OffT)12);
+    const float dx = on ? dv.x : 0.f, dy = on ? dv.y : 0.f, dz = on ? dv.z : 0.f;
     float4 rc[NS][ISO ? 1 : 3];
     float av[NS], dv2[NS];
 #pragma unroll
     for (int a = 0; a < NS; ++a) { av[a] = 0.f; dv2[a] = 0.f; }
-    if (live[0]) {
-      if (vec) {                // wide accesses: the group is aligned and inside the pixel's row
+    {
+      int idr[NS];
+      float wr[NS], lr[NS], ar[NS], dr[NS], gr_[NS];
+#pragma unroll
+      for (int a = 0; a < NS; ++a) { idr[a] = -1; wr[a] = 0.f; lr[a] = VOGE_SENT_LEN; ar[a] = 0.f; dr[a] = 0.f; gr_[a] = 0.f; }
+      const bool gw_wide = SRC == 1 && g_img != nullptr && vec && gs_c == 1 && gs_pix == (long)K;
+      if (vec) {                // (uniform) wide accesses: the group is aligned and inside the pixel's row
 #pragma unroll
         for (int h2 = 0; h2 < NS / 2; ++h2) {
           const OffT fo = fb + (OffT)(8 * h2);
-          if (h2 > 0 && !live[2 * h2]) break;
           const int2 i2 = at_bytes<int2>(idx, fo);
           const v2f w2 = at_bytes<v2f>(weight, fo), l2 = at_bytes<v2f>(len, fo);
-          id[2 * h2] = i2.x; wv[2 * h2] = w2.x; lm[2 * h2] = l2.x;
-          if (live[2 * h2 + 1]) { id[2 * h2 + 1] = i2.y; wv[2 * h2 + 1] = w2.y; lm[2 * h2 + 1] = l2.y; }
+          idr[2 * h2] = i2.x; idr[2 * h2 + 1] = i2.y; wr[2 * h2] = w2.x; wr[2 * h2 + 1] = w2.y; lr[2 * h2] = l2.x; lr[2 * h2 + 1] = l2.y;
           if (!NOAD) {
             const v2f a2 = at_bytes<v2f>(act, fo), d2 = at_bytes<v2f>(dsd, fo);
-            av[2 * h2] = a2.x; av[2 * h2 + 1] = a2.y; dv2[2 * h2] = d2.x; dv2[2 * h2 + 1] = d2.y;
+            ar[2 * h2] = a2.x; ar[2 * h2 + 1] = a2.y; dr[2 * h2] = d2.x; dr[2 * h2 + 1] = d2.y;
+          }
+          if (gw_wide) {        // (uniform)
+            const v2f g2 = at_bytes<v2f>(g_img, fo);
+            gr_[2 * h2] = g2.x; gr_[2 * h2 + 1] = g2.y;
           }
         }
-      } else {
+      } else {                  // slot by slot; a slot behind the pixel's row re-reads the row's last one (never live)
 #pragma unroll
         for (int a = 0; a < NS; ++a) {
-          if (!live[a]) break;
-          const OffT fo = fb + (OffT)(4 * a);
-          id[a] = at_bytes<int>(idx, fo); wv[a] = at_bytes<float>(weight, fo); lm[a] = at_bytes<float>(len, fo);
-          if (!NOAD) { av[a] = at_bytes<float>(act, fo); dv2[a] = at_bytes<float>(dsd, fo); }
+          const OffT fo = (pix * (OffT)K + (OffT)min(k0 + a, K - 1)) * (OffT)4;
+          idr[a] = at_bytes<int>(idx, fo); wr[a] = at_bytes<float>(weight, fo); lr[a] = at_bytes<float>(len, fo);
+          if (!NOAD) { ar[a] = at_bytes<float>(act, fo); dr[a] = at_bytes<float>(dsd, fo); }
         }
       }
-      if (!NOAD) {
+      if (SRC == 1 && g_img != nullptr && !gw_wide) {      // (uniform) the consumers' gradient of the weights, any strides
 #pragma unroll
-        for (int a = 0; a < NS; ++a)
-          if (live[a]) { em[a] = FAST_EXP(-av[a]); sm[a] = FAST_SQRT(dv2[a] + 1e-10f); }
+        for (int a = 0; a < NS; ++a) gr_[a] = g_img[(long)pix * gs_pix + (long)min(k0 + a, K - 1) * gs_c];
       }
-      if (SRC == 1 && g_img != nullptr) {      // the consumers' gradient of the weights
-        if (vec && gs_c == 1 && gs_pix == (long)K) {
-#pragma unroll
-          for (int h2 = 0; h2 < NS / 2; ++h2) {
-            if (h2 > 0 && !live[2 * h2]) break;
-            const v2f g2 = at_bytes<v2f>(g_img, fb + (OffT)(8 * h2));
-            gwv[2 * h2] = g2.x; gwv[2 * h2 + 1] = g2.y;
-          }
-        } else {
-#pragma unroll
-          for (int a = 0; a < NS; ++a)
-            if (live[a]) gwv[a] = g_img[(long)pix * gs_pix + (long)(k0 + a) * gs_c];
-        }
-      }
-    }
-    if (NOAD && ISO) {          // act / dsd from the records (gathered here once, used again by the trace terms below)
-      const float dn2f = (dx * dx + dy * dy) + dz * dz;      // the forward's association
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
-        const bool ok = live[a] && id[a] >= 0 && id[a] < P;
-        rc[a][0] = ok ? at_bytes<float4>(rec, (uint32_t)id[a] * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
-          const PairOut o = pair_eval_iso_at(rc[a][0].x, rc[a][0].y, rc[a][0].z, rc[a][0].w, lm[a], dx, dy, dz, dn2f);
-          em[a] = FAST_EXP(-o.act); sm[a] = FAST_SQRT(o.dsd + 1e-10f);
-        }
+        if (live[a]) { id[a] = idr[a]; wv[a] = wr[a]; lm[a] = lr[a]; av[a] = ar[a]; dv2[a] = dr[a]; gwv[a] = gr_[a]; }
       }
     }
-    if (NOAD && !ISO) {         // general forms: the same from the packed (mu, A) records, with the forward's operations
-      // (make_eval + pair_eval, as the deferred composite; the 48-byte records are gathered AGAIN for the trace terms below
-      // rather than held across the composite: 24 registers)
+    // the pixel's forward sums and upstream gradient (the shade stage), requested with the slots
+    float gr[4] = {0.f, 0.f, 0.f, 0.f}, g_sum_w = 0.0f;
+    float px_ws = 0.f, px_rgb[4] = {0.f, 0.f, 0.f, 0.f}, px_g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (SRC == 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) px_g[c] = g_img[(long)pix * gs_pix + c * gs_c];
+      if (wsum != nullptr) px_ws = at_bytes<float>(wsum, pix * (OffT)4);
+      if (bg != nullptr) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) px_rgb[c] = at_bytes<float>(rgb, pix * (OffT)(4 * C) + (OffT)(4 * c));
+      }
+    }
+    // ---- second wave of requests: what the slots' Gaussians carry (records, colours), at clamped ids ----
+    bool okv[NS];
+#pragma unroll
+    for (int a = 0; a < NS; ++a) okv[a] = live[a] && id[a] >= 0 && id[a] < P;
+    if (NOAD) {      // (act / dsd re-derived from the records; with act / dsd given the records are only needed by the trace terms)
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
-        const bool ok = live[a] && id[a] >= 0 && id[a] < P;
-        if (ok) {
-          const uint32_t ro = (uint32_t)id[a] * 48u;
-          const float4 r0 = at_bytes<float4>(rec, ro), r1 = at_bytes<float4>(rec, ro + 16u), r2 = at_bytes<float4>(rec, ro + 32u);
-          const float A[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-          const PairOut o = pair_eval(r0.x, r0.y, r0.z, make_eval(r0.x, r0.y, r0.z, A), dx, dy, dz, dx * dx, dy * dy, dz * dz,
-                                      dx * dy, dx * dz, dy * dz);
-          em[a] = FAST_EXP(-o.act); sm[a] = FAST_SQRT(o.dsd + 1e-10f);
-        }
+        const uint32_t ro = (uint32_t)(okv[a] ? id[a] : 0) * (ISO ? 16u : 48u);      // (P < 2^26: host)
+#pragma unroll
+        for (int r = 0; r < (ISO ? 1 : 3); ++r) rc[a][r] = !(VOGE_FB_ABL & 8) ? at_bytes<float4>(rec, ro + 16u * r) : make_float4(0.f, 0.f, 0.f, 0.f);      // (P >= 1, Nattr >= 1 here: host)
       }
     }
-    // gathers: the slots' colours and (mu, a); the pixel's ray, upstream gradient and forward sums
     float col[NS][4];
 #pragma unroll
     for (int a = 0; a < NS; ++a) {
-      const bool ok = live[a] && id[a] >= 0 && id[a] < P;
-      live[a] = ok;
       col[a][0] = col[a][1] = col[a][2] = col[a][3] = 0.0f;
-      if (SRC == 0 && ok && id[a] < Nattr && !(VOGE_FB_ABL & 4)) {
-        const uint32_t o = (uint32_t)id[a] * (uint32_t)(4 * C);      // (bytes; Nattr * C < 2^30: host)
+      if (SRC == 0 && !(VOGE_FB_ABL & 4)) {
+        const bool cok = okv[a] && id[a] < Nattr;
+        const uint32_t o = (uint32_t)(cok ? id[a] : 0) * (uint32_t)(4 * C);      // (bytes; Nattr * C < 2^30: host)
         if (C == 3) {
           const float3 v = at_bytes<float3>(colors, o);
-          col[a][0] = v.x; col[a][1] = v.y; col[a][2] = v.z;
+          col[a][0] = cok ? v.x : 0.f; col[a][1] = cok ? v.y : 0.f; col[a][2] = cok ? v.z : 0.f;
         } else if (C == 4) {
           const float4 v = at_bytes<float4>(colors, o);
-          col[a][0] = v.x; col[a][1] = v.y; col[a][2] = v.z; col[a][3] = v.w;
+          col[a][0] = cok ? v.x : 0.f; col[a][1] = cok ? v.y : 0.f; col[a][2] = cok ? v.z : 0.f; col[a][3] = cok ? v.w : 0.f;
         } else {
 #pragma unroll
-          for (int c = 0; c < C; ++c) col[a][c] = at_bytes<float>(colors, o + 4u * c);
+          for (int c = 0; c < C; ++c) { const float v = at_bytes<float>(colors, o + 4u * c); col[a][c] = cok ? v : 0.f; }
         }
       }
     }
-    float gr[4] = {0.f, 0.f, 0.f, 0.f}, g_sum_w = 0.0f;
+    // ---- em / sm of the slots: from act / dsd, or (NOAD) re-derived from the records with the forward's own operations ----
+    if (!NOAD) {
+#pragma unroll
+      for (int a = 0; a < NS; ++a)
+        if (live[a]) { em[a] = FAST_EXP(-av[a]); sm[a] = FAST_SQRT(dv2[a] + 1e-10f); }
+    }
+    if (NOAD && ISO) {
+      const float dn2f = (dx * dx + dy * dy) + dz * dz;      // the forward's association
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const PairOut o = pair_eval_iso_at(rc[a][0].x, rc[a][0].y, rc[a][0].z, rc[a][0].w, lm[a], dx, dy, dz, dn2f);
+        em[a] = okv[a] ? FAST_EXP(-o.act) : em[a]; sm[a] = okv[a] ? FAST_SQRT(o.dsd + 1e-10f) : sm[a];
+      }
+    }
+    if (NOAD && !ISO) {         // general forms: the same from the packed (mu, A) records, with the forward's operations
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const float4 r0 = rc[a][0], r1 = rc[a][ISO ? 0 : 1], r2 = rc[a][ISO ? 0 : 2];
+        const float A[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+        const PairOut o = pair_eval(r0.x, r0.y, r0.z, make_eval(r0.x, r0.y, r0.z, A), dx, dy, dz, dx * dx, dy * dy, dz * dz,
+                                    dx * dy, dx * dz, dy * dz);
+        em[a] = okv[a] ? FAST_EXP(-o.act) : em[a]; sm[a] = okv[a] ? FAST_SQRT(o.dsd + 1e-10f) : sm[a];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NS; ++a) live[a] = okv[a];
     if (SRC == 0 && on && bg == nullptr) {
       // merge_final alone (interpolate_attr): the image's gradient is the merged attributes' own, and `wsum` carries the
       // gradient of the per-pixel weight sum (what a get_silhouette on the same fragments hands back), or is NULL
 #pragma unroll
-      for (int c = 0; c < C; ++c) gr[c] = g_img[(long)pix * gs_pix + c * gs_c];
-      if (wsum != nullptr) g_sum_w = at_bytes<float>(wsum, pix * (OffT)4);
+      for (int c = 0; c < C; ++c) gr[c] = px_g[c];
+      if (wsum != nullptr) g_sum_w = px_ws;
     } else if (SRC == 0 && on) {
-      const OffT pb = pix * (OffT)4;
-      const float ws = at_bytes<float>(wsum, pb);
+      const float ws = px_ws;
       float sil = fminf(ws, 1.0f);
       const float pass_s = (thr > 0.0f) ? 0.0f : (ws < 1.0f ? 1.0f : (ws == 1.0f ? 0.5f : 0.0f));
       if (thr > 0.0f) sil = sil > thr ? 1.0f : 0.0f;
       float g_mask = 0.0f;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const float xc = fmaf(1.0f - sil, bg[c], at_bytes<float>(rgb, pb * (OffT)C + (OffT)(4 * c)));
-        gr[c] = g_img[(long)pix * gs_pix + c * gs_c] * (xc < 1.0f ? 1.0f : (xc == 1.0f ? 0.5f : 0.0f));     // min(x, 1) passes like torch.min
+        const float xc = fmaf(1.0f - sil, bg[c], px_rgb[c]);
+        gr[c] = px_g[c] * (xc < 1.0f ? 1.0f : (xc == 1.0f ? 0.5f : 0.0f));     // min(x, 1) passes like torch.min
         g_mask = fmaf(-gr[c], bg[c], g_mask);
       }
       g_sum_w = g_mask * pass_s;
@@ -316,13 +333,16 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     }
     // ---- trace backward terms (isotropic: trace_bwd.hip) + the colour term, one table entry per Gaussian.  (The
     // (mu, a) records are gathered only now: held across the composite they cost the kernel a wave per SIMD.) ----
+    // (scalar sigmas without act / dsd: the records gathered above serve here too.  Otherwise they are gathered only now:
+    //  held across the composite they cost the kernel a wave per SIMD -- 24 registers for the full forms)
     if (!NOAD || !ISO)
 #pragma unroll
-    for (int a = 0; a < NS; ++a)
+    for (int a = 0; a < NS; ++a) {
+      const uint32_t ro = (uint32_t)(live[a] ? id[a] : 0) * (ISO ? 16u : 48u);      // (P < 2^26: host)
 #pragma unroll
       for (int r = 0; r < (ISO ? 1 : 3); ++r)
-        rc[a][r] = (live[a] && !(VOGE_FB_ABL & 8)) ? at_bytes<float4>(rec, (uint32_t)id[a] * (ISO ? 16u : 48u) + 16u * r)
-                                                     : make_float4(0.f, 0.f, 0.f, 0.f);   // (P < 2^26: host)
+        rc[a][r] = !(VOGE_FB_ABL & 8) ? at_bytes<float4>(rec, ro + 16u * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float dn2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float idn = __builtin_amdgcn_rcpf(dn2);
     // (two slots per lane: both slots' terms first, then ONE election loop for both -- wt_add2)
@@ -613,8 +633,11 @@ struct FbArgs {      // what every form of the fused backward hands its kernel
 template <int SRC, int C, int NS, typename OffT, bool ISO, bool NOAD>
 void fb_launch(const FbArgs &a, hipStream_t st) {
   const long blocks = (long)((a.W + kFbGW - 1) / kFbGW) * ((a.nrows + kFbGH - 1) / kFbGH);
+  // (the kernel's gathers are unconditional at clamped ids: row 0 of the records (P >= 1 here) and of the colour table must be
+  //  readable.  An empty colour table reads its dropped row out of the records instead.)
+  const float *colors = (a.Nattr > 0 && a.colors != nullptr) ? a.colors : reinterpret_cast<const float *>(a.rec);
   hipLaunchKernelGGL((fragment_bwd_kernel<SRC, C, NS, OffT, ISO, NOAD>), dim3((unsigned)blocks), dim3(64), 0, st, a.rec, a.rays,
-                     a.colors, a.idx, a.cnt, a.weight, a.act, a.len, a.dsd, a.rgb, a.wsum, a.bg, a.thr, a.g, a.gs_pix, a.gs_c,
+                     colors, a.idx, a.cnt, a.weight, a.act, a.len, a.dsd, a.rgb, a.wsum, a.bg, a.thr, a.g, a.gs_pix, a.gs_c,
                      a.g_hitlen, a.occ, a.P, a.nrows, a.W, a.K, a.Nattr, a.acc);
 }
 template <int SRC, int C, int NS, bool ISO>
