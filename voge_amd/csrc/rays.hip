@@ -50,7 +50,8 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
     const int nstx = (W + kST - 1) / kST;
     const int st = (int)blockIdx.x - ray_blocks;
     const int x0 = (st % nstx) * kST, y0 = (st / nstx) * kST;
-    const int ly = threadIdx.x >> 3, lx0 = (threadIdx.x & 7) * 4;
+    int ly, lx0;
+    cone_thread_rays(threadIdx.x, lx0, ly);
     const float ifx = 1.0f / fx, ify = 1.0f / fy;
     float cx[4], cy[4], cz[4];
     unsigned has = 0u;
@@ -118,7 +119,8 @@ cones_kernel(const float *__restrict__ rays, const int H, const int W, ConeRec *
   __shared__ ConeHierLds Lc;
   const int b = blockIdx.y, nstx = (W + kST - 1) / kST;
   const int x0 = ((int)blockIdx.x % nstx) * kST, y0 = ((int)blockIdx.x / nstx) * kST;
-  const int ly = threadIdx.x >> 3, lx0 = (threadIdx.x & 7) * 4;
+  int ly, lx0;
+  cone_thread_rays(threadIdx.x, lx0, ly);
   float cx[4], cy[4], cz[4];
   unsigned has = 0u;
 #pragma unroll

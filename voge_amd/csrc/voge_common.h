@@ -505,13 +505,15 @@ __device__ __forceinline__ ConeRec block_cone256(const float (&rx)[NR], const fl
 // Layout of the `cones` buffer (voge_cones_floats), per batch element (so that a sub-batch is a pointer offset):
 // [nst] super-tile records, then [nst][4] quad records (quad qy * 2 + qx), then [nst][16] tile records (tile ty * 4 + tx,
 // local to the super-tile): kConeRecsPerST records per super-tile in all.
-// Thread t of the 256 holds the four rays (x = 4 (t & 7) .. + 3, y = t >> 3) of the super-tile: a tile is the 16 lanes of
-// wave ty whose ((lane & 7) >> 1) == tx, i.e. the lanes reached by xor 1, 8, 16, 32.
+// Thread t of the 256 holds four rays of the super-tile (cone_thread_rays): wave ty = t >> 6 is a row of four tiles, and a tile
+// is one DPP ROW of 16 lanes (tx = lane >> 4; lane j of the row holds x = 4 (j & 1) .. + 3, y = j >> 1 of the tile), so a
+// tile's sums and extrema are four DPP steps on the vector unit -- no LDS crossbar.  (As first written a tile's lanes were
+// xor 1, 8, 16, 32 apart: 44 ds_bpermute shuffles per thread, and the ray kernel went from 5 to 9.4 us.)
 // ------------------------------------------------------------------------------------------
 struct ConeHierLds {
   float4 sum[16];      // per tile: (sum of the unit directions, all finite)
   float cnt[16];       // per tile: rays inside the image
-  float ext[16][6];    // per tile: (s2max, cmin) w.r.t. the tile's, its quad's and the super-tile's axis
+  float ext[16][4];    // per tile: (s2max, cmin) w.r.t. the tile's and the super-tile's axis
 };
 constexpr int kConeRecsPerST = 21;
 // record index of batch element b's super-tile st / its quad q / its tile t (nst = super-tiles per batch element)
@@ -519,23 +521,30 @@ __host__ __device__ inline size_t cone_super_at(const size_t b, const size_t nst
 __host__ __device__ inline size_t cone_quad_at(const size_t b, const size_t nst, const size_t st, const int q) { return b * nst * kConeRecsPerST + nst + st * 4 + q; }
 __host__ __device__ inline size_t cone_tile_at(const size_t b, const size_t nst, const size_t st, const int t) { return b * nst * kConeRecsPerST + nst * 5 + st * 16 + t; }
 __host__ __device__ inline size_t cone_records(const size_t B, const size_t nst) { return B * nst * kConeRecsPerST; }
+// the super-tile pixel (x of the first of four, y) thread t holds
+__device__ __forceinline__ void cone_thread_rays(const int t, int &lx0, int &ly) {
+  const int lane = t & 63, j = lane & 15;
+  lx0 = (lane >> 4) * 8 + (j & 1) * 4;
+  ly = (t >> 6) * 8 + (j >> 1);
+}
+// reductions over a DPP row of 16 lanes, result in every lane of the row
 __device__ __forceinline__ float tile16_sum(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+  v += VOGE_DPP(v, 0xB1); v += VOGE_DPP(v, 0x4E); v += VOGE_DPP(v, 0x141); v += VOGE_DPP(v, 0x140);
   return v;
 }
 __device__ __forceinline__ float tile16_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
+  v = fmaxf(v, VOGE_DPP(v, 0xB1)); v = fmaxf(v, VOGE_DPP(v, 0x4E)); v = fmaxf(v, VOGE_DPP(v, 0x141)); v = fmaxf(v, VOGE_DPP(v, 0x140));
   return v;
 }
 __device__ __forceinline__ float tile16_min(float v) {
-  v = fminf(v, __shfl_xor(v, 1, 64)); v = fminf(v, __shfl_xor(v, 8, 64)); v = fminf(v, __shfl_xor(v, 16, 64)); v = fminf(v, __shfl_xor(v, 32, 64));
+  v = fminf(v, VOGE_DPP(v, 0xB1)); v = fminf(v, VOGE_DPP(v, 0x4E)); v = fminf(v, VOGE_DPP(v, 0x141)); v = fminf(v, VOGE_DPP(v, 0x140));
   return v;
 }
 __device__ __forceinline__ void block_cones_hier256(const float (&rx)[4], const float (&ry)[4], const float (&rz)[4], const unsigned has,
                                                     ConeRec *__restrict__ c_super, ConeRec *__restrict__ c_quad /* [4] */,
                                                     ConeRec *__restrict__ c_tile /* [16] */, ConeHierLds &L) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int ltx = (lane & 7) >> 1, tile = wave * 4 + ltx;
+  const int ltx = lane >> 4, tile = wave * 4 + ltx;
   float sx = 0.f, sy = 0.f, sz = 0.f, okf = 1.f, np = 0.f;
   float inv[4];
   bool fin[4];
@@ -550,33 +559,32 @@ __device__ __forceinline__ void block_cones_hier256(const float (&rx)[4], const 
     np += on ? 1.f : 0.f;
   }
   sx = tile16_sum(sx); sy = tile16_sum(sy); sz = tile16_sum(sz); okf = tile16_min(okf); np = tile16_sum(np);
-  if ((lane & 0x39) == 0) { L.sum[tile] = make_float4(sx, sy, sz, okf); L.cnt[tile] = np; }      // (the tile's first lane)
+  if ((lane & 15) == 0) { L.sum[tile] = make_float4(sx, sy, sz, okf); L.cnt[tile] = np; }      // (the tile's first lane)
   __syncthreads();
-  // the three axes this thread's rays are measured against: its tile's, its quad's, the super-tile's
-  float ax[3], ay[3], az[3];
+  // the two axes this thread's rays are measured against: its tile's and the super-tile's.  (The QUAD cones are the
+  // conservative unions of their four tile cones, made by the finishing threads -- binA's child_extrema formula: a third
+  // less per-ray work in a kernel the frame waits for; binB filters with the quad cone first and the tile cones after.)
+  float ax[2], ay[2], az[2];
   {
-    float qx = 0.f, qy = 0.f, qz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-    const int q0 = (wave & 2) * 4 + (ltx & 2);      // the quad's first tile
+    float gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const float4 v = L.sum[i];
       gx += v.x; gy += v.y; gz += v.z;
-      const bool inq = (i == q0) || (i == q0 + 1) || (i == q0 + 4) || (i == q0 + 5);
-      qx += inq ? v.x : 0.f; qy += inq ? v.y : 0.f; qz += inq ? v.z : 0.f;
     }
-    const float vx[3] = {sx, qx, gx}, vy[3] = {sy, qy, gy}, vz[3] = {sz, qz, gz};
+    const float vx[2] = {sx, gx}, vy[2] = {sy, gy}, vz[2] = {sz, gz};
 #pragma unroll
-    for (int l = 0; l < 3; ++l) {
-      const float n = sqrtf(fmaf(vz[l], vz[l], fmaf(vy[l], vy[l], vx[l] * vx[l])));
-      ax[l] = vx[l] / n; ay[l] = vy[l] / n; az[l] = vz[l] / n;
+    for (int l = 0; l < 2; ++l) {      // (any axis gives a valid cone: the hardware rsq's last ulp does not matter)
+      const float rn = __builtin_amdgcn_rsqf(fmaf(vz[l], vz[l], fmaf(vy[l], vy[l], vx[l] * vx[l])));
+      ax[l] = vx[l] * rn; ay[l] = vy[l] * rn; az[l] = vz[l] * rn;
     }
   }
-  float s2m[3] = {0.f, 0.f, 0.f}, cmn[3] = {1.f, 1.f, 1.f};
+  float s2m[2] = {0.f, 0.f}, cmn[2] = {1.f, 1.f};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const bool on = (has >> k) & 1u;
 #pragma unroll
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < 2; ++l) {
       const float da = fmaf(rz[k], az[l], fmaf(ry[k], ay[l], rx[k] * ax[l]));
       const float qx = fmaf(-da, ax[l], rx[k]), qy = fmaf(-da, ay[l], ry[k]), qz = fmaf(-da, az[l], rz[k]);
       const float s2 = fmaf(qz, qz, fmaf(qy, qy, qx * qx)) * (inv[k] * inv[k]);
@@ -585,10 +593,10 @@ __device__ __forceinline__ void block_cones_hier256(const float (&rx)[4], const 
     }
   }
 #pragma unroll
-  for (int l = 0; l < 3; ++l) { s2m[l] = tile16_max(s2m[l]); cmn[l] = tile16_min(cmn[l]); }
-  if ((lane & 0x39) == 0) {
+  for (int l = 0; l < 2; ++l) { s2m[l] = tile16_max(s2m[l]); cmn[l] = tile16_min(cmn[l]); }
+  if ((lane & 15) == 0) {
 #pragma unroll
-    for (int l = 0; l < 3; ++l) { L.ext[tile][2 * l] = s2m[l]; L.ext[tile][2 * l + 1] = cmn[l]; }
+    for (int l = 0; l < 2; ++l) { L.ext[tile][2 * l] = s2m[l]; L.ext[tile][2 * l + 1] = cmn[l]; }
   }
   __syncthreads();
   if (t < 21) {      // threads 0..15: the tiles; 16..19: the quads; 20: the super-tile
@@ -603,14 +611,39 @@ __device__ __forceinline__ void block_cones_hier256(const float (&rx)[4], const 
       vx += in ? v.x : 0.f; vy += in ? v.y : 0.f; vz += in ? v.z : 0.f;
       ok = (in && c > 0.f) ? fminf(ok, v.w) : ok;
       n_in += in ? c : 0.f;
-      const float e_s = level == 0 ? L.ext[i][0] : (level == 1 ? L.ext[i][2] : L.ext[i][4]);
-      const float e_c = level == 0 ? L.ext[i][1] : (level == 1 ? L.ext[i][3] : L.ext[i][5]);
-      s2 = (in && c > 0.f) ? fmaxf(s2, e_s) : s2;
-      cm = (in && c > 0.f) ? fminf(cm, e_c) : cm;
+      const float e_s = level == 0 ? L.ext[i][0] : L.ext[i][2];
+      const float e_c = level == 0 ? L.ext[i][1] : L.ext[i][3];
+      s2 = (in && c > 0.f && level != 1) ? fmaxf(s2, e_s) : s2;
+      cm = (in && c > 0.f && level != 1) ? fminf(cm, e_c) : cm;
     }
-    const float n = sqrtf(fmaf(vz, vz, fmaf(vy, vy, vx * vx)));
-    // v_rsq is good to ~1 ulp: pad the bounds by 4e-7 relative on top of cone_finish's margins (as block_cone256)
-    const Cone c = cone_finish(vx / n, vy / n, vz / n, n / fmaxf(n_in, 1.f), sqrtf(s2) * (1.0f + 4e-7f) + 4e-7f, cm - 4e-7f, ok != 0.f);
+    // (the SAME axis the extrema above were measured against: the same rsq of the same sums)
+    const float n2 = fmaf(vz, vz, fmaf(vy, vy, vx * vx)), rn = __builtin_amdgcn_rsqf(n2);
+    const float Ax = vx * rn, Ay = vy * rn, Az = vz * rn;
+    float smax = sqrtf(s2) * (1.0f + 4e-7f) + 4e-7f, cmin = cm - 4e-7f;      // (v_rsq is good to ~1 ulp: padded as block_cone256 pads)
+    bool all_ok = ok != 0.f;
+    if (level == 1) {
+      // the quad: union of its tiles' cones about the quad's own axis.  A ray of tile i makes at most alpha_i + theta_i with
+      // that axis (alpha_i: angle between the axes):  cos >= cos(alpha_i) cs_i - sin(alpha_i) sn_i,  sin <= sin(alpha_i) + cos(alpha_i) sn_i
+      smax = 0.f; cmin = 1.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = q0 + (k >> 1) * 4 + (k & 1);
+        if (!(L.cnt[i] > 0.f)) continue;
+        const float4 v = L.sum[i];
+        const float trn = __builtin_amdgcn_rsqf(fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));      // the tile's axis, as its own record has it
+        const float tx = v.x * trn, ty = v.y * trn, tz = v.z * trn;
+        const float t_sn = (sqrtf(L.ext[i][0]) * (1.0f + 4e-7f) + 4e-7f) * (1.0f + 1e-5f) + 1e-7f;      // (cone_finish's margins on the tile's bounds)
+        const float t_cs = (L.ext[i][1] - 4e-7f) - 1e-6f;
+        const float ca = fmaf(tz, Az, fmaf(ty, Ay, tx * Ax));
+        const float qx = fmaf(-ca, Ax, tx), qy = fmaf(-ca, Ay, ty), qz = fmaf(-ca, Az, tz);
+        const float sa = sqrtf(fmaf(qz, qz, fmaf(qy, qy, qx * qx))) * (1.0f + 1e-6f) + 1e-7f;
+        const float cl = fminf(ca, 1.0f) - 1e-7f;
+        if (!(cl > 0.0f) || !(t_cs > 0.0f)) all_ok = false;
+        cmin = fminf(cmin, fmaf(cl, t_cs, -sa * t_sn));
+        smax = fmaxf(smax, fmaf(fminf(ca + 1e-7f, 1.0f), t_sn, sa));
+      }
+    }
+    const Cone c = cone_finish(Ax, Ay, Az, (n2 * rn) / fmaxf(n_in, 1.f), smax, cmin, all_ok);
     // (a tile / quad without a pixel inside the image: ok = -1, "no such tile" -- nothing is ever tested against it)
     const ConeRec rec = {c.ax, c.ay, c.az, c.cs, c.sn, n_in > 0.f ? (c.ok ? 1.f : 0.f) : -1.f, 0.f, 0.f};
     if (level == 0) c_tile[t] = rec; else if (level == 1) c_quad[t - 16] = rec; else *c_super = rec;
