@@ -148,7 +148,7 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
     }
     ex = x;
     __builtin_amdgcn_wave_barrier();
-    wave_rmax = in_wg ? __uint_as_float(*reinterpret_cast<volatile unsigned *>(Lcell)) : 0.0f;
+    wave_rmax = in_wg ? __uint_as_float(*lds_volatile(Lcell)) : 0.0f;
   } else {
     v2f x = {esum, mx};
     const v2f y = (v2f){__shfl_up(x.x, 1, 64), __shfl_up(x.y, 1, 64)};
@@ -270,7 +270,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
     __builtin_amdgcn_wave_barrier();
     if (in_wg && mx > 0.0f) atomicMax(Lcell, __float_as_uint(mx));
     __builtin_amdgcn_wave_barrier();
-    wave_rmax = in_wg ? __uint_as_float(*reinterpret_cast<volatile unsigned *>(Lcell)) : 0.0f;
+    wave_rmax = in_wg ? __uint_as_float(*lds_volatile(Lcell)) : 0.0f;
   } else {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {

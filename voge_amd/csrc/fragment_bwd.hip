@@ -423,7 +423,7 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
       const int slot = wt_find(L.tab, id[a], go);
 #ifdef VOGE_FB_TIMES      // (election rounds per accumulation: tools/fb_sections.py)
       {
-        volatile int *owner = L.tab.owner;
+        lds_vint *owner = lds_volatile(L.tab.owner);
         bool pending = go && slot >= 0;
         const unsigned long long m0 = __ballot(pending);
         unsigned rounds = 0;
@@ -474,7 +474,7 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     const int e = lane / NACC, c = lane - e * NACC;
     const float *vals = reinterpret_cast<const float *>(L.tab.vals);
     const int n = wt_compact(L.tab, lane);
-    const volatile int *list = L.tab.owner;
+    const lds_vint *list = lds_volatile(L.tab.owner);
     for (int i = e; i < n && e < EPI; i += EPI) {
       const int s = list[i];
       unsafeAtomicAdd(acc + NACC * (size_t)L.tab.keys[s] + c, vals[s * NACC + c]);

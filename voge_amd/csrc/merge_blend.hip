@@ -384,7 +384,7 @@ shade_bwd_tile_kernel(const float *__restrict__ attr, const int32_t *__restrict_
     const int c = lane & 3;
     const float *vals = reinterpret_cast<const float *>(L.tab.vals);
     const int n = wt_compact(L.tab, lane);
-    const volatile int *list = L.tab.owner;
+    const lds_vint *list = lds_volatile(L.tab.owner);
     for (int i = lane >> 2; i < n; i += 16) {
       const int s = list[i];
       const int p = L.tab.keys[s];

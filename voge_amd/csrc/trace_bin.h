@@ -423,7 +423,7 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
                 for (int q = 0; q < kU; ++q) {
                   const unsigned long long m = __ballot(kp[q]);
                   const int e = f + __popcll(m & ((1ull << lane) - 1ull)) - kSegCap;
-                  if (kp[q] && e >= 0) arena[*reinterpret_cast<volatile int *>(&L.extc[cc][e / kExtChunk]) + (e % kExtChunk)] = id[q];
+                  if (kp[q] && e >= 0) arena[*lds_volatile(&L.extc[cc][e / kExtChunk]) + (e % kExtChunk)] = id[q];
                   f += __popcll(m);
                 }
               }
@@ -1107,7 +1107,12 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
         const int i = base + q * 64 + lane;
         k[q] = (i < total) ? L.sorted[i] : 0u;
         cr[q] = make_float4(0.f, 0.f, 0.f, -1.f);
-        if (i < total) cr[q] = (i < kQRec) ? L.rec[i] : cullb[k[q] & 0x7fffffffu];
+        // (an LDS read at a clamped index, and -- uniform, rare: a quad list beyond kQRec entries -- a gather for the rest.  As
+        //  one `in LDS ? L.rec[i] : cullb[id]` expression this was a select of two pointers and a FLAT load in the filter's loop.)
+        if (i < total) cr[q] = L.rec[min(i, kQRec - 1)];
+        if (__any(i >= kQRec && i < total)) {
+          if (i >= kQRec && i < total) cr[q] = cullb[k[q] & 0x7fffffffu];
+        }
       }
       bool kp[kFU];
 #pragma unroll
@@ -1158,7 +1163,9 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
     for (int i = tid; i < total; i += kQT) {
       const uint32_t word = L.sorted[i];
       oid[i] = (int32_t)(word & 0x7fffffffu);
-      olb[i] = len_bound(word, (i < kQRec) ? L.rec[i] : cullb[word & 0x7fffffffu]);
+      float4 crec = L.rec[min(i, kQRec - 1)];
+      if (i >= kQRec) crec = cullb[word & 0x7fffffffu];
+      olb[i] = len_bound(word, crec);
     }
   }
   if (tid == 0) q_count[quad] = L.spill ? total : -2;     // (-2: never read -- every tile of this quad has its own list)

@@ -227,7 +227,7 @@ trace_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
     const int c = lane & 15;
     const float *vals = reinterpret_cast<const float *>(L.tab.vals);
     const int n = wt_compact(L.tab, lane);
-    const volatile int *list = L.tab.owner;
+    const lds_vint *list = lds_volatile(L.tab.owner);
     for (int i = lane >> 4; i < n; i += 4) {
       const int s = list[i];
       const int p = L.tab.keys[s];
@@ -415,7 +415,7 @@ trace_bwd_iso_kernel(const float4 *__restrict__ rec /* (mu, a) */, const float *
     const int c = lane & 3;
     const float *vals = reinterpret_cast<const float *>(L.tab.vals);
     const int n = wt_compact(L.tab, lane);
-    const volatile int *list = L.tab.owner;
+    const lds_vint *list = lds_volatile(L.tab.owner);
     for (int i = lane >> 2; i < n; i += 16) {
       const int s = list[i];
       unsafeAtomicAdd(acc + 4 * (size_t)L.tab.keys[s] + c, vals[s * 4 + c]);

@@ -701,6 +701,15 @@ __device__ __forceinline__ bool cone_keep_ell(const float4 c, const float4 e0, c
 // (LDS float atomics cost ~3 LDS cycles per lane and value on gfx950 -- SQ_LDS_IDX_ACTIVE in
 // profiles/ -- the plain b128 path is ~20x cheaper.)
 // ------------------------------------------------------------------------------------------
+// A volatile access through a GENERIC pointer compiles into flat_load / flat_store ... sc0 sc1 (the address-space inference
+// leaves volatile operations alone): an election round of the table below was a system-scope flat store, a vmcnt wait, a flat
+// load and another wait.  These types name the LDS address space outright: ds_write_b32 / ds_read_b32.
+typedef __attribute__((address_space(3))) volatile int lds_vint;
+typedef __attribute__((address_space(3))) volatile unsigned lds_vuint;
+__device__ __forceinline__ lds_vint *lds_volatile(int *p) { return (lds_vint *)p; }
+__device__ __forceinline__ const lds_vint *lds_volatile(const int *p) { return (const lds_vint *)p; }
+__device__ __forceinline__ lds_vuint *lds_volatile(unsigned *p) { return (lds_vuint *)p; }
+
 template <int NE, int NV4>
 struct WaveTable {
   int keys[NE];
@@ -742,7 +751,7 @@ __device__ __forceinline__ int wt_find(WaveTable<NE, NV4> &t, const int key, con
 template <int NE, int NV4>
 __device__ __forceinline__ void wt_add(WaveTable<NE, NV4> &t, const int slot, const float4 (&v)[NV4],
                                        const bool on, const int lane) {
-  volatile int *owner = t.owner;
+  lds_vint *owner = lds_volatile(t.owner);
   bool pending = on;
 #pragma unroll 1
   while (__any(pending)) {
@@ -766,7 +775,7 @@ __device__ __forceinline__ void wt_add(WaveTable<NE, NV4> &t, const int slot, co
 template <int NE, int NV4>
 __device__ __forceinline__ void wt_add2(WaveTable<NE, NV4> &t, const int slot0, const float4 (&v0)[NV4], const bool on0,
                                         const int slot1, const float4 (&v1)[NV4], const bool on1, const int lane) {
-  volatile int *owner = t.owner;
+  lds_vint *owner = lds_volatile(t.owner);
   bool p0 = on0, p1 = on1;
 #pragma unroll 1
   while (__any(p0 | p1)) {
@@ -793,7 +802,7 @@ __device__ __forceinline__ void wt_add2(WaveTable<NE, NV4> &t, const int slot0, 
 // Must be called by the whole wave.
 template <int NE, int NV4>
 __device__ __forceinline__ int wt_compact(WaveTable<NE, NV4> &t, const int lane) {
-  volatile int *list = t.owner;
+  lds_vint *list = lds_volatile(t.owner);
   int n = 0;
 #pragma unroll
   for (int base = 0; base < NE; base += VOGE_WAVE) {
