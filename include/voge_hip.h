@@ -340,6 +340,8 @@ int voge_fragment_merge_bwd_iso(const float *records, const float *sigmas, int s
  *             loss alone hands back); NULL = zero.
  *   g_hitlen: NULL, or [nrows*W,K] contiguous: the gradient of vert_hit_length (= the trace's len, Aggregation.py:107).
  * Any K <= VOGE_MAX_K (odd K too; lists of more than 128 slots put four slots on a lane).  cnt required.
+ * idx must be what the trace wrote: the first cnt[p] slots of a pixel hold DISTINCT Gaussians (the per-Gaussian
+ * accumulation takes a pixel's lanes through its table together, without arbitration between them).
  * Writes g_verts / g_sigmas (iso: through the view's chain rule, as voge_trace_bwd_iso_view) or g_mus [P,3] /
  * g_isigmas [P,3,3] (raw outer-product sums, as voge_trace_bwd).  No ray gradient: callers that optimise the rays
  * themselves use voge_composite_bwd + voge_trace_bwd.  workspace: >= voge_fragment_bwd_workspace_bytes(B*N) bytes.

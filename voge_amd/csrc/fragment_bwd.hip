@@ -73,6 +73,9 @@ struct FragBwdLds {
 #ifndef VOGE_FB_PAIR_TABLE
 #define VOGE_FB_PAIR_TABLE 1      // a lane's two table accumulations share one election loop (wt_add2)
 #endif
+#ifndef VOGE_FB_TABLE_BY_PIXEL
+#define VOGE_FB_TABLE_BY_PIXEL 1  // the table is taken pixel by pixel (no election: wt_add2_by_group) instead of by wt_add2's elections
+#endif
 #ifndef VOGE_FB_WPE
 #define VOGE_FB_WPE 4      // capping the registers for 5 / 6 waves per SIMD spills and is slower
 #endif
@@ -450,9 +453,13 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     }
     if (PAIR && __any(gop[0] | gop[1])) {
       FB_TICK(3);
-      const int slot0 = wt_find(L.tab, id[0], gop[0]);
-      const int slot1 = wt_find(L.tab, id[NS - 1], gop[1]);
+      int slot0, slot1;
+      wt_find2(L.tab, id[0], gop[0], id[NS - 1], gop[1], slot0, slot1);
+#if VOGE_FB_TABLE_BY_PIXEL
+      wt_add2_by_group(L.tab, slot0, valp[0], gop[0] && slot0 >= 0, slot1, valp[PAIR ? 1 : 0], gop[1] && slot1 >= 0, pk.ord);
+#else
       wt_add2(L.tab, slot0, valp[0], gop[0] && slot0 >= 0, slot1, valp[PAIR ? 1 : 0], gop[1] && slot1 >= 0, lane);
+#endif
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int sl = a == 0 ? slot0 : slot1;

@@ -747,6 +747,29 @@ __device__ __forceinline__ int wt_find(WaveTable<NE, NV4> &t, const int key, con
   return slot;
 }
 
+// The same for TWO keys per lane in one probing loop: both compare-and-swaps of a step are in flight together, and the loop
+// lasts as long as the longer of a lane's two probe sequences instead of their sum.  Must be called by the whole wave.
+template <int NE, int NV4>
+__device__ __forceinline__ void wt_find2(WaveTable<NE, NV4> &t, const int key0, const bool want0, const int key1, const bool want1,
+                                         int &slot0, int &slot1) {
+  unsigned h0 = ((unsigned)key0 * 2654435761u) >> (32 - __builtin_ctz(NE));
+  unsigned h1 = ((unsigned)key1 * 2654435761u) >> (32 - __builtin_ctz(NE));
+  slot0 = slot1 = -1;
+  bool p0 = want0, p1 = want1;
+#pragma unroll 1
+  for (int pr = 0; pr < kWtProbe && __any(p0 | p1); ++pr) {
+    int old0 = -2, old1 = -2;
+    if (p0) old0 = atomicCAS(&t.keys[h0], -1, key0);
+    if (p1) old1 = atomicCAS(&t.keys[h1], -1, key1);
+    if (p0) {
+      if (old0 == -1 || old0 == key0) { slot0 = (int)h0; p0 = false; } else h0 = (h0 + 1) & (NE - 1);
+    }
+    if (p1) {
+      if (old1 == -1 || old1 == key1) { slot1 = (int)h1; p1 = false; } else h1 = (h1 + 1) & (NE - 1);
+    }
+  }
+}
+
 // vals[slot] += v for every lane with `on` (slot >= 0).  Must be called by the whole wave.
 template <int NE, int NV4>
 __device__ __forceinline__ void wt_add(WaveTable<NE, NV4> &t, const int slot, const float4 (&v)[NV4],
@@ -794,6 +817,42 @@ __device__ __forceinline__ void wt_add2(WaveTable<NE, NV4> &t, const int slot0, 
       p1 = use0 ? p1 : false;
       p0 = false;
     }
+  }
+}
+
+// The same two accumulations per lane WITHOUT an election, for callers whose lanes come in groups that cannot collide: the
+// lanes of one PIXEL hold distinct Gaussians (a Gaussian sits in a pixel's list once), so the pixels of a round take the table
+// one after the other -- `ord` = the lane's pixel ordinal in the round, 0 .. n - 1 -- and inside a step every lane reads,
+// adds and writes its two entries with no owner word written, read back and compared.  The fused backward's rounds hold 3-4
+// pixels and its elections took 3.4 rounds: as many steps, each a third cheaper.  Must be called by the whole wave.
+template <int NE, int NV4>
+__device__ __forceinline__ void wt_add2_by_group(WaveTable<NE, NV4> &t, const int slot0, const float4 (&v0)[NV4], const bool on0,
+                                                 const int slot1, const float4 (&v1)[NV4], const bool on1, const int ord) {
+  bool pend = on0 | on1;
+#pragma unroll 1
+  for (int g = 0; __any(pend); ++g) {
+    if (pend && ord == g) {
+      if (on0) {
+        float4 *dst = t.vals + slot0 * NV4;
+#pragma unroll
+        for (int q = 0; q < NV4; ++q) {
+          float4 x = dst[q];
+          x.x += v0[q].x; x.y += v0[q].y; x.z += v0[q].z; x.w += v0[q].w;
+          dst[q] = x;
+        }
+      }
+      if (on1) {
+        float4 *dst = t.vals + slot1 * NV4;
+#pragma unroll
+        for (int q = 0; q < NV4; ++q) {
+          float4 x = dst[q];
+          x.x += v1[q].x; x.y += v1[q].y; x.z += v1[q].z; x.w += v1[q].w;
+          dst[q] = x;
+        }
+      }
+      pend = false;
+    }
+    __builtin_amdgcn_wave_barrier();      // (the next pixel's reads come after this pixel's writes in the wave's LDS queue)
   }
 }
 
