@@ -510,6 +510,51 @@ def test_rebuilt_sweep_equals_round_3_sweep_bit_for_bit(hip_lib, N, H, W, K, B, 
         assert np.array_equal(out[0][1][0], out[0][0][0]) and np.array_equal(out[0][1][1], out[0][0][1])
 
 
+@pytest.mark.parametrize("N,H,W,K,B,iso_every", [
+    (3000, 72, 88, 40, 1, 0),       # every Gaussian a full 3x3 form, K = 40, ragged image
+    (1500, 40, 56, 25, 2, 3),       # a third of them isotropic (mixed trips), odd K, two views
+    (70000, 64, 64, 12, 1, 0),      # more than 65536 Gaussians: list entries carry stream positions
+])
+def test_general_sweep_equals_round_3_general_sweep_bit_for_bit(hip_lib, N, H, W, K, B, iso_every):
+    """Round 5: sweep_iso_kernel<true> -- the scalar kernel's design (fp32 len + 16-bit handle per list entry, float-compare
+    commits, SoA-staged records, packed evaluation, exit test every 16) for full 3x3 forms -- against round 3's general sweep,
+    trace_fwd_kernel<1, false> (64-bit keys), which lives on in the -DVOGE_AB build: the same index lists, hit counts and the
+    same len / act / dsd BITS (pair_eval_gen's operations in both), with and without act / dsd."""
+    from voge_amd import ops
+    rng = np.random.default_rng(N + K + 1)
+    verts = rng.uniform(-1.0, 1.0, (N, 3)).astype(np.float32)
+    r = rng.uniform(0.03, 0.08, N) * (1.0 if N < 50000 else 0.3)
+    L = rng.normal(size=(N, 3, 3)) * 0.35 + np.eye(3)[None]
+    S = np.einsum("nij,nkj->nik", L, L) / (r * r / (2 * np.log(1 / 0.6)))[:, None, None]      # SPD, anisotropic
+    if iso_every:
+        S[::iso_every] = np.eye(3)[None] * (1.0 / (r[::iso_every] ** 2 / (2 * np.log(1 / 0.6))))[:, None, None]
+    S = S.astype(np.float32)
+    R, T = camera_np.look_at_view_transform([3.0, 3.3][:B], [10.0, -25.0][:B], [20.0, 160.0][:B])
+    rays, origin = camera_np.pixel_rays(R, T, 1.1 * W, (W / 2.0, H / 2.0), (H, W))
+    mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32)
+    isg = np.ascontiguousarray(np.broadcast_to((2 * S)[None], (B, N, 3, 3))).astype(np.float32)
+    thr_act = oracle.thr_act_of(0.01)
+
+    def both():
+        full = [n(x) for x in ops.ray_trace_fine(t(mus.reshape(-1, 3)), t(isg.reshape(-1, 3, 3)), t(rays), None, thr_act, 16, K)]
+        li, ll, lz = ops.trace_lean(0, t(mus.reshape(-1, 3)), t(isg.reshape(-1, 3, 3)), None, t(rays), None, thr_act, K)      # (no act / dsd)
+        return full, [n(li), n(ll), n(lz.cnt)]
+    new = both()
+    ctx, ab = _ab_library()
+    try:
+        assert ab.voge_debug_sweep_variant(1) == 0
+        old = both()
+    finally:
+        ab.voge_debug_sweep_variant(0)
+        ctx.__exit__()
+    assert (new[0][0] >= 0).sum() > 500
+    for x, y, name in zip(new[0], old[0], ("idx", "len", "act", "dsd")):
+        assert np.array_equal(x, y), name
+    for x, y, name in zip(new[1], old[1], ("idx", "len", "cnt")):
+        assert np.array_equal(x, y), name
+    assert np.array_equal(new[1][0], new[0][0]) and np.array_equal(new[1][1], new[0][1])
+
+
 @pytest.mark.parametrize("N,extent,r_lo,r_hi,K,what", [
     (70000, 0.5, 0.6, 0.7, 6, "stream-everything fallback with more than 65536 Gaussians: 32-bit handles, two half-tile passes"),
     (90000, 0.05, 0.002, 0.004, 9, "pooled tile lists longer than 65536 entries"),

@@ -36,7 +36,15 @@ struct Sweep2Stage {
 };
 __host__ __device__ inline size_t sweep2_len_bytes(const int K) { return (sizeof(float) * (size_t)(K + 1) * kS2TP + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t sweep2_pos_bytes(const int K) { return (sizeof(uint16_t) * (size_t)(K + 1) * kS2TQ + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t sweep2_lds_bytes(const int K) { return sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage); }
+// GEN (full 3x3 forms, round 5): the staged chunk's eleven further coefficients of pair_eval_gen's record -- s11, s22, s01, s02,
+// s12, b (3), k (3); s00 sits in Sweep2Stage::a, where an isotropic candidate keeps its a -- SoA like the rest.  e[0][i]
+// (s11) is NaN for a staged ISOTROPIC candidate (and for the padding): that is how the consume loop tells the two apart.
+struct Sweep2Gen {
+  float e[11][64 + kS2Pad];
+};
+__host__ __device__ inline size_t sweep2_lds_bytes(const int K, const bool gen = false) {
+  return sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage) + (gen ? sizeof(Sweep2Gen) : 0);
+}
 
 #ifndef VOGE_S2_EPI_B
 #define VOGE_S2_EPI_B 5      // epilogue: items (4 slots each) per thread and batch
@@ -61,8 +69,12 @@ constexpr int kExitGroup = VOGE_S2_EXIT_GROUP;
 #define VOGE_S2_PRIO_LEN 0   // (experiment) tiles with at least this many candidates run at raised wave priority; 0: off
 #endif
 
+// GEN = false: every Gaussian is A = a I (ms = (mu, a)).  GEN = true: the general entry points' kernel -- ms = (mu, s00 | NaN),
+// NaN sending the reader to evr[3 g .. 3 g + 2], pair_eval_gen's record (VoGE/csrc/ray_trace_voge/ray_trace_voge.cu:11-38: all
+// nine entries of isigmas are inputs); an isotropic Gaussian among them is evaluated exactly as the scalar kernel does.
+template <bool GEN>
 __global__ void __launch_bounds__(64)
-sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms, const float *__restrict__ rays,
+sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms, const float4 *__restrict__ evr, const float *__restrict__ rays,
                  const int *__restrict__ bin_count, const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb,
                  const int32_t *__restrict__ tl_id, const float *__restrict__ tl_lb, const int32_t *__restrict__ pool_id,
                  const float *__restrict__ pool_lb, const int *__restrict__ tl_off, const int2 *__restrict__ order,
@@ -73,6 +85,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   float *const Llen = reinterpret_cast<float *>(smem_raw);
   unsigned char *const Lpos_raw = smem_raw + sweep2_len_bytes(K);
   Sweep2Stage &S = *reinterpret_cast<Sweep2Stage *>(smem_raw + sweep2_len_bytes(K) + sweep2_pos_bytes(K));
+  Sweep2Gen &G = *reinterpret_cast<Sweep2Gen *>(smem_raw + sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage));      // (GEN only)
 
   const int lane = threadIdx.x;
   const int tiles_x = (W + 7) >> 3;
@@ -146,6 +159,9 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   auto id_of = [&](const unsigned h) -> int { return h_is_id ? (int)h : src_id[h]; };
   const float not_full = __uint_as_float(__float_as_uint(VOGE_SENT_LEN) - 1u);      // len <= this  <=>  len < the sentinel
   if (lane < kS2Pad) { S.x[64 + lane] = 0.f; S.y[64 + lane] = 0.f; S.z[64 + lane] = 0.f; S.a[64 + lane] = INFINITY; }
+  if (GEN && lane < kS2Pad) G.e[0][64 + lane] = __uint_as_float(0x7fc00000u);      // (padding counts as isotropic)
+  const float4 *evrb = GEN ? evr + (size_t)b * N * 3 : nullptr;
+  bool tile_gen = false;      // (GEN) a general candidate was staged at some point: the epilogue needs the full records
 
   // ---- the wave's bounding cone over all 64 rays of the tile (only a cone-filtered stream needs it), unit-ray flag ----
   // (evaluated inside run(), BEHIND the first requests for the tile's list: the flag is needed at the first exit test only,
@@ -201,9 +217,18 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       const voge_v4f r = __builtin_amdgcn_raw_buffer_load_b128(rs_cull, id * 16, 0, 0);
       return make_float4(r[0], r[1], r[2], (id >= 0) ? r[3] : -1.f);
     };
+    // (GEN: pair_eval_gen's record, three 16-byte loads per candidate, requested with (mu, s00 | NaN) -- for every candidate of
+    //  a general launch: whether it is needed is known only when that first load is back)
+    const __amdgpu_buffer_rsrc_t rs_ev = out_rsrc(const_cast<float4 *>(GEN ? evrb : msb), GEN ? (unsigned)N * 48u : 0u);
+    auto load_ev = [&](const int id, const int k) {
+      const voge_v4f r = __builtin_amdgcn_raw_buffer_load_b128(rs_ev, id * 48 + 16 * k, 0, 0);
+      return make_float4(r[0], r[1], r[2], r[3]);
+    };
     // (the first chunk's records go out as soon as its ids are here; the rays' set-up runs while they travel)
     float4 m0 = load_ms(id0);
     float4 c0 = pref ? cull_none : load_cull(id0);
+    float4 ea0 = rec_none, ea1 = rec_none, ea2 = rec_none;
+    if (GEN) { ea0 = load_ev(id0, 0); ea1 = load_ev(id0, 1); ea2 = load_ev(id0, 2); }
     if (pass == 0) ray_setup(!WIDE, dx, dy, dz);
     const float rdn2 = __builtin_amdgcn_rcpf((dx * dx + dy * dy) + dz * dz);      // (pair_eval_iso: md * rcp(qxx + qyy + qzz))
     // (24-bit multiplies of 32-bit offsets: a plain `row * stride` index becomes a quarter-rate 64-bit multiply-add)
@@ -284,6 +309,59 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
     };
     int Kv = K;
     asm volatile("" : "+v"(Kv));      // (K in a VGPR for good: the compiler re-materialised it from its SGPR in front of every select)
+    // (GEN) The insertion where it is NOT nearly always an append or one row deep: full 3x3 forms arrive ordered by their centres'
+    // depth, their lens along a ray are not -- a third of the candidates of a tile land out of order, four rows deep on average
+    // (round 3's counters).  Four rows per round trip: the four entries below the gap are read together, the prefix of them
+    // behind the new entry moves up (the list is sorted: it IS a prefix), and only a lane that moved all four goes round again.
+    // Exact (len, id) order: an exact len tie is resolved by the ids in a uniform, rare branch.  (lean_insert / slow_insert
+    // cost this kernel + 34 % on long thin ellipsoids: 255 against round 3's 187 us.)
+    auto deep_insert = [&](const float len, const unsigned p, const bool slow) {
+      const bool full = (cnt == K);
+      bool go = slow;
+      int my_id = -1;
+      if (__builtin_expect(__ballot(go & full & (len == worstf)) != 0ull, 0)) {      // a tie with the K-th entry: the id rule says who stays
+        if (go & full & (len == worstf)) {
+          my_id = id_of(p);
+          if (!(my_id < id_of(pos_at(K - 1)))) go = false;
+        }
+      }
+      int pos = full ? K - 1 : cnt;      // the row the entry takes if nothing moves (a full list drops its row K - 1)
+      const int pos0 = pos;
+      float top = len;                   // (full lists) what ends up in row K - 1
+      bool walking = go, first = true;
+      while (__ballot(walking) != 0ull) {
+        const int r1 = max(pos - 1, 0), r2 = max(pos - 2, 0), r3 = max(pos - 3, 0), r4 = max(pos - 4, 0);
+        const float l1 = len_at(r1), l2 = len_at(r2), l3 = len_at(r3), l4 = len_at(r4);
+        const unsigned h1 = pos_at(r1), h2 = pos_at(r2), h3 = pos_at(r3), h4 = pos_at(r4);
+        bool g1 = l1 > len, g2 = l2 > len, g3 = l3 > len, g4 = l4 > len;
+        if (__builtin_expect(__ballot(walking & ((l1 == len) | (l2 == len) | (l3 == len) | (l4 == len))) != 0ull, 0)) {
+          if (walking & ((l1 == len) | (l2 == len) | (l3 == len) | (l4 == len))) {      // equal lens: the larger id is behind
+            if (my_id < 0) my_id = id_of(p);
+            g1 = g1 | ((l1 == len) && id_of(h1) > my_id); g2 = g2 | ((l2 == len) && id_of(h2) > my_id);
+            g3 = g3 | ((l3 == len) && id_of(h3) > my_id); g4 = g4 | ((l4 == len) && id_of(h4) > my_id);
+          }
+        }
+        const bool c1 = walking & (pos >= 1) & g1, c2 = c1 & (pos >= 2) & g2, c3 = c2 & (pos >= 3) & g3, c4 = c3 & (pos >= 4) & g4;
+        if (first) top = c1 ? l1 : len;
+        first = false;
+        put(c1 ? pos : Kv, l1, h1);              // (a lane that moves nothing writes the spare row)
+        put(c2 ? pos - 1 : Kv, l2, h2);
+        put(c3 ? pos - 2 : Kv, l3, h3);
+        put(c4 ? pos - 3 : Kv, l4, h4);
+        pos -= (c1 ? 1 : 0) + (c2 ? 1 : 0) + (c3 ? 1 : 0) + (c4 ? 1 : 0);
+        walking = c4;
+      }
+      put(go ? pos : Kv, len, p);
+      if (go) {
+        if (full) {
+          tailf = top; worstf = top;
+        } else {
+          if (pos == pos0) tailf = len;      // (a tie with the tail and the larger id: still the last entry)
+          if (++cnt == K) worstf = tailf;
+        }
+      }
+    };
+
     auto commit = [&](const float len, const float act, const unsigned p) {
       const bool take = (act < thr_act) & (len <= worstf);
       const bool app = take & (len > tailf);      // (a full list has tail == worst: it never appends)
@@ -301,9 +379,13 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 #ifdef VOGE_SWEEP_SLOW
         dbg_moved = 0;
 #endif
-        const bool hard = lean_insert(len, p, slow, Kv);
-        if (__builtin_expect(__ballot(hard) != 0ull, 0)) {
-          if (hard) slow_insert(len, p);
+        if (GEN) {
+          deep_insert(len, p, slow);
+        } else {
+          const bool hard = lean_insert(len, p, slow, Kv);
+          if (__builtin_expect(__ballot(hard) != 0ull, 0)) {
+            if (hard) slow_insert(len, p);
+          }
         }
 #ifdef VOGE_SWEEP_SLOW
         ts_slow += wall_clock64() - tss; ++st_slow;
@@ -328,9 +410,11 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       const int id = id0;
       const float lbv = lb0;
       const float4 mrec = m0, crec = c0;
+      const float4 e0 = ea0, e1 = ea1, e2 = ea2;
       id0 = id1; lb0 = lb1;
       m0 = load_ms(id0);
       c0 = pref ? cull_none : load_cull(id0);
+      if (GEN) { ea0 = load_ev(id0, 0); ea1 = load_ev(id0, 1); ea2 = load_ev(id0, 2); }
       id1 = load_id(base + 128 + lane);
       lb1 = load_lb(base + 128 + lane);
 #ifdef VOGE_SWEEP_TIMES
@@ -391,10 +475,20 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       // ---- stage ----
       int nbuf;
       __syncthreads();      // (the previous chunk's readers are done)
+      // (GEN) what a staged candidate leaves in the eleven further arrays; an isotropic one (mrec.w is its a, not NaN) only the
+      // marker.  A general candidate's s00 takes a's place.
+      const bool cgen = GEN && !(mrec.w == mrec.w);
+      auto stage_gen = [&](const int sl) {
+        G.e[0][sl] = cgen ? e0.y : __uint_as_float(0x7fc00000u);
+        G.e[1][sl] = e0.z; G.e[2][sl] = e0.w; G.e[3][sl] = e1.x; G.e[4][sl] = e1.y; G.e[5][sl] = e1.z; G.e[6][sl] = e1.w;
+        G.e[7][sl] = e2.x; G.e[8][sl] = e2.y; G.e[9][sl] = e2.z; G.e[10][sl] = e2.w;
+      };
+      const float a_st = cgen ? e0.x : mrec.w;
       if (pref) {
-        S.x[lane] = mrec.x; S.y[lane] = mrec.y; S.z[lane] = mrec.z; S.a[lane] = mrec.w;      // (behind the list: never-hit records)
+        S.x[lane] = mrec.x; S.y[lane] = mrec.y; S.z[lane] = mrec.z; S.a[lane] = a_st;      // (behind the list: never-hit records)
         S.lb[lane] = lbv;
         S.pos[lane] = h_is_id ? id : base + lane;
+        if (GEN) stage_gen(lane);
         nbuf = min(64, src_n - base);
       } else {
         const bool keep = cone_keep(crec, wcone);      // (padding: reach -1, never kept)
@@ -402,13 +496,22 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
         nbuf = __popcll(m);
         if (keep) {
           const int sl = __popcll(m & ((1ull << lane) - 1ull));
-          S.x[sl] = mrec.x; S.y[sl] = mrec.y; S.z[sl] = mrec.z; S.a[sl] = mrec.w;
+          S.x[sl] = mrec.x; S.y[sl] = mrec.y; S.z[sl] = mrec.z; S.a[sl] = a_st;
           S.lb[sl] = lbv;
           S.pos[sl] = h_is_id ? id : base + lane;
+          if (GEN) stage_gen(sl);
         }
         if (lane < kS2Pad) { S.x[nbuf + lane] = 0.f; S.y[nbuf + lane] = 0.f; S.z[nbuf + lane] = 0.f; S.a[nbuf + lane] = INFINITY; }
+        if (GEN && lane < kS2Pad) G.e[0][nbuf + lane] = __uint_as_float(0x7fc00000u);
       }
       __syncthreads();
+      // (GEN) bit s: staged entry s is a general candidate
+      unsigned long long gmask = 0ull;
+      if (GEN) {
+        const float mk = G.e[0][lane];
+        gmask = __ballot(lane < nbuf && mk == mk);
+        tile_gen = tile_gen || gmask != 0ull;
+      }
 #ifdef VOGE_SWEEP_TIMES
       const unsigned long long tsb = wall_clock64();
       ts_fill += tsb - tsa;
@@ -432,6 +535,13 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
              Zn = *reinterpret_cast<const float4 *>(&S.z[0]), An = *reinterpret_cast<const float4 *>(&S.a[0]);
       int4 Pn = *reinterpret_cast<const int4 *>(&S.pos[0]);
 #endif
+      // (GEN: the eleven further arrays one trip ahead as well -- read at their use they stalled every trip for an LDS round
+      //  trip at two waves per SIMD: SQ_WAIT_ANY + 28 % against round 3's general sweep, profiles/r5_pmc_sq_counters_gen.txt)
+      float4 Evn[GEN ? 11 : 1];
+      if (GEN) {
+#pragma unroll
+        for (int r = 0; r < 11; ++r) Evn[GEN ? r : 0] = *reinterpret_cast<const float4 *>(&G.e[r][0]);
+      }
       for (int s0 = 0; s0 < n; s0 += 4) {
         if ((s0 & (kExitGroup - 1)) == 0 && binned && unit_rays && __all(!valid || cnt == K)) {
           const float wmax = wave_max(valid ? worstf : -INFINITY);
@@ -452,6 +562,58 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 #endif
         const int pv[4] = {P.x, P.y, P.z, P.w};
         float len[4], act[4];
+        const unsigned gbits = GEN ? (unsigned)(gmask >> s0) & 15u : 0u;      // (uniform) which of the trip's four are general
+        if (GEN && gbits != 0u) {
+          // ---- pair_eval_gen's operations, bit for bit (voge_common.h): two candidates per packed instruction when all four
+          // of the trip are general, one by one (uniform branches) in a mixed trip ----
+          float4 Ev[11];
+#pragma unroll
+          for (int r = 0; r < 11; ++r) Ev[r] = Evn[GEN ? r : 0];
+          const float qxx = dx * dx, qyy = dy * dy, qzz = dz * dz, qxy = dx * dy, qxz = dx * dz, qyz = dy * dz;
+          if (gbits == 15u) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              auto half = [&](const float4 v) { return h ? (v2f){v.z, v.w} : (v2f){v.x, v.y}; };
+              const v2f x2 = half(X), y2 = half(Y), z2 = half(Z), s00 = half(A), s11 = half(Ev[0]), s22 = half(Ev[1]), s01 = half(Ev[2]),
+                        s02 = half(Ev[3]), s12 = half(Ev[4]), bx = half(Ev[5]), by = half(Ev[6]), bz = half(Ev[7]), kx = half(Ev[8]),
+                        ky = half(Ev[9]), kz = half(Ev[10]);
+              v2f ksk = s00 * splat(qxx);
+              ksk = pk_fma(s11, splat(qyy), ksk); ksk = pk_fma(s22, splat(qzz), ksk); ksk = pk_fma(s01, splat(qxy), ksk);
+              ksk = pk_fma(s02, splat(qxz), ksk); ksk = pk_fma(s12, splat(qyz), ksk);
+              v2f msk = bx * splat(dx);
+              msk = pk_fma(by, splat(dy), msk); msk = pk_fma(bz, splat(dz), msk);
+              const v2f t = msk * (v2f){__builtin_amdgcn_rcpf(ksk.x), __builtin_amdgcn_rcpf(ksk.y)} + splat(0.0f);      // (+0 canonicalises -0, as pair_eval_gen)
+              const v2f vx = pk_fma(-t, splat(dx), x2), vy = pk_fma(-t, splat(dy), y2), vz = pk_fma(-t, splat(dz), z2);
+              v2f a = s00 * (vx * vx);
+              a = pk_fma(s11, vy * vy, a); a = pk_fma(s22, vz * vz, a); a = pk_fma(s01, vx * vy, a);
+              a = pk_fma(s02, vx * vz, a); a = pk_fma(s12, vy * vz, a);
+              v2f kd = kx * splat(dx);
+              kd = pk_fma(ky, splat(dy), kd); kd = pk_fma(kz, splat(dz), kd);
+              a = pk_fma(t, kd, a);
+              len[2 * h] = t.x; len[2 * h + 1] = t.y;
+              act[2 * h] = a.x; act[2 * h + 1] = a.y;
+            }
+          } else {
+            const float mxs[4] = {X.x, X.y, X.z, X.w}, mys[4] = {Y.x, Y.y, Y.z, Y.w}, mzs[4] = {Z.x, Z.y, Z.z, Z.w}, avs[4] = {A.x, A.y, A.z, A.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              auto el = [&](const float4 v) { return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w)); };
+              if ((gbits >> q) & 1u) {      // (uniform)
+                EvalRec e;
+                e.s00 = avs[q]; e.s11 = el(Ev[0]); e.s22 = el(Ev[1]); e.s01 = el(Ev[2]); e.s02 = el(Ev[3]); e.s12 = el(Ev[4]);
+                e.bx = el(Ev[5]); e.by = el(Ev[6]); e.bz = el(Ev[7]); e.kx = el(Ev[8]); e.ky = el(Ev[9]); e.kz = el(Ev[10]);
+                const PairOut o = pair_eval_gen(mxs[q], mys[q], mzs[q], e, dx, dy, dz, qxx, qyy, qzz, qxy, qxz, qyz);
+                len[q] = o.len; act[q] = o.act;
+              } else {                      // an isotropic candidate (or padding): the scalar kernel's operations
+                const float md = fmaf(mzs[q], dz, fmaf(mys[q], dy, mxs[q] * dx));
+                const float t = md * rdn2;
+                const float vx = fmaf(-t, dx, mxs[q]), vy = fmaf(-t, dy, mys[q]), vz = fmaf(-t, dz, mzs[q]);
+                len[q] = t;
+                act[q] = avs[q] * fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+              }
+            }
+          }
+        } else {
 #if VOGE_S2_PACKED
         // pair_eval_iso's operations, bit for bit, two candidates per instruction (v_pk_mul / v_pk_fma_f32: the halves of a
         // ds_read_b128 are aligned register pairs already).  A packed FMA costs 1.7x a plain one on a SIMD that is shared
@@ -479,6 +641,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
           act[q] = av[q] * fmaf(vz, vz, fmaf(vy, vy, vx * vx));
         }
 #endif
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(len[q]), "+v"(act[q]));      // four interleaved chains, then the commits
 #if VOGE_S2_PREFETCH
@@ -486,6 +649,10 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
         Zn = *reinterpret_cast<const float4 *>(&S.z[s0 + 4]); An = *reinterpret_cast<const float4 *>(&S.a[s0 + 4]);
         Pn = *reinterpret_cast<const int4 *>(&S.pos[s0 + 4]);
 #endif
+        if (GEN && gmask != 0ull) {      // (uniform: a chunk without a general candidate reads none of them)
+#pragma unroll
+          for (int r = 0; r < 11; ++r) Evn[GEN ? r : 0] = *reinterpret_cast<const float4 *>(&G.e[r][s0 + 4]);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) commit(len[q], act[q], (unsigned)pv[q]);
       }
@@ -587,6 +754,38 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
               st16f<false>(t_len + rel[u], ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
             }
           }
+        } else if (GEN && tile_gen) {
+          // (GEN) a tile that staged general candidates: centre and full record (four gathers per slot) of one item in flight
+          // together; pair_eval's dispatch on the record, so an isotropic entry of such a tile is still exact
+          float *const t_act = out_act + tile_pix * K, *const t_dsd = out_dsd + tile_pix * K;
+#pragma unroll
+          for (int u = 0; u < kEpiB; ++u) {
+            const unsigned pr = rel[u] / (unsigned)K;      // pixel offset (rr W + x)
+            const float *ry = rays + (tile_pix + pr) * 3;
+            const float ex = ry[0], ey = ry[1], ez = ry[2];
+            float4 rc[4], g0[4], g1[4], g2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const size_t gi = (size_t)((q < nv[u]) ? oi[u][q] : gofs);
+              rc[q] = ms[gi]; g0[q] = evr[gi * 3]; g1[q] = evr[gi * 3 + 1]; g2[q] = evr[gi * 3 + 2];
+            }
+            float oa[4], od[4];
+            const float dn2 = (ex * ex + ey * ey) + ez * ez;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              PairOut o;
+              if (rc[q].w == rc[q].w) o = pair_eval_iso_at(rc[q].x, rc[q].y, rc[q].z, rc[q].w, ol[u][q], ex, ey, ez, dn2);
+              else o = pair_eval_gen(rc[q].x, rc[q].y, rc[q].z, unpack_eval(g0[q], g1[q], g2[q]), ex, ey, ez, ex * ex, ey * ey, ez * ez,
+                                     ex * ey, ex * ez, ey * ez);
+              oa[q] = (q < nv[u]) ? o.act : VOGE_SENT_ACT;
+              od[q] = (q < nv[u]) ? o.dsd : 0.0f;
+            }
+            if (nv[u] < 0) continue;
+            st16i<(VOGE_NT_STORES & 2) != 0>(t_idx + rel[u], oi[u][0], oi[u][1], oi[u][2], oi[u][3]);
+            st16f<(VOGE_NT_STORES & 2) != 0>(t_len + rel[u], ol[u][0], ol[u][1], ol[u][2], ol[u][3]);
+            st16f<(VOGE_NT_STORES & 2) != 0>(t_act + rel[u], oa[0], oa[1], oa[2], oa[3]);
+            st16f<(VOGE_NT_STORES & 2) != 0>(t_dsd + rel[u], od[0], od[1], od[2], od[3]);
+          }
         } else {
           float *const t_act = out_act + tile_pix * K, *const t_dsd = out_dsd + tile_pix * K;
 #pragma unroll
@@ -679,8 +878,15 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
           for (int u = 0; u < kOddU; ++u) {
             const float *ry = rays + (tile_pix + pr[u]) * 3;
             const float ex = ry[0], ey = ry[1], ez = ry[2];
-            const float4 cc = ms[in[u] ? oi[u] : gofs];
-            const PairOut o = pair_eval_iso_at(cc.x, cc.y, cc.z, cc.w, ol[u], ex, ey, ez, (ex * ex + ey * ey) + ez * ez);
+            const size_t gi = (size_t)(in[u] ? oi[u] : gofs);
+            const float4 cc = ms[gi];
+            PairOut o;
+            if (GEN && tile_gen && !(cc.w == cc.w)) {      // (a general entry: its full record, pair_eval_gen)
+              o = pair_eval_gen(cc.x, cc.y, cc.z, unpack_eval(evr[gi * 3], evr[gi * 3 + 1], evr[gi * 3 + 2]), ex, ey, ez, ex * ex, ey * ey,
+                                ez * ez, ex * ey, ex * ez, ey * ez);
+            } else {
+              o = pair_eval_iso_at(cc.x, cc.y, cc.z, cc.w, ol[u], ex, ey, ez, (ex * ex + ey * ey) + ez * ez);
+            }
             oa[u] = in[u] ? o.act : VOGE_SENT_ACT; od[u] = in[u] ? o.dsd : 0.0f;
           }
 #pragma unroll

@@ -497,7 +497,10 @@ struct BinLds {
 #define VOGE_ELL_KEY 0
 #endif
 
-constexpr int kGU = 8;      // gathers in flight per thread of binB's source passes
+#ifndef VOGE_BINB_GU
+#define VOGE_BINB_GU 8
+#endif
+constexpr int kGU = VOGE_BINB_GU;      // gathers in flight per thread of binB's source passes
 
 // What one pass over a quad's sources needs: the super-tile's segments (as binA filled them), the per-Gaussian records
 // for the slices whose segment overflowed, and the quad's cone.
@@ -1098,7 +1101,10 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
     int32_t *oid = tl_id + (size_t)tile * kTileCap;
     float *olb = tl_lb + (size_t)tile * kTileCap;
     BIN_WTS(0);
-    constexpr int kFU = 4;
+#ifndef VOGE_BINB_FU
+#define VOGE_BINB_FU 4
+#endif
+    constexpr int kFU = VOGE_BINB_FU;
     for (int base = 0; base < total; base += 64 * kFU) {
       uint32_t k[kFU];
       float4 cr[kFU];

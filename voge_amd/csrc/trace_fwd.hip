@@ -1150,22 +1150,27 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
   const size_t comp = (weight != nullptr) ? sizeof(float) * 3 * (size_t)compn_rows(K, 4, 64, true) : 0;
   const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + ((sizeof(TraceLds<T, ISO>) + 15) & ~(size_t)15) +
                      comp + VOGE_SWEEP_LDS_PAD;
-  // scalar sigmas, no composite inside the epilogue: round 4's kernel (sweep_iso.h: float-compare commits, 6-byte list entries)
+  // no composite inside the epilogue: sweep_iso_kernel (sweep_iso.h: float-compare commits, 6-byte list entries) -- <false> for
+  // scalar sigmas (round 4), <true> for the general forms (round 5)
 #ifdef VOGE_AB
-  const bool v2 = ISO && VOGE_SWEEP_V2 && weight == nullptr && g_sweep_variant.load(std::memory_order_relaxed) != 1;
-  constexpr bool kOldIso = true;
+  const bool v2 = VOGE_SWEEP_V2 && weight == nullptr && g_sweep_variant.load(std::memory_order_relaxed) != 1;
+  constexpr bool kOld = true;
 #else
-  const bool v2 = ISO && VOGE_SWEEP_V2 && weight == nullptr;
-  constexpr bool kOldIso = !VOGE_SWEEP_V2 || VOGE_FUSED_EPILOGUE;      // (the product keeps round 3's ISO kernel out of the library)
-  if (ISO && !v2 && !kOldIso) return VOGE_ERR_BAD_ARG;
+  const bool v2 = VOGE_SWEEP_V2 && weight == nullptr;
+  constexpr bool kOld = !VOGE_SWEEP_V2 || VOGE_FUSED_EPILOGUE;      // (the product keeps round 3's sweeps out of the library)
+  if (!v2 && !kOld) return VOGE_ERR_BAD_ARG;
 #endif
-  // (ISO && !kOldIso: the name below is the general kernel's -- never launched for scalar sigmas, see the check above)
-  auto kern = trace_fwd_kernel<1, ISO && kOldIso>;
-  const size_t lds2 = sweep2_lds_bytes(K) + VOGE_SWEEP_LDS_PAD;
+  const size_t lds2 = sweep2_lds_bytes(K, !ISO) + VOGE_SWEEP_LDS_PAD;
   {
-    static DynLdsCache cache, cache2;
-    const int rc = v2 ? ensure_dynamic_lds(reinterpret_cast<const void *>(sweep_iso_kernel), lds2, cache2)
-                      : ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, cache);
+    static DynLdsCache cache2;
+    if (v2) {
+      const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sweep_iso_kernel<!ISO>), lds2, cache2);
+      if (rc) return rc;
+    }
+  }
+  if constexpr (kOld) if (!v2) {
+    static DynLdsCache cache;
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(trace_fwd_kernel<1, ISO && kOld>), lds, cache);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(binB_kernel<!ISO>, dim3(ws.nstx * ws.nsty * 4, B), dim3(kQT), 0, st, ws.cull, ws.ell, ws.seg_count, ws.seg_id, ws.seg_rec,
@@ -1184,14 +1189,16 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
 #endif
   dim3 grid(ws.nbin * kTilesPerBin);     // one workgroup per tile slot of every super-tile (slots outside the image exit)
   if (v2) {
-    hipLaunchKernelGGL(sweep_iso_kernel, grid, dim3(T), lds2, st, ws.cull, ws.ms, rays, ws.q_count, ws.q_id, ws.q_lb, ws.tl_id, ws.tl_lb,
-                       ws.pool_id, ws.pool_lb, ws.tl_off, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx, ws.nstx * ws.nsty, N, H, W, K,
+    hipLaunchKernelGGL(sweep_iso_kernel<!ISO>, grid, dim3(T), lds2, st, ws.cull, ws.ms, ws.evr, rays, ws.q_count, ws.q_id, ws.q_lb, ws.tl_id,
+                       ws.tl_lb, ws.pool_id, ws.pool_lb, ws.tl_off, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx, ws.nstx * ws.nsty, N, H, W, K,
                        thr_act, idx, len, act, dsd, cnt);
     return launch_status();
   }
-  hipLaunchKernelGGL(kern, grid, dim3(T), lds, st, ws.cull, ws.evr, ws.ms, rays, ws.q_count, ws.q_id, ws.q_lb,
-                     ws.tl_count, ws.tl_id, ws.tl_lb, ws.pool_id, ws.pool_lb, ws.tl_off, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx,
-                     ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, weight, valid_num);
+  if constexpr (kOld) {
+    hipLaunchKernelGGL((trace_fwd_kernel<1, ISO && kOld>), grid, dim3(T), lds, st, ws.cull, ws.evr, ws.ms, rays, ws.q_count, ws.q_id, ws.q_lb,
+                       ws.tl_count, ws.tl_id, ws.tl_lb, ws.pool_id, ws.pool_lb, ws.tl_off, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx,
+                       ws.nstx * ws.nsty, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, weight, valid_num);
+  }
   return launch_status();
 }
 
