@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L3_BYTES = 256 << 20   # Infinity Cache: stage timings rotate over buffer sets larger than this
-TRACE_KERNELS = "voge_trace_topk_fwd(_iso) = binA + binB + sweep_iso_kernel (scalar sigmas; trace_fwd_kernel for 3x3 forms); super-tile cones come with the rays"
+TRACE_KERNELS = "voge_trace_topk_fwd(_iso) = binA + binB + sweep_iso_kernel<false> (scalar sigmas; <true> for 3x3 forms); the cone hierarchy (super-tiles, quads, tiles) comes with the rays"
 
 
 def parse():
@@ -690,7 +690,7 @@ def main():
         dom = "trace_fwd"  # the sweep BASELINE.json's metric names
         a = stages[dom]["GBps"]
         traffic, traffic_src = None, None
-        tname = next((t for t in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), None)
+        tname = next((t for t in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), None)
         tcfg = {}
         if tname is not None and not args.anisotropic:
             # HBM bytes per launch from rocprofv3 PMC passes of this same command (not collectable from inside the run)

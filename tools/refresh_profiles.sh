@@ -2,7 +2,7 @@
 # On the GPU box: regenerate everything under profiles/ for the current build (outputs land in
 # gpurun_out/refresh/, which gpurun merges back; copy them into profiles/ locally afterwards).
 # usage: tools/refresh_profiles.sh <round-tag, e.g. r2>
-TAG=${1:-r4}
+TAG=${1:-r5}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/refresh
