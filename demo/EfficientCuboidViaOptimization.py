@@ -1,0 +1,124 @@
+"""A cuboid from 102 anisotropic Gaussians, found by optimisation: the counterpart of the reference's
+demo/EfficientCuboidViaOptimization.py.
+
+Target: a unit cuboid of ~4000 isotropic surface Gaussians (`Cuboid.cuboid_gauss((-1,1),(-1,1),(-1,1), 4000, percentage=0.7)`,
+EfficientCuboidViaOptimization.py:58) whose attribute is the one-hot index of its face; rendered with max_assign 50,
+max_point_per_bin 1500 (:75).  Fitted: 6 faces x 17 Gaussians at fixed template positions (:21-42: the face centre and four
+rings of four points), each with a full 3x3 form `sigma = tril(L) tril(L)^T` (:17-18) and L the ONLY parameter, L = 4 I at the start and (4/3) I for the face centres (:65-67); rendered with max_assign = all 102,
+max_point_per_bin -1, thr_activation 0 (:78).  Loss: L1 between the two six-channel `interpolate_attr` maps (:88, :104-111);
+256 x 256, focal 200 (:73); Adam lr 0.02 betas (0.8, 0.6) stepping every 10th iteration on the accumulated gradient
+(:86, :116-119); views: one of six axis views for the first 1500 iterations, then random elev in [-60, 60), azim in [0, 360)
+at distance 5 (:90-98); 3200 iterations.  This is the general-form (`[N,3,3]` sigma) training loop of the package.
+
+What differs: the videos of :121-205 are left out (`--save DIR` writes the fitted cuboid from three views as PNG, PIL
+only); the run reports and returns the loss history; `tests/test_gpu_demo_loops.py` asserts that the loss goes down.
+
+usage: python demo/EfficientCuboidViaOptimization.py [--iters 3200] [--save DIR]"""
+import argparse
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from VoGE.Converter import Cuboid                                                                      # noqa: E402
+from VoGE.Meshes import GaussianMeshesNaive                                                            # noqa: E402
+from VoGE.Renderer import GaussianRenderer, GaussianRenderSettings, interpolate_attr                   # noqa: E402
+from voge_amd.cameras import PerspectiveCameras, look_at_view_transform                               # noqa: E402
+
+AXIS_VIEWS = ((-90, 0), (0, 0), (90, 0), (0, 90), (0, 180), (0, 270))                                  # :92 (elev, azim)
+FACE_RGB = ((1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0.8, 0.8), (0.8, 0, 0.8), (0.8, 0.8, 0))              # :55
+
+
+def face_template():
+    """In-plane coordinates (u, w) of a face's 17 Gaussians (:21-29): the centre and four groups of four points."""
+    a = np.array([0.0, 0.4, 0.6, 0.85])
+    b = np.array([0.85, 0.6, 0.4, 0.85])
+    u = np.concatenate(([0.0], a, -a, b, -b))
+    w = np.concatenate(([0.0], b, -b, -a, a))
+    return u, w
+
+
+def template_cuboid(scale=1.0):
+    """Centres [6 * n, 3] of the fitted Gaussians, face by face in the target's face order (z-, z+, y-, y+, x-, x+; :32-42),
+    and n = Gaussians per face."""
+    u, w = face_template()
+    one = np.ones_like(u)
+    faces = [np.stack((u, w, -one), 1), np.stack((u, w, one), 1), np.stack((u, -one, w), 1), np.stack((u, one, w), 1),
+             np.stack((-one, u, w), 1), np.stack((one, u, w), 1)]
+    return np.concatenate(faces, 0).astype(np.float32) * scale, len(u)
+
+
+def lower_to_form(L):
+    T = torch.tril(L)
+    return T @ T.transpose(-2, -1)
+
+
+def run(iters=3200, device="cuda", save=None, seed=0, log=print):
+    """-> {"loss": [per-iteration L1], "sec_per_iter": s, "L": fitted parameter [N,3,3]}"""
+    torch.manual_seed(seed)
+    rng = random.Random(seed)
+    size = (256, 256)
+    tv, ts, tc = Cuboid.cuboid_gauss((-1, 1), (-1, 1), (-1, 1), 4000, colors=np.eye(6, dtype=np.float32), percentage=0.7)
+    tv, ts, tc = (torch.as_tensor(np.asarray(a), dtype=torch.float32, device=device) for a in (tv, ts, tc))
+    target_mesh = GaussianMeshesNaive(verts=tv, sigmas=ts)
+    centres, per_face = template_cuboid()
+    centres = torch.from_numpy(centres).to(device)
+    N = centres.shape[0]
+    L0 = torch.eye(3)[None].repeat(N, 1, 1) * 4
+    L0[::per_face] /= 3                                   # the face centres start three times wider (:66-67)
+    L = torch.nn.Parameter(L0.to(device))
+    face_attr = torch.eye(6, device=device)[:, None].expand(-1, per_face, -1).reshape(N, 6).contiguous()
+    cams = PerspectiveCameras(focal_length=200, principal_point=((size[0] // 2, size[1] // 2),), image_size=(size,), device=device)
+    pp = (size[0] // 2, size[1] // 2)
+    r_target = GaussianRenderer(cameras=cams, render_settings=GaussianRenderSettings(
+        max_assign=50, principal=pp, image_size=size, max_point_per_bin=1500)).to(device)
+    r_fit = GaussianRenderer(cameras=cams, render_settings=GaussianRenderSettings(
+        max_assign=N, principal=pp, image_size=size, max_point_per_bin=-1, thr_activation=0)).to(device)
+    opt = torch.optim.Adam([L], lr=0.02, betas=(0.8, 0.6))
+    losses = []
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for it in range(iters):
+        if it <= 1500:
+            elev, azim = AXIS_VIEWS[rng.randint(0, 5)]
+        else:
+            elev, azim = rng.randrange(-60, 60), rng.randrange(0, 360)
+        R, T = look_at_view_transform(5, elev, azim, device=device)
+        with torch.no_grad():
+            want = interpolate_attr(r_target(target_mesh, R=R, T=T), tc)
+        got = interpolate_attr(r_fit(GaussianMeshesNaive(centres, lower_to_form(L)), R=R, T=T), face_attr)
+        loss = torch.nn.functional.l1_loss(got, want)
+        loss.backward()
+        losses.append(loss.detach())
+        if (it + 1) % 10 == 0:
+            opt.step()
+            opt.zero_grad()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t_start) / max(iters, 1)
+    losses = [float(x) for x in losses]
+    head, tail = float(np.mean(losses[:50])), float(np.mean(losses[-50:]))
+    log(f"{iters} iterations, {sec * 1e3:.2f} ms each ({N} Gaussians of full 3x3 form against {tv.shape[0]}): "
+        f"L1 {head:.4f} (first 50) -> {tail:.4f} (last 50)")
+    if save:
+        from PIL import Image
+        os.makedirs(save, exist_ok=True)
+        rgb = torch.tensor(FACE_RGB, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for name, (elev, azim) in (("fit_20_30", (20, 30)), ("fit_10_120", (10, 120)), ("fit_50_0", (50, 0))):
+                R, T = look_at_view_transform(4, elev, azim, device=device)
+                m = interpolate_attr(r_fit(GaussianMeshesNaive(centres, lower_to_form(L)), R=R, T=T), face_attr)
+                img = (m @ rgb).clamp(0, 1)[0].cpu().numpy() * 255
+                Image.fromarray(img.astype(np.uint8)).save(os.path.join(save, name + ".png"))
+    return {"loss": losses, "sec_per_iter": sec, "L": L.detach()}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=3200)
+    ap.add_argument("--save", default=None)
+    a = ap.parse_args()
+    run(a.iters, save=a.save)

@@ -497,6 +497,9 @@ struct BinLds {
 #define VOGE_ELL_KEY 0
 #endif
 
+#ifndef VOGE_BINB_XCD
+#define VOGE_BINB_XCD 0      // 1: the four quads of a super-tile on one XCD (measured: entry 69.8 -> 70.9 us, lean equal -- off)
+#endif
 #ifndef VOGE_BINB_GU
 #define VOGE_BINB_GU 8
 #endif
@@ -873,7 +876,13 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   BIN_TS(1, 7);      // (kernel entry)
   const int b = blockIdx.y;
-  const int binl = blockIdx.x >> 2, qq = blockIdx.x & 3;            // super-tile of this batch element, quad inside it
+  // super-tile of this batch element, quad inside it.  (VOGE_BINB_XCD=1 puts the four quads of a super-tile, which read the same
+  // 16 segments, 8 workgroup ids apart = on one XCD's L2: fewer HBM reads, but the entry is 1 us SLOWER with it and the
+  // renderer's form unchanged -- HISTORY R5 -- so it is off.)
+  int binl = blockIdx.x >> 2, qq = blockIdx.x & 3;
+#if VOGE_BINB_XCD
+  if ((int)blockIdx.x < ((nstx * nsty) >> 3) << 5) { binl = ((blockIdx.x >> 5) << 3) + (blockIdx.x & 7); qq = (blockIdx.x >> 3) & 3; }
+#endif
   const int stx = binl % nstx, sty = binl / nstx;
   const int bin = b * nstx * nsty + binl;
   const int quad = bin * 4 + qq;
