@@ -48,7 +48,7 @@ __host__ __device__ inline size_t comp_lds_bytes(const int K, const bool bwd) {
 // (the wave form keeps no per-workgroup state: no CompLds block in front of the arrays)
 __host__ __device__ inline size_t compn_lds_bytes(const int K, const int NS, const bool bwd, const int threads, const bool wave) {
   // (+ one cell per pixel of a wave: the window radius, composite_core.h)
-  return (wave ? 0 : sizeof(CompLds)) + sizeof(float) * (size_t)compn_rows(K, NS, threads, wave) * (bwd ? 4 : 3) + (wave ? 64 * sizeof(unsigned) : 0);
+  return (wave ? 0 : sizeof(CompLds)) + sizeof(float) * (size_t)compn_rows(K, NS, threads, wave) * (bwd ? 5 : 3) + (wave ? 64 * sizeof(unsigned) : 0);      // (backward: + u, + the row sums of compn_bwd_wave<NS, true>)
 }
 
 
@@ -375,6 +375,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
   float *const Lsp = Llen + rows;
   float *const LE = Lsp + rows;     // E (forward) or E * s' (backward)
   float *const Lu = LE + rows;      // backward only
+  float *const LR = Lu + rows;      // backward, wave form: the row sums the column walks accumulate (composite_core.h)
   const int tid = threadIdx.x, lane = tid & 63;
   const int LP = compn_lanes(K, NS);
   int p, q;
@@ -538,14 +539,14 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
       *reinterpret_cast<v2f *>(Llen + d0 + a) = (v2f){has[a] ? lm[a] : kBig, has[a + 1] ? lm[a + 1] : kBig};
       *reinterpret_cast<v2f *>(Lsp + d0 + a) = (v2f){has[a] ? sp[a] : 1.0f, has[a + 1] ? sp[a + 1] : 1.0f};
       *reinterpret_cast<v2f *>(LE + d0 + a) = (v2f){Es[a], Es[a + 1]};
-      if (BWD) *reinterpret_cast<v2f *>(Lu + d0 + a) = splat(0.0f);
+      if (BWD) { *reinterpret_cast<v2f *>(Lu + d0 + a) = splat(0.0f); if (WAVE) *reinterpret_cast<v2f *>(LR + d0 + a) = splat(0.0f); }
     }
     if (q < 2) {      // the sentinel pair in front of the row and the one behind it
       const int r0 = p * RS;
       for (int t = q; t < 2; t += LP) {
-        Llen[r0 + t] = -kBig; Lsp[r0 + t] = 1.0f; LE[r0 + t] = 0.0f; if (BWD) Lu[r0 + t] = 0.0f;
+        Llen[r0 + t] = -kBig; Lsp[r0 + t] = 1.0f; LE[r0 + t] = 0.0f; if (BWD) { Lu[r0 + t] = 0.0f; if (WAVE) LR[r0 + t] = 0.0f; }
         const int eb = r0 + RS - 2 + t;
-        Llen[eb] = kBig; Lsp[eb] = 1.0f; LE[eb] = 0.0f; if (BWD) Lu[eb] = 0.0f;
+        Llen[eb] = kBig; Lsp[eb] = 1.0f; LE[eb] = 0.0f; if (BWD) { Lu[eb] = 0.0f; if (WAVE) LR[eb] = 0.0f; }
       }
     }
   }
@@ -573,8 +574,8 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
     float um[NS], ga[NS], gl[NS], gd[NS];
 #pragma unroll
     for (int a = 0; a < NS; ++a) um[a] = gw[a] * wg[a];
-    compn_bwd_wave<NS>(lm, sm, em, um, Llen, Lsp, LE, Lu, d0, k0, K, q, LP, LP, in_wg, active, active && !wave_unsorted, seg_lo,
-                       occ, ga, gl, gd);
+    compn_bwd_wave<NS, true>(lm, sm, em, um, Llen, Lsp, LE, Lu, d0, k0, K, q, LP, LP, in_wg, active, active && !wave_unsorted, seg_lo,
+                             occ, ga, gl, gd, nullptr, LR);
     if (active) {
       if (vec && NS == 4) {
         at_bytes_w<float4>(out0, fb) = make_float4(ga[0], ga[1], ga[NS - 2], ga[NS - 1]);

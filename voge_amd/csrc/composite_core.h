@@ -246,13 +246,22 @@ __device__ unsigned long long g_cw_stats[1 << 16][4];
 // Backward, wave form, with the forward's weights given (u_m = g_m w_m comes from the caller): the closed-form
 // gradients of the lane's own slots (header of composite.hip).  The pixel's padded rows len / s' / E s' are in LDS
 // (the sentinel pads' u entries are zero); this routine stores u into Lu itself.  Same conventions as compn_fwd_rows.
-template <int NS>
+// RCOL (round 5): the row sums r_m = sum_j E_j s_j phi(x_mj) are not walked for at all.  phi(x_mj), x_mj = (len_m - len_j) s_j,
+// is a value the COLUMN walk of j's owner evaluates anyway (for u_m phi(x_mj)); that lane adds E_j s_j phi to row m's cell of
+// LR (an LDS row array laid out like Lu, zeroed by the caller) and the row's owner reads the sum afterwards.  The add is a plain
+// read - add - write: in one iteration of a walk the lanes of a wave address DIFFERENT row pairs (a pixel's lanes start NS rows
+// apart and step by two together; other pixels have other rows), and a wave's LDS operations complete in order, so the next
+// iteration's read sees this one's write -- the wave_barrier only keeps the compiler from moving the read above the write.
+// (ds_add_f32 instead costs ~60 cycles per wave instruction: the kernel 129 -> 251 us.)  The column walk reaches every row inside column j's OWN window 3.5 / s_j -- where phi >= 4.8e-6 --
+// while the row walk went as far as the pixel's widest window: the terms dropped are below that, like the column sums' own.
+// One of the kernel's two window walks and its divergence are gone for one packed multiply and two LDS adds per column pair.
+template <int NS, bool RCOL = false>
 __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const float (&sm)[NS], const float (&em)[NS],
                                                const float (&um)[NS], const float *Llen, const float *Lsp, const float *LE,
                                                float *Lu, const int d0, const int k0, const int K, const int q, const int LP,
                                                const int LPmax, const bool in_wg, const bool active, const bool sorted,
                                                const int seg_lo, const float occ, float (&ga)[NS], float (&gl)[NS],
-                                               float (&gd)[NS], unsigned *Lcell = nullptr) {
+                                               float (&gd)[NS], unsigned *Lcell = nullptr, float *LR = nullptr) {
   constexpr int NP = NS / 2;
   const int lane = threadIdx.x & 63;
   float sp[NS], Es[NS];
@@ -304,6 +313,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
         accR[b2].y = fmaf(Es[a], g.y, accR[b2].y);
       }
     }
+    if (!RCOL) {
     float lmB = lm[0];                 // the last live row decides how far back to walk
 #pragma unroll
     for (int a = 1; a < NS; ++a) lmB = (em[a] != 0.0f) ? lm[a] : lmB;
@@ -327,8 +337,10 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
         accR[a] = pk_fma(E2, gauss_pair(xa), accR[a]);
       }
     }
+    }
+    // (RCOL: the own block only; the other lanes' columns arrive through LR during their column walks below)
 #pragma unroll
-    for (int a = 0; a < NS; ++a) rterm[a] = (accR[a].x + accR[a].y) * (kRsqrtPi / kCs);
+    for (int a = 0; a < NS; ++a) rterm[a] = (accR[a].x + accR[a].y) * (RCOL ? 1.0f : kRsqrtPi / kCs);
   } else if (any_e && active) {          // unsorted list: every column
     const int r0 = d0 - k0;
     for (int j = 0; j < K; ++j) {
@@ -389,6 +401,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
       }
       for (int e = d0 + NS;; e += 2) {     // row pairs behind every own column
         const v2f l2 = ld2(Llen, e), u2 = ld2(Lu, e);
+        v2f racc = RCOL ? ld2(LR, e) : splat(0.0f);
         bool need = false;
 #pragma unroll
         for (int b2 = 0; b2 < NS; ++b2) need = need || (l2.x - lm[b2] < rj[b2]);
@@ -398,12 +411,16 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
         for (int b2 = 0; b2 < NS; ++b2) {
           const v2f d = l2 - splat(lm[b2]);
           const v2f xp = d * splat(sp[b2]);
-          const v2f y = u2 * gauss_pair(xp);
+          const v2f g = gauss_pair(xp);
+          const v2f y = u2 * g;
           aH[b2] = pk_fma(u2, h_pair(xp), aH[b2]); aP[b2] = aP[b2] + y; aL[b2] = pk_fma(y, d, aL[b2]);
+          if (RCOL) racc = pk_fma(splat(Es[b2]), g, racc);
         }
+        if (RCOL) { *reinterpret_cast<v2f *>(LR + e) = racc; __builtin_amdgcn_wave_barrier(); }
       }
       for (int e = d0 - 2;; e -= 2) {      // row pairs in front of every own column
         const v2f l2 = ld2(Llen, e), u2 = ld2(Lu, e);
+        v2f racc = RCOL ? ld2(LR, e) : splat(0.0f);
         bool need = false;
 #pragma unroll
         for (int b2 = 0; b2 < NS; ++b2) need = need || (lm[b2] - l2.y < rj[b2]);
@@ -413,9 +430,17 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
         for (int b2 = 0; b2 < NS; ++b2) {
           const v2f d = splat(lm[b2]) - l2;
           const v2f xp = d * splat(sp[b2]);
-          const v2f y = u2 * gauss_pair(xp);
+          const v2f g = gauss_pair(xp);
+          const v2f y = u2 * g;
           bH[b2] = pk_fma(u2, h_pair(xp), bH[b2]); bP[b2] = bP[b2] + y; bL[b2] = pk_fma(y, d, bL[b2]);
+          if (RCOL) racc = pk_fma(splat(Es[b2]), g, racc);
         }
+        if (RCOL) { *reinterpret_cast<v2f *>(LR + e) = racc; __builtin_amdgcn_wave_barrier(); }
+      }
+      if (RCOL) {      // every column walk of the pixel has passed (its lanes share this wave): the row sums are complete
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int a = 0; a < NS; ++a) rterm[a] = (rterm[a] + *lds_volatile(LR + d0 + a)) * (kRsqrtPi / kCs);
       }
       float suf = sx;
 #pragma unroll

@@ -53,6 +53,9 @@ __device__ unsigned long long g_fb_wall[kFbTimesWaves][2];       // its first an
 #define FB_TOUT() do {} while (0)
 #endif
 
+#ifndef VOGE_BWD_RCOL
+#define VOGE_BWD_RCOL 1
+#endif
 template <int NV4, int NS>
 struct FragBwdLds {
   // key = Gaussian index; values: (g_mu, g_a), (w g_rgb, -) for A = a I [NV4 = 2];
@@ -61,6 +64,9 @@ struct FragBwdLds {
   static constexpr int kRows = NS * 64 + 4 * kFbG;      // a round's padded rows: 64 lanes' slots + two sentinel pairs per pixel
   WaveTable<kFbNE, NV4> tab;
   float len[kRows], sp[kRows], E[kRows], u[kRows];
+#if VOGE_BWD_RCOL
+  float r[kRows];                 // row sums of the composite backward, accumulated by the column walks (compn_bwd_wave<NS, true>)
+#endif
   unsigned rmax[kFbG];            // per pixel of the round: its window radius (compn_bwd_wave)
 };
 
@@ -108,6 +114,9 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
   constexpr int NV4 = SRC == 0 ? (ISO ? 2 : 4) : (ISO ? 1 : 3), NACC = 4 * NV4;
   __shared__ __attribute__((aligned(16))) FragBwdLds<NV4, NS> L;
   float *const Llen = L.len, *const Lsp = L.sp, *const LE = L.E, *const Lu = L.u;
+#if VOGE_BWD_RCOL
+  float *const LR = L.r;
+#endif
   const int lane = threadIdx.x;
   FB_T0();
   const int blocks_x = (W + kFbGW - 1) / kFbGW;
@@ -310,12 +319,18 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
         *reinterpret_cast<v2f *>(Lsp + d0 + a) = (v2f){sm[a] * kCs, sm[a + 1] * kCs};
         *reinterpret_cast<v2f *>(LE + d0 + a) = (v2f){em[a] * (sm[a] * kCs), em[a + 1] * (sm[a + 1] * kCs)};
         *reinterpret_cast<v2f *>(Lu + d0 + a) = splat(0.0f);
+#if VOGE_BWD_RCOL
+        *reinterpret_cast<v2f *>(LR + d0 + a) = splat(0.0f);
+#endif
       }
       if (q < 2) {      // the sentinel pair in front of the pixel's row and the one behind it
         for (int t2 = q; t2 < 2; t2 += LP) {
           Llen[r0 + t2] = -kBig; Lsp[r0 + t2] = 1.0f; LE[r0 + t2] = 0.0f; Lu[r0 + t2] = 0.0f;
           const int eb = r0 + RS - 2 + t2;
           Llen[eb] = kBig; Lsp[eb] = 1.0f; LE[eb] = 0.0f; Lu[eb] = 0.0f;
+#if VOGE_BWD_RCOL
+          LR[r0 + t2] = 0.0f; LR[eb] = 0.0f;
+#endif
         }
       }
     }
@@ -324,8 +339,13 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
 #if VOGE_FB_ABL & 2       // (timing experiment: no composite)
     for (int a = 0; a < NS; ++a) { ga[a] = um[a]; gl[a] = um[a] * sm[a]; gd[a] = um[a] * em[a]; }
 #else
+#if VOGE_BWD_RCOL
+    compn_bwd_wave<NS, true>(lm, sm, em, um, Llen, Lsp, LE, Lu, d0, k0, NS * LP, q, LP, npm, on, on, true, pk.s0, occ, ga, gl, gd,
+                             VOGE_FB_LDS_RMAX ? &L.rmax[on ? pk.ord : 0] : nullptr, LR);
+#else
     compn_bwd_wave<NS>(lm, sm, em, um, Llen, Lsp, LE, Lu, d0, k0, NS * LP, q, LP, npm, on, on, true, pk.s0, occ, ga, gl, gd,
                        VOGE_FB_LDS_RMAX ? &L.rmax[on ? pk.ord : 0] : nullptr);
+#endif
 #endif
     __builtin_amdgcn_wave_barrier();      // the rows are rewritten by the next round
     FB_TICK(2);
