@@ -48,6 +48,11 @@ __global__ void __launch_bounds__(64) k_valu(float *out, const float seed, const
         }
         if (KIND == 8) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[u]) : "v"(c0));                  // v_mul_f32
         if (KIND == 9) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[u]) : "v"(pc0));              // v_pk_mul_f32
+        if (KIND == 10) asm volatile("v_exp_f32 %0, %0" : "+v"(a[u]));                                // v_exp_f32 (transcendental)
+        if (KIND == 11) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[u]));                                // v_rcp_f32
+        if (KIND == 12) { asm volatile("v_exp_f32 %0, %0" : "+v"(a[u])); asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[u]) : "v"(pc0), "v"(pc1));
+                          asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(u + 1) % kU]) : "v"(pc0), "v"(pc1));
+                          asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(u + 2) % kU]) : "v"(pc0), "v"(pc1)); }      // 1 exp + 3 pk_fma: do they overlap?
       }
     }
   }
@@ -88,6 +93,9 @@ int main() {
     run<5>("ds_read_b64 bcast + 2 add", out, w, 4.0 * kU);
     run<6>("ds_write_b32 + add", out, w, 4.0 * kU);
     run<7>("ds_write_b64 + add", out, w, 4.0 * kU);
+    run<10>("v_exp_f32", out, w, 4.0 * kU);
+    run<11>("v_rcp_f32", out, w, 4.0 * kU);
+    run<12>("v_exp_f32 + 3 v_pk_fma_f32 (per group)", out, w, 4.0 * kU);
   }
   return 0;
 }

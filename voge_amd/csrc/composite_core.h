@@ -19,6 +19,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define FAST_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #endif
 
+#ifndef VOGE_CF_ABL
+#define VOGE_CF_ABL 0      // timing experiments on the forward composite (bit 0: no window walks, bit 1: no own block)
+#endif
 #ifndef VOGE_COMP_MAXT
 #define VOGE_COMP_MAXT 256
 #endif
@@ -180,7 +183,7 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
     for (int a = 0; a < NS; ++a) {
       accF[a].x = em[a] * h0;         // self
 #pragma unroll
-      for (int b2 = a + 1; b2 < NS; ++b2) {
+      for (int b2 = a + 1; b2 < ((VOGE_CF_ABL & 2) ? 0 : NS); ++b2) {
         const float gap = lm[b2] - lm[a];
         const v2f xp = (v2f){gap * sp[b2], gap * sp[a]};                 // (row a, col b), (row b, col a)
         const v2f h = h_pair(xp);
@@ -191,6 +194,9 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
     float lmB = lm[0];                 // the last live row decides how far back to walk
 #pragma unroll
     for (int a = 1; a < NS; ++a) lmB = (em[a] != 0.0f) ? lm[a] : lmB;
+#if VOGE_CF_ABL & 1      // (timing experiment: no window walks)
+    if (lmB == -7.0f)
+#endif
     for (int e = d0 - 2;; e -= 2) {      // column pairs in front of every own row; row 0 is the nearest
       const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
       if (!(lm[0] - l2.y < rwin)) break;
@@ -200,6 +206,9 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
         accF[a] = pk_fma(E2, h_pair(xa), accF[a]);
       }
     }
+#if VOGE_CF_ABL & 1
+    if (lmB == -7.0f)
+#endif
     for (int e = d0 + NS;; e += 2) {     // column pairs behind every own row
       const v2f l2 = ld2(Llen, e), s2 = ld2(Lsp, e), E2 = ld2(LE, e);
       if (!(l2.x - lmB < rwin)) break;
