@@ -71,9 +71,12 @@ def run(iters=200, device="cuda", save=None, log=print):
             save_png(target, os.path.join(save, "target.png"))
             save_png(to_white_background(renderer(place(p0, p1), R=R, T=T), cols), os.path.join(save, "before.png"))
     losses = []
-    torch.cuda.synchronize()
+    warm = min(10, iters // 2)      # (the first iterations load the library and make the first allocations: not timed)
     t_start = time.perf_counter()
     for it in range(iters):
+        if it == warm:
+            torch.cuda.synchronize()
+            t_start = time.perf_counter()
         img = interpolate_attr(renderer(place(p0, p1), R=R, T=T), cols)
         loss = torch.nn.functional.mse_loss(img, target)
         loss.backward()
@@ -81,7 +84,7 @@ def run(iters=200, device="cuda", save=None, log=print):
         opt.zero_grad()
         losses.append(loss.detach())
     torch.cuda.synchronize()
-    sec = (time.perf_counter() - t_start) / max(iters, 1)
+    sec = (time.perf_counter() - t_start) / max(iters - warm, 1)
     losses = [float(x) for x in losses]
     out = {"loss": losses, "v0": p0.detach().cpu().numpy()[0], "v1": p1.detach().cpu().numpy()[0], "sec_per_iter": sec}
     log(f"{iters} iterations, {sec * 1e3:.2f} ms each: loss {losses[0]:.5f} -> {losses[-1]:.2e}; "
