@@ -17,6 +17,7 @@ principal_point).
 """
 import math
 
+import numpy as np
 import torch
 
 
@@ -142,10 +143,45 @@ def look_at_rotation(camera_position, at=((0, 0, 0),), up=((0, 1, 0),), device="
     return torch.stack([x, y, z], dim=-1)  # x, y, z as columns
 
 
+def _look_at_host(dist, elev, azim, degrees, eye, at, up):
+    """look_at_view_transform for plain numbers / lists / arrays, on the host in float32 (the same operations in the same
+    order as the tensor path below) -> R [B,3,3], T [B,3] as numpy arrays."""
+    f32 = np.float32
+    at = np.asarray(at, f32).reshape(-1, 3)
+    if eye is not None:
+        C = np.asarray(eye, f32).reshape(-1, 3)
+    else:
+        d, e, a = np.broadcast_arrays(*(np.asarray(v, f32).reshape(-1) for v in (dist, elev, azim)))
+        if degrees:
+            e, a = e * f32(math.pi / 180.0), a * f32(math.pi / 180.0)
+        C = np.stack([d * np.cos(e) * np.sin(a), d * np.sin(e), d * np.cos(e) * np.cos(a)], axis=-1).astype(f32) + at
+    B = C.shape[0]
+    at = np.broadcast_to(at, (B, 3))
+    up = np.broadcast_to(np.asarray(up, f32).reshape(-1, 3), (B, 3))
+    nrm = lambda v: v / np.maximum(np.sqrt((v * v).sum(-1, keepdims=True, dtype=f32)), f32(1e-5))
+    z = nrm(at - C)
+    x = nrm(np.cross(up, z).astype(f32))
+    y = nrm(np.cross(z, x).astype(f32))
+    degenerate = (np.abs(x) <= 5e-3).all(axis=1, keepdims=True)
+    x = np.where(degenerate, nrm(np.cross(y, z).astype(f32)), x)
+    R = np.stack([x, y, z], axis=-1).astype(f32)
+    T = -np.einsum("bji,bj->bi", R, C).astype(f32)
+    return R, T
+
+
 def look_at_view_transform(dist=1.0, elev=0.0, azim=0.0, degrees=True, eye=None, at=((0, 0, 0),),
                            up=((0, 1, 0),), device="cpu"):
     """(R [B,3,3], T [B,3]) with PyTorch3D's spherical convention:
-    C = dist*[cos(e)sin(a), sin(e), cos(e)cos(a)] + at,  T = -R^T C."""
+    C = dist*[cos(e)sin(a), sin(e), cos(e)cos(a)] + at,  T = -R^T C.
+    Arguments that are all plain numbers / sequences are evaluated on the host and R, T reach the device in ONE copy (as tensors
+    on the device every scalar is its own host-to-device copy and every operation a launch: ~ 0.67 ms per call, more than a
+    frame -- a training loop that draws a view per iteration spends its time here); tensors take the tensor path, which is
+    differentiable."""
+    if not any(isinstance(v, torch.Tensor) for v in (dist, elev, azim, eye, at, up)):
+        R, T = _look_at_host(dist, elev, azim, degrees, eye, at, up)
+        B = R.shape[0]
+        buf = torch.from_numpy(np.concatenate((R.reshape(-1), T.reshape(-1)))).to(device)
+        return buf[:B * 9].view(B, 3, 3), buf[B * 9:].view(B, 3)
     if eye is not None:
         C = torch.as_tensor(eye, dtype=torch.float32, device=device).reshape(-1, 3)
     else:
