@@ -357,6 +357,33 @@ def test_composite_random_vs_oracle(hip_lib, K):
         assert np.abs(n(got).reshape(npix, K) - ref).max() <= TOL * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("K", [7, 40, 130])
+def test_composite_every_pair_interacts(hip_lib, K):
+    """Windows as wide as the list (small dsd: 3.5 / s spans every depth) and runs of EQUAL depths: every row of a pixel takes a term
+    from every column.  The backward's row sums are accumulated by the column walks of the other lanes (composite_core.h,
+    compn_bwd_wave<NS, true>: ordered LDS read - add - write) -- here each cell is written once per iteration of every walk."""
+    from voge_amd import ops
+    rng = np.random.default_rng(100 + K)
+    npix = 2 * 41
+    ln = np.sort(np.round(rng.uniform(1, 8, (npix, K)) * 4) / 4, axis=1)      # quarter steps: many ties
+    act = rng.uniform(0, 4, (npix, K))
+    dsd = rng.uniform(0.05, 2.0, (npix, K))
+    idx = rng.integers(0, 1000, (npix, K)).astype(np.int32)
+    nv = rng.integers(K // 2, K + 1, npix)
+    hole = np.arange(K)[None] >= nv[:, None]
+    idx[hole], ln[hole], act[hole], dsd[hole] = -1, 1e10, 1e10, 0
+    shape = (2, 41, K)
+    ta, tl, td = (t(x.reshape(shape), rg=True) for x in (act, ln, dsd))
+    w, vn = ops.composite(t(idx.reshape(shape), torch.int32), ta, tl, td, 0.9)
+    wr, vr = oracle.composite_fwd(idx, act, ln, dsd, 0.9)
+    assert (n(vn).reshape(-1) == vr).all() and np.abs(n(w).reshape(npix, K) - wr).max() < TOL
+    gw = rng.normal(size=(npix, K))
+    (w * t(gw.reshape(shape))).sum().backward()
+    ra, rl, rd = oracle.composite_bwd(act.astype(np.float32), ln.astype(np.float32), dsd.astype(np.float32), gw, 0.9)
+    for got, ref, key in ((ta.grad, ra, "g_act"), (tl.grad, rl, "g_len"), (td.grad, rd, "g_dsd")):
+        assert np.abs(n(got).reshape(npix, K) - ref).max() <= TOL * max(1.0, np.abs(ref).max()), key
+
+
 def test_composite_unsorted_list(hip_lib):
     """Lists that are not depth sorted (possible through the public API) take the full K x K scan."""
     from voge_amd import ops
