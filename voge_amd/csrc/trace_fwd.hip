@@ -138,7 +138,29 @@ prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const 
 #include "trace_bin.h"
 #include "composite_core.h"
 
+#ifndef VOGE_ISO_PREP_SPLIT
+#define VOGE_ISO_PREP_SPLIT 131072      // Gaussians per batch element from which on the scalar-sigma records get their own pass
+#endif
+
 namespace voge {
+
+// The scalar-sigma records as a pass of their own: binA_kernel<true> derives them inside every (region, slice) workgroup -- one
+// launch less, and free while a slice is one round (cfg3: 3 Gaussians per thread).  At 200k Gaussians every thread derives 12
+// records -- as the same slice's workgroup of every other region does -- and the kernel is VALU-bound on it (5 of a workgroup's
+// 15.8 us, VOGE_HIP_LIB=bt.so tools/bin_times.py cfg4_200k_1024): from VOGE_ISO_PREP_SPLIT Gaussians on this pass runs first and
+// binA reads the records (cfg4: entry 297 -> 287 us, renderer form 272 -> 257).  Same functions, same bits.
+__global__ void __launch_bounds__(256)
+iso_prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const float *__restrict__ cam_fwd, const int N,
+                const float thr_act, const IsoView view, float4 *__restrict__ cull, float4 *__restrict__ ms) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (g >= N) return;
+  const BinAView V = binA_view<true>(b, cam_fwd, view);
+  const BinARaw raw = binA_fetch<true>(g, b, N, nullptr, mus, isg, view);
+  float a;
+  const float4 c = binA_derive<true>(raw, true, V, thr_act, view, a);
+  cull[(size_t)b * N + g] = c;
+  ms[(size_t)b * N + g] = make_float4(c.x, c.y, c.z, a);
+}
 
 // ------------------------------------------------------------------------------------------
 // sweep.  One workgroup = WAVES waves = a TW x TH pixel tile (each wave an 8x8 sub-tile, one
@@ -1365,7 +1387,12 @@ static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mu
     cones = ws.cones;
   }
   const dim3 gridA(ws.nst0x * ws.nst0y * kParts, B);
-  if (iso_in) {
+  if (iso_in && N >= VOGE_ISO_PREP_SPLIT) {
+    // scalar sigmas, slices of more than two rounds: the records in a pass of their own (iso_prep_kernel)
+    hipLaunchKernelGGL(iso_prep_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, mus, isigmas, cam_fwd, N, thr_act, view, ws.cull, ws.ms);
+    hipLaunchKernelGGL(binA_kernel<false>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
+                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top, ws.seg_ext, ws.ext_id, ws.ext_arena);
+  } else if (iso_in) {
     // scalar sigmas: binA derives the per-Gaussian records itself -- two launches in front of the sweep
     hipLaunchKernelGGL(binA_kernel<true>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
                        cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top, ws.seg_ext, ws.ext_id, ws.ext_arena);
