@@ -230,6 +230,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    # `multi`: the N > 1 code path.  VOGE_BENCH_FORCE_DIST=1 takes it with ONE rank too -- process group, split HIP graphs, the
+    # all_gather / all_reduce through the real backend (RCCL) -- which is what a single-GPU box can check of it
+    # (tests/test_gpu_parity.py::test_bench_one_rank_through_rccl).
+    multi = world > 1 or os.environ.get("VOGE_BENCH_FORCE_DIST", "0") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the VoGE hot path has no CPU fallback")
     # VOGE_BENCH_BACKEND=gloo lets several ranks share one GPU (a functional check of the multi-GPU
@@ -238,7 +242,7 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -266,8 +270,8 @@ def main():
         #  "row_bands": the same frame as one contiguous band per rank with measured rebalancing (rounds 1-2's scheme).
         #  "views": a batch of `world` views of the SAME Gaussians -- what a multi-view training iteration renders -- one whole
         #     view per rank (distributed.stacked_bounds); per-GPU work fixed: "scaling": "weak", value = all ranks' frames/s.
-        by_views = world > 1 and mode == "views"
-        striped = world > 1 and mode == "stripes"
+        by_views = multi and mode == "views"
+        striped = multi and mode == "stripes"
         stripe_h = stripe_height(H, world) if striped else None
         if by_views:
             Rv, Tv = look_at_view_transform(dist=[dd] * world, elev=[el] * world, azim=[az + 360.0 / world * r for r in range(world)], device=dev)
@@ -277,7 +281,7 @@ def main():
         # (the cameras carry the view too: the stand-alone stage timings below build their rays from `cams` alone)
         cams = PerspectiveCameras(focal_length=focal, principal_point=(pp,), image_size=((H, W),), R=R, T=T, device=dev)
         # row bands of the ranks: band r = rows [bounds[r], bounds[r + 1]); equal heights to start with
-        bands = {"bounds": [row_band(H, r, world)[0] for r in range(world)] + [H]} if (world > 1 and mode == "row_bands") else None
+        bands = {"bounds": [row_band(H, r, world)[0] for r in range(world)] + [H]} if (multi and mode == "row_bands") else None
         rows = (bands["bounds"][rank], bands["bounds"][rank + 1]) if bands is not None else None
         my_stripes = Stripes(H, rank, world, stripe_h) if striped else None
 
@@ -356,7 +360,7 @@ def main():
                 return step, "eager"
 
         def barrier():
-            if world > 1:
+            if multi:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -370,7 +374,7 @@ def main():
             barrier()
             dt = time.perf_counter() - t0
             timed.last_local_dt = dt      # (this rank's own clock; the line reports min / max over the ranks)
-            if world > 1:
+            if multi:
                 tt = torch.tensor([dt], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt = float(tt.item())
@@ -383,7 +387,7 @@ def main():
         balance_log = []
         if primary and args.only_stage and args.only_stage != "frame":      # ("frame": the frame alone, no stand-alone stage calls)
             run, launch = (lambda: None), "none (--only-stage)"
-        elif world == 1 and not args.split_graph:
+        elif not multi and not args.split_graph:
             run, launch = graphed_step(fwd, params)
         else:
             # Multi-GPU: the local compute is two HIP graphs -- band forward, band backward -- and the two exchanges
@@ -399,7 +403,7 @@ def main():
                 torch.autograd.backward(b, torch.ones_like(b))
             # Measured load balancing (stationary scene): every rank times its band's local compute, the times are exchanged
             # once per round and every rank moves the boundaries the same way (distributed.rebalance_bounds).  Setup, untimed.
-            if world > 1 and bands is not None and args.balance_rounds > 0:
+            if multi and bands is not None and args.balance_rounds > 0:
                 fixed = None
                 side = torch.cuda.Stream()      # (like every eager run in front of a capture: never on the default stream)
                 side.wait_stream(torch.cuda.current_stream())
@@ -471,7 +475,7 @@ def main():
 
         # settle (untimed, before the contract's W warmup steps): a fresh box ramps its clocks and pools over the first
         # tenths of a second of load; K steps of a 0.4 ms frame would otherwise be timed on the ramp
-        if world == 1:
+        if not multi:
             t_settle = time.perf_counter()
             while time.perf_counter() - t_settle < 0.3:
                 for _ in range(20):
@@ -485,7 +489,7 @@ def main():
         # are independent in every stage; stripes / bands / views only choose who computes which rows).  Every rank takes part
         # in the gather; rank 0 renders the whole frame (views mode: every view) alone and compares with torch.equal.
         split_exact = None
-        if world > 1 and primary and not (args.only_stage and args.only_stage != "frame"):
+        if multi and primary and not (args.only_stage and args.only_stage != "frame"):
             with torch.no_grad():
                 band = fwd()
                 whole = gather_stripes(band, H, stripe_h) if striped else gather_rows(band, H_all, bounds=gb)
@@ -506,7 +510,7 @@ def main():
         # what the line says about the job it ran on: the process group's own view of the world, and every rank's local clock
         # over the same timed region (before the max-reduction above)
         dist_info = None
-        if world > 1:
+        if multi:
             mine = [None] * world
             dist.all_gather_object(mine, float(timed.last_local_dt / args.steps * 1e3))
             dist_info = {"world_size": int(dist.get_world_size()), "backend": str(dist.get_backend()),
@@ -518,7 +522,7 @@ def main():
 
 
     mode = "views" if args.views else ("row_bands" if args.row_bands else "stripes")
-    M = measure(mode if world > 1 else "single")
+    M = measure(mode if multi else "single")
     (by_views, striped, stripe_h, bands, rows, my_stripes, cams, R, T, make_frame, graphed_step, timed, barrier, renderer_of, fwd, params, gm,
      colors, host_scene, balance_log, launch, dt, ms, fps, rows_kw, graph_checked) = (
         M.by_views, M.striped, M.stripe_h, M.bands, M.rows, M.my_stripes, M.cams, M.R, M.T, M.make_frame, M.graphed_step, M.timed, M.barrier,
@@ -534,7 +538,7 @@ def main():
         "config": {"workload": f"{args.config}: {N} random Gaussians ({sig_kind}), {H}x{W}, K={K}, max_point_per_bin={bins_kind}, "
                                f"fwd+bwd (grads to verts, sigmas, colors)",
                    "launch": launch, "graph_replay_gradients_checked_against_eager": bool(graph_checked),
-                   "parallelism": ("1 gpu" if world == 1 else
+                   "parallelism": ("1 gpu" if not multi else
                                    f"a batch of {world} views on the stacked (view, row) axis, view first: one whole view per rank; "
                                    f"all_gather(images) + all_reduce(gradients); a step = {world} frames" if by_views else
                                    f"ONE frame, pixel rows dealt to {world} ranks in interleaved stripes of {stripe_h} rows (each rank renders "
@@ -542,11 +546,11 @@ def main():
                                    f"ONE frame, one contiguous pixel-row band per rank x{world} (measured rebalancing), "
                                    f"all_gather(image)+all_reduce(grads)")},
     }
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         result["config"]["multi_gpu_mode"] = mode
         result["config"].update(M.dist_info)      # world_size / backend as torch.distributed reports them, per-rank ms, the exactness check
 
-    if world > 1 and bands is not None:
+    if multi and bands is not None:
         result["config"]["bands"] = list(bands["bounds"])      # rows [b[r], b[r+1]) of rank r, after the measured balancing
         result["band_balance"] = balance_log                      # (setup, untimed) what every round measured
     lib = _lib.load()
@@ -570,7 +574,7 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters, nset
 
-    if rank == 0 and world == 1:
+    if rank == 0 and not multi:
         # ---- per-stage kernel timings on the same inputs (HIP events, current stream) --------
         with torch.no_grad():
             from voge_amd.cameras import pixel_rays
@@ -762,7 +766,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(verts, sig, cols, H, W, K, focal, pp, (dd, el, az), args.cpu_seconds)
             # ... and the reference's own CPU-capable tensor program beside the C port
             result["cpu_baseline_torch"] = cpu_baseline_torch(verts, sig, cols, H, W, K, focal, pp, (dd, el, az), args.cpu_seconds)
-    if world > 1 and not args.no_variants:
+    if multi and not args.no_variants:
         # the other ways to use the same N GPUs, same scene (every rank takes part): the contiguous bands of rounds 1-2, the
         # weak-scaling batch of views, and north_star's config 4 (200k Gaussians, 1024^2) in the default mode
         variants = {}
@@ -779,7 +783,7 @@ def main():
                 variants[vname] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
         result["variants"] = variants
-    if rank == 0 and world > 1:
+    if rank == 0 and multi:
         # the dominant kernel on rank 0's rows (same entry point, shorter image), timed live
         with torch.no_grad():
             from voge_amd.cameras import pixel_rays
@@ -810,9 +814,19 @@ def main():
                                   "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                                   "algorithmic_bytes": nb, "avg_launch_ms": round(t_ms, 4)}
+    # the ONE line, and the LAST one: RCCL writes a version banner to the C library's stdout, which sits in its buffer until the
+    # process ends -- behind the line -- when stdout is a pipe or a file; every rank sends it out first
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if multi:
+        dist.barrier()
     if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+        print(json.dumps(result), flush=True)
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1177,6 +1177,36 @@ def test_bench_two_ranks_on_one_gpu(hip_lib, mode):
         assert v["views_weak_scaling"]["scaling"] == "weak" and all(x["value"] > 0 for x in v.values())
 
 
+def test_bench_one_rank_through_rccl(hip_lib):
+    """What ONE GPU can check of the N > 1 path under its real backend: VOGE_BENCH_FORCE_DIST=1 makes bench.py take that path with a
+    world of one rank -- `init_process_group("nccl", device_id=...)` (RCCL), the split HIP graphs captured with
+    capture_error_mode="thread_local" while RCCL's watchdog thread runs, `all_gather_into_tensor` between the two graphs and the
+    flat `all_reduce` behind them through RCCL, `all_gather_object` / `barrier` of the timing, and the untimed exactness check
+    (the assembled frame == the plain render).  The 2-rank runs of this box go through gloo (above); no hardware with more than
+    one GPU has run this path."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VOGE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    env.pop("VOGE_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-variants",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])      # (the LAST line: bench.py flushes RCCL's stdout banner out first)
+    c = line["config"]
+    assert c["world_size"] == 1 and c["backend"] == "nccl" and c["multi_gpu_mode"] == "stripes"
+    assert c["gathered_frame_equals_single_gpu_render"] is True
+    assert "hip graphs (band forward, band backward)" in c["launch"], c["launch"]      # (not the eager fallback)
+    assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0
+
+
 @pytest.mark.parametrize("form", ["iso", "iso_view_shared", "general", "fragments_iso_lean"])
 def test_batch_walked_in_chunks_equals_one_chunk(hip_lib, form):
     """the trace's scratch is sized for a chunk of the batch and the entry points walk the batch in chunks
