@@ -307,6 +307,32 @@ def test_trace_iso_scalar_form_vs_oracle(hip_lib):
         assert err <= TOL * max(1.0, np.abs(want).max()), f"{name}: {err:.3e} vs scale {np.abs(want).max():.3e}"
 
 
+def test_trace_iso_records_in_their_own_pass(hip_lib):
+    """From 131 072 Gaussians per batch element on, the scalar-sigma entry points make the (centre, reach) / (centre, a) records in
+    a pass of their own and binA reads them (trace_fwd.hip: iso_prep_kernel) instead of deriving them per region.  Two views with
+    their own 140 000 Gaussians each (the pass's batch axis), a fused preamble (origin subtraction, a = 2 sigma) and the plain
+    entry, against the oracle and against each other."""
+    from voge_amd import ops
+    rng = np.random.default_rng(140)
+    B, N, H, W, K = 2, 140000, 16, 24, 12
+    verts = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    sig = rng.uniform(900, 3000, (B, N)).astype(np.float32)
+    R, T = camera_np.look_at_view_transform([3.4] * B, [8.0, -15.0], [20.0, 130.0])
+    rays, origin = camera_np.pixel_rays(R, T, 40.0, (W / 2.0, H / 2.0), (H, W))
+    rays, origin = rays.astype(np.float32), origin.astype(np.float32)
+    thr_act = oracle.thr_act_of(0.01)
+    out_view = ops._RayTraceVoGEIsoView.apply(t(verts), t(sig), t(origin), t(rays), None, thr_act, K, 1)
+    mus = (verts - origin[:, None]).astype(np.float32)
+    a = (2.0 * sig).astype(np.float32)
+    out_plain = ops._RayTraceVoGEIso.apply(t(mus.reshape(-1, 3)), t(a.reshape(-1)), t(rays), None, thr_act, K)
+    for x, y in zip(out_view, out_plain):
+        assert torch.equal(x, y)
+    isg = a[..., None, None] * np.eye(3, dtype=np.float32)
+    ref = oracle.trace_fwd(mus, isg, rays, K, thr_act)
+    assert (ref[0] >= 0).mean() > 0.5
+    compare_trace([n(x) for x in out_plain], ref, thr_act, min_match=0.99, max_flips=8)
+
+
 # ------------------------------------------------------------------------------- composite
 @pytest.mark.parametrize("name", ["k5", "k25", "k40"])
 def test_composite_golden(hip_lib, name):
