@@ -264,6 +264,7 @@ __device__ unsigned long long g_cw_stats[1 << 16][4];
 // (ds_add_f32 instead costs ~60 cycles per wave instruction: the kernel 129 -> 251 us.)  The column walk reaches every row inside column j's OWN window 3.5 / s_j -- where phi >= 4.8e-6 --
 // while the row walk went as far as the pixel's widest window: the terms dropped are below that, like the column sums' own.
 // One of the kernel's two window walks and its divergence are gone for one packed multiply and two LDS adds per column pair.
+// (RCOL = true needs LR: a row array of the caller's LDS laid out like Lu, zeroed together with it.)
 template <int NS, bool RCOL = false>
 __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const float (&sm)[NS], const float (&em)[NS],
                                                const float (&um)[NS], const float *Llen, const float *Lsp, const float *LE,

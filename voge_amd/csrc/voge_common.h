@@ -711,10 +711,6 @@ __device__ __forceinline__ const lds_vint *lds_volatile(const int *p) { return (
 __device__ __forceinline__ lds_vuint *lds_volatile(unsigned *p) { return (lds_vuint *)p; }
 typedef __attribute__((address_space(3))) volatile float lds_vfloat;
 __device__ __forceinline__ const lds_vfloat *lds_volatile(const float *p) { return (const lds_vfloat *)p; }
-// ds_add_f32 (no return value) on a cell of the workgroup's LDS
-__device__ __forceinline__ void lds_add_f32(float *p, const float v) {
-  __hip_atomic_fetch_add((__attribute__((address_space(3))) float *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
 
 template <int NE, int NV4>
 struct WaveTable {
