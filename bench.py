@@ -506,6 +506,11 @@ def main():
             torch.cuda.synchronize()
         dt = timed(run, args.steps, args.warmup)
         ms = dt / args.steps * 1e3
+        # (not part of the contract's number: four more regions of the same K steps, so that the line shows the spread of its
+        #  headline -- at cfg3 a region is 20 x 0.26 ms)
+        repeats = None
+        if primary and not multi:
+            repeats = [round(timed(run, args.steps, 0) / args.steps * 1e3, 5) for _ in range(4)]
         fps = (world if by_views else 1) * args.steps / dt      # (views mode: every step renders `world` frames, one per rank)
         # what the line says about the job it ran on: the process group's own view of the world, and every rank's local clock
         # over the same timed region (before the max-reduction above)
@@ -546,6 +551,8 @@ def main():
                                    f"ONE frame, one contiguous pixel-row band per rank x{world} (measured rebalancing), "
                                    f"all_gather(image)+all_reduce(grads)")},
     }
+    if M.repeats is not None:
+        result["repeat_ms_per_step"] = M.repeats      # four more K-step regions behind the contract's one: the headline's spread
     if multi and rank == 0:
         result["config"]["multi_gpu_mode"] = mode
         result["config"].update(M.dist_info)      # world_size / backend as torch.distributed reports them, per-rank ms, the exactness check
