@@ -125,10 +125,25 @@ __device__ __forceinline__ EvalRec unpack_eval(const float4 a, const float4 b, c
 
 // One thread per Gaussian: the general (3x3) entry point's records.  (The scalar-sigma entry points derive
 // theirs inside binA.)
+// Small sets (VOGE_SMALL_N Gaussians per batch element or fewer): no binA at all.  The prep pass marks every (super-tile,
+// slice) segment as overflowed (count -1) and resets binB's pool counter, which is what binA does for a slice it could not
+// hold -- binB then takes a quad's candidates straight from the per-Gaussian records (its tested fallback: N / 256 cone tests per
+// thread and pass).  For a few thousand Gaussians that is cheaper than a launch whose workgroups are pure latency (binA: 8.4 us
+// at cfg5's 2 562 Gaussians; profiles/r5_kernel_trace_cfg5_loop.txt).
+__device__ __forceinline__ void small_set_marks(int *__restrict__ seg_count, const long n_seg, unsigned long long *__restrict__ pool_top) {
+  if (seg_count == nullptr) return;
+  const long t = ((long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+  const long nt = (long)gridDim.x * gridDim.y * blockDim.x;
+  for (long i = t; i < n_seg; i += nt) seg_count[i] = -1;
+  if (t == 0) *pool_top = 0ull;
+}
+
 __global__ void __launch_bounds__(256)
 prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const float *__restrict__ cam_fwd, const int N,
             const int P, const float thr_act, float4 *__restrict__ cull, float4 *__restrict__ evr,
-            float4 *__restrict__ ms, float4 *__restrict__ ell, float4 *__restrict__ pk) {
+            float4 *__restrict__ ms, float4 *__restrict__ ell, float4 *__restrict__ pk,
+            int *__restrict__ seg_count = nullptr, const long n_seg = 0, unsigned long long *__restrict__ pool_top = nullptr) {
+  small_set_marks(seg_count, n_seg, pool_top);
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < P) prep_one(g, mus, isg, cam_fwd, N, thr_act, 0, cull, evr, ms, ell, IsoView{nullptr, 0, 0}, pk);
 }
@@ -138,6 +153,9 @@ prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const 
 #include "trace_bin.h"
 #include "composite_core.h"
 
+#ifndef VOGE_SMALL_N
+#define VOGE_SMALL_N 4096      // Gaussians per batch element up to which binA is skipped (small_set_marks)
+#endif
 #ifndef VOGE_ISO_PREP_SPLIT
 #define VOGE_ISO_PREP_SPLIT 131072      // Gaussians per batch element from which on the scalar-sigma records get their own pass
 #endif
@@ -151,7 +169,9 @@ namespace voge {
 // binA reads the records (cfg4: entry 297 -> 287 us, renderer form 272 -> 257).  Same functions, same bits.
 __global__ void __launch_bounds__(256)
 iso_prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const float *__restrict__ cam_fwd, const int N,
-                const float thr_act, const IsoView view, float4 *__restrict__ cull, float4 *__restrict__ ms) {
+                const float thr_act, const IsoView view, float4 *__restrict__ cull, float4 *__restrict__ ms,
+                int *__restrict__ seg_count = nullptr, const long n_seg = 0, unsigned long long *__restrict__ pool_top = nullptr) {
+  small_set_marks(seg_count, n_seg, pool_top);
   const int g = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (g >= N) return;
   const BinAView V = binA_view<true>(b, cam_fwd, view);
@@ -1387,7 +1407,16 @@ static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mu
     cones = ws.cones;
   }
   const dim3 gridA(ws.nst0x * ws.nst0y * kParts, B);
-  if (iso_in && N >= VOGE_ISO_PREP_SPLIT) {
+  const bool small_set = N > 0 && N <= VOGE_SMALL_N;
+  const long n_seg = (long)B * ws.nstx * ws.nsty * kParts;
+  if (small_set && iso_in) {
+    // a few thousand Gaussians: records + "every segment overflowed" marks, no binA (small_set_marks)
+    hipLaunchKernelGGL(iso_prep_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, mus, isigmas, cam_fwd, N, thr_act, view, ws.cull, ws.ms,
+                       ws.seg_count, n_seg, ws.pool_top);
+  } else if (small_set) {
+    hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P, thr_act, ws.cull,
+                       ws.evr, ws.ms, ws.ell, reinterpret_cast<float4 *>(records), ws.seg_count, n_seg, ws.pool_top);
+  } else if (iso_in && N >= VOGE_ISO_PREP_SPLIT) {
     // scalar sigmas, slices of more than two rounds: the records in a pass of their own (iso_prep_kernel)
     hipLaunchKernelGGL(iso_prep_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, mus, isigmas, cam_fwd, N, thr_act, view, ws.cull, ws.ms);
     hipLaunchKernelGGL(binA_kernel<false>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
