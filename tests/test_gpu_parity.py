@@ -333,6 +333,44 @@ def test_trace_iso_records_in_their_own_pass(hip_lib):
     compare_trace([n(x) for x in out_plain], ref, thr_act, min_match=0.99, max_flips=8)
 
 
+@pytest.mark.parametrize("general", [False, True])
+def test_small_set_path_equals_the_binned_path(hip_lib, general):
+    """Up to 4 096 Gaussians per batch element the trace skips binA (binB reads the per-Gaussian records, trace_fwd.hip:
+    small_set_marks); one Gaussian more and the same scene goes through binA's segments.  The extra Gaussian sits far behind
+    the camera and is never hit: both paths must produce the same bits."""
+    from voge_amd import ops
+    rng = np.random.default_rng(4096)
+    B, N, H, W, K = 2, 4096, 48, 64, 16
+    verts = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+    sig = rng.uniform(150, 700, N).astype(np.float32)
+    R, T = camera_np.look_at_view_transform([3.3] * B, [10.0, -20.0], [30.0, 100.0])
+    rays, origin = camera_np.pixel_rays(R, T, 70.0, (W / 2.0, H / 2.0), (H, W))
+    rays, origin = rays.astype(np.float32), origin.astype(np.float32)
+    thr_act = oracle.thr_act_of(0.01)
+    outs = []
+    for extra in (0, 1):
+        v = np.concatenate((verts, np.full((extra, 3), 40.0, np.float32)))            # (40, 40, 40): nowhere near a ray
+        s_ = np.concatenate((sig, np.full(extra, 300.0, np.float32)))
+        mus = (v[None] - origin[:, None]).astype(np.float32)                           # [B, N + extra, 3]
+        n_all = N + extra
+        if general:
+            isg = np.broadcast_to((2.0 * s_)[None, :, None, None] * np.eye(3, dtype=np.float32), (B, n_all, 3, 3)).copy()
+            isg[:, ::3, 0, 0] *= 1.5                                                    # a third of them anisotropic
+            o = ops.ray_trace_fine(t(mus.reshape(-1, 3)), t(isg.reshape(-1, 3, 3)), t(rays), None, thr_act, 16, K)
+        else:
+            a = np.broadcast_to((2.0 * s_)[None], (B, n_all)).copy()
+            o = ops._RayTraceVoGEIso.apply(t(mus.reshape(-1, 3)), t(a.reshape(-1)), t(rays), None, thr_act, K)
+        idx = n(o[0]).copy()
+        b_of = np.arange(B)[:, None, None, None]
+        local = np.where(idx >= 0, idx - b_of * n_all, -1)                             # indices are b * N + n: compare per view
+        assert local.max() < N
+        outs.append((local, [n(x) for x in o[1:]]))
+    assert (outs[0][0] >= 0).mean() > 0.3
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for x, y in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(x, y)
+
+
 # ------------------------------------------------------------------------------- composite
 @pytest.mark.parametrize("name", ["k5", "k25", "k40"])
 def test_composite_golden(hip_lib, name):
