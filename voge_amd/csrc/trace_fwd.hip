@@ -1407,7 +1407,9 @@ static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mu
     cones = ws.cones;
   }
   const dim3 gridA(ws.nst0x * ws.nst0y * kParts, B);
-  const bool small_set = N > 0 && N <= VOGE_SMALL_N;
+  // (the scan of tools/small_set_scan.py, profiles/r5_small_set_scan.txt: at 128^2 / 256^2 skipping binA pays up to ~4 096 Gaussians,
+  //  at 512^2 -- four times the quads, each reading every record -- up to ~2 000)
+  const bool small_set = N > 0 && N <= ((long)H * W <= 131072 ? VOGE_SMALL_N : VOGE_SMALL_N / 2);
   const long n_seg = (long)B * ws.nstx * ws.nsty * kParts;
   if (small_set && iso_in) {
     // a few thousand Gaussians: records + "every segment overflowed" marks, no binA (small_set_marks)
