@@ -7,6 +7,7 @@
 // coalesced runs, the per-pixel sums are segmented wave reductions, and merge + silhouette +
 // blend happen in one pass (shade_fwd) / one backward pass (shade_bwd).
 #include "voge_common.h"
+#include <algorithm>
 
 namespace voge {
 
@@ -426,6 +427,97 @@ merge_bwd_chan_kernel(const float *__restrict__ attr, const int32_t *__restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// merge alone (interpolate_attr) for what the 4-slot kernel above does not take -- more than four channels (one-hot label
+// maps, feature maps up to 64 channels), K not a multiple of four or above 64: ONE LANE PER (pixel, channel).  A wave stages
+// the contiguous (idx, weight) slots of its `ppw` pixels in LDS with coalesced loads (validity folded into the staged
+// weight: slot >= valid_num, index out of range or weight 0 -> weight 0, index 0), then every lane walks its pixel's K
+// slots: an LDS broadcast per slot, one gather of its own channel (the C lanes of a pixel read C adjacent floats), one FMA --
+// no cross-lane sum at all.  shade_fwd_kernel spends ~15 shuffles per 64 slots and channel on segmented sums and re-reads
+// the slots once per four channels: 256^2, K = 102, C = 6 (demo/EfficientCuboidViaOptimization.py): 99.5 us -> this kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int kMpcSlots = 1024;      // staged slots per wave
+__global__ void __launch_bounds__(256)
+merge_fwd_pc_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx, const float *__restrict__ weight,
+                    const int64_t *__restrict__ valid_num, const long npix, const int K, const int C, const long Nattr,
+                    const int fix_idx, const int ppw, float *__restrict__ out) {
+  __shared__ int Li[4][kMpcSlots];
+  __shared__ float Lw[4][kMpcSlots];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long pix0 = ((long)blockIdx.x * 4 + wave) * ppw;
+  if (pix0 >= npix) return;      // waves are independent
+  const int npx = (int)min((long)ppw, npix - pix0);
+  const int n_items = npx * K;
+  const long base = pix0 * K;
+  const float rK = 1.0f / (float)K;
+  for (int i = lane; i < n_items; i += 64) {
+    int lx = __float2int_rz(((float)i + 0.5f) * rK);      // i / K, corrected below (exact for any size)
+    int k = i - lx * K;
+    if (k < 0) { --lx; k += K; } else if (k >= K) { ++lx; k -= K; }
+    const int raw = idx[base + i];
+    const float w = weight[base + i];
+    const int p = raw + (raw < 0);
+    if (fix_idx && raw < 0) idx[base + i] = raw + 1;      // Aggregation.py:131
+    const bool ok = (k < valid_num[pix0 + lx]) && p >= 0 && p < Nattr && w != 0.0f;
+    Li[wave][i] = ok ? p : 0;
+    Lw[wave][i] = ok ? w : 0.0f;
+  }
+  __builtin_amdgcn_wave_barrier();      // (a wave's LDS operations complete in order: its own writes are there)
+  const int x = lane / C, c = lane - x * C;
+  if (x >= npx) return;
+  const int *li = Li[wave] + x * K;
+  const float *lw = Lw[wave] + x * K;
+  float acc = 0.0f;
+  int k = 0;
+  for (; k + 4 <= K; k += 4) {      // four gathers in flight
+    const float a0 = attr[(size_t)li[k] * C + c], a1 = attr[(size_t)li[k + 1] * C + c];
+    const float a2 = attr[(size_t)li[k + 2] * C + c], a3 = attr[(size_t)li[k + 3] * C + c];
+    acc = fmaf(a0, lw[k], acc); acc = fmaf(a1, lw[k + 1], acc); acc = fmaf(a2, lw[k + 2], acc); acc = fmaf(a3, lw[k + 3], acc);
+  }
+  for (; k < K; ++k) acc = fmaf(attr[(size_t)li[k] * C + c], lw[k], acc);
+  out[(pix0 + x) * C + c] = acc;
+}
+
+// merge backward for 4 < C <= 64: ONE LANE PER SLOT.  The run's g_up rows sit in LDS; a lane reads its slot's attribute row
+// and forms g_weight = <g_up[pixel], attr[p]> by itself -- no cross-lane sum, coalesced idx / weight / g_weight streams --
+// and, when the attributes want a gradient, adds w g_up[pixel][c] to their row (float atomics).  merge_bwd_chan_kernel (one
+// slot per wave iteration, lanes over channels) is built for hundreds of channels: at C = 6 it runs 6 of 64 lanes (256^2,
+// K = 102: 190 us).
+constexpr int kMbsRun = 8;      // pixels per wave run
+__global__ void __launch_bounds__(256)
+merge_bwd_slot_kernel(const float *__restrict__ attr, const int32_t *__restrict__ idx, const float *__restrict__ weight,
+                      const int64_t *__restrict__ valid_num, const float *__restrict__ g_up, const long npix, const int K,
+                      const int C, const long Nattr, float *__restrict__ g_attr, float *__restrict__ g_weight) {
+  __shared__ float Lg[4][kMbsRun * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long pix0 = ((long)blockIdx.x * 4 + wave) * kMbsRun;
+  if (pix0 >= npix) return;      // waves are independent
+  const int npx = (int)min((long)kMbsRun, npix - pix0);
+  for (int i = lane; i < npx * C; i += 64) Lg[wave][i] = g_up[pix0 * C + i];
+  __builtin_amdgcn_wave_barrier();
+  const int n_items = npx * K;
+  const long base = pix0 * K;
+  const float rK = 1.0f / (float)K;
+  for (int j = lane; j < n_items; j += 64) {
+    int lx = __float2int_rz(((float)j + 0.5f) * rK);
+    int k = j - lx * K;
+    if (k < 0) { --lx; k += K; } else if (k >= K) { ++lx; k -= K; }
+    const int raw = idx[base + j];
+    const float w = weight[base + j];
+    const int p = raw + (raw < 0);
+    float gw = 0.0f;
+    if (k < valid_num[pix0 + lx] && p >= 0 && p < Nattr) {
+      const float *g = Lg[wave] + lx * C;
+      for (int c = 0; c < C; ++c) {
+        const float gc = g[c];
+        if (attr != nullptr) gw = fmaf(gc, attr[(size_t)p * C + c], gw);
+        if (g_attr != nullptr && w != 0.0f && gc != 0.0f) unsafeAtomicAdd(g_attr + (size_t)p * C + c, w * gc);
+      }
+    }
+    if (g_weight != nullptr) g_weight[base + j] = gw;
+  }
+}
+
 // blend backward alone (C > 4, or a caller that merged separately): g_rgb [npix,C] and the
 // additive silhouette term g_weight_add [npix,K].
 __global__ void __launch_bounds__(256)
@@ -515,6 +607,13 @@ extern "C" int voge_shade_fwd(const float *attr, int32_t *idx, const float *weig
                        out_rgb, out_img, out_sil, out_wsum);
     return launch_status();
   }
+  if (C >= 1 && C <= 64 && K <= kMpcSlots && Nattr > 0 && attr && out_rgb && !out_img && !out_sil && !out_wsum) {      // merge alone
+    const int ppw = std::max(1, std::min(64 / C, kMpcSlots / K));
+    const long per_wg = 4L * ppw;
+    hipLaunchKernelGGL(merge_fwd_pc_kernel, dim3((unsigned)((npix + per_wg - 1) / per_wg)), dim3(256), 0, (hipStream_t)stream, attr, idx,
+                       weight, valid_num, npix, K, C, Nattr, fix_negative_idx, ppw, out_rgb);
+    return launch_status();
+  }
   hipLaunchKernelGGL(shade_fwd_kernel, dim3(run_grid(npix)), dim3(256), 0, (hipStream_t)stream, attr, idx, weight,
                      valid_num, nullptr, bg, thr, npix, K, C, Nattr, fix_negative_idx, out_rgb, out_img, out_sil, out_wsum);
   return launch_status();
@@ -561,6 +660,12 @@ extern "C" int voge_merge_bwd(const float *attr, const int32_t *idx, const float
   const long npix = nrows * W;
   if (npix == 0) return 0;
   if (!idx || !weight || !valid_num || !g_out || (Nattr > 0 && !attr && g_weight)) return VOGE_ERR_BAD_ARG;
+  if (C <= 64) {
+    const long per_wg = 4L * kMbsRun;
+    hipLaunchKernelGGL(merge_bwd_slot_kernel, dim3((unsigned)((npix + per_wg - 1) / per_wg)), dim3(256), 0, st, attr, idx, weight,
+                       valid_num, g_out, npix, K, C, Nattr, g_attr, g_weight);
+    return launch_status();
+  }
   long blocks = (npix + 3) / 4;
   if (blocks > 256L * 16) blocks = 256L * 16;
   hipLaunchKernelGGL(merge_bwd_chan_kernel, dim3((unsigned)blocks), dim3(256), 0, st, attr, idx, weight, valid_num,
