@@ -349,10 +349,14 @@ def main():
                 for _ in range(3):                                     # back-to-back replays, no host synchronisation between them
                     graph.replay()
                 torch.cuda.synchronize()
+                worst = 0.0
                 for p, w in zip(params, want):
                     err = float((p.grad - w).abs().max()) / max(float(w.abs().max()), 1e-30)
-                    assert err < 1e-3, f"HIP graph replay does not reproduce the eager step's gradients (rel. error {err:.2e})"
-                graph_checked.append(True)
+                    worst = max(worst, err)
+                    # (the only difference between two runs of the same step is the order of the backward's float atomics:
+                    #  measured 1e-7 .. 2e-6 of the largest entry; north_star's tolerance is the bound)
+                    assert err < 1e-4, f"HIP graph replay does not reproduce the eager step's gradients (rel. error {err:.2e})"
+                graph_checked.append(worst)
                 return graph.replay, "hip graph replay"
             except Exception as e:  # pragma: no cover - depends on the runtime
                 print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -543,6 +547,7 @@ def main():
         "config": {"workload": f"{args.config}: {N} random Gaussians ({sig_kind}), {H}x{W}, K={K}, max_point_per_bin={bins_kind}, "
                                f"fwd+bwd (grads to verts, sigmas, colors)",
                    "launch": launch, "graph_replay_gradients_checked_against_eager": bool(graph_checked),
+                   "graph_replay_gradient_rel_err": (max(graph_checked) if graph_checked else None),
                    "parallelism": ("1 gpu" if not multi else
                                    f"a batch of {world} views on the stacked (view, row) axis, view first: one whole view per rank; "
                                    f"all_gather(images) + all_reduce(gradients); a step = {world} frames" if by_views else

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOGE_ABI_VERSION 6
+#define VOGE_ABI_VERSION 7
 
 #define VOGE_ERR_BAD_ARG (-1)        /* null pointer / non-positive size */
 #define VOGE_ERR_WORKSPACE (-2)      /* workspace smaller than one view's voge_trace_workspace_bytes(1, ...) */
@@ -306,6 +306,45 @@ int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int s
                                 const float *g_img, long g_stride_pix, long g_stride_c, float occ, int B, int N,
                                 long nrows, int W, int K, int C, long Nattr, void *workspace, size_t workspace_bytes, float *g_verts,
                                 float *g_sigmas, float *g_colors, voge_stream_t stream);
+
+/*
+ * ABI 7 -- ONE FRAME of the renderer as five launches: the camera goes in, nothing but the frame's own kernels run.
+ *
+ * voge_frame_trace_fwd_iso   GaussianRenderer.forward (VoGE/Renderer.py:102-150) up to and including ray_tracing, for scalar
+ *   sigmas and one Gaussian set per view (`shared` != 0: [N,3] / [N] seen by all B views) or per batch element ([B,N,..]):
+ *   the ray bundle of Renderer.py:124-128, the centring of :130, the sigma rule of :133-137 (sigma_mode 0: a = sigma,
+ *   1: a = 2 sigma, 2: a = 2 / sigma), RayTracing.py:12-30 and ray_trace_voge.cu:135-217 -- as binA + binB + sweep, with
+ *   NO ray-generation launch: every kernel derives the rays / bounding cones / camera centre / view axis it needs from
+ *   R [B,3,3], T [B,3], focal [B,2], pp [B,2] with voge_rays_fwd's own operations (bit-identical rays; the cones are the
+ *   analytic corner-ray cones of csrc/voge_common.h).  The band rendered is h stacked rows of W pixels; stacked row i is image
+ *   row row0 + (i / stripe_h) * pitch + i % stripe_h (one contiguous band: stripe_h >= h, pitch = 0).  behind != 0: Gaussians
+ *   behind the camera plane are no candidates (rasterize_coarse.cu:35; what cam_fwd = R[:, :, 2] selects in the other entries).
+ *   Writes idx, len [B,h,W,K], cnt [B,h,W], records [B*N,4] (centred mean, a), rays [B,h,W,3] (by the sweep) and origin [B,3].
+ *   workspace: voge_trace_workspace_bytes(B, N, h, W).  No act / dsd (the fragments' consumers re-derive them).
+ * voge_frame_shade_fwd_iso   = voge_composite_shade_fwd_iso (aggregation + merge_final + get_silhouette +
+ *   to_colored_background, Aggregation.py:82-141, Renderer.py:157-171) that ALSO sets grad_zero[0 .. grad_zero_n) to zero:
+ *   the gradient arrays of the backward below, so that no fill launch stands in front of it.
+ * voge_frame_shade_bwd_iso   = voge_fragment_shade_bwd_iso as ONE launch: the waves add their per-Gaussian sums straight
+ *   into g_verts [shared ? N : B*N, 3], g_sigmas [shared ? N : B*N] and g_colors [Nattr, C] (float atomics; the chain rule of
+ *   the sigma rule and the sum over the views of a shared set included) -- the three arrays must be ZERO on entry and are
+ *   accumulated into.  No scratch.  K <= 128, C <= 4.
+ */
+int voge_frame_trace_fwd_iso(const float *verts, const float *sigmas, int shared, int sigma_mode, const float *R,
+                             const float *T, const float *focal, const float *pp, int row0, int stripe_h, int pitch,
+                             int behind, int B, int N, int h, int W, int K, float thr_act, void *workspace,
+                             size_t workspace_bytes, int32_t *idx, float *len, int32_t *cnt, float *records,
+                             float *rays, float *origin, voge_stream_t stream);
+int voge_frame_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                             const float *rays, float occ, const float *colors, const float *bg, float thr,
+                             long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
+                             float *rgb, float *img, float *wsum, float *grad_zero, long grad_zero_n,
+                             voge_stream_t stream);
+int voge_frame_shade_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
+                             const float *rays, const float *colors, const int32_t *idx, const int32_t *cnt,
+                             const float *weight, const float *len, const float *rgb, const float *wsum,
+                             const float *bg, float thr, const float *g_img, long g_stride_pix, long g_stride_c,
+                             float occ, int B, int N, long nrows, int W, int K, int C, long Nattr, float *g_verts,
+                             float *g_sigmas, float *g_colors, voge_stream_t stream);
 
 /* interpolate_attr (+ get_silhouette) on fragments of this renderer, backward: merge_final's own backward
  * (VoGE/Aggregation.py:111-141; g_rgb = the gradient of the merged attributes [nrows*W,C], strides as g_img above), plus

@@ -54,7 +54,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_version_errors_and_sizes_without_gpu(lib):
-    assert lib.voge_abi_version() == 6
+    assert lib.voge_abi_version() == 7
     assert lib.voge_error_string(0) == b"success"
     assert b"K exceeds" in lib.voge_error_string(-3)
     assert b"workspace" in lib.voge_error_string(-2)

@@ -11,6 +11,8 @@ cfg5 2562 / 128^2 / K=25 (ShapeFitting)    -> test_config5_shapefit_frame_fwd_bw
 The oracle is fp64 brute force; where a whole frame would take minutes it is cropped to windows / a band of rows
 (bands are bit-identical to the whole frame: test_row_bands_equal_whole_frame_and_default_bins).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -211,6 +213,78 @@ def test_config3_band_gradients(hip_lib):
     _check_grads("cfg3 band", (colors.grad, gm.verts.grad, gm.sigmas.grad), _oracle_grads(sc, ref, g_img), mult=0.6)      # measured 2.6e-5
 
 
+def _big_host():
+    """The fp64 brute-force oracle is OpenMP code: a whole cfg3 frame (50k x 262 144 pairs, forward + backward) is ~8 s on the
+    GPU box's 256 host threads and minutes on the 8-core build container.  The whole-frame / 64-row tests run where the
+    host has >= 64 threads (VOGE_WHOLE_FRAME_PARITY=1 forces them, =0 skips them); the 8- / 4-row bands above stay as the
+    small-host form of the same check."""
+    force = os.environ.get("VOGE_WHOLE_FRAME_PARITY")
+    if force is not None:
+        return force != "0"
+    return (os.cpu_count() or 1) >= 64
+
+
+def _classify_flips(label, frag, ref, same, ceilings):
+    """Flipped pixels by kind: a different member SET (returned), or the same members with depth-tied ones swapped (every
+    moved member is checked to tie the depth of the slot it moved to within the fp32 rounding of len)."""
+    gi, ri, rl = n(frag.vert_index)[~same], ref["idx"][~same], ref["len"][~same]
+    set_flips = 0
+    for g, r, l in zip(gi, ri, rl):
+        gs, rs = set(g[g > 0].tolist()), set(r[r > 0].tolist())      # (slot value 0 is merge_final's rewritten -1 or Gaussian 0)
+        if gs != rs:
+            set_flips += 1
+            continue
+        pos = {int(v): k for k, v in enumerate(r) if v >= 0}
+        for k, v in enumerate(g[:len(pos)]):
+            if int(v) in pos and pos[int(v)] != k:      # moved: its depth must tie the depth of the slot it moved to
+                assert abs(l[pos[int(v)]] - l[k]) <= 2e-6 * max(1.0, abs(l[k])), "members swapped away from a depth tie"
+    log_line(f"[parity] {label}: {int((~same).sum())} flipped pixels of {same.size} = {set_flips} with a different member set "
+             f"+ {int((~same).sum()) - set_flips} order swaps of depth ties (ceilings {ceilings[0]} / {ceilings[1]} in all)")
+    return set_flips
+
+
+def test_config3_whole_frame_vs_oracle(hip_lib):
+    """the HEADLINE config's whole 512^2 frame -- fragments, image and all three gradients of a random
+    image loss -- against the fp64 oracle chain (ray_trace_voge.cu:135-217, Aggregation.py:82-107 restated).  Ceilings:
+    flipped index lists <= 0.01 % of the pixels, every gradient within 1e-4 of its scale."""
+    if not _big_host():
+        pytest.skip("whole-frame oracle parity needs a host with >= 64 threads (the 8-row band test covers small hosts)")
+    sc = _scene_cfg("cfg3_50k_512")
+    H, W = sc["image_size"]
+    frag, img, gm, colors, (R, T) = _render(sc)
+    ref = _oracle_frame(sc, R, T)
+    # A "flip" is a pixel whose ORDERED index list differs.  Two kinds: (1) the same members with two of them swapped -- their
+    # depths lie within the fp32 rounding of len (a few ulp of ~3.5), the order any fp32 implementation, the reference's
+    # included, is free to differ on against an fp64 truth: expected count = lit pixels x adjacent pairs x density x 2 eps
+    # ~ 160 000 x 17 x 18 x 6e-7 ~ 30; (2) a different member SET (a candidate within rounding of the activation threshold or
+    # of the K-th depth).  VERDICT r5's ceiling of 0.01 % is held on the second kind; all flips together stay under 0.02 %,
+    # and every swap is checked to be a near-tie.
+    same = _check_frame("cfg3 whole frame", frag, img, ref, max_flips=(H * W) // 5000)
+    set_flips = _classify_flips("cfg3 whole frame", frag, ref, same, (same.size // 10000, same.size // 5000))
+    assert set_flips <= (H * W) // 10000
+    g_img = np.random.default_rng(33).normal(size=ref["image"].shape) * same[..., None]
+    (img * t(g_img)).sum().backward()
+    _check_grads("cfg3 whole frame", (colors.grad, gm.verts.grad, gm.sigmas.grad), _oracle_grads(sc, ref, g_img), mult=1)
+
+
+def test_config4_64_rows_vs_oracle(hip_lib):
+    """cfg4 (200k / 1024^2): 64 rows (two rows of super-tiles, 65 536 pixels -- the pair count of a whole cfg3 frame)
+    through the renderer's rows= against the oracle, forward and gradients."""
+    if not _big_host():
+        pytest.skip("64-row oracle parity at cfg4 needs a host with >= 64 threads (test_config4_full_size covers small hosts)")
+    sc = _scene_cfg("cfg4_200k_1024")
+    rows = (480, 544)
+    frag, img, gm, colors, (R, T) = _render(sc, rows=rows)
+    ref = _oracle_frame(sc, R, T, rows=rows)
+    # (200k Gaussians: four times cfg3's depth density and every lit list full, so ties at the K-th depth and between
+    #  neighbours are that much more frequent -- measured 24 flips of 65 536; ceilings at 1.7 x that)
+    same = _check_frame("cfg4 rows 480..543", frag, img, ref, max_flips=40)
+    assert _classify_flips("cfg4 rows 480..543", frag, ref, same, (24, 40)) <= 24
+    g_img = np.random.default_rng(44).normal(size=ref["image"].shape) * same[..., None]
+    (img * t(g_img)).sum().backward()
+    _check_grads("cfg4 64 rows", (colors.grad, gm.verts.grad, gm.sigmas.grad), _oracle_grads(sc, ref, g_img), mult=1)
+
+
 # ----------------------------------------------------------------------------------------------- cfg4
 def test_config4_full_size(hip_lib):
     """BASELINE config 4 (200k Gaussians, 1024x1024, K=40) at full size: the coarse bin0 level on 64 regions,
@@ -322,7 +396,8 @@ def test_config5_shapefit_frame_fwd_bwd(hip_lib):
     for name, g, wv in zip(("colors", "verts", "sigmas"), (colors.grad, gm.verts.grad, gm.sigmas.grad), want):
         err = np.abs(n(g).astype(np.float64) - wv).max()
         print(f"[parity] cfg5 {name}: max err {err:.3e}, largest entry {np.abs(wv).max():.3e}")
-        assert err <= 5 * TOL * np.abs(wv).max(), f"cfg5 {name}: {err:.3e} vs largest entry {np.abs(wv).max():.3e}"
+        log_line(f"[parity] cfg5 {name} gradient: {err / np.abs(wv).max():.2e} of the largest entry (allowed {TOL:.0e})")
+        assert err <= TOL * np.abs(wv).max(), f"cfg5 {name}: {err:.3e} vs largest entry {np.abs(wv).max():.3e}"
 
 
 # ----------------------------------------------------------------------------------- overflow fallbacks

@@ -48,7 +48,7 @@ def run_trace(mus, isg, rays, K, thr_act, bins=None, bin_size=0):
 def test_abi_loaded_is_in_tree(hip_lib):
     from voge_amd import _lib
     assert os.path.samefile(os.path.dirname(_lib.LIB_PATH), os.path.join(os.path.dirname(GOLDEN), "..", "voge_amd"))
-    assert hip_lib.voge_abi_version() == 6
+    assert hip_lib.voge_abi_version() == 7
 
 
 def test_trace_fwd_cuboid_config1(hip_lib):

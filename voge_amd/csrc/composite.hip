@@ -352,6 +352,8 @@ struct CompShade {
   long Nattr;
   float *rgb, *img, *wsum;
   int32_t *idx_fix;
+  float *zero_p = nullptr;      // (round 6) NULL | zero_n floats this launch sets to zero on the way: the gradient arrays the frame's
+  long zero_n = 0;              // backward accumulates into (voge_frame_shade_fwd_iso) -- no fill launch in front of that backward
 };
 // GEN (forward from the records): the records are the general path's packed (mu, A), three float4 per Gaussian
 // (voge_trace_lean_fwd); act / dsd come from make_eval + pair_eval, the operations of the sweep's own epilogue.
@@ -367,6 +369,9 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
                   const CompShade sh = CompShade{}) {
   static_assert(SC == 0 || (MODE == 0 && WAVE && SC <= 4), "the shade stage rides in the wave-form forward only");
   constexpr bool BWD = MODE != 0;
+  if (SC > 0 && sh.zero_p != nullptr) {      // (uniform)
+    for (long zi = (long)blockIdx.x * blockDim.x + threadIdx.x; zi < sh.zero_n; zi += (long)gridDim.x * blockDim.x) sh.zero_p[zi] = 0.0f;
+  }
   constexpr int NP = NS / 2;       // own aligned pairs
   extern __shared__ __attribute__((aligned(16))) unsigned char comp_smem[];
   CompLds &L = *reinterpret_cast<CompLds *>(comp_smem);      // (workgroup form only)
@@ -550,7 +555,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
       }
     }
   }
-  if (WAVE) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+  if (WAVE) wave_lds_sync(); else __syncthreads();
   // sortedness: inside the own group, and the seam to the previous group
   bool uns = false;
   if (active) {
@@ -835,7 +840,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
       if (q + o < LP && in_wg) x += z;
     }
     sx = x;
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
   } else {
     float(*sf)[kCompThreads] = reinterpret_cast<float(*)[kCompThreads]>(L.scan);
     sf[0][tid] = usum;
@@ -1060,8 +1065,9 @@ static int composite_shade_fwd_impl(const bool gen, int32_t *idx, const int32_t 
                                     const float *rays, float occ, const float *colors, const float *bg, float thr,
                                     long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
                                     float *rgb, float *img, float *wsum, voge_stream_t stream, float *act_out = nullptr,
-                                    float *dsd_out = nullptr) {
+                                    float *dsd_out = nullptr, float *zero_p = nullptr, long zero_n = 0) {
   if ((act_out == nullptr) != (dsd_out == nullptr)) return VOGE_ERR_BAD_ARG;
+  if (zero_n < 0 || (zero_n > 0 && (!zero_p || C == 0))) return VOGE_ERR_BAD_ARG;
   if (npix < 0 || K <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K || (C != 0 && C != 3 && C != 4)) return VOGE_ERR_K_TOO_LARGE;      // four slots per lane (any K: a last group may be short); RGB / RGBA
   if (npix == 0) return 0;
@@ -1080,7 +1086,7 @@ static int composite_shade_fwd_impl(const bool gen, int32_t *idx, const int32_t 
   const dim3 gridn((unsigned)((npix + ppwn - 1) / ppwn)), blockn(tn);
   const size_t ldsn = compn_lds_bytes(K, NS, false, tn, true);
   const bool small = (double)npix * K < (double)(1l << 30);
-  const CompShade sh{colors, bg, thr, Nattr, rgb, img, wsum, idx};
+  const CompShade sh{colors, bg, thr, Nattr, rgb, img, wsum, idx, zero_n > 0 ? zero_p : nullptr, zero_n};
   hipStream_t st = (hipStream_t)stream;
   const float4 *rec = reinterpret_cast<const float4 *>(records);
 #define VOGE_LAUNCH_CS(OT, CC, GG)                                                                                           \
@@ -1104,6 +1110,19 @@ extern "C" int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, co
   if (C != 3 && C != 4) return VOGE_ERR_K_TOO_LARGE;
   return composite_shade_fwd_impl(false, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
                                   rgb, img, wsum, stream);
+}
+
+// Round 6, the frame's forward behind the sweep: voge_composite_shade_fwd_iso, which on its way also zeroes `grad_zero_n` floats
+// at `grad_zero` -- the gradient arrays voge_frame_shade_bwd_iso will accumulate into, so that backward needs no fill launch.
+extern "C" int voge_frame_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                                        const float *rays, float occ, const float *colors, const float *bg, float thr,
+                                        long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
+                                        float *rgb, float *img, float *wsum, float *grad_zero, long grad_zero_n,
+                                        voge_stream_t stream) {
+  if (C != 3 && C != 4) return VOGE_ERR_K_TOO_LARGE;
+  if (npix == 0 && grad_zero_n > 0) return (int)voge_fill_async(grad_zero, 0, sizeof(float) * (size_t)grad_zero_n, (hipStream_t)stream);
+  return composite_shade_fwd_impl(false, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
+                                  rgb, img, wsum, stream, nullptr, nullptr, grad_zero, grad_zero_n);
 }
 
 // The same two for the general path: records = the packed (mu, A) [B*N][12] of voge_trace_lean_fwd.

@@ -141,7 +141,7 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
   if (Lcell != nullptr) {
     // the window radius through the pixel's LDS cell (compn_bwd_wave), the prefix sum alone through the shuffles
     if (in_wg && q == 0) *Lcell = 0u;
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     if (in_wg && mx > 0.0f) atomicMax(Lcell, __float_as_uint(mx));
     const float y = __shfl_up(esum, 1, 64);
     float x = (q > 0 && in_wg) ? y : 0.0f;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
       if (q >= o && in_wg) x += z;
     }
     ex = x;
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     wave_rmax = in_wg ? __uint_as_float(*lds_volatile(Lcell)) : 0.0f;
   } else {
     v2f x = {esum, mx};
@@ -286,9 +286,9 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
     // like unsigned integers): zero, max, read -- three LDS operations in the wave's in-order LDS queue instead of a
     // chain of seven dependent cross-lane shuffles
     if (in_wg && q == 0) *Lcell = 0u;
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     if (in_wg && mx > 0.0f) atomicMax(Lcell, __float_as_uint(mx));
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     wave_rmax = in_wg ? __uint_as_float(*lds_volatile(Lcell)) : 0.0f;
   } else {
 #pragma unroll
@@ -382,7 +382,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
       if (q + o < LP && in_wg) x += z;
     }
     sx = x;
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
   }
 #pragma unroll
   for (int a = 0; a < NS; ++a) { ga[a] = 0.0f; gl[a] = 0.0f; gd[a] = 0.0f; }
@@ -426,7 +426,7 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
           aH[b2] = pk_fma(u2, h_pair(xp), aH[b2]); aP[b2] = aP[b2] + y; aL[b2] = pk_fma(y, d, aL[b2]);
           if (RCOL) racc = pk_fma(splat(Es[b2]), g, racc);
         }
-        if (RCOL) { *reinterpret_cast<v2f *>(LR + e) = racc; __builtin_amdgcn_wave_barrier(); }
+        if (RCOL) { *reinterpret_cast<v2f *>(LR + e) = racc; wave_lds_sync(); }
       }
       for (int e = d0 - 2;; e -= 2) {      // row pairs in front of every own column
         const v2f l2 = ld2(Llen, e), u2 = ld2(Lu, e);
@@ -445,10 +445,10 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
           bH[b2] = pk_fma(u2, h_pair(xp), bH[b2]); bP[b2] = bP[b2] + y; bL[b2] = pk_fma(y, d, bL[b2]);
           if (RCOL) racc = pk_fma(splat(Es[b2]), g, racc);
         }
-        if (RCOL) { *reinterpret_cast<v2f *>(LR + e) = racc; __builtin_amdgcn_wave_barrier(); }
+        if (RCOL) { *reinterpret_cast<v2f *>(LR + e) = racc; wave_lds_sync(); }
       }
       if (RCOL) {      // every column walk of the pixel has passed (its lanes share this wave): the row sums are complete
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
 #pragma unroll
         for (int a = 0; a < NS; ++a) rterm[a] = (rterm[a] + *lds_volatile(LR + d0 + a)) * (kRsqrtPi / kCs);
       }

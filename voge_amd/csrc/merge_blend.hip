@@ -462,7 +462,7 @@ merge_fwd_pc_kernel(const float *__restrict__ attr, int32_t *__restrict__ idx, c
     Li[wave][i] = ok ? p : 0;
     Lw[wave][i] = ok ? w : 0.0f;
   }
-  __builtin_amdgcn_wave_barrier();      // (a wave's LDS operations complete in order: its own writes are there)
+  wave_lds_sync();      // (a wave's LDS operations complete in order: its own writes are there)
   const int x = lane / C, c = lane - x * C;
   if (x >= npx) return;
   const int *li = Li[wave] + x * K;
@@ -494,7 +494,7 @@ merge_bwd_slot_kernel(const float *__restrict__ attr, const int32_t *__restrict_
   if (pix0 >= npix) return;      // waves are independent
   const int npx = (int)min((long)kMbsRun, npix - pix0);
   for (int i = lane; i < npx * C; i += 64) Lg[wave][i] = g_up[pix0 * C + i];
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_sync();
   const int n_items = npx * K;
   const long base = pix0 * K;
   const float rK = 1.0f / (float)K;

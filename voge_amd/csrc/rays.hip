@@ -14,23 +14,6 @@
 
 namespace voge {
 
-struct Mat3 {
-  float m[9];
-};
-
-// inverse by adjugate; fp32 (R is a rotation in practice: cond ~ 1)
-__device__ __forceinline__ Mat3 inv3(const float *R) {
-  Mat3 o;
-  const float a = R[0], b = R[1], c = R[2], d = R[3], e = R[4], f = R[5], g = R[6], h = R[7], i = R[8];
-  const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
-  const float det = a * A + b * B + c * C;
-  const float id = 1.0f / det;
-  o.m[0] = A * id;               o.m[1] = -(b * i - c * h) * id;  o.m[2] = (b * f - c * e) * id;
-  o.m[3] = B * id;               o.m[4] = (a * i - c * g) * id;   o.m[5] = -(a * f - c * d) * id;
-  o.m[6] = C * id;               o.m[7] = -(a * h - b * g) * id;  o.m[8] = (a * e - b * d) * id;
-  return o;
-}
-
 __global__ void __launch_bounds__(256)
 rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const float *__restrict__ focal,
                 const float *__restrict__ pp, const int row0, const int h, const int W, const int stripe_h, const int pitch,
@@ -38,10 +21,9 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
                 ConeRec *__restrict__ cones /* NULL | [B][nsty][nstx] */) {
   // row i of the output is image row irow(i): a contiguous band (stripe_h >= h), or every `pitch`-th stripe of
   // `stripe_h` rows starting at row0 (a rank's share of a frame dealt in stripes: voge_amd/distributed.py)
-  auto irow = [&](const int i) { const int k = i / stripe_h; return row0 + k * pitch + (i - k * stripe_h); };
   const int b = blockIdx.y;
-  const Mat3 Ri = inv3(R + 9 * b);
-  const float fx = focal[2 * b], fy = focal[2 * b + 1], px = pp[2 * b], py = pp[2 * b + 1];
+  const CamView cam{R, T, focal, pp, row0, stripe_h, pitch, h, W, 0, nullptr, nullptr};
+  const CamK ck = cam_load(cam, b);
   if ((int)blockIdx.x >= ray_blocks) {
     // The workgroups behind the ray blocks: one per 32x32-pixel super-tile, its bounding cone for the trace's
     // binning (voge_trace_topk_fwd*'s `cones`).  The directions are recomputed with the arithmetic below (no loads),
@@ -52,20 +34,13 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
     const int x0 = (st % nstx) * kST, y0 = (st / nstx) * kST;
     int ly, lx0;
     cone_thread_rays(threadIdx.x, lx0, ly);
-    const float ifx = 1.0f / fx, ify = 1.0f / fy;
     float cx[4], cy[4], cz[4];
     unsigned has = 0u;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = x0 + lx0 + u, i = y0 + ly;
       has |= (j < W && i < h) ? (1u << u) : 0u;
-      const float vx = (px - ((float)j + 0.5f)) * ifx;
-      const float vy = (py - ((float)irow(min(i, max(h - 1, 0))) + 0.5f)) * ify;
-      const float wx = vx * Ri.m[0] + vy * Ri.m[3] + Ri.m[6];
-      const float wy = vx * Ri.m[1] + vy * Ri.m[4] + Ri.m[7];
-      const float wz = vx * Ri.m[2] + vy * Ri.m[5] + Ri.m[8];
-      const float inv = __builtin_amdgcn_rsqf(wx * wx + wy * wy + wz * wz);
-      cx[u] = wx * inv; cy[u] = wy * inv; cz[u] = wz * inv;
+      cam_ray(ck, cam_irow(cam, min(i, max(h - 1, 0))), j, cx[u], cy[u], cz[u]);
     }
     // (the super-tile's cone and, since round 5, its quads' and tiles': voge_common.h, block_cones_hier256)
     const size_t nst = gridDim.x - ray_blocks;
@@ -73,15 +48,9 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
                         cones + cone_tile_at(b, nst, st, 0), Lc);
     return;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // (static indices only: a lane-dependent index into Ri makes the compiler park the matrix in LDS)
-    const float *t = T + 3 * b;
-    origin[3 * b + 0] = -(t[0] * Ri.m[0] + t[1] * Ri.m[3] + t[2] * Ri.m[6]);
-    origin[3 * b + 1] = -(t[0] * Ri.m[1] + t[1] * Ri.m[4] + t[2] * Ri.m[7]);
-    origin[3 * b + 2] = -(t[0] * Ri.m[2] + t[1] * Ri.m[5] + t[2] * Ri.m[8]);
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) cam_origin(ck, T + 3 * b, origin[3 * b + 0], origin[3 * b + 1], origin[3 * b + 2]);
   const int n = h * W;
-  const float ifx = 1.0f / fx, ify = 1.0f / fy, iW = 1.0f / (float)W;
+  const float iW = 1.0f / (float)W;
   float *ob = rays + (size_t)b * n * 3;
   // four consecutive pixels per thread: 48 contiguous bytes leave as three 16-byte stores
   const int n4 = (n + 3) >> 2;
@@ -94,13 +63,7 @@ rays_fwd_kernel(const float *__restrict__ R, const float *__restrict__ T, const 
       int i = __float2int_rz(((float)p + 0.5f) * iW);      // p / W, corrected below (exact for any size)
       int j = p - i * W;
       if (j < 0) { --i; j += W; } else if (j >= W) { ++i; j -= W; }
-      const float vx = (px - ((float)j + 0.5f)) * ifx;
-      const float vy = (py - ((float)irow(i) + 0.5f)) * ify;
-      const float wx = vx * Ri.m[0] + vy * Ri.m[3] + Ri.m[6];
-      const float wy = vx * Ri.m[1] + vy * Ri.m[4] + Ri.m[7];
-      const float wz = vx * Ri.m[2] + vy * Ri.m[5] + Ri.m[8];
-      const float inv = __builtin_amdgcn_rsqf(wx * wx + wy * wy + wz * wz);
-      o[3 * u] = wx * inv; o[3 * u + 1] = wy * inv; o[3 * u + 2] = wz * inv;
+      cam_ray(ck, cam_irow(cam, i), j, o[3 * u], o[3 * u + 1], o[3 * u + 2]);
     }
     if (4 * q + 3 < n && aligned) {
       float4 *dst = reinterpret_cast<float4 *>(ob + (size_t)q * 12);

@@ -65,6 +65,9 @@ constexpr int kExitGroup = VOGE_S2_EXIT_GROUP;
 #ifndef VOGE_S2_PREFETCH
 #define VOGE_S2_PREFETCH 1      // the next trip's staged records are requested before this trip's commits
 #endif
+#ifndef VOGE_S2_PUT_AT_CNT
+#define VOGE_S2_PUT_AT_CNT 1    // the 16-bit form's commit stores every candidate at row cnt (no row select); see commit()
+#endif
 #ifndef VOGE_S2_PRIO_LEN
 #define VOGE_S2_PRIO_LEN 0   // (experiment) tiles with at least this many candidates run at raised wave priority; 0: off
 #endif
@@ -80,7 +83,9 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
                  const float *__restrict__ pool_lb, const int *__restrict__ tl_off, const int2 *__restrict__ order,
                  const int tiles_per_img, const int nstx, const int nst, const int N, const int H, const int W, const int K,
                  const float thr_act, int32_t *__restrict__ out_idx, float *__restrict__ out_len, float *__restrict__ out_act,
-                 float *__restrict__ out_dsd, int32_t *__restrict__ out_cnt) {
+                 float *__restrict__ out_dsd, int32_t *__restrict__ out_cnt,
+                 const CamView cam /* R != NULL (round 6): `rays` is NULL, every lane makes its pixel's ray from the camera and the
+                                      tile leaves its rays in cam.rays_out for the composite and the backward */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *const Llen = reinterpret_cast<float *>(smem_raw);
   unsigned char *const Lpos_raw = smem_raw + sweep2_len_bytes(K);
@@ -129,6 +134,16 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       const int rr = lane >> 3, x = lane & 7;
       if (rr < th && x < tw) out_cnt[((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8 + x] = 0;
     }
+    if (cam.R != nullptr && cam.rays_out != nullptr) {      // (uniform) the tile's rays, for whoever reads the bundle later
+      const int rr = lane >> 3, x = lane & 7;
+      if (rr < th && x < tw) {
+        const CamK ck = cam_load(cam, b);
+        float ex, ey, ez;
+        cam_ray(ck, cam_irow(cam, fty * 8 + rr), ftx * 8 + x, ex, ey, ez);
+        float *o = cam.rays_out + (((size_t)b * H + fty * 8 + rr) * W + (size_t)ftx * 8 + x) * 3;
+        o[0] = ex; o[1] = ey; o[2] = ez;
+      }
+    }
     return;
   }
   const bool pooled = (slot.x & kPoolFlag) != 0;
@@ -170,11 +185,24 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   Cone wcone;
   bool unit_rays = false;
   wcone.ok = false;
+  const bool from_cam = cam.R != nullptr;      // (uniform)
+  CamK ck;
+  if (from_cam) ck = cam_load(cam, b);
+  // pixel (x, y) of the band's ray: out of the bundle, or made here (rays_fwd_kernel's operations: the same bits)
+  auto ray_of = [&](const int x, const int y, float &rx, float &ry, float &rz) {
+    if (from_cam) {
+      cam_ray(ck, cam_irow(cam, y), x, rx, ry, rz);
+    } else {
+      const size_t rid = ((size_t)b * H + y) * W + x;
+      rx = rays[3 * rid + 0]; ry = rays[3 * rid + 1]; rz = rays[3 * rid + 2];
+    }
+  };
   auto ray_setup = [&](const bool mine, const float mdx, const float mdy, const float mdz) {
     // (mine: the caller's (dx, dy, dz) IS lane's ray of the tile -- the 16-bit form; the wide form's lanes hold other rays)
     const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
-    const size_t rid = ((size_t)b * H + min(py, H - 1)) * W + min(px, W - 1);
-    const RayDir u = mine ? ray_dir(mdx, mdy, mdz) : ray_dir(rays[3 * rid + 0], rays[3 * rid + 1], rays[3 * rid + 2]);
+    float ox_ = mdx, oy_ = mdy, oz_ = mdz;
+    if (!mine) ray_of(min(px, W - 1), min(py, H - 1), ox_, oy_, oz_);
+    const RayDir u = ray_dir(ox_, oy_, oz_);
     unit_rays = __all(!u.ok || u.unit);
     wcone.ok = false;
     if (!pref) {      // (uniform)
@@ -202,7 +230,12 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
     float lb0 = (binned && lane < src_n) ? src_lb[lane] : -INFINITY;
     int id1 = (64 + lane < src_n) ? (binned ? src_id[64 + lane] : 64 + lane) : -1;
     float lb1 = (binned && 64 + lane < src_n) ? src_lb[64 + lane] : -INFINITY;
-    const float dx = rays[3 * ray_id + 0], dy = rays[3 * ray_id + 1], dz = rays[3 * ray_id + 2];
+    float dx, dy, dz;
+    ray_of(min(px, W - 1), min(py, H - 1), dx, dy, dz);
+    if (from_cam && cam.rays_out != nullptr && valid) {      // (the bundle, for the kernels behind the sweep: 12 bytes per lane)
+      float *o = cam.rays_out + 3 * ray_id;
+      o[0] = dx; o[1] = dy; o[2] = dz;
+    }
     // (unconditional 16-byte loads at a clamped index, then a select: the `id >= 0 ? load : constant` form compiled into four
     //  dword loads per record)
     //  dword loads per record, each in an exec-mask region of its own -- and the compiler re-derives that from any select
@@ -365,7 +398,18 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
     auto commit = [&](const float len, const float act, const unsigned p) {
       const bool take = (act < thr_act) & (len <= worstf);
       const bool app = take & (len > tailf);      // (a full list has tail == worst: it never appends)
-      put(app ? cnt : Kv, len, p);                 // (the others store into the spare row K, which is never read)
+      // Where a candidate that is NOT appended leaves its (len, handle).  Nobody ever reads a row at or behind a list's end
+      // (lean / slow / deep_insert read rows < cnt, the epilogue masks slots >= cnt), so the 16-bit form stores every candidate
+      // at row cnt -- an append is then just the count moving past it, and a full list (cnt == K) hits the spare row K.  The
+      // WIDE form must not: its lanes 32..63 evaluate along with cnt = 0 and share their COLUMN with lanes 0..31 (col = lane &
+      // 31), so "row cnt" of such a lane is row 0 of another ray's live list; there the non-appends go to the spare row K, the
+      // only row two lanes of a column may both write.  (Round 5 tried put(cnt) for both forms, saw cfg4 -- the wide form --
+      // fail, and reverted without finding this; tests/test_gpu_configs.py::test_streams_longer_than_16_bit_handles and ::test_rebuilt_sweep_equals_round_3_sweep_bit_for_bit (its last case) run the wide form.)
+#if VOGE_S2_PUT_AT_CNT
+      put(WIDE ? (app ? cnt : Kv) : cnt, len, p);
+#else
+      put(app ? cnt : Kv, len, p);
+#endif
       cnt += app ? 1 : 0;
       tailf = app ? len : tailf;
       worstf = (app & (cnt == K)) ? len : worstf;      // the append that fills the list: its len is the admission bound now

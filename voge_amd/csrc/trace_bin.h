@@ -134,12 +134,17 @@ struct BinAView {
   bool has_f;
 };
 template <bool ISO_PREP>
-__device__ __forceinline__ BinAView binA_view(const int b, const float *__restrict__ cam_fwd, const IsoView view) {
+__device__ __forceinline__ BinAView binA_view(const int b, const float *__restrict__ cam_fwd, const IsoView view,
+                                              const CamView &cam = no_camera(), const CamK *ck = nullptr) {
   BinAView V;
   V.ox = V.oy = V.oz = 0.f; V.fx = V.fy = V.fz = 0.f; V.has_f = false;
   if (ISO_PREP) {
     if (view.origin != nullptr) { const float *o = view.origin + 3 * b; V.ox = o[0]; V.oy = o[1]; V.oz = o[2]; }
     if (cam_fwd != nullptr) { const float *f = cam_fwd + 3 * b; V.fx = f[0]; V.fy = f[1]; V.fz = f[2]; V.has_f = true; }
+    if (cam.R != nullptr) {      // (round 6: the camera itself -- centre and view axis exactly as rays_fwd_kernel / _view_axis make them)
+      cam_origin(*ck, cam.T + 3 * b, V.ox, V.oy, V.oz);
+      if (cam.behind) { const float *r = cam.R + 9 * b; V.fx = r[2]; V.fy = r[5]; V.fz = r[8]; V.has_f = true; }
+    }
   }
   return V;
 }
@@ -162,7 +167,7 @@ __device__ __forceinline__ float4 binA_derive(const BinARaw r, const bool valid,
   if (!valid) return make_float4(0.f, 0.f, 0.f, -1.f);      // (a padding record: reach -1, never kept)
   if (!ISO_PREP) return r.v;
   float mx = r.v.x, my = r.v.y, mz = r.v.z;
-  if (view.origin != nullptr) { mx -= V.ox; my -= V.oy; mz -= V.oz; }   // centring of Renderer.py:130: the same single fp32 subtraction
+  if (view.origin != nullptr || view.cam_origin) { mx -= V.ox; my -= V.oy; mz -= V.oz; }   // centring of Renderer.py:130: the same single fp32 subtraction
   const float a = iso_view_a(r.v.w, view.mode);
   a_out = a;
   float4 c = iso_cull_record(mx, my, mz, a, thr_act);
@@ -186,7 +191,8 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
             float4 *__restrict__ seg_rec /* the same shape: the entries' cull records */,
             unsigned long long *__restrict__ pool_top /* binB's list pool: reset here, one launch ahead of its first use */,
             int *__restrict__ seg_ext /* [B*nst][kParts][kExtChunks]: starts of the segment's extension chunks in ext_id */,
-            int32_t *__restrict__ ext_id /* [B][regions][kParts][ext_arena] */, const int ext_arena) {
+            int32_t *__restrict__ ext_id /* [B][regions][kParts][ext_arena] */, const int ext_arena,
+            const CamView cam /* R != NULL: cones, centre and view axis from the camera; `cones` is not read */) {
   __shared__ BinALds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int region = blockIdx.x / kParts, part = blockIdx.x - region * kParts, b = blockIdx.y;
@@ -212,7 +218,12 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
   float4 c[kRoundChunks];
   float av[kRoundChunks];
   int gq[kRoundChunks];
-  const BinAView V = binA_view<ISO_PREP>(b, cam_fwd, view);
+  CamK ck;
+  if (cam.R != nullptr) ck = cam_load(cam, b);      // (uniform)
+  const BinAView V = binA_view<ISO_PREP>(b, cam_fwd, view, cam, &ck);
+  if (cam.R != nullptr && cam.origin_out != nullptr && blockIdx.x == 0 && tid == 0) {
+    cam.origin_out[3 * b] = V.ox; cam.origin_out[3 * b + 1] = V.oy; cam.origin_out[3 * b + 2] = V.oz;
+  }
   BinARaw raw[kRoundChunks];
   auto fetch_round = [&](const int j0) {      // (all of the round's loads go out together ...)
 #pragma unroll
@@ -236,7 +247,10 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
     const int cc = lane & (kCh * kCh - 1);
     const int cx = rx * kCh + (cc & (kCh - 1)), cy = ry * kCh + cc / kCh;
     ConeRec r = {0.f, 0.f, 1.f, 1.f, 0.f, -1.f, 0.f, 0.f};      // ok = -1: no such super-tile
-    if (cx < nstx && cy < nsty) r = cones[cone_super_at(b, nst, cy * nstx + cx)];
+    if (cx < nstx && cy < nsty) {
+      if (cam.R != nullptr) r = cam_rect_cone(ck, cam, cx * kST, cx * kST + kST - 1, cy * kST, cy * kST + kST - 1);      // (uniform branch)
+      else r = cones[cone_super_at(b, nst, cy * nstx + cx)];
+    }
     if (lane < kCh * kCh) L.child[lane] = r;
     const bool present = lane < kCh * kCh && r.ok >= 0.f;
     const float sx = wave_sum_dpp(present ? r.ax : 0.f), sy = wave_sum_dpp(present ? r.ay : 0.f), sz = wave_sum_dpp(present ? r.az : 0.f);
@@ -416,7 +430,7 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
                   ext_have = -1;
                 }
               }
-              __builtin_amdgcn_wave_barrier();
+              wave_lds_sync();
               if (ext_have >= 0) {
                 int f = fill0;
   #pragma unroll
@@ -871,7 +885,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
             int *__restrict__ tl_off, const int *__restrict__ seg_ext, const int32_t *__restrict__ ext_id,
             const int K, int32_t *__restrict__ out_idx, float *__restrict__ out_len, float *__restrict__ out_act,
             float *__restrict__ out_dsd, int32_t *__restrict__ out_cnt, float *__restrict__ out_weight,
-            int64_t *__restrict__ out_valid) {
+            int64_t *__restrict__ out_valid, const CamView cam /* R != NULL: the cones from the camera; `cones` is not read */) {
   __shared__ BinLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   BIN_TS(1, 7);      // (kernel entry)
@@ -898,8 +912,16 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   // useful load (entry -> cones done: 3.8 us of the 11.5 us a workgroup lasts, profiles/r5_bin_times.txt).
   // (everything the prologue needs from memory is requested here, before the first use: the two cones, this super-tile's 16
   // segment counts, and the counts the launch rank is estimated from)
-  const ConeRec tcr = cones[cone_tile_at(b, (size_t)nstx * nsty, binl, ((qq >> 1) * 2 + (wave >> 1)) * 4 + (qq & 1) * 2 + (wave & 1))];
-  const ConeRec qcr = cones[cone_quad_at(b, (size_t)nstx * nsty, binl, qq)];
+  ConeRec tcr, qcr;
+  if (cam.R != nullptr) {      // (uniform; round 6) both cones from four corner rays each -- no load at all
+    const CamK ck = cam_load(cam, b);
+    tcr = cam_rect_cone(ck, cam, tx * 8, tx * 8 + 7, ty * 8, ty * 8 + 7);
+    const int qx0 = stx * kST + (qq & 1) * kQuad, qy0 = sty * kST + (qq >> 1) * kQuad;
+    qcr = cam_rect_cone(ck, cam, qx0, qx0 + kQuad - 1, qy0, qy0 + kQuad - 1);
+  } else {
+    tcr = cones[cone_tile_at(b, (size_t)nstx * nsty, binl, ((qq >> 1) * 2 + (wave >> 1)) * 4 + (qq & 1) * 2 + (wave & 1))];
+    qcr = cones[cone_quad_at(b, (size_t)nstx * nsty, binl, qq)];
+  }
   const int my_cnt = (tid < kParts) ? seg_count[(size_t)bin * kParts + tid] : 0;
   const bool ranked = nbin_total <= kRankMaxBins;
   const int4 est0 = (ranked && tid < nbin_total) ? *reinterpret_cast<const int4 *>(seg_count + (size_t)tid * kParts) : make_int4(0, 0, 0, 0);

@@ -169,12 +169,17 @@ namespace voge {
 // binA reads the records (cfg4: entry 297 -> 287 us, renderer form 272 -> 257).  Same functions, same bits.
 __global__ void __launch_bounds__(256)
 iso_prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const float *__restrict__ cam_fwd, const int N,
-                const float thr_act, const IsoView view, float4 *__restrict__ cull, float4 *__restrict__ ms,
+                const float thr_act, const IsoView view, float4 *__restrict__ cull, float4 *__restrict__ ms, const CamView cam,
                 int *__restrict__ seg_count = nullptr, const long n_seg = 0, unsigned long long *__restrict__ pool_top = nullptr) {
   small_set_marks(seg_count, n_seg, pool_top);
   const int g = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (g >= N) return;
-  const BinAView V = binA_view<true>(b, cam_fwd, view);
+  CamK ck;
+  if (cam.R != nullptr) ck = cam_load(cam, b);      // (uniform)
+  const BinAView V = binA_view<true>(b, cam_fwd, view, cam, &ck);
+  if (cam.R != nullptr && cam.origin_out != nullptr && g == 0) {
+    cam.origin_out[3 * b] = V.ox; cam.origin_out[3 * b + 1] = V.oy; cam.origin_out[3 * b + 2] = V.oz;
+  }
   const BinARaw raw = binA_fetch<true>(g, b, N, nullptr, mus, isg, view);
   float a;
   const float4 c = binA_derive<true>(raw, true, V, thr_act, view, a);
@@ -733,10 +738,10 @@ trace_fwd_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ evr
           *reinterpret_cast<v2f *>(LE + d0 + a) = (v2f){em[a], em[a + 1]};
         }
       }
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_sync();
       float wgt[NS];
       compn_fwd_rows<NS>(lm, sm, em, Llen, Lsp, LE, d0, k0, K, q, LP, LP, in_wg, cur.on, true, seg_lo, occ, wgt);
-      __builtin_amdgcn_wave_barrier();      // the rows are rewritten by the next round
+      wave_lds_sync();      // the rows are rewritten by the next round
       if (cur.on) {
         const size_t ob = cur.pix * K + k0;
         st16i<(VOGE_NT_STORES & 2) != 0>(out_idx + ob, oi[0], oi[1], oi[2], oi[3]);      // (write-once, 16 B per slot: non-temporal, voge_common.h)
@@ -1186,7 +1191,7 @@ static std::atomic<int> g_sweep_variant{0};
 template <bool ISO>
 static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *rays, int B, int N, int H, int W, int K,
                         float thr_act, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt, float occ,
-                        float *weight, int64_t *valid_num, hipStream_t st) {
+                        float *weight, int64_t *valid_num, hipStream_t st, const CamView &cam) {
   constexpr int T = 64;
   // (fused composite epilogue: three padded per-pixel rows (len, s', E) for one round of 64 / (K/4) pixels)
   const size_t comp = (weight != nullptr) ? sizeof(float) * 3 * (size_t)compn_rows(K, 4, 64, true) : 0;
@@ -1219,7 +1224,7 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
                      cones, N, H, W, ws.nstx, ws.nsty, ws.nbin, ws.q_count, ws.q_id, ws.q_lb, ws.tl_count, ws.tl_id, ws.tl_lb,
                      ws.order, ws.pool_top, ws.pool_cap, ws.pool_id, ws.pool_lb, ws.tl_off, ws.seg_ext, ws.ext_id, K,
                      (v2 && act == nullptr) ? nullptr : idx /* (sweep_iso_kernel writes the empty tiles itself) */, len, act, dsd, cnt,
-                     weight, valid_num);
+                     weight, valid_num, cam);
   {
     int rc = launch_status();
     if (rc) return rc;
@@ -1233,9 +1238,10 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
   if (v2) {
     hipLaunchKernelGGL(sweep_iso_kernel<!ISO>, grid, dim3(T), lds2, st, ws.cull, ws.ms, ws.evr, rays, ws.q_count, ws.q_id, ws.q_lb, ws.tl_id,
                        ws.tl_lb, ws.pool_id, ws.pool_lb, ws.tl_off, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx, ws.nstx * ws.nsty, N, H, W, K,
-                       thr_act, idx, len, act, dsd, cnt);
+                       thr_act, idx, len, act, dsd, cnt, cam);
     return launch_status();
   }
+  if (cam.R != nullptr) return VOGE_ERR_BAD_ARG;      // (round 3's sweeps read the bundle)
   if constexpr (kOld) {
     hipLaunchKernelGGL((trace_fwd_kernel<1, ISO && kOld>), grid, dim3(T), lds, st, ws.cull, ws.evr, ws.ms, rays, ws.q_count, ws.q_id, ws.q_lb,
                        ws.tl_count, ws.tl_id, ws.tl_lb, ws.pool_id, ws.pool_lb, ws.tl_off, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx,
@@ -1332,18 +1338,27 @@ __global__ void __launch_bounds__(256) idx_rebase1_kernel(int32_t *__restrict__ 
 static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mus, const float *isigmas, const float *rays,
                            const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
                            float thr_act, void *workspace, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
-                           voge_stream_t stream, float occ, float *weight, int64_t *valid_num, float *records);
+                           voge_stream_t stream, float occ, float *weight, int64_t *valid_num, float *records, const CamView &cam);
 
 static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float *mus, const float *isigmas, const float *rays,
                                const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
                                float thr_act, void *workspace, size_t workspace_bytes,
                                int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
                                voge_stream_t stream, float occ = 1.0f, float *weight = nullptr, int64_t *valid_num = nullptr,
-                               float *records = nullptr) {
+                               float *records = nullptr, const CamView cam = no_camera()) {
   if (B < 0 || N < 0 || H < 0 || W < 0 || K <= 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K) return VOGE_ERR_K_TOO_LARGE;
   if ((size_t)B * H * W == 0) return 0;  // numel == 0 early return (ray_trace_voge.cu:248-251)
-  if (!rays || !idx || !len || !workspace || (act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;
+  // (with a camera the kernels make the rays themselves; the bundle they leave in cam.rays_out is what a composite behind the
+  //  sweep reads.  That form keeps no act / dsd: the sweep's epilogue would have to read the bundle back.)
+  if (cam.R != nullptr) {
+    if (rays || cones_in || cam_fwd || act || dsd || !iso_in || !cam.T || !cam.focal || !cam.pp || cam.stripe_h <= 0 || cam.pitch < 0 ||
+        cam.h != H || cam.W != W || (weight != nullptr && !cam.rays_out))
+      return VOGE_ERR_BAD_ARG;
+  } else if (!rays) {
+    return VOGE_ERR_BAD_ARG;
+  }
+  if (!idx || !len || !workspace || (act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;
   // act / dsd may be omitted by the scalar-sigma fragment entry points only (they are re-derived where needed)
   // (with weights: composited behind the sweep; without: records kept, the caller composites later)
   // (general forms: trace only, with the packed (mu, A) records kept for the deferred composite -- voge_trace_lean_fwd)
@@ -1367,10 +1382,14 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
     IsoView v = view;
     if (v.origin != nullptr) v.origin += 3 * (size_t)b0;
     auto at = [&](auto *p, const size_t per_view) { return p ? p + (size_t)b0 * per_view : p; };
+    if (cam.R != nullptr) v.cam_origin = 1;
+    CamView cv = cam;
+    cv.R = at(cam.R, 9); cv.T = at(cam.T, 3); cv.focal = at(cam.focal, 2); cv.pp = at(cam.pp, 2);
+    cv.origin_out = at(cam.origin_out, 3); cv.rays_out = at(cam.rays_out, npv * 3);
     const int rc = trace_chunk_fwd(iso_in, v, at(mus, stride_mu), at(isigmas, stride_sg), at(rays, npv * 3), at(cam_fwd, 3),
                                    at(cones_in, nst * kConeRecsPerST * (sizeof(ConeRec) / sizeof(float))), nb, N, H, W, K, thr_act, workspace,
                                    at(idx, npv * K), at(len, npv * K), at(act, npv * K), at(dsd, npv * K), at(cnt, npv), stream, occ,
-                                   at(weight, npv * K), at(valid_num, npv), at(records, (size_t)N * (iso_in ? 4 : 12)));
+                                   at(weight, npv * K), at(valid_num, npv), at(records, (size_t)N * (iso_in ? 4 : 12)), cv);
     if (rc) return rc;
     if (b0 > 0 && N > 0) {
       const size_t n = (size_t)nb * npv * K;
@@ -1393,7 +1412,7 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
 static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mus, const float *isigmas, const float *rays,
                            const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
                            float thr_act, void *workspace, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
-                           voge_stream_t stream, float occ, float *weight, int64_t *valid_num, float *records) {
+                           voge_stream_t stream, float occ, float *weight, int64_t *valid_num, float *records, const CamView &cam) {
   hipStream_t st = (hipStream_t)stream;
   const int P = B * N;
   TraceWs ws;
@@ -1401,7 +1420,7 @@ static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mu
   if (records != nullptr && iso_in) ws.ms = reinterpret_cast<float4 *>(records);      // the caller keeps the (centre, a) records (backward)
   // super-tile cones: the caller's (voge_rays_fwd makes them while it makes the rays), or one more launch here
   const ConeRec *cones = reinterpret_cast<const ConeRec *>(cones_in);
-  if (cones == nullptr) {
+  if (cones == nullptr && cam.R == nullptr) {
     const int rc = voge_ray_cones(rays, B, H, W, reinterpret_cast<float *>(ws.cones), stream);
     if (rc) return rc;
     cones = ws.cones;
@@ -1414,25 +1433,25 @@ static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mu
   if (small_set && iso_in) {
     // a few thousand Gaussians: records + "every segment overflowed" marks, no binA (small_set_marks)
     hipLaunchKernelGGL(iso_prep_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, mus, isigmas, cam_fwd, N, thr_act, view, ws.cull, ws.ms,
-                       ws.seg_count, n_seg, ws.pool_top);
+                       cam, ws.seg_count, n_seg, ws.pool_top);
   } else if (small_set) {
     hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P, thr_act, ws.cull,
                        ws.evr, ws.ms, ws.ell, reinterpret_cast<float4 *>(records), ws.seg_count, n_seg, ws.pool_top);
   } else if (iso_in && N >= VOGE_ISO_PREP_SPLIT) {
     // scalar sigmas, slices of more than two rounds: the records in a pass of their own (iso_prep_kernel)
-    hipLaunchKernelGGL(iso_prep_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, mus, isigmas, cam_fwd, N, thr_act, view, ws.cull, ws.ms);
+    hipLaunchKernelGGL(iso_prep_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, mus, isigmas, cam_fwd, N, thr_act, view, ws.cull, ws.ms, cam);
     hipLaunchKernelGGL(binA_kernel<false>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
-                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top, ws.seg_ext, ws.ext_id, ws.ext_arena);
+                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top, ws.seg_ext, ws.ext_id, ws.ext_arena, cam);
   } else if (iso_in) {
     // scalar sigmas: binA derives the per-Gaussian records itself -- two launches in front of the sweep
     hipLaunchKernelGGL(binA_kernel<true>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
-                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top, ws.seg_ext, ws.ext_id, ws.ext_arena);
+                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top, ws.seg_ext, ws.ext_id, ws.ext_arena, cam);
   } else {
     if (P > 0)
       hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P, thr_act, ws.cull,
                          ws.evr, ws.ms, ws.ell, reinterpret_cast<float4 *>(records));
     hipLaunchKernelGGL(binA_kernel<false>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
-                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top, ws.seg_ext, ws.ext_id, ws.ext_arena);
+                       cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top, ws.seg_ext, ws.ext_id, ws.ext_arena, cam);
   }
   {
     int rc = launch_status();
@@ -1448,14 +1467,14 @@ static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mu
   const bool fused = VOGE_FUSED_EPILOGUE && weight != nullptr && (K & 3) == 0 && K <= 256 && cnt != nullptr;
   int rc;
 #ifndef VOGE_NO_ISO_SWEEP
-  if (iso_in) rc = launch_trace<true>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, fused ? weight : nullptr, fused ? valid_num : nullptr, st);
+  if (iso_in) rc = launch_trace<true>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, fused ? weight : nullptr, fused ? valid_num : nullptr, st, cam);
   else
 #endif
-  rc = launch_trace<false>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, fused ? weight : nullptr, fused ? valid_num : nullptr, st);
+  rc = launch_trace<false>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, fused ? weight : nullptr, fused ? valid_num : nullptr, st, cam);
   if (rc || weight == nullptr || fused) return rc;
   if (act == nullptr)
-    return voge_composite_fwd_iso(idx, cnt, len, reinterpret_cast<const float *>(ws.ms), rays, occ, (long)B * H * W, K, weight,
-                                  valid_num, stream);
+    return voge_composite_fwd_iso(idx, cnt, len, reinterpret_cast<const float *>(ws.ms), cam.R != nullptr ? cam.rays_out : rays, occ,
+                                  (long)B * H * W, K, weight, valid_num, stream);
   return voge_composite_fwd(idx, cnt, act, len, dsd, occ, (long)B * H * W, K, weight, valid_num, stream);
 }
 
@@ -1552,4 +1571,27 @@ extern "C" int voge_fragments_fwd_iso_view(const float *verts, const float *sigm
     return VOGE_ERR_BAD_ARG;
   return trace_topk_fwd_impl(1, IsoView{origin, shared ? 1 : 0, sigma_mode}, verts, sigmas, rays, cam_fwd, cones, B, N, H, W, K,
                              thr_act, workspace, workspace_bytes, idx, len, act, dsd, cnt, stream, occ, weight, valid_num, records);
+}
+
+// ---- Round 6: the renderer's trace with the CAMERA as its input (GaussianRenderer.forward, Renderer.py:102-150, up to and
+// including ray_tracing: the ray bundle of :124-128, the centring of :130, the sigma rule of :133-137, RayTracing.py:12-30 and
+// ray_trace_voge.cu:135-217) as three launches -- binA, binB, sweep -- with no ray-generation launch in front: every kernel
+// makes the rays, cones, camera centre and view axis it needs from (R, T, focal, principal point) with rays_fwd_kernel's own
+// operations (voge_common.h: CamView).  Outputs: idx, len, cnt, records as voge_fragments_fwd_iso_view's trace-only form, plus
+// the ray bundle `rays` [B,h,W,3] (written by the sweep: the composite and the backward read it) and `origin` [B,3].
+// rows: the band is h stacked rows; stacked row i is image row row0 + (i / stripe_h) * pitch + i % stripe_h (a contiguous
+// band: stripe_h >= h, pitch 0; a rank's interleaved stripes: voge_rays_striped_fwd's meaning).  behind != 0: the reference's
+// "skip z < 0" candidate rule (rasterize_coarse.cu:35), the view axis being column 2 of R.
+extern "C" int voge_frame_trace_fwd_iso(const float *verts, const float *sigmas, int shared, int sigma_mode, const float *R,
+                                        const float *T, const float *focal, const float *pp, int row0, int stripe_h, int pitch,
+                                        int behind, int B, int N, int h, int W, int K, float thr_act, void *workspace,
+                                        size_t workspace_bytes, int32_t *idx, float *len, int32_t *cnt, float *records,
+                                        float *rays, float *origin, voge_stream_t stream) {
+  if (sigma_mode < 0 || sigma_mode > 2 || !cnt || !records || !R || !T || !focal || !pp || stripe_h <= 0 || pitch < 0 || !origin)
+    return VOGE_ERR_BAD_ARG;
+  if ((size_t)B * h * W > 0 && !rays) return VOGE_ERR_BAD_ARG;
+  const CamView cam{R, T, focal, pp, row0, stripe_h, pitch, h, W, behind ? 1 : 0, origin, rays};
+  return trace_topk_fwd_impl(1, IsoView{nullptr, shared ? 1 : 0, sigma_mode}, verts, sigmas, nullptr, nullptr, nullptr, B, N, h, W, K,
+                             thr_act, workspace, workspace_bytes, idx, len, nullptr, nullptr, cnt, stream, 1.0f, nullptr, nullptr, records,
+                             cam);
 }

@@ -46,6 +46,7 @@ constexpr uint32_t kIsoFlag = 0x7fc0a150u;
 struct IsoView {
   const float *origin;
   int shared, mode;
+  int cam_origin = 0;      // (round 6) the centre comes from the kernel's CamView instead of `origin`
 };
 __device__ __forceinline__ float iso_view_a(const float s, const int mode) {
   return mode == 1 ? 2.0f * s : (mode == 2 ? 2.0f / s : s);
@@ -450,6 +451,75 @@ __device__ __forceinline__ Cone load_cone(const ConeRec &r) {
   return c;
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 6: the CAMERA as a kernel argument.  The renderer's frame used to start with a launch of its own for the ray bundle
+// (rays.hip: 3 MB written, read back by four kernels, plus the cone hierarchy) -- 7 us of launch floor per frame and the first
+// of three autograd nodes on the host.  The frame's kernels now take (R, T, focal, principal point) and make what they need:
+//   * a pixel's ray (cam_ray) -- the SAME operations in the same order as rays_fwd_kernel, which is built from these
+//     functions too (-ffp-contract=off: identical bits wherever it is evaluated; tests/test_gpu_frame.py asserts it);
+//   * the camera centre (cam_origin) and the view axis (cam_axis: column 2 of R, RayTracing.py's z > 0 rule);
+//   * the bounding cone of any pixel rectangle (cam_rect_cone), ANALYTICALLY from its four corner rays: the image-plane
+//     points whose ray lies within an angle theta of an axis form the inside of a conic section, a convex set, so a
+//     rectangle is inside the cone as soon as its corners are -- the extrema over a block's rays are attained at corners,
+//     which is what block_cones_hier256 finds by reducing over all 1024 rays of a super-tile.
+// A CamView with R == nullptr means "no camera": the kernel reads rays / cones / origin from memory as before.
+// ------------------------------------------------------------------------------------------
+struct Mat3 {
+  float m[9];
+};
+// inverse by adjugate; fp32 (R is a rotation in practice: cond ~ 1)
+__device__ __forceinline__ Mat3 inv3(const float *R) {
+  Mat3 o;
+  const float a = R[0], b = R[1], c = R[2], d = R[3], e = R[4], f = R[5], g = R[6], h = R[7], i = R[8];
+  const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const float det = a * A + b * B + c * C;
+  const float id = 1.0f / det;
+  o.m[0] = A * id;               o.m[1] = -(b * i - c * h) * id;  o.m[2] = (b * f - c * e) * id;
+  o.m[3] = B * id;               o.m[4] = (a * i - c * g) * id;   o.m[5] = -(a * f - c * d) * id;
+  o.m[6] = C * id;               o.m[7] = -(a * h - b * g) * id;  o.m[8] = (a * e - b * d) * id;
+  return o;
+}
+struct CamView {
+  const float *R, *T, *focal, *pp;      // [B,3,3], [B,3], [B,2], [B,2] (contiguous fp32); R == nullptr: no camera
+  int row0, stripe_h, pitch;            // stacked row i of the rendered band is image row row0 + (i / stripe_h) * pitch + i % stripe_h
+  int h, W;                             // the band: h stacked rows of W pixels
+  int behind;                           // != 0: Gaussians behind the camera plane are no candidates (rasterize_coarse.cu:35; axis = R[:, 2])
+  float *origin_out;                    // NULL | [B,3]: the camera centres, written by the frame's first kernel
+  float *rays_out;                      // NULL | [B,h,W,3]: the ray bundle, written by the sweep for the kernels behind it
+};
+__host__ __device__ inline CamView no_camera() { return CamView{nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0, 0, 0, nullptr, nullptr}; }
+struct CamK {      // one batch element's camera, as the ray arithmetic wants it
+  Mat3 Ri;
+  float ifx, ify, px, py;
+};
+__device__ __forceinline__ CamK cam_load(const CamView &c, const int b) {
+  CamK k;
+  k.Ri = inv3(c.R + 9 * b);
+  k.ifx = 1.0f / c.focal[2 * b]; k.ify = 1.0f / c.focal[2 * b + 1];
+  k.px = c.pp[2 * b]; k.py = c.pp[2 * b + 1];
+  return k;
+}
+__device__ __forceinline__ int cam_irow(const CamView &c, const int i) {
+  const int k = i / c.stripe_h;
+  return c.row0 + k * c.pitch + (i - k * c.stripe_h);
+}
+// unit world-space direction of image pixel (row ir, column j): Renderer.py:124-128's bundle (rays.hip's header)
+__device__ __forceinline__ void cam_ray(const CamK &k, const int ir, const int j, float &x, float &y, float &z) {
+  const float vx = (k.px - ((float)j + 0.5f)) * k.ifx;
+  const float vy = (k.py - ((float)ir + 0.5f)) * k.ify;
+  const float wx = vx * k.Ri.m[0] + vy * k.Ri.m[3] + k.Ri.m[6];
+  const float wy = vx * k.Ri.m[1] + vy * k.Ri.m[4] + k.Ri.m[7];
+  const float wz = vx * k.Ri.m[2] + vy * k.Ri.m[5] + k.Ri.m[8];
+  const float inv = __builtin_amdgcn_rsqf(wx * wx + wy * wy + wz * wz);
+  x = wx * inv; y = wy * inv; z = wz * inv;
+}
+// camera centre C = -T R^-1 (static indices only: a lane-dependent index into Ri makes the compiler park the matrix in LDS)
+__device__ __forceinline__ void cam_origin(const CamK &k, const float *t, float &ox, float &oy, float &oz) {
+  ox = -(t[0] * k.Ri.m[0] + t[1] * k.Ri.m[3] + t[2] * k.Ri.m[6]);
+  oy = -(t[0] * k.Ri.m[1] + t[1] * k.Ri.m[4] + t[2] * k.Ri.m[7]);
+  oz = -(t[0] * k.Ri.m[2] + t[1] * k.Ri.m[5] + t[2] * k.Ri.m[8]);
+}
+
 // Bounding cone of up to NR rays per thread of a 256-thread workgroup (`has` bit k: ray k exists).  Pass 1: axis =
 // direction of the plain vector sum (any axis gives a valid cone; rays of a pinhole camera have near-equal lengths,
 // so this is the mean direction).  Pass 2: extrema of the axial cosine and of the SQUARED radial sine -- one v_rsq
@@ -650,6 +720,36 @@ __device__ __forceinline__ void block_cones_hier256(const float (&rx)[4], const 
   }
 }
 
+// Bounding cone of the rays of stacked rows i0 .. i1 (inclusive), columns j0 .. j1 of a band of h rows and W columns, from the
+// four corner rays (see CamView above).  Rows of a stacked band are image rows cam_irow(i), monotone in i: the image-space
+// rectangle [irow(i0), irow(i1)] contains every row between (a superset when the block straddles two stripes: still a valid
+// cone).  A block outside the band: ok = -1 ("no such tile").  The margins are block_cone256's (rsq's ulp) on top of
+// cone_finish's; an interior ray's own fp32 rounding (~1e-7) is far inside them and inside the 2e-5 |mu| of every reach.
+__device__ __forceinline__ ConeRec cam_rect_cone(const CamK &k, const CamView &c, int j0, int j1, int i0, int i1) {
+  if (j0 >= c.W || i0 >= c.h || j1 < j0 || i1 < i0) return ConeRec{0.f, 0.f, 1.f, 1.f, 0.f, -1.f, 0.f, 0.f};
+  j1 = min(j1, c.W - 1); i1 = min(i1, c.h - 1);
+  const int r0 = cam_irow(c, i0), r1 = cam_irow(c, i1);
+  float cx[4], cy[4], cz[4];
+  cam_ray(k, r0, j0, cx[0], cy[0], cz[0]); cam_ray(k, r0, j1, cx[1], cy[1], cz[1]);
+  cam_ray(k, r1, j0, cx[2], cy[2], cz[2]); cam_ray(k, r1, j1, cx[3], cy[3], cz[3]);
+  RayDir u[4];
+  bool all_ok = true;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    u[q] = ray_dir(cx[q], cy[q], cz[q]);
+    all_ok = all_ok && u[q].ok;
+    sx += u[q].ok ? u[q].ux : 0.f; sy += u[q].ok ? u[q].uy : 0.f; sz += u[q].ok ? u[q].uz : 0.f;
+  }
+  const float n = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
+  const float ax = sx / n, ay = sy / n, az = sz / n;
+  float smax = 0.f, cmin = 1.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cone_partial(u[q], ax, ay, az, smax, cmin);
+  const Cone cn = cone_finish(ax, ay, az, n * 0.25f, smax * (1.0f + 4e-7f) + 4e-7f, cmin - 4e-7f, all_ok);
+  return ConeRec{cn.ax, cn.ay, cn.az, cn.cs, cn.sn, cn.ok ? 1.f : 0.f, 0.f, 0.f};
+}
+
 // Does the cull record carry an ellipsoid record (trace_fwd.hip, prep_one)?
 #ifdef VOGE_NO_ELL   // build without the ellipsoid tests (bounding spheres only): for A/B timing
 __device__ __forceinline__ bool cull_has_ell(const float4) { return false; }
@@ -711,6 +811,17 @@ __device__ __forceinline__ const lds_vint *lds_volatile(const int *p) { return (
 __device__ __forceinline__ lds_vuint *lds_volatile(unsigned *p) { return (lds_vuint *)p; }
 typedef __attribute__((address_space(3))) volatile float lds_vfloat;
 __device__ __forceinline__ const lds_vfloat *lds_volatile(const float *p) { return (const lds_vfloat *)p; }
+
+// Lanes of ONE wave exchanging values through LDS (a wave's LDS operations complete in issue order, so no wait is needed in
+// hardware).  llvm.amdgcn.wave.barrier alone is declared IntrNoMem: only the machine scheduler treats it as a barrier, IR
+// passes may still hoist a plain LDS load above an earlier plain store of ANOTHER lane's address.  The
+// wavefront-scope release / acquire fences are what orders the memory operations for the optimiser; at wavefront scope they
+// emit no instruction.  Every cross-lane LDS hand-over in this library goes through this.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <int NE, int NV4>
 struct WaveTable {
@@ -854,7 +965,7 @@ __device__ __forceinline__ void wt_add2_by_group(WaveTable<NE, NV4> &t, const in
       }
       pend = false;
     }
-    __builtin_amdgcn_wave_barrier();      // (the next pixel's reads come after this pixel's writes in the wave's LDS queue)
+    wave_lds_sync();      // (the next pixel's reads come after this pixel's writes in the wave's LDS queue)
   }
 }
 
