@@ -100,7 +100,38 @@ def stage_bytes(P, npix, K, C=3, iso=False):
         "trace_lean_fwd": P * 16 + npix * 12 + npix * K * 8 + npix * 4 + P * 16,
         # composite + shade in one pass: idx, len, cnt, rays, records, colours in; weight, valid_num, rgb, img, wsum out
         "composite_shade_fwd": npix * K * 8 + npix * 4 + npix * 12 + P * 16 + P * 4 * C + npix * K * 4 + npix * 8 + 2 * npix * 4 * C + npix * 4,
+        # round 6, the frame path (ABI 7).  The trace from the camera: Gaussians (verts 12 + sigma 4) in; idx, len, cnt, records AND the
+        # ray bundle out (no rays in: they are made in registers)
+        "frame_trace_fwd": P * 16 + npix * K * 8 + npix * 4 + P * 16 + npix * 12,
+        # composite_shade_fwd + the zeroed accumulator of the backward (32 bytes per Gaussian)
+        "frame_shade_fwd": (npix * K * 8 + npix * 4 + npix * 12 + P * 16 + P * 4 * C + npix * K * 4 + npix * 8 + 2 * npix * 4 * C + npix * 4
+                            + P * 32),
+        # fragment_bwd without its fill launch: the same algorithmic bytes
+        "frame_shade_bwd": npix * K * 12 + npix * (2 * 4 * C + 4 + 12) + P * (4 * C + 16) + P * (4 * C + 16),
     }
+
+
+def valu_table():
+    """Per dominant kernel {VALU wave-instructions (M), VALU utilisation, share of wave cycles in s_waitcnt} from the newest
+    profiles/r*_valu_utilisation.txt (tools/valu_util.py over rocprofv3 --pmc SQ passes of this command; counters cannot be read
+    from inside the run).  The LAST block of the file is the round's final build."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_utilisation.txt")), key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+    if not files:
+        return None
+    rows, out = [], {}
+    for line in open(files[-1]):
+        if line.startswith("=="):
+            rows = []
+        else:
+            rows.append(line)
+    for line in rows:
+        m = re.match(r"(\S.*?)\s+VALU\s+([\d.]+) M.*?busy\s+([\d.]+) us.*?VALU utilisation ([\d.]+).*?waiting \(s_waitcnt\) ([\d.]+)", line)
+        if m:
+            out[m.group(1).strip()] = {"valu_Minst": float(m.group(2)), "busy_us": float(m.group(3)), "valu_utilisation": float(m.group(4)),
+                                       "s_waitcnt_share": float(m.group(5))}
+    return {"source": "profiles/" + os.path.basename(files[-1]), "kernels": out}
 
 
 def loop_bench(args):
@@ -674,6 +705,32 @@ def main():
                         lambda s: lib.voge_composite_shade_fwd_iso(P_(s["i"]), P_(s["c"]), P_(s["l"]), P_(recs), P_(rays), 1.0, P_(colors),
                                                                    P_(bg), -1.0, npix, K, 3, N, P_(s["w"]), P_(s["v"]), P_(s["rgb"]),
                                                                    P_(s["img"]), P_(s["ws"]), st))
+                # round 6: the frame path's three entry points (what the renderer launches for scalar sigmas and fixed cameras)
+                from voge_amd.cameras import camera_tensors
+                cam = camera_tensors(cams, (H, W))
+                if cam is not None:
+                    Rc, Tc, fc, pc = (x.contiguous() for x in cam[:4])
+                    vts, sgs = gm.verts.detach().contiguous(), gm.sigmas.detach().contiguous()
+                    stage_defs["frame_trace_fwd"] = (
+                        lambda: dict(ws=torch.empty(nws, dtype=torch.uint8, device=dev), i=E(idx), l=E(w),
+                                     c=torch.empty((1, H, W), dtype=torch.int32, device=dev), r=torch.empty((N, 4), device=dev),
+                                     ry=E(rays), o=torch.empty((1, 3), device=dev)),
+                        lambda s: lib.voge_frame_trace_fwd_iso(P_(vts), P_(sgs), 1, 1, P_(Rc), P_(Tc), P_(fc), P_(pc), 0, H, 0, 0, 1, N, H, W, K,
+                                                               thr_act, P_(s["ws"]), nws, P_(s["i"]), P_(s["l"]), P_(s["c"]), P_(s["r"]),
+                                                               P_(s["ry"]), P_(s["o"]), st))
+                    stage_defs["frame_shade_fwd"] = (
+                        lambda: dict(i=C_(sel[0]), c=C_(cnt), l=C_(sel[1]), w=E(w), v=E(vn), rgb=E(rgb), img=E(rgb), ws=E(wsum),
+                                     acc=torch.empty(N * 32, dtype=torch.uint8, device=dev)),
+                        lambda s: lib.voge_frame_shade_fwd_iso(P_(s["i"]), P_(s["c"]), P_(s["l"]), P_(recs), P_(rays), 1.0, P_(colors),
+                                                               P_(bg), -1.0, npix, K, 3, N, P_(s["w"]), P_(s["v"]), P_(s["rgb"]),
+                                                               P_(s["img"]), P_(s["ws"]), P_(s["acc"]), N * 32, st))
+                    # (the accumulator is not re-zeroed between the timed calls: the kernel adds to whatever is there -- same work)
+                    stage_defs["frame_shade_bwd"] = (
+                        lambda: dict(i=C_(idx), c=C_(cnt), w=C_(w), l=C_(sel[1]), rgb=C_(rgb), ws=C_(wsum), g=torch.ones_like(rgb),
+                                     acc=torch.zeros(N * 32, dtype=torch.uint8, device=dev), gv=E(mus), gs=E(isg), gc=torch.empty_like(colors)),
+                        lambda s: lib.voge_frame_shade_bwd_iso(P_(recs), P_(sgs), 1, 1, P_(rays), P_(colors), P_(s["i"]), P_(s["c"]), P_(s["w"]),
+                                                               P_(s["l"]), P_(s["rgb"]), P_(s["ws"]), P_(bg), -1.0, P_(s["g"]), 3, 1, 1.0,
+                                                               1, N, H, W, K, 3, N, P_(s["acc"]), N * 32, P_(s["gv"]), P_(s["gs"]), P_(s["gc"]), st))
             else:
                 # the general path's fused backward (voge_fragment_shade_bwd): full 3x3 forms
                 nfb = lib.voge_fragment_bwd_workspace_bytes(N)
@@ -721,15 +778,23 @@ def main():
         result["stages"] = stages
         result["stages_note"] = ("ms / GBps: the call cycling over `buffer_sets` independent sets of operands (> 3 x the 256 MB "
                                  "Infinity Cache in total), i.e. served from HBM; ms_same_buffers: replayed on one set (L3-assisted)")
-        on_frame = (("trace_lean_fwd", "composite_shade_fwd", "fragment_bwd") if "composite_shade_fwd" in stages
+        on_frame = (("frame_trace_fwd", "frame_shade_fwd", "frame_shade_bwd") if "frame_shade_bwd" in stages and ops.FRAME_PATH
+                    else ("trace_lean_fwd", "composite_shade_fwd", "fragment_bwd") if "composite_shade_fwd" in stages
                     else ("fragments_fwd", "shade_fwd", "fragment_bwd") if "fragments_fwd" in stages
                     else ("trace_fwd", "composite_fwd", "shade_fwd", "fragment_bwd"))
         result["stages_on_frame"] = list(on_frame)      # (the stand-alone entry points are timed for reference, not launched)
+        # SURVEY 8d's second fraction and the variant the frame actually runs: the trace as the renderer
+        # launches it (no act / dsd), and the SQ counters of the dominant kernels from the committed rocprofv3 --pmc passes
+        tr = on_frame[0]
+        result["roofline"]["on_frame"] = {"entry": tr, "algorithmic_bytes": nbytes[tr], "avg_launch_ms": stages[tr]["ms"],
+                                          "achieved": stages[tr]["GBps"], "frac": round(stages[tr]["GBps"] / HBM_PEAK_GBS, 4),
+                                          "note": "the renderer keeps no act / dsd: about half of the stand-alone entry's bytes"}
+        result["roofline"]["valu"] = valu_table()
         result["frame_kernel_ms_sum"] = round(sum(stages[k]["ms"] for k in on_frame), 4)
         result["hits_per_pixel"] = round(hits / npix, 2)
         # the whole frame against the same roofline: algorithmic bytes of the entry points it launches, and the HBM bytes
         # the PMC counters saw for one frame of this config (committed passes), both over the measured ms_per_step
-        f_algo = sum(nbytes[k] for k in on_frame) + npix * 12
+        f_algo = sum(nbytes[k] for k in on_frame) + (0 if on_frame[0] == "frame_trace_fwd" else npix * 12)
         f_traffic = tcfg.get("frame_hbm_bytes")
         result["frame_roofline"] = {
             "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes": f_algo,

@@ -58,7 +58,7 @@ const char *voge_error_string(int code);
  * view, never more than the batch.  Any size >= one view's (voge_trace_workspace_bytes(1, ...))
  * is accepted and used in full; pass more to keep a big batch in one chunk.  Caller allocates,
  * 256-byte aligned (any torch allocation is); the contents need no initialisation and nothing
- * in it outlives the call except what voge_trace_pool_usage reads (the LAST chunk's pool).
+ * in it outlives the call except what voge_trace_pool_usage reads (every chunk's pool counter, in the scratch's last 512 bytes).
  */
 size_t voge_trace_workspace_bytes(int B, int N, int H, int W);
 
@@ -66,10 +66,13 @@ size_t voge_trace_workspace_bytes(int B, int N, int H, int W);
  * Diagnostic: how much of the workspace's candidate-list POOL the last forward trace that ran on `workspace` (same
  * B, N, H, W) used.  The pool holds the lists of image quads (16x16 px) with more candidates than the in-LDS sort
  * takes (a small object behind a few dozen pixels); *used > *capacity means it ran out and those quads' tiles fell
- * back to streaming every Gaussian (slow, still exact).  Synchronous (copies one int from the device).  No reference
+ * back to streaming every Gaussian (slow, still exact).  workspace_bytes = what the trace was given: the chunks it walked
+ * follow from it, and *used is the LARGEST use of any chunk (ABI 7; ABI 6 derived the layout from the default size and saw
+ * the last chunk only).  Synchronous (copies 512 bytes from the device).  No reference
  * counterpart: the reference's coarse stage drops points when a bin overflows (rasterize_coarse.cu).
  */
-int voge_trace_pool_usage(const void *workspace, int B, int N, int H, int W, int *used, int *capacity);
+int voge_trace_pool_usage(const void *workspace, size_t workspace_bytes, int B, int N, int H, int W, int *used,
+                          int *capacity);
 
 /*
  * (Not part of this ABI: `voge_debug_sweep_variant(int)` exists in -DVOGE_AB builds only -- voge_amd/libvoge_hip_ab.so, a
@@ -308,7 +311,8 @@ int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int s
                                 float *g_sigmas, float *g_colors, voge_stream_t stream);
 
 /*
- * ABI 7 -- ONE FRAME of the renderer as five launches: the camera goes in, nothing but the frame's own kernels run.
+ * ABI 7 -- ONE FRAME of the renderer as six launches (binA, binB, sweep | composite | fused backward, finish): the camera goes
+ * in, no ray-generation launch and no fill launch run.
  *
  * voge_frame_trace_fwd_iso   GaussianRenderer.forward (VoGE/Renderer.py:102-150) up to and including ray_tracing, for scalar
  *   sigmas and one Gaussian set per view (`shared` != 0: [N,3] / [N] seen by all B views) or per batch element ([B,N,..]):
@@ -319,16 +323,19 @@ int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int s
  *   analytic corner-ray cones of csrc/voge_common.h).  The band rendered is h stacked rows of W pixels; stacked row i is image
  *   row row0 + (i / stripe_h) * pitch + i % stripe_h (one contiguous band: stripe_h >= h, pitch = 0).  behind != 0: Gaussians
  *   behind the camera plane are no candidates (rasterize_coarse.cu:35; what cam_fwd = R[:, :, 2] selects in the other entries).
- *   Writes idx, len [B,h,W,K], cnt [B,h,W], records [B*N,4] (centred mean, a), rays [B,h,W,3] (by the sweep) and origin [B,3].
+ *   Writes idx, len [B,h,W,K], cnt [B,h,W], records [B*N,4] (centred mean, a), rays [B,h,W,3] (by the sweep) and origin [B,3]
+ *   (NULL: not wanted).
  *   workspace: voge_trace_workspace_bytes(B, N, h, W).  No act / dsd (the fragments' consumers re-derive them).
  * voge_frame_shade_fwd_iso   = voge_composite_shade_fwd_iso (aggregation + merge_final + get_silhouette +
- *   to_colored_background, Aggregation.py:82-141, Renderer.py:157-171) that ALSO sets grad_zero[0 .. grad_zero_n) to zero:
- *   the gradient arrays of the backward below, so that no fill launch stands in front of it.
- * voge_frame_shade_bwd_iso   = voge_fragment_shade_bwd_iso as ONE launch: the waves add their per-Gaussian sums straight
- *   into g_verts [shared ? N : B*N, 3], g_sigmas [shared ? N : B*N] and g_colors [Nattr, C] (float atomics; the chain rule of
- *   the sigma rule and the sum over the views of a shared set included) -- the three arrays must be ZERO on entry and are
- *   accumulated into.  No scratch.  K <= 128, C <= 4.
+ *   to_colored_background, Aggregation.py:82-141, Renderer.py:157-171; img = bg = NULL: interpolate_attr + the weight sum)
+ *   that ALSO zeroes bwd_acc [bwd_acc_bytes, a multiple of 16, 16-byte aligned; NULL: nothing] on its way: the accumulator
+ *   of the backward below (voge_frame_bwd_acc_bytes(B * N)), so that no fill launch stands in front of it.
+ * voge_frame_shade_bwd_iso / voge_frame_merge_bwd_iso   = voge_fragment_shade_bwd_iso / voge_fragment_merge_bwd_iso for
+ *   fragments that keep no act / dsd, taking that accumulator -- ZEROED, good for one call -- in place of a scratch they would
+ *   have to fill first: the fused kernel + the finishing pass.  (Adding the per-Gaussian sums straight into the gradient
+ *   arrays was built and measured: one launch less, 30 us slower -- three atomic requests per table entry instead of one.)
  */
+size_t voge_frame_bwd_acc_bytes(int P);
 int voge_frame_trace_fwd_iso(const float *verts, const float *sigmas, int shared, int sigma_mode, const float *R,
                              const float *T, const float *focal, const float *pp, int row0, int stripe_h, int pitch,
                              int behind, int B, int N, int h, int W, int K, float thr_act, void *workspace,
@@ -337,14 +344,20 @@ int voge_frame_trace_fwd_iso(const float *verts, const float *sigmas, int shared
 int voge_frame_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                              const float *rays, float occ, const float *colors, const float *bg, float thr,
                              long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
-                             float *rgb, float *img, float *wsum, float *grad_zero, long grad_zero_n,
+                             float *rgb, float *img, float *wsum, void *bwd_acc, size_t bwd_acc_bytes,
                              voge_stream_t stream);
 int voge_frame_shade_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
                              const float *rays, const float *colors, const int32_t *idx, const int32_t *cnt,
                              const float *weight, const float *len, const float *rgb, const float *wsum,
                              const float *bg, float thr, const float *g_img, long g_stride_pix, long g_stride_c,
-                             float occ, int B, int N, long nrows, int W, int K, int C, long Nattr, float *g_verts,
-                             float *g_sigmas, float *g_colors, voge_stream_t stream);
+                             float occ, int B, int N, long nrows, int W, int K, int C, long Nattr, void *acc_zeroed,
+                             size_t acc_bytes, float *g_verts, float *g_sigmas, float *g_colors, voge_stream_t stream);
+int voge_frame_merge_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
+                             const float *rays, const float *attr, const int32_t *idx, const int32_t *cnt,
+                             const float *weight, const float *len, const float *g_rgb, long g_stride_pix,
+                             long g_stride_c, const float *g_wsum, float occ, int B, int N, long nrows, int W, int K,
+                             int C, long Nattr, void *acc_zeroed, size_t acc_bytes, float *g_verts, float *g_sigmas,
+                             float *g_attr, voge_stream_t stream);
 
 /* interpolate_attr (+ get_silhouette) on fragments of this renderer, backward: merge_final's own backward
  * (VoGE/Aggregation.py:111-141; g_rgb = the gradient of the merged attributes [nrows*W,C], strides as g_img above), plus

@@ -688,7 +688,7 @@ def test_every_public_fragments_transformation_is_classified(hip_lib):
     KEEP = {"copy": lambda f: f.copy(), "squeeze": lambda f: f.squeeze(), "unsqueeze": lambda f: f.squeeze().unsqueeze(),
             "__getitem__": lambda f: f[0]}
     DROP = {"__getitem__ of a multi-view batch": None}
-    NOT_A_TRANSFORMATION = {"to_dict", "shape", "vert_weight", "valid_num", "__len__", "__init__"}
+    NOT_A_TRANSFORMATION = {"to_dict", "shape", "vert_weight", "valid_num", "vert_hit_length", "__len__", "__init__"}
     public = {k for k, v in vars(Fragments).items() if not k.startswith("_") or k in ("__getitem__", "__len__", "__init__")}
     public -= {"_fields"}
     assert public == set(KEEP) | NOT_A_TRANSFORMATION, public ^ (set(KEEP) | NOT_A_TRANSFORMATION)

@@ -15,7 +15,7 @@ from . import ops
 from .Aggregation import aggregation, expend_sigma, merge_final
 from . import RayTracing
 from .RayTracing import _view_axis
-from .cameras import pixel_rays
+from .cameras import camera_tensors, pixel_rays
 
 # Fold `verts - origin` and `2 * sigmas` into the trace kernels when the inputs allow it (see forward()).
 # VOGE_FUSED_PREAMBLE=0 (or setting this flag) keeps the reference's elementwise torch ops: same results.
@@ -37,9 +37,21 @@ class Fragments(object):
         self._vert_weight = vert_weight
         self.vert_index = vert_index
         self._valid_num = valid_num
-        self.vert_hit_length = vert_hit_length
+        self._hit_length = vert_hit_length
         self._lazy = _lazy if vert_weight is None else None
+        # (the camera-input trace hands out vert_hit_length without a grad_fn; the differentiable alias is made when it is read)
+        self._hl_src = _lazy if (_lazy is not None and _lazy.frame and _lazy.sel_len is vert_hit_length) else None
         self._wsum = None      # (per-pixel weight sum left by a one-pass composite + merge: see get_silhouette)
+
+    @property
+    def vert_hit_length(self):
+        if self._hl_src is not None:
+            self._hit_length, self._hl_src = self._hl_src.hit_length(), None
+        return self._hit_length
+
+    @vert_hit_length.setter
+    def vert_hit_length(self, value):
+        self._hit_length, self._hl_src = value, None
 
     def _composite(self):
         lz, self._lazy = self._lazy, None
@@ -102,7 +114,7 @@ class Fragments(object):
 
     def copy(self):
         if self._lazy is not None:      # nothing to copy yet: the same deferred composite (tensors are shared either way,
-            return Fragments(None, self.vert_index, self._valid_num, self.vert_hit_length, _lazy=self._lazy)   # .contiguous() is a no-op)
+            return Fragments(None, self.vert_index, self._valid_num, self._hit_length, _lazy=self._lazy)   # .contiguous() is a no-op)
         return self._map(lambda t: t.contiguous())
 
 
@@ -136,12 +148,35 @@ class GaussianRenderer(nn.Module):
         self.cameras = cameras
         self.render_settings = render_settings
         self.device = cameras.device
+        object.__setattr__(self, "_frame_memo", None)      # (see _frame_camera)
 
     def to(self, device):
         # cameras are not nn.Modules: move them by hand (Renderer.py:96-100)
         self.cameras = self.cameras.to(device)
         self.device = device
         return self
+
+    def _frame_camera(self, cams, image_size, rows):
+        """cameras.camera_tensors with the per-frame constants remembered: in a loop only R and T move, the intrinsics, the
+        image size and the band are the same objects every frame -- their preparation (two expands, a cache look-up by
+        weak reference, the band arithmetic) was 9 us of every frame's host time."""
+        R, T = cams.R, cams.T
+        f, p = cams.focal_length, cams.principal_point
+        memo = self._frame_memo
+        if (memo is not None and memo[0] is f and memo[1] is p and memo[2] is image_size and memo[3] is rows and torch.is_tensor(R)
+                and torch.is_tensor(T) and R.dim() == 3 and T.dim() == 2 and R.shape[0] == memo[4] == T.shape[0] and R.is_cuda
+                and R.dtype is torch.float32 is T.dtype and T.device == R.device and not (R.requires_grad or T.requires_grad)
+                and (not torch.is_tensor(f) or f._version == memo[5]) and (not torch.is_tensor(p) or p._version == memo[6])
+                and not torch.cuda.is_current_stream_capturing()):
+            return (R, T) + memo[7]
+        cam = camera_tensors(cams, image_size, rows)
+        object.__setattr__(self, "_frame_memo", None)
+        if (cam is not None and cam[0] is R and cam[1] is T and not torch.cuda.is_current_stream_capturing()
+                and (rows is None or isinstance(rows, tuple) or hasattr(rows, "stripe_h"))):
+            # (remembered by identity: the objects are held here, so an id cannot be recycled while the memo lives)
+            object.__setattr__(self, "_frame_memo", (f, p, image_size, rows, R.shape[0], f._version if torch.is_tensor(f) else 0,
+                                                     p._version if torch.is_tensor(p) else 0, cam[2:]))
+        return cam
 
     def forward(self, gmeshes, **kwargs):
         """gmeshes() -> (verts [N,3] | [B,N,3], sigmas [N] | [N,3] | [N,3,3], radians);
@@ -162,13 +197,22 @@ class GaussianRenderer(nn.Module):
         if shared_verts:                     #  select + zero-fill + copy into every backward)
             verts = verts[None]
 
+        thr_act = -math.log(st['thr_activation'] + 1 / 1e10)                     # RayTracing.py:76,85
+        K, occ = st['max_assign'], st['absorptivity']
+        behind = st['max_point_per_bin'] != -1      # the coarse stage's "skip z < 0" candidate rule (rasterize_coarse.cu:35)
+        if sigmas.dim() == 1 and shared_verts and FUSED_PREAMBLE and not (behind and RayTracing.REFERENCE_CANDIDATES):
+            # Round 6, the frame path: one (verts [N,3], sigmas [N]) set, fixed cameras -- the trace takes the CAMERA itself
+            # (ops._FrameTrace: no ray-generation launch, no ray node; rays, cones, camera centre and view axis are made inside
+            # binA / binB / the sweep with the ray kernel's own operations) and stops behind the sweep like trace_lean
+            cam = self._frame_camera(cams, image_size, kwargs.get('rows'))
+            if cam is not None and ops.frame_eligible(verts2d, sigmas, *cam[:4], K, cam[4][1] * cam[5]):
+                index, hit_len, lz = ops.frame_trace(verts2d, sigmas, *cam[:4], cam[4], cam[5], behind, thr_act, K,
+                                                     2 if st['inverse_sigma'] else 1, occ)
+                return Fragments(None, index, None, hit_len, _lazy=lz)
         rays, origin = pixel_rays(cams, image_size, rows=kwargs.get('rows'))     # [B,h,W,3], [B,3]
         # ray_tracing (RayTracing.py:12-30) + aggregation (Aggregation.py:82-107) as ONE call: the trace's sweep
         # composites the fragments in its epilogue (voge_fragments_fwd*).  The stand-alone ray_tracing* / aggregation
         # functions remain the public API and produce the same values.
-        thr_act = -math.log(st['thr_activation'] + 1 / 1e10)                     # RayTracing.py:76,85
-        K, occ = st['max_assign'], st['absorptivity']
-        behind = st['max_point_per_bin'] != -1      # the coarse stage's "skip z < 0" candidate rule (rasterize_coarse.cu:35)
         if behind and RayTracing.REFERENCE_CANDIDATES:
             # the reference's own coarse candidate lists (lossy on purpose): explicit lists, unfused calls
             sig3 = expend_sigma(sigmas)
@@ -265,10 +309,10 @@ _BG_CACHE = {}
 def _background_tensor(color, device):
     """Device tensor of a constant background colour, uploaded once per (colour, device): a
     host-to-device copy per frame would also make the frame impossible to capture in a HIP graph."""
-    key = (tuple(float(c) for c in color), str(device))
+    key = (color if type(color) is tuple else tuple(color), device)      # ((1, 1, 1) and (1.0, 1.0, 1.0) hash and compare equal)
     t = _BG_CACHE.get(key)
     if t is None:
-        t = _BG_CACHE[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+        t = _BG_CACHE[key] = torch.tensor(tuple(float(c) for c in color), dtype=torch.float32, device=device)
     return t
 
 
@@ -276,7 +320,8 @@ def to_colored_background(fragments: Fragments, colors: torch.Tensor,
                           background_color: Union[torch.Tensor, tuple, list] = (1, 1, 1), thr: float = -1):
     if not torch.is_tensor(background_color):
         background_color = _background_tensor(background_color, colors.device)
-    background_color = background_color.to(colors.device)
+    elif background_color.device != colors.device:
+        background_color = background_color.to(colors.device)
     lz = getattr(fragments, "_lazy", None)
     if lz is not None:
         # fragments whose composite is still pending: weights AND image in one pass (ops._CompositeShade)

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VOGE_HIP_LIB points at another build of the same ABI (kernel tuning variants)
 LIB_PATH = os.environ.get("VOGE_HIP_LIB") or os.path.join(_HERE, "libvoge_hip.so")
 ABI_VERSION = 7
+MAX_K = 256      # VOGE_MAX_K of include/voge_hip.h: the top-K lists of a tile live in LDS
 
 _c_void_p = ctypes.c_void_p
 _c_int = ctypes.c_int
@@ -22,7 +23,7 @@ SIGNATURES = {
     "voge_abi_version": (_c_int, []),
     "voge_error_string": (ctypes.c_char_p, [_c_int]),
     "voge_trace_workspace_bytes": (_c_size_t, [_c_int] * 4),
-    "voge_trace_pool_usage": (_c_int, [_c_void_p] + [_c_int] * 4 + [_c_void_p] * 2),
+    "voge_trace_pool_usage": (_c_int, [_c_void_p, _c_size_t] + [_c_int] * 4 + [_c_void_p] * 2),
     "voge_trace_topk_fwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_float, _c_void_p, _c_size_t]
                             + [_c_void_p] * 6),
     "voge_trace_topk_list_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 9 + [_c_float] + [_c_void_p] * 6),
@@ -44,9 +45,12 @@ SIGNATURES = {
     "voge_frame_trace_fwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 4 + [_c_int] * 9
                                  + [_c_float, _c_void_p, _c_size_t] + [_c_void_p] * 7),
     "voge_frame_shade_fwd_iso": (_c_int, [_c_void_p] * 5 + [_c_float, _c_void_p, _c_void_p, _c_float, _c_long, _c_int, _c_int, _c_long]
-                                 + [_c_void_p] * 6 + [_c_long, _c_void_p]),
+                                 + [_c_void_p] * 6 + [_c_size_t, _c_void_p]),
     "voge_frame_shade_bwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 9 + [_c_float, _c_void_p, _c_long, _c_long, _c_float]
-                                 + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_int, _c_long] + [_c_void_p] * 4),
+                                 + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),
+    "voge_frame_merge_bwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 7 + [_c_long, _c_long, _c_void_p, _c_float]
+                                 + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),
+    "voge_frame_bwd_acc_bytes": (_c_size_t, [_c_int]),
     "voge_fragment_bwd_workspace_bytes": (_c_size_t, [_c_int]),
     "voge_fragment_act_dsd_iso": (_c_int, [_c_void_p] * 5 + [_c_long, _c_int, _c_int] + [_c_void_p] * 3),
     "voge_composite_shade_fwd_iso": (_c_int, [_c_void_p] * 5 + [_c_float, _c_void_p, _c_void_p, _c_float, _c_long, _c_int, _c_int, _c_long]

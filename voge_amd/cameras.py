@@ -122,6 +122,31 @@ def pixel_rays(cameras, image_size, rows=None):
     return ops.pixel_rays(R, T, f, pp, r0, r1 - r0, W)
 
 
+def camera_tensors(cameras, image_size, rows=None):
+    """What the camera-input trace (ops._FrameTrace) takes: (R [B,3,3], T [B,3], focal [B,2], pp [B,2], band, W) with
+    band = (row0, h, stripe_h, pitch) -- pixel_rays' arguments without the ray kernel -- or None when the camera does not
+    fit that path (a pose or an intrinsic that wants a gradient, tensors on another device)."""
+    R, T = cameras.R, cameras.T
+    if not (torch.is_tensor(R) and torch.is_tensor(T)) or R.requires_grad or T.requires_grad or not R.is_cuda:
+        return None
+    if R.dim() != 3 or T.dim() != 2 or R.dtype != torch.float32 or T.dtype != torch.float32 or T.device != R.device:
+        R = R.to(torch.float32).reshape(-1, 3, 3)
+        T = torch.as_tensor(T, dtype=torch.float32, device=R.device).reshape(-1, 3)
+    B = max(R.shape[0], T.shape[0])
+    if R.shape[0] != B or T.shape[0] != B:
+        R, T = R.expand(B, 3, 3), T.expand(B, 3)
+    f, pp = _intrinsics(cameras.focal_length, cameras.principal_point, B, R.device)
+    if f.requires_grad or pp.requires_grad:
+        return None
+    H, W = int(image_size[0]), int(image_size[1])
+    if hasattr(rows, "stripe_h"):      # distributed.Stripes
+        band = (int(rows.row0), int(rows.h), int(rows.stripe_h), int(rows.pitch))
+    else:
+        r0, r1 = (0, H) if rows is None else (int(rows[0]), int(rows[1]))
+        band = (r0, r1 - r0, max(r1 - r0, 1), 0)
+    return R, T, f, pp, band, W
+
+
 def camera_position_from_spherical_angles(distance, elevation, azimuth, degrees=True, device="cpu"):
     d, e, a = torch.broadcast_tensors(*(torch.as_tensor(v, dtype=torch.float32, device=device).reshape(-1)
                                         for v in (distance, elevation, azimuth)))
@@ -155,8 +180,8 @@ def _look_at_host(dist, elev, azim, degrees, eye, at, up):
         if degrees:
             e, a = e * f32(math.pi / 180.0), a * f32(math.pi / 180.0)
         C = np.stack([d * np.cos(e) * np.sin(a), d * np.sin(e), d * np.cos(e) * np.cos(a)], axis=-1).astype(f32) + at
+    C, at = np.broadcast_arrays(C, at)      # (one eye with several targets broadcasts like the tensor path)
     B = C.shape[0]
-    at = np.broadcast_to(at, (B, 3))
     up = np.broadcast_to(np.asarray(up, f32).reshape(-1, 3), (B, 3))
     nrm = lambda v: v / np.maximum(np.sqrt((v * v).sum(-1, keepdims=True, dtype=f32)), f32(1e-5))
     z = nrm(at - C)
@@ -180,8 +205,13 @@ def look_at_view_transform(dist=1.0, elev=0.0, azim=0.0, degrees=True, eye=None,
     if not any(isinstance(v, torch.Tensor) for v in (dist, elev, azim, eye, at, up)):
         R, T = _look_at_host(dist, elev, azim, degrees, eye, at, up)
         B = R.shape[0]
-        buf = torch.from_numpy(np.concatenate((R.reshape(-1), T.reshape(-1)))).to(device)
-        return buf[:B * 9].view(B, 3, 3), buf[B * 9:].view(B, 3)
+        # (ONE host-to-device copy; T starts at a 16-byte boundary of the shared buffer, so a vectorised load of either is fine)
+        t0 = (B * 9 + 3) // 4 * 4
+        host = np.zeros(t0 + B * 3, np.float32)
+        host[:B * 9] = R.reshape(-1)
+        host[t0:] = T.reshape(-1)
+        buf = torch.from_numpy(host).to(device)
+        return buf[:B * 9].view(B, 3, 3), buf[t0:].view(B, 3)
     if eye is not None:
         C = torch.as_tensor(eye, dtype=torch.float32, device=device).reshape(-1, 3)
     else:

@@ -352,8 +352,12 @@ struct CompShade {
   long Nattr;
   float *rgb, *img, *wsum;
   int32_t *idx_fix;
-  float *zero_p = nullptr;      // (round 6) NULL | zero_n floats this launch sets to zero on the way: the gradient arrays the frame's
-  long zero_n = 0;              // backward accumulates into (voge_frame_shade_fwd_iso) -- no fill launch in front of that backward
+  // (round 6) zero_n4 float4s this launch sets to zero on its way: the accumulator of the frame's backward
+  // (voge_frame_shade_fwd_iso's bwd_acc) -- no fill launch in front of that backward.  The first ceil(zero_n4 / 64) workgroups
+  // store one float4 per thread; for everybody else it is one scalar compare (the kernel is VALU-bound: as a grid-stride loop
+  // in every thread the zeroing cost 1.3 us)
+  float4 *zero_p = nullptr;
+  long zero_n4 = 0;
 };
 // GEN (forward from the records): the records are the general path's packed (mu, A), three float4 per Gaussian
 // (voge_trace_lean_fwd); act / dsd come from make_eval + pair_eval, the operations of the sweep's own epilogue.
@@ -369,8 +373,9 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
                   const CompShade sh = CompShade{}) {
   static_assert(SC == 0 || (MODE == 0 && WAVE && SC <= 4), "the shade stage rides in the wave-form forward only");
   constexpr bool BWD = MODE != 0;
-  if (SC > 0 && sh.zero_p != nullptr) {      // (uniform)
-    for (long zi = (long)blockIdx.x * blockDim.x + threadIdx.x; zi < sh.zero_n; zi += (long)gridDim.x * blockDim.x) sh.zero_p[zi] = 0.0f;
+  if (SC > 0 && (long)blockIdx.x * blockDim.x < sh.zero_n4) {      // (uniform; the launch covers zero_n4: composite_shade_fwd_impl)
+    const long zi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (zi < sh.zero_n4) sh.zero_p[zi] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   constexpr int NP = NS / 2;       // own aligned pairs
   extern __shared__ __attribute__((aligned(16))) unsigned char comp_smem[];
@@ -1065,9 +1070,9 @@ static int composite_shade_fwd_impl(const bool gen, int32_t *idx, const int32_t 
                                     const float *rays, float occ, const float *colors, const float *bg, float thr,
                                     long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
                                     float *rgb, float *img, float *wsum, voge_stream_t stream, float *act_out = nullptr,
-                                    float *dsd_out = nullptr, float *zero_p = nullptr, long zero_n = 0) {
+                                    float *dsd_out = nullptr, void *zero_p = nullptr, size_t zero_bytes = 0) {
   if ((act_out == nullptr) != (dsd_out == nullptr)) return VOGE_ERR_BAD_ARG;
-  if (zero_n < 0 || (zero_n > 0 && (!zero_p || C == 0))) return VOGE_ERR_BAD_ARG;
+  if (zero_bytes > 0 && (!zero_p || C == 0 || (zero_bytes & 15) || (reinterpret_cast<uintptr_t>(zero_p) & 15))) return VOGE_ERR_BAD_ARG;
   if (npix < 0 || K <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
   if (K > VOGE_MAX_K || (C != 0 && C != 3 && C != 4)) return VOGE_ERR_K_TOO_LARGE;      // four slots per lane (any K: a last group may be short); RGB / RGBA
   if (npix == 0) return 0;
@@ -1086,7 +1091,15 @@ static int composite_shade_fwd_impl(const bool gen, int32_t *idx, const int32_t 
   const dim3 gridn((unsigned)((npix + ppwn - 1) / ppwn)), blockn(tn);
   const size_t ldsn = compn_lds_bytes(K, NS, false, tn, true);
   const bool small = (double)npix * K < (double)(1l << 30);
-  const CompShade sh{colors, bg, thr, Nattr, rgb, img, wsum, idx, zero_n > 0 ? zero_p : nullptr, zero_n};
+  CompShade sh{colors, bg, thr, Nattr, rgb, img, wsum, idx};
+  if (zero_bytes > 0) {
+    sh.zero_p = reinterpret_cast<float4 *>(zero_p); sh.zero_n4 = (long)(zero_bytes / 16);
+    if ((long)gridn.x * tn < sh.zero_n4) {      // (more to zero than the launch has threads: a fill of its own, once in a blue moon)
+      const hipError_t e = voge_fill_async(zero_p, 0, zero_bytes, (hipStream_t)stream);
+      if (e != hipSuccess) return (int)e;
+      sh.zero_p = nullptr; sh.zero_n4 = 0;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
   const float4 *rec = reinterpret_cast<const float4 *>(records);
 #define VOGE_LAUNCH_CS(OT, CC, GG)                                                                                           \
@@ -1112,17 +1125,19 @@ extern "C" int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, co
                                   rgb, img, wsum, stream);
 }
 
-// Round 6, the frame's forward behind the sweep: voge_composite_shade_fwd_iso, which on its way also zeroes `grad_zero_n` floats
-// at `grad_zero` -- the gradient arrays voge_frame_shade_bwd_iso will accumulate into, so that backward needs no fill launch.
+// Round 6, the frame's forward behind the sweep: voge_composite_shade_fwd_iso, which on its way also zeroes bwd_acc -- the
+// accumulator voge_frame_shade_bwd_iso / voge_frame_merge_bwd_iso add into (voge_frame_bwd_acc_bytes), so that backward has no
+// fill launch in front of it.  bwd_acc == NULL: nothing to zero (a frame nobody differentiates).
 extern "C" int voge_frame_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                                         const float *rays, float occ, const float *colors, const float *bg, float thr,
                                         long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
-                                        float *rgb, float *img, float *wsum, float *grad_zero, long grad_zero_n,
+                                        float *rgb, float *img, float *wsum, void *bwd_acc, size_t bwd_acc_bytes,
                                         voge_stream_t stream) {
   if (C != 3 && C != 4) return VOGE_ERR_K_TOO_LARGE;
-  if (npix == 0 && grad_zero_n > 0) return (int)voge_fill_async(grad_zero, 0, sizeof(float) * (size_t)grad_zero_n, (hipStream_t)stream);
+  if (bwd_acc == nullptr) bwd_acc_bytes = 0;
+  if (npix == 0) return bwd_acc_bytes ? (int)voge_fill_async(bwd_acc, 0, bwd_acc_bytes, (hipStream_t)stream) : 0;      // (no launch to ride on)
   return composite_shade_fwd_impl(false, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
-                                  rgb, img, wsum, stream, nullptr, nullptr, grad_zero, grad_zero_n);
+                                  rgb, img, wsum, stream, nullptr, nullptr, bwd_acc, bwd_acc_bytes);
 }
 
 // The same two for the general path: records = the packed (mu, A) [B*N][12] of voge_trace_lean_fwd.

@@ -85,17 +85,6 @@ struct FragBwdLds {
 #ifndef VOGE_FB_WPE
 #define VOGE_FB_WPE 4      // capping the registers for 5 / 6 waves per SIMD spills and is slower
 #endif
-// Round 6: where a wave's table goes when the CALLER's gradient arrays take it directly (scalar sigmas, shade form): no
-// acc [P][8], no fill in front of the kernel, no finishing pass behind it -- the arrays must arrive zeroed (the frame's
-// forward does that on its way: voge_frame_shade_fwd_iso) and every flush adds the chain rule's factor itself:
-//   g_verts[n]   += g_mu                       (n = id mod N for a Gaussian set shared by the views, else id)
-//   g_sigmas[n]  += g_a * d a / d sigma        (a = sigma: 1; a = 2 sigma: 2; a = 2 / sigma: -2 / sigma^2)
-//   g_colors[id] += w g_rgb                    (id < Nattr)
-struct FbDirect {
-  float *g_verts, *g_sigmas, *g_colors;      // g_verts == NULL: not this form (acc + finish)
-  const float *sigmas;                        // the user's sigmas (mode 2 only)
-  int N, shared, mode;
-};
 // SRC: where the gradient of the weights comes from.
 //   0: the shade stage is part of the pass (colours, rgb, wsum, bg, g_img given): g_w = <g_rgb, colour> + g_sum_w, and the
 //      colours' own gradient w g_rgb rides in the table (C: colour channels, 1..4);
@@ -120,24 +109,14 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
                         const float *__restrict__ bg, const float thr, const float *__restrict__ g_img, const long gs_pix,
                         const long gs_c, const float *__restrict__ g_hitlen, const float occ,
                         const int P, const long nrows, const int W, const int K, const long Nattr,
-                        float *__restrict__ acc /* [P][NACC], zeroed */, const FbDirect dir) {
+                        float *__restrict__ acc /* [P][NACC], zeroed */) {
   static_assert(NS == 2 || NS == 4, "a lane owns one or two aligned pairs of slots");
   constexpr int NV4 = SRC == 0 ? (ISO ? 2 : 4) : (ISO ? 1 : 3), NACC = 4 * NV4;
-  // sum c (0 .. NACC - 1) of Gaussian `key`: into acc, or (FbDirect) straight into the caller's gradient arrays
-  const bool direct = SRC == 0 && ISO && dir.g_verts != nullptr;      // (uniform)
-  auto sum_add = [&](const int key, const int c, float v) {
-    if (!direct) { unsafeAtomicAdd(acc + NACC * (size_t)key + c, v); return; }
-    const int n = dir.shared ? key % dir.N : key;
-    if (c < 3) {
-      unsafeAtomicAdd(dir.g_verts + 3 * (size_t)n + c, v);
-    } else if (c == 3) {
-      if (dir.mode == 1) v = 2.0f * v;
-      else if (dir.mode == 2) { const float sg = dir.sigmas[n]; v = -2.0f * v / (sg * sg); }
-      unsafeAtomicAdd(dir.g_sigmas + n, v);
-    } else if (c - 4 < C && key < Nattr && dir.g_colors != nullptr) {
-      unsafeAtomicAdd(dir.g_colors + (size_t)C * key + (c - 4), v);
-    }
-  };
+  // sum c (0 .. NACC - 1) of Gaussian `key`.  (Round 6 tried adding the table straight into the caller's gradient arrays --
+  // g_verts [N][3], g_sigmas [N], g_colors [N][C], zeroed by the forward -- instead of acc [P][8] + a finishing pass: one launch
+  // less, and the kernel went from 107 to 137 us.  An entry's eight sums are ONE 32-byte atomic request here and three requests
+  // into three arrays there; the kernel's tail is bound by those requests.  acc stays; the forward zeroes it on its way.)
+  auto sum_add = [&](const int key, const int c, const float v) { unsafeAtomicAdd(acc + NACC * (size_t)key + c, v); };
   __shared__ __attribute__((aligned(16))) FragBwdLds<NV4, NS> L;
   float *const Llen = L.len, *const Lsp = L.sp, *const LE = L.E, *const Lu = L.u;
 #if VOGE_BWD_RCOL
@@ -682,7 +661,6 @@ namespace {
 struct FbArgs {      // what every form of the fused backward hands its kernel
   const float4 *rec; const float *rays, *colors; const int32_t *idx, *cnt; const float *weight, *act, *len, *dsd, *rgb, *wsum, *bg;
   float thr; const float *g; long gs_pix, gs_c; const float *g_hitlen; float occ; int P; long nrows; int W, K; long Nattr; float *acc;
-  FbDirect dir = FbDirect{nullptr, nullptr, nullptr, nullptr, 1, 0, 0};
 };
 template <int SRC, int C, int NS, typename OffT, bool ISO, bool NOAD>
 void fb_launch(const FbArgs &a, hipStream_t st) {
@@ -692,7 +670,7 @@ void fb_launch(const FbArgs &a, hipStream_t st) {
   const float *colors = (a.Nattr > 0 && a.colors != nullptr) ? a.colors : reinterpret_cast<const float *>(a.rec);
   hipLaunchKernelGGL((fragment_bwd_kernel<SRC, C, NS, OffT, ISO, NOAD>), dim3((unsigned)blocks), dim3(64), 0, st, a.rec, a.rays,
                      colors, a.idx, a.cnt, a.weight, a.act, a.len, a.dsd, a.rgb, a.wsum, a.bg, a.thr, a.g, a.gs_pix, a.gs_c,
-                     a.g_hitlen, a.occ, a.P, a.nrows, a.W, a.K, a.Nattr, a.acc, a.dir);
+                     a.g_hitlen, a.occ, a.P, a.nrows, a.W, a.K, a.Nattr, a.acc);
 }
 template <int SRC, int C, int NS, bool ISO>
 void fb_launch_off(const FbArgs &a, hipStream_t st) {
@@ -748,29 +726,59 @@ extern "C" int voge_fragment_shade_bwd_iso(const float *records, const float *si
   return launch_status();
 }
 
-// Round 6, the frame's backward as ONE launch: voge_fragment_shade_bwd_iso whose waves add their tables straight into the
-// caller's gradient arrays (FbDirect) -- no scratch, no fill, no finishing pass.  g_verts [N | B*N, 3], g_sigmas [N | B*N],
-// g_colors [Nattr, C] must be ZERO on entry (voge_frame_shade_fwd_iso's grad_zero range, or the caller's own fill); the
-// call accumulates.  act / dsd are not kept by the frame's forward and are re-derived from the records.
-extern "C" int voge_frame_shade_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
-                                        const float *rays, const float *colors, const int32_t *idx, const int32_t *cnt,
-                                        const float *weight, const float *len, const float *rgb, const float *wsum,
-                                        const float *bg, float thr, const float *g_img, long g_stride_pix, long g_stride_c,
-                                        float occ, int B, int N, long nrows, int W, int K, int C, long Nattr, float *g_verts,
-                                        float *g_sigmas, float *g_colors, voge_stream_t stream) {
+// Round 6, the frame's backward: voge_fragment_shade_bwd_iso / voge_fragment_merge_bwd_iso WITHOUT the fill launch in front --
+// `acc` (voge_frame_bwd_acc_bytes(B * N) bytes) arrives zeroed: the frame's forward does that on its way
+// (voge_frame_shade_fwd_iso's bwd_acc), and it is good for ONE backward.  The fused kernel + the finishing pass.
+extern "C" size_t voge_frame_bwd_acc_bytes(int P) { return P <= 0 ? 0 : (size_t)P * 32; }
+
+static int frame_bwd_impl(const bool merge, const float *records, const float *sigmas, int shared, int sigma_mode, const float *rays,
+                          const float *colors, const int32_t *idx, const int32_t *cnt, const float *weight, const float *len,
+                          const float *rgb, const float *wsum, const float *bg, float thr, const float *g, long g_stride_pix,
+                          long g_stride_c, float occ, int B, int N, long nrows, int W, int K, int C, long Nattr, void *acc_zeroed,
+                          size_t acc_bytes, float *g_verts, float *g_sigmas, float *g_colors, voge_stream_t stream) {
   if (B < 0 || N < 0 || nrows < 0 || W < 0 || K <= 0 || C <= 0 || C > 4 || Nattr < 0 || sigma_mode < 0 || sigma_mode > 2)
     return VOGE_ERR_BAD_ARG;
   if (K > 128) return VOGE_ERR_K_TOO_LARGE;
   const int P = B * N;
-  if (P == 0 || nrows * W == 0) return 0;      // (nothing to add to the zeroed arrays)
-  if (!records || !rays || !colors || !idx || !cnt || !weight || !len || !rgb || !wsum || !bg || !g_img) return VOGE_ERR_BAD_ARG;
-  if (!g_verts || !g_sigmas || (sigma_mode == 2 && !sigmas)) return VOGE_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 0 || nrows * W == 0) {
+    if (g_colors && Nattr > 0) return (int)voge_fill_async(g_colors, 0, sizeof(float) * (size_t)Nattr * C, st);
+    return 0;
+  }
+  if (!records || !rays || !colors || !idx || !cnt || !weight || !len || !g || !acc_zeroed) return VOGE_ERR_BAD_ARG;
+  if (!merge && (!rgb || !wsum || !bg)) return VOGE_ERR_BAD_ARG;
+  if ((g_verts == nullptr) != (g_sigmas == nullptr) || (sigma_mode == 2 && g_sigmas && !sigmas)) return VOGE_ERR_BAD_ARG;
+  if (acc_bytes < voge_frame_bwd_acc_bytes(P)) return VOGE_ERR_WORKSPACE;
   if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
-  FbArgs a{reinterpret_cast<const float4 *>(records), rays, colors, idx, cnt, weight, nullptr, len, nullptr, rgb, wsum, bg, thr, g_img,
-           g_stride_pix, g_stride_c, nullptr, occ, P, nrows, W, K, Nattr, nullptr};
-  a.dir = FbDirect{g_verts, g_sigmas, g_colors, sigmas, N > 0 ? N : 1, shared ? 1 : 0, sigma_mode};
-  fb_launch_shade<true>(a, C, (hipStream_t)stream);
+  float *acc = reinterpret_cast<float *>(acc_zeroed);
+  // (merge form: bg = NULL selects it inside the kernel; its `wsum` operand carries g_wsum)
+  const FbArgs a{reinterpret_cast<const float4 *>(records), rays, colors, idx, cnt, weight, nullptr, len, nullptr, merge ? nullptr : rgb, wsum,
+                 merge ? nullptr : bg, merge ? -1.0f : thr, g, g_stride_pix, g_stride_c, nullptr, occ, P, nrows, W, K, Nattr, acc};
+  fb_launch_shade<true>(a, C, st);
+  const long n_fin = (Nattr > P) ? Nattr : P;
+  hipLaunchKernelGGL(fragment_bwd_finish_kernel, dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, st, acc, 8, sigmas, P, N, B,
+                     IsoView{nullptr, shared ? 1 : 0, sigma_mode}, C, Nattr, g_verts, g_sigmas, g_colors);
   return launch_status();
+}
+
+extern "C" int voge_frame_shade_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
+                                        const float *rays, const float *colors, const int32_t *idx, const int32_t *cnt,
+                                        const float *weight, const float *len, const float *rgb, const float *wsum,
+                                        const float *bg, float thr, const float *g_img, long g_stride_pix, long g_stride_c,
+                                        float occ, int B, int N, long nrows, int W, int K, int C, long Nattr, void *acc_zeroed,
+                                        size_t acc_bytes, float *g_verts, float *g_sigmas, float *g_colors, voge_stream_t stream) {
+  return frame_bwd_impl(false, records, sigmas, shared, sigma_mode, rays, colors, idx, cnt, weight, len, rgb, wsum, bg, thr, g_img,
+                        g_stride_pix, g_stride_c, occ, B, N, nrows, W, K, C, Nattr, acc_zeroed, acc_bytes, g_verts, g_sigmas, g_colors, stream);
+}
+
+extern "C" int voge_frame_merge_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
+                                        const float *rays, const float *attr, const int32_t *idx, const int32_t *cnt,
+                                        const float *weight, const float *len, const float *g_rgb, long g_stride_pix,
+                                        long g_stride_c, const float *g_wsum, float occ, int B, int N, long nrows, int W, int K,
+                                        int C, long Nattr, void *acc_zeroed, size_t acc_bytes, float *g_verts, float *g_sigmas,
+                                        float *g_attr, voge_stream_t stream) {
+  return frame_bwd_impl(true, records, sigmas, shared, sigma_mode, rays, attr, idx, cnt, weight, len, nullptr, g_wsum, nullptr, -1.0f, g_rgb,
+                        g_stride_pix, g_stride_c, occ, B, N, nrows, W, K, C, Nattr, acc_zeroed, acc_bytes, g_verts, g_sigmas, g_attr, stream);
 }
 
 extern "C" int voge_fragment_shade_bwd(const float *mus, const float *isigmas, const float *rays, const float *colors,

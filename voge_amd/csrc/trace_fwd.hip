@@ -1097,6 +1097,16 @@ static size_t trace_pool_entries(const size_t P) {
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// The list pool's counters: one per chunk of the batch an entry point walks (chunk c uses slot min(c, kPoolSlots - 1)), in the
+// LAST kPoolTail bytes of the scratch the caller handed over -- the same addresses whatever a chunk's view count, so that
+// voge_trace_pool_usage finds every chunk's counter behind the call, and out of the way of a caller who lets later, smaller
+// entry points reuse the buffer's head (voge_amd.ops._workspace does: at the head of the scratch the fused backward's
+// records overwrote them).
+constexpr int kPoolSlots = 64;
+constexpr size_t kPoolTail = 512;
+static unsigned long long *trace_pool_slots(void *workspace, const size_t workspace_bytes) {
+  return reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(workspace) + ((workspace_bytes - kPoolTail) & ~(size_t)255));
+}
 
 static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *ws) {
   const size_t P = (size_t)B * N;
@@ -1112,7 +1122,7 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
        *ti = take(ntile * kTileCap * 4), *tl = take(ntile * kTileCap * 4), *sr = take(nbin * kParts * (size_t)kSegCap * 16),
        *cq = take(nbin * kTilesPerBin * 8 * 2);      // (second half: the exactly sorted copy of VOGE_EXACT_ORDER builds)
   const size_t npool = trace_pool_entries(P);
-  char *pt = take(8), *pi = take(npool * 4), *pl = take(npool * 4), *to = take(ntile * 4);
+  char *pi = take(npool * 4), *pl = take(npool * 4), *to = take(ntile * 4);
   const int nst0x = (W + kST0 - 1) / kST0, nst0y = (H + kST0 - 1) / kST0;
   size_t arena = (size_t)kExtMul * slice_cap(N);
   // (seg_ext holds 32-bit offsets into ext_id: a batch so large that the extensions would pass 2^31 ids goes without them
@@ -1121,7 +1131,7 @@ static size_t trace_ws_layout(int B, int N, int H, int W, void *base, TraceWs *w
   char *se = take(nbin * kParts * kExtChunks * 4), *ei = take((size_t)B * nst0x * nst0y * kParts * arena * 4);
   if (ws) {
     ws->seg_ext = reinterpret_cast<int *>(se); ws->ext_id = reinterpret_cast<int32_t *>(ei); ws->ext_arena = (int)arena;
-    ws->pool_top = reinterpret_cast<unsigned long long *>(pt); ws->pool_id = reinterpret_cast<int32_t *>(pi);
+    ws->pool_top = nullptr /* (trace_pool_slots: the scratch's tail) */; ws->pool_id = reinterpret_cast<int32_t *>(pi);
     ws->pool_lb = reinterpret_cast<float *>(pl); ws->tl_off = reinterpret_cast<int *>(to);
     ws->pool_cap = (int)npool;
     ws->cull = reinterpret_cast<float4 *>(c); ws->evr = reinterpret_cast<float4 *>(e);
@@ -1293,26 +1303,42 @@ extern "C" int voge_debug_sweep_variant(int variant) {
 // size asked for here is what the largest chunk under kTraceWsCap needs (never less than one view).  A caller that wants a
 // big batch in ONE chunk passes more: any size >= this is accepted and used.
 constexpr size_t kTraceWsCap = (size_t)1 << 30;
+static size_t trace_ws_bytes(const int nb, const int N, const int H, const int W) {      // a chunk's arrays + the counters' tail
+  return trace_ws_layout(nb, N, H, W, nullptr, nullptr) + 256 + kPoolTail;
+}
 static int trace_views_that_fit(const int B, const int N, const int H, const int W, const size_t bytes) {
   int nb = 1;      // (layout is monotone in the view count: the largest nb whose layout fits)
   for (int step = B; step >= 1; step >>= 1)
-    while (nb + step <= B && trace_ws_layout(nb + step, N, H, W, nullptr, nullptr) <= bytes) nb += step;
+    while (nb + step <= B && trace_ws_bytes(nb + step, N, H, W) <= bytes) nb += step;
   return nb;
 }
 extern "C" size_t voge_trace_workspace_bytes(int B, int N, int H, int W) {
   if (B <= 0 || N < 0 || H <= 0 || W <= 0) return 0;
-  return trace_ws_layout(trace_views_that_fit(B, N, H, W, kTraceWsCap), N, H, W, nullptr, nullptr);
+  return trace_ws_bytes(trace_views_that_fit(B, N, H, W, kTraceWsCap), N, H, W);
 }
 
-extern "C" int voge_trace_pool_usage(const void *workspace, int B, int N, int H, int W, int *used, int *capacity) {
+extern "C" int voge_trace_pool_usage(const void *workspace, size_t workspace_bytes, int B, int N, int H, int W, int *used,
+                                     int *capacity) {
   if (!workspace || !used || !capacity || B <= 0 || N < 0 || H <= 0 || W <= 0) return VOGE_ERR_BAD_ARG;
-  TraceWs ws;      // (the pool of the LAST chunk the entry point walked: chunks share the scratch)
-  trace_ws_layout(trace_views_that_fit(B, N, H, W, kTraceWsCap), N, H, W, const_cast<void *>(workspace), &ws);
-  *capacity = ws.pool_cap;
+  if (workspace_bytes < trace_ws_bytes(1, N, H, W)) return VOGE_ERR_WORKSPACE;
+  // the chunks the entry point walked with THIS scratch (the same rule: trace_topk_fwd_impl), each with a counter of its own in
+  // the scratch's tail; reported: the largest use of any chunk, against the smallest capacity
+  const int per = trace_views_that_fit(B, N, H, W, workspace_bytes);
+  const int nchunks = (B + per - 1) / per;
+  unsigned long long tops[kPoolSlots];
+  const hipError_t e = hipMemcpy(tops, trace_pool_slots(const_cast<void *>(workspace), workspace_bytes), sizeof(tops), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return (int)e;
   unsigned long long top = 0ull;
-  const hipError_t e = hipMemcpy(&top, ws.pool_top, sizeof(top), hipMemcpyDeviceToHost);
+  for (int c = 0; c < nchunks && c < kPoolSlots; ++c) top = tops[c] > top ? tops[c] : top;
+  TraceWs ws;
+  trace_ws_layout(per, N, H, W, const_cast<void *>(workspace), &ws);
+  *capacity = ws.pool_cap;
+  if (nchunks > 1 && B % per != 0) {      // (the last, shorter chunk: its pool is sized for its own Gaussians)
+    trace_ws_layout(B % per, N, H, W, const_cast<void *>(workspace), &ws);
+    *capacity = ws.pool_cap < *capacity ? ws.pool_cap : *capacity;
+  }
   *used = top > 0x7fffffffull ? 0x7fffffff : (int)top;
-  return (int)e;
+  return 0;
 }
 
 extern "C" int voge_ray_cones(const float *rays, int B, int H, int W, float *cones, voge_stream_t stream);   // rays.hip
@@ -1338,7 +1364,8 @@ __global__ void __launch_bounds__(256) idx_rebase1_kernel(int32_t *__restrict__ 
 static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mus, const float *isigmas, const float *rays,
                            const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
                            float thr_act, void *workspace, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
-                           voge_stream_t stream, float occ, float *weight, int64_t *valid_num, float *records, const CamView &cam);
+                           voge_stream_t stream, float occ, float *weight, int64_t *valid_num, float *records, const CamView &cam,
+                           unsigned long long *pool_top);
 
 static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float *mus, const float *isigmas, const float *rays,
                                const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
@@ -1367,7 +1394,7 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
     return VOGE_ERR_BAD_ARG;
   if (N > 0 && (!mus || !isigmas)) return VOGE_ERR_BAD_ARG;
   // (one view's scratch is the least that works; voge_trace_workspace_bytes(B, ...) is what to allocate)
-  if (workspace_bytes < trace_ws_layout(1, N, H, W, nullptr, nullptr)) return VOGE_ERR_WORKSPACE;
+  if (workspace_bytes < trace_ws_bytes(1, N, H, W)) return VOGE_ERR_WORKSPACE;
   // the top-K lists of one 8x8 tile must fit the CU's LDS: validated before anything is enqueued
   if (sizeof(uint64_t) * (size_t)(K + 1) * 65 + 16 + sizeof(TraceLds<64, false>) > 160 * 1024) return VOGE_ERR_K_TOO_LARGE;
   // ---- the batch in chunks of as many views as the scratch holds (all of them, when it was sized for that): every array the
@@ -1389,7 +1416,8 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
     const int rc = trace_chunk_fwd(iso_in, v, at(mus, stride_mu), at(isigmas, stride_sg), at(rays, npv * 3), at(cam_fwd, 3),
                                    at(cones_in, nst * kConeRecsPerST * (sizeof(ConeRec) / sizeof(float))), nb, N, H, W, K, thr_act, workspace,
                                    at(idx, npv * K), at(len, npv * K), at(act, npv * K), at(dsd, npv * K), at(cnt, npv), stream, occ,
-                                   at(weight, npv * K), at(valid_num, npv), at(records, (size_t)N * (iso_in ? 4 : 12)), cv);
+                                   at(weight, npv * K), at(valid_num, npv), at(records, (size_t)N * (iso_in ? 4 : 12)), cv,
+                                   trace_pool_slots(workspace, workspace_bytes) + ((b0 / per) < kPoolSlots ? (b0 / per) : kPoolSlots - 1));
     if (rc) return rc;
     if (b0 > 0 && N > 0) {
       const size_t n = (size_t)nb * npv * K;
@@ -1412,11 +1440,13 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
 static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mus, const float *isigmas, const float *rays,
                            const float *cam_fwd, const float *cones_in, int B, int N, int H, int W, int K,
                            float thr_act, void *workspace, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt,
-                           voge_stream_t stream, float occ, float *weight, int64_t *valid_num, float *records, const CamView &cam) {
+                           voge_stream_t stream, float occ, float *weight, int64_t *valid_num, float *records, const CamView &cam,
+                           unsigned long long *pool_top) {
   hipStream_t st = (hipStream_t)stream;
   const int P = B * N;
   TraceWs ws;
   trace_ws_layout(B, N, H, W, workspace, &ws);
+  ws.pool_top = pool_top;      // (this chunk's own counter, in the scratch's tail: voge_trace_pool_usage)
   if (records != nullptr && iso_in) ws.ms = reinterpret_cast<float4 *>(records);      // the caller keeps the (centre, a) records (backward)
   // super-tile cones: the caller's (voge_rays_fwd makes them while it makes the rays), or one more launch here
   const ConeRec *cones = reinterpret_cast<const ConeRec *>(cones_in);
@@ -1587,8 +1617,8 @@ extern "C" int voge_frame_trace_fwd_iso(const float *verts, const float *sigmas,
                                         int behind, int B, int N, int h, int W, int K, float thr_act, void *workspace,
                                         size_t workspace_bytes, int32_t *idx, float *len, int32_t *cnt, float *records,
                                         float *rays, float *origin, voge_stream_t stream) {
-  if (sigma_mode < 0 || sigma_mode > 2 || !cnt || !records || !R || !T || !focal || !pp || stripe_h <= 0 || pitch < 0 || !origin)
-    return VOGE_ERR_BAD_ARG;
+  if (sigma_mode < 0 || sigma_mode > 2 || !cnt || !records || !R || !T || !focal || !pp || stripe_h <= 0 || pitch < 0)
+    return VOGE_ERR_BAD_ARG;      // (origin may be NULL: nobody on the frame's path reads it)
   if ((size_t)B * h * W > 0 && !rays) return VOGE_ERR_BAD_ARG;
   const CamView cam{R, T, focal, pp, row0, stripe_h, pitch, h, W, behind ? 1 : 0, origin, rays};
   return trace_topk_fwd_impl(1, IsoView{nullptr, shared ? 1 : 0, sigma_mode}, verts, sigmas, nullptr, nullptr, nullptr, B, N, h, W, K,

@@ -500,8 +500,12 @@ __device__ __forceinline__ CamK cam_load(const CamView &c, const int b) {
   return k;
 }
 __device__ __forceinline__ int cam_irow(const CamView &c, const int i) {
-  const int k = i / c.stripe_h;
-  return c.row0 + k * c.pitch + (i - k * c.stripe_h);
+  if (i < c.stripe_h) return c.row0 + i;      // (a contiguous band is one stripe: no division on the frame's path)
+  // i / stripe_h by a float reciprocal, corrected: exact for any sizes an image has (i < 2^22)
+  int k = __float2int_rz(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)c.stripe_h));
+  int r = i - k * c.stripe_h;
+  if (r < 0) { --k; r += c.stripe_h; } else if (r >= c.stripe_h) { ++k; r -= c.stripe_h; }
+  return c.row0 + k * c.pitch + r;
 }
 // unit world-space direction of image pixel (row ir, column j): Renderer.py:124-128's bundle (rays.hip's header)
 __device__ __forceinline__ void cam_ray(const CamK &k, const int ir, const int j, float &x, float &y, float &z) {
@@ -729,24 +733,28 @@ __device__ __forceinline__ ConeRec cam_rect_cone(const CamK &k, const CamView &c
   if (j0 >= c.W || i0 >= c.h || j1 < j0 || i1 < i0) return ConeRec{0.f, 0.f, 1.f, 1.f, 0.f, -1.f, 0.f, 0.f};
   j1 = min(j1, c.W - 1); i1 = min(i1, c.h - 1);
   const int r0 = cam_irow(c, i0), r1 = cam_irow(c, i1);
-  float cx[4], cy[4], cz[4];
-  cam_ray(k, r0, j0, cx[0], cy[0], cz[0]); cam_ray(k, r0, j1, cx[1], cy[1], cz[1]);
-  cam_ray(k, r1, j0, cx[2], cy[2], cz[2]); cam_ray(k, r1, j1, cx[3], cy[3], cz[3]);
-  RayDir u[4];
-  bool all_ok = true;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
+  // (the corner rays are unit to an ulp already -- cam_ray normalises with v_rsq -- and hardware sqrt / rsq serve below: every
+  //  bound is padded by far more.  As first written -- ray_dir's IEEE 1 / sqrt per corner, IEEE sqrt per extremum, integer
+  //  divisions for the rows -- the two cones cost binB's workgroups ~750 instructions per thread in front of their first load:
+  //  binB + 3.6 us, more than half of what the ray launch had cost.)
+  float ux[4], uy[4], uz[4];
+  cam_ray(k, r0, j0, ux[0], uy[0], uz[0]); cam_ray(k, r0, j1, ux[1], uy[1], uz[1]);
+  cam_ray(k, r1, j0, ux[2], uy[2], uz[2]); cam_ray(k, r1, j1, ux[3], uy[3], uz[3]);
+  const float sx = (ux[0] + ux[1]) + (ux[2] + ux[3]), sy = (uy[0] + uy[1]) + (uy[2] + uy[3]), sz = (uz[0] + uz[1]) + (uz[2] + uz[3]);
+  const float n2 = fmaf(sz, sz, fmaf(sy, sy, sx * sx));
+  const float rn = __builtin_amdgcn_rsqf(n2);
+  const float ax = sx * rn, ay = sy * rn, az = sz * rn;
+  float s2max = 0.f, cmin = 1.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    u[q] = ray_dir(cx[q], cy[q], cz[q]);
-    all_ok = all_ok && u[q].ok;
-    sx += u[q].ok ? u[q].ux : 0.f; sy += u[q].ok ? u[q].uy : 0.f; sz += u[q].ok ? u[q].uz : 0.f;
+    const float cl = fmaf(uz[q], az, fmaf(uy[q], ay, ux[q] * ax));
+    const float qx = fmaf(-cl, ax, ux[q]), qy = fmaf(-cl, ay, uy[q]), qz = fmaf(-cl, az, uz[q]);
+    s2max = fmaxf(s2max, fmaf(qz, qz, fmaf(qy, qy, qx * qx)));
+    cmin = fminf(cmin, cl);
   }
-  const float n = sqrtf(fmaf(sz, sz, fmaf(sy, sy, sx * sx)));
-  const float ax = sx / n, ay = sy / n, az = sz / n;
-  float smax = 0.f, cmin = 1.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) cone_partial(u[q], ax, ay, az, smax, cmin);
-  const Cone cn = cone_finish(ax, ay, az, n * 0.25f, smax * (1.0f + 4e-7f) + 4e-7f, cmin - 4e-7f, all_ok);
+  const bool fin = n2 > 1e-30f && n2 < 1e30f;      // (NaN / inf corners: a degenerate camera -- nothing may be culled)
+  // margins: the corners' |u| = 1 +- 1e-7 (2e-7 on sin and cos), v_sqrt's ulp, the axis' own normalisation -- 1e-6 covers them
+  const Cone cn = cone_finish(ax, ay, az, n2 * rn * 0.25f, __builtin_amdgcn_sqrtf(s2max) * (1.0f + 1e-6f) + 1e-6f, cmin - 1e-6f, fin);
   return ConeRec{cn.ax, cn.ay, cn.az, cn.cs, cn.sn, cn.ok ? 1.f : 0.f, 0.f, 0.f};
 }
 

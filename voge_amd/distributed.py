@@ -323,14 +323,19 @@ def _stripe_index(H, world, stripe_h, device):
     return hit
 
 
-_STRIPE_CHECKED = set()
+_STRIPE_CHECKS = {}      # id(group) -> calls of _check_stripe_layout that ran the collective check so far
+_STRIPE_CHECK_CALLS = 4  # ... which the first few calls on a group do UNCONDITIONALLY
 
 
 def _check_stripe_layout(band, H, stripe_h, group):
     """Every rank derives the padded layout and the row permutation of the gather LOCALLY from (H, world, stripe_h): a rank
     that disagrees on any of them -- or on the band's trailing shape -- would scramble the frame silently or hang the
     collective.  Checked here: locally on every call (this rank's rows; every rank owns at least one stripe), and across
-    the ranks ONCE per layout with one small all_gather of (H, stripe_h, B, W, C) (VOGE_DIST_CHECK=0 turns that off)."""
+    the ranks with one small all_gather of (H, stripe_h, B, W, C) on the FIRST FEW CALLS on a group (VOGE_DIST_CHECK=0 turns
+    that off -- on every rank or on none).  Whether the extra collective is issued depends on the group's call count alone,
+    never on the values being checked: ranks that disagree still enter the same collectives in the same order and get the
+    assertion instead of a hang (a per-rank cache keyed by the layout let a disagreeing rank skip it).  Inside a
+    stream capture nothing is checked (the comparison reads the result back)."""
     import os
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     B, h, W, C = band.shape
@@ -339,15 +344,17 @@ def _check_stripe_layout(band, H, stripe_h, group):
     last = Stripes(H, world - 1, world, stripe_h)
     assert last.h >= 1, (f"stripes of {stripe_h} rows leave rank {world - 1} of {world} without a row of an {H}-row frame: "
                          f"use distributed.stripe_height(H, world) = {stripe_height(H, world, stripe_h)}")
-    key = (int(H), int(stripe_h), int(B), int(W), int(C), world, id(group))
-    if key in _STRIPE_CHECKED or os.environ.get("VOGE_DIST_CHECK", "1") == "0":
+    done = _STRIPE_CHECKS.get(id(group), 0)
+    if done >= _STRIPE_CHECK_CALLS or os.environ.get("VOGE_DIST_CHECK", "1") == "0":
         return
-    me = torch.tensor(key[:5], dtype=torch.int64, device=band.device)
+    if band.is_cuda and torch.cuda.is_current_stream_capturing():
+        return
+    _STRIPE_CHECKS[id(group)] = done + 1
+    me = torch.tensor((int(H), int(stripe_h), int(B), int(W), int(C)), dtype=torch.int64, device=band.device)
     every = me.new_empty(world * 5)      # (the concatenated form: gloo takes no other)
     dist.all_gather_into_tensor(every, me, group=group)
     every = every.view(world, 5)
     assert bool((every == me[None]).all()), f"ranks disagree on (H, stripe_h, B, W, C): {every.tolist()}"
-    _STRIPE_CHECKED.add(key)
 
 
 def _gather_stripes(band, H, stripe_h, group, async_op=False):

@@ -160,7 +160,7 @@ def trace_pool_usage(dev, B, N, H, W):
         ws = _workspace(dev, nbytes)
         used, cap = ctypes.c_int(0), ctypes.c_int(0)
         torch.cuda.current_stream(dev).synchronize()
-        _lib.check(lib.voge_trace_pool_usage(_p(ws), B, N, H, W, ctypes.byref(used), ctypes.byref(cap)), "voge_trace_pool_usage")
+        _lib.check(lib.voge_trace_pool_usage(_p(ws), nbytes, B, N, H, W, ctypes.byref(used), ctypes.byref(cap)), "voge_trace_pool_usage")
     return used.value, cap.value
 
 
@@ -754,15 +754,135 @@ class _TraceLean(torch.autograd.Function):
         return None, g0, g1, None, None, None, None, None, None
 
 
+def _plain(t_, dtype, name):
+    """_dev for an input the call only READS through its pointer: no torch op may see it (a `.contiguous()` on a parameter would
+    put a node into the graph of a call that has none)."""
+    if not t_.is_cuda:
+        raise _lib.VogeHipError(f"{name} is on {t_.device}: the VoGE hot path runs on a HIP device only (no CPU fallback)")
+    if t_.dtype != dtype or not t_.is_contiguous():
+        t_ = t_.detach().to(dtype).contiguous()
+    return t_
+
+
+def frame_trace(verts, sigmas, R, T, focal, pp, band, W, behind, thr_act, n_assign, sigma_mode, occ, origin_out=None):
+    """Round 6: the renderer's forward up to the sweep with the CAMERA as input (voge_frame_trace_fwd_iso): no ray-generation
+    launch and no autograd node at all -- the trace's three kernels make rays, cones, camera centre and view axis from
+    (R, T, focal, pp) themselves, with the ray kernel's own operations, and the sweep leaves the bundle behind for the composite
+    and the backward.  verts [N,3] | [B,N,3], sigmas [N] | [B,N], R [B,3,3], T [B,3], focal [B,2], pp [B,2], band = (row0, h,
+    stripe_h, pitch).  Fixed cameras only (callers that optimise the camera take pixel_rays + the rays-taking entries).
+    origin_out: None | a contiguous fp32 [B,3] tensor that receives the camera centres.
+    -> (sel_idx, sel_len, LazyComposite): sel_len carries NO grad_fn here; whoever reads Fragments.vert_hit_length gets a
+    differentiable alias on demand (LazyComposite.hit_length, _HitLength) -- the weights' consumers never pay for that node."""
+    lib = _lib.load()
+    v_c, s_c = _plain(verts, torch.float32, "verts"), _plain(sigmas, torch.float32, "sigmas")
+    R_c, T_c = _plain(R, torch.float32, "R"), _plain(T, torch.float32, "T")
+    f_c, p_c = _plain(focal, torch.float32, "focal_length"), _plain(pp, torch.float32, "principal_point")
+    B = R_c.shape[0]
+    row0, h, stripe_h, pitch = band
+    shared = v_c.dim() == 2
+    assert R_c.shape == (B, 3, 3) and T_c.shape == (B, 3) and f_c.shape == (B, 2) and p_c.shape == (B, 2)
+    assert v_c.shape[-1] == 3 and (shared or v_c.shape[0] == B) and s_c.shape == v_c.shape[:-1]
+    N, K, dev = v_c.shape[-2], int(n_assign), v_c.device
+    empty = torch.empty
+    sel_idx = empty((B, h, W, K), dtype=torch.int32, device=dev)
+    sel_len = empty((B, h, W, K), dtype=torch.float32, device=dev)
+    cnt = empty((B, h, W), dtype=torch.int32, device=dev)
+    records = empty((B * N, 4), dtype=torch.float32, device=dev)
+    rays = empty((B, h, W, 3), dtype=torch.float32, device=dev)
+    with _on(dev):
+        nbytes = lib.voge_trace_workspace_bytes(B, N, h, W)
+        ws = _workspace(dev, nbytes)
+        rc = lib.voge_frame_trace_fwd_iso(v_c.data_ptr(), s_c.data_ptr(), int(shared), int(sigma_mode), R_c.data_ptr(), T_c.data_ptr(),
+                                          f_c.data_ptr(), p_c.data_ptr(), int(row0), int(stripe_h), int(pitch), int(bool(behind)), B, N,
+                                          int(h), int(W), K, float(thr_act), ws.data_ptr(), nbytes, sel_idx.data_ptr(),
+                                          sel_len.data_ptr(), cnt.data_ptr(), records.data_ptr(), rays.data_ptr(), _p(origin_out), _stream())
+    if rc:
+        _lib.check(rc, "voge_frame_trace_fwd_iso")
+    _tag_index(sel_idx, cnt, B * N)
+    lz = LazyComposite.__new__(LazyComposite)
+    (lz.mode, lz.sigma_mode, lz.shared, lz.occ, lz.B, lz.N, lz.K, lz.p0, lz.p1, lz.sel_idx, lz.sel_len, lz.cnt, lz.records, lz.rays,
+     lz.rays_version, lz.grad_mode, lz.idx_version, lz.p0_version, lz.frame, lz.hit_len) = (
+        2, int(sigma_mode), shared, float(occ), B, N, K, verts, sigmas, sel_idx, sel_len, cnt, records, rays, 0, torch.is_grad_enabled(),
+        sel_idx._version, verts._version, True, None)
+    return sel_idx, sel_len, lz
+
+
+class _HitLength(torch.autograd.Function):
+    """Fragments.vert_hit_length of the camera-input trace as a differentiable tensor (the reference's is: the trace's len itself,
+    Aggregation.py:107): forward(verts, sigmas, sel_len, lz) -> an alias of sel_len with this node behind it; backward: the
+    trace's chain rule for a gradient of len alone (voge_fragment_bwd_iso with g_weight = NULL), as _TraceLean.backward."""
+
+    @staticmethod
+    def forward(ctx, p0, p1, sel_len, lz):
+        ctx.lz = lz
+        ctx.save_for_backward(p1)
+        ctx.set_materialize_grads(False)
+        return sel_len.view_as(sel_len)
+
+    @staticmethod
+    def backward(ctx, g_len):
+        if g_len is None:
+            return None, None, None, None
+        lib = _lib.load()
+        lz = ctx.lz
+        lz.check()
+        (p1,) = ctx.saved_tensors
+        p1 = _dev(p1, torch.float32, "sigmas")
+        ln, sel_idx = lz.sel_len, lz.sel_idx
+        B, H, W, K = sel_idx.shape
+        gh = _dev(g_len, torch.float32, "grad_hit_length")
+        g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=ln.device)
+        g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=ln.device)
+        with _on(ln.device):
+            nbytes = lib.voge_fragment_bwd_workspace_bytes(lz.B * lz.N)
+            ws = _workspace(ln.device, nbytes)
+            rc = lib.voge_fragment_bwd_iso(_p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(sel_idx), _p(lz.cnt),
+                                           _p(ln), None, _p(ln), None, None, 0, 0, _p(gh), 1.0, lz.B, lz.N, B * H, W, K, _p(ws), nbytes,
+                                           _p(g0), _p(g1), _stream())
+        _lib.check(rc, "voge_fragment_bwd")
+        return g0, g1, None, None
+
+
+# VOGE_FRAME_PATH=0 (or ops.FRAME_PATH = False): the renderer generates its ray bundle with voge_rays_fwd and traces through the
+# rays-taking entries (round 5's chain); VOGE_FRAME_DIRECT_BWD=0: the frame's backward fills its accumulator itself.  Same results.
+FRAME_PATH = os.environ.get("VOGE_FRAME_PATH", "1") != "0"
+FRAME_DIRECT_BWD = os.environ.get("VOGE_FRAME_DIRECT_BWD", "1") != "0"
+
+
+def frame_eligible(verts, sigmas, R, T, focal, pp, n_assign, numel):
+    """The camera-input frame path: scalar sigmas on the device, fixed cameras, a non-empty band, 32-bit record offsets."""
+    if not (LAZY_COMPOSITE and FRAME_PATH) or n_assign > _lib.MAX_K or os.environ.get("VOGE_FRAGMENTS_KEEP_ACT_DSD", "0") == "1":
+        return False
+    if not (verts.is_cuda and sigmas.is_cuda and sigmas.dim() == verts.dim() - 1) or numel == 0 or verts.shape[-2] == 0:
+        return False
+    dev = verts.device
+    if R.device != dev or T.device != dev or focal.device != dev or pp.device != dev:      # (fixed cameras: cameras.camera_tensors)
+        return False
+    return R.shape[0] * verts.shape[-2] < (1 << 26)
+
+
 class LazyComposite:
     """What the deferred composite needs from a _TraceLean call (nothing in it has a grad_fn except sel_len, which the
     composite nodes take as an input)."""
     __slots__ = ("mode", "sigma_mode", "shared", "occ", "B", "N", "K", "p0", "p1", "sel_idx", "sel_len", "cnt", "records", "rays",
-                 "rays_version", "grad_mode", "idx_version", "p0_version")
+                 "rays_version", "grad_mode", "idx_version", "p0_version", "frame", "hit_len")
 
     def __init__(self, **kw):
+        self.frame = False      # (made by frame_trace: the shade stage may take the frame entries of ABI 7)
+        self.hit_len = None     # (frame_trace: the differentiable alias of sel_len, made when somebody asks for it)
         for k, v in kw.items():
             setattr(self, k, v)
+
+    def hit_length(self):
+        """Fragments.vert_hit_length: sel_len itself, or (frame_trace, whose sel_len has no grad_fn) its differentiable alias,
+        made on first request under the render call's autograd mode."""
+        if not self.frame:
+            return self.sel_len
+        # (NOT remembered here: the alias' grad_fn holds this object -- the Fragments that asked keeps what it gets)
+        if self.grad_mode and (self.p0.requires_grad or self.p1.requires_grad):
+            with torch.enable_grad():
+                return _HitLength.apply(self.p0, self.p1, self.sel_len, self)
+        return self.sel_len
 
     def means(self):
         """(general forms) the centres as the trace saw them: contiguous fp32, no grad_fn."""
@@ -792,16 +912,35 @@ class LazyComposite:
         return torch.set_grad_enabled(self.grad_mode)
 
     def through(self, weight):
-        """Tag freshly composited weights the way fragments() does (a later to_colored_background takes _ShadeThrough)."""
+        """Tag freshly composited weights the way fragments() does (a later to_colored_background takes _ShadeThrough).  The
+        bookkeeping is filled in when somebody first LOOKS at it (_Through): the frame that never does pays for no detach."""
         if (self.p0.requires_grad or self.p1.requires_grad) and self.grad_mode:
-            len_d = self.sel_len.detach()
-            act, dsd = getattr(weight, "voge_act_dsd", (None, None))      # (general forms: what the composite kept)
-            weight.voge_through = dict(
-                mode=self.mode, sigma_mode=self.sigma_mode, shared=self.shared, occ=self.occ, B=self.B, N=self.N,
-                records=self.records, rays=self.rays, act=act, dsd=dsd, len=len_d, cnt=self.cnt, idx=self.sel_idx,
-                sigmas=self.p1.detach(), means=self.p0.detach(), p0=self.p0, p1=self.p1, rays_requires_grad=False,
-                versions=(weight._version, len_d._version, self.rays._version, self.sel_idx._version))
+            weight.voge_through = _Through(self, weight)
         return weight
+
+
+class _Through(dict):
+    """The `voge_through` bookkeeping of deferred-composite weights (see fragments()), materialised on first lookup.  The version
+    counters are read when the object is made -- that is what "untouched since" refers to."""
+
+    def __init__(self, lz, weight):
+        dict.__init__(self)
+        self._src = (lz, weight, (weight._version, lz.sel_len._version, lz.rays._version, lz.sel_idx._version))
+
+    def _fill(self):
+        lz, weight, versions = self._src
+        self._src = None
+        len_d = lz.sel_len.detach()
+        act, dsd = getattr(weight, "voge_act_dsd", (None, None))      # (general forms: what the composite kept)
+        self.update(mode=lz.mode, sigma_mode=lz.sigma_mode, shared=lz.shared, occ=lz.occ, B=lz.B, N=lz.N, records=lz.records,
+                    rays=lz.rays, act=act, dsd=dsd, len=len_d, cnt=lz.cnt, idx=lz.sel_idx, sigmas=lz.p1.detach(), means=lz.p0.detach(),
+                    p0=lz.p0, p1=lz.p1, rays_requires_grad=False, versions=versions)
+
+    def __missing__(self, key):
+        if self._src is None:
+            raise KeyError(key)
+        self._fill()
+        return dict.__getitem__(self, key)
 
 
 def _general_act_dsd(lz, sel_len, need):
@@ -890,12 +1029,19 @@ class _CompositeShade(torch.autograd.Function):
         rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
         img = torch.empty_like(rgb)
         wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
+        # (round 6) fragments of the camera-input trace: the accumulator of the coming backward is allocated here and this launch
+        # zeroes it on its way -- no fill launch in front of that backward (voge_frame_shade_bwd_iso)
+        ctx.gbuf = None
+        if lz.frame and lz.mode != 0 and any(ctx.needs_input_grad[:3]) and K <= 128 and FRAME_DIRECT_BWD:
+            ctx.gbuf = torch.empty((lz.B * lz.N * 32,), dtype=torch.uint8, device=idx.device)
         with _on(idx.device):
             ctx.ad = _general_act_dsd(lz, sel_len, any(ctx.needs_input_grad))
             args = (_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c), _p(bg_c), float(thr),
                     idx.numel() // K, K, C, Nattr, _p(weight), _p(valid), _p(rgb), _p(img), _p(wsum))
             if lz.mode == 0:
                 rc = lib.voge_composite_shade_fwd_rec(*args, _p(ctx.ad[0]), _p(ctx.ad[1]), _stream())
+            elif ctx.gbuf is not None:
+                rc = lib.voge_frame_shade_fwd_iso(*args, _p(ctx.gbuf), ctx.gbuf.numel(), _stream())
             else:
                 rc = lib.voge_composite_shade_fwd_iso(*args, _stream())
         _lib.check(rc, "voge_composite_shade_fwd")
@@ -921,6 +1067,18 @@ class _CompositeShade(torch.autograd.Function):
                 go, gs_pix, gs_c = g_img, 0, 0      # autograd's broadcast scalar (sum / mean losses), read in place
             else:
                 go, gs_pix, gs_c = _dev(g_img, torch.float32, "grad_image"), C, 1
+            gbuf, ctx.gbuf = ctx.gbuf, None      # (zeroed by the forward, good for ONE backward: a second one takes the scratch form)
+            if gbuf is not None:
+                g_attr = torch.empty_like(attr)
+                g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=idx.device)
+                g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=idx.device)
+                with _on(idx.device):
+                    rc = lib.voge_frame_shade_bwd_iso(
+                        _p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(attr), _p(idx), _p(lz.cnt), _p(weight),
+                        _p(ln), _p(rgb), _p(wsum), _p(bg), ctx.thr, _p(go), gs_pix, gs_c, lz.occ, lz.B, lz.N, B * H, W, K, C, Nattr,
+                        _p(gbuf), gbuf.numel(), _p(g0), _p(g1), _p(g_attr), _stream())
+                _lib.check(rc, "voge_frame_shade_bwd_iso")
+        if g_img is not None and g0 is None:
             g_attr = torch.empty_like(attr)
             g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=idx.device)
             g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=idx.device)
@@ -963,12 +1121,17 @@ class _CompositeMerge(torch.autograd.Function):
         valid = torch.empty(idx.shape[:-1], dtype=torch.int64, device=idx.device)
         rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
         wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
+        ctx.gbuf = None      # (see _CompositeShade: the frame path's one-launch backward)
+        if lz.frame and lz.mode != 0 and any(ctx.needs_input_grad[:3]) and K <= 128 and FRAME_DIRECT_BWD:
+            ctx.gbuf = torch.empty((lz.B * lz.N * 32,), dtype=torch.uint8, device=idx.device)
         with _on(idx.device):
             ctx.ad = _general_act_dsd(lz, sel_len, any(ctx.needs_input_grad))
             args = (_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c), None, -1.0, idx.numel() // K, K,
                     C, Nattr, _p(weight), _p(valid), _p(rgb), None, _p(wsum))
             if lz.mode == 0:
                 rc = lib.voge_composite_shade_fwd_rec(*args, _p(ctx.ad[0]), _p(ctx.ad[1]), _stream())
+            elif ctx.gbuf is not None:
+                rc = lib.voge_frame_shade_fwd_iso(*args, _p(ctx.gbuf), ctx.gbuf.numel(), _stream())
             else:
                 rc = lib.voge_composite_shade_fwd_iso(*args, _stream())
         _lib.check(rc, "voge_composite_shade_fwd")
@@ -997,6 +1160,18 @@ class _CompositeMerge(torch.autograd.Function):
             else:
                 go, gs_pix, gs_c = _dev(g_rgb, torch.float32, "grad_out"), C, 1
             gws = None if g_wsum is None else _dev(g_wsum, torch.float32, "grad_weight_sum")
+            gbuf, ctx.gbuf = ctx.gbuf, None      # (zeroed by the forward, good for ONE backward)
+            if gbuf is not None:
+                g_attr = torch.empty_like(attr)
+                g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=idx.device)
+                g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=idx.device)
+                with _on(idx.device):
+                    rc = lib.voge_frame_merge_bwd_iso(
+                        _p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(attr), _p(idx), _p(lz.cnt), _p(weight),
+                        _p(ln), _p(go), gs_pix, gs_c, _p(gws), lz.occ, lz.B, lz.N, B * H, W, K, C, Nattr, _p(gbuf), gbuf.numel(),
+                        _p(g0), _p(g1), _p(g_attr), _stream())
+                _lib.check(rc, "voge_frame_merge_bwd_iso")
+        if (g_rgb is not None or g_wsum is not None) and g0 is None:
             g_attr = torch.empty_like(attr)
             g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=idx.device)
             g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=idx.device)
@@ -1074,8 +1249,11 @@ def composite_shade(lz, attr, bg, thr):
         return None      # (K <= 128: the image's backward is voge_fragment_shade_bwd_iso)
     if os.environ.get("VOGE_SHADE_THROUGH", "1") == "0":
         return None
-    with lz.grad():
+    if torch.is_grad_enabled() == lz.grad_mode:      # (the usual case: no mode switch to pay for)
         img, weight, valid = _CompositeShade.apply(attr, lz.p0, lz.p1, lz.sel_len, lz, bg, thr)
+    else:
+        with lz.grad():
+            img, weight, valid = _CompositeShade.apply(attr, lz.p0, lz.p1, lz.sel_len, lz, bg, thr)
     return img, lz.through(weight), valid
 
 
