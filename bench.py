@@ -763,7 +763,7 @@ def main():
         dom = "trace_fwd"  # the sweep BASELINE.json's metric names
         a = stages[dom]["GBps"]
         traffic, traffic_src = None, None
-        tname = next((t for t in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), None)
+        tname = next((t for t in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), None)
         tcfg = {}
         if tname is not None and not args.anisotropic:
             # HBM bytes per launch from rocprofv3 PMC passes of this same command (not collectable from inside the run)

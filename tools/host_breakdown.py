@@ -52,11 +52,9 @@ for nm in ("voge_rays_striped_fwd", "voge_fragments_fwd_iso_view", "voge_composi
            "voge_frame_shade_fwd_iso", "voge_frame_shade_bwd_iso"):
     wrap(lib, nm, "C: " + nm)
 wrap(Rm, "camera_tensors", "cameras.camera_tensors (glue)")
-wrap_static(Rm.GaussianRenderer, "_frame_camera", "_frame_camera") if False else None
 wrap(ops, "frame_trace", "ops.frame_trace (glue)")
 wrap(ops, "frame_eligible")
 wrap(ops, "_tag_index")
-wrap(ops, "composite_shade", "ops.composite_shade (glue)") if False else None
 wrap(cameras, "_intrinsics")
 wrap(ops, "pixel_rays", "ops.pixel_rays (glue)")
 wrap(Rm, "pixel_rays", "cameras.pixel_rays (glue)")
