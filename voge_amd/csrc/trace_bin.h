@@ -915,9 +915,7 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   ConeRec tcr, qcr;
   if (cam.R != nullptr) {      // (uniform; round 6) both cones from four corner rays each -- no load at all
     const CamK ck = cam_load(cam, b);
-    tcr = cam_rect_cone(ck, cam, tx * 8, tx * 8 + 7, ty * 8, ty * 8 + 7);
-    const int qx0 = stx * kST + (qq & 1) * kQuad, qy0 = sty * kST + (qq >> 1) * kQuad;
-    qcr = cam_rect_cone(ck, cam, qx0, qx0 + kQuad - 1, qy0, qy0 + kQuad - 1);
+    cam_two_cones(ck, cam, tx * 8, ty * 8, 8, stx * kST + (qq & 1) * kQuad, sty * kST + (qq >> 1) * kQuad, kQuad, tcr, qcr);
   } else {
     tcr = cones[cone_tile_at(b, (size_t)nstx * nsty, binl, ((qq >> 1) * 2 + (wave >> 1)) * 4 + (qq & 1) * 2 + (wave & 1))];
     qcr = cones[cone_quad_at(b, (size_t)nstx * nsty, binl, qq)];
