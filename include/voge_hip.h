@@ -359,6 +359,38 @@ int voge_frame_merge_bwd_iso(const float *records, const float *sigmas, int shar
                              int C, long Nattr, void *acc_zeroed, size_t acc_bytes, float *g_verts, float *g_sigmas,
                              float *g_attr, voge_stream_t stream);
 
+/*
+ * ABI 7, the frame path for (N,3) / (N,3,3) sigmas (Renderer.py:130-137 with Aggregation.py:144-175: A = 2 expend_sigma(sigmas);
+ * no inverse_sigma).  voge_frame_trace_fwd_gen: voge_frame_trace_fwd_iso's contract with the USER's arrays as inputs -- verts
+ * [N | B*N][3] (shared_verts: one set for all views), sigmas [N | B*N][3] (kind 1: per-axis) or [N | B*N][3][3] (kind 2) -- the record pass
+ * centres and expands them (the preamble's own fp32 operations), so neither a ray launch nor a preamble launch stands in front
+ * of the frame; records = kind 2: the packed (centred mu, A) [B*N][12]; kind 1: the compact (centred mu, a0, a1, a2, 0, 0) [B*N][8], which
+ * the composite and the backward evaluate with the three coefficients alone (the general chain's bits on such a form).
+ * voge_frame_shade_fwd_rec = voge_composite_shade_fwd_rec (C = 0: voge_composite_fwd_rec) on records of `kind` that also zeroes
+ * bwd_acc (voge_frame_bwd_gen_acc_bytes); kind 1 keeps no act / dsd (pass NULL).  voge_frame_bwd_gen: EVERY backward route of such fragments -- form 0: the image's
+ * gradient (voge_fragment_shade_bwd), 1: merge_final's (voge_fragment_merge_bwd; wsum = g_wsum | NULL), 2: the weights' own
+ * (voge_fragment_bwd: g = g_weight with strides, g_hitlen | NULL; attr / rgb / bg unused, C = 0) -- reading the forward's records (no
+ * pack launch), with acc zeroed already (acc_is_zero != 0) or filled here, and writing the gradients of verts and sigmas AS THE USER
+ * HOLDS THEM (the sum over the views of a shared set, d A / d sigma = 2: no preamble-backward launch).  K <= 128 (form 2: 256).
+ */
+size_t voge_frame_bwd_gen_acc_bytes(int P);
+int voge_frame_trace_fwd_gen(const float *verts, const float *sigmas, int shared_verts, int shared_sigmas, int kind,
+                             const float *R, const float *T, const float *focal, const float *pp, int row0, int stripe_h,
+                             int pitch, int behind, int B, int N, int h, int W, int K, float thr_act, void *workspace,
+                             size_t workspace_bytes, int32_t *idx, float *len, int32_t *cnt, float *records, float *rays,
+                             float *origin, voge_stream_t stream);
+int voge_frame_shade_fwd_rec(int kind, int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                             const float *rays, float occ, const float *colors, const float *bg, float thr,
+                             long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
+                             float *rgb, float *img, float *wsum, float *act, float *dsd, void *bwd_acc,
+                             size_t bwd_acc_bytes, voge_stream_t stream);
+int voge_frame_bwd_gen(int form, const float *records, int shared_verts, int shared_sigmas, int kind, const float *rays,
+                       const float *attr, const int32_t *idx, const int32_t *cnt, const float *weight, const float *act,
+                       const float *len, const float *dsd, const float *rgb, const float *wsum, const float *bg, float thr,
+                       const float *g, long g_stride0, long g_stride1, const float *g_hitlen, float occ, int B, int N,
+                       long nrows, int W, int K, int C, long Nattr, void *acc, size_t acc_bytes, int acc_is_zero,
+                       float *g_verts, float *g_sigmas, float *g_attr, voge_stream_t stream);
+
 /* interpolate_attr (+ get_silhouette) on fragments of this renderer, backward: merge_final's own backward
  * (VoGE/Aggregation.py:111-141; g_rgb = the gradient of the merged attributes [nrows*W,C], strides as g_img above), plus
  * g_wsum [nrows*W] or NULL = the gradient of the per-pixel weight sum (get_silhouette = min(sum, 1) of the same fragments),

@@ -321,3 +321,74 @@ def test_hit_length_of_the_frame_path_is_differentiable_on_demand(hip_lib):
     with torch.no_grad():
         frag, img, gm, colors, lz = _render(verts, sig, cols, R, T, (56, 64), 10, frame=True, grad=False)
         assert not frag.vert_hit_length.requires_grad
+
+
+def _general_scene(N, seed, kind, per_view=0):
+    """(N,3) per-axis or (N,3,3) L L^T sigmas (scenes.random_gaussians' forms); per_view = B: a [B,N,...] stack of them."""
+    from voge_amd import scenes
+    verts, sig, cols = scenes.random_gaussians(N, seed=seed, anisotropic=("diag" if kind == 1 else True), r_lo=0.04, r_hi=0.09)
+    if per_view:
+        rng = np.random.default_rng(seed)
+        sig = np.stack([sig * rng.uniform(0.8, 1.25) for _ in range(per_view)]).astype(np.float32)
+    return verts, sig, cols
+
+
+@pytest.mark.parametrize("kind,B,per_view,route", [
+    (1, 1, 0, "white"), (2, 1, 0, "white"), (1, 2, 0, "white"), (2, 2, 2, "white"),
+    (1, 1, 0, "merge"), (2, 2, 0, "merge"), (1, 1, 0, "weights"), (2, 1, 0, "weights+white"), (1, 2, 0, "hit_length"),
+])
+def test_general_forms_on_the_frame_path(hip_lib, kind, B, per_view, route):
+    """(N,3) / (N,3,3) sigmas through voge_frame_trace_fwd_gen + voge_frame_shade_fwd_rec + voge_frame_bwd_gen (the camera and the
+    user's own arrays in, the user's own gradients out: no ray launch, no preamble launch either way, no pack, no fill) against the
+    ray-bundle chain (general_preamble + voge_trace_lean_fwd + voge_fragment_*bwd): forward bits, gradients to the atomics' order,
+    on every consumer route of the fragments."""
+    from voge_amd import ops
+    from voge_amd.Meshes import GaussianMeshes
+    from voge_amd.Renderer import GaussianRenderer, GaussianRenderSettings, get_silhouette, interpolate_attr, to_white_background
+    from voge_amd.cameras import PerspectiveCameras
+    verts, sig, cols = _general_scene(1500, seed=60 + kind + B, kind=kind, per_view=per_view)
+    R, T = _views(B, seed=kind + 2 * B)
+    size = (72, 80)
+    rng = np.random.default_rng(3)
+    w_img, w_sil, w_w = t(rng.normal(size=(B,) + size + (3,))), t(rng.normal(size=(B,) + size)), t(rng.normal(size=(B,) + size + (14,)))
+    out = []
+    for frame in (True, False):
+        cams = PerspectiveCameras(focal_length=95.0, principal_point=((40.5, 35.0),), image_size=(size,), device=DEV)
+        renderer = GaussianRenderer(cams, GaussianRenderSettings(image_size=size, max_assign=14, max_point_per_bin=-1)).to(DEV)
+        gm = GaussianMeshes(t(verts), t(sig)).to(DEV)
+        colors = t(cols, rg=True)
+        colsB = colors.repeat(B, 1) if B > 1 else colors
+        old = ops.FRAME_PATH
+        ops.FRAME_PATH = frame
+        try:
+            frag = renderer(gm, R=t(R), T=t(T))
+            assert (frag._lazy is not None and frag._lazy.frame and frag._lazy.gen is not None) == frame
+            if route == "white":
+                vals = [to_white_background(frag, colsB)]
+                loss = (vals[0] * w_img).sum()
+            elif route == "merge":
+                vals = [interpolate_attr(frag, colsB), get_silhouette(frag)]
+                loss = (vals[0] * w_img).sum() + (vals[1] * w_sil).sum()
+            elif route == "weights":
+                vals = [frag.vert_weight]
+                loss = (vals[0] * w_w).sum()
+            elif route == "weights+white":      # a second consumer of the weights next to the image
+                img = to_white_background(frag, colsB)
+                vals = [img, frag.vert_weight]
+                loss = (img * w_img).sum() + (frag.vert_weight * w_w).sum()
+            else:
+                hl = frag.vert_hit_length
+                vals = [hl, to_white_background(frag, colsB)]
+                loss = (torch.where(hl < 1e9, hl, torch.zeros_like(hl)) * w_w).sum() * 0.01 + (vals[1] * w_img).sum()
+            loss.backward()
+        finally:
+            ops.FRAME_PATH = old
+        out.append(([v.detach() for v in vals], [frag.vert_index, frag.valid_num], [gm.verts.grad, gm.sigmas.grad, colors.grad]))
+    for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert torch.equal(a, b), route
+    for name, ga, gb in zip(("verts", "sigmas", "colors"), out[0][2], out[1][2]):
+        if gb is None:
+            assert ga is None or float(ga.abs().max()) == 0.0, (route, name)
+            continue
+        assert ga is not None and ga.shape == gb.shape, (route, name)
+        assert float((ga - gb).abs().max()) <= 2e-5 * max(1.0, float(gb.abs().max())), (route, name)

@@ -209,6 +209,14 @@ class GaussianRenderer(nn.Module):
                 index, hit_len, lz = ops.frame_trace(verts2d, sigmas, *cam[:4], cam[4], cam[5], behind, thr_act, K,
                                                      2 if st['inverse_sigma'] else 1, occ)
                 return Fragments(None, index, None, hit_len, _lazy=lz)
+        if (sigmas.dim() >= 2 and sigmas.shape[-1] == 3 and not st['inverse_sigma'] and FUSED_PREAMBLE and verts.is_cuda
+                and not (behind and RayTracing.REFERENCE_CANDIDATES) and os.environ.get("VOGE_LAZY_GENERAL", "1") != "0"):
+            # (N,3) / (N,3,3) sigmas on the frame path: the camera AND the user's own arrays go into the trace, whose record pass
+            # does the centring and 2 * expend_sigma of Renderer.py:130-137 (no ray launch, no preamble launch, no node here)
+            cam = self._frame_camera(cams, image_size, kwargs.get('rows'))
+            if cam is not None and ops.frame_eligible(verts2d, sigmas, *cam[:4], K, cam[4][1] * cam[5]):
+                index, hit_len, lz = ops.frame_trace_gen(verts2d, sigmas, *cam[:4], cam[4], cam[5], behind, thr_act, K, occ)
+                return Fragments(None, index, None, hit_len, _lazy=lz)
         rays, origin = pixel_rays(cams, image_size, rows=kwargs.get('rows'))     # [B,h,W,3], [B,3]
         # ray_tracing (RayTracing.py:12-30) + aggregation (Aggregation.py:82-107) as ONE call: the trace's sweep
         # composites the fragments in its epilogue (voge_fragments_fwd*).  The stand-alone ray_tracing* / aggregation

@@ -361,7 +361,9 @@ struct CompShade {
 };
 // GEN (forward from the records): the records are the general path's packed (mu, A), three float4 per Gaussian
 // (voge_trace_lean_fwd); act / dsd come from make_eval + pair_eval, the operations of the sweep's own epilogue.
-template <int MODE, int NS, bool WAVE, typename OffT, int SC = 0, bool GEN = false>   // MODE 0: forward, 2: backward with weights; OffT: composite_core.h at_bytes
+// GEN 2 (round 6): the compact per-axis records (mu, a0, a1, a2, 0, 0), two float4 per Gaussian (voge_frame_trace_fwd_gen, kind 1);
+// act / dsd from pair_eval_diag -- the general chain's bits without its zero coefficients.
+template <int MODE, int NS, bool WAVE, typename OffT, int SC = 0, int GEN = 0>   // MODE 0: forward, 2: backward with weights; OffT: composite_core.h at_bytes
 __global__ void __launch_bounds__(kCompThreads) __attribute__((amdgpu_waves_per_eu(VOGE_COMP_WPE)))
 compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
                   const float *__restrict__ len, const float *__restrict__ dsd,
@@ -469,12 +471,13 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
         const v2f l2 = at_bytes<v2f>(len, fb);
         iv[0] = i2.x; iv[1] = i2.y; lv[0] = l2.x; lv[1] = l2.y;
       }
-      float4 rc[NS][GEN ? 3 : 1];
+      constexpr int NR = GEN == 1 ? 3 : (GEN == 2 ? 2 : 1);      // float4s per record
+      float4 rc[NS][NR];
 #pragma unroll
       for (int a = 0; a < NS; ++a)
 #pragma unroll
-        for (int r = 0; r < (GEN ? 3 : 1); ++r)
-          rc[a][r] = at_bytes<float4>(rec, (uint32_t)max(iv[a], 0) * (GEN ? 48u : 16u) + 16u * r);      // (a slot beyond the count: record 0, selected out below -- no exec-mask region per slot)
+        for (int r = 0; r < NR; ++r)
+          rc[a][r] = at_bytes<float4>(rec, (uint32_t)max(iv[a], 0) * (16u * NR) + 16u * r);      // (a slot beyond the count: record 0, selected out below -- no exec-mask region per slot)
       if (SC > 0) {
 #pragma unroll
         for (int a = 0; a < NS; ++a) ivk[a] = (k0 + a < lead) ? iv[a] : -1;
@@ -484,8 +487,12 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
         if (GEN && !(k0 + a < lead)) continue;
         {
           PairOut o;
-          if (GEN) {
-            const float4 r0 = rc[a][0], r1 = rc[a][GEN ? 1 : 0], r2 = rc[a][GEN ? 2 : 0];
+          if (GEN == 2) {
+            const float4 r0 = rc[a][0], r1 = rc[a][NR - 1];
+            o = pair_eval_diag(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, d.x, d.y, d.z);
+            if (out1 != nullptr) { out1[f + a] = o.act; out2[f + a] = o.dsd; }
+          } else if (GEN) {
+            const float4 r0 = rc[a][0], r1 = rc[a][GEN == 1 ? 1 : 0], r2 = rc[a][GEN == 1 ? 2 : 0];
             const float A[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
             o = pair_eval(r0.x, r0.y, r0.z, make_eval(r0.x, r0.y, r0.z, A), d.x, d.y, d.z, d.x * d.x, d.y * d.y, d.z * d.z,
                           d.x * d.y, d.x * d.z, d.y * d.z);
@@ -1066,7 +1073,7 @@ extern "C" int voge_composite_fwd_iso(const int32_t *idx, const int32_t *cnt, co
 
 // Composite forward (from the records) with the shade stage in the same pass: weights, valid_num AND the image.
 // gen: the records are the general path's packed (mu, A) (voge_trace_lean_fwd) instead of (mu, a).  C = 0: no shade stage.
-static int composite_shade_fwd_impl(const bool gen, int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+static int composite_shade_fwd_impl(const int gen /* 0: (mu, a) records; 1: packed (mu, A); 2: compact per-axis */, int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                                     const float *rays, float occ, const float *colors, const float *bg, float thr,
                                     long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
                                     float *rgb, float *img, float *wsum, voge_stream_t stream, float *act_out = nullptr,
@@ -1106,10 +1113,12 @@ static int composite_shade_fwd_impl(const bool gen, int32_t *idx, const int32_t 
   hipLaunchKernelGGL((compositen_kernel<0, NS, true, OT, CC, GG>), gridn, blockn, ldsn, st, idx, nullptr, len, nullptr, nullptr, nullptr, \
                      cnt, occ, npix, K, ppwn, weight, act_out, dsd_out, valid_num, rec, rays, sh)
 #define VOGE_LAUNCH_CS2(CC, GG) do { if (small) VOGE_LAUNCH_CS(uint32_t, CC, GG); else VOGE_LAUNCH_CS(size_t, CC, GG); } while (0)
-  if (gen) {
-    if (C == 3) VOGE_LAUNCH_CS2(3, true); else if (C == 4) VOGE_LAUNCH_CS2(4, true); else VOGE_LAUNCH_CS2(0, true);
+  if (gen == 2) {
+    if (C == 3) VOGE_LAUNCH_CS2(3, 2); else if (C == 4) VOGE_LAUNCH_CS2(4, 2); else VOGE_LAUNCH_CS2(0, 2);
+  } else if (gen) {
+    if (C == 3) VOGE_LAUNCH_CS2(3, 1); else if (C == 4) VOGE_LAUNCH_CS2(4, 1); else VOGE_LAUNCH_CS2(0, 1);
   } else {
-    if (C == 3) VOGE_LAUNCH_CS2(3, false); else if (C == 4) VOGE_LAUNCH_CS2(4, false); else VOGE_LAUNCH_CS2(0, false);
+    if (C == 3) VOGE_LAUNCH_CS2(3, 0); else if (C == 4) VOGE_LAUNCH_CS2(4, 0); else VOGE_LAUNCH_CS2(0, 0);
   }
 #undef VOGE_LAUNCH_CS2
 #undef VOGE_LAUNCH_CS
@@ -1121,7 +1130,7 @@ extern "C" int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, co
                                             long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
                                             float *rgb, float *img, float *wsum, voge_stream_t stream) {
   if (C != 3 && C != 4) return VOGE_ERR_K_TOO_LARGE;
-  return composite_shade_fwd_impl(false, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
+  return composite_shade_fwd_impl(0, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
                                   rgb, img, wsum, stream);
 }
 
@@ -1136,8 +1145,23 @@ extern "C" int voge_frame_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const 
   if (C != 3 && C != 4) return VOGE_ERR_K_TOO_LARGE;
   if (bwd_acc == nullptr) bwd_acc_bytes = 0;
   if (npix == 0) return bwd_acc_bytes ? (int)voge_fill_async(bwd_acc, 0, bwd_acc_bytes, (hipStream_t)stream) : 0;      // (no launch to ride on)
-  return composite_shade_fwd_impl(false, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
+  return composite_shade_fwd_impl(0, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
                                   rgb, img, wsum, stream, nullptr, nullptr, bwd_acc, bwd_acc_bytes);
+}
+
+// ... and for the general forms (records = the packed (mu, A) of voge_frame_trace_fwd_gen / voge_trace_lean_fwd; act / dsd kept
+// for the backward when given): bwd_acc = voge_frame_bwd_gen_acc_bytes(B * N) bytes.
+extern "C" int voge_frame_shade_fwd_rec(int kind, int32_t *idx, const int32_t *cnt, const float *len, const float *records,
+                                        const float *rays, float occ, const float *colors, const float *bg, float thr,
+                                        long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
+                                        float *rgb, float *img, float *wsum, float *act, float *dsd, void *bwd_acc,
+                                        size_t bwd_acc_bytes, voge_stream_t stream) {
+  if (C != 0 && C != 3 && C != 4) return VOGE_ERR_K_TOO_LARGE;      // (C = 0: the weights alone -- voge_composite_fwd_rec's form)
+  if (kind != 1 && kind != 2) return VOGE_ERR_BAD_ARG;
+  if (bwd_acc == nullptr || C == 0) bwd_acc_bytes = 0;
+  if (npix == 0) return bwd_acc_bytes ? (int)voge_fill_async(bwd_acc, 0, bwd_acc_bytes, (hipStream_t)stream) : 0;
+  return composite_shade_fwd_impl(kind == 1 ? 2 : 1, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
+                                  rgb, img, wsum, stream, act, dsd, bwd_acc, bwd_acc_bytes);
 }
 
 // The same two for the general path: records = the packed (mu, A) [B*N][12] of voge_trace_lean_fwd.
@@ -1146,13 +1170,13 @@ extern "C" int voge_composite_shade_fwd_rec(int32_t *idx, const int32_t *cnt, co
                                             long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
                                             float *rgb, float *img, float *wsum, float *act, float *dsd, voge_stream_t stream) {
   if (C != 3 && C != 4) return VOGE_ERR_K_TOO_LARGE;
-  return composite_shade_fwd_impl(true, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
+  return composite_shade_fwd_impl(1, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
                                   rgb, img, wsum, stream, act, dsd);
 }
 extern "C" int voge_composite_fwd_rec(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                                       const float *rays, float occ, long npix, int K, float *weight, int64_t *valid_num,
                                       float *act, float *dsd, voge_stream_t stream) {
-  return composite_shade_fwd_impl(true, idx, cnt, len, records, rays, occ, nullptr, nullptr, -1.0f, npix, K, 0, 0, weight,
+  return composite_shade_fwd_impl(1, idx, cnt, len, records, rays, occ, nullptr, nullptr, -1.0f, npix, K, 0, 0, weight,
                                   valid_num, nullptr, nullptr, nullptr, stream, act, dsd);
 }
 

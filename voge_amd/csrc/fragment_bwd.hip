@@ -100,7 +100,10 @@ struct FragBwdLds {
 // from the records, the ray and len with the forward's own operations (pair_eval_iso_at / pair_eval): 8 bytes per slot less to read.
 // K need not be a multiple of NS: `vec` (uniform) says whether a lane's group is aligned and inside its pixel's row
 // (wide loads) or is read slot by slot.
-template <int SRC, int C, int NS, typename OffT, bool ISO, bool NOAD>
+// DIAG (round 6; !ISO, NOAD): rec = [P][2] compact per-axis records (mu, a0 | a1, a2, 0, 0) of voge_frame_trace_fwd_gen (kind 1):
+// em / sm from pair_eval_diag, the trace terms of the diagonal alone (the general terms' bits on such a form: their other
+// coefficients multiply zeros), table entries of 12 | 8 floats instead of 16 | 12 -- (g_mu, g_A00), (g_A11, g_A22, w g_rgb ...).
+template <int SRC, int C, int NS, typename OffT, bool ISO, bool NOAD, bool DIAG = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS == 4 ? 2 : (ISO ? VOGE_FB_WPE : 3))))
 fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ rays,
                         const float *__restrict__ colors, const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt,
@@ -111,7 +114,9 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
                         const int P, const long nrows, const int W, const int K, const long Nattr,
                         float *__restrict__ acc /* [P][NACC], zeroed */) {
   static_assert(NS == 2 || NS == 4, "a lane owns one or two aligned pairs of slots");
-  constexpr int NV4 = SRC == 0 ? (ISO ? 2 : 4) : (ISO ? 1 : 3), NACC = 4 * NV4;
+  static_assert(!DIAG || (!ISO && NOAD && C <= 4), "the per-axis form keeps no act / dsd");
+  constexpr int NV4 = SRC == 0 ? (ISO ? 2 : (DIAG ? 3 : 4)) : (ISO ? 1 : (DIAG ? 2 : 3)), NACC = 4 * NV4;
+  constexpr int NRC = ISO ? 1 : (DIAG ? 2 : 3);      // float4s per record
   // sum c (0 .. NACC - 1) of Gaussian `key`.  (Round 6 tried adding the table straight into the caller's gradient arrays --
   // g_verts [N][3], g_sigmas [N], g_colors [N][C], zeroed by the forward -- instead of acc [P][8] + a finishing pass: one launch
   // less, and the kernel went from 107 to 137 us.  An entry's eight sums are ONE 32-byte atomic request here and three requests
@@ -173,7 +178,7 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     // (a lane that is off reads pixel 0, slot 0: pix = 0 and q = 0 there)
     const float3 dv = at_bytes<float3>(rays, pix * (OffT)12);
     const float dx = on ? dv.x : 0.f, dy = on ? dv.y : 0.f, dz = on ? dv.z : 0.f;
-    float4 rc[NS][ISO ? 1 : 3];
+    float4 rc[NS][NRC];
     float av[NS], dv2[NS];
 #pragma unroll
     for (int a = 0; a < NS; ++a) { av[a] = 0.f; dv2[a] = 0.f; }
@@ -235,9 +240,9 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     if (NOAD) {      // (act / dsd re-derived from the records; with act / dsd given the records are only needed by the trace terms)
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
-        const uint32_t ro = (uint32_t)(okv[a] ? id[a] : 0) * (ISO ? 16u : 48u);      // (P < 2^26: host)
+        const uint32_t ro = (uint32_t)(okv[a] ? id[a] : 0) * (16u * NRC);      // (P < 2^26: host)
 #pragma unroll
-        for (int r = 0; r < (ISO ? 1 : 3); ++r) rc[a][r] = !(VOGE_FB_ABL & 8) ? at_bytes<float4>(rec, ro + 16u * r) : make_float4(0.f, 0.f, 0.f, 0.f);      // (P >= 1, Nattr >= 1 here: host)
+        for (int r = 0; r < NRC; ++r) rc[a][r] = !(VOGE_FB_ABL & 8) ? at_bytes<float4>(rec, ro + 16u * r) : make_float4(0.f, 0.f, 0.f, 0.f);      // (P >= 1, Nattr >= 1 here: host)
       }
     }
     float col[NS][4];
@@ -273,10 +278,18 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
         em[a] = okv[a] ? FAST_EXP(-o.act) : em[a]; sm[a] = okv[a] ? FAST_SQRT(o.dsd + 1e-10f) : sm[a];
       }
     }
-    if (NOAD && !ISO) {         // general forms: the same from the packed (mu, A) records, with the forward's operations
+    if (NOAD && DIAG) {         // per-axis forms: the same from the compact records
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
-        const float4 r0 = rc[a][0], r1 = rc[a][ISO ? 0 : 1], r2 = rc[a][ISO ? 0 : 2];
+        const float4 r0 = rc[a][0], r1 = rc[a][NRC - 1];
+        const PairOut o = pair_eval_diag(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, dx, dy, dz);
+        em[a] = okv[a] ? FAST_EXP(-o.act) : em[a]; sm[a] = okv[a] ? FAST_SQRT(o.dsd + 1e-10f) : sm[a];
+      }
+    }
+    if (NOAD && !ISO && !DIAG) {         // general forms: the same from the packed (mu, A) records, with the forward's operations
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const float4 r0 = rc[a][0], r1 = rc[a][NRC == 3 ? 1 : 0], r2 = rc[a][NRC == 3 ? 2 : 0];
         const float A[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
         const PairOut o = pair_eval(r0.x, r0.y, r0.z, make_eval(r0.x, r0.y, r0.z, A), dx, dy, dz, dx * dx, dy * dy, dz * dz,
                                     dx * dy, dx * dz, dy * dz);
@@ -366,9 +379,9 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
     if (!NOAD || !ISO)
 #pragma unroll
     for (int a = 0; a < NS; ++a) {
-      const uint32_t ro = (uint32_t)(live[a] ? id[a] : 0) * (ISO ? 16u : 48u);      // (P < 2^26: host)
+      const uint32_t ro = (uint32_t)(live[a] ? id[a] : 0) * (16u * NRC);      // (P < 2^26: host)
 #pragma unroll
-      for (int r = 0; r < (ISO ? 1 : 3); ++r)
+      for (int r = 0; r < NRC; ++r)
         rc[a][r] = !(VOGE_FB_ABL & 8) ? at_bytes<float4>(rec, ro + 16u * r) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float dn2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
@@ -395,9 +408,35 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
           const float c1 = gl[a] * idn, c2 = 2.0f * aa * ga[a];
           val[0] = make_float4(fmaf(c1, dx, c2 * vx), fmaf(c1, dy, c2 * vy), fmaf(c1, dz, c2 * vz),
                                fmaf(ga[a], fmaf(vz, vz, fmaf(vy, vy, vx * vx)), gd[a] * dn2));
+        } else if (DIAG) {
+          // A = diag(a0, a1, a2): the general terms below with every product by a zero coefficient left out (they add +-0 there)
+          const float4 r0 = rc[a][0], r1 = rc[a][NRC - 1];
+          const float mx = r0.x, my = r0.y, mz = r0.z;
+          const float adx = r0.w * dx, ady = r1.x * dy, adz = r1.y * dz;
+          const float ksk = fmaf(dz, adz, fmaf(dy, ady, dx * adx)), msk = fmaf(mz, adz, fmaf(my, ady, mx * adx));
+          const float ik = __builtin_amdgcn_rcpf(ksk);
+          const float t = msk * ik;
+          float vx = fmaf(-t, dx, mx), vy = fmaf(-t, dy, my), vz = fmaf(-t, dz, mz);
+          {
+            const float rr = fmaf(vz, adz, fmaf(vy, ady, vx * adx)) * ik;
+            vx = fmaf(-rr, dx, vx); vy = fmaf(-rr, dy, vy); vz = fmaf(-rr, dz, vz);
+          }
+          const float avx = r0.w * vx, avy = r1.x * vy, avz = r1.y * vz;
+          const float c1 = gl[a] * ik, g_a = ga[a], g_d = gd[a];
+          const float o0 = fmaf(c1, adx, g_a * (avx + avx)), o1 = fmaf(c1, ady, g_a * (avy + avy)), o2 = fmaf(c1, adz, g_a * (avz + avz));
+          const float o3 = fmaf(g_a, vx * vx, fmaf(g_d, dx * dx, c1 * (vx * dx)));
+          const float o4 = fmaf(g_a, vy * vy, fmaf(g_d, dy * dy, c1 * (vy * dy)));
+          const float o5 = fmaf(g_a, vz * vz, fmaf(g_d, dz * dz, c1 * (vz * dz)));
+          val[0] = make_float4(o0, o1, o2, o3);
+          if (SRC == 0) {
+            val[NV4 >= 2 ? 1 : 0] = make_float4(o4, o5, wv[a] * gr[0], wv[a] * gr[1]);
+            val[NV4 >= 3 ? 2 : 0] = make_float4(wv[a] * gr[2], wv[a] * gr[3], 0.f, 0.f);
+          } else {
+            val[NV4 >= 2 ? 1 : 0] = make_float4(o4, o5, 0.f, 0.f);
+          }
         } else {
           // the merged per-target terms of trace_bwd.hip (header there): g_mu (3) and the unsymmetrised g_A (9)
-          const float4 r0 = rc[a][0], r1 = rc[a][ISO ? 0 : 1], r2 = rc[a][ISO ? 0 : 2];
+          const float4 r0 = rc[a][0], r1 = rc[a][NRC == 3 ? 1 : 0], r2 = rc[a][NRC == 3 ? 2 : 0];
           const float mx = r0.x, my = r0.y, mz = r0.z;
           const float A[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
           const float adx = fmaf(A[2], dz, fmaf(A[1], dy, A[0] * dx)), ady = fmaf(A[5], dz, fmaf(A[4], dy, A[3] * dx)),
@@ -428,10 +467,10 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
             for (int c = 0; c < 3; ++c)
               o[3 + 3 * i + c] = fmaf(g_a, fmaf(v[i], v[c], t * (d[i] * v[c] - v[i] * d[c])), fmaf(g_d, d[i] * d[c], c1 * (v[i] * d[c])));
           val[0] = make_float4(o[0], o[1], o[2], o[3]);
-          val[ISO ? 0 : 1] = make_float4(o[4], o[5], o[6], o[7]);
-          val[ISO ? 0 : 2] = make_float4(o[8], o[9], o[10], o[11]);
+          val[NV4 >= 3 ? 1 : 0] = make_float4(o[4], o[5], o[6], o[7]);
+          val[NV4 >= 3 ? 2 : 0] = make_float4(o[8], o[9], o[10], o[11]);
         }
-        if (SRC == 0) val[NV4 - 1] = make_float4(wv[a] * gr[0], wv[a] * gr[1], wv[a] * gr[2], wv[a] * gr[3]);
+        if (SRC == 0 && !DIAG) val[NV4 - 1] = make_float4(wv[a] * gr[0], wv[a] * gr[1], wv[a] * gr[2], wv[a] * gr[3]);
         go = false;
 #pragma unroll
         for (int r = 0; r < NV4; ++r) go = go || (val[r].x != 0.f || val[r].y != 0.f || val[r].z != 0.f || val[r].w != 0.f);
@@ -672,6 +711,18 @@ void fb_launch(const FbArgs &a, hipStream_t st) {
                      colors, a.idx, a.cnt, a.weight, a.act, a.len, a.dsd, a.rgb, a.wsum, a.bg, a.thr, a.g, a.gs_pix, a.gs_c,
                      a.g_hitlen, a.occ, a.P, a.nrows, a.W, a.K, a.Nattr, a.acc);
 }
+template <int SRC, int C, int NS, typename OffT>
+void fb_launch_diag_t(const FbArgs &a, hipStream_t st) {
+  const long blocks = (long)((a.W + kFbGW - 1) / kFbGW) * ((a.nrows + kFbGH - 1) / kFbGH);
+  const float *colors = (a.Nattr > 0 && a.colors != nullptr) ? a.colors : reinterpret_cast<const float *>(a.rec);
+  hipLaunchKernelGGL((fragment_bwd_kernel<SRC, C, NS, OffT, false, true, true>), dim3((unsigned)blocks), dim3(64), 0, st, a.rec, a.rays,
+                     colors, a.idx, a.cnt, a.weight, a.act, a.len, a.dsd, a.rgb, a.wsum, a.bg, a.thr, a.g, a.gs_pix, a.gs_c,
+                     a.g_hitlen, a.occ, a.P, a.nrows, a.W, a.K, a.Nattr, a.acc);
+}
+template <int SRC, int C, int NS>
+void fb_launch_diag(const FbArgs &a, hipStream_t st) {
+  if ((double)a.nrows * a.W * a.K < (double)(1l << 30)) fb_launch_diag_t<SRC, C, NS, uint32_t>(a, st); else fb_launch_diag_t<SRC, C, NS, size_t>(a, st);
+}
 template <int SRC, int C, int NS, bool ISO>
 void fb_launch_off(const FbArgs &a, hipStream_t st) {
   const bool small = (double)a.nrows * a.W * a.K < (double)(1l << 30);      // every byte offset fits 32 bits
@@ -779,6 +830,110 @@ extern "C" int voge_frame_merge_bwd_iso(const float *records, const float *sigma
                                         float *g_attr, voge_stream_t stream) {
   return frame_bwd_impl(true, records, sigmas, shared, sigma_mode, rays, attr, idx, cnt, weight, len, nullptr, g_wsum, nullptr, -1.0f, g_rgb,
                         g_stride_pix, g_stride_c, occ, B, N, nrows, W, K, C, Nattr, acc_zeroed, acc_bytes, g_verts, g_sigmas, g_attr, stream);
+}
+
+// ---- the general forms on the frame path: every backward route of fragments made by voge_frame_trace_fwd_gen.  The packed
+// (mu, A) records come from the forward (no pack launch), `acc` [P][16 | 12] floats is either zeroed already (acc_is_zero: the
+// frame's composite did it on its way) or filled here, and the finishing pass applies the renderer's own chain rule
+// (Renderer.py:130-137 backwards: the sum over the views of a shared set; d A / d sigma = 2 on the diagonal for per-axis sigmas,
+// 2 everywhere for [3][3] ones) -- no general_preamble_bwd launch behind it.
+//   form 0: the image's gradient (to_colored_background: rgb, wsum, bg, thr, g = g_img);   form 1: merge_final's (interpolate_attr:
+//   g = g_rgb, wsum = g_wsum | NULL);   form 2: the weights' own (g = g_weight with strides, g_hitlen | NULL; C = 0, no attr).
+__global__ void __launch_bounds__(256)
+fragment_bwd_finish_view_kernel(const float *__restrict__ acc, const int S, const int P, const int N, const int B, const int shared_v,
+                                const int shared_s, const int kind, const int C, const long Nattr, float *__restrict__ g_verts,
+                                float *__restrict__ g_sigmas, float *__restrict__ g_attr) {
+  // acc per Gaussian -- kind 2 (S = 16 | 12): g_mu [0..2], g_A [3..11], w g_rgb [12..15]; kind 1, the per-axis kernel's entries
+  // (S = 12 | 8): g_mu [0..2], g_A00 [3], g_A11 [4], g_A22 [5], w g_rgb [6..9]
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g_attr != nullptr && t < Nattr) {
+    for (int c = 0; c < C; ++c) g_attr[t * C + c] = (t < P) ? acc[t * S + (kind == 1 ? 6 : 12) + c] : 0.0f;
+  }
+  if (g_verts != nullptr && t < (shared_v ? N : P)) {
+    float v[3] = {0.f, 0.f, 0.f};
+    for (int b = 0; b < (shared_v ? B : 1); ++b) {      // (a shared set: its views in a fixed order)
+      const float *a = acc + ((long)b * N + t) * S;
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2];
+    }
+    g_verts[3 * t] = v[0]; g_verts[3 * t + 1] = v[1]; g_verts[3 * t + 2] = v[2];
+  }
+  if (g_sigmas != nullptr && kind == 1 && t < (shared_s ? N : P)) {
+    float v[3] = {0.f, 0.f, 0.f};
+    for (int b = 0; b < (shared_s ? B : 1); ++b) {
+      const float *a = acc + ((long)b * N + t) * S + 3;
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2];
+    }
+    g_sigmas[3 * t] = 2.0f * v[0]; g_sigmas[3 * t + 1] = 2.0f * v[1]; g_sigmas[3 * t + 2] = 2.0f * v[2];
+  } else if (g_sigmas != nullptr && t < (shared_s ? N : P)) {
+    float v[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = 0.f;
+    for (int b = 0; b < (shared_s ? B : 1); ++b) {
+      const float *a = acc + ((long)b * N + t) * S + 3;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v[i] += a[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g_sigmas[9 * t + i] = 2.0f * v[i];
+  }
+}
+
+extern "C" size_t voge_frame_bwd_gen_acc_bytes(int P) { return P <= 0 ? 0 : (size_t)P * 64; }      // (kind 1 uses 48 | 32 of them)
+
+extern "C" int voge_frame_bwd_gen(int form, const float *records, int shared_verts, int shared_sigmas, int kind, const float *rays,
+                                  const float *attr, const int32_t *idx, const int32_t *cnt, const float *weight, const float *act,
+                                  const float *len, const float *dsd, const float *rgb, const float *wsum, const float *bg, float thr,
+                                  const float *g, long g_stride0, long g_stride1, const float *g_hitlen, float occ, int B, int N,
+                                  long nrows, int W, int K, int C, long Nattr, void *acc, size_t acc_bytes, int acc_is_zero,
+                                  float *g_verts, float *g_sigmas, float *g_attr, voge_stream_t stream) {
+  if (form < 0 || form > 2 || (kind != 1 && kind != 2) || B < 0 || N < 0 || nrows < 0 || W < 0 || K <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
+  if (form != 2 && (C <= 0 || C > 4)) return VOGE_ERR_BAD_ARG;
+  if (K > (form == 2 ? VOGE_MAX_K : 128)) return VOGE_ERR_K_TOO_LARGE;
+  const int P = B * N;
+  hipStream_t st = (hipStream_t)stream;
+  const long nv = shared_verts ? N : P, ns = (long)(shared_sigmas ? N : P) * (kind == 1 ? 3 : 9);
+  if (P == 0 || nrows * W == 0) {      // nothing was traced: zero gradients
+    hipError_t e = hipSuccess;
+    if (g_verts && nv > 0) e = voge_fill_async(g_verts, 0, sizeof(float) * 3 * (size_t)nv, st);
+    if (e == hipSuccess && g_sigmas && ns > 0) e = voge_fill_async(g_sigmas, 0, sizeof(float) * (size_t)ns, st);
+    if (e == hipSuccess && g_attr && Nattr > 0 && form != 2) e = voge_fill_async(g_attr, 0, sizeof(float) * (size_t)Nattr * C, st);
+    return (int)e;
+  }
+  if (!records || !rays || !idx || !cnt || !weight || !len || !acc || (act == nullptr) != (dsd == nullptr)) return VOGE_ERR_BAD_ARG;
+  if (form != 2 && (!attr || !g)) return VOGE_ERR_BAD_ARG;
+  if (form == 0 && (!rgb || !wsum || !bg)) return VOGE_ERR_BAD_ARG;
+  if ((g_verts == nullptr) != (g_sigmas == nullptr)) return VOGE_ERR_BAD_ARG;
+  const int S = kind == 1 ? (form == 2 ? 8 : 12) : (form == 2 ? 12 : 16);
+  if (kind == 1 && (act || dsd)) return VOGE_ERR_BAD_ARG;      // (the per-axis form keeps neither: re-derived from its 32-byte records)
+  if (acc_bytes < (size_t)P * S * 4) return VOGE_ERR_WORKSPACE;
+  if (P >= (1 << 26) || (form != 2 && Nattr * C >= (1l << 30))) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
+  float *accf = reinterpret_cast<float *>(acc);
+  if (!acc_is_zero) { const hipError_t e = voge_fill_async(accf, 0, (size_t)P * S * 4, st); if (e != hipSuccess) return (int)e; }
+  const float4 *rec = reinterpret_cast<const float4 *>(records);
+  if (form == 2) {
+    const FbArgs a{rec, rays, nullptr, idx, cnt, weight, act, len, dsd, nullptr, nullptr, nullptr, -1.0f, g, g_stride0, g_stride1, g_hitlen,
+                   occ, P, nrows, W, K, 0, accf};
+    if (kind == 1) { if (K <= 128) fb_launch_diag<1, 0, 2>(a, st); else fb_launch_diag<1, 0, 4>(a, st); }
+    else fb_launch_gw<false>(a, st);
+  } else {
+    const FbArgs a{rec, rays, attr, idx, cnt, weight, act, len, dsd, form == 0 ? rgb : nullptr, wsum, form == 0 ? bg : nullptr,
+                   form == 0 ? thr : -1.0f, g, g_stride0, g_stride1, nullptr, occ, P, nrows, W, K, Nattr, accf};
+    if (kind == 1) {
+      switch (C) {
+        case 1: fb_launch_diag<0, 1, 2>(a, st); break;
+        case 2: fb_launch_diag<0, 2, 2>(a, st); break;
+        case 3: fb_launch_diag<0, 3, 2>(a, st); break;
+        default: fb_launch_diag<0, 4, 2>(a, st); break;
+      }
+    } else {
+      fb_launch_shade<false>(a, C, st);
+    }
+  }
+  const long n_fin = (form != 2 && Nattr > P) ? Nattr : P;
+  hipLaunchKernelGGL(fragment_bwd_finish_view_kernel, dim3((unsigned)((n_fin + 255) / 256)), dim3(256), 0, st, accf, S, P, N, B,
+                     shared_verts ? 1 : 0, shared_sigmas ? 1 : 0, kind, form == 2 ? 0 : C, form == 2 ? 0l : Nattr, g_verts, g_sigmas,
+                     form == 2 ? nullptr : g_attr);
+  return launch_status();
 }
 
 extern "C" int voge_fragment_shade_bwd(const float *mus, const float *isigmas, const float *rays, const float *colors,

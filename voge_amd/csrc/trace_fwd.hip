@@ -34,10 +34,21 @@ __device__ __forceinline__ void prep_one(const int g, const float *__restrict__ 
                                          const float *__restrict__ cam_fwd, const int N, const float thr_act,
                                          const int iso_in, float4 *__restrict__ cull, float4 *__restrict__ evr,
                                          float4 *__restrict__ ms, float4 *__restrict__ ell, const IsoView view,
-                                         float4 *__restrict__ pk = nullptr /* [P][3] packed (mu, A): kept by the caller */) {
+                                         float4 *__restrict__ pk = nullptr /* [P][3] packed (mu, A): kept by the caller */,
+                                         const CamView cam = no_camera()) {
   float mx, my, mz;
   const int src = view.shared ? g % N : g;
-  if (view.origin != nullptr) {   // centring of Renderer.py:130 done here: the same single fp32 subtraction
+  float fwd[3] = {0.f, 0.f, 0.f};
+  bool has_fwd = false;
+  if (cam.R != nullptr) {      // (round 6) centre and view axis from the camera, as rays_fwd_kernel / _view_axis make them
+    const int b = g / N;
+    const CamK ck = cam_load(cam, b);
+    float ox, oy, oz;
+    cam_origin(ck, cam.T + 3 * b, ox, oy, oz);
+    mx = mus[3 * (size_t)src + 0] - ox; my = mus[3 * (size_t)src + 1] - oy; mz = mus[3 * (size_t)src + 2] - oz;
+    if (cam.origin_out != nullptr && g == b * N) { cam.origin_out[3 * b] = ox; cam.origin_out[3 * b + 1] = oy; cam.origin_out[3 * b + 2] = oz; }
+    if (cam.behind) { const float *r = cam.R + 9 * b; fwd[0] = r[2]; fwd[1] = r[5]; fwd[2] = r[8]; has_fwd = true; }
+  } else if (view.origin != nullptr) {   // centring of Renderer.py:130 done here: the same single fp32 subtraction
     const float *o = view.origin + 3 * (g / N);
     mx = mus[3 * (size_t)src + 0] - o[0]; my = mus[3 * (size_t)src + 1] - o[1]; mz = mus[3 * (size_t)src + 2] - o[2];
   } else {
@@ -48,12 +59,23 @@ __device__ __forceinline__ void prep_one(const int g, const float *__restrict__ 
     const float a = iso_view_a(isg[src], view.mode);
 #pragma unroll
     for (int i = 0; i < 9; ++i) A[i] = (i % 4 == 0) ? a : 0.0f;
+  } else if (view.gen_kind == 1) {      // the user's per-axis sigmas: A = 2 diag(s) (general_preamble_fwd_kernel's operations)
+    const float *sg = isg + 3 * (size_t)(view.sigma_shared ? g % N : g);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = (i % 4 == 0) ? 2.0f * sg[i / 4] : 0.0f;
+  } else if (view.gen_kind == 2) {      // the user's [3][3] sigmas: A = 2 S
+    const float *sg = isg + 9 * (size_t)(view.sigma_shared ? g % N : g);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = 2.0f * sg[i];
   } else {
 #pragma unroll
     for (int i = 0; i < 9; ++i) A[i] = isg[9 * (size_t)g + i];
   }
   const EvalRec e = make_eval(mx, my, mz, A);
-  if (pk != nullptr) {      // what the deferred composite and the fused backward gather (fragment_bwd.hip's record layout)
+  if (pk != nullptr && view.gen_kind == 1) {      // per-axis sigmas: the compact (centred mu, a0, a1, a2) record, 32 bytes
+    pk[2 * (size_t)g + 0] = make_float4(mx, my, mz, A[0]);
+    pk[2 * (size_t)g + 1] = make_float4(A[4], A[8], 0.0f, 0.0f);
+  } else if (pk != nullptr) {      // what the deferred composite and the fused backward gather (fragment_bwd.hip's record layout)
     pk[3 * (size_t)g + 0] = make_float4(mx, my, mz, A[0]);
     pk[3 * (size_t)g + 1] = make_float4(A[1], A[2], A[3], A[4]);
     pk[3 * (size_t)g + 2] = make_float4(A[5], A[6], A[7], A[8]);
@@ -106,6 +128,7 @@ __device__ __forceinline__ void prep_one(const int g, const float *__restrict__ 
     const float *f = cam_fwd + 3 * (g / N);
     if (fmaf(mz, f[2], fmaf(my, f[1], mx * f[0])) < 0.0f) reach = -1.0f;
   }
+  if (has_fwd && fmaf(mz, fwd[2], fmaf(my, fwd[1], mx * fwd[0])) < 0.0f) reach = -1.0f;
   cull[g] = make_float4(mx, my, mz, reach);
   evr[3 * (size_t)g + 0] = make_float4(e.s00, e.s11, e.s22, e.s01);
   evr[3 * (size_t)g + 1] = make_float4(e.s02, e.s12, e.bx, e.by);
@@ -141,11 +164,11 @@ __device__ __forceinline__ void small_set_marks(int *__restrict__ seg_count, con
 __global__ void __launch_bounds__(256)
 prep_kernel(const float *__restrict__ mus, const float *__restrict__ isg, const float *__restrict__ cam_fwd, const int N,
             const int P, const float thr_act, float4 *__restrict__ cull, float4 *__restrict__ evr,
-            float4 *__restrict__ ms, float4 *__restrict__ ell, float4 *__restrict__ pk,
+            float4 *__restrict__ ms, float4 *__restrict__ ell, float4 *__restrict__ pk, const IsoView view, const CamView cam,
             int *__restrict__ seg_count = nullptr, const long n_seg = 0, unsigned long long *__restrict__ pool_top = nullptr) {
   small_set_marks(seg_count, n_seg, pool_top);
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < P) prep_one(g, mus, isg, cam_fwd, N, thr_act, 0, cull, evr, ms, ell, IsoView{nullptr, 0, 0}, pk);
+  if (g < P) prep_one(g, mus, isg, cam_fwd, N, thr_act, 0, cull, evr, ms, ell, view, pk, cam);
 }
 
 }  // namespace voge
@@ -1379,7 +1402,7 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   // (with a camera the kernels make the rays themselves; the bundle they leave in cam.rays_out is what a composite behind the
   //  sweep reads.  That form keeps no act / dsd: the sweep's epilogue would have to read the bundle back.)
   if (cam.R != nullptr) {
-    if (rays || cones_in || cam_fwd || act || dsd || !iso_in || !cam.T || !cam.focal || !cam.pp || cam.stripe_h <= 0 || cam.pitch < 0 ||
+    if (rays || cones_in || cam_fwd || act || dsd || !cam.T || !cam.focal || !cam.pp || cam.stripe_h <= 0 || cam.pitch < 0 ||
         cam.h != H || cam.W != W || (weight != nullptr && !cam.rays_out))
       return VOGE_ERR_BAD_ARG;
   } else if (!rays) {
@@ -1403,7 +1426,9 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
   const int per = trace_views_that_fit(B, N, H, W, workspace_bytes);
   const size_t npv = (size_t)H * W;      // pixels per view
   const size_t nst = (size_t)((W + kST - 1) / kST) * ((H + kST - 1) / kST);
-  const size_t stride_mu = view.shared ? 0 : (size_t)N * 3, stride_sg = view.shared ? 0 : (size_t)N * (iso_in ? 1 : 9);
+  const size_t stride_mu = view.shared ? 0 : (size_t)N * 3;
+  const size_t stride_sg = iso_in ? (view.shared ? 0 : (size_t)N)
+                                  : (view.gen_kind ? (view.sigma_shared ? 0 : (size_t)N * (view.gen_kind == 1 ? 3 : 9)) : (size_t)N * 9);
   for (int b0 = 0; b0 < B; b0 += per) {
     const int nb = (B - b0 < per) ? B - b0 : per;
     IsoView v = view;
@@ -1416,7 +1441,7 @@ static int trace_topk_fwd_impl(const int iso_in, const IsoView view, const float
     const int rc = trace_chunk_fwd(iso_in, v, at(mus, stride_mu), at(isigmas, stride_sg), at(rays, npv * 3), at(cam_fwd, 3),
                                    at(cones_in, nst * kConeRecsPerST * (sizeof(ConeRec) / sizeof(float))), nb, N, H, W, K, thr_act, workspace,
                                    at(idx, npv * K), at(len, npv * K), at(act, npv * K), at(dsd, npv * K), at(cnt, npv), stream, occ,
-                                   at(weight, npv * K), at(valid_num, npv), at(records, (size_t)N * (iso_in ? 4 : 12)), cv,
+                                   at(weight, npv * K), at(valid_num, npv), at(records, (size_t)N * (iso_in ? 4 : (view.gen_kind == 1 ? 8 : 12))), cv,
                                    trace_pool_slots(workspace, workspace_bytes) + ((b0 / per) < kPoolSlots ? (b0 / per) : kPoolSlots - 1));
     if (rc) return rc;
     if (b0 > 0 && N > 0) {
@@ -1466,7 +1491,7 @@ static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mu
                        cam, ws.seg_count, n_seg, ws.pool_top);
   } else if (small_set) {
     hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P, thr_act, ws.cull,
-                       ws.evr, ws.ms, ws.ell, reinterpret_cast<float4 *>(records), ws.seg_count, n_seg, ws.pool_top);
+                       ws.evr, ws.ms, ws.ell, reinterpret_cast<float4 *>(records), view, cam, ws.seg_count, n_seg, ws.pool_top);
   } else if (iso_in && N >= VOGE_ISO_PREP_SPLIT) {
     // scalar sigmas, slices of more than two rounds: the records in a pass of their own (iso_prep_kernel)
     hipLaunchKernelGGL(iso_prep_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, mus, isigmas, cam_fwd, N, thr_act, view, ws.cull, ws.ms, cam);
@@ -1479,7 +1504,7 @@ static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mu
   } else {
     if (P > 0)
       hipLaunchKernelGGL(prep_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mus, isigmas, cam_fwd, N, P, thr_act, ws.cull,
-                         ws.evr, ws.ms, ws.ell, reinterpret_cast<float4 *>(records));
+                         ws.evr, ws.ms, ws.ell, reinterpret_cast<float4 *>(records), view, cam);
     hipLaunchKernelGGL(binA_kernel<false>, gridA, dim3(kBinThreads), 0, st, cones, ws.nstx, ws.nsty, ws.nst0x, mus, isigmas,
                        cam_fwd, N, thr_act, view, ws.cull, ws.ms, ws.seg_count, ws.seg_id, ws.seg_rec, ws.pool_top, ws.seg_ext, ws.ext_id, ws.ext_arena, cam);
   }
@@ -1624,4 +1649,24 @@ extern "C" int voge_frame_trace_fwd_iso(const float *verts, const float *sigmas,
   return trace_topk_fwd_impl(1, IsoView{nullptr, shared ? 1 : 0, sigma_mode}, verts, sigmas, nullptr, nullptr, nullptr, B, N, h, W, K,
                              thr_act, workspace, workspace_bytes, idx, len, nullptr, nullptr, cnt, stream, 1.0f, nullptr, nullptr, records,
                              cam);
+}
+
+// ... and for (N,3) / (N,3,3) sigmas (Renderer.py:130-137 with Aggregation.py:144-175: centred = verts - origin[b], A = 2 *
+// expend_sigma(sigmas); no inverse_sigma here): the general trace with the camera AND the user's own arrays as inputs -- the
+// record pass does the centring and the expansion (general_preamble_fwd_kernel's operations: the same bits), so neither the ray
+// launch nor the preamble launch stands in front of the frame.  kind 1: sigmas [N | B*N][3], kind 2: [N | B*N][3][3];
+// shared_verts / shared_sigmas: one set seen by every view.  records: what the deferred composite and voge_frame_bwd_gen read --
+// kind 2: the packed (centred mu, A) [B*N][12]; kind 1: the compact (centred mu, a0, a1, a2, 0, 0) [B*N][8].
+extern "C" int voge_frame_trace_fwd_gen(const float *verts, const float *sigmas, int shared_verts, int shared_sigmas, int kind,
+                                        const float *R, const float *T, const float *focal, const float *pp, int row0, int stripe_h,
+                                        int pitch, int behind, int B, int N, int h, int W, int K, float thr_act, void *workspace,
+                                        size_t workspace_bytes, int32_t *idx, float *len, int32_t *cnt, float *records, float *rays,
+                                        float *origin, voge_stream_t stream) {
+  if ((kind != 1 && kind != 2) || !cnt || !records || !R || !T || !focal || !pp || stripe_h <= 0 || pitch < 0) return VOGE_ERR_BAD_ARG;
+  if ((size_t)B * h * W > 0 && !rays) return VOGE_ERR_BAD_ARG;
+  const CamView cam{R, T, focal, pp, row0, stripe_h, pitch, h, W, behind ? 1 : 0, origin, rays};
+  IsoView view{nullptr, shared_verts ? 1 : 0, 0};
+  view.gen_kind = kind; view.sigma_shared = shared_sigmas ? 1 : 0;
+  return trace_topk_fwd_impl(0, view, verts, sigmas, nullptr, nullptr, nullptr, B, N, h, W, K, thr_act, workspace, workspace_bytes, idx, len,
+                             nullptr, nullptr, cnt, stream, 1.0f, nullptr, nullptr, records, cam);
 }

@@ -47,6 +47,10 @@ struct IsoView {
   const float *origin;
   int shared, mode;
   int cam_origin = 0;      // (round 6) the centre comes from the kernel's CamView instead of `origin`
+  // (round 6, the general entry's frame form) how prep_kernel reads its `isg` argument: 0: A [P][9] as given; 1: the user's
+  // per-axis sigmas [N | B*N][3], A = 2 diag(s); 2: the user's [N | B*N][3][3], A = 2 S (Renderer.py:133 + Aggregation.py:144-175);
+  // sigma_shared: one [N, ...] set seen by every view.  `shared` above then says the same for the centres.
+  int gen_kind = 0, sigma_shared = 0;
 };
 __device__ __forceinline__ float iso_view_a(const float s, const int mode) {
   return mode == 1 ? 2.0f * s : (mode == 2 ? 2.0f / s : s);
@@ -120,6 +124,33 @@ __device__ __forceinline__ PairOut pair_eval_gen(const float mx, const float my,
   kd = fmaf(e.ky, dy, kd);
   kd = fmaf(e.kz, dz, kd);
   a = fmaf(t, kd, a);
+  o.len = t;
+  o.act = a;
+  o.dsd = ksk;
+  return o;
+}
+
+// A = diag(a0, a1, a2) (the user's per-axis sigmas, Aggregation.py:169-172): pair_eval's result on such a form, bit for bit,
+// without the nine coefficients that are zero -- the general chain's fmaf(0, q, x) / fmaf(t, 0, x) steps return x exactly for
+// finite operands, b = A mu is (a0 mx, a1 my, a2 mz) exactly, and three equal axes take pair_eval_iso like make_eval's flag says.
+__device__ __forceinline__ PairOut pair_eval_diag(const float mx, const float my, const float mz, const float a0, const float a1,
+                                                  const float a2, const float dx, const float dy, const float dz) {
+  const float qxx = dx * dx, qyy = dy * dy, qzz = dz * dz;
+  if (a0 == a1 && a0 == a2) return pair_eval_iso(mx, my, mz, a0, dx, dy, dz, qxx, qyy, qzz);
+  PairOut o;
+  float ksk = a0 * qxx;
+  ksk = fmaf(a1, qyy, ksk);
+  ksk = fmaf(a2, qzz, ksk);
+  float msk = (a0 * mx) * dx;
+  msk = fmaf(a1 * my, dy, msk);
+  msk = fmaf(a2 * mz, dz, msk);
+  const float t = fast_div(msk, ksk) + 0.0f;  // +0 canonicalises -0
+  const float vx = fmaf(-t, dx, mx);
+  const float vy = fmaf(-t, dy, my);
+  const float vz = fmaf(-t, dz, mz);
+  float a = a0 * (vx * vx);
+  a = fmaf(a1, vy * vy, a);
+  a = fmaf(a2, vz * vz, a);
   o.len = t;
   o.act = a;
   o.dsd = ksk;

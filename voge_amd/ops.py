@@ -801,10 +801,83 @@ def frame_trace(verts, sigmas, R, T, focal, pp, band, W, behind, thr_act, n_assi
     _tag_index(sel_idx, cnt, B * N)
     lz = LazyComposite.__new__(LazyComposite)
     (lz.mode, lz.sigma_mode, lz.shared, lz.occ, lz.B, lz.N, lz.K, lz.p0, lz.p1, lz.sel_idx, lz.sel_len, lz.cnt, lz.records, lz.rays,
-     lz.rays_version, lz.grad_mode, lz.idx_version, lz.p0_version, lz.frame, lz.hit_len) = (
+     lz.rays_version, lz.grad_mode, lz.idx_version, lz.p0_version, lz.frame, lz.hit_len, lz.gen) = (
         2, int(sigma_mode), shared, float(occ), B, N, K, verts, sigmas, sel_idx, sel_len, cnt, records, rays, 0, torch.is_grad_enabled(),
-        sel_idx._version, verts._version, True, None)
+        sel_idx._version, verts._version, True, None, None)
     return sel_idx, sel_len, lz
+
+
+def _sigma_kind(sigmas):
+    """(kind, shared) of a general sigma tensor: kind 1 = per-axis [.., N, 3], kind 2 = [.., N, 3, 3] (_GeneralPreamble's rule)."""
+    kind = 2 if tuple(sigmas.shape[-2:]) == (3, 3) and sigmas.dim() >= 3 else 1
+    return kind, sigmas.dim() == (3 if kind == 2 else 2)
+
+
+def frame_trace_gen(verts, sigmas, R, T, focal, pp, band, W, behind, thr_act, n_assign, occ, origin_out=None):
+    """frame_trace for (N,3) / (N,3,3) sigmas (voge_frame_trace_fwd_gen): the camera AND the user's own arrays go in -- the record
+    pass centres the vertices and expands 2 * sigma itself (Renderer.py:130-137: no ray launch, no preamble launch, no autograd
+    node).  verts [N,3] | [B,N,3]; sigmas [N,3] | [N,3,3] | [B,N,3] | [B,N,3,3].  -> (sel_idx, sel_len, LazyComposite) with
+    mode 0, lz.gen = (kind, shared_verts, shared_sigmas) and lz.p0 / lz.p1 the USER's tensors: every backward route of such
+    fragments goes through voge_frame_bwd_gen, which hands the gradients to exactly those."""
+    lib = _lib.load()
+    v_c, s_c = _plain(verts, torch.float32, "verts"), _plain(sigmas, torch.float32, "sigmas")
+    R_c, T_c = _plain(R, torch.float32, "R"), _plain(T, torch.float32, "T")
+    f_c, p_c = _plain(focal, torch.float32, "focal_length"), _plain(pp, torch.float32, "principal_point")
+    B = R_c.shape[0]
+    row0, h, stripe_h, pitch = band
+    shared_v = v_c.dim() == 2
+    kind, shared_s = _sigma_kind(s_c)
+    N, K, dev = v_c.shape[-2], int(n_assign), v_c.device
+    assert R_c.shape == (B, 3, 3) and T_c.shape == (B, 3) and f_c.shape == (B, 2) and p_c.shape == (B, 2)
+    assert v_c.shape[-1] == 3 and (shared_v or v_c.shape[0] == B)
+    assert s_c.shape[-(kind + 1)] == N and s_c.shape[-1] == 3 and (shared_s or s_c.shape[0] == B)
+    empty = torch.empty
+    sel_idx = empty((B, h, W, K), dtype=torch.int32, device=dev)
+    sel_len = empty((B, h, W, K), dtype=torch.float32, device=dev)
+    cnt = empty((B, h, W), dtype=torch.int32, device=dev)
+    records = empty((B * N, 8 if kind == 1 else 12), dtype=torch.float32, device=dev)      # (kind 1: the compact per-axis records)
+    rays = empty((B, h, W, 3), dtype=torch.float32, device=dev)
+    with _on(dev):
+        nbytes = lib.voge_trace_workspace_bytes(B, N, h, W)
+        ws = _workspace(dev, nbytes)
+        rc = lib.voge_frame_trace_fwd_gen(v_c.data_ptr(), s_c.data_ptr(), int(shared_v), int(shared_s), kind, R_c.data_ptr(), T_c.data_ptr(),
+                                          f_c.data_ptr(), p_c.data_ptr(), int(row0), int(stripe_h), int(pitch), int(bool(behind)), B, N,
+                                          int(h), int(W), K, float(thr_act), ws.data_ptr(), nbytes, sel_idx.data_ptr(),
+                                          sel_len.data_ptr(), cnt.data_ptr(), records.data_ptr(), rays.data_ptr(), _p(origin_out), _stream())
+    if rc:
+        _lib.check(rc, "voge_frame_trace_fwd_gen")
+    _tag_index(sel_idx, cnt, B * N)
+    lz = LazyComposite(mode=0, sigma_mode=0, shared=False, occ=float(occ), B=B, N=N, K=K, p0=verts, p1=sigmas, sel_idx=sel_idx,
+                       sel_len=sel_len, cnt=cnt, records=records, rays=rays, rays_version=0, grad_mode=torch.is_grad_enabled(),
+                       idx_version=sel_idx._version, p0_version=verts._version, frame=True, gen=(kind, int(shared_v), int(shared_s)))
+    return sel_idx, sel_len, lz
+
+
+def _frame_gen_bwd(lib, lz, form, attr, weight, ad, ln, rgb, wsum, bg, thr, g, gs0, gs1, g_hitlen, acc=None):
+    """voge_frame_bwd_gen on fragments of frame_trace_gen: -> (g_p0, g_p1, g_attr | None), the gradients of the user's verts / sigmas
+    (and attributes).  acc: the accumulator the composite zeroed on its way (good for one call), or None (scratch, filled here)."""
+    lz.check()
+    kind, shared_v, shared_s = lz.gen
+    dev = ln.device
+    B, H, W = lz.cnt.shape
+    K, P = lz.K, lz.B * lz.N
+    g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=dev)
+    g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=dev)
+    g_attr = None if attr is None else torch.empty_like(attr)
+    C, Nattr = (0, 0) if attr is None else (attr.shape[1], attr.shape[0])
+    with _on(dev):
+        zeroed = acc is not None
+        if acc is None:
+            nbytes = lib.voge_frame_bwd_gen_acc_bytes(P)
+            acc = _workspace(dev, nbytes)
+        else:
+            nbytes = acc.numel()
+        rc = lib.voge_frame_bwd_gen(form, _p(lz.records), shared_v, shared_s, kind, _p(lz.rays), _p(attr), _p(lz.sel_idx), _p(lz.cnt),
+                                    _p(weight), _p(ad[0]), _p(ln), _p(ad[1]), _p(rgb), _p(wsum), _p(bg), float(thr), _p(g), gs0, gs1,
+                                    _p(g_hitlen), lz.occ, lz.B, lz.N, B * H, W, K, C, Nattr, _p(acc), nbytes, int(zeroed), _p(g0), _p(g1),
+                                    _p(g_attr), _stream())
+    _lib.check(rc, "voge_frame_bwd_gen")
+    return g0, g1, g_attr
 
 
 class _HitLength(torch.autograd.Function):
@@ -826,6 +899,10 @@ class _HitLength(torch.autograd.Function):
         lib = _lib.load()
         lz = ctx.lz
         lz.check()
+        if lz.gen is not None:      # (general forms: the weights' form with g_weight = NULL -- `weight` is read but multiplies zero)
+            gh = _dev(g_len, torch.float32, "grad_hit_length")
+            g0, g1, _ = _frame_gen_bwd(lib, lz, 2, None, lz.sel_len, (None, None), lz.sel_len, None, None, None, -1.0, None, 0, 0, gh)
+            return g0, g1, None, None
         (p1,) = ctx.saved_tensors
         p1 = _dev(p1, torch.float32, "sigmas")
         ln, sel_idx = lz.sel_len, lz.sel_idx
@@ -853,8 +930,10 @@ def frame_eligible(verts, sigmas, R, T, focal, pp, n_assign, numel):
     """The camera-input frame path: scalar sigmas on the device, fixed cameras, a non-empty band, 32-bit record offsets."""
     if not (LAZY_COMPOSITE and FRAME_PATH) or n_assign > _lib.MAX_K or os.environ.get("VOGE_FRAGMENTS_KEEP_ACT_DSD", "0") == "1":
         return False
-    if not (verts.is_cuda and sigmas.is_cuda and sigmas.dim() == verts.dim() - 1) or numel == 0 or verts.shape[-2] == 0:
+    if not (verts.is_cuda and sigmas.is_cuda) or numel == 0 or verts.shape[-2] == 0:
         return False
+    if sigmas.dim() != verts.dim() - 1 and not (sigmas.dim() >= 2 and sigmas.shape[-1] == 3 and sigmas.dtype == torch.float32):
+        return False      # (scalar sigmas [N] | [B,N], or the general forms [.., N, 3] / [.., N, 3, 3])
     dev = verts.device
     if R.device != dev or T.device != dev or focal.device != dev or pp.device != dev:      # (fixed cameras: cameras.camera_tensors)
         return False
@@ -865,11 +944,12 @@ class LazyComposite:
     """What the deferred composite needs from a _TraceLean call (nothing in it has a grad_fn except sel_len, which the
     composite nodes take as an input)."""
     __slots__ = ("mode", "sigma_mode", "shared", "occ", "B", "N", "K", "p0", "p1", "sel_idx", "sel_len", "cnt", "records", "rays",
-                 "rays_version", "grad_mode", "idx_version", "p0_version", "frame", "hit_len")
+                 "rays_version", "grad_mode", "idx_version", "p0_version", "frame", "hit_len", "gen")
 
     def __init__(self, **kw):
         self.frame = False      # (made by frame_trace: the shade stage may take the frame entries of ABI 7)
-        self.hit_len = None     # (frame_trace: the differentiable alias of sel_len, made when somebody asks for it)
+        self.hit_len = None     # (unused; kept for pickles of round 6's first builds)
+        self.gen = None         # (frame_trace_gen: (kind, shared_verts, shared_sigmas) -- p0 / p1 are the USER's verts / sigmas)
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -886,6 +966,7 @@ class LazyComposite:
 
     def means(self):
         """(general forms) the centres as the trace saw them: contiguous fp32, no grad_fn."""
+        assert self.gen is None, "fragments of frame_trace_gen keep the USER's vertices: their backward reads the records"
         return _dev(self.p0.detach(), torch.float32, "means")
 
     def usable(self):
@@ -914,7 +995,9 @@ class LazyComposite:
     def through(self, weight):
         """Tag freshly composited weights the way fragments() does (a later to_colored_background takes _ShadeThrough).  The
         bookkeeping is filled in when somebody first LOOKS at it (_Through): the frame that never does pays for no detach."""
-        if (self.p0.requires_grad or self.p1.requires_grad) and self.grad_mode:
+        # (fragments of frame_trace_gen carry the user's own verts / sigmas: _ShadeThrough's entry points want the centred means
+        #  and the expanded forms -- such weights stay untagged and a later to_colored_background takes the ordinary nodes)
+        if (self.p0.requires_grad or self.p1.requires_grad) and self.grad_mode and self.gen is None:
             weight.voge_through = _Through(self, weight)
         return weight
 
@@ -948,13 +1031,17 @@ class _Through(dict):
 def _general_act_dsd(lz, sel_len, need):
     """(act, dsd) buffers the general composite fills for its backward (VOGE_GENERAL_KEEP_ACT_DSD=0: none -- the backward
     re-derives them from the packed records, 19 us slower at the cfg3 size); scalar-sigma fragments never keep them."""
-    if lz.mode != 0 or os.environ.get("VOGE_GENERAL_KEEP_ACT_DSD", "1") == "0" or not need:
-        return (None, None)
+    if lz.mode != 0 or os.environ.get("VOGE_GENERAL_KEEP_ACT_DSD", "1") == "0" or not need or (lz.gen is not None and lz.gen[0] == 1):
+        return (None, None)      # (per-axis sigmas on the frame path: re-derived from their 32-byte records, three coefficients)
     return (torch.empty_like(sel_len), torch.empty_like(sel_len))
 
 
 def _lazy_fragment_bwd(lib, lz, p1, weight, ln, g_weight, K, ad=(None, None)):
     """composite + trace backward in one pass for a deferred composite: -> (g_p0, g_p1)."""
+    if lz.gen is not None:
+        gw, gs_pix, gs_k = _grad_weight_layout(g_weight, K)
+        g0, g1, _ = _frame_gen_bwd(lib, lz, 2, None, weight, ad, ln, None, None, None, -1.0, gw, gs_pix, gs_k, None)
+        return g0, g1
     lz.check()
     gw, gs_pix, gs_k = _grad_weight_layout(g_weight, K)
     g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=ln.device)
@@ -988,7 +1075,11 @@ class _CompositeLean(torch.autograd.Function):
         valid = torch.empty(idx.shape[:-1], dtype=torch.int64, device=idx.device)
         with _on(idx.device):
             ctx.ad = _general_act_dsd(lz, sel_len, any(ctx.needs_input_grad))
-            if lz.mode == 0:
+            if lz.gen is not None:
+                rc = lib.voge_frame_shade_fwd_rec(lz.gen[0], _p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, None, None,
+                                                  -1.0, idx.numel() // K, K, 0, 0, _p(weight), _p(valid), None, None, None, _p(ctx.ad[0]),
+                                                  _p(ctx.ad[1]), None, 0, _stream())
+            elif lz.mode == 0:
                 rc = lib.voge_composite_fwd_rec(_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, idx.numel() // K,
                                                 K, _p(weight), _p(valid), _p(ctx.ad[0]), _p(ctx.ad[1]), _stream())
             else:
@@ -1034,13 +1125,16 @@ class _CompositeShade(torch.autograd.Function):
         # (round 6) fragments of the camera-input trace: the accumulator of the coming backward is allocated here and this launch
         # zeroes it on its way -- no fill launch in front of that backward (voge_frame_shade_bwd_iso)
         ctx.gbuf = None
-        if lz.frame and lz.mode != 0 and any(ctx.needs_input_grad[:3]) and K <= 128 and FRAME_DIRECT_BWD:
-            ctx.gbuf = torch.empty((lz.B * lz.N * 32,), dtype=torch.uint8, device=idx.device)
+        if lz.frame and any(ctx.needs_input_grad[:3]) and K <= 128 and FRAME_DIRECT_BWD:
+            ctx.gbuf = torch.empty((lz.B * lz.N * (32 if lz.gen is None else (48 if lz.gen[0] == 1 else 64)),), dtype=torch.uint8, device=idx.device)
         with _on(idx.device):
             ctx.ad = _general_act_dsd(lz, sel_len, any(ctx.needs_input_grad))
             args = (_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c), _p(bg_c), float(thr),
                     idx.numel() // K, K, C, Nattr, _p(weight), _p(valid), _p(rgb), _p(img), _p(wsum))
-            if lz.mode == 0:
+            if lz.gen is not None:
+                rc = lib.voge_frame_shade_fwd_rec(lz.gen[0], *args, _p(ctx.ad[0]), _p(ctx.ad[1]), _p(ctx.gbuf),
+                                                  0 if ctx.gbuf is None else ctx.gbuf.numel(), _stream())
+            elif lz.mode == 0:
                 rc = lib.voge_composite_shade_fwd_rec(*args, _p(ctx.ad[0]), _p(ctx.ad[1]), _stream())
             elif ctx.gbuf is not None:
                 rc = lib.voge_frame_shade_fwd_iso(*args, _p(ctx.gbuf), ctx.gbuf.numel(), _stream())
@@ -1070,7 +1164,9 @@ class _CompositeShade(torch.autograd.Function):
             else:
                 go, gs_pix, gs_c = _dev(g_img, torch.float32, "grad_image"), C, 1
             gbuf, ctx.gbuf = ctx.gbuf, None      # (zeroed by the forward, good for ONE backward: a second one takes the scratch form)
-            if gbuf is not None:
+            if lz.gen is not None:      # (general forms of the frame path: the user's verts / sigmas get their gradients directly)
+                g0, g1, g_attr = _frame_gen_bwd(lib, lz, 0, attr, weight, ctx.ad, ln, rgb, wsum, bg, ctx.thr, go, gs_pix, gs_c, None, acc=gbuf)
+            elif gbuf is not None:
                 g_attr = torch.empty_like(attr)
                 g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=idx.device)
                 g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=idx.device)
@@ -1123,14 +1219,17 @@ class _CompositeMerge(torch.autograd.Function):
         valid = torch.empty(idx.shape[:-1], dtype=torch.int64, device=idx.device)
         rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
         wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
-        ctx.gbuf = None      # (see _CompositeShade: the frame path's one-launch backward)
-        if lz.frame and lz.mode != 0 and any(ctx.needs_input_grad[:3]) and K <= 128 and FRAME_DIRECT_BWD:
-            ctx.gbuf = torch.empty((lz.B * lz.N * 32,), dtype=torch.uint8, device=idx.device)
+        ctx.gbuf = None      # (see _CompositeShade: the frame path's backward without a fill launch)
+        if lz.frame and any(ctx.needs_input_grad[:3]) and K <= 128 and FRAME_DIRECT_BWD:
+            ctx.gbuf = torch.empty((lz.B * lz.N * (32 if lz.gen is None else (48 if lz.gen[0] == 1 else 64)),), dtype=torch.uint8, device=idx.device)
         with _on(idx.device):
             ctx.ad = _general_act_dsd(lz, sel_len, any(ctx.needs_input_grad))
             args = (_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c), None, -1.0, idx.numel() // K, K,
                     C, Nattr, _p(weight), _p(valid), _p(rgb), None, _p(wsum))
-            if lz.mode == 0:
+            if lz.gen is not None:
+                rc = lib.voge_frame_shade_fwd_rec(lz.gen[0], *args, _p(ctx.ad[0]), _p(ctx.ad[1]), _p(ctx.gbuf),
+                                                  0 if ctx.gbuf is None else ctx.gbuf.numel(), _stream())
+            elif lz.mode == 0:
                 rc = lib.voge_composite_shade_fwd_rec(*args, _p(ctx.ad[0]), _p(ctx.ad[1]), _stream())
             elif ctx.gbuf is not None:
                 rc = lib.voge_frame_shade_fwd_iso(*args, _p(ctx.gbuf), ctx.gbuf.numel(), _stream())
@@ -1163,7 +1262,9 @@ class _CompositeMerge(torch.autograd.Function):
                 go, gs_pix, gs_c = _dev(g_rgb, torch.float32, "grad_out"), C, 1
             gws = None if g_wsum is None else _dev(g_wsum, torch.float32, "grad_weight_sum")
             gbuf, ctx.gbuf = ctx.gbuf, None      # (zeroed by the forward, good for ONE backward)
-            if gbuf is not None:
+            if lz.gen is not None:
+                g0, g1, g_attr = _frame_gen_bwd(lib, lz, 1, attr, weight, ctx.ad, ln, None, gws, None, -1.0, go, gs_pix, gs_c, None, acc=gbuf)
+            elif gbuf is not None:
                 g_attr = torch.empty_like(attr)
                 g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=idx.device)
                 g1 = torch.empty(lz.p1.shape, dtype=torch.float32, device=idx.device)
