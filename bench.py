@@ -723,7 +723,7 @@ def main():
                                      acc=torch.empty(N * 32, dtype=torch.uint8, device=dev)),
                         lambda s: lib.voge_frame_shade_fwd_iso(P_(s["i"]), P_(s["c"]), P_(s["l"]), P_(recs), P_(rays), 1.0, P_(colors),
                                                                P_(bg), -1.0, npix, K, 3, N, P_(s["w"]), P_(s["v"]), P_(s["rgb"]),
-                                                               P_(s["img"]), P_(s["ws"]), P_(s["acc"]), N * 32, st))
+                                                               P_(s["img"]), P_(s["ws"]), None, P_(s["acc"]), N * 32, st))
                     # (the accumulator is not re-zeroed between the timed calls: the kernel adds to whatever is there -- same work)
                     stage_defs["frame_shade_bwd"] = (
                         lambda: dict(i=C_(idx), c=C_(cnt), w=C_(w), l=C_(sel[1]), rgb=C_(rgb), ws=C_(wsum), g=torch.ones_like(rgb),

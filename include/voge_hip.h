@@ -329,7 +329,11 @@ int voge_fragment_shade_bwd_iso(const float *records, const float *sigmas, int s
  * voge_frame_shade_fwd_iso   = voge_composite_shade_fwd_iso (aggregation + merge_final + get_silhouette +
  *   to_colored_background, Aggregation.py:82-141, Renderer.py:157-171; img = bg = NULL: interpolate_attr + the weight sum)
  *   that ALSO zeroes bwd_acc [bwd_acc_bytes, a multiple of 16, 16-byte aligned; NULL: nothing] on its way: the accumulator
- *   of the backward below (voge_frame_bwd_acc_bytes(B * N)), so that no fill launch stands in front of it.
+ *   of the backward below (voge_frame_bwd_acc_bytes(B * N)), so that no fill launch stands in front of it -- and writes
+ *   sil [npix] = min(sum_k w_k, 1) (get_silhouette, Renderer.py:157-159; NULL: not wanted) with the sum it has in hand: the
+ *   reference's training pattern (interpolate_attr + get_silhouette, demo/ShapeFitting.py:217-222) is this ONE launch, and its
+ *   backward ONE call: voge_frame_merge_bwd_iso with wsum_fwd = the forward's wsum takes g_wsum as the SILHOUETTE's gradient
+ *   (passed on like torch.minimum's: all below 1, half at a tie, none above; wsum_fwd = NULL: g_wsum is the sum's own gradient).
  * voge_frame_shade_bwd_iso / voge_frame_merge_bwd_iso   = voge_fragment_shade_bwd_iso / voge_fragment_merge_bwd_iso for
  *   fragments that keep no act / dsd, taking that accumulator -- ZEROED, good for one call -- in place of a scratch they would
  *   have to fill first: the fused kernel + the finishing pass.  (Adding the per-Gaussian sums straight into the gradient
@@ -344,7 +348,7 @@ int voge_frame_trace_fwd_iso(const float *verts, const float *sigmas, int shared
 int voge_frame_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                              const float *rays, float occ, const float *colors, const float *bg, float thr,
                              long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
-                             float *rgb, float *img, float *wsum, void *bwd_acc, size_t bwd_acc_bytes,
+                             float *rgb, float *img, float *wsum, float *sil, void *bwd_acc, size_t bwd_acc_bytes,
                              voge_stream_t stream);
 int voge_frame_shade_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
                              const float *rays, const float *colors, const int32_t *idx, const int32_t *cnt,
@@ -355,9 +359,9 @@ int voge_frame_shade_bwd_iso(const float *records, const float *sigmas, int shar
 int voge_frame_merge_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
                              const float *rays, const float *attr, const int32_t *idx, const int32_t *cnt,
                              const float *weight, const float *len, const float *g_rgb, long g_stride_pix,
-                             long g_stride_c, const float *g_wsum, float occ, int B, int N, long nrows, int W, int K,
-                             int C, long Nattr, void *acc_zeroed, size_t acc_bytes, float *g_verts, float *g_sigmas,
-                             float *g_attr, voge_stream_t stream);
+                             long g_stride_c, const float *g_wsum, const float *wsum_fwd, float occ, int B, int N, long nrows,
+                             int W, int K, int C, long Nattr, void *acc_zeroed, size_t acc_bytes, float *g_verts,
+                             float *g_sigmas, float *g_attr, voge_stream_t stream);
 
 /*
  * ABI 7, the frame path for (N,3) / (N,3,3) sigmas (Renderer.py:130-137 with Aggregation.py:144-175: A = 2 expend_sigma(sigmas);
@@ -382,7 +386,7 @@ int voge_frame_trace_fwd_gen(const float *verts, const float *sigmas, int shared
 int voge_frame_shade_fwd_rec(int kind, int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                              const float *rays, float occ, const float *colors, const float *bg, float thr,
                              long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
-                             float *rgb, float *img, float *wsum, float *act, float *dsd, void *bwd_acc,
+                             float *rgb, float *img, float *wsum, float *sil, float *act, float *dsd, void *bwd_acc,
                              size_t bwd_acc_bytes, voge_stream_t stream);
 int voge_frame_bwd_gen(int form, const float *records, int shared_verts, int shared_sigmas, int kind, const float *rays,
                        const float *attr, const int32_t *idx, const int32_t *cnt, const float *weight, const float *act,

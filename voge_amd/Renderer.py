@@ -296,7 +296,7 @@ def interpolate_attr(fragments: Fragments, vert_attr: torch.Tensor):
         out = ops.composite_merge(lz, vert_attr)
         if out is not None:
             fragments._set_composite(out[2], out[3])
-            fragments._wsum = (out[1], out[2], out[2]._version)
+            fragments._wsum = (out[1], out[2], out[2]._version, out[4])
             return out[0]
     return merge_final(vert_attr=vert_attr, weight=fragments.vert_weight, valid_num=fragments.valid_num,
                        vert_assign=fragments.vert_index)
@@ -305,6 +305,8 @@ def interpolate_attr(fragments: Fragments, vert_attr: torch.Tensor):
 def get_silhouette(fragments: Fragments):
     ws = getattr(fragments, "_wsum", None)
     if ws is not None and ws[1] is fragments._vert_weight and ws[1]._version == ws[2]:
+        if ws[3] is not None:      # (frame path: the composite wrote min(sum_k w_k, 1) itself -- an output of the same node as the merge)
+            return ws[3]
         # the weight sum the one-pass composite + merge left behind: min(sum_k w_k, 1) exactly as Renderer.py:157-159
         # (torch.minimum splits the gradient at a tie like torch.min(a, b))
         return torch.minimum(ws[0], torch.ones_like(ws[0]))

@@ -45,17 +45,17 @@ SIGNATURES = {
     "voge_frame_trace_fwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 4 + [_c_int] * 9
                                  + [_c_float, _c_void_p, _c_size_t] + [_c_void_p] * 7),
     "voge_frame_shade_fwd_iso": (_c_int, [_c_void_p] * 5 + [_c_float, _c_void_p, _c_void_p, _c_float, _c_long, _c_int, _c_int, _c_long]
-                                 + [_c_void_p] * 6 + [_c_size_t, _c_void_p]),
+                                 + [_c_void_p] * 7 + [_c_size_t, _c_void_p]),
     "voge_frame_shade_bwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 9 + [_c_float, _c_void_p, _c_long, _c_long, _c_float]
                                  + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),
-    "voge_frame_merge_bwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 7 + [_c_long, _c_long, _c_void_p, _c_float]
+    "voge_frame_merge_bwd_iso": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 7 + [_c_long, _c_long, _c_void_p, _c_void_p, _c_float]
                                  + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t] + [_c_void_p] * 4),
     "voge_frame_bwd_acc_bytes": (_c_size_t, [_c_int]),
     "voge_frame_bwd_gen_acc_bytes": (_c_size_t, [_c_int]),
     "voge_frame_trace_fwd_gen": (_c_int, [_c_void_p] * 2 + [_c_int] * 3 + [_c_void_p] * 4 + [_c_int] * 9
                                  + [_c_float, _c_void_p, _c_size_t] + [_c_void_p] * 7),
     "voge_frame_shade_fwd_rec": (_c_int, [_c_int] + [_c_void_p] * 5 + [_c_float, _c_void_p, _c_void_p, _c_float, _c_long, _c_int, _c_int, _c_long]
-                                 + [_c_void_p] * 8 + [_c_size_t, _c_void_p]),
+                                 + [_c_void_p] * 9 + [_c_size_t, _c_void_p]),
     "voge_frame_bwd_gen": (_c_int, [_c_int, _c_void_p] + [_c_int] * 3 + [_c_void_p] * 11 + [_c_float, _c_void_p, _c_long, _c_long, _c_void_p, _c_float]
                            + [_c_int, _c_int, _c_long, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_size_t, _c_int] + [_c_void_p] * 4),
     "voge_fragment_bwd_workspace_bytes": (_c_size_t, [_c_int]),

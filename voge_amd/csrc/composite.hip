@@ -358,6 +358,7 @@ struct CompShade {
   // in every thread the zeroing cost 1.3 us)
   float4 *zero_p = nullptr;
   long zero_n4 = 0;
+  float *sil = nullptr;      // (round 6) NULL | [npix]: get_silhouette = min(sum_k w_k, 1) (Renderer.py:157-159), written with the sum
 };
 // GEN (forward from the records): the records are the general path's packed (mu, A), three float4 per Gaussian
 // (voge_trace_lean_fwd); act / dsd come from make_eval + pair_eval, the operations of the sweep's own epilogue.
@@ -429,6 +430,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
         if (!BWD && q == 0) valid_num[pix] = 0;
         if (SC > 0 && q == 0) {      // nothing was hit: the background
           sh.wsum[pix] = 0.0f;
+          if (sh.sil != nullptr) sh.sil[pix] = 0.0f;
 #pragma unroll
           for (int c = 0; c < SC; ++c) {
             sh.rgb[pix * SC + c] = 0.0f;
@@ -676,6 +678,7 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
           float sil = fminf(ws, 1.0f);
           if (sh.thr > 0.0f) sil = sil > sh.thr ? 1.0f : 0.0f;
           sh.wsum[pix] = ws;
+          if (sh.sil != nullptr) sh.sil[pix] = fminf(ws, 1.0f);
 #pragma unroll
           for (int c = 0; c < SC; ++c) {
             sh.rgb[pix * SC + c] = part[c];
@@ -1077,7 +1080,7 @@ static int composite_shade_fwd_impl(const int gen /* 0: (mu, a) records; 1: pack
                                     const float *rays, float occ, const float *colors, const float *bg, float thr,
                                     long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
                                     float *rgb, float *img, float *wsum, voge_stream_t stream, float *act_out = nullptr,
-                                    float *dsd_out = nullptr, void *zero_p = nullptr, size_t zero_bytes = 0) {
+                                    float *dsd_out = nullptr, void *zero_p = nullptr, size_t zero_bytes = 0, float *sil = nullptr) {
   if ((act_out == nullptr) != (dsd_out == nullptr)) return VOGE_ERR_BAD_ARG;
   if (zero_bytes > 0 && (!zero_p || C == 0 || (zero_bytes & 15) || (reinterpret_cast<uintptr_t>(zero_p) & 15))) return VOGE_ERR_BAD_ARG;
   if (npix < 0 || K <= 0 || Nattr < 0) return VOGE_ERR_BAD_ARG;
@@ -1099,6 +1102,7 @@ static int composite_shade_fwd_impl(const int gen /* 0: (mu, a) records; 1: pack
   const size_t ldsn = compn_lds_bytes(K, NS, false, tn, true);
   const bool small = (double)npix * K < (double)(1l << 30);
   CompShade sh{colors, bg, thr, Nattr, rgb, img, wsum, idx};
+  sh.sil = C > 0 ? sil : nullptr;
   if (zero_bytes > 0) {
     sh.zero_p = reinterpret_cast<float4 *>(zero_p); sh.zero_n4 = (long)(zero_bytes / 16);
     if ((long)gridn.x * tn < sh.zero_n4) {      // (more to zero than the launch has threads: a fill of its own, once in a blue moon)
@@ -1140,13 +1144,13 @@ extern "C" int voge_composite_shade_fwd_iso(int32_t *idx, const int32_t *cnt, co
 extern "C" int voge_frame_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                                         const float *rays, float occ, const float *colors, const float *bg, float thr,
                                         long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
-                                        float *rgb, float *img, float *wsum, void *bwd_acc, size_t bwd_acc_bytes,
+                                        float *rgb, float *img, float *wsum, float *sil, void *bwd_acc, size_t bwd_acc_bytes,
                                         voge_stream_t stream) {
   if (C != 3 && C != 4) return VOGE_ERR_K_TOO_LARGE;
   if (bwd_acc == nullptr) bwd_acc_bytes = 0;
   if (npix == 0) return bwd_acc_bytes ? (int)voge_fill_async(bwd_acc, 0, bwd_acc_bytes, (hipStream_t)stream) : 0;      // (no launch to ride on)
   return composite_shade_fwd_impl(0, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
-                                  rgb, img, wsum, stream, nullptr, nullptr, bwd_acc, bwd_acc_bytes);
+                                  rgb, img, wsum, stream, nullptr, nullptr, bwd_acc, bwd_acc_bytes, sil);
 }
 
 // ... and for the general forms (records = the packed (mu, A) of voge_frame_trace_fwd_gen / voge_trace_lean_fwd; act / dsd kept
@@ -1154,14 +1158,14 @@ extern "C" int voge_frame_shade_fwd_iso(int32_t *idx, const int32_t *cnt, const 
 extern "C" int voge_frame_shade_fwd_rec(int kind, int32_t *idx, const int32_t *cnt, const float *len, const float *records,
                                         const float *rays, float occ, const float *colors, const float *bg, float thr,
                                         long npix, int K, int C, long Nattr, float *weight, int64_t *valid_num,
-                                        float *rgb, float *img, float *wsum, float *act, float *dsd, void *bwd_acc,
+                                        float *rgb, float *img, float *wsum, float *sil, float *act, float *dsd, void *bwd_acc,
                                         size_t bwd_acc_bytes, voge_stream_t stream) {
   if (C != 0 && C != 3 && C != 4) return VOGE_ERR_K_TOO_LARGE;      // (C = 0: the weights alone -- voge_composite_fwd_rec's form)
   if (kind != 1 && kind != 2) return VOGE_ERR_BAD_ARG;
   if (bwd_acc == nullptr || C == 0) bwd_acc_bytes = 0;
   if (npix == 0) return bwd_acc_bytes ? (int)voge_fill_async(bwd_acc, 0, bwd_acc_bytes, (hipStream_t)stream) : 0;
   return composite_shade_fwd_impl(kind == 1 ? 2 : 1, idx, cnt, len, records, rays, occ, colors, bg, thr, npix, K, C, Nattr, weight, valid_num,
-                                  rgb, img, wsum, stream, act, dsd, bwd_acc, bwd_acc_bytes);
+                                  rgb, img, wsum, stream, act, dsd, bwd_acc, bwd_acc_bytes, sil);
 }
 
 // The same two for the general path: records = the packed (mu, A) [B*N][12] of voge_trace_lean_fwd.

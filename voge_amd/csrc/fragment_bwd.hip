@@ -231,6 +231,8 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
       if (bg != nullptr) {
 #pragma unroll
         for (int c = 0; c < C; ++c) px_rgb[c] = at_bytes<float>(rgb, pix * (OffT)(4 * C) + (OffT)(4 * c));
+      } else if (rgb != nullptr) {      // (merge form, round 6: `rgb` = the forward's weight sums [pix], `wsum` = the SILHOUETTE's gradient)
+        px_rgb[0] = at_bytes<float>(rgb, pix * (OffT)4);
       }
     }
     // ---- second wave of requests: what the slots' Gaussians carry (records, colours), at clamped ids ----
@@ -304,6 +306,9 @@ fragment_bwd_kernel(const float4 *__restrict__ rec, const float *__restrict__ ra
 #pragma unroll
       for (int c = 0; c < C; ++c) gr[c] = px_g[c];
       if (wsum != nullptr) g_sum_w = px_ws;
+      // (get_silhouette = min(sum w, 1) behind the same fragments: its gradient passes like torch.minimum's -- all of it below 1,
+      //  half at a tie, none above)
+      if (rgb != nullptr) g_sum_w *= (px_rgb[0] < 1.0f ? 1.0f : (px_rgb[0] == 1.0f ? 0.5f : 0.0f));
     } else if (SRC == 0 && on) {
       const float ws = px_ws;
       float sil = fminf(ws, 1.0f);
@@ -803,7 +808,9 @@ static int frame_bwd_impl(const bool merge, const float *records, const float *s
   if (Nattr * C >= (1l << 30) || P >= (1 << 26)) return VOGE_ERR_BAD_ARG;      // 32-bit byte offsets of the gathers
   float *acc = reinterpret_cast<float *>(acc_zeroed);
   // (merge form: bg = NULL selects it inside the kernel; its `wsum` operand carries g_wsum)
-  const FbArgs a{reinterpret_cast<const float4 *>(records), rays, colors, idx, cnt, weight, nullptr, len, nullptr, merge ? nullptr : rgb, wsum,
+  // (merge form: bg = NULL selects it inside the kernel; its `wsum` operand carries g_wsum -- or, with `rgb` = the forward's weight
+  //  sums, the silhouette's gradient)
+  const FbArgs a{reinterpret_cast<const float4 *>(records), rays, colors, idx, cnt, weight, nullptr, len, nullptr, rgb, wsum,
                  merge ? nullptr : bg, merge ? -1.0f : thr, g, g_stride_pix, g_stride_c, nullptr, occ, P, nrows, W, K, Nattr, acc};
   fb_launch_shade<true>(a, C, st);
   const long n_fin = (Nattr > P) ? Nattr : P;
@@ -825,10 +832,10 @@ extern "C" int voge_frame_shade_bwd_iso(const float *records, const float *sigma
 extern "C" int voge_frame_merge_bwd_iso(const float *records, const float *sigmas, int shared, int sigma_mode,
                                         const float *rays, const float *attr, const int32_t *idx, const int32_t *cnt,
                                         const float *weight, const float *len, const float *g_rgb, long g_stride_pix,
-                                        long g_stride_c, const float *g_wsum, float occ, int B, int N, long nrows, int W, int K,
-                                        int C, long Nattr, void *acc_zeroed, size_t acc_bytes, float *g_verts, float *g_sigmas,
-                                        float *g_attr, voge_stream_t stream) {
-  return frame_bwd_impl(true, records, sigmas, shared, sigma_mode, rays, attr, idx, cnt, weight, len, nullptr, g_wsum, nullptr, -1.0f, g_rgb,
+                                        long g_stride_c, const float *g_wsum, const float *wsum_fwd, float occ, int B, int N, long nrows,
+                                        int W, int K, int C, long Nattr, void *acc_zeroed, size_t acc_bytes, float *g_verts,
+                                        float *g_sigmas, float *g_attr, voge_stream_t stream) {
+  return frame_bwd_impl(true, records, sigmas, shared, sigma_mode, rays, attr, idx, cnt, weight, len, wsum_fwd, g_wsum, nullptr, -1.0f, g_rgb,
                         g_stride_pix, g_stride_c, occ, B, N, nrows, W, K, C, Nattr, acc_zeroed, acc_bytes, g_verts, g_sigmas, g_attr, stream);
 }
 
@@ -838,7 +845,7 @@ extern "C" int voge_frame_merge_bwd_iso(const float *records, const float *sigma
 // (Renderer.py:130-137 backwards: the sum over the views of a shared set; d A / d sigma = 2 on the diagonal for per-axis sigmas,
 // 2 everywhere for [3][3] ones) -- no general_preamble_bwd launch behind it.
 //   form 0: the image's gradient (to_colored_background: rgb, wsum, bg, thr, g = g_img);   form 1: merge_final's (interpolate_attr:
-//   g = g_rgb, wsum = g_wsum | NULL);   form 2: the weights' own (g = g_weight with strides, g_hitlen | NULL; C = 0, no attr).
+//   g = g_rgb, wsum = g_wsum | NULL -- or, with rgb = the forward's weight sums [pix], the gradient of get_silhouette);   form 2: the weights' own (g = g_weight with strides, g_hitlen | NULL; C = 0, no attr).
 __global__ void __launch_bounds__(256)
 fragment_bwd_finish_view_kernel(const float *__restrict__ acc, const int S, const int P, const int N, const int B, const int shared_v,
                                 const int shared_s, const int kind, const int C, const long Nattr, float *__restrict__ g_verts,
@@ -916,7 +923,7 @@ extern "C" int voge_frame_bwd_gen(int form, const float *records, int shared_ver
     if (kind == 1) { if (K <= 128) fb_launch_diag<1, 0, 2>(a, st); else fb_launch_diag<1, 0, 4>(a, st); }
     else fb_launch_gw<false>(a, st);
   } else {
-    const FbArgs a{rec, rays, attr, idx, cnt, weight, act, len, dsd, form == 0 ? rgb : nullptr, wsum, form == 0 ? bg : nullptr,
+    const FbArgs a{rec, rays, attr, idx, cnt, weight, act, len, dsd, rgb /* (form 1: NULL | the forward's weight sums) */, wsum, form == 0 ? bg : nullptr,
                    form == 0 ? thr : -1.0f, g, g_stride0, g_stride1, nullptr, occ, P, nrows, W, K, Nattr, accf};
     if (kind == 1) {
       switch (C) {

@@ -1077,8 +1077,8 @@ class _CompositeLean(torch.autograd.Function):
             ctx.ad = _general_act_dsd(lz, sel_len, any(ctx.needs_input_grad))
             if lz.gen is not None:
                 rc = lib.voge_frame_shade_fwd_rec(lz.gen[0], _p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, None, None,
-                                                  -1.0, idx.numel() // K, K, 0, 0, _p(weight), _p(valid), None, None, None, _p(ctx.ad[0]),
-                                                  _p(ctx.ad[1]), None, 0, _stream())
+                                                  -1.0, idx.numel() // K, K, 0, 0, _p(weight), _p(valid), None, None, None, None,
+                                                  _p(ctx.ad[0]), _p(ctx.ad[1]), None, 0, _stream())
             elif lz.mode == 0:
                 rc = lib.voge_composite_fwd_rec(_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, idx.numel() // K,
                                                 K, _p(weight), _p(valid), _p(ctx.ad[0]), _p(ctx.ad[1]), _stream())
@@ -1132,12 +1132,12 @@ class _CompositeShade(torch.autograd.Function):
             args = (_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c), _p(bg_c), float(thr),
                     idx.numel() // K, K, C, Nattr, _p(weight), _p(valid), _p(rgb), _p(img), _p(wsum))
             if lz.gen is not None:
-                rc = lib.voge_frame_shade_fwd_rec(lz.gen[0], *args, _p(ctx.ad[0]), _p(ctx.ad[1]), _p(ctx.gbuf),
+                rc = lib.voge_frame_shade_fwd_rec(lz.gen[0], *args, None, _p(ctx.ad[0]), _p(ctx.ad[1]), _p(ctx.gbuf),
                                                   0 if ctx.gbuf is None else ctx.gbuf.numel(), _stream())
             elif lz.mode == 0:
                 rc = lib.voge_composite_shade_fwd_rec(*args, _p(ctx.ad[0]), _p(ctx.ad[1]), _stream())
             elif ctx.gbuf is not None:
-                rc = lib.voge_frame_shade_fwd_iso(*args, _p(ctx.gbuf), ctx.gbuf.numel(), _stream())
+                rc = lib.voge_frame_shade_fwd_iso(*args, None, _p(ctx.gbuf), ctx.gbuf.numel(), _stream())
             else:
                 rc = lib.voge_composite_shade_fwd_iso(*args, _stream())
         _lib.check(rc, "voge_composite_shade_fwd")
@@ -1219,6 +1219,9 @@ class _CompositeMerge(torch.autograd.Function):
         valid = torch.empty(idx.shape[:-1], dtype=torch.int64, device=idx.device)
         rgb = torch.empty(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
         wsum = torch.empty(idx.shape[:-1], dtype=torch.float32, device=idx.device)
+        # (frame path: the composite writes get_silhouette = min(weight sum, 1) next to the sum, a differentiable OUTPUT of this
+        #  node -- the training pattern's silhouette costs no launch forward and none backward: see backward)
+        sil = torch.empty_like(wsum) if lz.frame else None
         ctx.gbuf = None      # (see _CompositeShade: the frame path's backward without a fill launch)
         if lz.frame and any(ctx.needs_input_grad[:3]) and K <= 128 and FRAME_DIRECT_BWD:
             ctx.gbuf = torch.empty((lz.B * lz.N * (32 if lz.gen is None else (48 if lz.gen[0] == 1 else 64)),), dtype=torch.uint8, device=idx.device)
@@ -1226,33 +1229,42 @@ class _CompositeMerge(torch.autograd.Function):
             ctx.ad = _general_act_dsd(lz, sel_len, any(ctx.needs_input_grad))
             args = (_p(idx), _p(lz.cnt), _p(sel_len), _p(lz.records), _p(lz.rays), lz.occ, _p(attr_c), None, -1.0, idx.numel() // K, K,
                     C, Nattr, _p(weight), _p(valid), _p(rgb), None, _p(wsum))
+            nacc = 0 if ctx.gbuf is None else ctx.gbuf.numel()
             if lz.gen is not None:
-                rc = lib.voge_frame_shade_fwd_rec(lz.gen[0], *args, _p(ctx.ad[0]), _p(ctx.ad[1]), _p(ctx.gbuf),
-                                                  0 if ctx.gbuf is None else ctx.gbuf.numel(), _stream())
+                rc = lib.voge_frame_shade_fwd_rec(lz.gen[0], *args, _p(sil), _p(ctx.ad[0]), _p(ctx.ad[1]), _p(ctx.gbuf), nacc, _stream())
             elif lz.mode == 0:
                 rc = lib.voge_composite_shade_fwd_rec(*args, _p(ctx.ad[0]), _p(ctx.ad[1]), _stream())
-            elif ctx.gbuf is not None:
-                rc = lib.voge_frame_shade_fwd_iso(*args, _p(ctx.gbuf), ctx.gbuf.numel(), _stream())
+            elif lz.frame:
+                rc = lib.voge_frame_shade_fwd_iso(*args, _p(sil), _p(ctx.gbuf), nacc, _stream())
             else:
                 rc = lib.voge_composite_shade_fwd_iso(*args, _stream())
         _lib.check(rc, "voge_composite_shade_fwd")
         weight.voge_act_dsd = ctx.ad
-        ctx.save_for_backward(attr_c, _dev(p1, torch.float32, "sigmas"), sel_len, weight)
+        ctx.save_for_backward(attr_c, _dev(p1, torch.float32, "sigmas"), sel_len, weight, wsum)
         ctx.lz = lz
         ctx.mark_non_differentiable(valid)
         ctx.set_materialize_grads(False)
-        return rgb, wsum, weight, valid
+        return rgb, wsum, weight, valid, sil
 
     @staticmethod
-    def backward(ctx, g_rgb, g_wsum, g_weight, _g_valid):
+    def backward(ctx, g_rgb, g_wsum, g_weight, _g_valid, g_sil=None):
         lib = _lib.load()
-        attr, p1, ln, weight = ctx.saved_tensors
+        attr, p1, ln, weight, wsum = ctx.saved_tensors
         lz = ctx.lz
         lz.check()
         idx = lz.sel_idx
         B, H, W, K = idx.shape
         Nattr, C = attr.shape
         g_attr = g0 = g1 = None
+        # the silhouette's gradient: handed to the fused kernel as it is (with the forward's sums, which say where min(sum, 1)
+        # passes it on) when that kernel runs on the forward's accumulator; any other combination turns it into the sum's own
+        wsum_fwd = None
+        if g_sil is not None:
+            if g_wsum is None and (ctx.gbuf is not None or lz.gen is not None):
+                g_wsum, wsum_fwd = g_sil, wsum
+            else:
+                passed = g_sil * torch.where(wsum < 1, 1.0, torch.where(wsum == 1, 0.5, 0.0))
+                g_wsum = passed if g_wsum is None else g_wsum + passed
         if g_rgb is not None or g_wsum is not None:
             if g_rgb is None:
                 g_rgb = torch.zeros(idx.shape[:-1] + (C,), dtype=torch.float32, device=idx.device)
@@ -1263,7 +1275,7 @@ class _CompositeMerge(torch.autograd.Function):
             gws = None if g_wsum is None else _dev(g_wsum, torch.float32, "grad_weight_sum")
             gbuf, ctx.gbuf = ctx.gbuf, None      # (zeroed by the forward, good for ONE backward)
             if lz.gen is not None:
-                g0, g1, g_attr = _frame_gen_bwd(lib, lz, 1, attr, weight, ctx.ad, ln, None, gws, None, -1.0, go, gs_pix, gs_c, None, acc=gbuf)
+                g0, g1, g_attr = _frame_gen_bwd(lib, lz, 1, attr, weight, ctx.ad, ln, wsum_fwd, gws, None, -1.0, go, gs_pix, gs_c, None, acc=gbuf)
             elif gbuf is not None:
                 g_attr = torch.empty_like(attr)
                 g0 = torch.empty(lz.p0.shape, dtype=torch.float32, device=idx.device)
@@ -1271,8 +1283,8 @@ class _CompositeMerge(torch.autograd.Function):
                 with _on(idx.device):
                     rc = lib.voge_frame_merge_bwd_iso(
                         _p(lz.records), _p(p1), int(lz.shared), lz.sigma_mode, _p(lz.rays), _p(attr), _p(idx), _p(lz.cnt), _p(weight),
-                        _p(ln), _p(go), gs_pix, gs_c, _p(gws), lz.occ, lz.B, lz.N, B * H, W, K, C, Nattr, _p(gbuf), gbuf.numel(),
-                        _p(g0), _p(g1), _p(g_attr), _stream())
+                        _p(ln), _p(go), gs_pix, gs_c, _p(gws), _p(wsum_fwd), lz.occ, lz.B, lz.N, B * H, W, K, C, Nattr, _p(gbuf),
+                        gbuf.numel(), _p(g0), _p(g1), _p(g_attr), _stream())
                 _lib.check(rc, "voge_frame_merge_bwd_iso")
         if (g_rgb is not None or g_wsum is not None) and g0 is None:
             g_attr = torch.empty_like(attr)
@@ -1307,8 +1319,8 @@ def composite_merge(lz, attr):
     if os.environ.get("VOGE_SHADE_THROUGH", "1") == "0":
         return None
     with lz.grad():
-        rgb, wsum, weight, valid = _CompositeMerge.apply(attr, lz.p0, lz.p1, lz.sel_len, lz)
-    return rgb, wsum, lz.through(weight), valid
+        rgb, wsum, weight, valid, sil = _CompositeMerge.apply(attr, lz.p0, lz.p1, lz.sel_len, lz)
+    return rgb, wsum, lz.through(weight), valid, sil
 
 
 def trace_lean(mode, p0, p1, origin, rays, cam_fwd, thr_act, n_assign, sigma_mode=0, occ=1.0):
