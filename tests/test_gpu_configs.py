@@ -585,12 +585,15 @@ def test_rebuilt_sweep_equals_round_3_sweep_bit_for_bit(hip_lib, N, H, W, K, B, 
         assert np.array_equal(out[0][1][0], out[0][0][0]) and np.array_equal(out[0][1][1], out[0][0][1])
 
 
-@pytest.mark.parametrize("N,H,W,K,B,iso_every", [
-    (3000, 72, 88, 40, 1, 0),       # every Gaussian a full 3x3 form, K = 40, ragged image
-    (1500, 40, 56, 25, 2, 3),       # a third of them isotropic (mixed trips), odd K, two views
-    (70000, 64, 64, 12, 1, 0),      # more than 65536 Gaussians: list entries carry stream positions
+@pytest.mark.parametrize("N,H,W,K,B,iso_every,diag_every", [
+    (3000, 72, 88, 40, 1, 0, 0),       # every Gaussian a full 3x3 form, K = 40, ragged image
+    (1500, 40, 56, 25, 2, 3, 0),       # a third of them isotropic (mixed trips), odd K, two views
+    (70000, 64, 64, 12, 1, 0, 0),      # more than 65536 Gaussians: list entries carry stream positions
+    (3000, 72, 88, 24, 1, 0, 1),       # round 6: every Gaussian a DIAGONAL form (per-axis sigmas): the sweep's diagonal trips
+    (2500, 56, 64, 17, 1, 4, 1),       # ... a quarter of them isotropic among diagonal ones (mixed trips inside all-diagonal chunks)
+    (2500, 56, 64, 16, 2, 5, 2),       # ... diagonal, full and isotropic forms side by side (chunks that are NOT all-diagonal)
 ])
-def test_general_sweep_equals_round_3_general_sweep_bit_for_bit(hip_lib, N, H, W, K, B, iso_every):
+def test_general_sweep_equals_round_3_general_sweep_bit_for_bit(hip_lib, N, H, W, K, B, iso_every, diag_every):
     """Round 5: sweep_iso_kernel<true> -- the scalar kernel's design (fp32 len + 16-bit handle per list entry, float-compare
     commits, SoA-staged records, packed evaluation, exit test every 16) for full 3x3 forms -- against round 3's general sweep,
     trace_fwd_kernel<1, false> (64-bit keys), which lives on in the -DVOGE_AB build: the same index lists, hit counts and the
@@ -601,6 +604,11 @@ def test_general_sweep_equals_round_3_general_sweep_bit_for_bit(hip_lib, N, H, W
     r = rng.uniform(0.03, 0.08, N) * (1.0 if N < 50000 else 0.3)
     L = rng.normal(size=(N, 3, 3)) * 0.35 + np.eye(3)[None]
     S = np.einsum("nij,nkj->nik", L, L) / (r * r / (2 * np.log(1 / 0.6)))[:, None, None]      # SPD, anisotropic
+    if diag_every:      # (per-axis forms: the off-diagonal coefficients exactly zero)
+        ax = rng.uniform(0.5, 2.0, (N, 3)) / (r * r / (2 * np.log(1 / 0.6)))[:, None]
+        D = np.zeros((N, 3, 3))
+        D[:, [0, 1, 2], [0, 1, 2]] = ax
+        S[::diag_every] = D[::diag_every]
     if iso_every:
         S[::iso_every] = np.eye(3)[None] * (1.0 / (r[::iso_every] ** 2 / (2 * np.log(1 / 0.6))))[:, None, None]
     S = S.astype(np.float32)

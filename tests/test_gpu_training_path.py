@@ -714,3 +714,34 @@ def test_every_public_fragments_transformation_is_classified(hip_lib):
     one = frag[1]
     assert ops.hit_count_of(one.vert_index) is None and ops.through_of(one.vert_weight, one.vert_index) is None
     assert torch.equal(one.vert_weight, frag.vert_weight[1]) and list(DROP)
+
+
+def test_duplicate_ids_in_an_edited_list_take_the_elected_kernels(hip_lib, monkeypatch):
+    """the one-pass backward adds a pixel's slots to its table without arbitration -- safe for the lists the trace
+    wrote (a Gaussian sits in a pixel's list once), a race for a list somebody edited so that it holds a Gaussian TWICE.
+    _Fragments.backward sees the edit (the index tensor's version counter) and runs the stand-alone kernels, whose accumulation
+    elects one writer per key: gradients against the oracle chain on the edited list, duplicates summed."""
+    from voge_amd import ops
+    monkeypatch.setenv("VOGE_FRAGMENTS_KEEP_ACT_DSD", "1")      # (the reference's layout: act / dsd as the forward wrote them)
+    verts, sig, _ = random_scene(700, seed=77, lo=0.06, hi=0.14)
+    H, W, K = 32, 40, 10
+    R, T = camera_np.look_at_view_transform(3.1, 5.0, 25.0)
+    rays, origin = camera_np.pixel_rays(R, T, 42.0, (W / 2.0, H / 2.0), (H, W))
+    mus = (verts[None] - origin[:, None].astype(np.float32)).astype(np.float32).reshape(-1, 3)
+    a = (2 * sig).astype(np.float32)
+    tm, ta = t(mus, rg=True), t(a, rg=True)
+    thr_act = oracle.thr_act_of(0.01)
+    weight, idx, valid, ln = ops.fragments(1, tm, ta, None, t(rays), None, thr_act, K)
+    th = weight.voge_through
+    act0, dsd0, len0, idx0 = (n(th[k]).copy() for k in ("act", "dsd", "len", "idx"))
+    full = n(valid)[0] >= 3
+    assert full.sum() > 50
+    with torch.no_grad():      # slot 1 := slot 0's Gaussian wherever a pixel holds three or more: the same id twice per pixel
+        idx[0, :, :, 1] = torch.where(torch.from_numpy(full).to(DEV), idx[0, :, :, 0], idx[0, :, :, 1])
+    g_w = np.random.default_rng(5).normal(size=act0.shape)
+    (weight * t(g_w)).sum().backward()
+    g_act, g_len, g_dsd = oracle.composite_bwd(act0, len0, dsd0, g_w * (idx0 >= 0), 1.0)
+    isg = (a[:, None, None] * np.eye(3, dtype=np.float32)[None]).astype(np.float32)
+    _, g_mu, g_A = oracle.trace_bwd(mus, isg, rays, n(idx), g_len, g_act, g_dsd)
+    grad_close("duplicate ids: means", n(tm.grad), g_mu, TOL)
+    grad_close("duplicate ids: a", n(ta.grad), np.einsum("nii->n", g_A), TOL)

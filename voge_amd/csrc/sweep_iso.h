@@ -551,11 +551,22 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       __syncthreads();
       // (GEN) bit s: staged entry s is a general candidate
       unsigned long long gmask = 0ull;
+      // (GEN, round 6) ... and a DIAGONAL one: s01 = s02 = s12 = 0 and k = 0 (the user's per-axis sigmas, Aggregation.py:169-172).
+      // A trip of four such candidates skips the chain's ten packed operations on those coefficients -- pk_fma(0, q, x) and
+      // pk_fma(t, 0, x) return x for finite operands: the same bits -- and a chunk of nothing else reads five of the eleven
+      // coefficient arrays per trip instead of all of them.
+      unsigned long long dmask = 0ull;
       if (GEN) {
         const float mk = G.e[0][lane];
         gmask = __ballot(lane < nbuf && mk == mk);
         tile_gen = tile_gen || gmask != 0ull;
+        if (gmask != 0ull) {      // (uniform)
+          const bool dg = G.e[2][lane] == 0.0f && G.e[3][lane] == 0.0f && G.e[4][lane] == 0.0f && G.e[8][lane] == 0.0f &&
+                          G.e[9][lane] == 0.0f && G.e[10][lane] == 0.0f;
+          dmask = __ballot(lane < nbuf && mk == mk && dg);
+        }
       }
+      const bool chunk_diag = GEN && gmask != 0ull && dmask == gmask;      // (uniform) every general form of the chunk is diagonal
 #ifdef VOGE_SWEEP_TIMES
       const unsigned long long tsb = wall_clock64();
       ts_fill += tsb - tsa;
@@ -585,6 +596,11 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       if (GEN) {
 #pragma unroll
         for (int r = 0; r < 11; ++r) Evn[GEN ? r : 0] = *reinterpret_cast<const float4 *>(&G.e[r][0]);
+        if (chunk_diag) {      // (the six arrays such a chunk never reads again ARE zero: a mixed trip's pair_eval_gen takes them from here)
+#pragma unroll
+          for (int r = 0; r < 11; ++r)
+            if (!(r < 2 || (r >= 5 && r < 8))) Evn[GEN ? r : 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
       for (int s0 = 0; s0 < n; s0 += 4) {
         if ((s0 & (kExitGroup - 1)) == 0 && binned && unit_rays && __all(!valid || cnt == K)) {
@@ -614,7 +630,24 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 #pragma unroll
           for (int r = 0; r < 11; ++r) Ev[r] = Evn[GEN ? r : 0];
           const float qxx = dx * dx, qyy = dy * dy, qzz = dz * dz, qxy = dx * dy, qxz = dx * dz, qyz = dy * dz;
-          if (gbits == 15u) {
+          if (gbits == 15u && ((unsigned)(dmask >> s0) & 15u) == 15u) {      // (uniform) four diagonal forms
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              auto half = [&](const float4 v) { return h ? (v2f){v.z, v.w} : (v2f){v.x, v.y}; };
+              const v2f x2 = half(X), y2 = half(Y), z2 = half(Z), s00 = half(A), s11 = half(Ev[0]), s22 = half(Ev[1]),
+                        bx = half(Ev[5]), by = half(Ev[6]), bz = half(Ev[7]);
+              v2f ksk = s00 * splat(qxx);
+              ksk = pk_fma(s11, splat(qyy), ksk); ksk = pk_fma(s22, splat(qzz), ksk);
+              v2f msk = bx * splat(dx);
+              msk = pk_fma(by, splat(dy), msk); msk = pk_fma(bz, splat(dz), msk);
+              const v2f t = msk * (v2f){__builtin_amdgcn_rcpf(ksk.x), __builtin_amdgcn_rcpf(ksk.y)} + splat(0.0f);
+              const v2f vx = pk_fma(-t, splat(dx), x2), vy = pk_fma(-t, splat(dy), y2), vz = pk_fma(-t, splat(dz), z2);
+              v2f a = s00 * (vx * vx);
+              a = pk_fma(s11, vy * vy, a); a = pk_fma(s22, vz * vz, a);
+              len[2 * h] = t.x; len[2 * h + 1] = t.y;
+              act[2 * h] = a.x; act[2 * h + 1] = a.y;
+            }
+          } else if (gbits == 15u) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               auto half = [&](const float4 v) { return h ? (v2f){v.z, v.w} : (v2f){v.x, v.y}; };
@@ -693,7 +726,11 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
         Zn = *reinterpret_cast<const float4 *>(&S.z[s0 + 4]); An = *reinterpret_cast<const float4 *>(&S.a[s0 + 4]);
         Pn = *reinterpret_cast<const int4 *>(&S.pos[s0 + 4]);
 #endif
-        if (GEN && gmask != 0ull) {      // (uniform: a chunk without a general candidate reads none of them)
+        if (GEN && chunk_diag) {         // (uniform) s11, s22 and b: all a diagonal trip reads
+#pragma unroll
+          for (int r = 0; r < 11; ++r)
+            if (r < 2 || (r >= 5 && r < 8)) Evn[GEN ? r : 0] = *reinterpret_cast<const float4 *>(&G.e[r][s0 + 4]);
+        } else if (GEN && gmask != 0ull) {      // (uniform: a chunk without a general candidate reads none of them)
 #pragma unroll
           for (int r = 0; r < 11; ++r) Evn[GEN ? r : 0] = *reinterpret_cast<const float4 *>(&G.e[r][s0 + 4]);
         }

@@ -548,6 +548,7 @@ class _Fragments(torch.autograd.Function):
         ctx.act_dsd = [sel_act, sel_dsd]
         ctx.meta = (int(mode), int(sigma_mode), bool(shared), float(occ), B, N)
         _tag_index(sel_idx, cnt, B * N)
+        ctx.idx_version = sel_idx._version      # (an index list edited through torch afterwards may hold a Gaussian TWICE in a pixel)
         ctx.mark_non_differentiable(sel_idx, valid, cnt)
         if records is not None:
             ctx.mark_non_differentiable(records)
@@ -571,7 +572,11 @@ class _Fragments(torch.autograd.Function):
             raise _lib.VogeHipError("the fused view form has no gradient for the camera centre; "
                                     "use ray_tracing_iso on centred vertices")
         g0, g1 = torch.empty_like(p0), torch.empty_like(p1)
-        if not (ctx.needs_input_grad[4] or THREE_KERNEL_BACKWARD or B * N >= (1 << 26)):
+        # (the one-pass kernel adds a pixel's slots to its table without arbitration -- a pixel's Gaussians are distinct
+        #  as the trace wrote them.  A list somebody edited through torch since is no longer known to be: it takes the stand-alone
+        #  kernels, whose table elects one writer per key)
+        edited = sel_idx._version != ctx.idx_version
+        if not (ctx.needs_input_grad[4] or THREE_KERNEL_BACKWARD or B * N >= (1 << 26) or edited):
             # ONE pass: composite backward + trace backward per slot in registers, per-Gaussian sums in a wave-private
             # table (fragment_bwd.hip, SRC = 1).  No act / dsd arrays, no g_len / g_act / g_dsd.
             gw, gs_pix, gs_k = _grad_weight_layout(g_weight, K)
