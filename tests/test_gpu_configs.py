@@ -279,7 +279,7 @@ def test_config4_64_rows_vs_oracle(hip_lib):
     # (200k Gaussians: four times cfg3's depth density and every lit list full, so ties at the K-th depth and between
     #  neighbours are that much more frequent -- measured 24 flips of 65 536; ceilings at 1.7 x that)
     same = _check_frame("cfg4 rows 480..543", frag, img, ref, max_flips=40)
-    assert _classify_flips("cfg4 rows 480..543", frag, ref, same, (24, 40)) <= 24
+    assert _classify_flips("cfg4 rows 480..543", frag, ref, same, (12, 40)) <= 12      # (measured: 5 member-set flips + 19 tie swaps)
     g_img = np.random.default_rng(44).normal(size=ref["image"].shape) * same[..., None]
     (img * t(g_img)).sum().backward()
     _check_grads("cfg4 64 rows", (colors.grad, gm.verts.grad, gm.sigmas.grad), _oracle_grads(sc, ref, g_img), mult=1)

@@ -327,14 +327,15 @@ def _general_scene(N, seed, kind, per_view=0):
     """(N,3) per-axis or (N,3,3) L L^T sigmas (scenes.random_gaussians' forms); per_view = B: a [B,N,...] stack of them."""
     from voge_amd import scenes
     verts, sig, cols = scenes.random_gaussians(N, seed=seed, anisotropic=("diag" if kind == 1 else True), r_lo=0.04, r_hi=0.09)
-    if per_view:
+    if per_view:      # (a [B,N,...] stack of sigmas AND of vertices: nothing shared between the views)
         rng = np.random.default_rng(seed)
         sig = np.stack([sig * rng.uniform(0.8, 1.25) for _ in range(per_view)]).astype(np.float32)
+        verts = np.stack([verts + rng.normal(size=verts.shape).astype(np.float32) * 0.01 for _ in range(per_view)]).astype(np.float32)
     return verts, sig, cols
 
 
 @pytest.mark.parametrize("kind,B,per_view,route", [
-    (1, 1, 0, "white"), (2, 1, 0, "white"), (1, 2, 0, "white"), (2, 2, 2, "white"),
+    (1, 1, 0, "white"), (2, 1, 0, "white"), (1, 2, 0, "white"), (2, 2, 2, "white"), (1, 2, 2, "merge"),
     (1, 1, 0, "merge"), (2, 2, 0, "merge"), (1, 1, 0, "weights"), (2, 1, 0, "weights+white"), (1, 2, 0, "hit_length"),
 ])
 def test_general_forms_on_the_frame_path(hip_lib, kind, B, per_view, route):
