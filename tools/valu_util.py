@@ -6,7 +6,12 @@ import re, sys
 txt = open(sys.argv[1]).read()
 want = ('sweep_iso_kernel<false>', 'compositen_kernel<0, 4, true, unsigned int, 3, false>', 'fragment_bwd_kernel<0, 3, 2, unsigned int, true, true>',
         'binA_kernel<true>', 'binB_kernel<false>', 'sweep_iso_kernel<true>', 'compositen_kernel<0, 4, true, unsigned int, 3, true>',
-        'fragment_bwd_kernel<0, 3, 2, unsigned int, false, false>', 'rays_fwd_kernel', 'sweep_iso_kernel', 'trace_fwd_kernel<1, false>')
+        'fragment_bwd_kernel<0, 3, 2, unsigned int, false, false>', 'rays_fwd_kernel', 'sweep_iso_kernel', 'trace_fwd_kernel<1, false>',
+        # round 6's template parameter lists (GEN an int; DIAG):
+        'compositen_kernel<0, 4, true, unsigned int, 3, 0>', 'compositen_kernel<0, 4, true, unsigned int, 3, 1>',
+        'compositen_kernel<0, 4, true, unsigned int, 3, 2>', 'fragment_bwd_kernel<0, 3, 2, unsigned int, true, true, false>',
+        'fragment_bwd_kernel<0, 3, 2, unsigned int, false, false, false>', 'fragment_bwd_kernel<0, 3, 2, unsigned int, false, true, true>',
+        'binB_kernel<true>', 'binA_kernel<false>')
 for b in re.split(r'\n(?=voge::)', txt):
     name = b.split('  vgpr')[0].replace('voge::', '')
     if name not in want:
