@@ -73,6 +73,19 @@ need_c, b_c, f_c = need_g.cpu(), b_g.cpu(), f_g.cpu()
 import numpy as np
 need_c, b_c, f_c = need_c.numpy(), b_c.numpy(), f_c.numpy()
 it_a = it_b = it_c = 0
+it_cap = {1.0: 0.0, 1.5: 0.0, 2.0: 0.0, 3.0: 0.0}      # (d) capped walks + the long lanes' rest taken over by the whole wave
+
+
+def capped(tr, c2):
+    """min over T of (T + 1) + c2 * #{lanes with more than T trips}: the walk stops at T, every lane that is not done gets ONE
+    wave-wide pass (its remaining row pairs spread over the 64 lanes, a wave reduction back to it) priced at c2 iterations."""
+    tr = np.sort(tr)[::-1]
+    best = tr[0] + 1.0
+    for k in range(1, min(len(tr), 24)):      # the k heaviest lanes go to the second phase: T = the (k+1)-th largest
+        T = tr[k] if k < len(tr) else 0
+        best = min(best, T + 1.0 + c2 * k)
+    return best
+
 lane_iters = 0
 rounds = 0
 for g in range(need_c.shape[0]):
@@ -93,7 +106,11 @@ for g in range(need_c.shape[0]):
         it_a += (bb.max() + 1) + (ff.max() + 1)
         it_b += (bb + ff).max() + 2
         it_c += -(-int((bb + ff + 2).sum()) // 64)
+        for c2 in it_cap:
+            it_cap[c2] += capped(bb, c2) + capped(ff, c2)
         lane_iters += int((bb + ff + 2).sum())
         rounds += 1
 print(f"{name}: {rounds} rounds; wave iterations  today {it_a}  merged walk {it_b} ({it_b / it_a:.2f})  flat {it_c} ({it_c / it_a:.2f}); "
       f"lanes active today {lane_iters / (64.0 * it_a):.2f}, merged {lane_iters / (64.0 * it_b):.2f}")
+print("capped walks, the long lanes' rest as one wave-wide pass each, priced at c2 iterations per long lane:  " +
+      "  ".join(f"c2={c2}: {v:.0f} ({v / it_a:.2f})" for c2, v in it_cap.items()))
