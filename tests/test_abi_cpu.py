@@ -76,6 +76,29 @@ def test_version_errors_and_sizes_without_gpu(lib):
     assert lib.voge_trace_workspace_bytes(5, 2562, 128, 128) > 3 * lib.voge_trace_workspace_bytes(1, 2562, 128, 128)   # small batches: one chunk (the list pool's floor does not scale)
 
 
+def test_frame_entries_validate_before_any_hip_call(lib):
+    """ABI 7's frame entries refuse bad arguments on the host (no GPU in this container: anything that reached HIP would fail
+    differently)."""
+    P = 1234      # (a non-NULL pointer value: nothing is dereferenced before validation is through)
+    tr = (P, P, 1, 1, P, P, P, P, 0, 64, 0, 0, 1, 100, 64, 64)
+    assert lib.voge_frame_trace_fwd_iso(*tr, 1000, 4.6, P, 1 << 30, P, P, P, P, P, None, None) == -3      # K above VOGE_MAX_K
+    assert lib.voge_frame_trace_fwd_iso(P, P, 1, 1, None, P, P, P, 0, 64, 0, 0, 1, 100, 64, 64, 16, 4.6, P, 1 << 30, P, P, P, P, P, None, None) == -1   # no R
+    assert lib.voge_frame_trace_fwd_iso(*tr, 16, 4.6, P, 1000, P, P, P, P, P, None, None) == -2          # scratch too small
+    assert lib.voge_frame_trace_fwd_iso(P, P, 1, 3, P, P, P, P, 0, 64, 0, 0, 1, 100, 64, 64, 16, 4.6, P, 1 << 30, P, P, P, P, P, None, None) == -1   # sigma rule 3
+    assert lib.voge_frame_trace_fwd_gen(P, P, 1, 1, 3, P, P, P, P, 0, 64, 0, 0, 1, 100, 64, 64, 16, 4.6, P, 1 << 30, P, P, P, P, P, None, None) == -1   # kind 3
+    assert lib.voge_frame_bwd_acc_bytes(1000) == 32000 and lib.voge_frame_bwd_gen_acc_bytes(1000) == 64000
+    # the backward: K beyond a pixel's lanes in one wave, a scratch that cannot hold the accumulator, an unknown form
+    bw = (P, P, 1, 1, P, P, P, P, P, P, P, P, P, -1.0, P, 3, 1, 1.0, 1, 100, 64, 64)
+    assert lib.voge_frame_shade_bwd_iso(*bw, 200, 3, 100, P, 3200, P, P, P, None) == -3
+    assert lib.voge_frame_shade_bwd_iso(*bw, 16, 3, 100, P, 100, P, P, P, None) == -2
+    assert lib.voge_frame_bwd_gen(7, P, 1, 1, 1, P, P, P, P, P, None, P, None, P, P, P, -1.0, P, 3, 1, None, 1.0, 1, 100, 64, 64, 16, 3, 100, P,
+                                  6400, 1, P, P, P, None) == -1
+    assert lib.voge_frame_bwd_gen(0, P, 1, 1, 1, P, P, P, P, P, P, P, P, P, P, P, -1.0, P, 3, 1, None, 1.0, 1, 100, 64, 64, 16, 3, 100, P,
+                                  6400, 1, P, P, P, None) == -1      # per-axis records keep no act / dsd
+    # the composite that zeroes the accumulator: 16-byte granularity
+    assert lib.voge_frame_shade_fwd_iso(P, P, P, P, P, 1.0, P, P, -1.0, 4096, 16, 3, 100, P, P, P, P, P, None, P + 4, 3200, None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from voge_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
