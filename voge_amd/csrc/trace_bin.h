@@ -19,6 +19,9 @@
 // Both tests are conservative (cone_keep / cone_keep_ell, voge_common.h), so the sweep's result equals the
 // brute-force "-1" candidate list of VoGE/RayTracing.py:22-26.
 #pragma once
+#ifndef VOGE_XCD_CHAIN
+#define VOGE_XCD_CHAIN 0     // 1: a region's 16 binA slices AND its 64 binB quads on XCD (region % 8): binB finds the segments in the L2 binA wrote them through
+#endif
 #include <type_traits>
 
 #include "voge_common.h"
@@ -195,7 +198,15 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
             const CamView cam /* R != NULL: cones, centre and view axis from the camera; `cones` is not read */) {
   __shared__ BinALds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int region = blockIdx.x / kParts, part = blockIdx.x - region * kParts, b = blockIdx.y;
+  int region = blockIdx.x / kParts, part = blockIdx.x - region * kParts;
+  const int b = blockIdx.y;
+#if VOGE_XCD_CHAIN
+  if (((gridDim.x / kParts) & 7) == 0) {      // workgroup id % 8 = the XCD (round-robin dispatch): all of a region's slices on XCD region % 8
+    const int j = blockIdx.x >> 3;
+    region = (blockIdx.x & 7) + 8 * (j / kParts);
+    part = j % kParts;
+  }
+#endif
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *pool_top = 0ull;
   const int rx = region % nst0x, ry = region / nst0x;
   const int nst = nstx * nsty;
@@ -896,6 +907,13 @@ binB_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ell, con
   int binl = blockIdx.x >> 2, qq = blockIdx.x & 3;
 #if VOGE_BINB_XCD
   if ((int)blockIdx.x < ((nstx * nsty) >> 3) << 5) { binl = ((blockIdx.x >> 5) << 3) + (blockIdx.x & 7); qq = (blockIdx.x >> 3) & 3; }
+#endif
+#if VOGE_XCD_CHAIN
+  if ((nstx & 3) == 0 && (nsty & 3) == 0 && (((nstx >> 2) * (nsty >> 2)) & 7) == 0) {      // (the same rule as binA's: whole regions, a multiple of 8 of them)
+    const int j = blockIdx.x >> 3, region = (blockIdx.x & 7) + 8 * (j >> 6), w = j & 63, nst0x = nstx >> 2;
+    qq = w & 3;
+    binl = ((region / nst0x) * 4 + (w >> 4)) * nstx + (region % nst0x) * 4 + ((w >> 2) & 3);
+  }
 #endif
   const int stx = binl % nstx, sty = binl / nstx;
   const int bin = b * nstx * nsty + binl;
