@@ -42,8 +42,28 @@ __host__ __device__ inline size_t sweep2_pos_bytes(const int K) { return (sizeof
 struct Sweep2Gen {
   float e[11][64 + kS2Pad];
 };
+#ifndef VOGE_S2_QUADS
+#define VOGE_S2_QUADS 0      // 1: the scalar kernel, a tile's own list: one candidate stream per 4x4-pixel QUADRANT of the tile (see Sweep2Quad).
+                             // Built and measured in round 6 (profiles/r6_quads_ab.txt): bit-identical results, 30 % fewer candidates
+                             // evaluated per tile (93.7 -> 65.5), and SLOWER: a trip of four costs 669 instead of 490 ns (four
+                             // distinct record addresses per ds_read_b128 instead of one broadcast, 12 v_mov to pair the AoS
+                             // records for the packed evaluation), staging + 1.0, prologue + 0.6, epilogue + 1.3 us per tile
+                             // (ids through the stream): lean trace 63.1 -> 65.7 us, entry 71.2 -> 75.0 us.  Off.
+#endif
+// QUADS (round 6; tools/quadrant_sim.py, HISTORY R4: a candidate of an 8x8 tile's list hits 28-37 % of its rays, one stream per
+// 4x4 quadrant cuts a tile's trips from 94 to 58.5).  The staged chunk is kept as AoS (x, y, z, a) records in the bytes of
+// Sweep2Stage::x..a, every candidate is tested against the four quadrants' bounding cones when it is staged, and the survivors'
+// chunk positions are compacted into four byte lists (in the bytes of Sweep2Stage::pos: a handle is the stream position now,
+// which needs no look-up).  A trip then evaluates, in every lane, the next four candidates of ITS quadrant's list; the wave
+// runs as long as its longest quadrant.  The cones live here.
+struct Sweep2Quad {
+  float4 c[4];                  // (axis, cos) of quadrant q = (column >> 2) + 2 * (row >> 2)
+  float sn[4], ok[4];
+};
+constexpr int kS2QL = 64 + kS2Pad;      // bytes per quadrant list (padded with 64 = the never-hit record's position)
+static_assert(4 * kS2QL == sizeof(int) * (64 + kS2Pad), "the four byte lists take Sweep2Stage::pos's bytes");
 __host__ __device__ inline size_t sweep2_lds_bytes(const int K, const bool gen = false) {
-  return sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage) + (gen ? sizeof(Sweep2Gen) : 0);
+  return sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage) + (gen ? sizeof(Sweep2Gen) : (VOGE_S2_QUADS ? sizeof(Sweep2Quad) : 0));
 }
 
 #ifndef VOGE_S2_EPI_B
@@ -91,6 +111,9 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   unsigned char *const Lpos_raw = smem_raw + sweep2_len_bytes(K);
   Sweep2Stage &S = *reinterpret_cast<Sweep2Stage *>(smem_raw + sweep2_len_bytes(K) + sweep2_pos_bytes(K));
   Sweep2Gen &G = *reinterpret_cast<Sweep2Gen *>(smem_raw + sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage));      // (GEN only)
+  Sweep2Quad &QC = *reinterpret_cast<Sweep2Quad *>(smem_raw + sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage));   // (!GEN, QUADS)
+  float4 *const QR = reinterpret_cast<float4 *>(&S.x[0]);                      // (QUADS) the staged records, AoS
+  unsigned char *const Q8 = reinterpret_cast<unsigned char *>(&S.pos[0]);      // (QUADS) the four position lists
 
   const int lane = threadIdx.x;
   const int tiles_x = (W + 7) >> 3;
@@ -170,10 +193,13 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   // What a list entry carries in its 16 (32) bits: the Gaussian's id itself where every id of the batch element fits 16
   // bits -- no look-up anywhere --, else the entry's POSITION in the tile's stream, resolved through the stream's id list
   // on an exact len tie and in the epilogue.
-  const bool h_is_id = (N <= 65536) || !binned;
+  const bool quads = (VOGE_S2_QUADS != 0) && !GEN && pref && src_n <= 65536;      // (uniform) the per-quadrant form: handles are stream positions
+  const bool h_is_id = !quads && ((N <= 65536) || !binned);
   auto id_of = [&](const unsigned h) -> int { return h_is_id ? (int)h : src_id[h]; };
   const float not_full = __uint_as_float(__float_as_uint(VOGE_SENT_LEN) - 1u);      // len <= this  <=>  len < the sentinel
-  if (lane < kS2Pad) { S.x[64 + lane] = 0.f; S.y[64 + lane] = 0.f; S.z[64 + lane] = 0.f; S.a[64 + lane] = INFINITY; }
+  if (quads) {
+    if (lane < kS2Pad) QR[64 + lane] = rec_none;
+  } else if (lane < kS2Pad) { S.x[64 + lane] = 0.f; S.y[64 + lane] = 0.f; S.z[64 + lane] = 0.f; S.a[64 + lane] = INFINITY; }
   if (GEN && lane < kS2Pad) G.e[0][64 + lane] = __uint_as_float(0x7fc00000u);      // (padding counts as isotropic)
   const float4 *evrb = GEN ? evr + (size_t)b * N * 3 : nullptr;
   bool tile_gen = false;      // (GEN) a general candidate was staged at some point: the epilogue needs the full records
@@ -213,6 +239,34 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       float smax = 0.f, cmin = 1.f;
       cone_partial(u, ax, ay, az, smax, cmin);
       wcone = cone_finish(ax, ay, az, n, wave_max(smax), wave_min(cmin), dirs_ok);
+    }
+    if (quads) {      // (uniform) the four quadrants' cones: reductions over lane bits 0, 1 (columns) and 3, 4 (rows)
+      // (bit 4 = the other 16-lane row of the pair: v_permlane16_swap hands every lane both rows' values -- no LDS round trip)
+      auto rows = [&](const float v, float &lo, float &hi) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+      };
+      auto qsum = [&](float v) { v += VOGE_DPP(v, 0xB1); v += VOGE_DPP(v, 0x4E); v += VOGE_DPP(v, 0x128); float a, b2; rows(v, a, b2); return a + b2; };
+      auto qmax = [&](float v) { v = fmaxf(v, VOGE_DPP(v, 0xB1)); v = fmaxf(v, VOGE_DPP(v, 0x4E)); v = fmaxf(v, VOGE_DPP(v, 0x128)); float a, b2; rows(v, a, b2); return fmaxf(a, b2); };
+      const float sx = qsum(u.ok ? u.ux : 0.f), sy = qsum(u.ok ? u.uy : 0.f), sz = qsum(u.ok ? u.uz : 0.f);
+      const float n2 = fmaf(sz, sz, fmaf(sy, sy, sx * sx));
+      const float rn = __builtin_amdgcn_rsqf(n2);      // (the axis need not be exactly unit: the bounds below are taken against THIS axis, renormalised)
+      float ax = sx * rn, ay = sy * rn, az = sz * rn;
+      const float fix = __builtin_amdgcn_rsqf(fmaf(az, az, fmaf(ay, ay, ax * ax)));
+      ax *= fix; ay *= fix; az *= fix;
+      float smax = 0.f, cmin = 1.f;
+      {
+        const float cl = fmaf(u.uz, az, fmaf(u.uy, ay, u.ux * ax));
+        const float rx = fmaf(-cl, ax, u.ux), ry = fmaf(-cl, ay, u.uy), rz = fmaf(-cl, az, u.uz);
+        const float sl = __builtin_amdgcn_sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx * rx)));
+        smax = u.ok ? sl : 2.0f; cmin = u.ok ? cl : -1.0f;
+      }
+      smax = qmax(smax) * (1.0f + 1e-6f) + 1e-6f; cmin = -qmax(-cmin) - 1e-6f;      // (hardware sqrt / rsq, ~1 ulp: margins as cam_rect_cone's)
+      const int myq = ((lane >> 2) & 1) | ((lane >> 4) & 2);
+      const unsigned long long qm = (0x0F0F0F0Full << (4 * (myq & 1))) << (32 * (myq >> 1));
+      const bool qok = (__ballot(u.ok) & qm) == qm;
+      const Cone c = cone_finish(ax, ay, az, n2 * rn * 0.25f, smax, cmin, qok);
+      if ((lane & 0x1B) == 0) { QC.c[myq] = make_float4(c.ax, c.ay, c.az, c.cs); QC.sn[myq] = c.sn; QC.ok[myq] = c.ok ? 1.f : 0.f; }
     }
   };
 
@@ -281,6 +335,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
     float worstf = valid ? not_full : __uint_as_float(0x7fc00000u);      // (NaN: a ray outside the image takes nothing)
     float tailf = -INFINITY;
     bool wdone = false;
+    unsigned qdone = 0u;      // (QUADS) bit q: quadrant q's stream is over (its exit test fired)
 
     // a candidate that passed `act < thr && len <= worst` but is not a plain append: exact (len, id) insertion
     auto slow_insert = [&](const float len, const unsigned p) {
@@ -514,6 +569,121 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
         st_eval += min(n, nb);
 #endif
         continue;
+      }
+#endif
+#if VOGE_S2_QUADS
+      if constexpr (!GEN && !WIDE) {
+        if (quads) {      // (uniform) ---- the tile's own list, one stream per quadrant (Sweep2Quad) ----
+          const int nb = min(64, src_n - base);
+          __syncthreads();      // (the previous chunk's readers are done)
+          QR[lane] = mrec;      // (behind the list: never-hit records)
+          S.lb[lane] = lbv;
+          reinterpret_cast<unsigned *>(Q8)[lane] = 0x40404040u;
+          if (lane < kS2Pad) reinterpret_cast<unsigned *>(Q8)[64 + lane] = 0x40404040u;
+          // (straight-line: the four cones are requested first, the candidate's reach is iso_cull_record's with selects for its
+          //  branches, cone_keep's early return is a mask -- as `if`s every quadrant's test sat in exec-mask regions of its own,
+          //  each behind its own LDS round trip: 1 us per chunk)
+          const float4 c0q = QC.c[0], c1q = QC.c[1], c2q = QC.c[2], c3q = QC.c[3];
+          const float4 snq = *reinterpret_cast<const float4 *>(&QC.sn[0]), okq = *reinterpret_cast<const float4 *>(&QC.ok[0]);
+          const float nm2 = fmaf(mrec.z, mrec.z, fmaf(mrec.y, mrec.y, mrec.x * mrec.x));
+          const float nm = __builtin_amdgcn_sqrtf(nm2);
+          float reach = __builtin_amdgcn_sqrtf(fmaxf(thr_act, 0.0f) * __builtin_amdgcn_rcpf(mrec.w * (1.0f - 4e-6f))) * (1.0f + 2e-5f) + 2e-5f * nm + 1e-30f;
+          reach = (mrec.w > 0.0f && mrec.w < 3e38f && reach >= 0.0f) ? reach : INFINITY;      // (iso_cull_record, trace_bin.h: conservative)
+          int cq[4];
+          unsigned kbits = 0u;      // bit q: this lane's staged entry is in quadrant q's list (the exit test re-counts with it)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 c4 = q == 0 ? c0q : (q == 1 ? c1q : (q == 2 ? c2q : c3q));
+            const float snv = q == 0 ? snq.x : (q == 1 ? snq.y : (q == 2 ? snq.z : snq.w));
+            const float okv = q == 0 ? okq.x : (q == 1 ? okq.y : (q == 2 ? okq.z : okq.w));
+            const float pp_ = fmaf(mrec.z, c4.z, fmaf(mrec.y, c4.y, mrec.x * c4.x));
+            const float rx = fmaf(-pp_, c4.x, mrec.x), ry = fmaf(-pp_, c4.y, mrec.y), rz = fmaf(-pp_, c4.z, mrec.z);
+            const float qq = __builtin_amdgcn_sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx * rx))) * (1.0f - 1e-6f);      // (cone_keep with the hardware root, rounded down)
+            const float gap = fmaf(qq, c4.w, -fabsf(pp_) * snv);
+            const bool keep = (lane < nb) & !((qdone >> q) & 1u) & ((okv == 0.f) | !(gap > reach));
+            const unsigned long long m = __ballot(keep);
+            cq[q] = __popcll(m);
+            kbits |= keep ? (1u << q) : 0u;
+            Q8[q * kS2QL + (keep ? __popcll(m & ((1ull << lane) - 1ull)) : kS2QL - 1)] = (unsigned char)(keep ? lane : 64);
+          }
+          __syncthreads();
+#ifdef VOGE_SWEEP_TIMES
+          const unsigned long long tsb = wall_clock64();
+          ts_fill += tsb - tsa;
+          int st_trips = 0;
+#endif
+          const float lbl = S.lb[lane];
+          const int myq = ((lane >> 2) & 1) | ((lane >> 4) & 2);
+          const unsigned char *const myQ = Q8 + myq * kS2QL;
+          int trips = (max(max(cq[0], cq[1]), max(cq[2], cq[3])) + 3) >> 2;
+          unsigned Icur = *reinterpret_cast<const unsigned *>(myQ), Inx = *reinterpret_cast<const unsigned *>(myQ + 4);
+          float4 Rn[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) Rn[k] = QR[(Icur >> (8 * k)) & 0xffu];
+          for (int t = 0; t < trips; ++t) {
+            if ((t & 3) == 0 && binned && unit_rays) {
+              // the exit test, per quadrant: all of its rays hold K hits and the bound of a staged entry lies above every K-th len
+              const unsigned long long fullm = __ballot(!valid || cnt == K);
+              unsigned ready = 0u;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const unsigned long long qm = (0x0F0F0F0Full << (4 * (q & 1))) << (32 * (q >> 1));
+                if (!((qdone >> q) & 1u) && (fullm & qm) == qm) ready |= 1u << q;
+              }
+              if (ready != 0u) {      // (uniform)
+                float v = valid ? worstf : -INFINITY;
+                v = fmaxf(v, VOGE_DPP(v, 0xB1)); v = fmaxf(v, VOGE_DPP(v, 0x4E)); v = fmaxf(v, VOGE_DPP(v, 0x128));
+                const float wq[4] = {fmaxf(VOGE_LANE(v, 0), VOGE_LANE(v, 16)), fmaxf(VOGE_LANE(v, 4), VOGE_LANE(v, 20)),
+                                     fmaxf(VOGE_LANE(v, 32), VOGE_LANE(v, 48)), fmaxf(VOGE_LANE(v, 36), VOGE_LANE(v, 52))};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  if ((ready >> q) & 1u) {
+                    const unsigned long long ex = __ballot(lane < nb && lbl > wq[q]);
+                    if (ex) {
+                      cq[q] = __popcll(__ballot((kbits >> q) & 1u) & ((1ull << __builtin_ctzll(ex)) - 1ull));
+                      qdone |= 1u << q;
+                    }
+                  }
+                }
+                trips = (max(max(cq[0], cq[1]), max(cq[2], cq[3])) + 3) >> 2;
+                wdone = qdone == 15u;
+                if (t >= trips) break;
+              }
+            }
+            const unsigned I = Icur;
+            float len[4], act[4];
+            {
+              // pair_eval_iso's operations, bit for bit, two candidates per packed instruction (as the 64-ray form below)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const float4 r0 = Rn[2 * h], r1 = Rn[2 * h + 1];
+                const v2f x2 = (v2f){r0.x, r1.x}, y2 = (v2f){r0.y, r1.y}, z2 = (v2f){r0.z, r1.z}, a2 = (v2f){r0.w, r1.w};
+                const v2f md = pk_fma(z2, splat(dz), pk_fma(y2, splat(dy), x2 * splat(dx)));
+                const v2f tt = md * splat(rdn2);
+                const v2f vx = pk_fma(-tt, splat(dx), x2), vy = pk_fma(-tt, splat(dy), y2), vz = pk_fma(-tt, splat(dz), z2);
+                const v2f a = a2 * pk_fma(vz, vz, pk_fma(vy, vy, vx * vx));
+                len[2 * h] = tt.x; len[2 * h + 1] = tt.y;
+                act[2 * h] = a.x; act[2 * h + 1] = a.y;
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(len[q]), "+v"(act[q]));
+            Icur = Inx;
+            Inx = *reinterpret_cast<const unsigned *>(myQ + min(4 * (t + 2), 64));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Rn[k] = QR[(Icur >> (8 * k)) & 0xffu];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) commit(len[k], act[k], (unsigned)base + ((I >> (8 * k)) & 0xffu));
+#ifdef VOGE_SWEEP_TIMES
+            ++st_trips;
+#endif
+          }
+#ifdef VOGE_SWEEP_TIMES
+          ts_cons += wall_clock64() - tsb;
+          st_eval += 4 * st_trips;
+#endif
+          continue;
+        }
       }
 #endif
       // ---- stage ----
