@@ -21,6 +21,7 @@ import json
 import os
 import subprocess
 import sys
+import gc
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -48,6 +49,7 @@ def parse():
                     help="profiling aid: launch nothing but this stage's entry point (no frame), e.g. trace_fwd for the PMC passes; "
                          "'frame': the frame's steps alone")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-launch-probe", action="store_true", help="time the HIP graph replay whatever the eager launches of the same step would do")
     ap.add_argument("--split-graph", action="store_true",
                     help="single GPU: use the multi-GPU launch scheme (forward graph / eager exchange / backward graph)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU oracle work for cpu_baseline")
@@ -388,6 +390,7 @@ def main():
                     #  measured 1e-7 .. 2e-6 of the largest entry; north_star's tolerance is the bound)
                     assert err < 1e-4, f"HIP graph replay does not reproduce the eager step's gradients (rel. error {err:.2e})"
                 graph_checked.append(worst)
+                graphed_step.eager = step      # (the same step launched eagerly: see the launch probe in front of the timed region)
                 return graph.replay, "hip graph replay"
             except Exception as e:  # pragma: no cover - depends on the runtime
                 print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -403,11 +406,16 @@ def main():
             for _ in range(warmup):
                 run()
             barrier()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                run()
-            barrier()
-            dt = time.perf_counter() - t0
+            gc.collect()
+            gc.disable()      # (as timeit does: a collection of the interpreter's garbage inside a 7 ms region is 10 % of it)
+            try:
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    run()
+                barrier()
+                dt = time.perf_counter() - t0
+            finally:
+                gc.enable()
             timed.last_local_dt = dt      # (this rank's own clock; the line reports min / max over the ranks)
             if multi:
                 tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -520,6 +528,20 @@ def main():
             for _ in range(300):
                 run()
             torch.cuda.synchronize()
+        # Launch probe (untimed, one GPU): a HIP graph replay leaves the GPU idle for ~9 us between two replays (the dependency of
+        # a graph launch on the one before it: tools/frame_gaps.sh, profiles/r6_frame_gaps.txt), eager launches follow each other
+        # within 0.2 us -- but only if the host enqueues a frame (~165 us of Python and C) faster than the GPU renders it (~250 us),
+        # which depends on the box.  Both are the same step on the same tensors; the contract's region runs the faster one.
+        launch_probe = None
+        if primary and not multi and launch == "hip graph replay" and getattr(graphed_step, "eager", None) is not None and not args.no_launch_probe:
+            launch_probe = {}
+            for name, fn in (("hip graph replay", run), ("eager", graphed_step.eager)):
+                launch_probe[name] = round(min(timed(fn, max(args.steps, 30), 30) for _ in range(2)) / max(args.steps, 30) * 1e3, 5)
+            if launch_probe["eager"] < 0.985 * launch_probe["hip graph replay"]:
+                run, launch = graphed_step.eager, "eager (same step; faster than its hip graph replay on this host, see launch_probe_ms_per_step)"
+                for _ in range(30):
+                    run()
+                torch.cuda.synchronize()
         # Once, untimed, N > 1 only: the frame the split assembles must be the frame ONE GPU renders -- the same bits (pixels
         # are independent in every stage; stripes / bands / views only choose who computes which rows).  Every rank takes part
         # in the gather; rank 0 renders the whole frame (views mode: every view) alone and compares with torch.equal.
@@ -587,6 +609,8 @@ def main():
                                    f"ONE frame, one contiguous pixel-row band per rank x{world} (measured rebalancing), "
                                    f"all_gather(image)+all_reduce(grads)")},
     }
+    if M.launch_probe is not None:
+        result["config"]["launch_probe_ms_per_step"] = M.launch_probe      # (untimed, in front of the contract's region: both launch modes of the same step)
     if M.repeats is not None:
         result["repeat_ms_per_step"] = M.repeats      # four more K-step regions behind the contract's one: the headline's spread
     if multi and rank == 0:
