@@ -22,6 +22,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef VOGE_CF_ABL
 #define VOGE_CF_ABL 0      // timing experiments on the forward composite (bit 0: no window walks, bit 1: no own block)
 #endif
+#ifndef VOGE_CF_COLWALK
+#define VOGE_CF_COLWALK 1  // forward composite, sorted pixels: walks over the rows around a lane's own COLUMNS (each column's own window) instead of
+#endif                     // over the columns around its rows (the pixel's widest window); see compn_fwd_rows
 #ifndef VOGE_COMP_MAXT
 #define VOGE_COMP_MAXT 256
 #endif
@@ -137,6 +140,18 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
   }
   // Exclusive prefix (over the lanes of the pixel) of the per-lane sums of E, Hillis-Steele on wave shuffles with the
   // window radius riding along
+#if VOGE_CF_COLWALK
+  float ex;      // (no pixel-wide window radius: a column walk goes as far as its own columns reach)
+  {
+    const float y = __shfl_up(esum, 1, 64);
+    float x = (q > 0 && in_wg) ? y : 0.0f;
+    for (int o = 1; o < LPmax; o <<= 1) {
+      const float z = __shfl_up(x, o, 64);
+      if (q >= o && in_wg) x += z;
+    }
+    ex = x;
+  }
+#else
   float ex, wave_rmax;
   if (Lcell != nullptr) {
     // the window radius through the pixel's LDS cell (compn_bwd_wave), the prefix sum alone through the shuffles
@@ -166,7 +181,10 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
     ex = x.x;
     wave_rmax = __shfl(x.y, min(63, seg_lo + LP - 1), 64);      // the pixel's last lane holds the maximum
   }
+#endif
+#if !VOGE_CF_COLWALK
   const float rwin = sorted ? (in_wg ? wave_rmax : 0.0f) : 0.0f;
+#endif
   bool any_e = false;
 #pragma unroll
   for (int a = 0; a < NS; ++a) any_e = any_e || (em[a] != 0.0f);
@@ -191,6 +209,57 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
         accF[b2].y = fmaf(em[a], h.y, accF[b2].y);
       }
     }
+#if VOGE_CF_COLWALK
+    // Column walks (round 6): the lane walks the ROWS around its own columns, each as far as that column's own window
+    // kSat / s_j reaches, and adds -E_j h (row behind: the column is in front of it) / +E_j h (row in front) to the row's cell
+    // of LR -- the pixel's s' row, which a sorted pixel's walks no longer read: a lane's own s' and E are in its registers.
+    // The row walks below went as far as the pixel's WIDEST window for every column.  Read - add - write as in
+    // compn_bwd_wave<NS, true>: in one iteration the lanes of a wave address different row pairs.
+    float *const LR = const_cast<float *>(Lsp);
+    float reachB = -kBig, reachF = kBig, lmS[NS], spS[NS];
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+      const bool live = em[a] != 0.0f;
+      const float r = kSat * __builtin_amdgcn_rcpf(sm[a]);
+      reachB = live ? fmaxf(reachB, lm[a] + r) : reachB;
+      reachF = live ? fminf(reachF, lm[a] - r) : reachF;
+      lmS[a] = live ? lm[a] : 0.0f; spS[a] = live ? sp[a] : 0.0f;      // (an empty column: x = 0, E = 0 -- nothing, and nothing non-finite)
+    }
+#pragma unroll
+    for (int a = 0; a < NS; a += 2) *reinterpret_cast<v2f *>(LR + d0 + a) = splat(0.0f);
+    wave_lds_sync();
+    for (int e = d0 + NS;; e += 2) {     // row pairs behind the own columns
+      const v2f l2 = ld2(Llen, e);
+      if (!(l2.x < reachB)) break;
+      v2f racc = ld2(LR, e);
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const v2f xa = (l2 - splat(lmS[a])) * splat(spS[a]);
+        racc = pk_fma(splat(-em[a]), h_pair(xa), racc);
+      }
+      *reinterpret_cast<v2f *>(LR + e) = racc;
+      wave_lds_sync();
+    }
+    for (int e = d0 - 2;; e -= 2) {      // row pairs in front of the own columns
+      const v2f l2 = ld2(Llen, e);
+      if (!(l2.y > reachF)) break;
+      v2f racc = ld2(LR, e);
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const v2f xa = (splat(lmS[a]) - l2) * splat(spS[a]);
+        racc = pk_fma(splat(em[a]), h_pair(xa), racc);
+      }
+      *reinterpret_cast<v2f *>(LR + e) = racc;
+      wave_lds_sync();
+    }
+    wave_lds_sync();      // (every column walk of the pixel has passed: its lanes share this wave)
+    float pre = ex;
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+      pre += em[a];                                                     // inclusive prefix sum of E
+      S[a] = ((pre - (accF[a].x + accF[a].y)) + (accB[a].x + accB[a].y)) + *lds_volatile(LR + d0 + a);
+    }
+#else
     float lmB = lm[0];                 // the last live row decides how far back to walk
 #pragma unroll
     for (int a = 1; a < NS; ++a) lmB = (em[a] != 0.0f) ? lm[a] : lmB;
@@ -224,6 +293,7 @@ __device__ __forceinline__ void compn_fwd_rows(const float (&lm)[NS], const floa
       pre += em[a];                                                     // inclusive prefix sum of E
       S[a] = (pre - (accF[a].x + accF[a].y)) + (accB[a].x + accB[a].y);
     }
+#endif
   } else if (any_e && active) {          // unsorted list: every column, signs from the data
     const int r0 = d0 - k0;
     for (int j = 0; j < K; ++j) {

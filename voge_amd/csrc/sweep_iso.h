@@ -113,7 +113,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   Sweep2Gen &G = *reinterpret_cast<Sweep2Gen *>(smem_raw + sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage));      // (GEN only)
   Sweep2Quad &QC = *reinterpret_cast<Sweep2Quad *>(smem_raw + sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage));   // (!GEN, QUADS)
   float4 *const QR = reinterpret_cast<float4 *>(&S.x[0]);                      // (QUADS) the staged records, AoS
-  unsigned char *const Q8 = reinterpret_cast<unsigned char *>(&S.pos[0]);      // (QUADS) the four position lists
+  [[maybe_unused]] unsigned char *const Q8 = reinterpret_cast<unsigned char *>(&S.pos[0]);      // (QUADS) the four position lists
 
   const int lane = threadIdx.x;
   const int tiles_x = (W + 7) >> 3;
@@ -335,7 +335,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
     float worstf = valid ? not_full : __uint_as_float(0x7fc00000u);      // (NaN: a ray outside the image takes nothing)
     float tailf = -INFINITY;
     bool wdone = false;
-    unsigned qdone = 0u;      // (QUADS) bit q: quadrant q's stream is over (its exit test fired)
+    [[maybe_unused]] unsigned qdone = 0u;      // (QUADS) bit q: quadrant q's stream is over (its exit test fired)
 
     // a candidate that passed `act < thr && len <= worst` but is not a plain append: exact (len, id) insertion
     auto slow_insert = [&](const float len, const unsigned p) {
