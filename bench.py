@@ -49,6 +49,7 @@ def parse():
                     help="profiling aid: launch nothing but this stage's entry point (no frame), e.g. trace_fwd for the PMC passes; "
                          "'frame': the frame's steps alone")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--graph-steps", type=int, default=0, help="consecutive steps captured per HIP graph (0: the largest of 6..1 that divides --steps)")
     ap.add_argument("--no-launch-probe", action="store_true", help="time the HIP graph replay whatever the eager launches of the same step would do")
     ap.add_argument("--split-graph", action="store_true",
                     help="single GPU: use the multi-GPU launch scheme (forward graph / eager exchange / backward graph)")
@@ -376,9 +377,16 @@ def main():
                 warm_side_stream(step)
                 torch.cuda.synchronize()
                 want = [p.grad.detach().clone() for p in params]      # (the eager step's gradients: what a replay must reproduce)
+                # U consecutive steps per graph: two graph launches are 9 us apart on a fast host and 25 us on a slow one (a launch
+                # waits for the one before it through a completion signal the host's runtime thread forwards -- tools/frame_gaps.sh,
+                # profiles/r6_frame_gaps.txt), kernels inside a graph follow each other without a gap.  `replay` below is called once
+                # per STEP and launches the graph on every U-th call: any K calls with K % U == 0 run exactly K steps on the GPU.
+                U = (args.graph_steps if args.graph_steps > 0 and args.steps % args.graph_steps == 0 else
+                     max(u for u in (6, 5, 4, 3, 2, 1) if args.steps % u == 0))
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    step()
+                    for _ in range(U):
+                        step()
                 for _ in range(3):                                     # back-to-back replays, no host synchronisation between them
                     graph.replay()
                 torch.cuda.synchronize()
@@ -391,7 +399,15 @@ def main():
                     assert err < 1e-4, f"HIP graph replay does not reproduce the eager step's gradients (rel. error {err:.2e})"
                 graph_checked.append(worst)
                 graphed_step.eager = step      # (the same step launched eagerly: see the launch probe in front of the timed region)
-                return graph.replay, "hip graph replay"
+                pending = [0]
+
+                def replay():
+                    pending[0] += 1
+                    if pending[0] == U:
+                        pending[0] = 0
+                        graph.replay()
+                replay.U = U
+                return replay, ("hip graph replay" if U == 1 else f"hip graph replay, {U} consecutive steps per graph launch")
             except Exception as e:  # pragma: no cover - depends on the runtime
                 print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 torch.cuda.synchronize()
@@ -403,6 +419,10 @@ def main():
             torch.cuda.synchronize()
 
         def timed(run, steps, warmup):
+            # (a graph of U steps per launch: the region is made of whole launches -- `steps` is rounded up to a multiple of U, which
+            #  the contract's K already is; timed.last_steps says how many steps the region ran)
+            steps = -(-steps // getattr(run, "U", 1)) * getattr(run, "U", 1)
+            timed.last_steps = steps
             for _ in range(warmup):
                 run()
             barrier()
@@ -533,10 +553,11 @@ def main():
         # within 0.2 us -- but only if the host enqueues a frame (~165 us of Python and C) faster than the GPU renders it (~250 us),
         # which depends on the box.  Both are the same step on the same tensors; the contract's region runs the faster one.
         launch_probe = None
-        if primary and not multi and launch == "hip graph replay" and getattr(graphed_step, "eager", None) is not None and not args.no_launch_probe:
+        if primary and not multi and launch.startswith("hip graph replay") and getattr(graphed_step, "eager", None) is not None and not args.no_launch_probe:
             launch_probe = {}
+            np_ = 30 * ((max(args.steps, 30) + 29) // 30)      # (a multiple of every U)
             for name, fn in (("hip graph replay", run), ("eager", graphed_step.eager)):
-                launch_probe[name] = round(min(timed(fn, max(args.steps, 30), 30) for _ in range(2)) / max(args.steps, 30) * 1e3, 5)
+                launch_probe[name] = round(min(timed(fn, np_, 30) for _ in range(2)) / np_ * 1e3, 5)
             if launch_probe["eager"] < 0.985 * launch_probe["hip graph replay"]:
                 run, launch = graphed_step.eager, "eager (same step; faster than its hip graph replay on this host, see launch_probe_ms_per_step)"
                 for _ in range(30):
@@ -840,7 +861,7 @@ def main():
                 fwd, params, gm, colors, _ = make_frame(an, db, pat)
                 vrun, vlaunch = graphed_step(fwd, params)
                 vdt = timed(vrun, max(10, args.steps // 2), 3)
-                variants[vname] = {"value": round(max(10, args.steps // 2) / vdt, 1), "unit": "frames/s", "launch": vlaunch}
+                variants[vname] = {"value": round(timed.last_steps / vdt, 1), "unit": "frames/s", "launch": vlaunch}
             # the honest companion of the graph-replay headline: launched eagerly, and the camera MOVES every step (a new
             # R, T on the device each frame -- nothing about a frame can be reused from the last one)
             del fwd, params, gm, colors
