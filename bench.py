@@ -3,7 +3,7 @@
 
 A "step" is one forward+backward frame of BASELINE.json's metric config (config 3: 50 000
 synthetic Gaussians, 512x512, K=40, max_point_per_bin=-1):
-    frag = renderer(gaussians, R=R, T=T); img = to_white_background(frag, colors); img.sum().backward()
+    frag = renderer(gaussians, R=R, T=T); img = to_white_background(frag, colors); img.sum().backward(one)      # one = a 1.0 on the device, made once
 with gradients to verts [N,3], sigmas [N] and colours [N,3].  Inputs are resident in HBM before
 the timed region.  With --gpus N > 1 (one process per GPU) the frame's pixel rows are sharded over the
 ranks -- dealt in interleaved 32-row stripes (voge_amd.distributed.Stripes), so that every rank gets a sample of
@@ -49,7 +49,7 @@ def parse():
                     help="profiling aid: launch nothing but this stage's entry point (no frame), e.g. trace_fwd for the PMC passes; "
                          "'frame': the frame's steps alone")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
-    ap.add_argument("--graph-steps", type=int, default=0, help="consecutive steps captured per HIP graph (0: the largest of 6..1 that divides --steps)")
+    ap.add_argument("--graph-steps", type=int, default=0, help="consecutive steps captured per HIP graph (0: the largest of 10, 6, 5, 4, 3, 2, 1 that divides --steps)")
     ap.add_argument("--no-launch-probe", action="store_true", help="time the HIP graph replay whatever the eager launches of the same step would do")
     ap.add_argument("--split-graph", action="store_true",
                     help="single GPU: use the multi-GPU launch scheme (forward graph / eager exchange / backward graph)")
@@ -364,10 +364,12 @@ def main():
         def graphed_step(fwd, params):
             """One frame as a HIP graph replay (every replay runs exactly the kernels of an eager step on the same static
             tensors); eager on capture failure or --no-graph.  Returns (callable, launch description)."""
+            one = torch.ones((), dtype=torch.float32, device=dev)      # d loss / d loss, made once: backward() without it fills a fresh
+                                                                       # one-element tensor every step (a 4.8 us launch at its floor)
             def step():
                 for p in params:
                     p.grad = None
-                fwd().sum().backward()
+                fwd().sum().backward(one)
             if args.no_graph:
                 for _ in range(60):      # allocator pools, lazily loaded code objects, clocks: what graph capture warms on the way
                     step()
@@ -382,7 +384,7 @@ def main():
                 # profiles/r6_frame_gaps.txt), kernels inside a graph follow each other without a gap.  `replay` below is called once
                 # per STEP and launches the graph on every U-th call: any K calls with K % U == 0 run exactly K steps on the GPU.
                 U = (args.graph_steps if args.graph_steps > 0 and args.steps % args.graph_steps == 0 else
-                     max(u for u in (6, 5, 4, 3, 2, 1) if args.steps % u == 0))
+                     max(u for u in (10, 6, 5, 4, 3, 2, 1) if args.steps % u == 0))
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     for _ in range(U):
