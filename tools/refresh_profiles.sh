@@ -39,7 +39,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -- python3 b
 python tools/rocprof_summary.py $OUT/ktrace $OUT/${TAG}_kernel_trace_cfg5_loop.txt > /dev/null
 rm -rf $OUT/ktrace
 python bench.py | tail -1 > $OUT/${TAG}_bench_line.json
-python bench.py --no-graph --no-cpu-baseline --no-variants | tail -1 > $OUT/${TAG}_bench_line_eager.json
+python bench.py --no-graph --no-cpu-baseline --no-variants --steps 300 | tail -1 > $OUT/${TAG}_bench_line_eager.json      # (300 steps: the first frames behind a synchronisation run on a cold host -- 30 eager steps read 0.284 ms where 300 read 0.249)
 python bench.py --config cfg4_200k_1024 --no-cpu-baseline --no-variants --steps 20 | tail -1 > $OUT/${TAG}_bench_line_cfg4.json
 python bench.py --config cfg5_shapefit_128 --no-variants --steps 50 | tail -1 > $OUT/${TAG}_bench_line_cfg5.json
 python bench.py --loop | tail -1 > $OUT/${TAG}_bench_line_cfg5_loop.json
