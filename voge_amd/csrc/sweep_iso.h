@@ -62,8 +62,11 @@ struct Sweep2Quad {
 };
 constexpr int kS2QL = 64 + kS2Pad;      // bytes per quadrant list (padded with 64 = the never-hit record's position)
 static_assert(4 * kS2QL == sizeof(int) * (64 + kS2Pad), "the four byte lists take Sweep2Stage::pos's bytes");
-__host__ __device__ inline size_t sweep2_lds_bytes(const int K, const bool gen = false) {
-  return sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage) + (gen ? sizeof(Sweep2Gen) : (VOGE_S2_QUADS ? sizeof(Sweep2Quad) : 0));
+// gen: 0 scalar sigmas, 1 general forms (eleven coefficient arrays), 2 a launch of per-axis forms only (five: s11, s22, b)
+constexpr int kS2DiagRows = 5;
+__host__ __device__ inline size_t sweep2_lds_bytes(const int K, const int gen = 0) {
+  return sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage) +
+         (gen == 1 ? sizeof(Sweep2Gen) : (gen == 2 ? sizeof(float) * kS2DiagRows * (64 + kS2Pad) : (VOGE_S2_QUADS ? sizeof(Sweep2Quad) : 0)));
 }
 
 #ifndef VOGE_S2_EPI_B
@@ -88,14 +91,20 @@ constexpr int kExitGroup = VOGE_S2_EXIT_GROUP;
 #ifndef VOGE_S2_PUT_AT_CNT
 #define VOGE_S2_PUT_AT_CNT 1    // the 16-bit form's commit stores every candidate at row cnt (no row select); see commit()
 #endif
+#ifndef VOGE_S2_GEN_LEAN
+#define VOGE_S2_GEN_LEAN 0      // (experiment) the general kernel takes the scalar kernel's lean_insert / slow_insert instead of deep_insert
+#endif
 #ifndef VOGE_S2_PRIO_LEN
 #define VOGE_S2_PRIO_LEN 0   // (experiment) tiles with at least this many candidates run at raised wave priority; 0: off
 #endif
 
-// GEN = false: every Gaussian is A = a I (ms = (mu, a)).  GEN = true: the general entry points' kernel -- ms = (mu, s00 | NaN),
+// GEN = 2 (round 6): a launch whose general forms are ALL diagonal (the frame path's per-axis sigmas, gen_kind 1): five of the eleven
+// coefficient arrays exist (8 instead of 7 workgroups per CU at K = 40), the trips are the diagonal ones, and the insertion is the
+// scalar kernel's (tools/quads_stats.py SLOW=1: the walks of such a scene are as short as a scalar one's -- 304 against 542 ns per event).
+// GEN = 0: every Gaussian is A = a I (ms = (mu, a)).  GEN = 1: the general entry points' kernel -- ms = (mu, s00 | NaN),
 // NaN sending the reader to evr[3 g .. 3 g + 2], pair_eval_gen's record (VoGE/csrc/ray_trace_voge/ray_trace_voge.cu:11-38: all
 // nine entries of isigmas are inputs); an isotropic Gaussian among them is evaluated exactly as the scalar kernel does.
-template <bool GEN>
+template <int GEN>
 __global__ void __launch_bounds__(64)
 sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms, const float4 *__restrict__ evr, const float *__restrict__ rays,
                  const int *__restrict__ bin_count, const int32_t *__restrict__ bin_id, const float *__restrict__ bin_lb,
@@ -111,6 +120,9 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
   unsigned char *const Lpos_raw = smem_raw + sweep2_len_bytes(K);
   Sweep2Stage &S = *reinterpret_cast<Sweep2Stage *>(smem_raw + sweep2_len_bytes(K) + sweep2_pos_bytes(K));
   Sweep2Gen &G = *reinterpret_cast<Sweep2Gen *>(smem_raw + sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage));      // (GEN only)
+  // (GEN = 2: rows s11, s22, bx, by, bz of the eleven -- the others do not exist in that launch's LDS)
+  auto grow = [&](const int r) -> float * { return &G.e[GEN == 2 ? (r < 2 ? r : r - 3) : r][0]; };
+  auto ghas = [](const int r) { return GEN != 2 || r < 2 || (r >= 5 && r < 8); };
   Sweep2Quad &QC = *reinterpret_cast<Sweep2Quad *>(smem_raw + sweep2_len_bytes(K) + sweep2_pos_bytes(K) + sizeof(Sweep2Stage));   // (!GEN, QUADS)
   float4 *const QR = reinterpret_cast<float4 *>(&S.x[0]);                      // (QUADS) the staged records, AoS
   [[maybe_unused]] unsigned char *const Q8 = reinterpret_cast<unsigned char *>(&S.pos[0]);      // (QUADS) the four position lists
@@ -478,7 +490,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
 #ifdef VOGE_SWEEP_SLOW
         dbg_moved = 0;
 #endif
-        if (GEN) {
+        if (GEN == 1 && !(VOGE_S2_GEN_LEAN)) {
           deep_insert(len, p, slow);
         } else {
           const bool hard = lean_insert(len, p, slow, Kv);
@@ -693,9 +705,10 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       // marker.  A general candidate's s00 takes a's place.
       const bool cgen = GEN && !(mrec.w == mrec.w);
       auto stage_gen = [&](const int sl) {
-        G.e[0][sl] = cgen ? e0.y : __uint_as_float(0x7fc00000u);
-        G.e[1][sl] = e0.z; G.e[2][sl] = e0.w; G.e[3][sl] = e1.x; G.e[4][sl] = e1.y; G.e[5][sl] = e1.z; G.e[6][sl] = e1.w;
-        G.e[7][sl] = e2.x; G.e[8][sl] = e2.y; G.e[9][sl] = e2.z; G.e[10][sl] = e2.w;
+        const float ev[11] = {cgen ? e0.y : __uint_as_float(0x7fc00000u), e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
+#pragma unroll
+        for (int r = 0; r < 11; ++r)
+          if (ghas(r)) grow(r)[sl] = ev[r];
       };
       const float a_st = cgen ? e0.x : mrec.w;
       if (pref) {
@@ -730,7 +743,9 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
         const float mk = G.e[0][lane];
         gmask = __ballot(lane < nbuf && mk == mk);
         tile_gen = tile_gen || gmask != 0ull;
-        if (gmask != 0ull) {      // (uniform)
+        if (GEN == 2) {
+          dmask = gmask;      // (a launch of per-axis forms)
+        } else if (gmask != 0ull) {      // (uniform)
           const bool dg = G.e[2][lane] == 0.0f && G.e[3][lane] == 0.0f && G.e[4][lane] == 0.0f && G.e[8][lane] == 0.0f &&
                           G.e[9][lane] == 0.0f && G.e[10][lane] == 0.0f;
           dmask = __ballot(lane < nbuf && mk == mk && dg);
@@ -765,8 +780,8 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
       float4 Evn[GEN ? 11 : 1];
       if (GEN) {
 #pragma unroll
-        for (int r = 0; r < 11; ++r) Evn[GEN ? r : 0] = *reinterpret_cast<const float4 *>(&G.e[r][0]);
-        if (chunk_diag) {      // (the six arrays such a chunk never reads again ARE zero: a mixed trip's pair_eval_gen takes them from here)
+        for (int r = 0; r < 11; ++r) Evn[GEN ? r : 0] = ghas(r) ? *reinterpret_cast<const float4 *>(grow(r)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (GEN != 2 && chunk_diag) {      // (the six arrays such a chunk never reads again ARE zero: a mixed trip's pair_eval_gen takes them from here)
 #pragma unroll
           for (int r = 0; r < 11; ++r)
             if (!(r < 2 || (r >= 5 && r < 8))) Evn[GEN ? r : 0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -817,7 +832,7 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
               len[2 * h] = t.x; len[2 * h + 1] = t.y;
               act[2 * h] = a.x; act[2 * h + 1] = a.y;
             }
-          } else if (gbits == 15u) {
+          } else if (GEN != 2 && gbits == 15u) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               auto half = [&](const float4 v) { return h ? (v2f){v.z, v.w} : (v2f){v.x, v.y}; };
@@ -899,8 +914,8 @@ sweep_iso_kernel(const float4 *__restrict__ cull, const float4 *__restrict__ ms,
         if (GEN && chunk_diag) {         // (uniform) s11, s22 and b: all a diagonal trip reads
 #pragma unroll
           for (int r = 0; r < 11; ++r)
-            if (r < 2 || (r >= 5 && r < 8)) Evn[GEN ? r : 0] = *reinterpret_cast<const float4 *>(&G.e[r][s0 + 4]);
-        } else if (GEN && gmask != 0ull) {      // (uniform: a chunk without a general candidate reads none of them)
+            if (r < 2 || (r >= 5 && r < 8)) Evn[GEN ? r : 0] = *reinterpret_cast<const float4 *>(grow(r) + s0 + 4);
+        } else if (GEN == 1 && gmask != 0ull) {      // (uniform: a chunk without a general candidate reads none of them)
 #pragma unroll
           for (int r = 0; r < 11; ++r) Evn[GEN ? r : 0] = *reinterpret_cast<const float4 *>(&G.e[r][s0 + 4]);
         }

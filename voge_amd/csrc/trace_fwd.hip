@@ -1224,8 +1224,11 @@ static std::atomic<int> g_sweep_variant{0};
 template <bool ISO>
 static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *rays, int B, int N, int H, int W, int K,
                         float thr_act, int32_t *idx, float *len, float *act, float *dsd, int32_t *cnt, float occ,
-                        float *weight, int64_t *valid_num, hipStream_t st, const CamView &cam) {
+                        float *weight, int64_t *valid_num, hipStream_t st, const CamView &cam, const bool diag = false) {
   constexpr int T = 64;
+  // (diag: every general form of the launch is a per-axis one -- the frame path's gen_kind 1 -- sweep_iso_kernel<2>)
+  const int gen = ISO ? 0 : (diag ? 2 : 1);
+  const auto sweep = ISO ? sweep_iso_kernel<0> : (diag ? sweep_iso_kernel<2> : sweep_iso_kernel<1>);
   // (fused composite epilogue: three padded per-pixel rows (len, s', E) for one round of 64 / (K/4) pixels)
   const size_t comp = (weight != nullptr) ? sizeof(float) * 3 * (size_t)compn_rows(K, 4, 64, true) : 0;
   const size_t lds = ((sizeof(uint64_t) * (size_t)(K + 1) * (T + 1) + 15) & ~(size_t)15) + ((sizeof(TraceLds<T, ISO>) + 15) & ~(size_t)15) +
@@ -1240,11 +1243,11 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
   constexpr bool kOld = !VOGE_SWEEP_V2 || VOGE_FUSED_EPILOGUE;      // (the product keeps round 3's sweeps out of the library)
   if (!v2 && !kOld) return VOGE_ERR_BAD_ARG;
 #endif
-  const size_t lds2 = sweep2_lds_bytes(K, !ISO) + VOGE_SWEEP_LDS_PAD;
+  const size_t lds2 = sweep2_lds_bytes(K, gen) + VOGE_SWEEP_LDS_PAD;
   {
-    static DynLdsCache cache2;
+    static DynLdsCache cache2[2];      // (one per kernel of this instantiation)
     if (v2) {
-      const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sweep_iso_kernel<!ISO>), lds2, cache2);
+      const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sweep), lds2, cache2[diag ? 1 : 0]);
       if (rc) return rc;
     }
   }
@@ -1269,7 +1272,7 @@ static int launch_trace(const TraceWs &ws, const ConeRec *cones, const float *ra
 #endif
   dim3 grid(ws.nbin * kTilesPerBin);     // one workgroup per tile slot of every super-tile (slots outside the image exit)
   if (v2) {
-    hipLaunchKernelGGL(sweep_iso_kernel<!ISO>, grid, dim3(T), lds2, st, ws.cull, ws.ms, ws.evr, rays, ws.q_count, ws.q_id, ws.q_lb, ws.tl_id,
+    hipLaunchKernelGGL(sweep, grid, dim3(T), lds2, st, ws.cull, ws.ms, ws.evr, rays, ws.q_count, ws.q_id, ws.q_lb, ws.tl_id,
                        ws.tl_lb, ws.pool_id, ws.pool_lb, ws.tl_off, order, ((W + 7) / 8) * ((H + 7) / 8), ws.nstx, ws.nstx * ws.nsty, N, H, W, K,
                        thr_act, idx, len, act, dsd, cnt, cam);
     return launch_status();
@@ -1525,7 +1528,8 @@ static int trace_chunk_fwd(const int iso_in, const IsoView view, const float *mu
   if (iso_in) rc = launch_trace<true>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, fused ? weight : nullptr, fused ? valid_num : nullptr, st, cam);
   else
 #endif
-  rc = launch_trace<false>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, fused ? weight : nullptr, fused ? valid_num : nullptr, st, cam);
+  rc = launch_trace<false>(ws, cones, rays, B, N, H, W, K, thr_act, idx, len, act, dsd, cnt, occ, fused ? weight : nullptr, fused ? valid_num : nullptr, st, cam,
+                           view.gen_kind == 1);
   if (rc || weight == nullptr || fused) return rc;
   if (act == nullptr)
     return voge_composite_fwd_iso(idx, cnt, len, reinterpret_cast<const float *>(ws.ms), cam.R != nullptr ? cam.rays_out : rays, occ,
