@@ -425,11 +425,13 @@ def main():
             #  the contract's K already is; timed.last_steps says how many steps the region ran)
             steps = -(-steps // getattr(run, "U", 1)) * getattr(run, "U", 1)
             timed.last_steps = steps
-            for _ in range(warmup):
+            gc.collect()      # (a collection walks the whole heap: tens of milliseconds in which the GPU idles and drops its clocks, and
+            gc.disable()      #  the host's caches are cold afterwards -- a region timed right behind one read 0.264 ms where the same
+            for _ in range(100):      #  callable behind 30 steps of work read 0.252.  So: collect, switch the collector off as timeit
+                run()         #  does, put the GPU and the host back under load with 100 untimed steps, THEN the contract's W warm-up
+            for _ in range(warmup):      # steps, the barrier and the K timed steps.)
                 run()
             barrier()
-            gc.collect()
-            gc.disable()      # (as timeit does: a collection of the interpreter's garbage inside a 7 ms region is 10 % of it)
             try:
                 t0 = time.perf_counter()
                 for _ in range(steps):
@@ -881,7 +883,8 @@ def main():
             for _ in range(60):
                 moving()
             torch.cuda.synchronize()
-            nm = max(20, args.steps)
+            nm = 10 * max(20, args.steps)      # (an eager loop's first frames behind a synchronisation run on a cold host: 30 steps read 0.284 ms
+                                               #  where 300 read 0.249 -- this variant is about the loop's steady state)
             vdt = timed(moving, nm, 5)
             variants["eager_moving_camera"] = {"value": round(nm / vdt, 1), "unit": "frames/s", "launch": "eager, a different camera every step"}
             result["variants"] = variants
