@@ -49,7 +49,7 @@ def parse():
                     help="profiling aid: launch nothing but this stage's entry point (no frame), e.g. trace_fwd for the PMC passes; "
                          "'frame': the frame's steps alone")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
-    ap.add_argument("--graph-steps", type=int, default=0, help="consecutive steps captured per HIP graph (0: the largest of 10, 6, 5, 4, 3, 2, 1 that divides --steps)")
+    ap.add_argument("--graph-steps", type=int, default=0, help="consecutive steps captured per HIP graph (0: the largest of 30, 20, 15, 10, 6, 5, 4, 3, 2, 1 that divides --steps)")
     ap.add_argument("--no-launch-probe", action="store_true", help="time the HIP graph replay whatever the eager launches of the same step would do")
     ap.add_argument("--split-graph", action="store_true",
                     help="single GPU: use the multi-GPU launch scheme (forward graph / eager exchange / backward graph)")
@@ -384,7 +384,7 @@ def main():
                 # profiles/r6_frame_gaps.txt), kernels inside a graph follow each other without a gap.  `replay` below is called once
                 # per STEP and launches the graph on every U-th call: any K calls with K % U == 0 run exactly K steps on the GPU.
                 U = (args.graph_steps if args.graph_steps > 0 and args.steps % args.graph_steps == 0 else
-                     max(u for u in (10, 6, 5, 4, 3, 2, 1) if args.steps % u == 0))
+                     max(u for u in (30, 20, 15, 10, 6, 5, 4, 3, 2, 1) if args.steps % u == 0))
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     for _ in range(U):

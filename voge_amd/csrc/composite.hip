@@ -335,6 +335,9 @@ composite_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act,
 #ifndef VOGE_COMP_WPE
 #define VOGE_COMP_WPE 1
 #endif
+#ifndef VOGE_CS_LDS
+#define VOGE_CS_LDS 1      // the shade sums' cross-lane reduction through LDS columns instead of a shuffle tree (see the shade block)
+#endif
 #ifndef VOGE_COMP_LDS_RMAX
 #define VOGE_COMP_LDS_RMAX 1
 #endif
@@ -657,11 +660,51 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
         }
         part[SC] += w[a];
       }
+#if VOGE_CS_LDS
+      if (SC == 3 && LP >= 3) {      // (uniform)
+        // Three colour sums and sum w over the pixel's lanes.  Round 6: through LDS -- every lane leaves its four partial sums in the
+        // (now idle) row arrays, the pixel's lanes 0 .. 2 each add up ONE colour's column and the weights' column in lane order:
+        // two dependent LDS round trips instead of the four of a shuffle tree (which were 5 us of this kernel, -DVOGE_CS_ABL; a
+        // tree with fewer shuffles but five dependent steps gained nothing).  A fixed association per pixel, as before.
+        float *const A0 = const_cast<float *>(Llen), *const A1 = const_cast<float *>(Lsp), *const A2 = const_cast<float *>(LE);
+        wave_lds_sync();      // (the walks' reads of these rows are over)
+        const int T_ = (int)blockDim.x;      // (rows >= 2 T for every K with LP >= 3: compn_rows)
+        A0[tid] = part[0]; A1[tid] = part[1]; A2[tid] = part[2]; A0[T_ + tid] = part[3];
+        wave_lds_sync();
+        float xs = 0.0f, ws = 0.0f;
+        if (in_wg && q < 3) {
+          const float *const col = (q == 0 ? A0 : (q == 1 ? A1 : A2)) + (tid - q), *const wc = A0 + T_ + (tid - q);
+          for (int j = 0; j < LP; ++j) { xs += col[j]; ws += wc[j]; }
+        }
+        if (active) {
+          // merge_final rewrites empty slots of the index list in place, -1 -> 0 (Aggregation.py:131)
+          if (k0 + NS > lead) {
+#pragma unroll
+            for (int a = 0; a < NS; ++a) if (has[a] && k0 + a >= lead) sh.idx_fix[f + a] = 0;
+          }
+          if (q < 3) {
+            float sil = fminf(ws, 1.0f);
+            if (sh.thr > 0.0f) sil = sil > sh.thr ? 1.0f : 0.0f;
+            sh.rgb[pix * SC + q] = xs;
+            if (sh.img != nullptr) sh.img[pix * SC + q] = fminf(fmaf(1.0f - sil, sh.bg[q], xs), 1.0f);
+            if (q == 0) {
+              sh.wsum[pix] = ws;
+              if (sh.sil != nullptr) sh.sil[pix] = fminf(ws, 1.0f);
+            }
+          }
+        }
+        return;
+      }
+#endif
       // the pixel's lanes are consecutive in the wave: sum towards its first lane (a fixed association per pixel)
 #pragma unroll
       for (int c = 0; c <= SC; ++c) {
         float x = part[c];
+#ifdef VOGE_CS_ABL      // (timing experiment: no cross-lane reduction of the shade sums)
+        for (int o = 64; o < LP; o <<= 1) {
+#else
         for (int o = 1; o < LP; o <<= 1) {
+#endif
           const float y = __shfl_down(x, o, 64);
           if (q + o < LP && in_wg) x += y;
         }
