@@ -350,8 +350,11 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
   float mx = 0.0f;
 #pragma unroll
   for (int a = 0; a < NS; ++a) mx = fmaxf(mx, (em[a] != 0.0f) ? kSat * __builtin_amdgcn_rcpf(sm[a]) : 0.0f);
-  float wave_rmax;
-  if (Lcell != nullptr) {
+  float wave_rmax = 0.0f;
+  if (RCOL) {
+    // (the column walks go as far as each column's OWN window: nobody reads the pixel-wide radius -- until round 6 this form still
+    //  paid for it: an LDS store, an LDS atomic max and a read-back, three dependent round trips per round)
+  } else if (Lcell != nullptr) {
     // the pixel's window radius through ONE LDS cell (the pixel's own; radii are >= 0, so their bit patterns order
     // like unsigned integers): zero, max, read -- three LDS operations in the wave's in-order LDS queue instead of a
     // chain of seven dependent cross-lane shuffles
@@ -445,6 +448,8 @@ __device__ __forceinline__ void compn_bwd_wave(const float (&lm)[NS], const floa
   }
   float sx;   // sum of u over the slots behind this lane's group
   {
+    // (Round 6 tried this ladder two other ways -- LDS cells: a store, then LPmax - 1 reads per lane, + 5 us; a linear scan on DPP
+    //  wave_shl:1 shifts, LPmax - 1 dependent VALU operations and no LDS trip, + 0.7 us -- the 1 + log2(LP) shuffles stay.)
     const float y = __shfl_down(usum, 1, 64);
     float x = (q + 1 < LP && in_wg) ? y : 0.0f;
     for (int o = 1; o < LPmax; o <<= 1) {
