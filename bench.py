@@ -383,8 +383,16 @@ def main():
                 # waits for the one before it through a completion signal the host's runtime thread forwards -- tools/frame_gaps.sh,
                 # profiles/r6_frame_gaps.txt), kernels inside a graph follow each other without a gap.  `replay` below is called once
                 # per STEP and launches the graph on every U-th call: any K calls with K % U == 0 run exactly K steps on the GPU.
+                # (a graph of at most ~8 ms: thirty steps of the 1.2 ms cfg4 frame in one graph replayed at 1.6 ms per step -- its
+                #  intermediates no longer stay in the memory-side cache from one step to the next)
+                torch.cuda.synchronize()
+                t_e = time.perf_counter()
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                u_cap = max(1, int(8e-3 / max((time.perf_counter() - t_e) / 5, 1e-6)))
                 U = (args.graph_steps if args.graph_steps > 0 and args.steps % args.graph_steps == 0 else
-                     max(u for u in (30, 20, 15, 10, 6, 5, 4, 3, 2, 1) if args.steps % u == 0))
+                     max(u for u in (30, 20, 15, 10, 6, 5, 4, 3, 2, 1) if args.steps % u == 0 and (u <= u_cap or u == 1)))
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     for _ in range(U):
