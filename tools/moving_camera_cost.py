@@ -64,3 +64,6 @@ for i in (0, 16, 32, 48, 63):
     print(f"view {i:2d} (azim {az + 0.5 * i:.1f}): eager loop host {h:.1f} us, wall {w:.1f} us per frame; graph replay {gus:.1f} us")
 h, w = loop(lambda k: step(k % nview), 640)
 print(f"moving camera, 64 views in turn: host {h:.1f} us, wall {w:.1f} us per frame = {1e6 / w:.0f} frames/s")
+with torch.autograd.set_multithreading_enabled(False):      # (the node's backward in the calling thread: no hand-over to the device's autograd thread)
+    h, w = loop(lambda k: step(k % nview), 640)
+print(f"the same with torch.autograd.set_multithreading_enabled(False): host {h:.1f} us, wall {w:.1f} us per frame = {1e6 / w:.0f} frames/s")

@@ -661,14 +661,15 @@ compositen_kernel(const int32_t *__restrict__ idx, const float *__restrict__ act
         part[SC] += w[a];
       }
 #if VOGE_CS_LDS
-      if (SC == 3 && LP >= 3) {      // (uniform)
+      if (SC == 3 && LP >= 3 && blockDim.x == 64) {      // (uniform; one-wave workgroups: the scratch below is the wave's OWN rows -- in a
+                                                          //  workgroup of several waves another wave may still be walking them)
         // Three colour sums and sum w over the pixel's lanes.  Round 6: through LDS -- every lane leaves its four partial sums in the
         // (now idle) row arrays, the pixel's lanes 0 .. 2 each add up ONE colour's column and the weights' column in lane order:
         // two dependent LDS round trips instead of the four of a shuffle tree (which were 5 us of this kernel, -DVOGE_CS_ABL; a
         // tree with fewer shuffles but five dependent steps gained nothing).  A fixed association per pixel, as before.
         float *const A0 = const_cast<float *>(Llen), *const A1 = const_cast<float *>(Lsp), *const A2 = const_cast<float *>(LE);
         wave_lds_sync();      // (the walks' reads of these rows are over)
-        const int T_ = (int)blockDim.x;      // (rows >= 2 T for every K with LP >= 3: compn_rows)
+        constexpr int T_ = 64;      // (rows >= 128 for every K with LP >= 3: compn_rows)
         A0[tid] = part[0]; A1[tid] = part[1]; A2[tid] = part[2]; A0[T_ + tid] = part[3];
         wave_lds_sync();
         float xs = 0.0f, ws = 0.0f;
