@@ -19,6 +19,9 @@
 // Both tests are conservative (cone_keep / cone_keep_ell, voge_common.h), so the sweep's result equals the
 // brute-force "-1" candidate list of VoGE/RayTracing.py:22-26.
 #pragma once
+#ifndef VOGE_BINA_REGION_RECT
+#define VOGE_BINA_REGION_RECT 1
+#endif
 #ifndef VOGE_XCD_CHAIN
 #define VOGE_XCD_CHAIN 0     // 1: a region's 16 binA slices AND its 64 binB quads on XCD (region % 8): binB finds the segments in the L2 binA wrote them through
 #endif
@@ -258,11 +261,22 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
     const int cc = lane & (kCh * kCh - 1);
     const int cx = rx * kCh + (cc & (kCh - 1)), cy = ry * kCh + cc / kCh;
     ConeRec r = {0.f, 0.f, 1.f, 1.f, 0.f, -1.f, 0.f, 0.f};      // ok = -1: no such super-tile
-    if (cx < nstx && cy < nsty) {
-      if (cam.R != nullptr) r = cam_rect_cone(ck, cam, cx * kST, cx * kST + kST - 1, cy * kST, cy * kST + kST - 1);      // (uniform branch)
-      else r = cones[cone_super_at(b, nst, cy * nstx + cx)];
+    // (VOGE_BINA_REGION_RECT, round 6: with the camera at hand and a contiguous band the region's OWN cone comes from its own four
+    //  corner rays -- lane 16 makes it in the same call that makes the sixteen children -- instead of the conservative union of the
+    //  children below: tighter, and the union's chain of wave reductions leaves the head of every workgroup)
+    const bool region_rect = (VOGE_BINA_REGION_RECT != 0) && cam.R != nullptr && cam.h <= cam.stripe_h;      // (uniform)
+    if (cam.R != nullptr) {      // (uniform branch)
+      const bool reg = region_rect && lane == kCh * kCh;
+      const int j0 = reg ? rx * kCh * kST : cx * kST, i0 = reg ? ry * kCh * kST : cy * kST, ext = reg ? kCh * kST : kST;
+      if ((cx < nstx && cy < nsty) || reg) r = cam_rect_cone(ck, cam, j0, j0 + ext - 1, i0, i0 + ext - 1);
+    } else if (cx < nstx && cy < nsty) {
+      r = cones[cone_super_at(b, nst, cy * nstx + cx)];
     }
     if (lane < kCh * kCh) L.child[lane] = r;
+    if (region_rect) {
+      if (lane == kCh * kCh) L.region = r;      // (ok = -1 cannot happen: the region holds at least one super-tile of the image)
+      if (lane == 0) L.use_rows = 0;
+    } else {
     const bool present = lane < kCh * kCh && r.ok >= 0.f;
     const float sx = wave_sum_dpp(present ? r.ax : 0.f), sy = wave_sum_dpp(present ? r.ay : 0.f), sz = wave_sum_dpp(present ? r.az : 0.f);
     const float npres = wave_sum_dpp(present ? 1.f : 0.f);
@@ -316,6 +330,7 @@ binA_kernel(const ConeRec *__restrict__ cones /* [B][nst] */, const int nstx, co
       const float widest_row = wave_max((lane < kCh * kCh && qn > 0.f) ? (rcn.ok ? rcn.sn : 2.0f) : 0.f);
       if (lane == 0) L.use_rows = (!cn.ok || cn.sn > 1.6f * widest_row) ? 1 : 0;
     }
+    }      // (!region_rect)
   }
   BIN_TS(0, 6);      // (wave 0: the region's cone is in LDS)
   // (the first round's records: derived behind the cone block, so that wave 0's cone loads -- requested right after its
